@@ -1,0 +1,429 @@
+"""CPU ORACLE for the vid2vid hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under vid2vid_amd/ does (tests/test_cpu_boundary.py enforces it).
+
+A functional fp32 restatement (plain torch CPU ops) of the reference's algorithm, driven by
+state_dicts that use the reference's parameter names.  Every function cites the reference
+lines it follows (paths relative to the reference root).
+
+Pinning (tests/test_cpu_oracle.py):
+  * generators / discriminators / inference() are pinned against tests/golden/*.npz, which
+    tests/golden/make_golden.py produced by executing the reference's own Python on CPU;
+  * correlation / resample2d / channelnorm are CUDA-only in the reference (no nvcc, legacy ATen
+    API, warp-32 code) and the reference ships no test vectors for them: their restatements
+    below follow the .cu files line by line and are checked against hand-computed cases only
+    -> "parity unpinned by the reference" for these three.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# layer primitives
+# --------------------------------------------------------------------------------------
+def _conv(sd, key, x, stride=1, padding=0):
+    return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=stride, padding=padding)
+
+
+def _convT(sd, key, x):
+    # nn.ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1)   models/networks.py:147,176
+    return F.conv_transpose2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=2, padding=1, output_padding=1)
+
+
+def _norm(sd, key, x, norm):
+    """get_norm_layer (models/networks.py:23-30).  Modules are never put in eval(), so
+    'batch' = batch statistics + affine, 'instance' = per-sample statistics, no affine."""
+    if norm == "batch":
+        return F.batch_norm(x, None, None, sd[key + ".weight"], sd[key + ".bias"], True, 0.1, 1e-5)
+    if norm == "instance":
+        return F.instance_norm(x, eps=1e-5)
+    raise ValueError(norm)
+
+
+def _reflect(x, p):
+    return F.pad(x, (p, p, p, p), mode="reflect")
+
+
+class _Walker:
+    """Index bookkeeping for the reference's nn.Sequential lists: prefix.<idx>.<param>"""
+
+    def __init__(self, sd, prefix, norm):
+        self.sd, self.p, self.i, self.norm = sd, prefix, 0, norm
+
+    def key(self, off=0):
+        return "%s.%d" % (self.p, self.i + off)
+
+    def stem7(self, x, act=True):
+        # [ReflectionPad2d(3), Conv2d(k7), norm, ReLU]        models/networks.py:153
+        x = _conv(self.sd, self.key(1), _reflect(x, 3))
+        x = F.relu(_norm(self.sd, self.key(2), x, self.norm))
+        self.i += 4
+        return x
+
+    def down3(self, x):
+        # [Conv2d(k3, s2, p1), norm, ReLU]                     models/networks.py:156-157
+        x = F.relu(_norm(self.sd, self.key(1), _conv(self.sd, self.key(0), x, 2, 1), self.norm))
+        self.i += 3
+        return x
+
+    def up3(self, x):
+        # [ConvTranspose2d(k3, s2, p1, op1), norm, ReLU]       models/networks.py:176-177
+        x = F.relu(_norm(self.sd, self.key(1), _convT(self.sd, self.key(0), x), self.norm))
+        self.i += 3
+        return x
+
+    def resblock(self, x):
+        # ResnetBlock with reflect padding                     models/networks.py:554-593
+        k = "%s.%d.conv_block" % (self.p, self.i)
+        h = F.relu(_norm(self.sd, k + ".2", _conv(self.sd, k + ".1", _reflect(x, 1)), self.norm))
+        h = _norm(self.sd, k + ".6", _conv(self.sd, k + ".5", _reflect(h, 1)), self.norm)
+        self.i += 1
+        return x + h
+
+    def head7(self, x, act=None):
+        # [ReflectionPad2d(3), Conv2d(k7)] (+ Tanh / Sigmoid)  models/networks.py:178,182-183
+        x = _conv(self.sd, self.key(1), _reflect(x, 3))
+        self.i += 2 + (1 if act else 0)
+        if act == "tanh":
+            return torch.tanh(x)
+        if act == "sigmoid":
+            return torch.sigmoid(x)
+        return x
+
+
+# --------------------------------------------------------------------------------------
+# warping (models/networks.py:79-115)
+# --------------------------------------------------------------------------------------
+def get_grid(b, rows, cols):
+    hor = torch.linspace(-1.0, 1.0, cols).view(1, 1, 1, cols).expand(b, 1, rows, cols)
+    ver = torch.linspace(-1.0, 1.0, rows).view(1, 1, rows, 1).expand(b, 1, rows, cols)
+    return torch.cat([hor, ver], 1)
+
+
+def resample(image, flow, align_corners=False):
+    """BaseNetwork.resample: grid = linspace + flow / ((w-1)/2, (h-1)/2); F.grid_sample(bilinear, border).
+    align_corners=False is what the reference executes under torch >= 1.3."""
+    b, c, h, w = image.shape
+    grid = get_grid(b, h, w)
+    flow = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], dim=1)
+    final_grid = (grid + flow).permute(0, 2, 3, 1)
+    return F.grid_sample(image, final_grid, mode="bilinear", padding_mode="border", align_corners=align_corners)
+
+
+# --------------------------------------------------------------------------------------
+# generators
+# --------------------------------------------------------------------------------------
+def composite_generator(sd, x, img_prev, mask, n_downsampling, n_blocks, use_fg, no_flow=False,
+                        use_raw_only=False, norm="batch", align_corners=False):
+    """CompositeGenerator.forward (models/networks.py:203-232); layer layout :128-201."""
+    def tower(prefix, inp):
+        w = _Walker(sd, prefix, norm)
+        h = w.stem7(inp)
+        for _ in range(n_downsampling):
+            h = w.down3(h)
+        for _ in range(n_blocks - n_blocks // 2):
+            h = w.resblock(h)
+        return h
+
+    def res_up(res_prefix, up_prefix, h):
+        w = _Walker(sd, res_prefix, norm)
+        for _ in range(n_blocks // 2):
+            h = w.resblock(h)
+        w = _Walker(sd, up_prefix, norm)
+        for _ in range(n_downsampling):
+            h = w.up3(h)
+        return h
+
+    downsample = tower("model_down_seg", x) + tower("model_down_img", img_prev)
+    img_feat = res_up("model_res_img", "model_up_img", downsample)
+    img_raw = _Walker(sd, "model_final_img", norm).head7(img_feat, "tanh")
+    flow = weight = flow_feat = None
+    if not no_flow:
+        flow_feat = res_up("model_res_flow", "model_up_flow", downsample)
+        flow = _Walker(sd, "model_final_flow", norm).head7(flow_feat) * 20
+        weight = _Walker(sd, "model_final_w", norm).head7(flow_feat, "sigmoid")
+    if use_raw_only or no_flow:
+        img_final = img_raw
+    else:
+        img_warp = resample(img_prev[:, -3:], flow, align_corners)
+        img_final = img_raw * weight + img_warp * (1 - weight)
+    img_fg_feat = None
+    if use_fg:
+        w = _Walker(sd, "indv_down", norm)
+        h = w.stem7(x)
+        for _ in range(n_downsampling):
+            h = w.down3(h)
+        w = _Walker(sd, "indv_res", norm)
+        for _ in range(n_blocks):
+            h = w.resblock(h)
+        w = _Walker(sd, "indv_up", norm)
+        for _ in range(n_downsampling):
+            h = w.up3(h)
+        img_fg_feat = h
+        img_fg = _Walker(sd, "indv_final", norm).head7(img_fg_feat, "tanh")
+        m = mask.expand_as(img_raw)
+        img_final = img_fg * m + img_final * (1 - m)
+        img_raw = img_fg * m + img_raw * (1 - m)
+    return img_final, flow, weight, img_raw, img_feat, flow_feat, img_fg_feat
+
+
+def composite_local_generator(sd, x, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse,
+                              n_blocks_local, scale, use_fg, no_flow=False, use_raw_only=False, norm="batch",
+                              align_corners=False):
+    """CompositeLocalGenerator.forward (models/networks.py:296-325); layer layout :244-294."""
+    def stem_down(prefix, inp):
+        w = _Walker(sd, prefix, norm)
+        return w.down3(w.stem7(inp))
+
+    def up(prefix, h):
+        w = _Walker(sd, prefix, norm)
+        for _ in range(n_blocks_local):
+            h = w.resblock(h)
+        return w.up3(h)
+
+    flow_multiplier = 20 * (2 ** scale)
+    down_img = stem_down("model_down_seg", x) + stem_down("model_down_img", img_prev)
+    img_feat = up("model_up_img", down_img + img_feat_coarse)
+    img_raw = _Walker(sd, "model_final_img", norm).head7(img_feat, "tanh")
+    flow = weight = flow_feat = None
+    if not no_flow:
+        flow_feat = up("model_up_flow", down_img + flow_feat_coarse)
+        flow = _Walker(sd, "model_final_flow", norm).head7(flow_feat) * flow_multiplier
+        weight = _Walker(sd, "model_final_w", norm).head7(flow_feat, "sigmoid")
+    if use_raw_only or no_flow:
+        img_final = img_raw
+    else:
+        img_warp = resample(img_prev[:, -3:], flow, align_corners)
+        img_final = img_raw * weight + img_warp * (1 - weight)
+    img_fg_feat = None
+    if use_fg:
+        img_fg_feat = up("indv_up", stem_down("indv_down", x) + img_fg_feat_coarse)
+        img_fg = _Walker(sd, "indv_final", norm).head7(img_fg_feat, "tanh")
+        m = mask.expand_as(img_raw)
+        img_final = img_fg * m + img_final * (1 - m)
+        img_raw = img_fg * m + img_raw * (1 - m)
+    return img_final, flow, weight, img_raw, img_feat, flow_feat, img_fg_feat
+
+
+def global_generator(sd, x, n_downsampling, n_blocks, norm="instance", prefix="model", with_head=True):
+    """GlobalGenerator.forward (models/networks.py:335-359)."""
+    w = _Walker(sd, prefix, norm)
+    h = w.stem7(x)
+    for _ in range(n_downsampling):
+        h = w.down3(h)
+    for _ in range(n_blocks):
+        h = w.resblock(h)
+    for _ in range(n_downsampling):
+        h = w.up3(h)
+    return w.head7(h, "tanh") if with_head else h
+
+
+def avgpool3s2(x):
+    # nn.AvgPool2d(3, stride=2, padding=[1,1], count_include_pad=False)   models/networks.py:400,652
+    return F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+
+
+def local_enhancer(sd, x, n_downsample_global, n_blocks_global, n_local_enhancers, n_blocks_local, norm="instance"):
+    """LocalEnhancer.forward (models/networks.py:402-419)."""
+    pyr = [x]
+    for _ in range(n_local_enhancers):
+        pyr.append(avgpool3s2(pyr[-1]))
+    out = global_generator(sd, pyr[-1], n_downsample_global, n_blocks_global, norm, "model", with_head=False)
+    for n in range(1, n_local_enhancers + 1):
+        w = _Walker(sd, "model%d_1" % n, norm)
+        h = w.down3(w.stem7(pyr[n_local_enhancers - n])) + out
+        w = _Walker(sd, "model%d_2" % n, norm)
+        for _ in range(n_blocks_local):
+            h = w.resblock(h)
+        h = w.up3(h)
+        out = w.head7(h, "tanh") if n == n_local_enhancers else h
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# discriminators (models/networks.py:634-725)
+# --------------------------------------------------------------------------------------
+def nlayer_discriminator_feats(sd, prefix_fmt, x, n_layers, norm="batch"):
+    """One PatchGAN with intermediate features; prefix_fmt % j names group j ('scale0_layer%d')."""
+    feats = []
+    h = F.leaky_relu(_conv(sd, (prefix_fmt % 0) + ".0", x, 2, 2), 0.2)
+    feats.append(h)
+    for j in range(1, n_layers):
+        k = prefix_fmt % j
+        h = F.leaky_relu(_norm(sd, k + ".1", _conv(sd, k + ".0", h, 2, 2), norm), 0.2)
+        feats.append(h)
+    k = prefix_fmt % n_layers
+    h = F.leaky_relu(_norm(sd, k + ".1", _conv(sd, k + ".0", h, 1, 2), norm), 0.2)
+    feats.append(h)
+    h = _conv(sd, (prefix_fmt % (n_layers + 1)) + ".0", h, 1, 2)
+    feats.append(h)
+    return feats
+
+
+def multiscale_discriminator(sd, x, n_layers, num_D, norm="batch"):
+    """MultiscaleDiscriminator.forward with getIntermFeat=True (models/networks.py:663-675)."""
+    result = []
+    cur = x
+    for i in range(num_D):
+        result.append(nlayer_discriminator_feats(sd, "scale%d_layer%%d" % (num_D - 1 - i), cur, n_layers, norm))
+        if i != num_D - 1:
+            cur = avgpool3s2(cur)
+    return result
+
+
+# --------------------------------------------------------------------------------------
+# model-level input encoding and inference (models/vid2vid_model_G.py, models/base_model.py)
+# --------------------------------------------------------------------------------------
+def get_edges(t):
+    """models/base_model.py:146-152 -- 4-neighbour instance boundaries."""
+    edge = torch.zeros_like(t, dtype=torch.bool)
+    edge[..., :, 1:] |= t[..., :, 1:] != t[..., :, :-1]
+    edge[..., :, :-1] |= t[..., :, 1:] != t[..., :, :-1]
+    edge[..., 1:, :] |= t[..., 1:, :] != t[..., :-1, :]
+    edge[..., :-1, :] |= t[..., 1:, :] != t[..., :-1, :]
+    return edge.float()
+
+
+def encode_input(input_map, inst_map, label_nc):
+    """models/vid2vid_model_G.py:86-112.  input_map (B,T,1,H,W) floats holding ints -> (B,T,label_nc(+1),H,W)."""
+    if label_nc != 0:
+        b, t, _, h, w = input_map.shape
+        onehot = torch.zeros(b, t, label_nc, h, w)
+        input_map = onehot.scatter_(2, input_map.long(), 1.0)
+    if inst_map is not None:
+        input_map = torch.cat([input_map, get_edges(inst_map)], dim=2)
+    return input_map
+
+
+def build_pyr(t, n_scales):
+    """models/base_model.py:122-134 on (B,T,C,H,W)."""
+    pyr = [t]
+    for _ in range(1, n_scales):
+        b, tt, c, h, w = pyr[-1].shape
+        pyr.append(avgpool3s2(pyr[-1].reshape(-1, 1, h, w)).reshape(b, tt, c, h // 2, w // 2))
+    return pyr
+
+
+def compute_mask(real_As, ts, fg_labels):
+    """models/vid2vid_model_G.py:322-330."""
+    m = real_As[:, ts:ts + 1, fg_labels[0]].clone()
+    for l in fg_labels[1:]:
+        m = m + real_As[:, ts:ts + 1, l]
+    return torch.clamp(m, 0, 1)
+
+
+class InferenceOracle:
+    """Vid2VidModelG.inference (models/vid2vid_model_G.py:198-229) with use_real_img / no_first_img
+    first frames (:231-251), for label2city-style integer label input or raw multi-channel input."""
+
+    def __init__(self, sds, label_nc, use_instance, fg, fg_labels, n_downsample_G, n_blocks, n_blocks_local,
+                 tG=3, no_first_img=False, align_corners=False):
+        self.sds, self.S = sds, len(sds)
+        self.label_nc, self.use_instance, self.fg, self.fg_labels = label_nc, use_instance, fg, list(fg_labels)
+        self.n_down, self.n_blocks, self.n_blocks_local, self.tG = n_downsample_G, n_blocks, n_blocks_local, tG
+        self.no_first_img, self.align_corners = no_first_img, align_corners
+        self.fake_B_prev = None
+
+    def step(self, input_A, input_B, inst_A):
+        tG, S = self.tG, self.S
+        with torch.no_grad():
+            real_A = encode_input(input_A, inst_A if self.use_instance else None, self.label_nc)
+            first = self.fake_B_prev is None
+            if first:
+                if self.no_first_img:
+                    b, _, _, h, w = real_A.shape
+                    fb = torch.zeros(b, tG - 1, 3, h, w)
+                else:
+                    fb = input_B[:, :tG - 1]
+                self.fake_B_prev = [p[0] for p in build_pyr(fb, S)]
+            pyr = build_pyr(real_A, S)
+            feat = flow_feat = fg_feat = None
+            fake_B = None
+            for s in range(S):
+                si = S - 1 - s
+                rA = pyr[si]
+                _, _, _, h, w = rA.shape
+                x = rA[0, :tG].reshape(1, -1, h, w)
+                prev = self.fake_B_prev[si].reshape(1, -1, h, w)
+                mask = compute_mask(rA, tG - 1, self.fg_labels)[0].unsqueeze(0) if self.fg else None
+                if mask is not None:
+                    mask = mask.reshape(1, 1, h, w)
+                raw_only = self.no_first_img and first
+                if s == 0:
+                    out = composite_generator(self.sds[0], x, prev, mask, self.n_down, self.n_blocks, self.fg,
+                                              use_raw_only=raw_only, align_corners=self.align_corners)
+                else:
+                    out = composite_local_generator(self.sds[s], x, prev, mask, feat, flow_feat, fg_feat,
+                                                    self.n_blocks_local, s, self.fg, use_raw_only=raw_only,
+                                                    align_corners=self.align_corners)
+                fake_B, _, _, _, feat, flow_feat, fg_feat = out
+                self.fake_B_prev[si] = torch.cat([self.fake_B_prev[si][1:], fake_B])
+            return fake_B, pyr[0][0, -1]
+
+
+# --------------------------------------------------------------------------------------
+# FlowNet2 native ops, restated from the CUDA sources
+# --------------------------------------------------------------------------------------
+def correlation(in1, in2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """correlation_cuda_kernel.cu:73-147 (forward) with the output-size rule of
+    correlation_cuda.cc:25-38.  in1, in2: (N,C,H,W) -> (N, D*D, OH, OW)."""
+    n, c, h, w = in1.shape
+    krad = (kernel_size - 1) // 2
+    border = krad + max_displacement
+    ph, pw = h + 2 * pad_size, w + 2 * pad_size
+    oh = int(math.ceil(float(ph - 2 * border) / float(stride1)))
+    ow = int(math.ceil(float(pw - 2 * border) / float(stride1)))
+    drad = max_displacement // stride2
+    d = 2 * drad + 1
+    p1 = F.pad(in1, (pad_size,) * 4)      # channels_first(): zero-padded copies (:46-70)
+    p2 = F.pad(in2, (pad_size,) * 4)
+    out = torch.zeros(n, d * d, oh, ow)
+    nelems = kernel_size * kernel_size * c
+    ys = torch.arange(oh) * stride1 + max_displacement
+    xs = torch.arange(ow) * stride1 + max_displacement
+    for tj in range(-drad, drad + 1):
+        for ti in range(-drad, drad + 1):
+            acc = torch.zeros(n, oh, ow)
+            for j in range(-krad, krad + 1):
+                for i in range(-krad, krad + 1):
+                    a = p1[:, :, (ys + j)[:, None], (xs + i)[None, :]]
+                    y2, x2 = ys + tj * stride2 + j, xs + ti * stride2 + i
+                    ok = ((y2 >= 0) & (y2 < ph))[:, None] & ((x2 >= 0) & (x2 < pw))[None, :]
+                    b = p2[:, :, y2.clamp(0, ph - 1)[:, None], x2.clamp(0, pw - 1)[None, :]] * ok
+                    acc += (a * b).sum(1)
+            out[:, (tj + drad) * d + (ti + drad)] = acc / nelems
+    return out
+
+
+def resample2d(img, flow, kernel_size=1):
+    """resample2d_kernel.cu:15-64: out[b,c,y,x] = bilinear(img[b,c], x+fx, y+fy); indices clamped to the
+    output extent, weights from the unclamped fractional part."""
+    b, c, _, _ = img.shape
+    _, _, oh, ow = flow.shape
+    ys, xs = torch.meshgrid(torch.arange(oh, dtype=torch.float32), torch.arange(ow, dtype=torch.float32),
+                            indexing="ij")
+    xf, yf = xs[None] + flow[:, 0], ys[None] + flow[:, 1]
+    alpha, beta = xf - torch.floor(xf), yf - torch.floor(yf)
+    xL = torch.floor(xf).long().clamp(0, ow - 1); xR = (torch.floor(xf).long() + 1).clamp(0, ow - 1)
+    yT = torch.floor(yf).long().clamp(0, oh - 1); yB = (torch.floor(yf).long() + 1).clamp(0, oh - 1)
+    out = torch.zeros(b, c, oh, ow)
+    bi = torch.arange(b)[:, None, None]
+    for ch in range(c):
+        im = img[:, ch]
+        val = torch.zeros(b, oh, ow)
+        for fy in range(kernel_size):
+            for fx in range(kernel_size):
+                val = val + (1. - alpha) * (1. - beta) * im[bi, yT + fy, xL + fx]
+                val = val + alpha * (1. - beta) * im[bi, yT + fy, xR + fx]
+                val = val + (1. - alpha) * beta * im[bi, yB + fy, xL + fx]
+                val = val + alpha * beta * im[bi, yB + fy, xR + fx]
+        out[:, ch] = val
+    return out
+
+
+def channelnorm(x):
+    """channelnorm_kernel.cu:18-60: out[b,0,y,x] = sqrt(sum_c x[b,c,y,x]^2)."""
+    return (x * x).sum(1, keepdim=True).sqrt()

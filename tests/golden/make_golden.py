@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by executing the REFERENCE implementation
+(/root/reference, read-only) on CPU.  Run in the build container only -- the GPU box has no
+/root/reference; the tests read the committed .npz files.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Shims follow SURVEY.md Appendix B: stub modules for absent third-party imports, Tensor.cuda ->
+identity, torch.cuda.FloatTensor/ByteTensor -> CPU types.  No reference file is modified and no
+reference source is copied: the script only imports and calls it.
+
+Each fixture stores: the (small) network's full state_dict, the seeded inputs and the reference
+outputs.  Weights are stored rather than re-derived from a seed so that the fixtures do not
+depend on the host's vectorised RNG paths.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("V2V_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_shims():
+    sys.path.insert(0, REF)
+    for m in ["torchvision", "torchvision.models", "cv2", "dominate", "dominate.tags", "scipy.misc"]:
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.ByteTensor = torch.ByteTensor
+    torch.Tensor.get_device = lambda self: 0
+
+
+def opt_ns(**kw):
+    d = dict(fp16=False, n_blocks=2, n_blocks_local=1, n_local_enhancers=1, fg=True, no_flow=False,
+             feat_num=3)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def synth_labels(gen, T, H, W, n_labels, cell=8, fg_label=26):
+    """Blocky label / instance maps, floats holding integers."""
+    lo = torch.randint(0, n_labels, (T, H // cell, W // cell), generator=gen)
+    lo[:, 0, :2] = fg_label % n_labels
+    lab = lo.repeat_interleave(cell, 1).repeat_interleave(cell, 2)
+    for t in range(T):
+        lab[t] = torch.roll(lab[t], shifts=2 * t, dims=1)
+    return lab.float()
+
+
+def sd_to_np(sd, prefix):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+def golden_composite(networks):
+    """CompositeGenerator.forward (models/networks.py:203-232), fg tower, n_downsampling=3."""
+    torch.manual_seed(11)
+    gen = torch.Generator().manual_seed(12)
+    label_nc, tG, H, W, ngf = 35, 3, 32, 64, 8
+    opt = opt_ns(n_blocks=2)
+    net = networks.define_G(tG * (label_nc + 1), 3, (tG - 1) * 3, ngf, "composite", 3, "batch", 0, [], opt)
+    x = torch.zeros(1, tG * (label_nc + 1), H, W)
+    lab = synth_labels(gen, tG, H, W, label_nc)
+    inst = synth_labels(gen, tG, H, W, 7)
+    for t in range(tG):
+        x[0, t * 36:(t * 36 + 35)].scatter_(0, lab[t].long().unsqueeze(0), 1.0)
+        e = torch.zeros(H, W, dtype=torch.bool)
+        e[:, 1:] |= inst[t][:, 1:] != inst[t][:, :-1]; e[:, :-1] |= inst[t][:, 1:] != inst[t][:, :-1]
+        e[1:, :] |= inst[t][1:, :] != inst[t][:-1, :]; e[:-1, :] |= inst[t][1:, :] != inst[t][:-1, :]
+        x[0, t * 36 + 35] = e.float()
+    prev = torch.tanh(torch.nn.functional.interpolate(torch.randn(1, 6, H // 8, W // 8, generator=gen),
+                                                      scale_factor=8, mode="bilinear", align_corners=False))
+    mask = (lab[tG - 1] == 26).float().view(1, 1, H, W)
+    # keep flows O(few px) so that the warp is a meaningful check
+    with torch.no_grad():
+        net.model_final_flow[1].weight.mul_(0.1)
+        outs = net.forward(x, prev, mask, None, None, None, False)
+        outs_raw = net.forward(x, prev, mask, None, None, None, True)
+    names = ["img_final", "flow", "weight", "img_raw", "img_feat", "flow_feat", "img_fg_feat"]
+    arrays = sd_to_np(net.state_dict(), "sd.")
+    arrays.update({"in.labels": lab.numpy(), "in.inst": inst.numpy(), "in.x": x.numpy(), "in.prev": prev.numpy(),
+                   "in.mask": mask.numpy()})
+    arrays.update({"out." + n: o.numpy() for n, o in zip(names, outs)})
+    arrays["out.img_final_rawonly"] = outs_raw[0].numpy()
+    arrays["cfg"] = np.array([label_nc, tG, H, W, ngf, 3, 2, 1], dtype=np.int64)  # ..., n_down, n_blocks, fg
+    save("composite_fg_32x64", **arrays)
+
+
+def golden_composite_local(networks):
+    """CompositeGenerator (scale 0) -> CompositeLocalGenerator (scale 1), no fg (models/networks.py:296-325)."""
+    torch.manual_seed(21)
+    gen = torch.Generator().manual_seed(22)
+    in_nc, H, W, ngf = 12, 32, 64, 8
+    opt = opt_ns(n_blocks=2, n_blocks_local=1, fg=False)
+    g0 = networks.define_G(in_nc, 3, 6, ngf, "composite", 2, "batch", 0, [], opt)
+    g1 = networks.define_G(in_nc, 3, 6, ngf // 2, "compositeLocal", 2, "batch", 1, [], opt)
+    x1 = torch.rand(1, in_nc, H, W, generator=gen)
+    p1 = torch.tanh(torch.randn(1, 6, H, W, generator=gen))
+    pool = torch.nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+    x0, p0 = pool(x1), pool(p1)
+    with torch.no_grad():
+        g0.model_final_flow[1].weight.mul_(0.1)
+        g1.model_final_flow[1].weight.mul_(0.1)
+        o0 = g0.forward(x0, p0, None, None, None, None, False)
+        o1 = g1.forward(x1, p1, None, o0[4], o0[5], o0[6], False)
+    arrays = sd_to_np(g0.state_dict(), "sd0.")
+    arrays.update(sd_to_np(g1.state_dict(), "sd1."))
+    arrays.update({"in.x1": x1.numpy(), "in.p1": p1.numpy(), "in.x0": x0.numpy(), "in.p0": p0.numpy()})
+    for i, n in enumerate(["img_final", "flow", "weight", "img_raw"]):
+        arrays["out0." + n] = o0[i].numpy()
+        arrays["out1." + n] = o1[i].numpy()
+    arrays["cfg"] = np.array([in_nc, H, W, ngf, 2, 2, 1], dtype=np.int64)
+    save("composite_local_32x64", **arrays)
+
+
+def golden_discriminator(networks):
+    """MultiscaleDiscriminator.forward with getIntermFeat (models/networks.py:663-675)."""
+    torch.manual_seed(31)
+    gen = torch.Generator().manual_seed(32)
+    in_nc, H, W, ndf = 13, 64, 96, 8
+    net = networks.define_D(in_nc, ndf, 3, "batch", 2, True, [])
+    x = torch.randn(1, in_nc, H, W, generator=gen)
+    with torch.no_grad():
+        res = net.forward(x)
+    arrays = sd_to_np(net.state_dict(), "sd.")
+    arrays["in.x"] = x.numpy()
+    for i, feats in enumerate(res):
+        for j, f in enumerate(feats):
+            arrays["out.%d.%d" % (i, j)] = f.numpy()
+    arrays["cfg"] = np.array([in_nc, H, W, ndf, 3, 2], dtype=np.int64)
+    save("multiscale_d_64x96", **arrays)
+
+
+def golden_global(networks):
+    """GlobalGenerator / LocalEnhancer with InstanceNorm (first-frame nets, models/networks.py:327-419)."""
+    torch.manual_seed(41)
+    gen = torch.Generator().manual_seed(42)
+    opt = opt_ns(n_blocks=2, n_blocks_local=1)
+    g = networks.define_G(11, 3, 0, 8, "global", 2, "instance", 0, [], opt)
+    le = networks.define_G(11, 3, 0, 4, "local", 2, "instance", 0, [], opt)
+    x = torch.rand(1, 11, 32, 64, generator=gen)
+    with torch.no_grad():
+        og = g.forward(x)
+        ol = le.forward(x)
+    arrays = sd_to_np(g.state_dict(), "sdg.")
+    arrays.update(sd_to_np(le.state_dict(), "sdl."))
+    arrays.update({"in.x": x.numpy(), "out.global": og.numpy(), "out.local": ol.numpy()})
+    save("first_frame_nets_32x64", **arrays)
+
+
+def golden_inference():
+    """create_model(opt) -> Vid2VidModelG.inference over 3 generated frames, label2city flags
+    (test.py:25-41, models/vid2vid_model_G.py:198-229), n_scales_spatial = 1 and 2."""
+    from options.test_options import TestOptions
+    from models import networks
+    from models.models import create_model
+    import tempfile
+    for S, tag in ((1, "s1"), (2, "s2")):
+        ck = tempfile.mkdtemp()
+        argv = ["test.py", "--name", "g", "--label_nc", "35", "--loadSize", "64", "--use_instance", "--fg",
+                "--use_real_img", "--gpu_ids", "-1", "--checkpoints_dir", ck, "--ngf", "8", "--n_blocks", "2",
+                "--n_blocks_local", "1", "--n_scales_spatial", str(S), "--n_downsample_G", "2"]
+        sys.argv = argv
+        opt = TestOptions().parse(save=False)
+        torch.manual_seed(50 + S)
+        nets = [networks.define_G(108, 3, 6, opt.ngf, "composite", opt.n_downsample_G, opt.norm, 0, [], opt)]
+        for s in range(1, S):
+            nets.append(networks.define_G(108, 3, 6, opt.ngf // (2 ** s), "compositeLocal", opt.n_downsample_G,
+                                          opt.norm, s, [], opt))
+        with torch.no_grad():
+            for n in nets:
+                n.model_final_flow[1].weight.mul_(0.1)
+        os.makedirs(os.path.join(ck, "g"), exist_ok=True)
+        for s, n in enumerate(nets):
+            torch.save(n.state_dict(), os.path.join(ck, "g", "latest_net_G%d.pth" % s))
+        model = create_model(opt)
+        gen = torch.Generator().manual_seed(60 + S)
+        H, W, T = 32, 64, 5
+        lab = synth_labels(gen, T, H, W, 35)
+        inst = synth_labels(gen, T, H, W, 9)
+        Bfirst = torch.tanh(torch.randn(1, 2, 3, H, W, generator=gen))
+        outs = []
+        model.fake_B_prev = None
+        for t in range(T - 2):
+            A = lab[t:t + 3].view(1, 3, 1, H, W)
+            I = inst[t:t + 3].view(1, 3, 1, H, W)
+            fake, real_A = model.inference(A, Bfirst if t == 0 else None, I)
+            outs.append(fake.clone())
+            if t == 0:
+                last_label = real_A.clone()
+        arrays = {}
+        for s, n in enumerate(nets):
+            arrays.update(sd_to_np(n.state_dict(), "sd%d." % s))
+        arrays.update({"in.labels": lab.numpy(), "in.inst": inst.numpy(), "in.B": Bfirst.numpy(),
+                       "out.fake": torch.cat(outs).numpy(), "out.real_A_last": last_label.numpy()})
+        save("inference_label2city_%s_32x64" % tag, **arrays)
+
+
+def main():
+    install_shims()
+    from models import networks
+    golden_composite(networks)
+    golden_composite_local(networks)
+    golden_discriminator(networks)
+    golden_global(networks)
+    golden_inference()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+"""CPU-side checks of the drop-in boundary: C ABI surface, checkpoint-key compatibility, the
+lowering (plan recording, no execution) and the 'oracle is test infrastructure' rule."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from util import sd_from_npz
+
+
+def test_library_exports_every_declared_symbol():
+    from vid2vid_amd import lib
+    header = open(os.path.join(ROOT, "include", "v2v_hip.h")).read()
+    declared = set(re.findall(r"\b(v2v_[a-z0-9_]+)\s*\(", header)) - {"v2v_conv_desc", "v2v_plan"}
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(lib.lib, name), "libv2v_hip.so does not export %s" % name
+    assert declared <= set(lib.exported_symbols()), sorted(declared - set(lib.exported_symbols()))
+    assert lib.lib.v2v_version() >= 100
+
+
+def test_conv_desc_layout_matches_header():
+    """ctypes mirror of struct v2v_conv_desc: field order and count follow the header."""
+    from vid2vid_amd.lib import ConvDesc
+    header = open(os.path.join(ROOT, "include", "v2v_hip.h")).read()
+    body = header[header.index("typedef struct v2v_conv_desc {"):header.index("} v2v_conv_desc;")]
+    names = []
+    for line in body.splitlines()[1:]:
+        line = line.split("/*")[0].strip().rstrip(";")
+        if not line:
+            continue
+        decl = line.split(None, 1)[1] if not line.startswith("const") else line.split("*", 1)[1]
+        names += [n.strip().lstrip("*").strip() for n in decl.replace("*", "").split(",")]
+    mine = [n.rstrip("_") for n, _ in ConvDesc._fields_]
+    assert mine == names
+
+
+def test_packed_weight_size_rule():
+    from vid2vid_amd import lib
+    L = lib.lib
+    # Conv2d 3x3 1024->1024 bf16: [1024][9*1024]
+    assert L.v2v_conv_packed_elems(1024, 1024, 1024, 3, 3, 0, 1, lib.BF16) == 1024 * 9216
+    # ConvTranspose2d 3x3 s2 p1: parity classes have 1,2,2,4 taps
+    assert L.v2v_conv_packed_elems(64, 64, 128, 3, 3, 1, 1, lib.F32) == 128 * 64 * (1 + 2 + 2 + 4)
+    # K padded to 128 bytes, cout padded to 128 rows
+    assert L.v2v_conv_packed_elems(6, 8, 3, 7, 7, 0, 0, lib.BF16) == 128 * 448
+
+
+def test_correlation_output_size_rule():
+    from vid2vid_amd import lib
+    import ctypes as C
+    c, h, w = C.c_int32(), C.c_int32(), C.c_int32()
+    lib.lib.v2v_correlation_out_size(32, 64, 20, 1, 20, 1, 2, C.byref(c), C.byref(h), C.byref(w))
+    assert (c.value, h.value, w.value) == (441, 32, 64)          # FlowNetC.py:31
+    lib.lib.v2v_correlation_out_size(17, 23, 4, 3, 4, 2, 1, C.byref(c), C.byref(h), C.byref(w))
+    assert (c.value, h.value, w.value) == (81, 8, 11)
+
+
+def test_invalid_arguments_fail_loudly():
+    from vid2vid_amd import lib
+    with pytest.raises(RuntimeError):
+        lib.check(lib.lib.v2v_channelnorm_forward(None, None, 1, 1, 1, 1, 2, None), "channelnorm")
+    d = lib.ConvDesc()
+    assert lib.lib.v2v_conv2d(d, None) != 0
+    assert b"null" in lib.lib.v2v_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+\.*oracle\b|oracle\.vid2vid_oracle|/oracle/", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vid2vid_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), "%s references the oracle" % f
+
+
+def _opt(**kw):
+    d = dict(fp16=False, n_blocks=2, n_blocks_local=1, n_local_enhancers=1, fg=True, no_flow=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def test_state_dict_keys_match_reference_checkpoints(golden):
+    """Strict load of reference-produced state_dicts = same parameter names and shapes."""
+    from vid2vid_amd import networks as N
+    g = golden("composite_fg_32x64")
+    net = N.define_G(108, 3, 6, 8, "composite", 3, "batch", 0, [], _opt())
+    net.load_state_dict(sd_from_npz(g, "sd."), strict=True)
+    g = golden("composite_local_32x64")
+    N.define_G(12, 3, 6, 8, "composite", 2, "batch", 0, [], _opt(fg=False)).load_state_dict(sd_from_npz(g, "sd0."), strict=True)
+    N.define_G(12, 3, 6, 4, "compositeLocal", 2, "batch", 1, [], _opt(fg=False)).load_state_dict(sd_from_npz(g, "sd1."), strict=True)
+    g = golden("multiscale_d_64x96")
+    N.define_D(13, 8, 3, "batch", 2, True, []).load_state_dict(sd_from_npz(g, "sd."), strict=True)
+    g = golden("first_frame_nets_32x64")
+    N.define_G(11, 3, 0, 8, "global", 2, "instance", 0, [], _opt()).load_state_dict(sd_from_npz(g, "sdg."), strict=True)
+    N.define_G(11, 3, 0, 4, "local", 2, "instance", 0, [], _opt()).load_state_dict(sd_from_npz(g, "sdl."), strict=True)
+
+
+def test_seeded_init_equals_reference_init(golden):
+    """Same construction order + same initialiser => identical weights under the same seed
+    (the golden state_dict was drawn by the reference under manual_seed(11))."""
+    from vid2vid_amd import networks as N
+    g = golden("composite_fg_32x64")
+    torch.manual_seed(11)
+    net = N.define_G(108, 3, 6, 8, "composite", 3, "batch", 0, [], _opt())
+    ref = sd_from_npz(g, "sd.")
+    for k, v in net.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            continue                         # buffers were updated by the reference's forward passes
+        if k == "model_final_flow.1.weight":
+            v = v * 0.1                      # make_golden.py scales the flow head after init
+        assert torch.allclose(v.float(), ref[k].float(), rtol=0, atol=1e-7), k
+
+
+def test_inference_lowering_census_512x256():
+    """Record (not run) the per-frame plan of BASELINE config C2 and compare the conv census with
+    SURVEY.md Appendix A.1: 79 convolutions, 2115.0 GFLOP, 411.3 M parameters."""
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models import create_model
+    if torch.cuda.is_available():
+        pytest.skip("dry-run census is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        opt = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True,
+                       precision="bf16", gpu_ids=[])
+        m = create_model(opt)
+        assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 411.3) < 0.1
+        H, W = 256, 512
+        A = torch.randint(0, 35, (1, 3, 1, H, W)).float()
+        inst = torch.randint(0, 20, (1, 3, 1, H, W)).float()
+        fake, lab = m.inference(A, torch.zeros(1, 2, 3, H, W), inst)
+        assert fake.shape == (1, 3, H, W) and lab.shape == (36, H, W)
+        fp = m._active_plan
+        assert len(fp.conv_log) == 79
+        assert abs(sum(c["flops"] for c in fp.conv_log) / 1e9 - 2115.0) < 0.5
+        assert fp.plan.num_ops > 200
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()

@@ -1,0 +1,123 @@
+"""The oracle (oracle/vid2vid_oracle.py) pinned against outputs of the REFERENCE itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import vid2vid_oracle as O
+from util import sd_from_npz, assert_close
+
+T = torch.from_numpy
+PIN = 2e-5   # oracle and reference run the same torch CPU kernels; only op grouping differs
+
+
+def test_composite_generator_matches_reference(golden):
+    g = golden("composite_fg_32x64")
+    sd = sd_from_npz(g, "sd.")
+    outs = O.composite_generator(sd, T(g["in.x"]), T(g["in.prev"]), T(g["in.mask"]), 3, 2, True)
+    for name, o in zip(["img_final", "flow", "weight", "img_raw", "img_feat", "flow_feat", "img_fg_feat"], outs):
+        assert_close(o, g["out." + name], PIN, name)
+    raw_only = O.composite_generator(sd, T(g["in.x"]), T(g["in.prev"]), T(g["in.mask"]), 3, 2, True, use_raw_only=True)
+    assert_close(raw_only[0], g["out.img_final_rawonly"], PIN, "img_final(use_raw_only)")
+
+
+def test_encode_input_matches_reference_tensor(golden):
+    g = golden("composite_fg_32x64")
+    lab, inst = T(g["in.labels"]), T(g["in.inst"])
+    enc = O.encode_input(lab.view(1, 3, 1, 32, 64), inst.view(1, 3, 1, 32, 64), 35)
+    assert torch.equal(enc.reshape(1, 108, 32, 64), T(g["in.x"]))
+    assert torch.equal(O.compute_mask(enc, 2, [26]).reshape(1, 1, 32, 64), T(g["in.mask"]))
+
+
+def test_composite_local_generator_matches_reference(golden):
+    g = golden("composite_local_32x64")
+    sd0, sd1 = sd_from_npz(g, "sd0."), sd_from_npz(g, "sd1.")
+    o0 = O.composite_generator(sd0, T(g["in.x0"]), T(g["in.p0"]), None, 2, 2, False)
+    o1 = O.composite_local_generator(sd1, T(g["in.x1"]), T(g["in.p1"]), None, o0[4], o0[5], o0[6], 1, 1, False)
+    for i, n in enumerate(["img_final", "flow", "weight", "img_raw"]):
+        assert_close(o0[i], g["out0." + n], PIN, "scale0." + n)
+        assert_close(o1[i], g["out1." + n], PIN, "scale1." + n)
+    assert_close(O.avgpool3s2(T(g["in.x1"])), g["in.x0"], 1e-6, "avgpool pyramid")
+
+
+def test_multiscale_discriminator_matches_reference(golden):
+    g = golden("multiscale_d_64x96")
+    res = O.multiscale_discriminator(sd_from_npz(g, "sd."), T(g["in.x"]), 3, 2)
+    for i, feats in enumerate(res):
+        assert len(feats) == 5
+        for j, f in enumerate(feats):
+            assert_close(f, g["out.%d.%d" % (i, j)], PIN, "D scale %d layer %d" % (i, j))
+
+
+def test_first_frame_generators_match_reference(golden):
+    g = golden("first_frame_nets_32x64")
+    x = T(g["in.x"])
+    assert_close(O.global_generator(sd_from_npz(g, "sdg."), x, 2, 2), g["out.global"], PIN, "GlobalGenerator")
+    assert_close(O.local_enhancer(sd_from_npz(g, "sdl."), x, 2, 2, 1, 1), g["out.local"], PIN, "LocalEnhancer")
+
+
+def _run_inference(g, S):
+    sds = [sd_from_npz(g, "sd%d." % s) for s in range(S)]
+    orc = O.InferenceOracle(sds, 35, True, True, [26], 2, 2, 1)
+    lab, inst, B = T(g["in.labels"]), T(g["in.inst"]), T(g["in.B"])
+    H, W = lab.shape[-2:]
+    outs = []
+    for t in range(lab.shape[0] - 2):
+        fake, real_A = orc.step(lab[t:t + 3].view(1, 3, 1, H, W), B if t == 0 else None, inst[t:t + 3].view(1, 3, 1, H, W))
+        outs.append(fake)
+        if t == 0:
+            first_label = real_A
+    return torch.cat(outs), first_label
+
+
+def test_inference_single_scale_matches_reference(golden):
+    g = golden("inference_label2city_s1_32x64")
+    fake, lab = _run_inference(g, 1)
+    assert_close(fake, g["out.fake"], PIN, "inference S=1")
+    assert torch.equal(lab, T(g["out.real_A_last"]))
+
+
+def test_inference_two_scales_matches_reference(golden):
+    g = golden("inference_label2city_s2_32x64")
+    fake, _ = _run_inference(g, 2)
+    assert_close(fake, g["out.fake"], 1e-4, "inference S=2")
+
+
+# ---- FlowNet2 native ops: no reference vectors exist (CUDA only) -> hand-computed cases ----
+def test_correlation_hand_cases():
+    # 1x1 kernel, single channel: out[tj,ti](y,x) = f1(y,x)*f2(y+2tj, x+2ti) / C with zero padding
+    f1 = torch.arange(1, 26, dtype=torch.float32).view(1, 1, 5, 5)
+    f2 = torch.arange(101, 126, dtype=torch.float32).view(1, 1, 5, 5)
+    out = O.correlation(f1, f2, pad_size=2, kernel_size=1, max_displacement=2, stride1=1, stride2=2)
+    assert out.shape == (1, 9, 5, 5)
+    assert out[0, 4, 2, 2] == f1[0, 0, 2, 2] * f2[0, 0, 2, 2]           # centre displacement
+    assert out[0, 0, 2, 2] == f1[0, 0, 2, 2] * f2[0, 0, 0, 0]           # (tj,ti) = (-1,-1) -> 2 px up/left
+    assert out[0, 8, 2, 2] == f1[0, 0, 2, 2] * f2[0, 0, 4, 4]
+    assert out[0, 0, 0, 0] == 0                                          # falls into the zero padding
+    # channel averaging
+    g1, g2 = torch.randn(2, 6, 7, 9), torch.randn(2, 6, 7, 9)
+    o = O.correlation(g1, g2, 4, 1, 4, 1, 2)
+    assert o.shape == (2, 25, 7, 9)
+    assert torch.allclose(o[:, 12], (g1 * g2).mean(1), atol=1e-6)
+    # FlowNetC geometry (FlowNetC.py:31): pad 20, k 1, max_disp 20, stride2 2 -> 441 channels, same H, W
+    assert O.correlation(torch.zeros(1, 2, 6, 8), torch.zeros(1, 2, 6, 8), 20, 1, 20, 1, 2).shape == (1, 441, 6, 8)
+
+
+def test_resample2d_hand_cases():
+    img = torch.arange(12, dtype=torch.float32).view(1, 1, 3, 4)
+    assert torch.equal(O.resample2d(img, torch.zeros(1, 2, 3, 4)), img)                      # identity
+    flow = torch.zeros(1, 2, 3, 4); flow[:, 0] = 1.0
+    shifted = O.resample2d(img, flow)
+    assert torch.equal(shifted[..., :3], img[..., 1:]) and torch.equal(shifted[..., 3], img[..., 3])  # border clamp
+    flow = torch.zeros(1, 2, 3, 4); flow[:, 0] = 0.5
+    half = O.resample2d(img, flow)
+    assert torch.allclose(half[..., :3], (img[..., :3] + img[..., 1:]) / 2)
+    # matches grid_sample(align_corners=True, border) away from the right/bottom border
+    torch.manual_seed(0)
+    im, fl = torch.randn(1, 3, 9, 11), torch.randn(1, 2, 9, 11) * 0.4
+    ref = O.resample(im, fl, align_corners=True)
+    assert torch.allclose(O.resample2d(im, fl)[..., 1:-2, 1:-2], ref[..., 1:-2, 1:-2], atol=1e-5)
+
+
+def test_channelnorm_hand_cases():
+    x = torch.tensor([3.0, 4.0]).view(1, 2, 1, 1)
+    assert O.channelnorm(x).item() == 5.0

@@ -1,0 +1,564 @@
+// Implicit-GEMM convolution / transposed convolution for gfx950 (MI355X), NHWC activations.
+//
+//   D[pixel][cout] = sum_{tap, cin} A[pixel @ tap][cin] * Wp[cout][tap][cin]
+//
+// One kernel template serves every conv on the vid2vid hot path (reference call sites:
+// models/networks.py:132-183 CompositeGenerator, :247-279 CompositeLocalGenerator, :335-352
+// GlobalGenerator, :571-587 ResnetBlock, :687-706 NLayerDiscriminator and
+// models/flownet2_pytorch/networks/submodules.py:7-38):
+//   * Conv2d k x k, stride 1/2, zero or reflection padding folded into the tile loader
+//     (no padded copy is ever materialised),
+//   * ConvTranspose2d(stride 2) as 4 output-parity classes (blockIdx.y) with 1/2/2/4 (3x3)
+//     or 4x(2x2) (4x4) taps each -- no zero insertion,
+//   * exact-fp32 path on v_mfma_f32_32x32x2_f32 (parity gate) and bf16 path on
+//     v_mfma_f32_32x32x16_bf16 (throughput), same LDS image / fragment addressing in bytes,
+//   * epilogue: bias, per-channel (sum, sum^2) partials for training-mode BatchNorm
+//     (deterministic: one row of partials per M tile), or activation + store.
+//
+// Tiling: a workgroup of 4 waves (wave64) owns a BM x BN output tile; K advances in
+// 128-byte chunks (32 fp32 / 64 bf16).  A and B tiles are staged global -> registers ->
+// LDS with a 2-deep LDS ring (loads for chunk k+1 are in flight while chunk k is on the
+// matrix cores; one barrier per chunk).  LDS rows are 128 B with the 16-byte slot index
+// XOR-swizzled by (row>>1)&7, which makes both the ds_write_b128 staging stores and the
+// ds_read_b128 fragment loads of the 32x32 MFMA operand layout bank-conflict free.
+// blockIdx.x is remapped so that the 32 workgroups resident on one XCD share weight
+// (N) tiles in that XCD's private L2.
+#include "v2v_internal.h"
+#include <cstdarg>
+#include <cstring>
+
+namespace v2v {
+
+struct ConvKArgs {
+    const char* in;
+    const char* w;
+    const float* bias;
+    char* out;
+    float* stats;
+    int N, H, W, cin_stride;
+    int cout, cout_stride, cout_p;
+    int OH, OW;
+    int sm;              // input step per class-grid step (conv: stride, convT: 1)
+    int os;              // output step per class-grid step (conv: 1, convT: 2)
+    int pad_mode;
+    int Mc, OHc, OWc;    // rows per class and class grid
+    int m_tiles, n_tiles;
+    int out_mode, act;
+    float act_param, out_scale;
+    // per class (conv: class 0 only)
+    int nkh[4], nkw[4];
+    int dh0[4], dw0[4];  // first tap's input offset
+    int dstep;           // +1 conv, -1 convT
+    int ktot[4], kpad[4];
+    long long woff[4];   // element offset of the class matrix inside w
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int ntot) {
+    const int q = ntot >> 3, r = ntot & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 Frag;
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4 Frag;
+    // lane (i = l&31, half h = l>>5) holds k = 4h..4h+3 of an 8-deep step: MFMA j multiplies
+    // k in {j, 4+j}; A and B use the same convention so every k is covered exactly once.
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int BKE = ElemTraits<T>::BKE;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int cls = blockIdx.y;
+
+    const int lin = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+    const int nt = lin / p.m_tiles;
+    const int mt = lin - nt * p.m_tiles;
+
+    const int nkh = p.nkh[cls], nkw = p.nkw[cls];
+    const int dh0 = p.dh0[cls], dw0 = p.dw0[cls], dstep = p.dstep;
+    const int kpad = p.kpad[cls];
+    const int nk = kpad / BKE;
+    const int H = p.H, W = p.W, cs = p.cin_stride;
+
+    // ---------------- loader state ----------------
+    const int slot = tid & 7;
+    const int lrow = tid >> 3;                 // 0..31
+    const int swz = (lrow >> 1) & 7;
+    const int lds_w_off = lrow * 128 + ((slot ^ swz) << 4);
+
+    int pixbase[RA], ohs[RA], ows[RA];
+    unsigned rowvalid = 0;
+    {
+        const int hw = p.OHc * p.OWc;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = mt * BM + lrow + 32 * i;
+            const bool ok = m < p.Mc;
+            const int mm = ok ? m : 0;
+            const int n = mm / hw;
+            const int rem = mm - n * hw;
+            const int oi = rem / p.OWc;
+            const int oj = rem - oi * p.OWc;
+            pixbase[i] = n * H * W;
+            ohs[i] = oi * p.sm;
+            ows[i] = oj * p.sm;
+            rowvalid |= (ok ? 1u : 0u) << i;
+        }
+    }
+    // k decode for this thread's 16-byte slot
+    int kc, kth, ktw;
+    {
+        const int k = slot * VEC;
+        const int t = k / cs;
+        kc = k - t * cs;
+        kth = t / nkw;
+        ktw = t - kth * nkw;
+    }
+    const char* wrow[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const long long r = (long long)nt * BN + lrow + 32 * i;
+        wrow[i] = p.w + ((long long)p.woff[cls] + r * kpad + slot * VEC) * (long long)sizeof(T);
+    }
+
+    uint4 ra[RA], rb[RB];
+    auto load_tiles = [&](int ks) {
+        const bool kvalid = kth < nkh;
+        const int dh = dh0 + kth * dstep, dw = dw0 + ktw * dstep;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int ih = ohs[i] + dh, iw = ows[i] + dw;
+            bool ok = kvalid && ((rowvalid >> i) & 1u);
+            if (p.pad_mode == V2V_PAD_REFLECT) {
+                ih = ih < 0 ? -ih : (ih >= H ? 2 * H - 2 - ih : ih);
+                iw = iw < 0 ? -iw : (iw >= W ? 2 * W - 2 - iw : iw);
+            } else {
+                ok = ok && ((unsigned)ih < (unsigned)H) && ((unsigned)iw < (unsigned)W);
+            }
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) {
+                const long long e = ((long long)(pixbase[i] + ih * W + iw)) * cs + kc;
+                v = *reinterpret_cast<const uint4*>(p.in + e * (long long)sizeof(T));
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (long long)ks * (BKE * (int)sizeof(T)));
+        // advance k state by one chunk
+        kc += BKE;
+        while (kc >= cs) {
+            kc -= cs;
+            if (++ktw == nkw) { ktw = 0; ++kth; }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* base = smem + buf * STAGE + lds_w_off;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(base + i * 32 * 128) = ra[i];
+        char* bb = base + BM * 128;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(bb + i * 32 * 128) = rb[i];
+    };
+
+    // ---------------- fragment addressing ----------------
+    const int lr = lane & 31, hi = lane >> 5;
+    const int fx = (lr >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = ((s * 2 + hi) ^ fx) << 4;
+    const int a_row_off = (wm * WM + lr) * 128;
+    const int b_row_off = BM * 128 + (wn * WN + lr) * 128;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---------------- main loop ----------------
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) load_tiles(ks + 1);
+        const char* sb = smem + (ks & 1) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Frag fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const Frag*>(sb + a_row_off + i * 32 * 128 + foff[s]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const Frag*>(sb + b_row_off + j * 32 * 128 + foff[s]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        if (more) store_tiles((ks + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2], LDS ring is free now
+    const bool want_stats = p.stats != nullptr;
+    const int a_par = cls >> 1, b_par = cls & 1;
+    const int hwc = p.OHc * p.OWc;
+    const long long ohow = (long long)p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ncol = nt * BN + wn * WN + j * 32 + lr;
+        const bool nvalid = ncol < p.cout;
+        const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int m = mt * BM + row;
+                if (m < p.Mc && nvalid) {
+                    float v = acc[i][j][r] + bv;
+                    long long opix;   // output pixel index in [N][OH][OW]
+                    if (p.os == 1) {
+                        opix = m;
+                    } else {
+                        const int n = m / hwc;
+                        const int rem = m - n * hwc;
+                        const int oi = rem / p.OWc;
+                        const int oj = rem - oi * p.OWc;
+                        opix = ((long long)n * p.OH + (oi * 2 + a_par)) * p.OW + (oj * 2 + b_par);
+                    }
+                    if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
+                        s1 += v;
+                        s2 += v * v;
+                        reinterpret_cast<float*>(p.out)[opix * p.cout_stride + ncol] = v;
+                    } else {
+                        v = apply_act(v, p.act, p.act_param) * p.out_scale;
+                        if (p.out_mode == V2V_OUT_ACT_NHWC) {
+                            store_act(reinterpret_cast<T*>(p.out), opix * p.cout_stride + ncol, v);
+                        } else {
+                            const long long n = opix / ohow;
+                            const long long pix = opix - n * ohow;
+                            reinterpret_cast<float*>(p.out)[(n * p.cout + ncol) * ohow + pix] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hi == 0) {
+                const int c = wn * WN + j * 32 + lr;
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = s2;
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int ncol = nt * BN + tid;
+            if (ncol < p.cout) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < WGM; ++q) {
+                    s1 += red[(q * BN + tid) * 2 + 0];
+                    s2 += red[(q * BN + tid) * 2 + 1];
+                }
+                float* dst = p.stats + ((long long)(cls * p.m_tiles + mt) * p.cout + ncol) * 2;
+                dst[0] = s1;
+                dst[1] = s2;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------
+struct TileCfg { int id, BM, BN; };
+static const TileCfg kCfgs[] = {
+    {1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {4, 128, 32}, {5, 64, 128}, {6, 256, 64},
+};
+static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+static const TileCfg* find_cfg(int id) {
+    for (int i = 0; i < kNumCfgs; ++i)
+        if (kCfgs[i].id == id) return &kCfgs[i];
+    return nullptr;
+}
+
+static int bke_of(int dtype) { return dtype == V2V_BF16 ? 64 : 32; }
+
+// taps of transposed-conv parity class `par` along one axis
+static void convt_axis(int K, int pad, int par, int* k0, int* nk, int* d0) {
+    *k0 = (par + pad) & 1;
+    *nk = (*k0 < K) ? (K - *k0 + 1) / 2 : 0;
+    *d0 = (par + pad - *k0) / 2;   // (par+pad-k0) is even
+}
+
+struct ConvGeom {
+    int ncls;
+    int nkh[4], nkw[4], kh0[4], kw0[4], dh0[4], dw0[4], ktot[4], kpad[4];
+    long long woff[4];
+    long long total;
+    int cout_p;
+};
+
+static int conv_geom(int cin_stride, int cout, int KH, int KW, int transposed, int pad, int dtype, ConvGeom* g) {
+    const int bke = bke_of(dtype);
+    memset(g, 0, sizeof(*g));
+    g->cout_p = (int)round_up(cout, 128);
+    long long off = 0;
+    if (!transposed) {
+        g->ncls = 1;
+        g->nkh[0] = KH; g->nkw[0] = KW; g->kh0[0] = 0; g->kw0[0] = 0;
+        g->dh0[0] = -pad; g->dw0[0] = -pad;
+        g->ktot[0] = KH * KW * cin_stride;
+        g->kpad[0] = (int)round_up(g->ktot[0], bke);
+        g->woff[0] = 0;
+        off = (long long)g->cout_p * g->kpad[0];
+    } else {
+        g->ncls = 4;
+        for (int c = 0; c < 4; ++c) {
+            const int a = c >> 1, b = c & 1;
+            convt_axis(KH, pad, a, &g->kh0[c], &g->nkh[c], &g->dh0[c]);
+            convt_axis(KW, pad, b, &g->kw0[c], &g->nkw[c], &g->dw0[c]);
+            g->ktot[c] = g->nkh[c] * g->nkw[c] * cin_stride;
+            g->kpad[c] = (int)round_up(g->ktot[c] > 0 ? g->ktot[c] : 1, bke);
+            g->woff[c] = off;
+            off += (long long)g->cout_p * g->kpad[c];
+        }
+    }
+    g->total = off;
+    return 0;
+}
+
+// ---- weight packing kernel: PyTorch layout fp32 -> packed class matrices ----------------
+struct PackArgs {
+    const float* w; void* dst;
+    int cin, cin_stride, cout, cout_p, KH, KW, transposed;
+    int ncls;
+    int nkh[4], nkw[4], kh0[4], kw0[4], kpad[4];
+    long long woff[4];
+    long long total;
+    int dtype;
+};
+
+__global__ void pack_weights_kernel(const PackArgs a) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < a.total; e += stride) {
+        int cls = 0;
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+            if (c < a.ncls && e >= a.woff[c]) cls = c;
+        const long long le = e - a.woff[cls];
+        const int kp = a.kpad[cls];
+        const int co = (int)(le / kp);
+        const int k = (int)(le - (long long)co * kp);
+        const int t = k / a.cin_stride;
+        const int c = k - t * a.cin_stride;
+        float v = 0.f;
+        const int ntaps = a.nkh[cls] * a.nkw[cls];
+        if (co < a.cout && t < ntaps && c < a.cin) {
+            const int th = t / a.nkw[cls], tw = t - th * a.nkw[cls];
+            int kh, kw;
+            if (a.transposed) { kh = a.kh0[cls] + 2 * th; kw = a.kw0[cls] + 2 * tw; }
+            else              { kh = th; kw = tw; }
+            long long src;
+            if (a.transposed) src = (((long long)c * a.cout + co) * a.KH + kh) * a.KW + kw;   // [cin][cout][kh][kw]
+            else              src = (((long long)co * a.cin + c) * a.KH + kh) * a.KW + kw;    // [cout][cin][kh][kw]
+            v = a.w[src];
+        }
+        if (a.dtype == V2V_BF16) reinterpret_cast<unsigned short*>(a.dst)[e] = f32_to_bf16_bits(v);
+        else                     reinterpret_cast<float*>(a.dst)[e] = v;
+    }
+}
+
+struct PackOp : Op {
+    PackArgs a;
+    int launch(hipStream_t s) override {
+        const int threads = 256;
+        long long blocks = ceil_div(a.total, threads);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "pack_weights"; }
+};
+
+// ---- conv launch ------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WGM, int WGN>
+static int launch_cfg(const ConvKArgs& k, int ncls, hipStream_t s) {
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    auto kern = conv_igemm_kernel<T, BM, BN, WGM, WGN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(k.m_tiles * k.n_tiles), (unsigned)ncls);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+    return check_launch();
+}
+
+template <typename T>
+static int launch_typed(int cfg, const ConvKArgs& k, int ncls, hipStream_t s) {
+    switch (cfg) {
+        case 1: return launch_cfg<T, 128, 128, 2, 2>(k, ncls, s);
+        case 2: return launch_cfg<T, 128, 64, 2, 2>(k, ncls, s);
+        case 3: return launch_cfg<T, 64, 64, 2, 2>(k, ncls, s);
+        case 4: return launch_cfg<T, 128, 32, 4, 1>(k, ncls, s);
+        case 5: return launch_cfg<T, 64, 128, 2, 2>(k, ncls, s);
+        case 6: return launch_cfg<T, 256, 64, 4, 1>(k, ncls, s);
+    }
+    set_error("conv: unknown tile config %d", cfg);
+    return V2V_EINVAL;
+}
+
+static int choose_cfg(long long Mc, int cout, int ncls) {
+    if (cout <= 32) return 4;
+    auto tiles = [&](int id) {
+        const TileCfg* c = find_cfg(id);
+        return ceil_div(Mc, c->BM) * ceil_div(cout, c->BN) * ncls;
+    };
+    if (cout <= 64) return tiles(2) >= 512 ? 2 : 3;
+    if (tiles(1) >= 448) return 1;
+    if (tiles(2) >= 224) return 2;
+    return 3;
+}
+
+struct ConvOp : Op {
+    ConvKArgs k;
+    int ncls, cfg, dtype;
+    int launch(hipStream_t s) override {
+        return dtype == V2V_BF16 ? launch_typed<bf16_t>(cfg, k, ncls, s) : launch_typed<float>(cfg, k, ncls, s);
+    }
+    const char* name() const override { return "conv_igemm"; }
+};
+
+static int build_conv(const v2v_conv_desc* d, ConvOp* op) {
+    if (!d || !d->in || !d->w || !d->out) { set_error("conv: null pointer"); return V2V_EINVAL; }
+    if (d->dtype != V2V_F32 && d->dtype != V2V_BF16) { set_error("conv: bad dtype"); return V2V_EINVAL; }
+    const int vec = d->dtype == V2V_BF16 ? 8 : 4;
+    if (d->cin_stride % vec != 0 || d->cin > d->cin_stride) { set_error("conv: cin_stride %d not a multiple of %d", d->cin_stride, vec); return V2V_EINVAL; }
+    if (d->transposed && (d->stride != 2 || d->OH != 2 * d->H || d->OW != 2 * d->W || d->pad_mode != V2V_PAD_ZERO)) {
+        set_error("conv: transposed conv supports stride 2 with OH = 2H only"); return V2V_EINVAL;
+    }
+    if (!d->transposed) {
+        const int oh = (d->H + 2 * d->pad - d->KH) / d->stride + 1, ow = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+        if (oh != d->OH || ow != d->OW) { set_error("conv: OH/OW mismatch (%d,%d) vs (%d,%d)", d->OH, d->OW, oh, ow); return V2V_EINVAL; }
+        if (d->pad_mode == V2V_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) { set_error("conv: reflect pad >= size"); return V2V_EINVAL; }
+    }
+    if (d->out_mode != V2V_OUT_F32_NCHW && d->cout > d->cout_stride) { set_error("conv: cout_stride"); return V2V_EINVAL; }
+    ConvGeom g;
+    conv_geom(d->cin_stride, d->cout, d->KH, d->KW, d->transposed, d->pad, d->dtype, &g);
+    ConvKArgs& k = op->k;
+    memset(&k, 0, sizeof(k));
+    k.in = (const char*)d->in; k.w = (const char*)d->w; k.bias = d->bias; k.out = (char*)d->out; k.stats = d->stats;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.cin_stride = d->cin_stride;
+    k.cout = d->cout; k.cout_stride = d->cout_stride; k.cout_p = g.cout_p;
+    k.OH = d->OH; k.OW = d->OW;
+    k.pad_mode = d->pad_mode;
+    if (d->transposed) { k.sm = 1; k.os = 2; k.OHc = d->H; k.OWc = d->W; k.dstep = -1; }
+    else               { k.sm = d->stride; k.os = 1; k.OHc = d->OH; k.OWc = d->OW; k.dstep = 1; }
+    const long long Mc = (long long)d->N * k.OHc * k.OWc;
+    if (Mc >= (1ll << 31) || (long long)d->N * d->H * d->W >= (1ll << 31)) { set_error("conv: too many pixels"); return V2V_EINVAL; }
+    k.Mc = (int)Mc;
+    for (int c = 0; c < 4; ++c) {
+        k.nkh[c] = g.nkh[c]; k.nkw[c] = g.nkw[c]; k.dh0[c] = g.dh0[c]; k.dw0[c] = g.dw0[c];
+        k.ktot[c] = g.ktot[c]; k.kpad[c] = g.kpad[c]; k.woff[c] = g.woff[c];
+    }
+    k.out_mode = d->out_mode; k.act = d->act; k.act_param = d->act_param; k.out_scale = d->out_scale;
+    op->ncls = g.ncls;
+    op->dtype = d->dtype;
+    op->cfg = d->tile ? d->tile : choose_cfg(Mc, d->cout, g.ncls);
+    const TileCfg* c = find_cfg(op->cfg);
+    if (!c) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
+    k.m_tiles = (int)ceil_div(Mc, c->BM);
+    k.n_tiles = (int)ceil_div(d->cout, c->BN);
+    return 0;
+}
+
+}  // namespace v2v
+
+using namespace v2v;
+
+extern "C" int64_t v2v_conv_packed_elems(int32_t cin, int32_t cin_stride, int32_t cout, int32_t KH, int32_t KW,
+                                         int32_t transposed, int32_t pad, int32_t dtype) {
+    (void)cin;
+    ConvGeom g;
+    conv_geom(cin_stride, cout, KH, KW, transposed, pad, dtype, &g);
+    return g.total;
+}
+
+extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t cin_stride, int32_t cout,
+                                     int32_t KH, int32_t KW, int32_t transposed, int32_t pad, int32_t dtype,
+                                     void* stream) {
+    if (!w || !dst) { set_error("pack: null pointer"); return V2V_EINVAL; }
+    ConvGeom g;
+    conv_geom(cin_stride, cout, KH, KW, transposed, pad, dtype, &g);
+    auto op = std::make_unique<PackOp>();
+    PackArgs& a = op->a;
+    a.w = w; a.dst = dst; a.cin = cin; a.cin_stride = cin_stride; a.cout = cout; a.cout_p = g.cout_p;
+    a.KH = KH; a.KW = KW; a.transposed = transposed; a.ncls = g.ncls; a.total = g.total; a.dtype = dtype;
+    for (int c = 0; c < 4; ++c) {
+        a.nkh[c] = g.nkh[c]; a.nkw[c] = g.nkw[c]; a.kh0[c] = g.kh0[c]; a.kw0[c] = g.kw0[c];
+        a.kpad[c] = g.kpad[c]; a.woff[c] = g.woff[c];
+    }
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_conv_stats_rows(const v2v_conv_desc* d) {
+    ConvOp op;
+    if (build_conv(d, &op) != 0) return V2V_EINVAL;
+    return op.ncls * op.k.m_tiles;
+}
+
+extern "C" int v2v_conv_tile_config(const v2v_conv_desc* d) {
+    ConvOp op;
+    if (build_conv(d, &op) != 0) return V2V_EINVAL;
+    return op.cfg;
+}
+
+extern "C" int v2v_conv2d(const v2v_conv_desc* d, void* stream) {
+    auto op = std::make_unique<ConvOp>();
+    int rc = build_conv(d, op.get());
+    if (rc != 0) return rc;
+    return submit(std::move(op), stream);
+}

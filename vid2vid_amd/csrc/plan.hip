@@ -1,0 +1,178 @@
+// Plan executor: a recorded sequence of launches that is replayed as one native call or as
+// one hipGraph.  The Python layer builds the network once per (model, resolution) against
+// preallocated buffers; per frame it only refreshes the input buffers and replays.  This is
+// the MI355X replacement for the reference's per-op Python dispatch (test.py:41 ->
+// Vid2VidModelG.inference -> ~240 ATen launches per frame).
+#include "v2v_internal.h"
+#include <cstdarg>
+#include <cstdio>
+
+namespace v2v {
+
+static thread_local char g_err[512] = "";
+static thread_local v2v_plan* g_recording = nullptr;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace v2v
+
+struct v2v_plan {
+    std::vector<std::unique_ptr<v2v::Op>> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+namespace v2v {
+
+int submit(std::unique_ptr<Op> op, void* stream) {
+    if (g_recording) {
+        g_recording->ops.push_back(std::move(op));
+        return 0;
+    }
+    return op->launch(reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // namespace v2v
+
+using namespace v2v;
+
+extern "C" v2v_plan* v2v_plan_create(void) { return new v2v_plan(); }
+
+extern "C" void v2v_plan_destroy(v2v_plan* p) {
+    if (!p) return;
+    if (g_recording == p) g_recording = nullptr;
+    if (p->exec) hipGraphExecDestroy(p->exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    delete p;
+}
+
+extern "C" int v2v_plan_begin_record(v2v_plan* p) {
+    if (!p || g_recording) { set_error("plan: already recording"); return V2V_EINVAL; }
+    g_recording = p;
+    return 0;
+}
+
+extern "C" int v2v_plan_end_record(v2v_plan* p) {
+    if (!p || g_recording != p) { set_error("plan: not recording this plan"); return V2V_EINVAL; }
+    g_recording = nullptr;
+    return 0;
+}
+
+extern "C" int v2v_plan_num_ops(const v2v_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int v2v_plan_run(v2v_plan* p, void* stream) {
+    if (!p) return V2V_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (auto& op : p->ops) {
+        int rc = op->launch(s);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+extern "C" int v2v_plan_instantiate_graph(v2v_plan* p, void* stream) {
+    if (!p) return V2V_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+    if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+    // one eager pass first: sets per-kernel attributes and faults in code objects outside capture
+    int rc = v2v_plan_run(p, stream);
+    if (rc != 0) return rc;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("plan: warm-up failed: %s", hipGetErrorString(e)); return (int)e; }
+    e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { set_error("plan: begin capture: %s", hipGetErrorString(e)); return (int)e; }
+    rc = v2v_plan_run(p, stream);
+    hipError_t e2 = hipStreamEndCapture(s, &p->graph);
+    if (rc != 0) return rc;
+    if (e2 != hipSuccess) { set_error("plan: end capture: %s", hipGetErrorString(e2)); return (int)e2; }
+    e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { set_error("plan: instantiate: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+extern "C" int v2v_plan_launch_graph(v2v_plan* p, void* stream) {
+    if (!p || !p->exec) { set_error("plan: graph not instantiated"); return V2V_EINVAL; }
+    hipError_t e = hipGraphLaunch(p->exec, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) { set_error("plan: graph launch: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+extern "C" int v2v_plan_profile(v2v_plan* p, void* stream, float* ms, int32_t n) {
+    if (!p || !ms || n < (int)p->ops.size()) { set_error("plan: profile buffer too small"); return V2V_EINVAL; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t nops = p->ops.size();
+    std::vector<hipEvent_t> ev(nops + 1);
+    for (auto& e : ev) hipEventCreate(&e);
+    hipEventRecord(ev[0], s);
+    int rc = 0;
+    for (size_t i = 0; i < nops && rc == 0; ++i) {
+        rc = p->ops[i]->launch(s);
+        hipEventRecord(ev[i + 1], s);
+    }
+    hipStreamSynchronize(s);
+    if (rc == 0)
+        for (size_t i = 0; i < nops; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
+}
+
+extern "C" const char* v2v_plan_op_name(const v2v_plan* p, int32_t i) {
+    if (!p || i < 0 || i >= (int)p->ops.size()) return "";
+    return p->ops[i]->name();
+}
+
+extern "C" int v2v_plan_set_label(v2v_plan* p, const char* label) {
+    // labels the most recently recorded op (layer name for per-op reports)
+    if (!p || p->ops.empty() || !label) return V2V_EINVAL;
+    p->ops.back()->label = label;
+    return 0;
+}
+
+extern "C" const char* v2v_plan_op_label(const v2v_plan* p, int32_t i) {
+    if (!p || i < 0 || i >= (int)p->ops.size()) return "";
+    return p->ops[i]->label.c_str();
+}
+
+extern "C" int v2v_version(void) { return 100; }
+extern "C" const char* v2v_last_error(void) { return g_err; }
+
+extern "C" int v2v_device_info(int32_t* cus, int32_t* lds_per_cu, int64_t* hbm_bytes, char* arch, int32_t arch_len) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        set_error("no HIP device");
+        return V2V_EINVAL;
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (lds_per_cu) *lds_per_cu = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+    return 0;
+}
+
+// Device-to-device copy as a recordable op (rolling fake_B_prev window,
+// models/vid2vid_model_G.py:228, and input staging inside a plan).
+namespace v2v {
+struct CopyOp : Op {
+    void* dst; const void* src; size_t bytes;
+    int launch(hipStream_t s) override {
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { set_error("memcpy_d2d: %s", hipGetErrorString(e)); return (int)e; }
+        return 0;
+    }
+    const char* name() const override { return "memcpy_d2d"; }
+};
+}  // namespace v2v
+
+extern "C" int v2v_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream) {
+    if (!dst || !src || bytes < 0) { set_error("memcpy_d2d: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<CopyOp>();
+    op->dst = dst; op->src = src; op->bytes = (size_t)bytes;
+    return submit(std::move(op), stream);
+}

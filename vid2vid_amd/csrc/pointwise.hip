@@ -1,0 +1,488 @@
+// HBM-bound helpers of the vid2vid hot path: input encoding, layout changes, pyramids and
+// the warp-and-blend tail of the composite generators.  All are one-pass streaming kernels
+// with coalesced accesses; none of them materialises the reference's intermediates
+// (one-hot NCHW tensor, normalised grid, expanded masks).
+#include "v2v_internal.h"
+
+namespace v2v {
+
+static inline unsigned grid_for(long long n, int threads = 256, long long cap = 4096) {
+    long long b = ceil_div(n, threads);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------------
+// encode_input + get_edges + compute_mask
+// ---------------------------------------------------------------------------------------
+struct EncodeArgs {
+    const float* labels; const float* inst; void* out; float* mask;
+    int T, H, W, label_nc, c_stride; const int* fg; int n_fg;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void encode_labels_kernel(const EncodeArgs a) {
+    // one thread per (pixel, 16-byte vector of output channels)
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int vpr = a.c_stride / VEC;
+    const long long hw = (long long)a.H * a.W;
+    const long long nvec = hw * vpr;
+    const int per_frame = a.label_nc + (a.inst ? 1 : 0);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    T* out = reinterpret_cast<T*>(a.out);
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        const long long pix = v / vpr;
+        const int c0 = (int)(v - pix * vpr) * VEC;
+        const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);
+        float o[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int ch = c0 + q;
+            float val = 0.f;
+            const int t = ch / per_frame;
+            if (t < a.T) {
+                const int c = ch - t * per_frame;
+                if (c < a.label_nc) {
+                    const int lab = (int)a.labels[t * hw + pix];
+                    val = (lab == c) ? 1.f : 0.f;
+                } else {
+                    // instance-boundary edge: 4-neighbour inequality (models/base_model.py:146-152)
+                    const float* ip = a.inst + t * hw;
+                    const float ctr = ip[pix];
+                    bool e = false;
+                    if (x > 0)       e = e || (ip[pix - 1] != ctr);
+                    if (x < a.W - 1) e = e || (ip[pix + 1] != ctr);
+                    if (y > 0)       e = e || (ip[pix - a.W] != ctr);
+                    if (y < a.H - 1) e = e || (ip[pix + a.W] != ctr);
+                    val = e ? 1.f : 0.f;
+                }
+            }
+            o[q] = val;
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) store_act(out, pix * a.c_stride + c0 + q, o[q]);
+        if (a.mask && c0 == 0) {
+            // compute_mask (models/vid2vid_model_G.py:322-330) on the last frame
+            const int lab = (int)a.labels[(long long)(a.T - 1) * hw + pix];
+            float m = 0.f;
+            for (int i = 0; i < a.n_fg; ++i) m += (a.fg[i] == lab) ? 1.f : 0.f;
+            a.mask[pix] = fminf(fmaxf(m, 0.f), 1.f);
+        }
+    }
+}
+
+struct EncodeOp : Op {
+    EncodeArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        const int vec = dtype == V2V_BF16 ? 8 : 4;
+        const long long nvec = (long long)a.H * a.W * (a.c_stride / vec);
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(encode_labels_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(encode_labels_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "encode_labels"; }
+};
+
+// ---------------------------------------------------------------------------------------
+// layout changes
+// ---------------------------------------------------------------------------------------
+struct PackArgs2 { const float* x; void* y; int N, C, H, W, c_stride; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_nchw_to_nhwc_kernel(const PackArgs2 a) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int vpr = a.c_stride / VEC;
+    const long long hw = (long long)a.H * a.W;
+    const long long nvec = (long long)a.N * hw * vpr;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    T* y = reinterpret_cast<T*>(a.y);
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        // consecutive threads -> consecutive pixels of one channel vector (coalesced reads)
+        const long long pixg = v % ((long long)a.N * hw);
+        const int cv = (int)(v / ((long long)a.N * hw));
+        const long long n = pixg / hw, pix = pixg - n * hw;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int c = cv * VEC + q;
+            const float val = c < a.C ? a.x[(n * a.C + c) * hw + pix] : 0.f;
+            store_act(y, pixg * a.c_stride + c, val);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_nhwc_to_nchw_kernel(const PackArgs2 a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long total = (long long)a.N * a.C * hw;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const T* y = reinterpret_cast<const T*>(a.y);
+    float* x = const_cast<float*>(a.x);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long pix = e % hw;
+        const long long nc = e / hw;
+        const long long n = nc / a.C;
+        const int c = (int)(nc - n * a.C);
+        x[e] = load_act(y, (n * hw + pix) * a.c_stride + c);
+    }
+}
+
+struct LayoutOp : Op {
+    PackArgs2 a; int dtype; bool pack;
+    int launch(hipStream_t s) override {
+        const int vec = dtype == V2V_BF16 ? 8 : 4;
+        const long long n = pack ? (long long)a.N * a.H * a.W * (a.c_stride / vec) : (long long)a.N * a.C * a.H * a.W;
+        if (pack) {
+            if (dtype == V2V_BF16) hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
+            else                   hipLaunchKernelGGL(pack_nchw_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        } else {
+            if (dtype == V2V_BF16) hipLaunchKernelGGL(unpack_nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
+            else                   hipLaunchKernelGGL(unpack_nhwc_to_nchw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        }
+        return check_launch();
+    }
+    const char* name() const override { return pack ? "pack_nchw_to_nhwc" : "unpack_nhwc_to_nchw"; }
+};
+
+// ---------------------------------------------------------------------------------------
+// AvgPool2d(3, stride 2, padding 1, count_include_pad=False)
+// ---------------------------------------------------------------------------------------
+struct PoolArgs { const void* x; void* y; long long planes; int N, H, W, OH, OW, c_stride; };
+
+__global__ __launch_bounds__(256) void avgpool_planar_kernel(const PoolArgs a) {
+    const float* x = reinterpret_cast<const float*>(a.x);
+    float* y = reinterpret_cast<float*>(a.y);
+    const long long total = a.planes * a.OH * a.OW;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int ox = (int)(e % a.OW);
+        const long long t = e / a.OW;
+        const int oy = (int)(t % a.OH);
+        const long long pl = t / a.OH;
+        const float* xp = x + pl * (long long)a.H * a.W;
+        float s = 0.f; int cnt = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = 2 * oy + dy;
+            if (iy < 0 || iy >= a.H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = 2 * ox + dx;
+                if (ix < 0 || ix >= a.W) continue;
+                s += xp[(long long)iy * a.W + ix];
+                ++cnt;
+            }
+        }
+        y[e] = s / (float)cnt;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const PoolArgs a) {
+    const T* x = reinterpret_cast<const T*>(a.x);
+    T* y = reinterpret_cast<T*>(a.y);
+    const long long total = (long long)a.N * a.OH * a.OW * a.c_stride;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int c = (int)(e % a.c_stride);
+        long long t = e / a.c_stride;
+        const int ox = (int)(t % a.OW); t /= a.OW;
+        const int oy = (int)(t % a.OH);
+        const long long n = t / a.OH;
+        float s = 0.f; int cnt = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = 2 * oy + dy;
+            if (iy < 0 || iy >= a.H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = 2 * ox + dx;
+                if (ix < 0 || ix >= a.W) continue;
+                s += load_act(x, ((n * a.H + iy) * a.W + ix) * a.c_stride + c);
+                ++cnt;
+            }
+        }
+        store_act(y, e, s / (float)cnt);
+    }
+}
+
+struct PoolOp : Op {
+    PoolArgs a; int dtype; bool planar;
+    int launch(hipStream_t s) override {
+        if (planar) {
+            hipLaunchKernelGGL(avgpool_planar_kernel, dim3(grid_for(a.planes * a.OH * a.OW)), dim3(256), 0, s, a);
+        } else {
+            const long long n = (long long)a.N * a.OH * a.OW * a.c_stride;
+            if (dtype == V2V_BF16) hipLaunchKernelGGL(avgpool_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
+            else                   hipLaunchKernelGGL(avgpool_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        }
+        return check_launch();
+    }
+    const char* name() const override { return planar ? "avgpool3s2_planar" : "avgpool3s2_nhwc"; }
+};
+
+// ---------------------------------------------------------------------------------------
+// grid_sample(bilinear, border) driven by a pixel-unit flow, and the composite blend
+// ---------------------------------------------------------------------------------------
+// Follows BaseNetwork.resample (models/networks.py:108-115): grid = linspace(-1,1) + flow /
+// ((W-1)/2, (H-1)/2), then F.grid_sample.  gx/gy hold torch.linspace(-1,1,W/H) so the base
+// grid is bit-identical to the reference's get_grid (models/networks.py:79-93).
+__device__ __forceinline__ float unnormalize(float coord, int size, int align_corners) {
+    if (align_corners) return ((coord + 1.f) / 2.f) * (float)(size - 1);
+    return ((coord + 1.f) * (float)size - 1.f) / 2.f;
+}
+
+__device__ __forceinline__ void bilinear_setup(float fx, float fy, float gxv, float gyv, int H, int W, int ac,
+                                               int& x0, int& y0, float& wx, float& wy) {
+    const float nx = gxv + fx / (((float)W - 1.0f) / 2.0f);
+    const float ny = gyv + fy / (((float)H - 1.0f) / 2.0f);
+    float ix = unnormalize(nx, W, ac), iy = unnormalize(ny, H, ac);
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.f));     // padding_mode='border'
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    x0 = (int)fx0; y0 = (int)fy0;
+    wx = ix - fx0; wy = iy - fy0;
+}
+
+__device__ __forceinline__ float bilinear_fetch(const float* img, int H, int W, int x0, int y0, float wx, float wy) {
+    // corners outside the image contribute 0 (their weight is 0 after the border clip)
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool xin = x1 < W, yin = y1 < H;
+    const float nw = img[(long long)y0 * W + x0];
+    const float ne = xin ? img[(long long)y0 * W + x1] : 0.f;
+    const float sw = yin ? img[(long long)y1 * W + x0] : 0.f;
+    const float se = (xin && yin) ? img[(long long)y1 * W + x1] : 0.f;
+    return nw * ((1.f - wx) * (1.f - wy)) + ne * (wx * (1.f - wy)) + sw * ((1.f - wx) * wy) + se * (wx * wy);
+}
+
+struct WarpArgs {
+    float* img_raw; const float* flow; const float* weight; const float* prev; const float* fg; const float* mask;
+    float* img_final; float* img_warp; const float* gx; const float* gy;
+    int N, C, H, W, align_corners;
+};
+
+__global__ __launch_bounds__(256) void warp_blend_kernel(const WarpArgs a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long total = (long long)a.N * hw;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long n = e / hw, pix = e - n * hw;
+        const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);
+        int x0 = 0, y0 = 0; float wx = 0.f, wy = 0.f;
+        const bool do_warp = a.flow != nullptr;
+        float wgt = 1.f;
+        if (do_warp) {
+            const float fx = a.flow[(n * 2 + 0) * hw + pix], fy = a.flow[(n * 2 + 1) * hw + pix];
+            bilinear_setup(fx, fy, a.gx[x], a.gy[y], a.H, a.W, a.align_corners, x0, y0, wx, wy);
+            wgt = a.weight[n * hw + pix];
+        }
+        const float m = a.fg ? a.mask[n * hw + pix] : 0.f;
+        for (int c = 0; c < a.C; ++c) {
+            const long long o = (n * a.C + c) * hw + pix;
+            float raw = a.img_raw[o];
+            float fin = raw;
+            if (do_warp) {
+                const float wv = bilinear_fetch(a.prev + (n * a.C + c) * hw, a.H, a.W, x0, y0, wx, wy);
+                if (a.img_warp) a.img_warp[o] = wv;
+                fin = raw * wgt + wv * (1.f - wgt);
+            }
+            if (a.fg) {
+                const float f = a.fg[o];
+                fin = f * m + fin * (1.f - m);
+                raw = f * m + raw * (1.f - m);
+                a.img_raw[o] = raw;
+            }
+            a.img_final[o] = fin;
+        }
+    }
+}
+
+struct WarpOp : Op {
+    WarpArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(warp_blend_kernel, dim3(grid_for((long long)a.N * a.H * a.W)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "warp_blend"; }
+};
+
+struct ResampleArgs { const float* img; const float* flow; float* out; const float* gx; const float* gy; int N, C, H, W, align_corners; };
+
+__global__ __launch_bounds__(256) void resample_flow_kernel(const ResampleArgs a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long total = (long long)a.N * hw;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long n = e / hw, pix = e - n * hw;
+        const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);
+        int x0, y0; float wx, wy;
+        bilinear_setup(a.flow[(n * 2 + 0) * hw + pix], a.flow[(n * 2 + 1) * hw + pix], a.gx[x], a.gy[y],
+                       a.H, a.W, a.align_corners, x0, y0, wx, wy);
+        for (int c = 0; c < a.C; ++c)
+            a.out[(n * a.C + c) * hw + pix] = bilinear_fetch(a.img + (n * a.C + c) * hw, a.H, a.W, x0, y0, wx, wy);
+    }
+}
+
+struct ResampleOp : Op {
+    ResampleArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(resample_flow_kernel, dim3(grid_for((long long)a.N * a.H * a.W)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "resample_flow"; }
+};
+
+// ---------------------------------------------------------------------------------------
+// y = a + b on NHWC activations (coarse-to-fine feature sums, models/networks.py:299,305,319)
+// ---------------------------------------------------------------------------------------
+struct AddArgs { const void* a; const void* b; void* y; long long nvec; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const AddArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const T* a = reinterpret_cast<const T*>(p.a);
+    const T* b = reinterpret_cast<const T*>(p.b);
+    T* y = reinterpret_cast<T*>(p.y);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < p.nvec; v += stride) {
+        const uint4 ua = *reinterpret_cast<const uint4*>(a + v * VEC);
+        const uint4 ub = *reinterpret_cast<const uint4*>(b + v * VEC);
+        uint4 uo;
+        if constexpr (VEC == 4) {
+            uo.x = __float_as_uint(__uint_as_float(ua.x) + __uint_as_float(ub.x));
+            uo.y = __float_as_uint(__uint_as_float(ua.y) + __uint_as_float(ub.y));
+            uo.z = __float_as_uint(__uint_as_float(ua.z) + __uint_as_float(ub.z));
+            uo.w = __float_as_uint(__uint_as_float(ua.w) + __uint_as_float(ub.w));
+        } else {
+            auto add2 = [](unsigned x, unsigned z) {
+                const float lo = bf16_bits_to_f32((unsigned short)(x & 0xffffu)) + bf16_bits_to_f32((unsigned short)(z & 0xffffu));
+                const float hi = bf16_bits_to_f32((unsigned short)(x >> 16)) + bf16_bits_to_f32((unsigned short)(z >> 16));
+                return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+            };
+            uo.x = add2(ua.x, ub.x); uo.y = add2(ua.y, ub.y); uo.z = add2(ua.z, ub.z); uo.w = add2(ua.w, ub.w);
+        }
+        *reinterpret_cast<uint4*>(y + v * VEC) = uo;
+    }
+}
+
+struct AddOp : Op {
+    AddArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(a.nvec)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(a.nvec)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "add_nhwc"; }
+};
+
+// ---------------------------------------------------------------------------------------
+// compute_mask (models/vid2vid_model_G.py:322-330) on an NHWC (possibly pooled) label tensor
+// ---------------------------------------------------------------------------------------
+struct FgMaskArgs { const void* x; float* mask; long long P; int c_stride, base_ch; const int* fg; int n_fg; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void fg_mask_kernel(const FgMaskArgs a) {
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < a.P; p += stride) {
+        float m = 0.f;
+        for (int i = 0; i < a.n_fg; ++i) m += load_act(x, p * a.c_stride + a.base_ch + a.fg[i]);
+        a.mask[p] = fminf(fmaxf(m, 0.f), 1.f);
+    }
+}
+
+struct FgMaskOp : Op {
+    FgMaskArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(fg_mask_kernel<bf16_t>, dim3(grid_for(a.P)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(fg_mask_kernel<float>, dim3(grid_for(a.P)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "fg_mask_nhwc"; }
+};
+
+}  // namespace v2v
+
+using namespace v2v;
+
+extern "C" int v2v_encode_labels(const float* labels, const float* inst, void* out, float* mask,
+                                 int32_t T, int32_t H, int32_t W, int32_t label_nc, int32_t c_stride,
+                                 const int32_t* fg_labels_dev, int32_t n_fg, int32_t dtype, void* stream) {
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    const int need = T * (label_nc + (inst ? 1 : 0));
+    if (!labels || !out || c_stride % vec != 0 || need > c_stride || (mask && n_fg > 0 && !fg_labels_dev)) {
+        set_error("encode_labels: bad argument"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<EncodeOp>();
+    op->a = EncodeArgs{labels, inst, out, mask, T, H, W, label_nc, c_stride, fg_labels_dev, n_fg};
+    op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_pack_nchw_to_nhwc(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                     int32_t c_stride, int32_t dtype, void* stream) {
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    if (!x || !y || c_stride % vec != 0 || C > c_stride) { set_error("pack: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<LayoutOp>();
+    op->a = PackArgs2{x, y, N, C, H, W, c_stride}; op->dtype = dtype; op->pack = true;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_unpack_nhwc_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                       int32_t c_stride, int32_t dtype, void* stream) {
+    if (!x || !y || C > c_stride) { set_error("unpack: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<LayoutOp>();
+    op->a = PackArgs2{y, const_cast<void*>(x), N, C, H, W, c_stride}; op->dtype = dtype; op->pack = false;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_avgpool3s2_planar(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream) {
+    if (!x || !y) { set_error("avgpool: null"); return V2V_EINVAL; }
+    auto op = std::make_unique<PoolOp>();
+    op->a = PoolArgs{x, y, planes, 1, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, 0}; op->planar = true; op->dtype = V2V_F32;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_avgpool3s2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t c_stride,
+                                   int32_t dtype, void* stream) {
+    if (!x || !y) { set_error("avgpool: null"); return V2V_EINVAL; }
+    auto op = std::make_unique<PoolOp>();
+    op->a = PoolArgs{x, y, 0, N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, c_stride}; op->planar = false; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_warp_blend(float* img_raw, const float* flow, const float* weight, const float* prev,
+                              const float* fg, const float* mask, float* img_final, float* img_warp,
+                              const float* gx, const float* gy,
+                              int32_t N, int32_t C, int32_t H, int32_t W, int32_t align_corners, void* stream) {
+    if (!img_raw || !img_final || (flow && (!weight || !prev || !gx || !gy)) || (fg && !mask)) {
+        set_error("warp_blend: bad argument"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<WarpOp>();
+    op->a = WarpArgs{img_raw, flow, weight, prev, fg, mask, img_final, img_warp, gx, gy, N, C, H, W, align_corners};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_resample_flow(const float* img, const float* flow, float* out, const float* gx, const float* gy,
+                                 int32_t N, int32_t C, int32_t H, int32_t W, int32_t align_corners, void* stream) {
+    if (!img || !flow || !out || !gx || !gy) { set_error("resample_flow: null"); return V2V_EINVAL; }
+    auto op = std::make_unique<ResampleOp>();
+    op->a = ResampleArgs{img, flow, out, gx, gy, N, C, H, W, align_corners};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_add_nhwc(const void* a, const void* b, void* y, int64_t n_elems, int32_t dtype, void* stream) {
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    if (!a || !b || !y || n_elems % vec != 0) { set_error("add: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<AddOp>();
+    op->a = AddArgs{a, b, y, n_elems / vec}; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_fg_mask_nhwc(const void* x, float* mask, int64_t P, int32_t c_stride, int32_t base_ch,
+                                const int32_t* fg_labels_dev, int32_t n_fg, int32_t dtype, void* stream) {
+    if (!x || !mask || !fg_labels_dev || n_fg <= 0) { set_error("fg_mask: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<FgMaskOp>();
+    op->a = FgMaskArgs{x, mask, P, c_stride, base_ch, fg_labels_dev, n_fg}; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}

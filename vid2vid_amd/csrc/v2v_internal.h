@@ -1,0 +1,81 @@
+// Internal helpers shared by the HIP translation units of libv2v_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <memory>
+#include "../../include/v2v_hip.h"
+
+namespace v2v {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8)))  __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4)))  float  f32x4;
+typedef __attribute__((ext_vector_type(16))) float  f32x16;
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned)b) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int VEC = 4;    // elements per 16-byte vector
+    static constexpr int BKE = 32;   // elements per 128-byte K chunk
+    static constexpr int DTYPE = V2V_F32;
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int VEC = 8;
+    static constexpr int BKE = 64;
+    static constexpr int DTYPE = V2V_BF16;
+};
+
+__device__ __forceinline__ float load_act(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float load_act(const bf16_t* p, int64_t i) {
+    return bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p)[i]);
+}
+__device__ __forceinline__ void store_act(float* p, int64_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void store_act(bf16_t* p, int64_t i, float v) {
+    reinterpret_cast<unsigned short*>(p)[i] = f32_to_bf16_bits(v);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float param) {
+    switch (act) {
+        case V2V_ACT_RELU:    return v > 0.f ? v : 0.f;
+        case V2V_ACT_LEAKY:   return v > 0.f ? v : v * param;
+        case V2V_ACT_TANH:    return tanhf(v);
+        case V2V_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default:              return v;
+    }
+}
+
+// ---- host side: op recording ---------------------------------------------------------
+struct Op {
+    virtual ~Op() {}
+    virtual int launch(hipStream_t s) = 0;
+    virtual const char* name() const = 0;
+    std::string label;
+};
+
+// Either launches `op` now on `stream` or, when a plan is recording on this thread,
+// appends it to the plan (plan.cpp).
+int submit(std::unique_ptr<Op> op, void* stream);
+void set_error(const char* fmt, ...);
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("HIP launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace v2v

@@ -1,0 +1,520 @@
+"""Lowering of the reference's nn.Module graphs onto libv2v_hip.so.
+
+The reference describes every network as nn.Sequential lists of Conv2d / ConvTranspose2d /
+ReflectionPad2d / BatchNorm2d / InstanceNorm2d / ReLU / LeakyReLU / Tanh / Sigmoid /
+ResnetBlock (models/networks.py:117-725).  `Engine.run_sequential` walks such a list and
+emits the fused HIP launches:
+
+    [ReflectionPad2d(p)] Conv2d|ConvTranspose2d  ->  v2v_conv2d (padding folded into the loader)
+       + norm [+ act]                            ->  conv(raw + statistics), v2v_bn_finalize,
+                                                     v2v_bn_apply (normalise + act + residual adds)
+       + act only / nothing                      ->  activation in the conv epilogue
+    ResnetBlock                                   ->  two of the above, residual in bn_apply
+
+All tensors handed to the library are NHWC with a channel stride padded to 16 bytes.  The
+emitted launches either run immediately (eager) or are recorded into a `Plan` that is then
+replayed per frame as one native call / one hipGraph.  No torch compute op is on this path.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .lib import lib, check, ConvDesc
+
+_TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    if not torch.cuda.is_available():
+        return None          # record-only dry runs on a CPU host never launch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def vec_of(dtype):
+    return 8 if dtype == L.BF16 else 4
+
+
+def pad_channels(c, dtype):
+    v = vec_of(dtype)
+    return (c + v - 1) // v * v
+
+
+class Act:
+    """NHWC activation: tensor [N,H,W,Cs] (Cs = padded channel stride), C real channels."""
+    __slots__ = ("t", "C")
+
+    def __init__(self, t, C):
+        self.t, self.C = t, C
+
+    @property
+    def N(self): return self.t.shape[0]
+    @property
+    def H(self): return self.t.shape[1]
+    @property
+    def W(self): return self.t.shape[2]
+    @property
+    def Cs(self): return self.t.shape[3]
+
+
+class PackedConv:
+    """Device-resident packed weights of one nn.Conv2d / nn.ConvTranspose2d."""
+
+    def __init__(self, eng, mod, cin_stride):
+        self.mod = mod
+        self.transposed = isinstance(mod, nn.ConvTranspose2d)
+        w = mod.weight
+        if self.transposed:
+            self.cin, self.cout = w.shape[0], w.shape[1]
+            if tuple(mod.stride) != (2, 2) or tuple(mod.kernel_size)[0] - 2 * mod.padding[0] + mod.output_padding[0] != 2:
+                raise NotImplementedError("ConvTranspose2d must be stride 2 with OH = 2H")
+        else:
+            self.cout, self.cin = w.shape[0], w.shape[1]
+        self.KH, self.KW = mod.kernel_size
+        self.stride = mod.stride[0]
+        self.pad = mod.padding[0]
+        self.cin_stride = cin_stride
+        self.dtype = eng.dtype
+        n = lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, self.KH, self.KW,
+                                      int(self.transposed), self.pad, eng.dtype)
+        self.buf = torch.empty(n, dtype=_TORCH_DTYPE[eng.dtype], device=eng.device)
+        self.bias = None
+        self.version = None
+        self.refresh()
+
+    def refresh(self, force=False):
+        """(Re)pack if the parameter changed (optimizer step / load_state_dict)."""
+        w = self.mod.weight
+        ver = (w._version, w.data_ptr(), None if self.mod.bias is None else self.mod.bias._version)
+        if not force and ver == self.version:
+            return
+        w32 = w.detach()
+        if w32.dtype != torch.float32 or not w32.is_contiguous():
+            w32 = w32.float().contiguous()
+        check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), self.cin, self.cin_stride, self.cout,
+                                        self.KH, self.KW, int(self.transposed), self.pad, self.dtype, _stream()),
+              "conv_pack_weights")
+        self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()
+        self.version = ver
+
+
+class Plan:
+    """Recorded launch sequence (v2v_plan) with optional hipGraph replay."""
+
+    def __init__(self):
+        self.h = C.c_void_p(lib.v2v_plan_create())
+        self.keep = []          # tensors the recorded launches point into
+        self.graph_ready = False
+
+    def __enter__(self):
+        check(lib.v2v_plan_begin_record(self.h), "plan_begin_record")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib.v2v_plan_end_record(self.h), "plan_end_record")
+        return False
+
+    def label(self, text):
+        lib.v2v_plan_set_label(self.h, text.encode())
+
+    @property
+    def num_ops(self):
+        return lib.v2v_plan_num_ops(self.h)
+
+    def run(self):
+        check(lib.v2v_plan_run(self.h, _stream()), "plan_run")
+
+    def instantiate_graph(self):
+        check(lib.v2v_plan_instantiate_graph(self.h, _stream()), "plan_instantiate_graph")
+        self.graph_ready = True
+
+    def launch(self):
+        if self.graph_ready:
+            check(lib.v2v_plan_launch_graph(self.h, _stream()), "plan_launch_graph")
+        else:
+            self.run()
+
+    def profile(self):
+        n = self.num_ops
+        ms = (C.c_float * n)()
+        check(lib.v2v_plan_profile(self.h, _stream(), ms, n), "plan_profile")
+        out = []
+        for i in range(n):
+            out.append((lib.v2v_plan_op_name(self.h, i).decode(), lib.v2v_plan_op_label(self.h, i).decode(), ms[i]))
+        return out
+
+    def __del__(self):
+        try:
+            lib.v2v_plan_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Engine:
+    """Emits v2v_* launches for one device / one activation dtype."""
+
+    def __init__(self, device, dtype=L.F32, align_corners=False, record_only=False):
+        self.device = torch.device(device)
+        # record_only: launches may only be RECORDED into a Plan (never executed).  Used by the CPU
+        # test-suite to check the lowering (layer census, argument validation) without a GPU.
+        self.record_only = record_only
+        if self.device.type != "cuda" and not record_only:
+            raise RuntimeError("vid2vid_amd runs on MI355X only (got device %s); there is no CPU path" % device)
+        self.dtype = dtype
+        self.tdtype = _TORCH_DTYPE[dtype]
+        self.align_corners = align_corners
+        self._packed = {}        # id(module) -> PackedConv
+        self._scratch = {}       # name -> tensor (grown on demand, shared between layers)
+        self._grids = {}
+        self.plan = None         # Plan being recorded (for labels / keep-alive)
+        self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
+        self.tile_override = {}  # (cin,cout,KH,stride,transposed) -> tile id (tuning)
+        self.update_running_stats = False
+
+    # ---------------- buffers ----------------
+    def empty_act(self, N, H, W, C):
+        t = torch.empty((N, H, W, pad_channels(C, self.dtype)), dtype=self.tdtype, device=self.device)
+        self._keep(t)
+        return Act(t, C)
+
+    def zeros_act(self, N, H, W, C):
+        a = self.empty_act(N, H, W, C)
+        a.t.zero_()
+        return a
+
+    def empty_f32(self, *shape):
+        t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        self._keep(t)
+        return t
+
+    def scratch(self, name, numel, dtype=torch.float32):
+        """Shared scratch (conv raw output, statistics): consumed by the next launch on the
+        same stream, so one buffer per kind is enough."""
+        key = (name, dtype)
+        t = self._scratch.get(key)
+        if t is None or t.numel() < numel:
+            if self.plan is not None and t is not None and not self.record_only:
+                raise RuntimeError("scratch '%s' must not grow while a plan is recording" % name)
+            t = torch.empty(int(numel), dtype=dtype, device=self.device)
+            self._scratch[key] = t
+        self._keep(t)
+        return t
+
+    def reserve_scratch(self, raw_elems, stats_elems):
+        self.scratch("raw", raw_elems)
+        self.scratch("stats", stats_elems)
+
+    def _keep(self, t):
+        if self.plan is not None:
+            self.plan.keep.append(t)
+
+    def label(self, text):
+        if self.plan is not None:
+            self.plan.label(text)
+
+    def grid(self, H, W):
+        """Base sampling grid of get_grid (models/networks.py:79-93): torch.linspace(-1,1,n)."""
+        key = (H, W)
+        if key not in self._grids:
+            gx = torch.linspace(-1.0, 1.0, W).to(self.device)
+            gy = torch.linspace(-1.0, 1.0, H).to(self.device)
+            self._grids[key] = (gx, gy)
+        return self._grids[key]
+
+    # ---------------- weights ----------------
+    def packed(self, mod, cin_stride):
+        key = (id(mod), cin_stride)
+        pc = self._packed.get(key)
+        if pc is None:
+            pc = PackedConv(self, mod, cin_stride)
+            self._packed[key] = pc
+        return pc
+
+    def refresh_weights(self, force=False):
+        for pc in self._packed.values():
+            pc.refresh(force)
+
+    # ---------------- primitive emitters ----------------
+    def conv(self, x, mod, pad_mode=L.PAD_ZERO, pad_override=None, out_mode=L.OUT_RAW_F32_NHWC,
+             act=L.ACT_NONE, act_param=0.0, out_scale=1.0, want_stats=False, out=None, label=""):
+        """Emit one convolution.  Returns (out, stats_rows, (N,OH,OW))."""
+        pc = self.packed(mod, x.Cs)
+        pad = pc.pad if pad_override is None else pad_override
+        N, H, W = x.N, x.H, x.W
+        if pc.transposed:
+            OH, OW = 2 * H, 2 * W
+        else:
+            OH = (H + 2 * pad - pc.KH) // pc.stride + 1
+            OW = (W + 2 * pad - pc.KW) // pc.stride + 1
+        d = ConvDesc()
+        d.in_ = x.t.data_ptr(); d.w = pc.buf.data_ptr()
+        d.bias = None if pc.bias is None else pc.bias.data_ptr()
+        d.N, d.H, d.W = N, H, W
+        d.cin, d.cin_stride, d.cout = pc.cin, x.Cs, pc.cout
+        d.KH, d.KW, d.stride, d.pad, d.pad_mode = pc.KH, pc.KW, pc.stride, pad, pad_mode
+        d.transposed = int(pc.transposed)
+        d.OH, d.OW = OH, OW
+        d.dtype, d.out_mode, d.act = self.dtype, out_mode, act
+        d.act_param, d.out_scale = act_param, out_scale
+        d.tile = self.tile_override.get((pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed)), 0)
+        if pc.cin != x.C:
+            raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
+        if out_mode == L.OUT_RAW_F32_NHWC:
+            cs = (pc.cout + 3) // 4 * 4
+            d.cout_stride = cs
+            if out is None:
+                out = self.scratch("raw", N * OH * OW * cs)
+            d.out = out.data_ptr()
+        elif out_mode == L.OUT_ACT_NHWC:
+            if out is None:
+                out = self.empty_act(N, OH, OW, pc.cout)
+                if out.Cs != pc.cout:
+                    out.t.zero_()          # padded channels must read as zero downstream
+            d.cout_stride = out.Cs
+            d.out = out.t.data_ptr()
+        else:
+            if out is None:
+                out = self.empty_f32(N, pc.cout, OH, OW)
+            d.cout_stride = pc.cout
+            d.out = out.data_ptr()
+        rows = 0
+        if want_stats:
+            d.stats = None
+            rows = lib.v2v_conv_stats_rows(C.byref(d))
+            if rows <= 0:
+                check(rows or -1, "conv_stats_rows")
+            st = self.scratch("stats", rows * pc.cout * 2)
+            d.stats = st.data_ptr()
+        self._keep(pc.buf)
+        if pc.bias is not None:
+            self._keep(pc.bias)
+        check(lib.v2v_conv2d(C.byref(d), _stream()), "conv2d " + label)
+        self.label(label)
+        ntaps = pc.KH * pc.KW
+        self.conv_log.append(dict(label=label, N=N, H=H, W=W, OH=OH, OW=OW, cin=pc.cin, cout=pc.cout,
+                                  KH=pc.KH, KW=pc.KW, stride=pc.stride, transposed=pc.transposed,
+                                  flops=2.0 * N * (H * W if pc.transposed else OH * OW) * pc.cout * pc.cin * ntaps,
+                                  tile=lib.v2v_conv_tile_config(C.byref(d))))
+        return out, rows, (N, OH, OW)
+
+    def norm_apply(self, raw, rows, shape, cout, norm, act, act_param, add0=None, add1=None, label=""):
+        """bn_finalize + bn_apply on the shared raw/statistics scratch."""
+        N, OH, OW = shape
+        cs_raw = (cout + 3) // 4 * 4
+        if isinstance(norm, nn.BatchNorm2d):
+            gamma = norm.weight.detach() if norm.affine else None
+            beta = norm.bias.detach() if norm.affine else None
+            eps, mom = norm.eps, (norm.momentum if norm.momentum is not None else 0.1)
+            rm = norm.running_mean if (self.update_running_stats and norm.track_running_stats) else None
+            rv = norm.running_var if (self.update_running_stats and norm.track_running_stats) else None
+        elif isinstance(norm, nn.InstanceNorm2d):
+            if N != 1:
+                raise NotImplementedError("InstanceNorm2d path supports batch 1 (per-sample statistics)")
+            gamma = norm.weight.detach() if norm.affine else None
+            beta = norm.bias.detach() if norm.affine else None
+            eps, mom, rm, rv = norm.eps, 0.1, None, None
+        else:
+            raise NotImplementedError("norm layer %r" % type(norm))
+        ss = self.scratch("scale_shift", 2 * cout)
+        st = self.scratch("stats", rows * cout * 2)
+        for t in (gamma, beta):
+            if t is not None:
+                self._keep(t)
+        check(lib.v2v_bn_finalize(_ptr(st), rows, cout, N * OH * OW, _ptr(gamma), _ptr(beta), eps,
+                                  _ptr(ss), _ptr(rm), _ptr(rv), mom, _stream()), "bn_finalize " + label)
+        self.label(label + ".norm")
+        y = self.empty_act(N, OH, OW, cout)
+        check(lib.v2v_bn_apply(_ptr(raw), cs_raw, _ptr(ss),
+                               _ptr(None if add0 is None else add0.t), _ptr(None if add1 is None else add1.t),
+                               _ptr(y.t), N * OH * OW, cout, y.Cs, act, act_param, self.dtype, _stream()),
+              "bn_apply " + label)
+        self.label(label + ".apply")
+        return y
+
+    # ---------------- nn.Sequential lowering ----------------
+    @staticmethod
+    def _act_code(m):
+        if isinstance(m, nn.ReLU): return L.ACT_RELU, 0.0
+        if isinstance(m, nn.LeakyReLU): return L.ACT_LEAKY, float(m.negative_slope)
+        if isinstance(m, nn.Tanh): return L.ACT_TANH, 0.0
+        if isinstance(m, nn.Sigmoid): return L.ACT_SIGMOID, 0.0
+        return None
+
+    def run_sequential(self, seq, x, extra_add=None, head_nchw=False, out_scale=1.0, name="", collect=None):
+        """Run an nn.Sequential (or list of modules) on Act `x`.
+
+        extra_add: Act added to the output of the LAST stage (tower sums, coarse features).
+        head_nchw: the last conv writes planar fp32 NCHW (API-facing heads).
+        collect:   optional list receiving the output of every top-level module group
+                   (MultiscaleDiscriminator.getIntermFeat).
+        """
+        mods = list(seq)
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            last_group = False
+            if isinstance(m, (nn.ReflectionPad2d, nn.Conv2d, nn.ConvTranspose2d)):
+                pad_mode, pad_override = L.PAD_ZERO, None
+                if isinstance(m, nn.ReflectionPad2d):
+                    pad_mode, pad_override = L.PAD_REFLECT, int(m.padding[0])
+                    i += 1
+                    m = mods[i]
+                    if not isinstance(m, nn.Conv2d) or m.padding[0] != 0:
+                        raise NotImplementedError("ReflectionPad2d must be followed by an unpadded Conv2d")
+                conv = m
+                i += 1
+                norm = None
+                if i < n and isinstance(mods[i], (nn.BatchNorm2d, nn.InstanceNorm2d)):
+                    norm = mods[i]; i += 1
+                act, act_param = L.ACT_NONE, 0.0
+                if i < n and self._act_code(mods[i]) is not None:
+                    act, act_param = self._act_code(mods[i]); i += 1
+                last_group = i >= n
+                lbl = "%s.%d" % (name, i)
+                if norm is not None:
+                    raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC,
+                                               want_stats=True, label=lbl)
+                    x = self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param,
+                                        add0=extra_add if last_group else None, label=lbl)
+                    if last_group:
+                        extra_add = None
+                elif head_nchw and last_group:
+                    out, _, _ = self.conv(x, conv, pad_mode, pad_override, L.OUT_F32_NCHW, act, act_param,
+                                          out_scale, label=lbl)
+                    return out
+                else:
+                    out, _, _ = self.conv(x, conv, pad_mode, pad_override, L.OUT_ACT_NHWC, act, act_param,
+                                          1.0, label=lbl)
+                    x = out
+            elif hasattr(m, "conv_block"):      # ResnetBlock (models/networks.py:554-593)
+                i += 1
+                last_group = i >= n
+                x = self.run_resblock(m, x, extra_add if last_group else None, "%s.%d" % (name, i - 1))
+                if last_group:
+                    extra_add = None
+            elif isinstance(m, nn.Sequential):
+                i += 1
+                x = self.run_sequential(m, x, name="%s.%d" % (name, i - 1))
+            elif isinstance(m, nn.Dropout):
+                raise NotImplementedError("dropout is never enabled on the vid2vid path")
+            else:
+                raise NotImplementedError("module %r in %s" % (type(m), name))
+            if collect is not None:
+                collect.append(x)
+        if extra_add is not None:
+            x = self.add(x, extra_add)
+        return x
+
+    def run_resblock(self, blk, x, extra_add, name):
+        mods = list(blk.conv_block)
+        # [pad, conv, norm, act, pad, conv, norm]   (reflect) -- zero padding variant has no pad modules
+        def take(j):
+            pad_mode, pad_override = L.PAD_ZERO, None
+            if isinstance(mods[j], nn.ReflectionPad2d):
+                pad_mode, pad_override = L.PAD_REFLECT, int(mods[j].padding[0]); j += 1
+            elif isinstance(mods[j], nn.ReplicationPad2d):
+                raise NotImplementedError("replicate padding is not used by vid2vid")
+            conv = mods[j]; norm = mods[j + 1]
+            return pad_mode, pad_override, conv, norm, j + 2
+        pm, po, conv1, norm1, j = take(0)
+        act, act_param = self._act_code(mods[j]); j += 1
+        raw, rows, shp = self.conv(x, conv1, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, label=name + ".c1")
+        h = self.norm_apply(raw, rows, shp, conv1.out_channels, norm1, act, act_param, label=name + ".c1")
+        pm, po, conv2, norm2, j = take(j)
+        raw, rows, shp = self.conv(h, conv2, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, label=name + ".c2")
+        return self.norm_apply(raw, rows, shp, conv2.out_channels, norm2, L.ACT_NONE, 0.0,
+                               add0=x, add1=extra_add, label=name + ".c2")
+
+    # ---------------- other ops ----------------
+    def add(self, a, b):
+        if a.t.shape != b.t.shape:
+            raise RuntimeError("add: shape mismatch %s vs %s" % (tuple(a.t.shape), tuple(b.t.shape)))
+        y = self.empty_act(a.N, a.H, a.W, a.C)
+        check(lib.v2v_add_nhwc(_ptr(a.t), _ptr(b.t), _ptr(y.t), a.t.numel(), self.dtype, _stream()), "add")
+        self.label("add_nhwc")
+        return y
+
+    def fg_mask(self, x, base_ch, fg_labels):
+        mask = self.empty_f32(x.N, 1, x.H, x.W)
+        fg = torch.tensor(list(fg_labels), dtype=torch.int32, device=self.device)
+        self._keep(fg)
+        check(lib.v2v_fg_mask_nhwc(_ptr(x.t), _ptr(mask), x.N * x.H * x.W, x.Cs, base_ch, _ptr(fg), fg.numel(),
+                                   self.dtype, _stream()), "fg_mask")
+        self.label("fg_mask_nhwc")
+        return mask
+
+    def memcpy(self, dst, src, nbytes):
+        check(lib.v2v_memcpy_d2d(_ptr(dst), _ptr(src), nbytes, _stream()), "memcpy_d2d")
+        self.label("memcpy_d2d")
+
+    def encode_labels(self, labels, inst, T, H, W, label_nc, fg_labels, want_mask):
+        per = label_nc + (1 if inst is not None else 0)
+        out = self.empty_act(1, H, W, T * per)
+        mask = self.empty_f32(1, 1, H, W) if want_mask else None
+        fg = None
+        if want_mask:
+            fg = torch.tensor(list(fg_labels), dtype=torch.int32, device=self.device)
+            self._keep(fg)
+        check(lib.v2v_encode_labels(_ptr(labels), _ptr(inst), _ptr(out.t), _ptr(mask), T, H, W, label_nc,
+                                    out.Cs, _ptr(fg), 0 if fg is None else fg.numel(), self.dtype, _stream()),
+              "encode_labels")
+        self.label("encode_labels")
+        return out, mask
+
+    def pack(self, x_nchw):
+        N, Cc, H, W = x_nchw.shape
+        out = self.empty_act(N, H, W, Cc)
+        check(lib.v2v_pack_nchw_to_nhwc(_ptr(x_nchw), _ptr(out.t), N, Cc, H, W, out.Cs, self.dtype, _stream()), "pack")
+        self.label("pack_nchw_to_nhwc")
+        return out
+
+    def unpack(self, x):
+        out = self.empty_f32(x.N, x.C, x.H, x.W)
+        check(lib.v2v_unpack_nhwc_to_nchw(_ptr(x.t), _ptr(out), x.N, x.C, x.H, x.W, x.Cs, self.dtype, _stream()), "unpack")
+        self.label("unpack_nhwc_to_nchw")
+        return out
+
+    def avgpool_nhwc(self, x):
+        OH, OW = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+        out = self.empty_act(x.N, OH, OW, x.C)
+        check(lib.v2v_avgpool3s2_nhwc(_ptr(x.t), _ptr(out.t), x.N, x.H, x.W, x.Cs, self.dtype, _stream()), "avgpool_nhwc")
+        self.label("avgpool3s2_nhwc")
+        return out
+
+    def avgpool_planar(self, x):
+        """x: fp32 [..., H, W] contiguous -> [..., OH, OW]"""
+        H, W = x.shape[-2], x.shape[-1]
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        planes = x.numel() // (H * W)
+        out = self.empty_f32(*x.shape[:-2], OH, OW)
+        check(lib.v2v_avgpool3s2_planar(_ptr(x), _ptr(out), planes, H, W, _stream()), "avgpool_planar")
+        self.label("avgpool3s2_planar")
+        return out
+
+    def warp_blend(self, img_raw, flow, weight, prev, fg, mask, want_warp=False):
+        N, Cc, H, W = img_raw.shape
+        gx, gy = self.grid(H, W)
+        final = self.empty_f32(N, Cc, H, W)
+        warp = self.empty_f32(N, Cc, H, W) if (want_warp and flow is not None) else None
+        for t in (gx, gy):
+            self._keep(t)
+        check(lib.v2v_warp_blend(_ptr(img_raw), _ptr(flow), _ptr(weight), _ptr(prev), _ptr(fg), _ptr(mask),
+                                 _ptr(final), _ptr(warp), _ptr(gx), _ptr(gy), N, Cc, H, W,
+                                 int(self.align_corners), _stream()), "warp_blend")
+        self.label("warp_blend")
+        return final, warp
+
+    def resample_flow(self, img, flow):
+        N, Cc, H, W = img.shape
+        gx, gy = self.grid(H, W)
+        out = self.empty_f32(N, Cc, H, W)
+        check(lib.v2v_resample_flow(_ptr(img), _ptr(flow), _ptr(out), _ptr(gx), _ptr(gy), N, Cc, H, W,
+                                    int(self.align_corners), _stream()), "resample_flow")
+        self.label("resample_flow")
+        return out

@@ -1,0 +1,105 @@
+"""ctypes binding of libv2v_hip.so (C ABI declared in include/v2v_hip.h).
+
+The library is the product; this module is plumbing.  There is NO fallback: if the shared
+object is missing or a symbol cannot be resolved the import fails loudly, and every
+non-zero return code becomes a RuntimeError carrying v2v_last_error() -- the same contract
+the reference's pybind11 ops have (correlation_cuda.cc:81-83 -> AT_ERROR -> RuntimeError).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libv2v_hip.so")
+
+# dtype / mode codes (include/v2v_hip.h)
+F32, BF16 = 0, 1
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+OUT_RAW_F32_NHWC, OUT_ACT_NHWC, OUT_F32_NCHW = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    """struct v2v_conv_desc"""
+    _fields_ = [
+        ("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("cin", C.c_int32), ("cin_stride", C.c_int32),
+        ("cout", C.c_int32), ("cout_stride", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("pad_mode", C.c_int32),
+        ("transposed", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32),
+        ("dtype", C.c_int32), ("out_mode", C.c_int32), ("act", C.c_int32),
+        ("act_param", C.c_float), ("out_scale", C.c_float),
+        ("tile", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/v2v_hip.h one to one
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+PROTOTYPES = {
+    "v2v_conv_packed_elems": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "v2v_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_conv_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "v2v_conv_tile_config": (C.c_int, [C.POINTER(ConvDesc)]),
+    "v2v_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
+    "v2v_bn_finalize": (C.c_int, [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P, _F, _P]),
+    "v2v_bn_apply": (C.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
+    "v2v_avgpool3s2_planar": (C.c_int, [_P, _P, _L, _I, _I, _P]),
+    "v2v_avgpool3s2_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_encode_labels": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "v2v_fg_mask_nhwc": (C.c_int, [_P, _P, _L, _I, _I, _P, _I, _I, _P]),
+    "v2v_pack_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_unpack_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_add_nhwc": (C.c_int, [_P, _P, _P, _L, _I, _P]),
+    "v2v_warp_blend": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_resample_flow": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_correlation_out_size": (C.c_int, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "v2v_correlation_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_resample2d_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_channelnorm_forward": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_plan_create": (_P, []),
+    "v2v_plan_destroy": (None, [_P]),
+    "v2v_plan_begin_record": (C.c_int, [_P]),
+    "v2v_plan_end_record": (C.c_int, [_P]),
+    "v2v_plan_num_ops": (C.c_int, [_P]),
+    "v2v_plan_run": (C.c_int, [_P, _P]),
+    "v2v_plan_instantiate_graph": (C.c_int, [_P, _P]),
+    "v2v_plan_launch_graph": (C.c_int, [_P, _P]),
+    "v2v_plan_profile": (C.c_int, [_P, _P, C.POINTER(C.c_float), _I]),
+    "v2v_plan_op_name": (C.c_char_p, [_P, _I]),
+    "v2v_plan_set_label": (C.c_int, [_P, C.c_char_p]),
+    "v2v_plan_op_label": (C.c_char_p, [_P, _I]),
+    "v2v_memcpy_d2d": (C.c_int, [_P, _P, _L, _P]),
+    "v2v_version": (C.c_int, []),
+    "v2v_last_error": (C.c_char_p, []),
+    "v2v_device_info": (C.c_int, [C.POINTER(_I), C.POINTER(_I), C.POINTER(_L), C.c_char_p, _I]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "vid2vid_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C vid2vid_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    """Raise RuntimeError for a non-zero v2v_* return code."""
+    if rc != 0:
+        msg = lib.v2v_last_error()
+        raise RuntimeError("v2v %s failed (code %d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def exported_symbols():
+    return sorted(PROTOTYPES.keys())

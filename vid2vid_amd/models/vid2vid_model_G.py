@@ -1,0 +1,275 @@
+"""Vid2VidModelG on the MI355X backend.
+
+API-compatible with the reference's models/vid2vid_model_G.py: `initialize(opt)`,
+`inference(input_A, input_B, inst_A) -> (fake_B, real_A_last)` with the rolling
+`self.fake_B_prev` state reset by assigning None (test.py:34-35), `forward(...)` for training,
+`compute_mask`, `compute_fake_B_prev`, `save`.
+
+Inference is plan based: the first call at a given resolution lowers the whole per-frame
+computation (input encoding -> label pyramid -> coarse-to-fine generators -> warp/blend ->
+rolling window update; reference :198-229) to a recorded launch sequence over preallocated
+buffers, instantiates it as a hipGraph, and every later frame is: refresh the input buffers,
+one graph launch.  The reference issues ~240 framework ops per frame from Python instead.
+"""
+import torch
+
+from .. import lib as L
+from .. import networks
+from ..engine import Act, Plan
+from .base_model import BaseModel
+
+
+class _FramePlan:
+    """Buffers + launch sequence generating one frame at every spatial scale."""
+
+    def __init__(self, model, H, W, in_ch, has_inst, use_raw_only, use_graph=True):
+        opt, eng = model.opt, model.engine
+        self.model, self.eng = model, eng
+        self.H, self.W, self.use_raw_only = H, W, use_raw_only
+        tG, S = opt.n_frames_G, model.n_scales
+        self.label_mode = opt.label_nc != 0
+        dev = eng.device
+        # ---- static inputs ----
+        if self.label_mode:
+            self.labels = torch.zeros(tG, H, W, dtype=torch.float32, device=dev)
+            self.inst = torch.zeros(tG, H, W, dtype=torch.float32, device=dev) if has_inst else None
+            self.raw_in = None
+        else:
+            self.labels = self.inst = None
+            self.raw_in = torch.zeros(1, tG * in_ch, H, W, dtype=torch.float32, device=dev)
+        # fake_B_prev[si]: (tG-1, 3, h, w) per scale, si = 0 finest  (reference :228, :248-250)
+        self.prev = [torch.zeros(tG - 1, opt.output_nc, H >> si, W >> si, dtype=torch.float32, device=dev)
+                     for si in range(S)]
+        self.out = {}
+        # warm-up pass sizes the shared scratch, then the same code is recorded
+        if not eng.record_only:
+            self._emit()
+            torch.cuda.synchronize(dev)
+        self.plan = Plan()
+        eng.plan = self.plan
+        try:
+            with self.plan:
+                self._emit()
+        finally:
+            eng.plan = None
+        if use_graph and not eng.record_only:
+            self.plan.instantiate_graph()
+
+    def _emit(self):
+        m, eng, opt = self.model, self.eng, self.model.opt
+        tG, S = opt.n_frames_G, m.n_scales
+        H, W = self.H, self.W
+        eng.conv_log = []
+        # encode_input (:86-112) + compute_mask (:322-330), fused, straight to NHWC
+        if self.label_mode:
+            x0, mask0 = eng.encode_labels(self.labels, self.inst, tG, H, W, opt.label_nc, opt.fg_labels, opt.fg)
+        else:
+            x0, mask0 = eng.pack(self.raw_in), None
+        xs, masks = [x0], [mask0]
+        for si in range(1, S):                      # build_pyr of the encoded labels (:205)
+            xs.append(eng.avgpool_nhwc(xs[-1]))
+            masks.append(None)
+        per = x0.C // tG
+        feat = flow_feat = fg_feat = None
+        fake_B = None
+        for s in range(S):                          # coarse -> fine (:207-208)
+            si = S - 1 - s
+            netG = getattr(m, "netG" + str(s))
+            x = xs[si]
+            mask = masks[si]
+            if opt.fg and mask is None:
+                mask = self._mask_from_pooled(x, per, tG)
+            prev_nchw = self.prev[si].view(1, -1, H >> si, W >> si)
+            fake_B, flow, weight, raw, feat, flow_feat, fg_feat = netG.emit(
+                eng, x, eng.pack(prev_nchw), prev_nchw, mask, feat, flow_feat, fg_feat, self.use_raw_only,
+                tag="G%d" % s)
+            # fake_B_prev[si] = cat(prev[1:], fake_B)   (:228)
+            self._roll(self.prev[si], fake_B)
+            self.out["flow%d" % si], self.out["weight%d" % si], self.out["raw%d" % si] = flow, weight, raw
+        self.out["fake_B"] = fake_B
+        # real_A[0][0, -1]: encoded last label frame, returned for visualisation (:209)
+        last = Act(x0.t[..., (tG - 1) * per:], per)
+        self.out["real_A_last"] = eng.unpack(last)[0]
+        self.conv_log = list(eng.conv_log)
+
+    def _roll(self, prev, fake_B):
+        n = prev.shape[0]
+        frame_bytes = prev[0].numel() * 4
+        for k in range(n - 1):
+            self.eng.memcpy(prev[k], prev[k + 1], frame_bytes)
+        self.eng.memcpy(prev[n - 1], fake_B, frame_bytes)
+
+    def _mask_from_pooled(self, x, per, tG):
+        # compute_mask on a pooled (fractional) one-hot pyramid level: clamp(sum of fg channels)
+        return self.eng.fg_mask(x, (tG - 1) * per, self.model.opt.fg_labels)
+
+    def run(self):
+        if self.eng.record_only:
+            return            # CPU dry run: the plan was validated and recorded, nothing can execute
+        self.plan.launch()
+
+
+class Vid2VidModelG(BaseModel):
+    def name(self):
+        return "Vid2VidModelG"
+
+    def initialize(self, opt):
+        BaseModel.initialize(self, opt)
+        self.n_scales = opt.n_scales_spatial
+        self.use_single_G = opt.use_single_G
+        self.split_gpus = (opt.n_gpus_gen < len(opt.gpu_ids)) and (opt.batchSize == 1)
+
+        input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+        netG_input_nc = input_nc * opt.n_frames_G
+        if opt.use_instance:
+            netG_input_nc += opt.n_frames_G
+        prev_output_nc = (opt.n_frames_G - 1) * opt.output_nc
+        if opt.openpose_only:
+            opt.no_flow = True
+        self.netG_input_nc, self.prev_output_nc = netG_input_nc, prev_output_nc
+
+        gpu_ids = self.dev_ids
+        self.netG0 = networks.define_G(netG_input_nc, opt.output_nc, prev_output_nc, opt.ngf, opt.netG,
+                                       opt.n_downsample_G, opt.norm, 0, gpu_ids, opt)
+        for s in range(1, self.n_scales):
+            setattr(self, "netG" + str(s),
+                    networks.define_G(netG_input_nc, opt.output_nc, prev_output_nc, opt.ngf // (2 ** s),
+                                      opt.netG + "Local", opt.n_downsample_G, opt.norm, s, gpu_ids, opt))
+        print("---------- Networks initialized -------------")
+
+        if not self.isTrain or opt.continue_train or opt.load_pretrain:
+            for s in range(self.n_scales):
+                self.load_network(getattr(self, "netG" + str(s)), "G" + str(s), opt.which_epoch, opt.load_pretrain)
+        self.netG_i = self.load_single_G() if self.use_single_G else None
+        self._plans = {}
+
+        if self.isTrain:
+            self.n_gpus = opt.n_gpus_gen if opt.batchSize == 1 else 1
+            self.n_frames_bp = 1
+            self.n_frames_per_gpu = min(opt.max_frames_per_gpu, opt.n_frames_total // self.n_gpus)
+            self.n_frames_load = self.n_gpus * self.n_frames_per_gpu
+            self.old_lr = opt.lr
+            self.finetune_all = opt.niter_fix_global == 0
+            params = list(getattr(self, "netG" + str(self.n_scales - 1)).parameters())
+            if self.finetune_all:
+                for s in range(self.n_scales - 1):
+                    params += list(getattr(self, "netG" + str(s)).parameters())
+            if opt.TTUR:
+                beta1, beta2, lr = 0, 0.9, opt.lr / 2
+            else:
+                beta1, beta2, lr = opt.beta1, 0.999, opt.lr
+            self.optimizer_G = torch.optim.Adam(params, lr=lr, betas=(beta1, beta2))
+
+    # ------------------------------------------------------------------ inference
+    def _frame_plan(self, H, W, in_ch, has_inst, use_raw_only):
+        key = (H, W, in_ch, has_inst, use_raw_only, self.precision)
+        fp = self._plans.get(key)
+        if fp is None:
+            self.engine.refresh_weights()
+            fp = _FramePlan(self, H, W, in_ch, has_inst, use_raw_only,
+                            use_graph=getattr(self.opt, "use_graph", True))
+            self._plans[key] = fp
+        return fp
+
+    def inference(self, input_A, input_B, inst_A):
+        """(fake_B (1,3,H,W), real_A_last (C,H,W)) for the newest of the tG label frames in input_A."""
+        opt = self.opt
+        tG = opt.n_frames_G
+        with torch.no_grad():
+            _, t_in, in_ch, H, W = input_A.shape
+            if t_in < tG:
+                raise ValueError("inference needs n_frames_G=%d label frames, got %d" % (tG, t_in))
+            self.is_first_frame = not hasattr(self, "fake_B_prev") or self.fake_B_prev is None
+            use_raw_only = bool(opt.no_first_img and self.is_first_frame)
+            has_inst = bool(opt.use_instance and inst_A is not None and opt.label_nc != 0)
+            fp = self._frame_plan(H, W, in_ch, has_inst, use_raw_only)
+            dev = self.device
+            # ---- stage inputs (H2D or D2D) into the plan's static buffers ----
+            if fp.label_mode:
+                fp.labels.copy_(input_A[0, :tG, 0].to(dev, torch.float32, non_blocking=True))
+                if has_inst:
+                    fp.inst.copy_(inst_A[0, :tG, 0].to(dev, torch.float32, non_blocking=True))
+            else:
+                fp.raw_in.copy_(input_A[0, :tG].reshape(1, tG * in_ch, H, W).to(dev, torch.float32, non_blocking=True))
+            if self.is_first_frame:
+                first = self.generate_first_frame(input_A, input_B, inst_A)     # list per scale (tG-1,3,h,w)
+                for si in range(self.n_scales):
+                    fp.prev[si].copy_(first[si])
+            elif self._active_plan is not fp:
+                for si in range(self.n_scales):                                  # e.g. first-frame plan -> steady plan
+                    fp.prev[si].copy_(self._active_plan.prev[si])
+            self._active_plan = fp
+            self.fake_B_prev = fp.prev
+            fp.run()
+            return fp.out["fake_B"], fp.out["real_A_last"]
+
+    def generate_first_frame(self, input_A, input_B, inst_A=None):
+        """Pyramid of the tG-1 frames that precede the first generated one (reference :231-251)."""
+        opt = self.opt
+        tG = opt.n_frames_G
+        _, _, _, H, W = input_A.shape
+        dev = self.device
+        if opt.no_first_img:
+            first = torch.zeros(1, tG - 1, opt.output_nc, H, W, dtype=torch.float32, device=dev)
+        elif opt.isTrain or opt.use_real_img:
+            if input_B is None:
+                raise ValueError("use_real_img needs the first real frames (input_B)")
+            first = input_B[:, :tG - 1].to(dev, torch.float32)
+        elif opt.use_single_G:
+            frames = []
+            lab = input_A[0, :, 0].to(dev, torch.float32).contiguous()
+            eng = self.engine
+            for i in range(tG - 1):       # one-hot labels only, no edge channel (reference :239-244)
+                onehot, _ = eng.encode_labels(lab[i:i + 1], None, 1, H, W, opt.label_nc, (), False)
+                frames.append(self.netG_i.emit(eng, onehot).unsqueeze(1))
+            first = torch.cat(frames, dim=1)
+        else:
+            raise ValueError("Please specify the method for generating the first frame")
+        pyr = self.build_pyr(first.contiguous())
+        return [p[0] for p in pyr]
+
+    def load_single_G(self):
+        """First-frame single-image generator (reference :261-288).  Only the Cityscapes nets are on
+        the hot path; their checkpoints are external downloads, so a missing file is an error unless
+        opt.random_init_ok."""
+        import os
+        opt = self.opt
+        gpu_ids = self.dev_ids
+        if "City" in opt.dataroot:
+            base = "checkpoints/label2city_single/"
+            if opt.loadSize == 512:
+                path, netG = base + "latest_net_G_512.pth", networks.define_G(35, 3, 0, 64, "global", 3, "instance", 0, gpu_ids, opt)
+            elif opt.loadSize == 1024:
+                path, netG = base + "latest_net_G_1024.pth", networks.define_G(35, 3, 0, 64, "global", 4, "instance", 0, gpu_ids, opt)
+            elif opt.loadSize == 2048:
+                path, netG = base + "latest_net_G_2048.pth", networks.define_G(35, 3, 0, 32, "local", 4, "instance", 0, gpu_ids, opt)
+            else:
+                raise ValueError("Single image generator does not exist")
+        else:
+            raise ValueError("Single image generator does not exist")
+        if os.path.isfile(path):
+            netG.load_state_dict(torch.load(path, map_location="cpu"))
+        elif not getattr(opt, "random_init_ok", False):
+            raise RuntimeError("%s not found" % path)
+        return netG
+
+    # ------------------------------------------------------------------ helpers used by train.py
+    def compute_mask(self, real_As, ts, te=None):
+        if te is None:
+            te = ts + 1
+        mask_F = real_As[:, ts:te, self.opt.fg_labels[0]].clone()
+        for i in range(1, len(self.opt.fg_labels)):
+            mask_F = mask_F + real_As[:, ts:te, self.opt.fg_labels[i]]
+        return torch.clamp(mask_F, 0, 1)
+
+    def compute_fake_B_prev(self, real_B_prev, fake_B_last, fake_B):
+        fake_B_prev = real_B_prev[:, 0:1] if fake_B_last is None else fake_B_last[0][:, -1:]
+        if fake_B.size()[1] > 1:
+            fake_B_prev = torch.cat([fake_B_prev, fake_B[:, :-1].detach()], dim=1)
+        return fake_B_prev
+
+    def save(self, label):
+        for s in range(self.n_scales):
+            self.save_network(getattr(self, "netG" + str(s)), "G" + str(s), label, self.gpu_ids)
+
+    _active_plan = None

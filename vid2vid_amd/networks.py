@@ -1,0 +1,537 @@
+"""vid2vid network zoo on the MI355X backend.
+
+Drop-in for the reference's models/networks.py: same factory functions (`define_G`,
+`define_D`), same class names and constructor signatures, and -- because checkpoints are
+the on-disk contract (models/base_model.py:43-107) -- the same parameter names and shapes:
+every network is assembled from the same nn.Sequential index layout as the reference
+(models/networks.py:117-201, :234-294, :327-353, :361-400, :554-589, :634-715), with
+torch.nn modules used purely as parameter containers.  Module creation order also follows
+the reference so that a seeded construction draws identical initial weights.
+
+`forward()` never runs torch.nn compute: it lowers the module lists to libv2v_hip.so
+launches through `engine.Engine` (implicit-GEMM MFMA convolutions with fused padding,
+training-mode norm, activations, residuals; fused warp-and-blend tail).
+"""
+import copy
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .engine import Engine, Act
+
+
+# --------------------------------------------------------------------------------------
+# engine registry: one Engine per (device, precision)
+# --------------------------------------------------------------------------------------
+_PRECISION = {"value": L.F32}
+_ALIGN_CORNERS = {"value": False}   # oracle in this container: torch>=1.3 default
+_ENGINES = {}
+
+
+def set_precision(p):
+    """'fp32' (exact fp32 MFMA, parity path) or 'bf16' (throughput path)."""
+    _PRECISION["value"] = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16}[p]
+
+
+def get_precision():
+    return "bf16" if _PRECISION["value"] == L.BF16 else "fp32"
+
+
+def set_align_corners(flag):
+    """grid_sample convention: False = current torch default (what the reference executes
+    under torch>=1.3), True = PyTorch-0.4 behaviour the checkpoints were trained with."""
+    _ALIGN_CORNERS["value"] = bool(flag)
+
+
+_RECORD_ONLY = {"value": False}
+
+
+def set_record_only(flag):
+    """CPU dry-run mode for the test-suite: engines on a CPU device may RECORD plans (argument
+    validation, layer census) but can never execute anything.  Not a compute fallback."""
+    _RECORD_ONLY["value"] = bool(flag)
+
+
+def get_engine(device=None, precision=None):
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    prec = _PRECISION["value"] if precision is None else precision
+    key = (str(device), prec, _ALIGN_CORNERS["value"])
+    if key not in _ENGINES:
+        _ENGINES[key] = Engine(device, prec, _ALIGN_CORNERS["value"],
+                               record_only=_RECORD_ONLY["value"] and device.type == "cpu")
+    return _ENGINES[key]
+
+
+# --------------------------------------------------------------------------------------
+# init / factories  (models/networks.py:15-68)
+# --------------------------------------------------------------------------------------
+def weights_init(m):
+    kind = type(m).__name__
+    if "Conv" in kind and hasattr(m, "weight"):
+        m.weight.data.normal_(0.0, 0.02)
+    elif "BatchNorm2d" in kind:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+def get_norm_layer(norm_type="instance"):
+    if norm_type == "batch":
+        return functools.partial(nn.BatchNorm2d, affine=True)
+    if norm_type == "instance":
+        return functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=True)
+    raise NotImplementedError("normalization layer [%s] is not found" % norm_type)
+
+
+def define_G(input_nc, output_nc, prev_output_nc, ngf, which_model_netG, n_downsampling, norm, scale,
+             gpu_ids=[], opt=[]):
+    norm_layer = get_norm_layer(norm_type=norm)
+    if which_model_netG == "global":
+        netG = GlobalGenerator(input_nc, output_nc, ngf, n_downsampling, opt.n_blocks, norm_layer)
+    elif which_model_netG == "local":
+        netG = LocalEnhancer(input_nc, output_nc, ngf, n_downsampling, opt.n_blocks, opt.n_local_enhancers,
+                             opt.n_blocks_local, norm_layer)
+    elif which_model_netG == "composite":
+        netG = CompositeGenerator(opt, input_nc, output_nc, prev_output_nc, ngf, n_downsampling, opt.n_blocks,
+                                  opt.fg, opt.no_flow, norm_layer)
+    elif which_model_netG == "compositeLocal":
+        netG = CompositeLocalGenerator(opt, input_nc, output_nc, prev_output_nc, ngf, n_downsampling,
+                                       opt.n_blocks_local, opt.fg, opt.no_flow, norm_layer, scale=scale)
+    elif which_model_netG in ("global_with_features", "local_with_features", "encoder"):
+        # face first-frame generators: SURVEY.md section 8(f) rank 3 -- out of the hot path
+        raise NotImplementedError("generator [%s] is outside the MI355X hot path (SURVEY 8f)" % which_model_netG)
+    else:
+        raise NotImplementedError("Generator model name [%s] is not recognized" % which_model_netG)
+    if len(gpu_ids) > 0 and gpu_ids[0] >= 0:
+        netG.cuda(gpu_ids[0])
+    netG.apply(weights_init)
+    return netG
+
+
+def define_D(input_nc, ndf, n_layers_D, norm="instance", num_D=1, getIntermFeat=False, gpu_ids=[]):
+    norm_layer = get_norm_layer(norm_type=norm)
+    netD = MultiscaleDiscriminator(input_nc, ndf, n_layers_D, norm_layer, num_D, getIntermFeat)
+    if len(gpu_ids) > 0 and gpu_ids[0] >= 0:
+        netD.cuda(gpu_ids[0])
+    netD.apply(weights_init)
+    return netD
+
+
+def print_network(net):
+    if isinstance(net, list):
+        net = net[0]
+    print(net)
+    print("Total number of parameters: %d" % sum(p.numel() for p in net.parameters()))
+
+
+# --------------------------------------------------------------------------------------
+# layer-list builders (index layout == reference's, which fixes the state_dict keys)
+# --------------------------------------------------------------------------------------
+def _stem7(cin, cout, norm_layer):
+    return [nn.ReflectionPad2d(3), nn.Conv2d(cin, cout, kernel_size=7, padding=0), norm_layer(cout), nn.ReLU(True)]
+
+
+def _down3(cin, cout, norm_layer):
+    return [nn.Conv2d(cin, cout, kernel_size=3, stride=2, padding=1), norm_layer(cout), nn.ReLU(True)]
+
+
+def _up3(cin, cout, norm_layer):
+    return [nn.ConvTranspose2d(cin, cout, kernel_size=3, stride=2, padding=1, output_padding=1),
+            norm_layer(cout), nn.ReLU(True)]
+
+
+def _head7(cin, cout, final_act=None):
+    mods = [nn.ReflectionPad2d(3), nn.Conv2d(cin, cout, kernel_size=7, padding=0)]
+    if final_act is not None:
+        mods.append(final_act)
+    return mods
+
+
+class ResnetBlock(nn.Module):
+    """x + norm(conv3(pad(act(norm(conv3(pad(x)))))))   (models/networks.py:554-593)"""
+
+    def __init__(self, dim, padding_type, norm_layer, activation=nn.ReLU(True), use_dropout=False):
+        super().__init__()
+        if use_dropout:
+            raise NotImplementedError("dropout is never enabled by vid2vid")
+        if padding_type not in ("reflect", "zero"):
+            raise NotImplementedError("padding [%s] is not implemented" % padding_type)
+        p = 1 if padding_type == "zero" else 0
+        blk = []
+        for half in range(2):
+            if padding_type == "reflect":
+                blk.append(nn.ReflectionPad2d(1))
+            blk += [nn.Conv2d(dim, dim, kernel_size=3, padding=p), norm_layer(dim)]
+            if half == 0:
+                blk.append(activation)
+        self.conv_block = nn.Sequential(*blk)
+
+    def forward(self, x):
+        eng = get_engine(x.device)
+        a = eng.pack(x.contiguous().float())
+        return eng.unpack(eng.run_resblock(self, a, None, "resblock"))
+
+
+class BaseNetwork(nn.Module):
+    def _engine(self, ref):
+        dev = ref.t.device if isinstance(ref, Act) else ref.device
+        return get_engine(dev)
+
+    @staticmethod
+    def _as_act(eng, x):
+        if x is None or isinstance(x, Act):
+            return x
+        return eng.pack(x.contiguous().float())
+
+    def resample(self, image, flow):
+        """BaseNetwork.resample (models/networks.py:108-115) on planar fp32 tensors."""
+        eng = get_engine(image.device)
+        return eng.resample_flow(image.contiguous().float(), flow.contiguous().float())
+
+    def _tail(self, eng, img_raw, flow, weight, img_prev_nchw, img_fg, mask, use_raw_only):
+        """models/networks.py:215-230 / :309-323 as one fused launch."""
+        do_warp = not (use_raw_only or self.no_flow)
+        if not do_warp and img_fg is None:
+            return img_raw, img_raw
+        prev3 = img_prev_nchw[:, -3:].contiguous() if do_warp else None
+        if mask is not None:
+            mask = mask.contiguous().float()
+        final, _ = eng.warp_blend(img_raw, flow if do_warp else None, weight if do_warp else None, prev3,
+                                  img_fg, mask if img_fg is not None else None)
+        return final, img_raw
+
+
+class CompositeGenerator(BaseNetwork):
+    """Coarsest-scale generator (models/networks.py:117-232)."""
+
+    def __init__(self, opt, input_nc, output_nc, prev_output_nc, ngf, n_downsampling, n_blocks, use_fg_model=False,
+                 no_flow=False, norm_layer=nn.BatchNorm2d, padding_type="reflect"):
+        assert n_blocks >= 0
+        super().__init__()
+        self.opt = opt
+        self.n_downsampling = n_downsampling
+        self.use_fg_model = use_fg_model
+        self.no_flow = no_flow
+        act = nn.ReLU(True)
+        res = lambda c: ResnetBlock(c, padding_type=padding_type, activation=act, norm_layer=norm_layer)
+
+        if use_fg_model:
+            nf = ngf // 2 if n_downsampling > 2 else ngf
+            indv_down = _stem7(input_nc, nf, norm_layer)
+            indv_down[-1] = act
+            for i in range(n_downsampling):
+                indv_down += _down3(nf * 2 ** i, nf * 2 ** (i + 1), norm_layer)[:2] + [act]
+            indv_res = [res(nf * 2 ** n_downsampling) for _ in range(n_blocks)]
+            indv_up = []
+            for i in range(n_downsampling):
+                m = 2 ** (n_downsampling - i)
+                indv_up += _up3(nf * m, nf * m // 2, norm_layer)[:2] + [act]
+            indv_final = _head7(nf, output_nc, nn.Tanh())
+
+        down_seg = _stem7(input_nc, ngf, norm_layer)
+        down_seg[-1] = act
+        for i in range(n_downsampling):
+            down_seg += _down3(ngf * 2 ** i, ngf * 2 ** (i + 1), norm_layer)[:2] + [act]
+        top = ngf * 2 ** n_downsampling
+        down_seg += [res(top) for _ in range(n_blocks - n_blocks // 2)]
+        down_img = _stem7(prev_output_nc, ngf, norm_layer)
+        down_img[-1] = act
+        down_img += copy.deepcopy(down_seg[4:])
+
+        res_img = [res(top) for _ in range(n_blocks // 2)]
+        if not no_flow:
+            res_flow = copy.deepcopy(res_img)
+        up_img = []
+        for i in range(n_downsampling):
+            m = 2 ** (n_downsampling - i)
+            up_img += _up3(ngf * m, ngf * m // 2, norm_layer)[:2] + [act]
+        final_img = _head7(ngf, output_nc, nn.Tanh())
+        if not no_flow:
+            up_flow = copy.deepcopy(up_img)
+            final_flow = _head7(ngf, 2)
+            final_w = _head7(ngf, 1, nn.Sigmoid())
+
+        if use_fg_model:
+            self.indv_down = nn.Sequential(*indv_down)
+            self.indv_res = nn.Sequential(*indv_res)
+            self.indv_up = nn.Sequential(*indv_up)
+            self.indv_final = nn.Sequential(*indv_final)
+        self.model_down_seg = nn.Sequential(*down_seg)
+        self.model_down_img = nn.Sequential(*down_img)
+        self.model_res_img = nn.Sequential(*res_img)
+        self.model_up_img = nn.Sequential(*up_img)
+        self.model_final_img = nn.Sequential(*final_img)
+        if not no_flow:
+            self.model_res_flow = nn.Sequential(*res_flow)
+            self.model_up_flow = nn.Sequential(*up_flow)
+            self.model_final_flow = nn.Sequential(*final_flow)
+            self.model_final_w = nn.Sequential(*final_w)
+
+    def flow_multiplier(self):
+        return 20.0
+
+    def emit(self, eng, x, prev, img_prev_nchw, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse,
+             use_raw_only, tag="G0"):
+        """x: Act labels (NHWC), prev: Act previous frames (NHWC), img_prev_nchw: fp32 planar."""
+        seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
+        down = eng.run_sequential(self.model_down_img, prev, extra_add=seg, name=tag + ".down_img")
+        img_feat = eng.run_sequential(self.model_up_img,
+                                      eng.run_sequential(self.model_res_img, down, name=tag + ".res_img"),
+                                      name=tag + ".up_img")
+        img_raw = eng.run_sequential(self.model_final_img, img_feat, head_nchw=True, name=tag + ".final_img")
+        flow = weight = flow_feat = None
+        if not self.no_flow:
+            res_flow = eng.run_sequential(self.model_res_flow, down, name=tag + ".res_flow")
+            flow_feat = eng.run_sequential(self.model_up_flow, res_flow, name=tag + ".up_flow")
+            flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
+                                      out_scale=self.flow_multiplier(), name=tag + ".final_flow")
+            weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
+        img_fg = img_fg_feat = None
+        if self.use_fg_model:
+            f = eng.run_sequential(self.indv_down, x, name=tag + ".indv_down")
+            f = eng.run_sequential(self.indv_res, f, name=tag + ".indv_res")
+            img_fg_feat = eng.run_sequential(self.indv_up, f, name=tag + ".indv_up")
+            img_fg = eng.run_sequential(self.indv_final, img_fg_feat, head_nchw=True, name=tag + ".indv_final")
+        img_final, img_raw = self._tail(eng, img_raw, flow, weight, img_prev_nchw, img_fg, mask, use_raw_only)
+        return img_final, flow, weight, img_raw, img_feat, flow_feat, img_fg_feat
+
+    def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
+        """Same signature / return tuple as the reference (models/networks.py:203-232).  `input`,
+        `img_prev`, `mask` are NCHW fp32 device tensors; feature maps are returned as NHWC `Act`
+        handles (they only ever feed the next scale's forward)."""
+        eng = get_engine(input.device)
+        img_prev = img_prev.contiguous().float()
+        return self.emit(eng, self._as_act(eng, input), eng.pack(img_prev), img_prev, mask,
+                         img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only)
+
+
+class CompositeLocalGenerator(BaseNetwork):
+    """Finer-scale generator (models/networks.py:234-325)."""
+
+    def __init__(self, opt, input_nc, output_nc, prev_output_nc, ngf, n_downsampling, n_blocks_local,
+                 use_fg_model=False, no_flow=False, norm_layer=nn.BatchNorm2d, padding_type="reflect", scale=1):
+        super().__init__()
+        self.opt = opt
+        self.use_fg_model = use_fg_model
+        self.no_flow = no_flow
+        self.scale = scale
+        act = nn.ReLU(True)
+        res = lambda c: ResnetBlock(c, padding_type=padding_type, activation=act, norm_layer=norm_layer)
+
+        def stem_down(cin, nf):
+            m = _stem7(cin, nf, norm_layer)
+            m[-1] = act
+            return m + _down3(nf, nf * 2, norm_layer)[:2] + [act]
+
+        if use_fg_model:
+            nf = ngf // 2 if n_downsampling > 2 else ngf
+            indv_down = stem_down(input_nc, nf)
+            indv_up = [res(nf * 2) for _ in range(n_blocks_local)]
+            indv_up += _up3(nf * 2, nf, norm_layer)[:2] + [act]
+            indv_final = _head7(nf, output_nc, nn.Tanh())
+
+        down_seg = stem_down(input_nc, ngf)
+        down_img = stem_down(prev_output_nc, ngf)
+        up_img = [res(ngf * 2) for _ in range(n_blocks_local)]
+        up_img += _up3(ngf * 2, ngf, norm_layer)[:2] + [act]
+        final_img = _head7(ngf, output_nc, nn.Tanh())
+        if not no_flow:
+            up_flow = copy.deepcopy(up_img)
+            final_flow = _head7(ngf, 2)
+            final_w = _head7(ngf, 1, nn.Sigmoid())
+
+        if use_fg_model:
+            self.indv_down = nn.Sequential(*indv_down)
+            self.indv_up = nn.Sequential(*indv_up)
+            self.indv_final = nn.Sequential(*indv_final)
+        self.model_down_seg = nn.Sequential(*down_seg)
+        self.model_down_img = nn.Sequential(*down_img)
+        self.model_up_img = nn.Sequential(*up_img)
+        self.model_final_img = nn.Sequential(*final_img)
+        if not no_flow:
+            self.model_up_flow = nn.Sequential(*up_flow)
+            self.model_final_flow = nn.Sequential(*final_flow)
+            self.model_final_w = nn.Sequential(*final_w)
+
+    def flow_multiplier(self):
+        return 20.0 * (2 ** self.scale)
+
+    def emit(self, eng, x, prev, img_prev_nchw, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse,
+             use_raw_only, tag="G1"):
+        seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
+        down = eng.run_sequential(self.model_down_img, prev, extra_add=seg, name=tag + ".down_img")
+        img_feat = eng.run_sequential(self.model_up_img, eng.add(down, img_feat_coarse), name=tag + ".up_img")
+        img_raw = eng.run_sequential(self.model_final_img, img_feat, head_nchw=True, name=tag + ".final_img")
+        flow = weight = flow_feat = None
+        if not self.no_flow:
+            flow_feat = eng.run_sequential(self.model_up_flow, eng.add(down, flow_feat_coarse), name=tag + ".up_flow")
+            flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
+                                      out_scale=self.flow_multiplier(), name=tag + ".final_flow")
+            weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
+        img_fg = img_fg_feat = None
+        if self.use_fg_model:
+            f = eng.run_sequential(self.indv_down, x, extra_add=img_fg_feat_coarse, name=tag + ".indv_down")
+            img_fg_feat = eng.run_sequential(self.indv_up, f, name=tag + ".indv_up")
+            img_fg = eng.run_sequential(self.indv_final, img_fg_feat, head_nchw=True, name=tag + ".indv_final")
+        img_final, img_raw = self._tail(eng, img_raw, flow, weight, img_prev_nchw, img_fg, mask, use_raw_only)
+        return img_final, flow, weight, img_raw, img_feat, flow_feat, img_fg_feat
+
+    def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
+        eng = get_engine(input.device)
+        img_prev = img_prev.contiguous().float()
+        return self.emit(eng, self._as_act(eng, input), eng.pack(img_prev), img_prev, mask,
+                         img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only)
+
+
+class GlobalGenerator(nn.Module):
+    """pix2pixHD global generator used for the first frame (models/networks.py:327-359)."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, norm_layer=nn.BatchNorm2d,
+                 padding_type="reflect"):
+        assert n_blocks >= 0
+        super().__init__()
+        act = nn.ReLU(True)
+        cap = lambda c: min(1024, c)
+        model = _stem7(input_nc, ngf, norm_layer)
+        model[-1] = act
+        for i in range(n_downsampling):
+            model += _down3(cap(ngf * 2 ** i), cap(ngf * 2 ** (i + 1)), norm_layer)[:2] + [act]
+        top = cap(ngf * 2 ** n_downsampling)
+        model += [ResnetBlock(top, padding_type=padding_type, activation=act, norm_layer=norm_layer)
+                  for _ in range(n_blocks)]
+        for i in range(n_downsampling):
+            m = 2 ** (n_downsampling - i)
+            model += _up3(cap(ngf * m), cap(int(ngf * m / 2)), norm_layer)[:2] + [act]
+        model += _head7(ngf, output_nc, nn.Tanh())
+        self.model = nn.Sequential(*model)
+
+    def emit(self, eng, x):
+        return eng.run_sequential(self.model, x, head_nchw=True, name="Gi")
+
+    def forward(self, input, feat=None):
+        if feat is not None:
+            input = torch.cat([input, feat], dim=1)
+        eng = get_engine(input.device)
+        return self.emit(eng, eng.pack(input.contiguous().float()))
+
+
+class LocalEnhancer(nn.Module):
+    """pix2pixHD local enhancer used for the 2048-wide first frame (models/networks.py:361-419)."""
+
+    def __init__(self, input_nc, output_nc, ngf=32, n_downsample_global=3, n_blocks_global=9, n_local_enhancers=1,
+                 n_blocks_local=3, norm_layer=nn.BatchNorm2d, padding_type="reflect"):
+        super().__init__()
+        self.n_local_enhancers = n_local_enhancers
+        g = GlobalGenerator(input_nc, output_nc, ngf * (2 ** n_local_enhancers), n_downsample_global,
+                            n_blocks_global, norm_layer).model
+        self.model = nn.Sequential(*[g[i] for i in range(len(g) - 3)])     # drop the output head
+        for n in range(1, n_local_enhancers + 1):
+            nf = ngf * (2 ** (n_local_enhancers - n))
+            down = _stem7(input_nc, nf, norm_layer) + _down3(nf, nf * 2, norm_layer)
+            up = [ResnetBlock(nf * 2, padding_type=padding_type, norm_layer=norm_layer) for _ in range(n_blocks_local)]
+            up += _up3(nf * 2, nf, norm_layer)
+            if n == n_local_enhancers:
+                up += _head7(ngf, output_nc, nn.Tanh())
+            setattr(self, "model%d_1" % n, nn.Sequential(*down))
+            setattr(self, "model%d_2" % n, nn.Sequential(*up))
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def forward(self, input, feat_map=None):
+        if feat_map is not None:
+            input = torch.cat([input, feat_map], dim=1)
+        eng = get_engine(input.device)
+        return self.emit(eng, eng.pack(input.contiguous().float()))
+
+    def emit(self, eng, x):
+        pyr = [x]
+        for _ in range(self.n_local_enhancers):
+            pyr.append(eng.avgpool_nhwc(pyr[-1]))
+        out = eng.run_sequential(self.model, pyr[-1], name="Gi.global")
+        for n in range(1, self.n_local_enhancers + 1):
+            last = n == self.n_local_enhancers
+            d = eng.run_sequential(getattr(self, "model%d_1" % n), pyr[self.n_local_enhancers - n], extra_add=out,
+                                   name="Gi.local%d_1" % n)
+            out = eng.run_sequential(getattr(self, "model%d_2" % n), d, head_nchw=last, name="Gi.local%d_2" % n)
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# discriminators (models/networks.py:634-725)
+# --------------------------------------------------------------------------------------
+class NLayerDiscriminator(nn.Module):
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, getIntermFeat=False):
+        super().__init__()
+        self.getIntermFeat = getIntermFeat
+        self.n_layers = n_layers
+        kw = 4
+        padw = int(np.ceil((kw - 1.0) / 2))
+        groups = [[nn.Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=padw), nn.LeakyReLU(0.2, True)]]
+        nf = ndf
+        for n in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            groups.append([nn.Conv2d(nf_prev, nf, kernel_size=kw, stride=2, padding=padw), norm_layer(nf),
+                           nn.LeakyReLU(0.2, True)])
+        nf_prev, nf = nf, min(nf * 2, 512)
+        groups.append([nn.Conv2d(nf_prev, nf, kernel_size=kw, stride=1, padding=padw), norm_layer(nf),
+                       nn.LeakyReLU(0.2, True)])
+        groups.append([nn.Conv2d(nf, 1, kernel_size=kw, stride=1, padding=padw)])
+        if getIntermFeat:
+            for n, g in enumerate(groups):
+                setattr(self, "model" + str(n), nn.Sequential(*g))
+        else:
+            self.model = nn.Sequential(*[m for g in groups for m in g])
+
+    def groups(self):
+        if self.getIntermFeat:
+            return [getattr(self, "model" + str(n)) for n in range(self.n_layers + 2)]
+        return [self.model]
+
+
+class MultiscaleDiscriminator(nn.Module):
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, num_D=3, getIntermFeat=False):
+        super().__init__()
+        self.num_D = num_D
+        self.n_layers = n_layers
+        self.getIntermFeat = getIntermFeat
+        ndf_max = 64
+        for i in range(num_D):
+            netD = NLayerDiscriminator(input_nc, min(ndf_max, ndf * (2 ** (num_D - 1 - i))), n_layers, norm_layer,
+                                       getIntermFeat)
+            if getIntermFeat:
+                for j in range(n_layers + 2):
+                    setattr(self, "scale%d_layer%d" % (i, j), getattr(netD, "model" + str(j)))
+            else:
+                setattr(self, "layer" + str(i), netD.model)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def scale_groups(self, i):
+        if self.getIntermFeat:
+            return [getattr(self, "scale%d_layer%d" % (i, j)) for j in range(self.n_layers + 2)]
+        return [getattr(self, "layer" + str(i))]
+
+    def emit(self, eng, x, tag="D"):
+        """x: Act (NHWC).  Returns list[num_D] of list of Act feature maps (last = prediction)."""
+        result = []
+        cur = x
+        for i in range(self.num_D):
+            feats = []
+            h = cur
+            for j, g in enumerate(self.scale_groups(self.num_D - 1 - i)):
+                h = eng.run_sequential(g, h, name="%s.s%d.l%d" % (tag, self.num_D - 1 - i, j))
+                feats.append(h)
+            result.append(feats)
+            if i != self.num_D - 1:
+                cur = eng.avgpool_nhwc(cur)
+        return result
+
+    def forward(self, input):
+        """NCHW fp32 in; list[num_D] of list of NCHW fp32 feature maps out (reference layout)."""
+        eng = get_engine(input.device)
+        res = self.emit(eng, eng.pack(input.contiguous().float()))
+        return [[eng.unpack(f) for f in feats] for feats in res]
