@@ -1,0 +1,284 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against a plain torch
+fp32 CPU evaluation of the same op.  Tolerances are stated per test:
+  fp32 path: exact-f32 MFMA, only the summation order differs from oneDNN -> 1e-4 (per-pixel,
+             see util.assert_close), well inside the north_star's 1e-3;
+  bf16 path: inputs/weights rounded to bf16 (the CPU reference rounds them the same way), fp32
+             accumulate -> 1e-2 covers the bf16 rounding of the stored output.
+"""
+import itertools
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _engine(prec):
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.engine import Engine
+    return Engine(DEV, L.BF16 if prec == "bf16" else L.F32)
+
+
+def _round(t, prec):
+    return t.bfloat16().float() if prec == "bf16" else t
+
+
+def test_device_is_mi355x():
+    import ctypes as C
+    from vid2vid_amd import lib
+    cus, lds, hbm = C.c_int32(), C.c_int32(), C.c_int64()
+    arch = C.create_string_buffer(64)
+    lib.check(lib.lib.v2v_device_info(C.byref(cus), C.byref(lds), C.byref(hbm), arch, 64), "device_info")
+    print("device:", arch.value.decode(), cus.value, "CUs", lds.value, "B LDS/CU", hbm.value / 2 ** 30, "GiB")
+    assert arch.value.decode().startswith("gfx950")
+    assert cus.value == 256
+
+
+def test_pack_unpack_roundtrip():
+    torch.manual_seed(0)
+    for prec in ("fp32", "bf16"):
+        eng = _engine(prec)
+        x = torch.randn(2, 13, 9, 17)
+        y = eng.unpack(eng.pack(x.to(DEV))).cpu()
+        assert torch.equal(y, _round(x, prec))
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, mode, H, W
+    (16, 32, 3, 1, 1, "reflect", 16, 24),
+    (64, 64, 3, 1, 1, "reflect", 34, 66),
+    (12, 8, 7, 1, 3, "reflect", 20, 28),
+    (6, 16, 7, 1, 3, "reflect", 19, 23),
+    (108, 32, 7, 1, 3, "reflect", 16, 32),
+    (32, 64, 3, 2, 1, "zero", 32, 48),
+    (32, 64, 3, 2, 1, "zero", 31, 45),
+    (13, 16, 4, 2, 2, "zero", 33, 47),
+    (16, 32, 4, 1, 2, "zero", 17, 19),
+    (32, 1, 4, 1, 2, "zero", 18, 22),
+    (128, 3, 7, 1, 3, "reflect", 24, 40),
+    (40, 24, 5, 2, 2, "zero", 30, 42),
+    (24, 16, 1, 1, 0, "zero", 13, 29),
+    (256, 256, 3, 1, 1, "reflect", 16, 32),
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_all_output_modes(case, prec):
+    from vid2vid_amd import lib as L
+    cin, cout, k, stride, pad, mode, H, W = case
+    torch.manual_seed(hash(case) % 1000)
+    eng = _engine(prec)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=0 if mode == "reflect" else pad)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.2)
+        conv.bias.normal_(0, 0.5)
+    x = torch.randn(2, cin, H, W)
+    xr, wr = _round(x, prec), _round(conv.weight.detach(), prec)
+    xp = F.pad(xr, (pad,) * 4, mode="reflect") if mode == "reflect" else xr
+    ref = F.conv2d(xp, wr, conv.bias.detach(), stride=stride, padding=0 if mode == "reflect" else pad)
+    tol = 1e-4 if prec == "fp32" else 1e-2
+    conv = conv.to(DEV)
+    xa = eng.pack(x.to(DEV))
+    pm = L.PAD_REFLECT if mode == "reflect" else L.PAD_ZERO
+    # raw fp32 NHWC + per-channel statistics
+    raw, rows, (N, OH, OW) = eng.conv(xa, conv, pm, pad, L.OUT_RAW_F32_NHWC, want_stats=True)
+    cs = (cout + 3) // 4 * 4
+    got = raw[:N * OH * OW * cs].view(N, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2).cpu()
+    assert_close(got, ref, 1e-4 if prec == "fp32" else 1e-4, "raw " + str(case))   # raw output is fp32 in both modes
+    st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+    assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "stats sum")
+    assert_close(st[:, 1], (ref * ref).sum((0, 2, 3)), 1e-3, "stats sumsq")
+    # activation-dtype NHWC with fused leaky relu
+    out, _, _ = eng.conv(xa, conv, pm, pad, L.OUT_ACT_NHWC, L.ACT_LEAKY, 0.2)
+    assert_close(eng.unpack(out).cpu(), F.leaky_relu(ref, 0.2), tol, "act " + str(case))
+    # planar NCHW head with tanh and scale
+    o2, _, _ = eng.conv(xa, conv, pm, pad, L.OUT_F32_NCHW, L.ACT_TANH, 0.0, 20.0)
+    assert_close(o2.cpu(), torch.tanh(ref) * 20.0, 1e-4 if prec == "fp32" else 2e-3, "nchw " + str(case))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_conv2d_every_tile_config(tile, prec):
+    from vid2vid_amd import lib as L
+    torch.manual_seed(tile)
+    eng = _engine(prec)
+    cin, cout, H, W = 72, 96, 21, 37      # M = 2*21*37 = 1554: ragged against every BM, cout ragged against BN
+    conv = nn.Conv2d(cin, cout, 3, padding=0)
+    x = torch.randn(2, cin, H, W)
+    ref = F.conv2d(F.pad(_round(x, prec), (1,) * 4, mode="reflect"), _round(conv.weight.detach(), prec), conv.bias.detach())
+    eng.tile_override[(cin, cout, 3, 1, 0)] = tile
+    conv = conv.to(DEV)
+    raw, rows, (N, OH, OW) = eng.conv(eng.pack(x.to(DEV)), conv, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
+    assert eng.conv_log[-1]["tile"] == tile
+    got = raw[:N * OH * OW * cout].view(N, OH, OW, cout).permute(0, 3, 1, 2).cpu()
+    assert_close(got, ref, 1e-4, "tile %d" % tile)
+    st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+    assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "stats")
+
+
+CONVT_CASES = [(16, 8, 3, 1, 1, 9, 13), (64, 32, 3, 1, 1, 16, 32), (24, 16, 4, 1, 0, 11, 7), (128, 64, 3, 1, 1, 32, 64)]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose2d(case, prec):
+    from vid2vid_amd import lib as L
+    cin, cout, k, pad, opad, H, W = case
+    torch.manual_seed(7)
+    eng = _engine(prec)
+    conv = nn.ConvTranspose2d(cin, cout, k, stride=2, padding=pad, output_padding=opad)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.2)
+    x = torch.randn(2, cin, H, W)
+    ref = F.conv_transpose2d(_round(x, prec), _round(conv.weight.detach(), prec), conv.bias.detach(), stride=2,
+                             padding=pad, output_padding=opad)
+    assert ref.shape[-2:] == (2 * H, 2 * W)
+    conv = conv.to(DEV)
+    raw, rows, (N, OH, OW) = eng.conv(eng.pack(x.to(DEV)), conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+    cs = (cout + 3) // 4 * 4
+    got = raw[:N * OH * OW * cs].view(N, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2).cpu()
+    assert_close(got, ref, 1e-4, "convT " + str(case))
+    st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+    assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "convT stats")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_batchnorm_training_mode_and_resblock(prec):
+    """conv -> training-mode BatchNorm2d -> ReLU and a full ResnetBlock against torch.nn."""
+    from vid2vid_amd import networks as N
+    torch.manual_seed(3)
+    eng = _engine(prec)
+    tol = 2e-4 if prec == "fp32" else 3e-2
+    blk = N.ResnetBlock(32, "reflect", N.get_norm_layer("batch"))
+    blk.apply(N.weights_init)
+    x = torch.randn(1, 32, 20, 28)
+    with torch.no_grad():
+        ref = x + blk.conv_block(x)          # torch.nn executes the same Sequential on CPU (training mode)
+    blk = blk.to(DEV)
+    got = eng.unpack(eng.run_resblock(blk, eng.pack(x.to(DEV)), None, "blk")).cpu()
+    assert_close(got, ref, tol, "resblock")
+    # InstanceNorm (first-frame nets): per-sample statistics, no affine
+    seq = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(5, 16, 7), nn.InstanceNorm2d(16, affine=False, track_running_stats=True), nn.ReLU(True))
+    x = torch.randn(1, 5, 18, 22)
+    with torch.no_grad():
+        ref = seq(x)
+    got = eng.unpack(eng.run_sequential(seq.to(DEV), eng.pack(x.to(DEV)))).cpu()
+    assert_close(got, ref, tol, "stem+instancenorm")
+
+
+def test_bn_running_stats_update():
+    from vid2vid_amd import lib as L
+    torch.manual_seed(4)
+    eng = _engine("fp32")
+    eng.update_running_stats = True
+    seq = nn.Sequential(nn.Conv2d(8, 12, 3, padding=1), nn.BatchNorm2d(12), nn.ReLU(True))
+    x = torch.randn(2, 8, 10, 14)
+    ref_seq = nn.Sequential(*[m for m in seq])
+    import copy
+    ref_seq = copy.deepcopy(seq)
+    with torch.no_grad():
+        ref = ref_seq(x)
+    got = eng.unpack(eng.run_sequential(seq.to(DEV), eng.pack(x.to(DEV)))).cpu()
+    assert_close(got, ref, 2e-4, "bn out")
+    assert_close(seq[1].running_mean.cpu(), ref_seq[1].running_mean, 1e-4, "running_mean")
+    assert_close(seq[1].running_var.cpu(), ref_seq[1].running_var, 1e-4, "running_var")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_encode_labels_and_mask(prec):
+    from oracle import vid2vid_oracle as O
+    torch.manual_seed(5)
+    eng = _engine(prec)
+    T, H, W, nc = 3, 37, 53, 35
+    lab = torch.randint(0, nc, (T, H, W)).float()
+    inst = torch.randint(0, 4, (T, H // 4 + 1, W // 4 + 1)).repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :H, :W].float()
+    enc = O.encode_input(lab.view(1, T, 1, H, W), inst.view(1, T, 1, H, W), nc)
+    x, mask = eng.encode_labels(lab.to(DEV), inst.to(DEV), T, H, W, nc, [26, 3], True)
+    got = eng.unpack(x).cpu()
+    assert torch.equal(got, enc.reshape(1, T * (nc + 1), H, W))          # exact: 0/1 values
+    assert torch.equal(mask.cpu(), O.compute_mask(enc, T - 1, [26, 3]).reshape(1, 1, H, W))
+    # pooled pyramid level + fractional fg mask
+    pooled = eng.avgpool_nhwc(x)
+    ref_p = O.avgpool3s2(enc.reshape(1, -1, H, W))
+    assert_close(eng.unpack(pooled).cpu(), ref_p, 1e-6 if prec == "fp32" else 1e-2, "avgpool nhwc")
+    m2 = eng.fg_mask(pooled, (T - 1) * (nc + 1), [26, 3]).cpu()
+    ref_m = O.compute_mask(_round(ref_p, prec).view(1, T, nc + 1, ref_p.shape[-2], ref_p.shape[-1]), T - 1, [26, 3])
+    assert_close(m2, ref_m.reshape(m2.shape), 1e-6 if prec == "fp32" else 2e-2, "coarse fg mask")
+
+
+def test_avgpool_planar_and_add():
+    from oracle import vid2vid_oracle as O
+    torch.manual_seed(6)
+    eng = _engine("fp32")
+    x = torch.randn(2, 3, 3, 31, 46)
+    got = eng.avgpool_planar(x.to(DEV)).cpu()
+    assert_close(got, O.avgpool3s2(x.view(-1, 1, 31, 46)).view(2, 3, 3, 16, 23), 1e-6, "avgpool planar")
+    for prec in ("fp32", "bf16"):
+        e = _engine(prec)
+        a, b = torch.randn(1, 12, 9, 11), torch.randn(1, 12, 9, 11)
+        y = e.unpack(e.add(e.pack(a.to(DEV)), e.pack(b.to(DEV)))).cpu()
+        assert_close(y, _round(a, prec) + _round(b, prec), 1e-6 if prec == "fp32" else 1e-2, "add")
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_warp_blend_matches_grid_sample(align):
+    from oracle import vid2vid_oracle as O
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.engine import Engine
+    torch.manual_seed(8)
+    eng = Engine(DEV, L.F32, align_corners=align)
+    H, W = 33, 47
+    raw, prev, fg = torch.randn(1, 3, H, W), torch.randn(1, 3, H, W), torch.randn(1, 3, H, W)
+    flow = torch.randn(1, 2, H, W) * 6.0           # large enough to hit the border clamp
+    wgt, mask = torch.rand(1, 1, H, W), (torch.rand(1, 1, H, W) > 0.7).float()
+    warp = O.resample(prev, flow, align)
+    fin = raw * wgt + warp * (1 - wgt)
+    fin_fg = fg * mask + fin * (1 - mask)
+    raw_fg = fg * mask + raw * (1 - mask)
+    d = lambda t: t.to(DEV).contiguous()
+    r = d(raw)
+    got_fin, got_warp = eng.warp_blend(r, d(flow), d(wgt), d(prev), d(fg), d(mask), want_warp=True)
+    assert_close(got_warp.cpu(), warp, 1e-4, "warp")
+    assert_close(got_fin.cpu(), fin_fg, 1e-4, "final")
+    assert_close(r.cpu(), raw_fg, 1e-6, "raw (in place fg blend)")
+    assert_close(eng.resample_flow(d(prev), d(flow)).cpu(), warp, 1e-4, "resample_flow")
+    # use_raw_only with fg: no warp
+    r = d(raw)
+    got, _ = eng.warp_blend(r, None, None, None, d(fg), d(mask))
+    assert_close(got.cpu(), raw_fg, 1e-6, "raw only + fg")
+
+
+def test_flownet2_native_ops():
+    """correlation / resample2d / channelnorm against the oracle's restatement of the .cu files
+    (fp32, summation order differs -> 1e-5)."""
+    import ctypes as C
+    from oracle import vid2vid_oracle as O
+    from vid2vid_amd import lib
+    torch.manual_seed(9)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (n, c, h, w, pad, k, md, s1, s2) in [(2, 16, 12, 20, 4, 1, 4, 1, 2), (1, 256, 8, 16, 20, 1, 20, 1, 2),
+                                             (1, 6, 17, 23, 4, 3, 4, 2, 1), (1, 3, 9, 9, 3, 1, 3, 1, 1)]:
+        a, b = torch.randn(n, c, h, w), torch.randn(n, c, h, w)
+        ref = O.correlation(a, b, pad, k, md, s1, s2)
+        out = torch.full(ref.shape, float("nan"), device=DEV)
+        ad, bd = a.to(DEV), b.to(DEV)
+        lib.check(lib.lib.v2v_correlation_forward(P(ad), P(bd), P(out), n, c, h, w, pad, k, md, s1, s2, 1, s), "corr")
+        assert_close(out.cpu(), ref, 1e-5, "correlation %s" % ((n, c, h, w, pad, k, md, s1, s2),))
+    img, fl = torch.randn(2, 3, 21, 33), torch.randn(2, 2, 21, 33) * 4
+    out = torch.empty(2, 3, 21, 33, device=DEV)
+    imd, fld = img.to(DEV), fl.to(DEV)
+    lib.check(lib.lib.v2v_resample2d_forward(P(imd), P(fld), P(out), 2, 3, 21, 33, 21, 33, 1, s), "resample2d")
+    assert_close(out.cpu(), O.resample2d(img, fl), 1e-5, "resample2d")
+    x = torch.randn(2, 3, 21, 33)
+    out = torch.empty(2, 1, 21, 33, device=DEV)
+    xd = x.to(DEV)
+    lib.check(lib.lib.v2v_channelnorm_forward(P(xd), P(out), 2, 3, 21, 33, 2, s), "channelnorm")
+    assert_close(out.cpu(), O.channelnorm(x), 1e-6, "channelnorm")

@@ -85,10 +85,16 @@ extern "C" int v2v_plan_instantiate_graph(v2v_plan* p, void* stream) {
     if (rc != 0) return rc;
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_error("plan: warm-up failed: %s", hipGetErrorString(e)); return (int)e; }
-    e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { set_error("plan: begin capture: %s", hipGetErrorString(e)); return (int)e; }
-    rc = v2v_plan_run(p, stream);
-    hipError_t e2 = hipStreamEndCapture(s, &p->graph);
+    // capture on a private stream: the caller's stream may be the legacy null stream, which
+    // cannot be captured (hipErrorStreamCaptureUnsupported)
+    hipStream_t cs = nullptr;
+    e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_error("plan: capture stream: %s", hipGetErrorString(e)); return (int)e; }
+    e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { set_error("plan: begin capture: %s", hipGetErrorString(e)); hipStreamDestroy(cs); return (int)e; }
+    rc = v2v_plan_run(p, cs);
+    hipError_t e2 = hipStreamEndCapture(cs, &p->graph);
+    hipStreamDestroy(cs);
     if (rc != 0) return rc;
     if (e2 != hipSuccess) { set_error("plan: end capture: %s", hipGetErrorString(e2)); return (int)e2; }
     e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
