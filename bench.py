@@ -159,8 +159,9 @@ def main():
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         from oracle import vid2vid_oracle as O
-        ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
+        # torch's default intra-op pool (one thread per physical core it detects); forcing
+        # os.cpu_count() SMT threads measured 9x slower on the 2x64-core EPYC host
+        ncores = torch.get_num_threads()
         sd = {k: v.detach().float().cpu() for k, v in model.netG0.state_dict().items()}
         orc = O.InferenceOracle([sd], 35, True, True, [26], opt.n_downsample_G, opt.n_blocks, opt.n_blocks_local)
         lc, ic, fc = lab.cpu(), inst.cpu(), frames.cpu()

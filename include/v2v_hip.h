@@ -65,6 +65,7 @@ typedef struct v2v_conv_desc {
     const float* bias;      /* [cout] fp32 or NULL                                           */
     void*        out;       /* see out_mode                                                  */
     float*       stats;     /* NULL or [n_classes*m_tiles][cout][2] fp32 (sum, sum of sq.)   */
+    const void*  zero_page; /* >= 16 zero bytes, 16-B aligned: source of padded / ragged lanes */
     int32_t N, H, W;        /* input batch / height / width                                  */
     int32_t cin;            /* real input channels (weights beyond are zero)                 */
     int32_t cin_stride;     /* channel stride of `in`, elements; multiple of 16 B            */

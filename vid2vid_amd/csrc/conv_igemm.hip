@@ -15,14 +15,23 @@
 //   * epilogue: bias, per-channel (sum, sum^2) partials for training-mode BatchNorm
 //     (deterministic: one row of partials per M tile), or activation + store.
 //
-// Tiling: a workgroup of 4 waves (wave64) owns a BM x BN output tile; K advances in
-// 128-byte chunks (32 fp32 / 64 bf16).  A and B tiles are staged global -> registers ->
-// LDS with a 2-deep LDS ring (loads for chunk k+1 are in flight while chunk k is on the
-// matrix cores; one barrier per chunk).  LDS rows are 128 B with the 16-byte slot index
-// XOR-swizzled by (row>>1)&7, which makes both the ds_write_b128 staging stores and the
-// ds_read_b128 fragment loads of the 32x32 MFMA operand layout bank-conflict free.
-// blockIdx.x is remapped so that the 32 workgroups resident on one XCD share weight
-// (N) tiles in that XCD's private L2.
+// Structure (1 workgroup = 4 waves owns a BM x BN tile, K advances in 128-byte chunks):
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+//     instruction): no VGPR round trip and no ds_write pass, which alone would eat >100% of
+//     the LDS cycles the MFMAs leave (ds_write_b128 = 13 cycles / wave-instruction);
+//   * NS-stage LDS ring with NS-1 tiles in flight, retired with a COUNTED s_waitcnt vmcnt(N)
+//     and ONE raw s_barrier per K chunk -- at batch 1 the dominant layer (1024->1024 3x3 at
+//     32x64 pixels) yields exactly one workgroup per CU, so there is no second workgroup to
+//     hide the ~1-2 us weight-stream latency and the prefetch distance has to do it;
+//   * LDS rows are 128 B; the 16-byte slot index is XOR-swizzled with (row>>1)&7.  LDS-DMA
+//     writes lane-linear, so the swizzle is applied to the per-lane SOURCE address and to the
+//     fragment read (cdna guide rule 21); ds_read_b128 of the 32x32 MFMA operand layout is
+//     bank-conflict free under it;
+//   * padding / K-tail / ragged-M lanes fetch from a 16-byte zero page instead of branching;
+//   * layers whose channel stride is a multiple of the K chunk (all wide layers) use a
+//     uniform tap walk: row pointers are recomputed only when the tap changes;
+//   * blockIdx.x is remapped so that the 32 workgroups resident on one XCD share weight
+//     (N) tiles in that XCD's private L2.
 #include "v2v_internal.h"
 #include <cstdarg>
 #include <cstring>
@@ -32,6 +41,7 @@ namespace v2v {
 struct ConvKArgs {
     const char* in;
     const char* w;
+    const char* zero_page;
     const float* bias;
     char* out;
     float* stats;
@@ -58,6 +68,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int ntot) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// 16 bytes per lane, global -> LDS, asynchronous (counted by vmcnt).  `lds` must be
+// wave-uniform: the hardware writes lane l at lds + 16*l.
+__device__ __forceinline__ void glds16(const char* g, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     typedef bf16x8 Frag;
@@ -77,7 +98,7 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BKE = ElemTraits<T>::BKE;
@@ -85,8 +106,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
     constexpr int STAGE = (BM + BN) * 128;
+    constexpr int D = NS - 1;                 // tiles in flight
+    constexpr int LPT = RA + RB;              // LDS-DMA instructions per tile per wave
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     static_assert(TM >= 1 && TN >= 1, "wave tile");
+    static_assert(NS >= 2 && LPT * (D - 1) <= 63, "vmcnt range");
     typedef typename Mma<T>::Frag Frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,12 +130,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
     const int kpad = p.kpad[cls];
     const int nk = kpad / BKE;
     const int H = p.H, W = p.W, cs = p.cin_stride;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+    const char* const zp = p.zero_page;
 
-    // ---------------- loader state ----------------
-    const int slot = tid & 7;
-    const int lrow = tid >> 3;                 // 0..31
-    const int swz = (lrow >> 1) & 7;
-    const int lds_w_off = lrow * 128 + ((slot ^ swz) << 4);
+    // ---------------- loader geometry ----------------
+    // wave `wid`, lane l writes LDS row (wid*8 + l>>3) + 32*i, physical 16-byte slot l&7, which
+    // must hold the LOGICAL slot (l&7) ^ swz(row): that is the slot this lane fetches.
+    const int lrow = wid * 8 + (lane >> 3);          // 0..31
+    const int lslot = (lane & 7) ^ ((lrow >> 1) & 7);
+    const int koff = lslot * VEC;                    // element offset inside the 128-byte chunk
+    char* const lds_wave = smem + wid * 8 * 128;     // wave-uniform part of the destination
 
     int pixbase[RA], ohs[RA], ows[RA];
     unsigned rowvalid = 0;
@@ -132,60 +160,98 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
             rowvalid |= (ok ? 1u : 0u) << i;
         }
     }
-    // k decode for this thread's 16-byte slot
-    int kc, kth, ktw;
-    {
-        const int k = slot * VEC;
-        const int t = k / cs;
-        kc = k - t * cs;
-        kth = t / nkw;
-        ktw = t - kth * nkw;
-    }
-    const char* wrow[RB];
+    const char* wp[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const long long r = (long long)nt * BN + lrow + 32 * i;
-        wrow[i] = p.w + ((long long)p.woff[cls] + r * kpad + slot * VEC) * (long long)sizeof(T);
+        wp[i] = p.w + ((long long)p.woff[cls] + r * kpad + koff) * (long long)sizeof(T);
     }
 
-    uint4 ra[RA], rb[RB];
-    auto load_tiles = [&](int ks) {
-        const bool kvalid = kth < nkh;
-        const int dh = dh0 + kth * dstep, dw = dw0 + ktw * dstep;
+    // resolves one tap for one row: source pointer of this lane's slot (channel 0 of the chunk)
+    auto tap_ptr = [&](int i, int dh, int dw, bool& ok) -> const char* {
+        int ih = ohs[i] + dh, iw = ows[i] + dw;
+        // branch-free: reflection is a select on a uniform flag, validity a bitwise AND
+        int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+        int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+        ih = reflect ? rh : ih;
+        iw = reflect ? rw : iw;
+        ok = (bool)((int)ok & (int)((unsigned)ih < (unsigned)H) & (int)((unsigned)iw < (unsigned)W));
+        ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+        iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        return p.in + ((long long)(pixbase[i] + ih * W + iw) * cs) * (long long)sizeof(T);
+    };
+
+    // ---- fast path (cs % BKE == 0): the tap is uniform over the workgroup ----
+    const bool fastk = (cs % BKE) == 0;
+    const char* ap[RA];
+    unsigned aok = 0;
+    int tap_h = 0, tap_w = 0, kcb = 0;               // uniform
+    const int row_bytes = cs * (int)sizeof(T);
+    auto set_tap = [&]() {
+        const int dh = dh0 + tap_h * dstep, dw = dw0 + tap_w * dstep;
+        const bool tvalid = tap_h < nkh;
+        aok = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            int ih = ohs[i] + dh, iw = ows[i] + dw;
-            bool ok = kvalid && ((rowvalid >> i) & 1u);
-            if (p.pad_mode == V2V_PAD_REFLECT) {
-                ih = ih < 0 ? -ih : (ih >= H ? 2 * H - 2 - ih : ih);
-                iw = iw < 0 ? -iw : (iw >= W ? 2 * W - 2 - iw : iw);
-            } else {
-                ok = ok && ((unsigned)ih < (unsigned)H) && ((unsigned)iw < (unsigned)W);
+            bool ok = tvalid && ((rowvalid >> i) & 1u);
+            ap[i] = tap_ptr(i, dh, dw, ok) + koff * (int)sizeof(T);
+            aok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    // ---- general path: per-lane (tap, channel) walk ----
+    int kc, kth, ktw;
+    {
+        const int t = koff / cs;
+        kc = koff - t * cs;
+        kth = t / nkw;
+        ktw = t - kth * nkw;
+    }
+    const int nwrap = (BKE + cs - 1) / cs;           // tap wraps per chunk (1 when cs >= BKE)
+    if (fastk) set_tap();
+
+    int issued = 0;                                  // tiles issued so far (uniform)
+    auto issue = [&]() {
+        char* sbase = lds_wave + (issued % NS) * STAGE;
+        if (fastk) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const char* src = ((aok >> i) & 1u) ? ap[i] + kcb : zp;
+                glds16(src, sbase + i * 32 * 128);
             }
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) {
-                const long long e = ((long long)(pixbase[i] + ih * W + iw)) * cs + kc;
-                v = *reinterpret_cast<const uint4*>(p.in + e * (long long)sizeof(T));
+        } else {
+            const bool kvalid = kth < nkh;
+            const int dh = dh0 + kth * dstep, dw = dw0 + ktw * dstep;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                bool ok = kvalid && ((rowvalid >> i) & 1u);
+                const char* src = tap_ptr(i, dh, dw, ok) + kc * (int)sizeof(T);
+                src = ok ? src : zp;
+                glds16(src, sbase + i * 32 * 128);
             }
-            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (long long)ks * (BKE * (int)sizeof(T)));
-        // advance k state by one chunk
-        kc += BKE;
-        while (kc >= cs) {
-            kc -= cs;
-            if (++ktw == nkw) { ktw = 0; ++kth; }
+            glds16(wp[i] + (long long)issued * 128, sbase + BM * 128 + i * 32 * 128);
+        // advance the K walk by one chunk
+        if (fastk) {
+            kcb += 128;
+            if (kcb == row_bytes) {
+                kcb = 0;
+                if (++tap_w == nkw) { tap_w = 0; ++tap_h; }
+                set_tap();
+            }
+        } else {
+            kc += BKE;
+            for (int it = 0; it < nwrap; ++it) {
+                const bool wr = kc >= cs;
+                kc -= wr ? cs : 0;
+                ktw += wr ? 1 : 0;
+                const bool w2 = ktw == nkw;
+                ktw = w2 ? 0 : ktw;
+                kth += w2 ? 1 : 0;
+            }
         }
-    };
-    auto store_tiles = [&](int buf) {
-        char* base = smem + buf * STAGE + lds_w_off;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(base + i * 32 * 128) = ra[i];
-        char* bb = base + BM * 128;
-#pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(bb + i * 32 * 128) = rb[i];
+        ++issued;
     };
 
     // ---------------- fragment addressing ----------------
@@ -206,34 +272,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---------------- main loop ----------------
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
+    for (int t = 0; t < D && t < nk; ++t) issue();
     for (int ks = 0; ks < nk; ++ks) {
-        const bool more = ks + 1 < nk;
-        if (more) load_tiles(ks + 1);
-        const char* sb = smem + (ks & 1) * STAGE;
+        // tile ks must have landed; in steady state tiles ks+1 .. ks+D-1 stay in flight
+        if (ks + D <= nk) wait_vmcnt<LPT * (D - 1)>();
+        else              wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();     // every wave's part of tile ks is in LDS, and every wave
+                                          // is done reading stage (ks-1)%NS, which is refilled now
+        if (ks + D < nk) issue();
+        const char* sb = smem + (ks % NS) * STAGE;
+        Frag fa[4][TM], fb[4][TN];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            Frag fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const Frag*>(sb + a_row_off + i * 32 * 128 + foff[s]);
+                fa[s][i] = *reinterpret_cast<const Frag*>(sb + a_row_off + i * 32 * 128 + foff[s]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const Frag*>(sb + b_row_off + j * 32 * 128 + foff[s]);
+                fb[s][j] = *reinterpret_cast<const Frag*>(sb + b_row_off + j * 32 * 128 + foff[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-        }
-        if (more) store_tiles((ks + 1) & 1);
-        __syncthreads();
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s][i], fb[s][j], acc[i][j]);
     }
+    __syncthreads();                      // LDS ring is free: reused for the statistics reduction
 
     // ---------------- epilogue ----------------
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2], LDS ring is free now
+    float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2]
     const bool want_stats = p.stats != nullptr;
     const int a_par = cls >> 1, b_par = cls & 1;
     const int hwc = p.OHc * p.OWc;
@@ -423,10 +492,10 @@ struct PackOp : Op {
 };
 
 // ---- conv launch ------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN, int NS>
 static int launch_cfg(const ConvKArgs& k, int ncls, hipStream_t s) {
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
-    auto kern = conv_igemm_kernel<T, BM, BN, WGM, WGN>;
+    const size_t lds = (size_t)NS * (BM + BN) * 128;
+    auto kern = conv_igemm_kernel<T, BM, BN, WGM, WGN, NS>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -440,12 +509,12 @@ static int launch_cfg(const ConvKArgs& k, int ncls, hipStream_t s) {
 template <typename T>
 static int launch_typed(int cfg, const ConvKArgs& k, int ncls, hipStream_t s) {
     switch (cfg) {
-        case 1: return launch_cfg<T, 128, 128, 2, 2>(k, ncls, s);
-        case 2: return launch_cfg<T, 128, 64, 2, 2>(k, ncls, s);
-        case 3: return launch_cfg<T, 64, 64, 2, 2>(k, ncls, s);
-        case 4: return launch_cfg<T, 128, 32, 4, 1>(k, ncls, s);
-        case 5: return launch_cfg<T, 64, 128, 2, 2>(k, ncls, s);
-        case 6: return launch_cfg<T, 256, 64, 4, 1>(k, ncls, s);
+        case 1: return launch_cfg<T, 128, 128, 2, 2, 3>(k, ncls, s);   //  96 KiB LDS
+        case 2: return launch_cfg<T, 128, 64, 2, 2, 4>(k, ncls, s);    //  96 KiB
+        case 3: return launch_cfg<T, 64, 64, 2, 2, 4>(k, ncls, s);     //  64 KiB (2 workgroups / CU)
+        case 4: return launch_cfg<T, 128, 32, 4, 1, 4>(k, ncls, s);    //  80 KiB (2 / CU)
+        case 5: return launch_cfg<T, 64, 128, 2, 2, 4>(k, ncls, s);    //  96 KiB
+        case 6: return launch_cfg<T, 256, 64, 4, 1, 3>(k, ncls, s);    // 120 KiB
     }
     set_error("conv: unknown tile config %d", cfg);
     return V2V_EINVAL;
@@ -473,7 +542,7 @@ struct ConvOp : Op {
 };
 
 static int build_conv(const v2v_conv_desc* d, ConvOp* op) {
-    if (!d || !d->in || !d->w || !d->out) { set_error("conv: null pointer"); return V2V_EINVAL; }
+    if (!d || !d->in || !d->w || !d->out || !d->zero_page) { set_error("conv: null pointer"); return V2V_EINVAL; }
     if (d->dtype != V2V_F32 && d->dtype != V2V_BF16) { set_error("conv: bad dtype"); return V2V_EINVAL; }
     const int vec = d->dtype == V2V_BF16 ? 8 : 4;
     if (d->cin_stride % vec != 0 || d->cin > d->cin_stride) { set_error("conv: cin_stride %d not a multiple of %d", d->cin_stride, vec); return V2V_EINVAL; }
@@ -486,11 +555,13 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op) {
         if (d->pad_mode == V2V_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) { set_error("conv: reflect pad >= size"); return V2V_EINVAL; }
     }
     if (d->out_mode != V2V_OUT_F32_NCHW && d->cout > d->cout_stride) { set_error("conv: cout_stride"); return V2V_EINVAL; }
+    if (((uintptr_t)d->in | (uintptr_t)d->w | (uintptr_t)d->zero_page) & 15) { set_error("conv: operands must be 16-byte aligned"); return V2V_EINVAL; }
     ConvGeom g;
     conv_geom(d->cin_stride, d->cout, d->KH, d->KW, d->transposed, d->pad, d->dtype, &g);
     ConvKArgs& k = op->k;
     memset(&k, 0, sizeof(k));
-    k.in = (const char*)d->in; k.w = (const char*)d->w; k.bias = d->bias; k.out = (char*)d->out; k.stats = d->stats;
+    k.in = (const char*)d->in; k.w = (const char*)d->w; k.zero_page = (const char*)d->zero_page;
+    k.bias = d->bias; k.out = (char*)d->out; k.stats = d->stats;
     k.N = d->N; k.H = d->H; k.W = d->W; k.cin_stride = d->cin_stride;
     k.cout = d->cout; k.cout_stride = d->cout_stride; k.cout_p = g.cout_p;
     k.OH = d->OH; k.OW = d->OW;

@@ -60,7 +60,7 @@ class Act:
     @property
     def W(self): return self.t.shape[2]
     @property
-    def Cs(self): return self.t.shape[3]
+    def Cs(self): return self.t.stride(2)      # true channel stride (a channel-sliced view keeps its parent's)
 
 
 class PackedConv:
@@ -172,7 +172,8 @@ class Engine:
         self._packed = {}        # id(module) -> PackedConv
         self._scratch = {}       # name -> tensor (grown on demand, shared between layers)
         self._grids = {}
-        self.plan = None         # Plan being recorded (for labels / keep-alive)
+        self._zero_page = None
+        self.plan = None        # Plan being recorded (for labels / keep-alive)
         self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
         self.tile_override = {}  # (cin,cout,KH,stride,transposed) -> tile id (tuning)
         self.update_running_stats = False
@@ -254,6 +255,10 @@ class Engine:
             OW = (W + 2 * pad - pc.KW) // pc.stride + 1
         d = ConvDesc()
         d.in_ = x.t.data_ptr(); d.w = pc.buf.data_ptr()
+        if self._zero_page is None:
+            self._zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        d.zero_page = self._zero_page.data_ptr()
+        self._keep(self._zero_page)
         d.bias = None if pc.bias is None else pc.bias.data_ptr()
         d.N, d.H, d.W = N, H, W
         d.cin, d.cin_stride, d.cout = pc.cin, x.Cs, pc.cout

@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
     """struct v2v_conv_desc"""
     _fields_ = [
         ("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
-        ("stats", C.c_void_p),
+        ("stats", C.c_void_p), ("zero_page", C.c_void_p),
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("cin", C.c_int32), ("cin_stride", C.c_int32),
         ("cout", C.c_int32), ("cout_stride", C.c_int32),
