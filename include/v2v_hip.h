@@ -72,10 +72,10 @@ typedef struct v2v_conv_desc {
     int32_t cout;           /* real output channels                                          */
     int32_t cout_stride;    /* channel stride of `out` for NHWC output modes                 */
     int32_t KH, KW;         /* kernel size                                                   */
-    int32_t stride;         /* 1 or 2 (transposed: always 2)                                 */
+    int32_t stride;         /* 1 or 2                                                        */
     int32_t pad;            /* symmetric padding                                             */
     int32_t pad_mode;       /* V2V_PAD_*  (transposed: zero only)                            */
-    int32_t transposed;     /* 0 = Conv2d, 1 = ConvTranspose2d(stride 2, OH = 2H)            */
+    int32_t transposed;     /* 0 = Conv2d, 1 = ConvTranspose2d (or Conv2d backward-data), see below */
     int32_t OH, OW;         /* output height / width                                         */
     int32_t dtype;          /* V2V_F32 / V2V_BF16 : dtype of in, w (and out in ACT mode)     */
     int32_t out_mode;       /* V2V_OUT_*                                                     */
@@ -85,28 +85,61 @@ typedef struct v2v_conv_desc {
     int32_t tile;           /* 0 = auto, else force tile config id (testing/tuning)          */
 } v2v_conv_desc;
 
-/* Packed weight layout.  One matrix per class (Conv2d: 1 class; ConvTranspose2d stride 2:
- * 4 output-parity classes (a,b)), each [round_up(cout,128)][kpad] with
+/* transposed = 1: out[s*i - pad + k] += in[i]*w[k] for any OH <= (H-1)*s - 2*pad + KH + (s-1)
+ * (output_padding < s).  The same operator is the backward-data pass of a Conv2d (same weight tensor,
+ * roles of cin / cout swapped): see v2v_conv2d. */
+
+/* Packed weight layout.  One matrix per class (Conv2d: 1 class; ConvTranspose2d stride 1: 1 class,
+ * stride 2: 4 output-parity classes (a,b)), each [round_up(cout,128)][kpad] with
  * k = tap * cin_stride + c (taps row-major over the class's (kh,kw) list) and kpad = k
  * rounded up to 128 bytes; zero filled.  v2v_conv_packed_elems gives the total element count;
  * v2v_conv_pack_weights is the device kernel that fills it from PyTorch-layout fp32 weights
  * [cout][cin][KH][KW] (Conv2d) or [cin][cout][KH][KW] (ConvTranspose2d), converting to `dtype`. */
 int64_t v2v_conv_packed_elems(int32_t cin, int32_t cin_stride, int32_t cout, int32_t KH, int32_t KW,
-                              int32_t transposed, int32_t pad, int32_t dtype);
+                              int32_t transposed, int32_t stride, int32_t pad, int32_t dtype);
 int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t cin_stride, int32_t cout,
-                              int32_t KH, int32_t KW, int32_t transposed, int32_t pad, int32_t dtype,
-                              void* stream);
+                              int32_t KH, int32_t KW, int32_t transposed, int32_t stride, int32_t pad,
+                              int32_t dtype, void* stream);
 
 /* Number of statistics rows (n_classes * m_tiles) the launch described by `d` writes. */
 int     v2v_conv_stats_rows(const v2v_conv_desc* d);
 /* Tile configuration id the launch would use (after auto selection). */
 int     v2v_conv_tile_config(const v2v_conv_desc* d);
-/* Launch.  nn.Conv2d / nn.ConvTranspose2d forward (models/networks.py:132-183 etc.). */
+/* Launch.  nn.Conv2d / nn.ConvTranspose2d forward (models/networks.py:132-183 etc.), and -- with the
+ * SAME parameter tensor packed in the opposite role -- their backward-data (autograd of F.conv2d /
+ * F.conv_transpose2d in the reference):
+ *   dX of Conv2d(w[cout][cin], stride s, zero pad p)   = transposed conv of dY with `w` read as a
+ *       ConvTranspose2d weight [cin'=cout][cout'=cin], stride s, pad p, OH = H of the forward input;
+ *   dX of Conv2d behind ReflectionPad2d(p)             = the same with pad 0 and OH = H + 2p, followed by
+ *       v2v_reflect_pad_fold;
+ *   dX of ConvTranspose2d(w[cin][cout], stride 2, p)   = Conv2d of dY with `w` read as a Conv2d weight
+ *       [cout'=cin][cin'=cout], stride 2, pad p. */
 int     v2v_conv2d(const v2v_conv_desc* d, void* stream);
+
+/* Weight gradient:  G[r][c][kh][kw] (+)= sum_{n,oi,oj} P[n][oi][oj][r] * Q[n][oi*s+kh-pad][oj*s+kw-pad][c]
+ *   Conv2d:           P = dY (rows = cout), Q = X  (cols = cin)  -> dW[cout][cin][KH][KW]
+ *   ConvTranspose2d:  P = X  (rows = cin),  Q = dY (cols = cout) -> dW[cin][cout][KH][KW], s = 2
+ * P, Q are NHWC activations of `dtype`; accumulation is exact fp32 (v_mfma_f32_32x32x2_f32). */
+typedef struct v2v_wgrad_desc {
+    const void*  p;          /* [N][OH][OW][p_stride]                                         */
+    const void*  q;          /* [N][QH][QW][q_stride]                                         */
+    float*       grad;       /* [rows][cols][KH][KW] fp32                                     */
+    float*       workspace;  /* v2v_conv_wgrad_workspace(d) bytes                             */
+    const void*  zero_page;  /* >= 16 zero bytes, 16-B aligned                                */
+    int32_t N, OH, OW, QH, QW;
+    int32_t rows, cols;      /* real channel counts of P / Q                                  */
+    int32_t p_stride, q_stride;
+    int32_t KH, KW, stride, pad, pad_mode;
+    int32_t dtype;
+    int32_t accumulate;      /* 1: add into grad (optimizer .grad buffer), 0: overwrite        */
+} v2v_wgrad_desc;
+int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d);
+int     v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream);
 
 /* Training-mode BatchNorm2d / InstanceNorm2d(batch 1) statistics -> per-channel scale/shift
  * (get_norm_layer, models/networks.py:23-30).  partials: [rows][C][2]; count = N*OH*OW.
- * gamma/beta may be NULL (affine=False).  scale_shift: [2][C] fp32.  If running_mean/var
+ * gamma/beta may be NULL (affine=False).  scale_shift: [4][C] fp32 = scale, shift, mean, invstd (the last
+ * two rows are what the backward pass needs).  If running_mean/var
  * are non-NULL they are updated with `momentum` (unbiased variance), as nn.BatchNorm2d does. */
 int v2v_bn_finalize(const float* partials, int32_t rows, int32_t C, int64_t count,
                     const float* gamma, const float* beta, float eps,
@@ -120,12 +153,36 @@ int v2v_bn_apply(const float* raw, int32_t c_stride_raw, const float* scale_shif
                  const void* add0, const void* add1, void* y, int64_t P, int32_t C, int32_t c_stride,
                  int32_t act, float act_param, int32_t dtype, void* stream);
 
+/* Backward of bn_finalize + bn_apply (autograd of training-mode BatchNorm2d/InstanceNorm2d + ReLU /
+ * LeakyReLU in the reference):  g = dY*act'(raw*scale+shift);  dbeta (+)= sum g;  dgamma (+)= sum g*xhat;
+ * dRaw = scale*(g - mean(g) - xhat*mean(g*xhat)), written NHWC in `dtype` with channel stride
+ * c_stride_out (pad channels zero).  dy: NHWC `dtype` [P][c_stride]; raw: fp32 [P][c_stride_raw];
+ * stats: the [4][C] array of v2v_bn_finalize.  dgamma/dbeta may be NULL.
+ * workspace: (v2v_bn_backward_rows(P)*2*C + 2*C) floats. */
+int v2v_bn_backward_rows(int64_t P);
+int v2v_bn_backward(const void* dy, const float* raw, int32_t c_stride_raw, const float* stats,
+                    void* draw, int32_t c_stride_out, float* dgamma, float* dbeta, int32_t accumulate,
+                    float* workspace, int64_t P, int32_t C, int32_t c_stride,
+                    int32_t act, float act_param, int32_t dtype, void* stream);
+/* out[c] (+)= sum over pixels of x[p][c]  (bias gradients).  workspace: v2v_bn_backward_rows(P)*2*C floats */
+int v2v_channel_sum(const void* x, float* out, int32_t accumulate, float* workspace,
+                    int64_t P, int32_t C, int32_t c_stride, int32_t dtype, void* stream);
+/* Backward of a conv epilogue activation without norm: g = dY * act'(y) * out_scale.  dy / y are NHWC
+ * `dtype` [P][c_stride_in] (nchw = 0) or planar fp32 [N][C][H][W] (nchw = 1, API-facing heads);
+ * g is NHWC `dtype` [P][c_stride_out], pad channels zero. */
+int v2v_act_backward(const void* dy, const void* y, void* g, int32_t N, int32_t H, int32_t W, int32_t C,
+                     int32_t c_stride_in, int32_t c_stride_out, int32_t nchw, int32_t act, float act_param,
+                     float out_scale, int32_t dtype, void* stream);
+
 /* AvgPool2d(3, stride 2, pad 1, count_include_pad=False) on planar fp32 [planes][H][W]
  * (build_pyr, models/base_model.py:122-134; MultiscaleDiscriminator.downsample :652). */
 int v2v_avgpool3s2_planar(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream);
 /* same on NHWC activations */
 int v2v_avgpool3s2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t c_stride,
                         int32_t dtype, void* stream);
+
+int v2v_avgpool3s2_nhwc_backward(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t c_stride,
+                                 int32_t dtype, void* stream);   /* H, W: the pooled layer's INPUT size */
 
 /* encode_input (models/vid2vid_model_G.py:86-112) + get_edges (models/base_model.py:146-152)
  * + compute_mask (:322-330) for `T` frames, written straight to the NHWC stem input:
@@ -147,6 +204,18 @@ int v2v_pack_nchw_to_nhwc(const float* x, void* y, int32_t N, int32_t C, int32_t
 int v2v_unpack_nhwc_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W,
                             int32_t c_stride, int32_t dtype, void* stream);
 
+/* torch.cat([x0, x1], dim=1) of planar fp32 tensors written straight to NHWC (discriminator inputs,
+ * models/vid2vid_model_D.py:169-170,185-187); x1 may be NULL (C1 = 0) and is multiplied by scale1
+ * (the temporal discriminator sees flow_ref/20, vid2vid_model_D.py:107-108). */
+int v2v_pack_concat_nhwc(const float* x0, int32_t C0, const float* x1, int32_t C1, float scale1, void* y,
+                         int32_t N, int32_t H, int32_t W, int32_t c_stride, int32_t dtype, void* stream);
+/* channels [c_offset, c_offset+C) of an NHWC tensor -> planar fp32 NCHW (backward of the above) */
+int v2v_unpack_channels_nchw(const void* y, float* x, int32_t N, int32_t C, int32_t H, int32_t W,
+                             int32_t c_stride, int32_t c_offset, int32_t dtype, void* stream);
+/* backward of nn.ReflectionPad2d(pad): xp [N][H+2p][W+2p][cs] -> x [N][H][W][cs] */
+int v2v_reflect_pad_fold(const void* xp, void* x, int32_t N, int32_t H, int32_t W, int32_t pad,
+                         int32_t c_stride, int32_t dtype, void* stream);
+
 /* y = a + b on NHWC activations, n_elems = N*H*W*c_stride (models/networks.py:299,305,319) */
 int v2v_add_nhwc(const void* a, const void* b, void* y, int64_t n_elems, int32_t dtype, void* stream);
 
@@ -160,6 +229,19 @@ int v2v_warp_blend(float* img_raw, const float* flow, const float* weight, const
                    const float* fg, const float* mask, float* img_final, float* img_warp,
                    const float* gx, const float* gy,
                    int32_t N, int32_t C, int32_t H, int32_t W, int32_t align_corners, void* stream);
+
+/* Backward of v2v_warp_blend.  raw = the PRE-blend img_raw; d_rawout = gradient w.r.t. the blended
+ * img_raw output (NULL if unused); d_prev (optional) must be pre-zeroed, it is accumulated atomically
+ * like ATen's grid_sampler backward.  Gradient through the border clip follows ATen
+ * (clip_coordinates_set_grad: a clipped coordinate passes no gradient to the flow). */
+int v2v_warp_blend_backward(const float* d_final, const float* d_rawout, const float* raw, const float* flow,
+                            const float* weight, const float* prev, const float* fg, const float* mask,
+                            const float* gx, const float* gy, float* d_raw, float* d_flow, float* d_weight,
+                            float* d_prev, float* d_fg, int32_t N, int32_t C, int32_t H, int32_t W,
+                            int32_t align_corners, void* stream);
+int v2v_resample_flow_backward(const float* d_out, const float* img, const float* flow, const float* gx,
+                               const float* gy, float* d_img, float* d_flow, int32_t N, int32_t C,
+                               int32_t H, int32_t W, int32_t align_corners, void* stream);
 
 /* F.grid_sample(bilinear, border) driven by a pixel-unit flow, planar fp32 (resample()). */
 int v2v_resample_flow(const float* img, const float* flow, float* out, const float* gx, const float* gy,
@@ -183,6 +265,27 @@ int v2v_resample2d_forward(const float* img, const float* flow, float* out,
 /* channelnorm_cuda.forward (channelnorm_kernel.cu:18-60): out[b,0,y,x] = sqrt(sum_c x^2) */
 int v2v_channelnorm_forward(const float* x, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
                             int32_t norm_deg, void* stream);
+
+/* ---- losses and optimizer (models/networks.py:731-812, models/vid2vid_model_D.py:199-213; torch.optim.Adam) ----
+ * kind: 0 = mean((a - target)^2) (LSGAN GANLoss), 1 = mean(|a*m - b*m|) (L1Loss / MaskedL1Loss); result * weight.
+ * NHWC mode (planar = 0): a, b are [P][c_stride] activations of `dtype`, mean over P*C real elements;
+ * planar mode: fp32 [N][CHW/HW][HW], optional mask [N][1][HW] broadcast over channels.
+ * workspace: v2v_loss_workspace_floats() floats.  backward: da = d(out)/da * grad_out[0] (device scalar). */
+#define V2V_LOSS_MSE_CONST 0
+#define V2V_LOSS_L1        1
+int v2v_loss_workspace_floats(void);
+int v2v_loss_forward(int32_t kind, const void* a, const void* b, const float* mask, float target, float weight,
+                     int64_t P, int32_t C, int32_t c_stride, int64_t N, int64_t CHW, int64_t HW, int32_t planar,
+                     float* workspace, float* out, int32_t dtype, void* stream);
+int v2v_loss_backward(int32_t kind, const void* a, const void* b, const float* mask, float target, float weight,
+                      int64_t P, int32_t C, int32_t c_stride, int64_t N, int64_t CHW, int64_t HW, int32_t planar,
+                      const float* grad_out, void* da, int32_t dtype, void* stream);
+/* one fused Adam update over flat fp32 buffers; `step` is the 1-based count of this update; the gradient is
+ * read as grad * grad_scale (1/world after a sum all-reduce, so averaging costs no extra pass) */
+int v2v_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                  int32_t step, void* stream);
+int v2v_memset_zero(void* p, int64_t bytes, void* stream);
 
 /* ---- plan executor: a recorded launch sequence replayed as one call / one hipGraph ---- */
 typedef struct v2v_plan v2v_plan;

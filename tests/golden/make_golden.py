@@ -206,14 +206,109 @@ def golden_inference():
         save("inference_label2city_%s_32x64" % tag, **arrays)
 
 
+def golden_training():
+    """One training chunk of the reference itself: Vid2VidModelG.forward (models/vid2vid_model_G.py:114-196),
+    Vid2VidModelD.forward for the image and the temporal discriminators (models/vid2vid_model_D.py:93-213),
+    get_losses (:249-264) and the three backward passes of train.py:86-93 (no optimizer step), label2city
+    flags, n_scales_spatial = 2, 3 frames.  flow_ref / conf_ref are seeded tensors (FlowNet2 is CUDA-only)."""
+    import tempfile
+    from options.train_options import TrainOptions
+    ck = tempfile.mkdtemp()
+    sys.argv = ["train.py", "--name", "g", "--label_nc", "35", "--loadSize", "64", "--use_instance", "--fg",
+                "--gpu_ids", "-1", "--checkpoints_dir", ck, "--ngf", "8", "--n_blocks", "2", "--n_blocks_local", "1",
+                "--n_scales_spatial", "2", "--n_downsample_G", "2", "--no_vgg", "--num_D", "2", "--ndf", "8",
+                "--n_frames_total", "6", "--max_frames_per_gpu", "3", "--n_scales_temporal", "1",
+                "--niter_fix_global", "0"]
+    opt = TrainOptions().parse(save=False)
+    opt.gpu_ids = [-1]
+    opt.n_gpus_gen = 1
+    from models.vid2vid_model_G import Vid2VidModelG
+    from models.vid2vid_model_D import Vid2VidModelD
+    torch.manual_seed(70)
+    G = Vid2VidModelG(); G.initialize(opt)
+    D = Vid2VidModelD(); D.initialize(opt)
+    with torch.no_grad():
+        G.netG0.model_final_flow[1].weight.mul_(0.1)
+        G.netG1.model_final_flow[1].weight.mul_(0.1)
+    gen = torch.Generator().manual_seed(71)
+    H, W, tG, tD = 32, 64, 3, 3
+    nfl = G.n_frames_load
+    t_len = nfl + tG - 1
+    lab = synth_labels(gen, t_len, H, W, 35).view(1, t_len, 1, H, W)
+    inst = synth_labels(gen, t_len, H, W, 9).view(1, t_len, 1, H, W)
+    Bimg = torch.tanh(torch.nn.functional.interpolate(torch.randn(t_len, 3, H // 4, W // 4, generator=gen), scale_factor=4,
+                                                      mode="bilinear", align_corners=False)).view(1, t_len, 3, H, W)
+    flow_ref = torch.randn(1, nfl, 2, H, W, generator=gen) * 2.0
+    conf_ref = (torch.rand(1, nfl, 1, H, W, generator=gen) > 0.3).float()
+
+    def reshape(ts):
+        return [None if t is None else t.contiguous().view(-1, t.size(2), t.size(3), t.size(4)) for t in ts]
+
+    fake_B, fake_B_raw, flow, weight, real_A, real_Bp, fake_B_last = G(lab, Bimg, inst, None)
+    real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
+    fake_B_prev = G.compute_fake_B_prev(real_B_prev, None, fake_B)
+    losses = D(0, reshape([real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref]))
+    losses = [torch.mean(x) if x is not None else 0 for x in losses]
+    loss_dict = dict(zip(D.loss_names, losses))
+    frames_all = (None, None, None, None)
+    frames_all, frames_skipped = D.get_all_skipped_frames(frames_all, real_B, fake_B, flow_ref, conf_ref, 1, tD, nfl, 0, None)
+    loss_dict_T = []
+    if frames_skipped[0][0] is not None:
+        lt = D(1, [f[0] for f in frames_skipped])
+        lt = [torch.mean(x) if not isinstance(x, int) else x for x in lt]
+        loss_dict_T.append(dict(zip(D.loss_names_T, lt)))
+    loss_G, loss_D, loss_D_T, t_act = D.get_losses(loss_dict, loss_dict_T, 1)
+    assert t_act == 1
+
+    nets = {"G0": G.netG0, "G1": G.netG1, "D": D.netD, "DT0": D.netD_T0}
+
+    def zero():
+        for n in nets.values():
+            for p in n.parameters():
+                p.grad = None
+
+    arrays = {}
+    for k, n in nets.items():
+        arrays.update(sd_to_np(n.state_dict(), "sd%s." % k))
+
+    def grab(tag, keys):
+        for k in keys:
+            for name, p in nets[k].named_parameters():
+                if p.grad is not None:
+                    arrays["grad%s.%s.%s" % (tag, k, name)] = p.grad.detach().numpy().copy()
+
+    zero(); loss_G.backward(retain_graph=True); grab("G", ["G0", "G1"])
+    zero(); loss_D.backward(retain_graph=True); grab("D", ["D"])
+    zero(); loss_D_T[0].backward(); grab("DT", ["DT0"])
+    arrays.update({"in.labels": lab.numpy(), "in.inst": inst.numpy(), "in.B": Bimg.numpy(),
+                   "in.flow_ref": flow_ref.numpy(), "in.conf_ref": conf_ref.numpy(),
+                   "out.fake_B": fake_B.detach().numpy(), "out.fake_B_raw": fake_B_raw.detach().numpy(),
+                   "out.flow": flow.detach().numpy(), "out.weight": weight.detach().numpy(),
+                   "out.real_A": real_A.detach().numpy()})
+    for k, v in loss_dict.items():
+        arrays["loss." + k] = np.array(float(v))
+    for k, v in loss_dict_T[0].items():
+        arrays["loss." + k] = np.array(float(v))
+    arrays["loss.total_G"] = np.array(float(loss_G)); arrays["loss.total_D"] = np.array(float(loss_D))
+    arrays["loss.total_D_T0"] = np.array(float(loss_D_T[0]))
+    for i, t in enumerate(frames_skipped):
+        arrays["skipped.%d" % i] = t[0].detach().numpy()
+    save("training_label2city_s2_32x64", **arrays)
+    print({k: float(v) for k, v in arrays.items() if k.startswith("loss.")})
+
+
 def main():
     install_shims()
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only == "training":
+        return golden_training()
     from models import networks
     golden_composite(networks)
     golden_composite_local(networks)
     golden_discriminator(networks)
     golden_global(networks)
     golden_inference()
+    golden_training()
 
 
 if __name__ == "__main__":

@@ -43,11 +43,11 @@ def test_packed_weight_size_rule():
     from vid2vid_amd import lib
     L = lib.lib
     # Conv2d 3x3 1024->1024 bf16: [1024][9*1024]
-    assert L.v2v_conv_packed_elems(1024, 1024, 1024, 3, 3, 0, 1, lib.BF16) == 1024 * 9216
+    assert L.v2v_conv_packed_elems(1024, 1024, 1024, 3, 3, 0, 1, 1, lib.BF16) == 1024 * 9216
     # ConvTranspose2d 3x3 s2 p1: parity classes have 1,2,2,4 taps
-    assert L.v2v_conv_packed_elems(64, 64, 128, 3, 3, 1, 1, lib.F32) == 128 * 64 * (1 + 2 + 2 + 4)
+    assert L.v2v_conv_packed_elems(64, 64, 128, 3, 3, 1, 2, 1, lib.F32) == 128 * 64 * (1 + 2 + 2 + 4)
     # K padded to 128 bytes, cout padded to 128 rows
-    assert L.v2v_conv_packed_elems(6, 8, 3, 7, 7, 0, 0, lib.BF16) == 128 * 448
+    assert L.v2v_conv_packed_elems(6, 8, 3, 7, 7, 0, 1, 0, lib.BF16) == 128 * 448
 
 
 def test_correlation_output_size_rule():

@@ -1,0 +1,378 @@
+"""GPU parity tests of the training-path custom ops (forward AND backward kernels through the C ABI)
+against torch CPU autograd of the same op in fp32.
+
+Tolerance: the backward kernels accumulate in exact fp32 (v_mfma_f32_32x32x2_f32 / fp32 VALU); only the
+summation order differs from ATen's CPU kernels -> 2e-4 per element with the rms floor of
+util.assert_close (north_star bound: 1e-3).  bf16 storage mode is checked at 3e-2 on the gradients
+(inputs, saved activations and dY are bf16-rounded; accumulation stays fp32).
+"""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _engine(prec="fp32"):
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.engine import Engine
+    return Engine(DEV, L.BF16 if prec == "bf16" else L.F32)
+
+
+def _pad_mode(mode):
+    from vid2vid_amd import lib as L
+    return L.PAD_REFLECT if mode == "reflect" else L.PAD_ZERO
+
+
+CONV_BWD_CASES = [
+    # cin, cout, k, stride, pad, mode, H, W, N
+    (16, 32, 3, 1, 1, "reflect", 16, 24, 2),
+    (64, 64, 3, 1, 1, "reflect", 18, 34, 1),
+    (12, 8, 7, 1, 3, "reflect", 20, 28, 1),
+    (6, 16, 7, 1, 3, "reflect", 9, 11, 2),      # pad 3 on a 9-wide image: overlapping mirror strips
+    (32, 64, 3, 2, 1, "zero", 32, 48, 1),
+    (32, 48, 3, 2, 1, "zero", 31, 45, 2),       # odd sizes: parity classes with different grids
+    (13, 16, 4, 2, 2, "zero", 33, 47, 1),       # PatchGAN layers (networks.py:685-706)
+    (16, 32, 4, 2, 2, "zero", 32, 64, 2),
+    (16, 32, 4, 1, 2, "zero", 17, 19, 1),
+    (32, 1, 4, 1, 2, "zero", 18, 22, 2),
+    (128, 3, 7, 1, 3, "reflect", 24, 40, 1),
+    (40, 24, 5, 2, 2, "zero", 30, 42, 1),       # FlowNet2 shapes
+    (24, 16, 1, 1, 0, "zero", 13, 29, 1),
+    (136, 200, 3, 1, 1, "zero", 12, 20, 1),     # several row / column tiles in the wgrad GEMM
+]
+
+
+def _ref_conv(x, conv, k, stride, pad, mode):
+    xp = F.pad(x, (pad,) * 4, mode="reflect") if mode == "reflect" else x
+    return F.conv2d(xp, conv.weight, conv.bias, stride=stride, padding=0 if mode == "reflect" else pad)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_BWD_CASES)
+def test_conv2d_backward(case, prec):
+    from vid2vid_amd import lib as L
+    from vid2vid_amd import autograd as AG
+    cin, cout, k, stride, pad, mode, H, W, N = case
+    torch.manual_seed(sum(case[:5]) + H)
+    eng = _engine(prec)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=0 if mode == "reflect" else pad)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.2)
+        conv.bias.normal_(0, 0.5)
+    x = torch.randn(N, cin, H, W)
+    rnd = (lambda t: t.bfloat16().float()) if prec == "bf16" else (lambda t: t.clone())
+    # ---- CPU autograd reference (operands rounded like the device copy) ----
+    xr = rnd(x).requires_grad_(True)
+    cref = nn.Conv2d(cin, cout, k, stride=stride, padding=0 if mode == "reflect" else pad)
+    with torch.no_grad():
+        cref.weight.copy_(rnd(conv.weight)); cref.bias.copy_(conv.bias)
+    yr = F.leaky_relu(_ref_conv(xr, cref, k, stride, pad, mode), 0.2)
+    r = rnd(torch.randn_like(yr))
+    (yr * r).sum().backward()
+    # ---- HIP ----
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    xa = eng.pack(xg)
+    assert xa.t.requires_grad
+    ya = AG.conv_group(eng, xa, conv, _pad_mode(mode), pad, None, L.ACT_LEAKY, 0.2, None, None, False, 1.0, "t")
+    y = eng.unpack(ya)
+    tol_f = 1e-4 if prec == "fp32" else 1e-2
+    assert_close(y.detach().cpu(), yr.detach(), tol_f, "forward " + str(case))
+    (y * r.to(DEV)).sum().backward()
+    tol = 2e-4 if prec == "fp32" else 3e-2
+    assert_close(xg.grad.cpu(), xr.grad, tol, "dX " + str(case))
+    assert_close(conv.weight.grad.cpu(), cref.weight.grad, tol, "dW " + str(case))
+    assert_close(conv.bias.grad.cpu(), cref.bias.grad, tol, "db " + str(case))
+    # gradient accumulation into an existing .grad buffer (kernels add in place)
+    y2 = eng.unpack(AG.conv_group(eng, eng.pack(xg), conv, _pad_mode(mode), pad, None, L.ACT_LEAKY, 0.2, None, None,
+                                  False, 1.0, "t"))
+    (y2 * r.to(DEV)).sum().backward()
+    assert_close(conv.weight.grad.cpu(), 2 * cref.weight.grad, tol, "dW accumulate " + str(case))
+
+
+CONVT_CASES = [
+    # cin, cout, k, pad, out_pad, H, W, N
+    (32, 16, 3, 1, 1, 12, 20, 2),      # generator up path (networks.py:176)
+    (64, 32, 3, 1, 1, 9, 7, 1),
+    (24, 8, 4, 1, 0, 10, 14, 1),       # FlowNet2 deconv (submodules.py:24-31)
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose2d_backward(case, prec):
+    from vid2vid_amd import lib as L
+    from vid2vid_amd import autograd as AG
+    cin, cout, k, pad, op, H, W, N = case
+    torch.manual_seed(sum(case))
+    eng = _engine(prec)
+    conv = nn.ConvTranspose2d(cin, cout, k, stride=2, padding=pad, output_padding=op)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.2)
+        conv.bias.normal_(0, 0.5)
+    rnd = (lambda t: t.bfloat16().float()) if prec == "bf16" else (lambda t: t.clone())
+    x = torch.randn(N, cin, H, W)
+    xr = rnd(x).requires_grad_(True)
+    cref = nn.ConvTranspose2d(cin, cout, k, stride=2, padding=pad, output_padding=op)
+    with torch.no_grad():
+        cref.weight.copy_(rnd(conv.weight)); cref.bias.copy_(conv.bias)
+    yr = F.relu(cref(xr))
+    r = rnd(torch.randn_like(yr))
+    (yr * r).sum().backward()
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    ya = AG.conv_group(eng, eng.pack(xg), conv, L.PAD_ZERO, None, None, L.ACT_RELU, 0.0, None, None, False, 1.0, "t")
+    y = eng.unpack(ya)
+    assert_close(y.detach().cpu(), yr.detach(), 1e-4 if prec == "fp32" else 1e-2, "forward " + str(case))
+    (y * r.to(DEV)).sum().backward()
+    tol = 2e-4 if prec == "fp32" else 3e-2
+    assert_close(xg.grad.cpu(), xr.grad, tol, "dX " + str(case))
+    assert_close(conv.weight.grad.cpu(), cref.weight.grad, tol, "dW " + str(case))
+    assert_close(conv.bias.grad.cpu(), cref.bias.grad, tol, "db " + str(case))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("norm_kind", ["batch", "instance"])
+@pytest.mark.parametrize("act", ["relu", "leaky", "none"])
+def test_conv_norm_act_residual_backward(norm_kind, act, prec):
+    """ResnetBlock-style group: reflect conv + training-mode norm + activation + two residual adds."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd import autograd as AG
+    from vid2vid_amd.engine import Act
+    torch.manual_seed(11)
+    eng = _engine(prec)
+    N, C, H, W = (2 if norm_kind == "batch" else 1), 24, 14, 18
+    conv = nn.Conv2d(C, C, 3)
+    norm = nn.BatchNorm2d(C, affine=True) if norm_kind == "batch" else nn.InstanceNorm2d(C, affine=False)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.2); conv.bias.normal_(0, 0.3)
+        if norm_kind == "batch":
+            norm.weight.normal_(1, 0.2); norm.bias.normal_(0, 0.3)
+    rnd = (lambda t: t.bfloat16().float()) if prec == "bf16" else (lambda t: t.clone())
+    x, a0, a1 = torch.randn(N, C, H, W), torch.randn(N, C, H, W), torch.randn(N, C, H, W)
+    xr, a0r, a1r = [rnd(t).requires_grad_(True) for t in (x, a0, a1)]
+    cref = nn.Conv2d(C, C, 3)
+    with torch.no_grad():
+        cref.weight.copy_(rnd(conv.weight)); cref.bias.copy_(conv.bias)
+    raw = cref(F.pad(xr, (1,) * 4, mode="reflect"))
+    if norm_kind == "batch":
+        gam = norm.weight.detach().clone().requires_grad_(True)
+        bet = norm.bias.detach().clone().requires_grad_(True)
+        h = F.batch_norm(raw, None, None, gam, bet, True, 0.1, 1e-5)
+    else:
+        h = F.instance_norm(raw, eps=1e-5)
+    h = {"relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.2), "none": lambda t: t}[act](h)
+    yr = h + a0r + a1r
+    r = rnd(torch.randn_like(yr))
+    (yr * r).sum().backward()
+
+    conv, norm = conv.to(DEV), norm.to(DEV)
+    xg, a0g, a1g = [t.to(DEV).requires_grad_(True) for t in (x, a0, a1)]
+    code = {"relu": (L.ACT_RELU, 0.0), "leaky": (L.ACT_LEAKY, 0.2), "none": (L.ACT_NONE, 0.0)}[act]
+    ya = AG.conv_group(eng, eng.pack(xg), conv, L.PAD_REFLECT, 1, norm, code[0], code[1], eng.pack(a0g), eng.pack(a1g),
+                       False, 1.0, "t")
+    y = eng.unpack(ya)
+    assert_close(y.detach().cpu(), yr.detach(), 2e-4 if prec == "fp32" else 2e-2, "forward")
+    (y * r.to(DEV)).sum().backward()
+    tol = 3e-4 if prec == "fp32" else 4e-2
+    assert_close(xg.grad.cpu(), xr.grad, tol, "dX")
+    assert_close(a0g.grad.cpu(), a0r.grad, tol, "d add0")
+    assert_close(a1g.grad.cpu(), a1r.grad, tol, "d add1")
+    assert_close(conv.weight.grad.cpu(), cref.weight.grad, tol, "dW")
+    if norm_kind == "batch":
+        assert_close(norm.weight.grad.cpu(), gam.grad, tol, "dgamma")
+        assert_close(norm.bias.grad.cpu(), bet.grad, tol, "dbeta")
+    # a conv bias in front of a norm has a mathematically zero gradient: both sides are rounding noise
+    assert conv.bias.grad.abs().max().item() < 1e-2 * (conv.weight.grad.abs().max().item() + 1e-6) + 1e-3
+
+
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "none"])
+def test_head_nchw_backward(act):
+    """7x7 reflect heads writing planar NCHW with tanh / sigmoid / x20 scale (networks.py:178,182-183,212)."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd import autograd as AG
+    torch.manual_seed(5)
+    eng = _engine("fp32")
+    cin, cout, H, W = 32, {"tanh": 3, "sigmoid": 1, "none": 2}[act], 16, 24
+    scale = 20.0 if act == "none" else 1.0
+    conv = nn.Conv2d(cin, cout, 7)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.05); conv.bias.normal_(0, 0.1)
+    x = torch.randn(1, cin, H, W)
+    xr = x.clone().requires_grad_(True)
+    cref = nn.Conv2d(cin, cout, 7)
+    cref.load_state_dict(conv.state_dict())
+    raw = cref(F.pad(xr, (3,) * 4, mode="reflect"))
+    yr = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "none": lambda t: t}[act](raw) * scale
+    r = torch.randn_like(yr)
+    (yr * r).sum().backward()
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    code = {"tanh": L.ACT_TANH, "sigmoid": L.ACT_SIGMOID, "none": L.ACT_NONE}[act]
+    y = AG.conv_group(eng, eng.pack(xg), conv, L.PAD_REFLECT, 3, None, code, 0.0, None, None, True, scale, "head")
+    assert y.shape == yr.shape and y.dtype == torch.float32
+    assert_close(y.detach().cpu(), yr.detach(), 1e-4, "forward")
+    (y * r.to(DEV)).sum().backward()
+    assert_close(xg.grad.cpu(), xr.grad, 2e-4, "dX")
+    assert_close(conv.weight.grad.cpu(), cref.weight.grad, 2e-4, "dW")
+    assert_close(conv.bias.grad.cpu(), cref.bias.grad, 2e-4, "db")
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 17, 23), (2, 8, 16, 32), (1, 3, 1, 9)])
+def test_avgpool_nhwc_backward(shape):
+    torch.manual_seed(3)
+    eng = _engine("fp32")
+    x = torch.randn(*shape)
+    xr = x.clone().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 3, stride=2, padding=1, count_include_pad=False)
+    r = torch.randn_like(yr)
+    (yr * r).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    y = eng.unpack(eng.avgpool_nhwc(eng.pack(xg)))
+    assert_close(y.detach().cpu(), yr.detach(), 1e-5, "forward")
+    (y * r.to(DEV)).sum().backward()
+    assert_close(xg.grad.cpu(), xr.grad, 1e-5, "dX")
+
+
+def _ref_resample(img, flow):
+    from oracle import vid2vid_oracle as O
+    return O.resample(img, flow, align_corners=False)
+
+
+def test_pack_concat_and_scale():
+    from vid2vid_amd import autograd as AG
+    torch.manual_seed(2)
+    eng = _engine("fp32")
+    a, b = torch.randn(2, 5, 7, 9), torch.randn(2, 2, 7, 9)
+    ag = a.to(DEV).requires_grad_(True)
+    x = AG.pack_concat(eng, ag, b.to(DEV), 1.0 / 20.0)
+    y = eng.unpack(x)
+    assert_close(y.detach().cpu(), torch.cat([a, b / 20.0], 1), 1e-6, "concat")
+    r = torch.randn_like(y)
+    (y * r).sum().backward()
+    assert_close(ag.grad.cpu(), r[:, :5].cpu(), 1e-6, "d x0")
+
+
+@pytest.mark.parametrize("with_fg", [False, True])
+@pytest.mark.parametrize("prev_grad", [False, True])
+def test_warp_blend_backward(with_fg, prev_grad):
+    """Composite tail vs the reference expression (networks.py:216-230) under CPU autograd."""
+    torch.manual_seed(17)
+    eng = _engine("fp32")
+    N, C, H, W = 1, 3, 20, 28
+    raw = torch.tanh(torch.randn(N, C, H, W))
+    flow = torch.randn(N, 2, H, W) * 3.0
+    flow[0, 0, 0, :4] = 40.0            # clipped coordinates: no gradient to the flow there (ATen semantics)
+    flow[0, 1, -1, :4] = -40.0
+    wgt = torch.sigmoid(torch.randn(N, 1, H, W))
+    prev = torch.tanh(F.interpolate(torch.randn(N, C, 5, 7), size=(H, W), mode="bilinear", align_corners=False))
+    fg = torch.tanh(torch.randn(N, C, H, W))
+    mask = (torch.rand(N, 1, H, W) > 0.6).float()
+    ts = [raw, flow, wgt, prev, fg]
+    tr = [t.clone().requires_grad_(True) for t in ts]
+    warp = _ref_resample(tr[3], tr[1])
+    fin = tr[0] * tr[2] + warp * (1 - tr[2])
+    rawo = tr[0]
+    if with_fg:
+        fin = tr[4] * mask + fin * (1 - mask)
+        rawo = tr[4] * mask + tr[0] * (1 - mask)
+    r1, r2 = torch.randn_like(fin), torch.randn_like(fin)
+    ((fin * r1).sum() + (rawo * r2).sum()).backward()
+
+    tg = [t.to(DEV).requires_grad_(True) for t in ts]
+    if not prev_grad:
+        tg[3] = prev.to(DEV)
+    (final, raw_blend), _ = eng.warp_blend(tg[0], tg[1], tg[2], tg[3], tg[4] if with_fg else None,
+                                           mask.to(DEV) if with_fg else None)
+    assert_close(final.detach().cpu(), fin.detach(), 1e-5, "final")
+    assert_close(raw_blend.detach().cpu(), rawo.detach(), 1e-6, "raw blend")
+    ((final * r1.to(DEV)).sum() + (raw_blend * r2.to(DEV)).sum()).backward()
+    assert_close(tg[0].grad.cpu(), tr[0].grad, 1e-5, "d raw")
+    assert_close(tg[1].grad.cpu(), tr[1].grad, 1e-4, "d flow")
+    assert_close(tg[2].grad.cpu(), tr[2].grad, 1e-4, "d weight")
+    if prev_grad:
+        assert_close(tg[3].grad.cpu(), tr[3].grad, 1e-4, "d prev")
+    if with_fg:
+        assert_close(tg[4].grad.cpu(), tr[4].grad, 1e-5, "d fg")
+
+
+def test_resample_backward():
+    torch.manual_seed(23)
+    eng = _engine("fp32")
+    img = torch.randn(2, 3, 12, 16)
+    flow = torch.randn(2, 2, 12, 16) * 2.5
+    ir, fr = img.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    out = _ref_resample(ir, fr)
+    r = torch.randn_like(out)
+    (out * r).sum().backward()
+    ig, fg_ = img.to(DEV).requires_grad_(True), flow.to(DEV).requires_grad_(True)
+    o = eng.resample_flow(ig, fg_)
+    assert_close(o.detach().cpu(), out.detach(), 1e-5, "forward")
+    (o * r.to(DEV)).sum().backward()
+    assert_close(ig.grad.cpu(), ir.grad, 1e-4, "d img")
+    assert_close(fg_.grad.cpu(), fr.grad, 1e-4, "d flow")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_losses_forward_backward(prec):
+    from vid2vid_amd import autograd as AG
+    torch.manual_seed(29)
+    eng = _engine(prec)
+    rnd = (lambda t: t.bfloat16().float()) if prec == "bf16" else (lambda t: t.clone())
+    tol = 1e-5 if prec == "fp32" else 1e-2
+    # GANLoss / feature matching on NHWC activations (pad channels must not count)
+    a, b = rnd(torch.randn(2, 5, 9, 11)), rnd(torch.randn(2, 5, 9, 11))
+    ar = a.clone().requires_grad_(True)
+    lr_ = F.mse_loss(ar, torch.ones_like(ar)) * 1.0 + F.l1_loss(ar, b) * 2.5
+    lr_.backward()
+    ag = a.to(DEV).requires_grad_(True)
+    xa, xb = eng.pack(ag), eng.pack(b.to(DEV))
+    l = AG.mse_const_act(eng, xa, 1.0) + AG.l1_act(eng, xa, xb, weight=2.5)
+    assert l.shape == (1, 1)
+    assert abs(l.item() - lr_.item()) <= tol * max(1.0, abs(lr_.item()))
+    l.sum().backward()
+    assert_close(ag.grad.cpu(), ar.grad, 1e-5 if prec == "fp32" else 2e-2, "d a (nhwc)")
+    # MaskedL1Loss on planar tensors (always fp32 at the API)
+    p, q = torch.randn(2, 3, 9, 11), torch.randn(2, 3, 9, 11)
+    m = (torch.rand(2, 1, 9, 11) > 0.4).float()
+    pr = p.clone().requires_grad_(True)
+    me = m.expand(-1, 3, -1, -1)
+    lm = F.l1_loss(pr * me, q * me) * 10.0
+    lm.backward()
+    pg = p.to(DEV).requires_grad_(True)
+    l2 = AG.masked_l1(eng, pg, q.to(DEV), m.to(DEV), weight=10.0)
+    assert abs(l2.item() - lm.item()) <= 1e-5 * max(1.0, abs(lm.item()))
+    l2.sum().backward()
+    assert_close(pg.grad.cpu(), pr.grad, 1e-5, "d a (masked planar)")
+
+
+def test_fused_adam_matches_torch():
+    from vid2vid_amd.optim import FusedAdam
+    torch.manual_seed(31)
+    shapes = [(7, 5, 3, 3), (13,), (4, 9)]
+    ref_p = [nn.Parameter(torch.randn(*s)) for s in shapes]
+    dev_p = [nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    ref_opt = torch.optim.Adam(ref_p, lr=2e-4, betas=(0.5, 0.999))
+    opt = FusedAdam(dev_p, lr=2e-4, betas=(0.5, 0.999))
+    for it in range(4):
+        grads = [torch.randn(*s) for s in shapes]
+        ref_opt.zero_grad(); opt.zero_grad()
+        for p, g in zip(ref_p, grads):
+            p.grad = g.clone()
+        for p, g in zip(dev_p, grads):
+            assert p.grad is not None and float(p.grad.abs().sum()) == 0.0      # zeroed flat views
+            p.grad.add_(g.to(DEV))
+        ref_opt.step(); opt.step()
+    for p, q in zip(dev_p, ref_p):
+        assert_close(p.detach().cpu(), q.detach(), 1e-6, "adam parameter")
+    # TTUR variant: beta1 = 0 (vid2vid_model_G.py:78-80)
+    p1, p2 = nn.Parameter(torch.ones(5)), nn.Parameter(torch.ones(5, device=DEV))
+    o1, o2 = torch.optim.Adam([p1], lr=1e-3, betas=(0.0, 0.9)), FusedAdam([p2], lr=1e-3, betas=(0.0, 0.9))
+    p1.grad = torch.arange(5.0); p2.grad.copy_(torch.arange(5.0).to(DEV))
+    o1.step(); o2.step()
+    assert_close(p2.detach().cpu(), p1.detach(), 1e-6, "adam ttur")

@@ -51,7 +51,7 @@ struct ConvKArgs {
     int sm;              // input step per class-grid step (conv: stride, convT: 1)
     int os;              // output step per class-grid step (conv: 1, convT: 2)
     int pad_mode;
-    int Mc, OHc, OWc;    // rows per class and class grid
+    int Mc[4], OHc[4], OWc[4];   // rows per class and class grid (transposed: output pixels of parity class)
     int m_tiles, n_tiles;
     int out_mode, act;
     float act_param, out_scale;
@@ -144,16 +144,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
     int pixbase[RA], ohs[RA], ows[RA];
     unsigned rowvalid = 0;
     {
-        const int hw = p.OHc * p.OWc;
+        const int owc = p.OWc[cls];
+        const int hw = p.OHc[cls] * owc;
+        const int mcls = p.Mc[cls];
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = mt * BM + lrow + 32 * i;
-            const bool ok = m < p.Mc;
+            const bool ok = m < mcls;
             const int mm = ok ? m : 0;
             const int n = mm / hw;
             const int rem = mm - n * hw;
-            const int oi = rem / p.OWc;
-            const int oj = rem - oi * p.OWc;
+            const int oi = rem / owc;
+            const int oj = rem - oi * owc;
             pixbase[i] = n * H * W;
             ohs[i] = oi * p.sm;
             ows[i] = oj * p.sm;
@@ -305,7 +307,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
     float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2]
     const bool want_stats = p.stats != nullptr;
     const int a_par = cls >> 1, b_par = cls & 1;
-    const int hwc = p.OHc * p.OWc;
+    const int owc_e = p.OWc[cls];
+    const int hwc = p.OHc[cls] * owc_e;
+    const int mcls_e = p.Mc[cls];
     const long long ohow = (long long)p.OH * p.OW;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int m = mt * BM + row;
-                if (m < p.Mc && nvalid) {
+                if (m < mcls_e && nvalid) {
                     float v = acc[i][j][r] + bv;
                     long long opix;   // output pixel index in [N][OH][OW]
                     if (p.os == 1) {
@@ -327,8 +331,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
                     } else {
                         const int n = m / hwc;
                         const int rem = m - n * hwc;
-                        const int oi = rem / p.OWc;
-                        const int oj = rem - oi * p.OWc;
+                        const int oi = rem / owc_e;
+                        const int oj = rem - oi * owc_e;
                         opix = ((long long)n * p.OH + (oi * 2 + a_par)) * p.OW + (oj * 2 + b_par);
                     }
                     if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
@@ -394,8 +398,10 @@ static const TileCfg* find_cfg(int id) {
 
 static int bke_of(int dtype) { return dtype == V2V_BF16 ? 64 : 32; }
 
-// taps of transposed-conv parity class `par` along one axis
-static void convt_axis(int K, int pad, int par, int* k0, int* nk, int* d0) {
+// taps of transposed-conv output class `par` (output index = stride*i + par) along one axis:
+// kernel taps k = k0 + stride*t, t = 0..nk-1, read input index i + d0 - t.
+static void convt_axis(int K, int pad, int stride, int par, int* k0, int* nk, int* d0) {
+    if (stride == 1) { *k0 = 0; *nk = K; *d0 = pad; return; }
     *k0 = (par + pad) & 1;
     *nk = (*k0 < K) ? (K - *k0 + 1) / 2 : 0;
     *d0 = (par + pad - *k0) / 2;   // (par+pad-k0) is even
@@ -409,7 +415,7 @@ struct ConvGeom {
     int cout_p;
 };
 
-static int conv_geom(int cin_stride, int cout, int KH, int KW, int transposed, int pad, int dtype, ConvGeom* g) {
+static int conv_geom(int cin_stride, int cout, int KH, int KW, int transposed, int stride, int pad, int dtype, ConvGeom* g) {
     const int bke = bke_of(dtype);
     memset(g, 0, sizeof(*g));
     g->cout_p = (int)round_up(cout, 128);
@@ -423,11 +429,11 @@ static int conv_geom(int cin_stride, int cout, int KH, int KW, int transposed, i
         g->woff[0] = 0;
         off = (long long)g->cout_p * g->kpad[0];
     } else {
-        g->ncls = 4;
-        for (int c = 0; c < 4; ++c) {
+        g->ncls = stride == 1 ? 1 : 4;
+        for (int c = 0; c < g->ncls; ++c) {
             const int a = c >> 1, b = c & 1;
-            convt_axis(KH, pad, a, &g->kh0[c], &g->nkh[c], &g->dh0[c]);
-            convt_axis(KW, pad, b, &g->kw0[c], &g->nkw[c], &g->dw0[c]);
+            convt_axis(KH, pad, stride, a, &g->kh0[c], &g->nkh[c], &g->dh0[c]);
+            convt_axis(KW, pad, stride, b, &g->kw0[c], &g->nkw[c], &g->dw0[c]);
             g->ktot[c] = g->nkh[c] * g->nkw[c] * cin_stride;
             g->kpad[c] = (int)round_up(g->ktot[c] > 0 ? g->ktot[c] : 1, bke);
             g->woff[c] = off;
@@ -441,7 +447,7 @@ static int conv_geom(int cin_stride, int cout, int KH, int KW, int transposed, i
 // ---- weight packing kernel: PyTorch layout fp32 -> packed class matrices ----------------
 struct PackArgs {
     const float* w; void* dst;
-    int cin, cin_stride, cout, cout_p, KH, KW, transposed;
+    int cin, cin_stride, cout, cout_p, KH, KW, transposed, kstep;
     int ncls;
     int nkh[4], nkw[4], kh0[4], kw0[4], kpad[4];
     long long woff[4];
@@ -467,7 +473,7 @@ __global__ void pack_weights_kernel(const PackArgs a) {
         if (co < a.cout && t < ntaps && c < a.cin) {
             const int th = t / a.nkw[cls], tw = t - th * a.nkw[cls];
             int kh, kw;
-            if (a.transposed) { kh = a.kh0[cls] + 2 * th; kw = a.kw0[cls] + 2 * tw; }
+            if (a.transposed) { kh = a.kh0[cls] + a.kstep * th; kw = a.kw0[cls] + a.kstep * tw; }
             else              { kh = th; kw = tw; }
             long long src;
             if (a.transposed) src = (((long long)c * a.cout + co) * a.KH + kh) * a.KW + kw;   // [cin][cout][kh][kw]
@@ -546,10 +552,16 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op) {
     if (d->dtype != V2V_F32 && d->dtype != V2V_BF16) { set_error("conv: bad dtype"); return V2V_EINVAL; }
     const int vec = d->dtype == V2V_BF16 ? 8 : 4;
     if (d->cin_stride % vec != 0 || d->cin > d->cin_stride) { set_error("conv: cin_stride %d not a multiple of %d", d->cin_stride, vec); return V2V_EINVAL; }
-    if (d->transposed && (d->stride != 2 || d->OH != 2 * d->H || d->OW != 2 * d->W || d->pad_mode != V2V_PAD_ZERO)) {
-        set_error("conv: transposed conv supports stride 2 with OH = 2H only"); return V2V_EINVAL;
-    }
-    if (!d->transposed) {
+    if (d->stride != 1 && d->stride != 2) { set_error("conv: stride %d (1 or 2 supported)", d->stride); return V2V_EINVAL; }
+    if (d->transposed) {
+        // nn.ConvTranspose2d(stride s, padding p, output_padding op < s): OH = (H-1)*s - 2p + KH + op
+        const int oh0 = (d->H - 1) * d->stride - 2 * d->pad + d->KH, ow0 = (d->W - 1) * d->stride - 2 * d->pad + d->KW;
+        if (d->pad_mode != V2V_PAD_ZERO || d->OH < 1 || d->OW < 1 || d->OH > oh0 + d->stride - 1 || d->OW > ow0 + d->stride - 1) {
+            set_error("conv: transposed conv output (%d,%d) inconsistent with input (%d,%d) k=%d s=%d p=%d",
+                      d->OH, d->OW, d->H, d->W, d->KH, d->stride, d->pad);
+            return V2V_EINVAL;
+        }
+    } else {
         const int oh = (d->H + 2 * d->pad - d->KH) / d->stride + 1, ow = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
         if (oh != d->OH || ow != d->OW) { set_error("conv: OH/OW mismatch (%d,%d) vs (%d,%d)", d->OH, d->OW, oh, ow); return V2V_EINVAL; }
         if (d->pad_mode == V2V_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) { set_error("conv: reflect pad >= size"); return V2V_EINVAL; }
@@ -557,7 +569,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op) {
     if (d->out_mode != V2V_OUT_F32_NCHW && d->cout > d->cout_stride) { set_error("conv: cout_stride"); return V2V_EINVAL; }
     if (((uintptr_t)d->in | (uintptr_t)d->w | (uintptr_t)d->zero_page) & 15) { set_error("conv: operands must be 16-byte aligned"); return V2V_EINVAL; }
     ConvGeom g;
-    conv_geom(d->cin_stride, d->cout, d->KH, d->KW, d->transposed, d->pad, d->dtype, &g);
+    conv_geom(d->cin_stride, d->cout, d->KH, d->KW, d->transposed, d->stride, d->pad, d->dtype, &g);
     ConvKArgs& k = op->k;
     memset(&k, 0, sizeof(k));
     k.in = (const char*)d->in; k.w = (const char*)d->w; k.zero_page = (const char*)d->zero_page;
@@ -566,11 +578,21 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op) {
     k.cout = d->cout; k.cout_stride = d->cout_stride; k.cout_p = g.cout_p;
     k.OH = d->OH; k.OW = d->OW;
     k.pad_mode = d->pad_mode;
-    if (d->transposed) { k.sm = 1; k.os = 2; k.OHc = d->H; k.OWc = d->W; k.dstep = -1; }
-    else               { k.sm = d->stride; k.os = 1; k.OHc = d->OH; k.OWc = d->OW; k.dstep = 1; }
-    const long long Mc = (long long)d->N * k.OHc * k.OWc;
-    if (Mc >= (1ll << 31) || (long long)d->N * d->H * d->W >= (1ll << 31)) { set_error("conv: too many pixels"); return V2V_EINVAL; }
-    k.Mc = (int)Mc;
+    if ((long long)d->N * d->H * d->W >= (1ll << 31) || (long long)d->N * d->OH * d->OW >= (1ll << 31)) { set_error("conv: too many pixels"); return V2V_EINVAL; }
+    if (d->transposed) {
+        // class (a,b) owns output pixels (os*i + a, os*j + b); its grid is ceil((OH-a)/os) x ceil((OW-b)/os)
+        k.sm = 1; k.os = d->stride; k.dstep = -1;
+        for (int c = 0; c < g.ncls; ++c) {
+            const int a = c >> 1, b = c & 1;
+            k.OHc[c] = (d->OH - a + k.os - 1) / k.os;
+            k.OWc[c] = (d->OW - b + k.os - 1) / k.os;
+            k.Mc[c] = d->N * k.OHc[c] * k.OWc[c];
+        }
+    } else {
+        k.sm = d->stride; k.os = 1; k.dstep = 1;
+        k.OHc[0] = d->OH; k.OWc[0] = d->OW; k.Mc[0] = d->N * d->OH * d->OW;
+    }
+    const long long Mc = k.Mc[0];   // class 0 is the largest
     for (int c = 0; c < 4; ++c) {
         k.nkh[c] = g.nkh[c]; k.nkw[c] = g.nkw[c]; k.dh0[c] = g.dh0[c]; k.dw0[c] = g.dw0[c];
         k.ktot[c] = g.ktot[c]; k.kpad[c] = g.kpad[c]; k.woff[c] = g.woff[c];
@@ -591,23 +613,23 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op) {
 using namespace v2v;
 
 extern "C" int64_t v2v_conv_packed_elems(int32_t cin, int32_t cin_stride, int32_t cout, int32_t KH, int32_t KW,
-                                         int32_t transposed, int32_t pad, int32_t dtype) {
+                                         int32_t transposed, int32_t stride, int32_t pad, int32_t dtype) {
     (void)cin;
     ConvGeom g;
-    conv_geom(cin_stride, cout, KH, KW, transposed, pad, dtype, &g);
+    conv_geom(cin_stride, cout, KH, KW, transposed, stride, pad, dtype, &g);
     return g.total;
 }
 
 extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t cin_stride, int32_t cout,
-                                     int32_t KH, int32_t KW, int32_t transposed, int32_t pad, int32_t dtype,
-                                     void* stream) {
+                                     int32_t KH, int32_t KW, int32_t transposed, int32_t stride, int32_t pad,
+                                     int32_t dtype, void* stream) {
     if (!w || !dst) { set_error("pack: null pointer"); return V2V_EINVAL; }
     ConvGeom g;
-    conv_geom(cin_stride, cout, KH, KW, transposed, pad, dtype, &g);
+    conv_geom(cin_stride, cout, KH, KW, transposed, stride, pad, dtype, &g);
     auto op = std::make_unique<PackOp>();
     PackArgs& a = op->a;
     a.w = w; a.dst = dst; a.cin = cin; a.cin_stride = cin_stride; a.cout = cout; a.cout_p = g.cout_p;
-    a.KH = KH; a.KW = KW; a.transposed = transposed; a.ncls = g.ncls; a.total = g.total; a.dtype = dtype;
+    a.KH = KH; a.KW = KW; a.transposed = transposed; a.kstep = stride; a.ncls = g.ncls; a.total = g.total; a.dtype = dtype;
     for (int c = 0; c < 4; ++c) {
         a.nkh[c] = g.nkh[c]; a.nkw[c] = g.nkw[c]; a.kh0[c] = g.kh0[c]; a.kw0[c] = g.kw0[c];
         a.kpad[c] = g.kpad[c]; a.woff[c] = g.woff[c];

@@ -1,0 +1,302 @@
+// Weight gradient of every Conv2d / ConvTranspose2d on the vid2vid training path, gfx950.
+//
+//   G[r][c][kh][kw] = sum_{n,oi,oj} P[n][oi][oj][r] * Q[n][oi*s + kh - p][oj*s + kw - p][c]
+//
+// with Q read through zero or reflection padding.  One formula serves both layer kinds:
+//   nn.Conv2d            (networks.py:132-183, :571-587, :687-706):  P = dY (rows = cout),  Q = X,
+//                        G = dW[cout][cin][kh][kw];
+//   nn.ConvTranspose2d   (networks.py:147,176,254,272; stride 2):    P = X  (rows = cin),   Q = dY,
+//                        G = dW[cin][cout][kh][kw]   (Y[2i-p+kh] += X[i] W[kh]  =>  dW[kh] = sum_i X[i] dY[2i-p+kh]).
+// In the reference this is the autograd of F.conv2d / F.conv_transpose2d (cuDNN bwd-filter).
+//
+// GEMM view: M = rows r (channels of P), N = columns (tap, c) with c on Q's channel stride, K = pixels.
+// Both operands are pixel-major NHWC, i.e. K-major: a tile row in LDS is one pixel's run of
+// channels, staged by LDS-DMA (global_load_lds_dwordx4, lane-linear, no padding needed) and read
+// back one scalar per lane -- exactly the A[i][k] / B[k][j] operand shape of
+// v_mfma_f32_32x32x2_f32 (lanes 0-31 take pixel 2kk, lanes 32-63 pixel 2kk+1), conflict-free
+// because the 32 lanes of a half read 32 consecutive words.  Accumulation is exact fp32 for both
+// storage dtypes (bf16 operands are widened on the LDS read), so the fp32 path is the parity path.
+//
+// K (pixels) is split over blockIdx.y; every split writes its own fp32 slab and
+// wgrad_reduce_kernel adds the slabs in a fixed order into the PyTorch-layout gradient
+// (deterministic, no atomics), optionally accumulating into an existing .grad buffer.
+#include "v2v_internal.h"
+#include <cstring>
+
+namespace v2v {
+
+struct WgradKArgs {
+    const char* P; const char* Q; const char* zero_page;
+    float* slab;
+    int N, OH, OW;          // P grid (conv: output pixels; convT: input pixels)
+    int QH, QW;             // Q grid
+    int PCs, QCs;           // channel strides (elements)
+    int ncols;              // KH*KW*QCs
+    int KW, stride, pad, pad_mode;
+    int Kpix, kper;         // total pixels, pixels per split (multiple of BK)
+    int m_tiles, n_tiles;
+    int Rp, Cp;             // slab rows / columns (tile multiples)
+};
+
+__device__ __forceinline__ void wg_glds16(const char* g, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ float lds_elem(const char* base, int idx, float) {
+    return reinterpret_cast<const float*>(base)[idx];
+}
+__device__ __forceinline__ float lds_elem(const char* base, int idx, bf16_t) {
+    return bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(base)[idx]);
+}
+
+// BM x BN output tile, BK pixels per chunk, 4 waves as 2 (rows) x 2 (columns)
+template <typename T, int BM, int BN, int BK, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs p) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VEC = 16 / ES;
+    constexpr int LPR_P = BM / VEC, LPR_Q = BN / VEC;       // lanes per pixel row
+    constexpr int RPI_P = 64 / LPR_P, RPI_Q = 64 / LPR_Q;   // pixel rows per wave instruction (1 KiB)
+    constexpr int NI_P = BK / RPI_P / 4, NI_Q = BK / RPI_Q / 4;   // instructions per wave per chunk
+    constexpr int PT_BYTES = BK * BM * ES, QT_BYTES = BK * BN * ES;
+    constexpr int STAGE = PT_BYTES + QT_BYTES;
+    constexpr int D = NS - 1;
+    constexpr int LPT = NI_P + NI_Q;
+    constexpr int TM = BM / 64, TN = BN / 64;               // 32x32 MFMA tiles per wave
+    static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
+    static_assert(NI_P >= 1 && NI_Q >= 1 && (BK % (RPI_P * 4)) == 0 && (BK % (RPI_Q * 4)) == 0, "loader split");
+    static_assert(LPT * (D - 1) <= 63, "vmcnt range");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
+    const int split = blockIdx.y;
+    const int kbeg = split * p.kper;
+    const int kend = min(kbeg + p.kper, p.Kpix);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const char* const zp = p.zero_page;
+
+    // ---- P loader: lane -> (pixel row inside the instruction, 16-byte channel group) ----
+    const int p_row = lane / LPR_P, p_cg = lane % LPR_P;
+    const int p_ch = mt * BM + p_cg * VEC;
+    const bool p_chok = p_ch < p.PCs;
+    // ---- Q loader: the lane's (tap, channel) is fixed for the whole K walk ----
+    const int q_row = lane / LPR_Q, q_cg = lane % LPR_Q;
+    const int q_col = nt * BN + q_cg * VEC;
+    const bool q_colok = q_col < p.ncols;
+    const int q_tap = q_colok ? q_col / p.QCs : 0;
+    const int q_c = q_col - q_tap * p.QCs;
+    const int q_dh = q_tap / p.KW - p.pad, q_dw = q_tap % p.KW - p.pad;
+    const int ohow = p.OH * p.OW;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+
+    int issued = 0;
+    auto issue = [&]() {
+        char* sbase = smem + (issued % NS) * STAGE;
+        const int k0 = kbeg + issued * BK;
+#pragma unroll
+        for (int j = 0; j < NI_P; ++j) {
+            const int q = wid + 4 * j;                       // instruction index inside the tile
+            const int pix = k0 + q * RPI_P + p_row;
+            const bool ok = p_chok && pix < kend;
+            const char* src = ok ? p.P + ((long long)pix * p.PCs + p_ch) * ES : zp;
+            wg_glds16(src, sbase + q * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NI_Q; ++j) {
+            const int q = wid + 4 * j;
+            const int pix = k0 + q * RPI_Q + q_row;
+            bool ok = q_colok && pix < kend;
+            const int pp = ok ? pix : 0;
+            const int n = pp / ohow;
+            const int rem = pp - n * ohow;
+            const int oi = rem / p.OW;
+            const int oj = rem - oi * p.OW;
+            int ih = oi * p.stride + q_dh, iw = oj * p.stride + q_dw;
+            int rh = ih < 0 ? -ih : ih;  rh = rh >= p.QH ? 2 * p.QH - 2 - rh : rh;
+            int rw = iw < 0 ? -iw : iw;  rw = rw >= p.QW ? 2 * p.QW - 2 - rw : rw;
+            ih = reflect ? rh : ih;
+            iw = reflect ? rw : iw;
+            ok = ok && ((unsigned)ih < (unsigned)p.QH) && ((unsigned)iw < (unsigned)p.QW);
+            ih = ih < 0 ? 0 : (ih >= p.QH ? p.QH - 1 : ih);
+            iw = iw < 0 ? 0 : (iw >= p.QW ? p.QW - 1 : iw);
+            const char* src = p.Q + ((((long long)n * p.QH + ih) * p.QW + iw) * p.QCs + q_c) * ES;
+            src = ok ? src : zp;
+            wg_glds16(src, sbase + PT_BYTES + q * 1024);
+        }
+        ++issued;
+    };
+
+    const int lr = lane & 31, hi = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int t = 0; t < D && t < nk; ++t) issue();
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + D <= nk) wg_wait_vmcnt<LPT * (D - 1)>();
+        else              wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (ks + D < nk) issue();
+        const char* pt = smem + (ks % NS) * STAGE;
+        const char* qt = pt + PT_BYTES;
+#pragma unroll 4
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int krow = 2 * kk + hi;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = lds_elem(pt, krow * BM + wm * (BM / 2) + i * 32 + lr, T());
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = lds_elem(qt, krow * BN + wn * (BN / 2) + j * 32 + lr, T());
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* slab = p.slab + (long long)split * p.Rp * p.Cp;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = nt * BN + wn * (BN / 2) + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * BM + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                slab[(long long)row * p.Cp + col] = acc[i][j][r];
+            }
+        }
+}
+
+struct WgradReduceArgs {
+    const float* slab; float* grad;
+    int splits, R, C, KHW, QCs, Rp, Cp, accumulate;
+};
+
+// one thread per slab column entry (coalesced slab reads); scattered 4-byte writes, once
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs a) {
+    const long long ncols = (long long)a.KHW * a.QCs;
+    const long long total = (long long)a.R * ncols;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long slab_sz = (long long)a.Rp * a.Cp;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int r = (int)(e / ncols);
+        const int col = (int)(e - (long long)r * ncols);
+        const int tap = col / a.QCs, c = col - tap * a.QCs;
+        if (c >= a.C) continue;
+        float s = 0.f;
+        const float* src = a.slab + (long long)r * a.Cp + col;
+        for (int k = 0; k < a.splits; ++k) s += src[(long long)k * slab_sz];
+        float* dst = a.grad + ((long long)r * a.C + c) * a.KHW + tap;
+        *dst = a.accumulate ? *dst + s : s;
+    }
+}
+
+struct WgradOp : Op {
+    WgradKArgs k; WgradReduceArgs r; int dtype, splits;
+    int launch(hipStream_t s) override {
+        dim3 grid((unsigned)(k.m_tiles * k.n_tiles), (unsigned)splits);
+        if (dtype == V2V_BF16) {
+            auto kern = conv_wgrad_kernel<bf16_t, 64, 128, 32, 3>;
+            const size_t lds = 3 * (32 * 64 + 32 * 128) * 2;
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+        } else {
+            auto kern = conv_wgrad_kernel<float, 64, 128, 32, 3>;
+            const size_t lds = 3 * (32 * 64 + 32 * 128) * 4;
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+        }
+        int rc = check_launch();
+        if (rc != 0) return rc;
+        const long long total = (long long)r.R * r.KHW * r.QCs;
+        long long blocks = ceil_div(total, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, r);
+        return check_launch();
+    }
+    const char* name() const override { return "conv_wgrad"; }
+};
+
+static const int WG_BM = 64, WG_BN = 128, WG_BK = 32;
+
+static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* splits, int* kper) {
+    const long long kpix = (long long)d->N * d->OH * d->OW;
+    const int ncols = d->KH * d->KW * d->q_stride;
+    *m_tiles = (int)ceil_div(d->rows, WG_BM);
+    *n_tiles = (int)ceil_div(ncols, WG_BN);
+    const long long tiles = (long long)*m_tiles * *n_tiles;
+    long long s = ceil_div(1024, tiles);                 // aim at ~4 workgroups per CU
+    const long long smax = ceil_div(kpix, 8 * WG_BK);     // at least 8 chunks per split
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    if (s > 512) s = 512;
+    long long kp = round_up(ceil_div(kpix, s), WG_BK);
+    s = ceil_div(kpix, kp);
+    *splits = (int)s; *kper = (int)kp;
+    return 0;
+}
+
+static int wgrad_check(const v2v_wgrad_desc* d) {
+    if (!d || !d->p || !d->q || !d->grad || !d->zero_page) { set_error("wgrad: null pointer"); return V2V_EINVAL; }
+    if (d->dtype != V2V_F32 && d->dtype != V2V_BF16) { set_error("wgrad: bad dtype"); return V2V_EINVAL; }
+    const int vec = d->dtype == V2V_BF16 ? 8 : 4;
+    if (d->p_stride % vec || d->q_stride % vec || d->rows > d->p_stride || d->cols > d->q_stride) {
+        set_error("wgrad: channel strides must be multiples of %d and cover rows/cols", vec); return V2V_EINVAL;
+    }
+    if (d->stride != 1 && d->stride != 2) { set_error("wgrad: stride"); return V2V_EINVAL; }
+    if (d->pad_mode == V2V_PAD_REFLECT && (d->pad >= d->QH || d->pad >= d->QW)) { set_error("wgrad: reflect pad >= size"); return V2V_EINVAL; }
+    if ((long long)d->N * d->OH * d->OW >= (1ll << 31) || (long long)d->N * d->QH * d->QW >= (1ll << 31)) { set_error("wgrad: too many pixels"); return V2V_EINVAL; }
+    if (((uintptr_t)d->p | (uintptr_t)d->q | (uintptr_t)d->zero_page) & 15) { set_error("wgrad: operands must be 16-byte aligned"); return V2V_EINVAL; }
+    return 0;
+}
+
+}  // namespace v2v
+
+using namespace v2v;
+
+extern "C" int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d) {
+    if (wgrad_check(d) != 0) return V2V_EINVAL;
+    int mt, nt, sp, kp;
+    wgrad_plan(d, &mt, &nt, &sp, &kp);
+    return (int64_t)sp * mt * WG_BM * nt * WG_BN * (int64_t)sizeof(float);
+}
+
+extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
+    int rc = wgrad_check(d);
+    if (rc != 0) return rc;
+    if (!d->workspace) { set_error("wgrad: workspace is NULL (size it with v2v_conv_wgrad_workspace)"); return V2V_EINVAL; }
+    auto op = std::make_unique<WgradOp>();
+    int mt, nt, sp, kp;
+    wgrad_plan(d, &mt, &nt, &sp, &kp);
+    WgradKArgs& k = op->k;
+    memset(&k, 0, sizeof(k));
+    k.P = (const char*)d->p; k.Q = (const char*)d->q; k.zero_page = (const char*)d->zero_page;
+    k.slab = (float*)d->workspace;
+    k.N = d->N; k.OH = d->OH; k.OW = d->OW; k.QH = d->QH; k.QW = d->QW;
+    k.PCs = d->p_stride; k.QCs = d->q_stride;
+    k.ncols = d->KH * d->KW * d->q_stride;
+    k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.pad_mode = d->pad_mode;
+    k.Kpix = d->N * d->OH * d->OW; k.kper = kp;
+    k.m_tiles = mt; k.n_tiles = nt; k.Rp = mt * WG_BM; k.Cp = nt * WG_BN;
+    WgradReduceArgs& r = op->r;
+    r.slab = k.slab; r.grad = d->grad; r.splits = sp; r.R = d->rows; r.C = d->cols; r.KHW = d->KH * d->KW;
+    r.QCs = d->q_stride; r.Rp = k.Rp; r.Cp = k.Cp; r.accumulate = d->accumulate;
+    op->dtype = d->dtype; op->splits = sp;
+    return submit(std::move(op), stream);
+}

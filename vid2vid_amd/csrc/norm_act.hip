@@ -9,6 +9,7 @@
 // which also performs the ResnetBlock residual add (models/networks.py:591-593) and the
 // tower sums (models/networks.py:204, :298-299) without extra passes.
 #include "v2v_internal.h"
+#include <cstring>
 
 namespace v2v {
 
@@ -46,6 +47,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinArgs a) {
         const double sc = g * invstd;
         a.scale_shift[c] = (float)sc;
         a.scale_shift[a.C + c] = (float)(b - mean * sc);
+        a.scale_shift[2 * a.C + c] = (float)mean;       // rows 2,3: saved for the backward pass
+        a.scale_shift[3 * a.C + c] = (float)invstd;
         if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
         if (a.running_var)  a.running_var[c]  = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * a.unbias);
     }
@@ -134,6 +137,215 @@ struct BnApplyOp : Op {
     const char* name() const override { return "bn_apply"; }
 };
 
+
+// ---------------------------------------------------------------------------------------
+// backward of  y = act(norm(raw)) (+ residuals)   (autograd of nn.BatchNorm2d / InstanceNorm2d
+// in training mode + ReLU / LeakyReLU in the reference)
+//   g      = dY * act'(raw*scale + shift)
+//   xhat   = (raw - mean) * invstd
+//   dbeta  = sum g,   dgamma = sum g*xhat
+//   dRaw   = scale * (g - dbeta/M - xhat * dgamma/M)
+// Three launches: per-block partial sums (deterministic rows), a tiny finalize, one streaming pass.
+// The same reduce/finalize pair with mode 1 gives plain per-channel sums (bias gradients).
+// ---------------------------------------------------------------------------------------
+struct BnBwdRedArgs {
+    const void* dy; const float* raw; const float* stats;   // stats: [4][C] scale, shift, mean, invstd
+    float* partials;                                        // [nblk][C][2]
+    long long P; int C, c_stride, c_stride_raw, act; float act_param; int mode;   // mode 1: sum of dy only
+    long long ppb;                                          // pixels per block
+};
+
+__device__ __forceinline__ float act_grad_pre(float pre, int act, float param) {
+    switch (act) {
+        case V2V_ACT_RELU:  return pre > 0.f ? 1.f : 0.f;
+        case V2V_ACT_LEAKY: return pre > 0.f ? 1.f : param;
+        default:            return 1.f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdRedArgs a) {
+    __shared__ float sh[256][2];
+    const T* dy = reinterpret_cast<const T*>(a.dy);
+    const long long p0 = (long long)blockIdx.x * a.ppb;
+    long long p1 = p0 + a.ppb; if (p1 > a.P) p1 = a.P;
+    // threads: tx over channels (coalesced), ty over pixels; channels are walked in slabs of TX
+    const int TX = a.C >= 64 ? 64 : (a.C >= 32 ? 32 : 16);
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    for (int c0 = 0; c0 < a.C; c0 += TX) {
+        const int c = c0 + tx;
+        float s1 = 0.f, s2 = 0.f;
+        if (c < a.C) {
+            float sc = 1.f, sf = 0.f, mean = 0.f, inv = 1.f;
+            if (a.mode == 0) { sc = a.stats[c]; sf = a.stats[a.C + c]; mean = a.stats[2 * a.C + c]; inv = a.stats[3 * a.C + c]; }
+            for (long long p = p0 + ty; p < p1; p += TY) {
+                float g = load_act(dy, p * a.c_stride + c);
+                if (a.mode == 0) {
+                    const float r = a.raw[p * a.c_stride_raw + c];
+                    g *= act_grad_pre(r * sc + sf, a.act, a.act_param);
+                    s2 += g * ((r - mean) * inv);
+                }
+                s1 += g;
+            }
+        }
+        sh[threadIdx.x][0] = s1; sh[threadIdx.x][1] = s2;
+        __syncthreads();
+        if (ty == 0 && c < a.C) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int q = 0; q < TY; ++q) { t1 += sh[q * TX + tx][0]; t2 += sh[q * TX + tx][1]; }
+            float* dst = a.partials + ((long long)blockIdx.x * a.C + c) * 2;
+            dst[0] = t1; dst[1] = t2;
+        }
+        __syncthreads();
+    }
+}
+
+struct BnBwdFinArgs {
+    const float* partials; int rows; int C; double inv_count;
+    float* dgamma; float* dbeta; float* coef;   // coef: [2][C] = (sum g / M, sum g*xhat / M) or NULL
+    int accumulate;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdFinArgs a) {
+    __shared__ double sh[4][64][2];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < a.C) {
+        for (int r = ph; r < a.rows; r += 4) {
+            const float2 v = *reinterpret_cast<const float2*>(a.partials + ((long long)r * a.C + c) * 2);
+            s1 += (double)v.x; s2 += (double)v.y;
+        }
+    }
+    sh[ph][cx][0] = s1; sh[ph][cx][1] = s2;
+    __syncthreads();
+    if (ph == 0 && c < a.C) {
+        s1 = ((sh[0][cx][0] + sh[1][cx][0]) + sh[2][cx][0]) + sh[3][cx][0];
+        s2 = ((sh[0][cx][1] + sh[1][cx][1]) + sh[2][cx][1]) + sh[3][cx][1];
+        if (a.dbeta)  a.dbeta[c]  = (a.accumulate ? a.dbeta[c] : 0.f) + (float)s1;
+        if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + (float)s2;
+        if (a.coef) { a.coef[c] = (float)(s1 * a.inv_count); a.coef[a.C + c] = (float)(s2 * a.inv_count); }
+    }
+}
+
+struct BnBwdApplyArgs {
+    const void* dy; const float* raw; const float* stats; const float* coef; void* draw;
+    long long P; int C, c_stride, c_stride_raw, c_stride_out, act; float act_param;
+};
+
+// one thread per (pixel, 4-channel group); writes dRaw in the activation dtype, pad channels zero
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
+    const T* dy = reinterpret_cast<const T*>(a.dy);
+    T* out = reinterpret_cast<T*>(a.draw);
+    const int gpr = a.c_stride_out / 4;
+    const long long total = a.P * gpr;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += stride) {
+        const long long pix = v / gpr;
+        const int c0 = (int)(v - pix * gpr) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q;
+            float o = 0.f;
+            if (c < a.C) {
+                const float sc = a.stats[c], sf = a.stats[a.C + c], mean = a.stats[2 * a.C + c], inv = a.stats[3 * a.C + c];
+                const float r = a.raw[pix * a.c_stride_raw + c];
+                const float g = load_act(dy, pix * a.c_stride + c) * act_grad_pre(r * sc + sf, a.act, a.act_param);
+                o = sc * (g - a.coef[c] - (r - mean) * inv * a.coef[a.C + c]);
+            }
+            store_act(out, pix * a.c_stride_out + c, o);
+        }
+    }
+}
+
+struct BnBwdOp : Op {
+    BnBwdRedArgs r; BnBwdFinArgs f; BnBwdApplyArgs ap; int dtype, nblk; bool do_apply;
+    int launch(hipStream_t s) override {
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, s, r);
+        else                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, s, r);
+        int rc = check_launch(); if (rc) return rc;
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(f.C, 64)), dim3(256), 0, s, f);
+        rc = check_launch(); if (rc) return rc;
+        if (do_apply) {
+            long long blocks = ceil_div(ap.P * (ap.c_stride_out / 4), 256);
+            if (blocks > 4096) blocks = 4096;
+            if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, ap);
+            else                   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, ap);
+            rc = check_launch();
+        }
+        return rc;
+    }
+    const char* name() const override { return do_apply ? "bn_backward" : "channel_sum"; }
+};
+
+// ---------------------------------------------------------------------------------------
+// backward of a conv epilogue activation (no norm):  g = dY * act'(y) * out_scale, with dY / y
+// either NHWC activations or planar fp32 NCHW (API-facing heads); g is NHWC, pad channels zero
+// ---------------------------------------------------------------------------------------
+struct ActBwdArgs {
+    const void* dy; const void* y; void* g;
+    long long NP; long long hw; int C, c_stride_in, c_stride_out, act, nchw; float act_param, out_scale;
+};
+
+__device__ __forceinline__ float act_grad_out(float yv, int act, float param, float out_scale) {
+    switch (act) {
+        case V2V_ACT_RELU:    return yv > 0.f ? out_scale : 0.f;
+        case V2V_ACT_LEAKY:   return (yv > 0.f ? 1.f : param) * out_scale;
+        case V2V_ACT_TANH:    { const float t = yv / out_scale; return (1.f - t * t) * out_scale; }
+        case V2V_ACT_SIGMOID: { const float t = yv / out_scale; return t * (1.f - t) * out_scale; }
+        default:              return out_scale;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const ActBwdArgs a) {
+    T* g = reinterpret_cast<T*>(a.g);
+    const long long total = a.NP * a.c_stride_out;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long pix = e / a.c_stride_out;       // n*hw + p
+        const int c = (int)(e - pix * a.c_stride_out);
+        float o = 0.f;
+        if (c < a.C) {
+            float d, yv;
+            if (a.nchw) {
+                const long long n = pix / a.hw, p = pix - n * a.hw;
+                const long long idx = (n * a.C + c) * a.hw + p;
+                d = reinterpret_cast<const float*>(a.dy)[idx];
+                yv = a.act == V2V_ACT_NONE ? 0.f : reinterpret_cast<const float*>(a.y)[idx];
+            } else {
+                d = load_act(reinterpret_cast<const T*>(a.dy), pix * a.c_stride_in + c);
+                yv = a.act == V2V_ACT_NONE ? 0.f : load_act(reinterpret_cast<const T*>(a.y), pix * a.c_stride_in + c);
+            }
+            o = d * act_grad_out(yv, a.act, a.act_param, a.out_scale);
+        }
+        store_act(g, e, o);
+    }
+}
+
+struct ActBwdOp : Op {
+    ActBwdArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        long long blocks = ceil_div(a.NP * a.c_stride_out, 256);
+        if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(act_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "act_backward"; }
+};
+
+static int bwd_blocks(long long P, long long* ppb) {
+    long long nblk = ceil_div(P, 64);
+    if (nblk > 512) nblk = 512;
+    if (nblk < 1) nblk = 1;
+    *ppb = ceil_div(P, nblk);
+    return (int)ceil_div(P, *ppb);
+}
+
 }  // namespace v2v
 
 using namespace v2v;
@@ -167,6 +379,54 @@ extern "C" int v2v_bn_apply(const float* raw, int32_t c_stride_raw, const float*
     a.raw = raw; a.c_stride_raw = c_stride_raw; a.scale_shift = scale_shift;
     a.add0 = add0; a.add1 = add1; a.y = y; a.P = P; a.C = C; a.c_stride = c_stride;
     a.act = act; a.act_param = act_param;
+    op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_bn_backward_rows(int64_t P) {
+    long long ppb; return bwd_blocks(P, &ppb);
+}
+
+extern "C" int v2v_bn_backward(const void* dy, const float* raw, int32_t c_stride_raw, const float* stats,
+                               void* draw, int32_t c_stride_out, float* dgamma, float* dbeta, int32_t accumulate,
+                               float* workspace, int64_t P, int32_t C, int32_t c_stride,
+                               int32_t act, float act_param, int32_t dtype, void* stream) {
+    if (!dy || !raw || !stats || !draw || !workspace || P <= 0 || C <= 0) { set_error("bn_backward: bad argument"); return V2V_EINVAL; }
+    if (c_stride_out % 4 != 0 || C > c_stride || C > c_stride_raw || C > c_stride_out) { set_error("bn_backward: strides"); return V2V_EINVAL; }
+    if (act != V2V_ACT_NONE && act != V2V_ACT_RELU && act != V2V_ACT_LEAKY) { set_error("bn_backward: activation"); return V2V_EINVAL; }
+    auto op = std::make_unique<BnBwdOp>();
+    long long ppb; const int nblk = bwd_blocks(P, &ppb);
+    op->dtype = dtype; op->nblk = nblk; op->do_apply = true;
+    float* partials = workspace;                      // [nblk][C][2]
+    float* coef = workspace + (long long)nblk * C * 2; // [2][C]
+    op->r = BnBwdRedArgs{dy, raw, stats, partials, P, C, c_stride, c_stride_raw, act, act_param, 0, ppb};
+    op->f = BnBwdFinArgs{partials, nblk, C, 1.0 / (double)P, dgamma, dbeta, coef, accumulate};
+    op->ap = BnBwdApplyArgs{dy, raw, stats, coef, draw, P, C, c_stride, c_stride_raw, c_stride_out, act, act_param};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_channel_sum(const void* x, float* out, int32_t accumulate, float* workspace,
+                               int64_t P, int32_t C, int32_t c_stride, int32_t dtype, void* stream) {
+    if (!x || !out || !workspace || P <= 0 || C <= 0 || C > c_stride) { set_error("channel_sum: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<BnBwdOp>();
+    long long ppb; const int nblk = bwd_blocks(P, &ppb);
+    op->dtype = dtype; op->nblk = nblk; op->do_apply = false;
+    op->r = BnBwdRedArgs{x, nullptr, nullptr, workspace, P, C, c_stride, 0, V2V_ACT_NONE, 0.f, 1, ppb};
+    op->f = BnBwdFinArgs{workspace, nblk, C, 1.0, nullptr, out, nullptr, accumulate};
+    memset(&op->ap, 0, sizeof(op->ap));
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_act_backward(const void* dy, const void* y, void* g, int32_t N, int32_t H, int32_t W, int32_t C,
+                                int32_t c_stride_in, int32_t c_stride_out, int32_t nchw, int32_t act, float act_param,
+                                float out_scale, int32_t dtype, void* stream) {
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    if (!dy || !g || (act != V2V_ACT_NONE && !y) || c_stride_out % vec != 0 || C > c_stride_out || (!nchw && C > c_stride_in)) {
+        set_error("act_backward: bad argument"); return V2V_EINVAL;
+    }
+    if ((act == V2V_ACT_TANH || act == V2V_ACT_SIGMOID) && out_scale == 0.f) { set_error("act_backward: out_scale 0"); return V2V_EINVAL; }
+    auto op = std::make_unique<ActBwdOp>();
+    op->a = ActBwdArgs{dy, y, g, (long long)N * H * W, (long long)H * W, C, c_stride_in, c_stride_out, act, nchw, act_param, out_scale};
     op->dtype = dtype;
     return submit(std::move(op), stream);
 }

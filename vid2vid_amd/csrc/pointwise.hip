@@ -401,6 +401,309 @@ struct FgMaskOp : Op {
     const char* name() const override { return "fg_mask_nhwc"; }
 };
 
+
+// ---------------------------------------------------------------------------------------
+// training-path helpers: channel concat while packing, channel-offset unpack (its backward),
+// reflection-pad fold (backward of nn.ReflectionPad2d), AvgPool backward, warp/blend backward
+// ---------------------------------------------------------------------------------------
+struct Pack2Args { const float* x0; const float* x1; void* y; int N, C0, C1, H, W, c_stride; float scale1; };
+
+// cat([x0, x1], dim=1) (vid2vid_model_D.py:169-170,185-187) written straight to NHWC
+template <typename T>
+__global__ __launch_bounds__(256) void pack_concat_kernel(const Pack2Args a) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int vpr = a.c_stride / VEC;
+    const long long hw = (long long)a.H * a.W;
+    const long long npix = (long long)a.N * hw;
+    const long long nvec = npix * vpr;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    T* y = reinterpret_cast<T*>(a.y);
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        const long long pixg = v % npix;
+        const int cv = (int)(v / npix);
+        const long long n = pixg / hw, pix = pixg - n * hw;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int c = cv * VEC + q;
+            float val = 0.f;
+            if (c < a.C0) val = a.x0[(n * a.C0 + c) * hw + pix];
+            else if (c < a.C0 + a.C1) val = a.x1[(n * a.C1 + (c - a.C0)) * hw + pix] * a.scale1;
+            store_act(y, pixg * a.c_stride + c, val);
+        }
+    }
+}
+
+struct Pack2Op : Op {
+    Pack2Args a; int dtype;
+    int launch(hipStream_t s) override {
+        const int vec = dtype == V2V_BF16 ? 8 : 4;
+        const long long n = (long long)a.N * a.H * a.W * (a.c_stride / vec);
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(pack_concat_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(pack_concat_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "pack_concat_nhwc"; }
+};
+
+struct UnpackAtArgs { const void* y; float* x; int N, C, H, W, c_stride, c_off; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_at_kernel(const UnpackAtArgs a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long total = (long long)a.N * a.C * hw;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const T* y = reinterpret_cast<const T*>(a.y);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long pix = e % hw;
+        const long long nc = e / hw;
+        const long long n = nc / a.C;
+        const int c = (int)(nc - n * a.C);
+        a.x[e] = load_act(y, (n * hw + pix) * a.c_stride + a.c_off + c);
+    }
+}
+
+struct UnpackAtOp : Op {
+    UnpackAtArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        const long long n = (long long)a.N * a.C * a.H * a.W;
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(unpack_at_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(unpack_at_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "unpack_channels_nchw"; }
+};
+
+// dX[h][w] = sum of the padded-gradient entries that mirror onto (h, w)
+struct FoldArgs { const void* xp; void* x; int N, H, W, pad, c_stride; };
+
+__device__ __forceinline__ int fold_sources(int h, int H, int p, int* src) {
+    int n = 0;
+    src[n++] = h + p;
+    if (h >= 1 && h <= p) src[n++] = p - h;
+    if (h >= H - 1 - p && h <= H - 2) src[n++] = 2 * (H - 1) - h + p;
+    return n;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const FoldArgs a) {
+    const T* xp = reinterpret_cast<const T*>(a.xp);
+    T* x = reinterpret_cast<T*>(a.x);
+    const int HP = a.H + 2 * a.pad, WP = a.W + 2 * a.pad;
+    const long long total = (long long)a.N * a.H * a.W * a.c_stride;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int c = (int)(e % a.c_stride);
+        long long t = e / a.c_stride;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H);
+        const long long n = t / a.H;
+        int hs[3], ws[3];
+        const int nh = fold_sources(h, a.H, a.pad, hs), nw = fold_sources(w, a.W, a.pad, ws);
+        float s = 0.f;
+        for (int i = 0; i < nh; ++i)
+            for (int j = 0; j < nw; ++j)
+                s += load_act(xp, ((n * HP + hs[i]) * WP + ws[j]) * a.c_stride + c);
+        store_act(x, e, s);
+    }
+}
+
+struct FoldOp : Op {
+    FoldArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        const long long n = (long long)a.N * a.H * a.W * a.c_stride;
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(reflect_fold_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "reflect_pad_fold"; }
+};
+
+__device__ __forceinline__ int pool_cnt(int o, int size) {   // valid taps of window o along one axis
+    int c = 0;
+    for (int d = -1; d <= 1; ++d) { const int i = 2 * o + d; c += (i >= 0 && i < size) ? 1 : 0; }
+    return c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_nhwc_bwd_kernel(const PoolArgs a) {
+    // a.x = dY [N][OH][OW][cs], a.y = dX [N][H][W][cs]
+    const T* dy = reinterpret_cast<const T*>(a.x);
+    T* dx = reinterpret_cast<T*>(a.y);
+    const long long total = (long long)a.N * a.H * a.W * a.c_stride;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int c = (int)(e % a.c_stride);
+        long long t = e / a.c_stride;
+        const int w = (int)(t % a.W); t /= a.W;
+        const int h = (int)(t % a.H);
+        const long long n = t / a.H;
+        float s = 0.f;
+        const int oh0 = h / 2, oh1 = (h + 1) / 2, ow0 = w / 2, ow1 = (w + 1) / 2;   // windows containing h / w
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            if (oh >= a.OH) continue;
+            const int ch = pool_cnt(oh, a.H);
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                if (ow >= a.OW) continue;
+                s += load_act(dy, ((n * a.OH + oh) * a.OW + ow) * a.c_stride + c) / (float)(ch * pool_cnt(ow, a.W));
+            }
+        }
+        store_act(dx, e, s);
+    }
+}
+
+struct PoolBwdOp : Op {
+    PoolArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        const long long n = (long long)a.N * a.H * a.W * a.c_stride;
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(avgpool_nhwc_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(avgpool_nhwc_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "avgpool3s2_nhwc_backward"; }
+};
+
+// d(ix)/d(flow_x) through get_grid + unnormalize, and the border clip's gradient mask
+// (ATen grid_sampler: clip_coordinates_set_grad -- borders count as out of bounds)
+__device__ __forceinline__ void bilinear_setup_grad(float fx, float fy, float gxv, float gyv, int H, int W, int ac,
+                                                    int& x0, int& y0, float& wx, float& wy, float& gmx, float& gmy) {
+    const float nx = gxv + fx / (((float)W - 1.0f) / 2.0f);
+    const float ny = gyv + fy / (((float)H - 1.0f) / 2.0f);
+    float ix = unnormalize(nx, W, ac), iy = unnormalize(ny, H, ac);
+    const float sx = (ac ? ((float)(W - 1) / 2.f) : ((float)W / 2.f)) / (((float)W - 1.0f) / 2.0f);
+    const float sy = (ac ? ((float)(H - 1) / 2.f) : ((float)H / 2.f)) / (((float)H - 1.0f) / 2.0f);
+    gmx = (ix <= 0.f || ix >= (float)(W - 1)) ? 0.f : sx;
+    gmy = (iy <= 0.f || iy >= (float)(H - 1)) ? 0.f : sy;
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    x0 = (int)fx0; y0 = (int)fy0;
+    wx = ix - fx0; wy = iy - fy0;
+}
+
+struct WarpBwdArgs {
+    const float* d_final; const float* d_rawout;           // incoming gradients (d_rawout may be NULL)
+    const float* raw; const float* flow; const float* weight; const float* prev; const float* fg; const float* mask;
+    const float* gx; const float* gy;
+    float* d_raw; float* d_flow; float* d_weight; float* d_prev; float* d_fg;   // d_prev: pre-zeroed, atomically accumulated
+    int N, C, H, W, align_corners;
+};
+
+__global__ __launch_bounds__(256) void warp_blend_bwd_kernel(const WarpBwdArgs a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long total = (long long)a.N * hw;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long n = e / hw, pix = e - n * hw;
+        const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);
+        const bool do_warp = a.flow != nullptr;
+        int x0 = 0, y0 = 0; float wx = 0.f, wy = 0.f, gmx = 0.f, gmy = 0.f, wgt = 1.f;
+        if (do_warp) {
+            bilinear_setup_grad(a.flow[(n * 2 + 0) * hw + pix], a.flow[(n * 2 + 1) * hw + pix], a.gx[x], a.gy[y],
+                                a.H, a.W, a.align_corners, x0, y0, wx, wy, gmx, gmy);
+            wgt = a.weight[n * hw + pix];
+        }
+        const float m = a.fg ? a.mask[n * hw + pix] : 0.f;
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const bool xin = x1 < a.W, yin = y1 < a.H;
+        float dwsum = 0.f, dix = 0.f, diy = 0.f;
+        for (int c = 0; c < a.C; ++c) {
+            const long long o = (n * a.C + c) * hw + pix;
+            const float df = a.d_final[o];
+            const float dr = a.d_rawout ? a.d_rawout[o] : 0.f;
+            if (a.d_fg) a.d_fg[o] = m * (df + dr);
+            const float dpre = (1.f - m) * df;               // gradient of raw*w + warp*(1-w)
+            float draw = (1.f - m) * dr;
+            if (do_warp) {
+                const float* img = a.prev + (n * a.C + c) * hw;
+                const float nw = img[(long long)y0 * a.W + x0];
+                const float ne = xin ? img[(long long)y0 * a.W + x1] : 0.f;
+                const float sw = yin ? img[(long long)y1 * a.W + x0] : 0.f;
+                const float se = (xin && yin) ? img[(long long)y1 * a.W + x1] : 0.f;
+                const float wv = nw * ((1.f - wx) * (1.f - wy)) + ne * (wx * (1.f - wy)) + sw * ((1.f - wx) * wy) + se * (wx * wy);
+                const float rawv = a.raw[o];
+                dwsum += dpre * (rawv - wv);
+                const float dwarp = dpre * (1.f - wgt);
+                dix += dwarp * ((ne - nw) * (1.f - wy) + (se - sw) * wy);
+                diy += dwarp * ((sw - nw) * (1.f - wx) + (se - ne) * wx);
+                if (a.d_prev) {
+                    float* dp = a.d_prev + (n * a.C + c) * hw;
+                    atomicAdd(dp + (long long)y0 * a.W + x0, dwarp * (1.f - wx) * (1.f - wy));
+                    if (xin) atomicAdd(dp + (long long)y0 * a.W + x1, dwarp * wx * (1.f - wy));
+                    if (yin) atomicAdd(dp + (long long)y1 * a.W + x0, dwarp * (1.f - wx) * wy);
+                    if (xin && yin) atomicAdd(dp + (long long)y1 * a.W + x1, dwarp * wx * wy);
+                }
+                draw += dpre * wgt;
+            } else {
+                draw += dpre;
+            }
+            a.d_raw[o] = draw;
+        }
+        if (do_warp) {
+            a.d_weight[n * hw + pix] = dwsum;
+            a.d_flow[(n * 2 + 0) * hw + pix] = dix * gmx;
+            a.d_flow[(n * 2 + 1) * hw + pix] = diy * gmy;
+        }
+    }
+}
+
+struct WarpBwdOp : Op {
+    WarpBwdArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(warp_blend_bwd_kernel, dim3(grid_for((long long)a.N * a.H * a.W)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "warp_blend_backward"; }
+};
+
+struct ResampleBwdArgs { const float* d_out; const float* img; const float* flow; const float* gx; const float* gy;
+                         float* d_img; float* d_flow; int N, C, H, W, align_corners; };
+
+__global__ __launch_bounds__(256) void resample_flow_bwd_kernel(const ResampleBwdArgs a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long total = (long long)a.N * hw;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long n = e / hw, pix = e - n * hw;
+        const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);
+        int x0, y0; float wx, wy, gmx, gmy;
+        bilinear_setup_grad(a.flow[(n * 2 + 0) * hw + pix], a.flow[(n * 2 + 1) * hw + pix], a.gx[x], a.gy[y],
+                            a.H, a.W, a.align_corners, x0, y0, wx, wy, gmx, gmy);
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const bool xin = x1 < a.W, yin = y1 < a.H;
+        float dix = 0.f, diy = 0.f;
+        for (int c = 0; c < a.C; ++c) {
+            const float* img = a.img + (n * a.C + c) * hw;
+            const float g = a.d_out[(n * a.C + c) * hw + pix];
+            const float nw = img[(long long)y0 * a.W + x0];
+            const float ne = xin ? img[(long long)y0 * a.W + x1] : 0.f;
+            const float sw = yin ? img[(long long)y1 * a.W + x0] : 0.f;
+            const float se = (xin && yin) ? img[(long long)y1 * a.W + x1] : 0.f;
+            dix += g * ((ne - nw) * (1.f - wy) + (se - sw) * wy);
+            diy += g * ((sw - nw) * (1.f - wx) + (se - ne) * wx);
+            if (a.d_img) {
+                float* dp = a.d_img + (n * a.C + c) * hw;
+                atomicAdd(dp + (long long)y0 * a.W + x0, g * (1.f - wx) * (1.f - wy));
+                if (xin) atomicAdd(dp + (long long)y0 * a.W + x1, g * wx * (1.f - wy));
+                if (yin) atomicAdd(dp + (long long)y1 * a.W + x0, g * (1.f - wx) * wy);
+                if (xin && yin) atomicAdd(dp + (long long)y1 * a.W + x1, g * wx * wy);
+            }
+        }
+        if (a.d_flow) {
+            a.d_flow[(n * 2 + 0) * hw + pix] = dix * gmx;
+            a.d_flow[(n * 2 + 1) * hw + pix] = diy * gmy;
+        }
+    }
+}
+
+struct ResampleBwdOp : Op {
+    ResampleBwdArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(resample_flow_bwd_kernel, dim3(grid_for((long long)a.N * a.H * a.W)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "resample_flow_backward"; }
+};
+
 }  // namespace v2v
 
 using namespace v2v;
@@ -484,5 +787,61 @@ extern "C" int v2v_fg_mask_nhwc(const void* x, float* mask, int64_t P, int32_t c
     if (!x || !mask || !fg_labels_dev || n_fg <= 0) { set_error("fg_mask: bad argument"); return V2V_EINVAL; }
     auto op = std::make_unique<FgMaskOp>();
     op->a = FgMaskArgs{x, mask, P, c_stride, base_ch, fg_labels_dev, n_fg}; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_pack_concat_nhwc(const float* x0, int32_t C0, const float* x1, int32_t C1, float scale1, void* y,
+                                    int32_t N, int32_t H, int32_t W, int32_t c_stride, int32_t dtype, void* stream) {
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    if (!x0 || !y || (C1 > 0 && !x1) || c_stride % vec != 0 || C0 + C1 > c_stride) { set_error("pack_concat: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<Pack2Op>();
+    op->a = Pack2Args{x0, x1, y, N, C0, C1 > 0 ? C1 : 0, H, W, c_stride, scale1}; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_unpack_channels_nchw(const void* y, float* x, int32_t N, int32_t C, int32_t H, int32_t W,
+                                        int32_t c_stride, int32_t c_offset, int32_t dtype, void* stream) {
+    if (!x || !y || c_offset < 0 || c_offset + C > c_stride) { set_error("unpack_channels: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<UnpackAtOp>();
+    op->a = UnpackAtArgs{y, x, N, C, H, W, c_stride, c_offset}; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_reflect_pad_fold(const void* xp, void* x, int32_t N, int32_t H, int32_t W, int32_t pad,
+                                    int32_t c_stride, int32_t dtype, void* stream) {
+    if (!xp || !x || pad < 0 || pad >= H || pad >= W) { set_error("reflect_pad_fold: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<FoldOp>();
+    op->a = FoldArgs{xp, x, N, H, W, pad, c_stride}; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_avgpool3s2_nhwc_backward(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t c_stride,
+                                            int32_t dtype, void* stream) {
+    if (!dy || !dx) { set_error("avgpool_backward: null"); return V2V_EINVAL; }
+    auto op = std::make_unique<PoolBwdOp>();
+    op->a = PoolArgs{dy, dx, 0, N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, c_stride}; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_warp_blend_backward(const float* d_final, const float* d_rawout, const float* raw, const float* flow,
+                                       const float* weight, const float* prev, const float* fg, const float* mask,
+                                       const float* gx, const float* gy, float* d_raw, float* d_flow, float* d_weight,
+                                       float* d_prev, float* d_fg, int32_t N, int32_t C, int32_t H, int32_t W,
+                                       int32_t align_corners, void* stream) {
+    if (!d_final || !d_raw || (flow && (!raw || !weight || !prev || !gx || !gy || !d_flow || !d_weight)) || (fg && (!mask || !d_fg))) {
+        set_error("warp_blend_backward: bad argument"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<WarpBwdOp>();
+    op->a = WarpBwdArgs{d_final, d_rawout, raw, flow, weight, prev, fg, mask, gx, gy, d_raw, d_flow, d_weight, d_prev,
+                        fg ? d_fg : nullptr, N, C, H, W, align_corners};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_resample_flow_backward(const float* d_out, const float* img, const float* flow, const float* gx,
+                                          const float* gy, float* d_img, float* d_flow, int32_t N, int32_t C,
+                                          int32_t H, int32_t W, int32_t align_corners, void* stream) {
+    if (!d_out || !img || !flow || !gx || !gy || (!d_img && !d_flow)) { set_error("resample_flow_backward: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<ResampleBwdOp>();
+    op->a = ResampleBwdArgs{d_out, img, flow, gx, gy, d_img, d_flow, N, C, H, W, align_corners};
     return submit(std::move(op), stream);
 }

@@ -53,6 +53,9 @@ class Act:
     def __init__(self, t, C):
         self.t, self.C = t, C
 
+    def detach(self):
+        return Act(self.t.detach(), self.C)
+
     @property
     def N(self): return self.t.shape[0]
     @property
@@ -63,26 +66,50 @@ class Act:
     def Cs(self): return self.t.stride(2)      # true channel stride (a channel-sliced view keeps its parent's)
 
 
-class PackedConv:
-    """Device-resident packed weights of one nn.Conv2d / nn.ConvTranspose2d."""
+_PARAM_EPOCH = [0]
 
-    def __init__(self, eng, mod, cin_stride):
+
+def bump_param_epoch():
+    """Called by optimizers that update parameters through a flat buffer (optim.FusedAdam): packed
+    weight copies are refreshed on next use."""
+    _PARAM_EPOCH[0] += 1
+
+
+class PackedConv:
+    """Device-resident packed weights of one nn.Conv2d / nn.ConvTranspose2d.
+
+    role 'fwd':   the layer's own operator.
+    role 'bwd':   its backward-data operator -- the SAME parameter tensor read with the roles of
+                  cin / cout swapped (include/v2v_hip.h, v2v_conv2d): a Conv2d becomes a transposed conv
+                  (stride s; pad p, or pad 0 behind a ReflectionPad2d), a ConvTranspose2d a stride-2 Conv2d.
+    """
+
+    def __init__(self, eng, mod, cin_stride, role="fwd", reflect=False):
         self.mod = mod
-        self.transposed = isinstance(mod, nn.ConvTranspose2d)
+        self.role = role
+        mod_t = isinstance(mod, nn.ConvTranspose2d)
         w = mod.weight
-        if self.transposed:
-            self.cin, self.cout = w.shape[0], w.shape[1]
-            if tuple(mod.stride) != (2, 2) or tuple(mod.kernel_size)[0] - 2 * mod.padding[0] + mod.output_padding[0] != 2:
-                raise NotImplementedError("ConvTranspose2d must be stride 2 with OH = 2H")
-        else:
-            self.cout, self.cin = w.shape[0], w.shape[1]
         self.KH, self.KW = mod.kernel_size
         self.stride = mod.stride[0]
-        self.pad = mod.padding[0]
+        if mod_t:
+            m_cin, m_cout = w.shape[0], w.shape[1]
+            if tuple(mod.stride) != (2, 2):
+                raise NotImplementedError("ConvTranspose2d must be stride 2")
+        else:
+            m_cout, m_cin = w.shape[0], w.shape[1]
+        if role == "fwd":
+            self.transposed = mod_t
+            self.cin, self.cout = m_cin, m_cout
+            self.pad = mod.padding[0]
+        else:
+            self.transposed = not mod_t
+            self.cin, self.cout = m_cout, m_cin          # dY channels in, dX channels out
+            self.pad = 0 if reflect else mod.padding[0]
+        self.out_pad = mod.output_padding[0] if mod_t else 0
         self.cin_stride = cin_stride
         self.dtype = eng.dtype
         n = lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, self.KH, self.KW,
-                                      int(self.transposed), self.pad, eng.dtype)
+                                      int(self.transposed), self.stride, self.pad, eng.dtype)
         self.buf = torch.empty(n, dtype=_TORCH_DTYPE[eng.dtype], device=eng.device)
         self.bias = None
         self.version = None
@@ -91,16 +118,18 @@ class PackedConv:
     def refresh(self, force=False):
         """(Re)pack if the parameter changed (optimizer step / load_state_dict)."""
         w = self.mod.weight
-        ver = (w._version, w.data_ptr(), None if self.mod.bias is None else self.mod.bias._version)
+        ver = (w._version, w.data_ptr(), None if self.mod.bias is None else self.mod.bias._version, _PARAM_EPOCH[0])
         if not force and ver == self.version:
             return
         w32 = w.detach()
         if w32.dtype != torch.float32 or not w32.is_contiguous():
             w32 = w32.float().contiguous()
         check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), self.cin, self.cin_stride, self.cout,
-                                        self.KH, self.KW, int(self.transposed), self.pad, self.dtype, _stream()),
+                                        self.KH, self.KW, int(self.transposed), self.stride, self.pad, self.dtype,
+                                        _stream()),
               "conv_pack_weights")
-        self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()
+        if self.role == "fwd":
+            self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()
         self.version = ver
 
 
@@ -219,6 +248,12 @@ class Engine:
         if self.plan is not None:
             self.plan.label(text)
 
+    def zero_page(self):
+        """256 zero bytes: source of padded / ragged lanes of the LDS-DMA loaders."""
+        if self._zero_page is None:
+            self._zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        return self._zero_page
+
     def grid(self, H, W):
         """Base sampling grid of get_grid (models/networks.py:79-93): torch.linspace(-1,1,n)."""
         key = (H, W)
@@ -229,12 +264,14 @@ class Engine:
         return self._grids[key]
 
     # ---------------- weights ----------------
-    def packed(self, mod, cin_stride):
-        key = (id(mod), cin_stride)
+    def packed(self, mod, cin_stride, role="fwd", reflect=False):
+        key = (id(mod), cin_stride, role, reflect)
         pc = self._packed.get(key)
         if pc is None:
-            pc = PackedConv(self, mod, cin_stride)
+            pc = PackedConv(self, mod, cin_stride, role, reflect)
             self._packed[key] = pc
+        elif self.plan is None:
+            pc.refresh()          # eager (training) use: follow optimizer updates
         return pc
 
     def refresh_weights(self, force=False):
@@ -249,15 +286,14 @@ class Engine:
         pad = pc.pad if pad_override is None else pad_override
         N, H, W = x.N, x.H, x.W
         if pc.transposed:
-            OH, OW = 2 * H, 2 * W
+            OH = (H - 1) * pc.stride - 2 * pad + pc.KH + pc.out_pad
+            OW = (W - 1) * pc.stride - 2 * pad + pc.KW + pc.out_pad
         else:
             OH = (H + 2 * pad - pc.KH) // pc.stride + 1
             OW = (W + 2 * pad - pc.KW) // pc.stride + 1
         d = ConvDesc()
         d.in_ = x.t.data_ptr(); d.w = pc.buf.data_ptr()
-        if self._zero_page is None:
-            self._zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
-        d.zero_page = self._zero_page.data_ptr()
+        d.zero_page = self.zero_page().data_ptr()
         self._keep(self._zero_page)
         d.bias = None if pc.bias is None else pc.bias.data_ptr()
         d.N, d.H, d.W = N, H, W
@@ -308,8 +344,9 @@ class Engine:
                                   tile=lib.v2v_conv_tile_config(C.byref(d))))
         return out, rows, (N, OH, OW)
 
-    def norm_apply(self, raw, rows, shape, cout, norm, act, act_param, add0=None, add1=None, label=""):
-        """bn_finalize + bn_apply on the shared raw/statistics scratch."""
+    def norm_apply(self, raw, rows, shape, cout, norm, act, act_param, add0=None, add1=None, label="", ss=None):
+        """bn_finalize + bn_apply on the shared raw/statistics scratch (ss: caller-owned [4][C] statistics
+        buffer, kept for the backward pass on the training path)."""
         N, OH, OW = shape
         cs_raw = (cout + 3) // 4 * 4
         if isinstance(norm, nn.BatchNorm2d):
@@ -326,7 +363,8 @@ class Engine:
             eps, mom, rm, rv = norm.eps, 0.1, None, None
         else:
             raise NotImplementedError("norm layer %r" % type(norm))
-        ss = self.scratch("scale_shift", 2 * cout)
+        if ss is None:
+            ss = self.scratch("scale_shift", 4 * cout)
         st = self.scratch("stats", rows * cout * 2)
         for t in (gamma, beta):
             if t is not None:
@@ -341,6 +379,25 @@ class Engine:
               "bn_apply " + label)
         self.label(label + ".apply")
         return y
+
+    def conv_group(self, x, conv, pad_mode, pad_override, norm, act, act_param, add0=None, add1=None,
+                   head_nchw=False, out_scale=1.0, label=""):
+        """One fused [pad] conv [norm] [act] [+ residuals] group.  Returns an Act, or the planar fp32 NCHW
+        tensor when head_nchw.  With autograd recording on (training) it is a v2v custom op
+        (autograd.ConvFn: same launches, tensors saved for the HIP backward kernels)."""
+        if self.plan is None and torch.is_grad_enabled() and not self.record_only:
+            from . import autograd as AG
+            return AG.conv_group(self, x, conv, pad_mode, pad_override, norm, act, act_param, add0, add1,
+                                 head_nchw, out_scale, label)
+        if norm is not None:
+            raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC, want_stats=True, label=label)
+            return self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param, add0=add0, add1=add1,
+                                   label=label)
+        if add0 is not None or add1 is not None:
+            raise NotImplementedError("residual adds need a norm layer in the group")
+        out, _, _ = self.conv(x, conv, pad_mode, pad_override, L.OUT_F32_NCHW if head_nchw else L.OUT_ACT_NHWC,
+                              act, act_param, out_scale if head_nchw else 1.0, label=label)
+        return out
 
     # ---------------- nn.Sequential lowering ----------------
     @staticmethod
@@ -383,20 +440,15 @@ class Engine:
                 last_group = i >= n
                 lbl = "%s.%d" % (name, i)
                 if norm is not None:
-                    raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC,
-                                               want_stats=True, label=lbl)
-                    x = self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param,
+                    x = self.conv_group(x, conv, pad_mode, pad_override, norm, act, act_param,
                                         add0=extra_add if last_group else None, label=lbl)
                     if last_group:
                         extra_add = None
                 elif head_nchw and last_group:
-                    out, _, _ = self.conv(x, conv, pad_mode, pad_override, L.OUT_F32_NCHW, act, act_param,
-                                          out_scale, label=lbl)
-                    return out
+                    return self.conv_group(x, conv, pad_mode, pad_override, None, act, act_param,
+                                           head_nchw=True, out_scale=out_scale, label=lbl)
                 else:
-                    out, _, _ = self.conv(x, conv, pad_mode, pad_override, L.OUT_ACT_NHWC, act, act_param,
-                                          1.0, label=lbl)
-                    x = out
+                    x = self.conv_group(x, conv, pad_mode, pad_override, None, act, act_param, label=lbl)
             elif hasattr(m, "conv_block"):      # ResnetBlock (models/networks.py:554-593)
                 i += 1
                 last_group = i >= n
@@ -429,17 +481,20 @@ class Engine:
             return pad_mode, pad_override, conv, norm, j + 2
         pm, po, conv1, norm1, j = take(0)
         act, act_param = self._act_code(mods[j]); j += 1
-        raw, rows, shp = self.conv(x, conv1, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, label=name + ".c1")
-        h = self.norm_apply(raw, rows, shp, conv1.out_channels, norm1, act, act_param, label=name + ".c1")
+        h = self.conv_group(x, conv1, pm, po, norm1, act, act_param, label=name + ".c1")
         pm, po, conv2, norm2, j = take(j)
-        raw, rows, shp = self.conv(h, conv2, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, label=name + ".c2")
-        return self.norm_apply(raw, rows, shp, conv2.out_channels, norm2, L.ACT_NONE, 0.0,
-                               add0=x, add1=extra_add, label=name + ".c2")
+        return self.conv_group(h, conv2, pm, po, norm2, L.ACT_NONE, 0.0, add0=x, add1=extra_add, label=name + ".c2")
 
     # ---------------- other ops ----------------
+    def _training(self):
+        return self.plan is None and torch.is_grad_enabled() and not self.record_only
+
     def add(self, a, b):
         if a.t.shape != b.t.shape:
             raise RuntimeError("add: shape mismatch %s vs %s" % (tuple(a.t.shape), tuple(b.t.shape)))
+        if self._training() and (a.t.requires_grad or b.t.requires_grad):
+            from . import autograd as AG
+            return Act(AG.AddFn.apply(self, a.t, b.t), a.C)
         y = self.empty_act(a.N, a.H, a.W, a.C)
         check(lib.v2v_add_nhwc(_ptr(a.t), _ptr(b.t), _ptr(y.t), a.t.numel(), self.dtype, _stream()), "add")
         self.label("add_nhwc")
@@ -474,12 +529,18 @@ class Engine:
 
     def pack(self, x_nchw):
         N, Cc, H, W = x_nchw.shape
+        if self._training() and x_nchw.requires_grad:
+            from . import autograd as AG
+            return Act(AG.PackFn.apply(self, x_nchw, None, 1.0), Cc)
         out = self.empty_act(N, H, W, Cc)
         check(lib.v2v_pack_nchw_to_nhwc(_ptr(x_nchw), _ptr(out.t), N, Cc, H, W, out.Cs, self.dtype, _stream()), "pack")
         self.label("pack_nchw_to_nhwc")
         return out
 
     def unpack(self, x):
+        if self._training() and x.t.requires_grad:
+            from . import autograd as AG
+            return AG.UnpackFn.apply(self, x.t, x.C)
         out = self.empty_f32(x.N, x.C, x.H, x.W)
         check(lib.v2v_unpack_nhwc_to_nchw(_ptr(x.t), _ptr(out), x.N, x.C, x.H, x.W, x.Cs, self.dtype, _stream()), "unpack")
         self.label("unpack_nhwc_to_nchw")
@@ -487,6 +548,9 @@ class Engine:
 
     def avgpool_nhwc(self, x):
         OH, OW = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+        if self._training() and x.t.requires_grad:
+            from . import autograd as AG
+            return Act(AG.AvgPoolFn.apply(self, x.t), x.C)
         out = self.empty_act(x.N, OH, OW, x.C)
         check(lib.v2v_avgpool3s2_nhwc(_ptr(x.t), _ptr(out.t), x.N, x.H, x.W, x.Cs, self.dtype, _stream()), "avgpool_nhwc")
         self.label("avgpool3s2_nhwc")
@@ -504,6 +568,10 @@ class Engine:
 
     def warp_blend(self, img_raw, flow, weight, prev, fg, mask, want_warp=False):
         N, Cc, H, W = img_raw.shape
+        if self._training() and any(t is not None and t.requires_grad for t in (img_raw, flow, weight, prev, fg)):
+            from . import autograd as AG
+            final, raw_blend = AG.WarpBlendFn.apply(self, img_raw, flow, weight, prev, fg, mask)
+            return (final, raw_blend), None
         gx, gy = self.grid(H, W)
         final = self.empty_f32(N, Cc, H, W)
         warp = self.empty_f32(N, Cc, H, W) if (want_warp and flow is not None) else None
@@ -517,6 +585,9 @@ class Engine:
 
     def resample_flow(self, img, flow):
         N, Cc, H, W = img.shape
+        if self._training() and (img.requires_grad or flow.requires_grad):
+            from . import autograd as AG
+            return AG.ResampleFn.apply(self, img, flow)
         gx, gy = self.grid(H, W)
         out = self.empty_f32(N, Cc, H, W)
         check(lib.v2v_resample_flow(_ptr(img), _ptr(flow), _ptr(out), _ptr(gx), _ptr(gy), N, Cc, H, W,

@@ -36,14 +36,44 @@ class ConvDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    """struct v2v_wgrad_desc"""
+    _fields_ = [
+        ("p", C.c_void_p), ("q", C.c_void_p), ("grad", C.c_void_p), ("workspace", C.c_void_p), ("zero_page", C.c_void_p),
+        ("N", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32), ("QH", C.c_int32), ("QW", C.c_int32),
+        ("rows", C.c_int32), ("cols", C.c_int32), ("p_stride", C.c_int32), ("q_stride", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("pad_mode", C.c_int32),
+        ("dtype", C.c_int32), ("accumulate", C.c_int32),
+    ]
+
+
+LOSS_MSE_CONST, LOSS_L1 = 0, 1
+
 # name -> (restype, argtypes); mirrors include/v2v_hip.h one to one
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 PROTOTYPES = {
-    "v2v_conv_packed_elems": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
-    "v2v_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_conv_packed_elems": (_L, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "v2v_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_conv_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_tile_config": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
+    "v2v_conv_wgrad_workspace": (_L, [C.POINTER(WgradDesc)]),
+    "v2v_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P]),
+    "v2v_bn_backward_rows": (C.c_int, [_L]),
+    "v2v_bn_backward": (C.c_int, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _L, _I, _I, _I, _F, _I, _P]),
+    "v2v_channel_sum": (C.c_int, [_P, _P, _I, _P, _L, _I, _I, _I, _P]),
+    "v2v_act_backward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "v2v_avgpool3s2_nhwc_backward": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_pack_concat_nhwc": (C.c_int, [_P, _I, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_unpack_channels_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_reflect_pad_fold": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_warp_blend_backward": (C.c_int, [_P] * 15 + [_I] * 5 + [_P]),
+    "v2v_resample_flow_backward": (C.c_int, [_P] * 7 + [_I] * 5 + [_P]),
+    "v2v_loss_workspace_floats": (C.c_int, []),
+    "v2v_loss_forward": (C.c_int, [_I, _P, _P, _P, _F, _F, _L, _I, _I, _L, _L, _L, _I, _P, _P, _I, _P]),
+    "v2v_loss_backward": (C.c_int, [_I, _P, _P, _P, _F, _F, _L, _I, _I, _L, _L, _L, _I, _P, _P, _I, _P]),
+    "v2v_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "v2v_memset_zero": (C.c_int, [_P, _L, _P]),
     "v2v_bn_finalize": (C.c_int, [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P, _F, _P]),
     "v2v_bn_apply": (C.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
     "v2v_avgpool3s2_planar": (C.c_int, [_P, _P, _L, _I, _I, _P]),

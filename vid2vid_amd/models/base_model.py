@@ -134,7 +134,8 @@ class BaseModel(torch.nn.Module):
         params = []
         for s in range(self.n_scales):
             params += list(getattr(self, "netG" + str(s)).parameters())
-        self.optimizer_G = torch.optim.Adam(params, lr=self.old_lr, betas=(self.opt.beta1, 0.999))
+        from ..optim import FusedAdam
+        self.optimizer_G = FusedAdam(params, lr=self.old_lr, betas=(self.opt.beta1, 0.999))
         self.finetune_all = True
         print("------------ Now finetuning all scales -----------")
 

@@ -1,0 +1,275 @@
+"""Vid2VidModelD on the MI355X backend.
+
+API-compatible with the reference's models/vid2vid_model_D.py: `initialize(opt)`,
+`forward(scale_T, tensors_list) -> [loss (1,1) tensors]` in the order of `loss_names` /
+`loss_names_T`, `get_all_skipped_frames`, `get_losses`, `save`, optimizers `optimizer_D`,
+`optimizer_D_T{s}`.  Every discriminator forward, loss reduction and their backward passes are
+libv2v_hip.so launches recorded as `v2v` custom ops (autograd.py); the only torch arithmetic left is
+the addition / scaling of the (1,1) loss scalars, exactly where the reference has it.
+"""
+import torch
+
+from .. import autograd as AG
+from .. import networks
+from ..optim import FusedAdam
+from .base_model import BaseModel
+
+
+class Vid2VidModelD(BaseModel):
+    def name(self):
+        return "Vid2VidModelD"
+
+    def initialize(self, opt):
+        BaseModel.initialize(self, opt)
+        self.tD = opt.n_frames_D
+        self.output_nc = opt.output_nc
+        self.n_scales = opt.n_scales_spatial
+        if opt.add_face_disc:
+            raise NotImplementedError("--add_face_disc (pose recipes) is outside the MI355X hot path (SURVEY 8a13)")
+        if not opt.no_vgg:
+            raise NotImplementedError("VGG19 perceptual loss needs downloaded torchvision weights "
+                                      "(SURVEY 8f rank 1): train with --no_vgg")
+        if opt.gan_mode != "ls":
+            raise NotImplementedError("only the LSGAN objective (--gan_mode ls, the reference default) is implemented")
+
+        # single-image discriminator (reference :29-36)
+        self.input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+        if opt.use_instance:
+            self.input_nc += 1
+        netD_input_nc = self.input_nc + opt.output_nc
+        gpu_ids = self.dev_ids
+        self.netD = networks.define_D(netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm, opt.num_D,
+                                      not opt.no_ganFeat, gpu_ids=gpu_ids)
+        # temporal discriminators (reference :42-46)
+        netD_input_nc = opt.output_nc * opt.n_frames_D + 2 * (opt.n_frames_D - 1)
+        for s in range(opt.n_scales_temporal):
+            setattr(self, "netD_T" + str(s),
+                    networks.define_D(netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm, opt.num_D,
+                                      not opt.no_ganFeat, gpu_ids=gpu_ids))
+        print("---------- Networks initialized -------------")
+
+        if opt.continue_train or opt.load_pretrain:
+            self.load_network(self.netD, "D", opt.which_epoch, opt.load_pretrain)
+            for s in range(opt.n_scales_temporal):
+                self.load_network(getattr(self, "netD_T" + str(s)), "D_T" + str(s), opt.which_epoch, opt.load_pretrain)
+
+        self.old_lr = opt.lr
+        self.loss_names = ["G_VGG", "G_GAN", "G_GAN_Feat", "D_real", "D_fake", "G_Warp", "F_Flow", "F_Warp", "W"]
+        self.loss_names_T = ["G_T_GAN", "G_T_GAN_Feat", "D_T_real", "D_T_fake", "G_T_Warp"]
+
+        if opt.TTUR:
+            beta1, beta2, lr = 0, 0.9, opt.lr * 2
+        else:
+            beta1, beta2, lr = opt.beta1, 0.999, opt.lr
+        self.optimizer_D = FusedAdam(list(self.netD.parameters()), lr=lr, betas=(beta1, beta2))
+        for s in range(opt.n_scales_temporal):
+            params = list(getattr(self, "netD_T" + str(s)).parameters())
+            setattr(self, "optimizer_D_T" + str(s), FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999)))
+
+    # ------------------------------------------------------------------ losses
+    def _zero(self):
+        return torch.zeros(1, 1, dtype=torch.float32, device=self.device)
+
+    def criterionGAN(self, preds, target_is_real):
+        """GANLoss.__call__ for multiscale predictions: sum over scales of MSE(pred_last, 1 or 0)
+        (models/networks.py:764-771)."""
+        eng = self.engine
+        target = 1.0 if target_is_real else 0.0
+        loss = None
+        for feats in preds:
+            l = AG.mse_const_act(eng, feats[-1], target)
+            loss = l if loss is None else loss + l
+        return loss
+
+    def GAN_and_FM_loss(self, pred_real, pred_fake):
+        """reference :199-213"""
+        opt, eng = self.opt, self.engine
+        loss_G_GAN = self.criterionGAN(pred_fake, True)
+        loss_FM = self._zero()
+        if not opt.no_ganFeat:
+            w = (4.0 / (opt.n_layers_D + 1)) * (1.0 / opt.num_D) * opt.lambda_feat
+            for i in range(min(len(pred_fake), opt.num_D)):
+                for j in range(len(pred_fake[i]) - 1):
+                    loss_FM = loss_FM + AG.l1_act(eng, pred_fake[i][j], pred_real[i][j], weight=w)
+        return loss_G_GAN, loss_FM
+
+    def _run_D(self, netD, x0, x1, scale1=1.0, tag="D"):
+        eng = self.engine
+        return netD.emit(eng, AG.pack_concat(eng, x0, x1, scale1), tag=tag)
+
+    def compute_loss_D(self, netD, real_A, real_B, fake_B):
+        """reference :168-179 -- three discriminator passes (real, fake detached, fake)."""
+        pred_real = self._run_D(netD, real_A, real_B)
+        pred_fake = self._run_D(netD, real_A, fake_B.detach())
+        loss_D_real = self.criterionGAN(pred_real, True)
+        loss_D_fake = self.criterionGAN(pred_fake, False)
+        pred_fake = self._run_D(netD, real_A, fake_B)
+        loss_G_GAN, loss_G_GAN_Feat = self.GAN_and_FM_loss(pred_real, pred_fake)
+        return loss_D_real, loss_D_fake, loss_G_GAN, loss_G_GAN_Feat
+
+    def compute_loss_D_T(self, real_B, fake_B, flow_ref, conf_ref, scale_T, flow_scale):
+        """reference :181-197; flow_ref arrives unscaled, the /20 of :107-108 is folded into the pack."""
+        netD_T = getattr(self, "netD_T" + str(scale_T))
+        H, W = self.height, self.width
+        real_B = real_B.reshape(-1, self.output_nc * self.tD, H, W)
+        fake_B = fake_B.reshape(-1, self.output_nc * self.tD, H, W)
+        if flow_ref is not None:
+            flow_ref = flow_ref.reshape(-1, 2 * (self.tD - 1), H, W)
+        tag = "D_T%d" % scale_T
+        pred_real = self._run_D(netD_T, real_B, flow_ref, flow_scale, tag)
+        pred_fake = self._run_D(netD_T, fake_B.detach(), flow_ref, flow_scale, tag)
+        loss_D_T_real = self.criterionGAN(pred_real, True)
+        loss_D_T_fake = self.criterionGAN(pred_fake, False)
+        pred_fake = self._run_D(netD_T, fake_B, flow_ref, flow_scale, tag)
+        loss_G_T_GAN, loss_G_T_GAN_Feat = self.GAN_and_FM_loss(pred_real, pred_fake)
+        return loss_D_T_real, loss_D_T_fake, loss_G_T_GAN, loss_G_T_GAN_Feat
+
+    def forward(self, scale_T, tensors_list, dummy_bs=0):
+        opt, eng = self.opt, self.engine
+        lambda_feat, lambda_F, lambda_T = opt.lambda_feat, opt.lambda_F, opt.lambda_T
+        scale_S = opt.n_scales_spatial
+        if dummy_bs:
+            tensors_list = [None if t is None else t[dummy_bs:] for t in tensors_list]
+        eng.refresh_weights()
+        dev = self.device
+
+        def dv(t):
+            return None if t is None else t.to(dev, torch.float32)
+
+        if scale_T > 0:
+            real_B, fake_B, flow_ref, conf_ref = [dv(t) for t in tensors_list]
+            _, _, _, self.height, self.width = real_B.size()
+            l_real, l_fake, l_gan, l_feat = self.compute_loss_D_T(real_B, fake_B, flow_ref, conf_ref, scale_T - 1, 1.0 / 20.0)
+            loss_list = [l_gan, l_feat, l_real, l_fake, self._zero()]
+            return [l.view(-1, 1) for l in loss_list]
+
+        (real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref) = \
+            [dv(t) for t in tensors_list]
+        _, _, self.height, self.width = real_B.size()
+
+        # ---- flow losses (reference :114-131) ----
+        if flow is not None:
+            loss_F_Flow = AG.masked_l1(eng, flow, flow_ref, conf_ref, weight=lambda_F / (2 ** (scale_S - 1)))
+            real_B_warp = eng.resample_flow(real_B_prev.contiguous(), flow.contiguous())
+            loss_F_Warp = AG.masked_l1(eng, real_B_warp, real_B, conf_ref, weight=lambda_T)
+            loss_W = self._zero()
+            if opt.no_first_img:
+                loss_W = AG.masked_l1(eng, weight, torch.zeros_like(weight), conf_ref)
+        else:
+            loss_F_Flow, loss_F_Warp, loss_W = self._zero(), self._zero(), self._zero()
+
+        # ---- image GAN + feature matching (reference :133-147) ----
+        loss_G_VGG = self._zero()
+        loss_D_real, loss_D_fake, loss_G_GAN, loss_G_GAN_Feat = self.compute_loss_D(self.netD, real_A, real_B, fake_B)
+        with torch.no_grad():
+            fake_B_warp_ref = eng.resample_flow(fake_B_prev.detach().contiguous(), flow_ref.contiguous())
+        loss_G_Warp = AG.masked_l1(eng, fake_B, fake_B_warp_ref, conf_ref, weight=lambda_T)
+        if fake_B_raw is not None:
+            l_D_real, l_D_fake, l_G_GAN, l_G_GAN_Feat = self.compute_loss_D(self.netD, real_A, real_B, fake_B_raw)
+            loss_G_GAN = loss_G_GAN + l_G_GAN
+            loss_G_GAN_Feat = loss_G_GAN_Feat + l_G_GAN_Feat
+            loss_D_real = loss_D_real + l_D_real
+            loss_D_fake = loss_D_fake + l_D_fake
+
+        loss_list = [loss_G_VGG, loss_G_GAN, loss_G_GAN_Feat, loss_D_real, loss_D_fake,
+                     loss_G_Warp, loss_F_Flow, loss_F_Warp, loss_W]
+        return [l.view(-1, 1) for l in loss_list]
+
+    # ------------------------------------------------------------------ bookkeeping used by train.py
+    def get_all_skipped_frames(self, frames_all, real_B, fake_B, flow_ref, conf_ref, t_scales, tD, n_frames_load, i, flowNet):
+        """Rolling frame history -> tD-strided groups per temporal scale (reference :232-247)."""
+        real_B_all, fake_B_all, flow_ref_all, conf_ref_all = frames_all
+        real_B_sk = fake_B_sk = flow_ref_sk = conf_ref_sk = None
+        if t_scales > 0:
+            if self.opt.sparse_D:
+                real_B_all, real_B_sk = get_skipped_frames_sparse(real_B_all, real_B, t_scales, tD, n_frames_load, i)
+                fake_B_all, fake_B_sk = get_skipped_frames_sparse(fake_B_all, fake_B, t_scales, tD, n_frames_load, i)
+                flow_ref_all, flow_ref_sk = get_skipped_frames_sparse(flow_ref_all, flow_ref, t_scales, tD, n_frames_load, i, is_flow=True)
+                conf_ref_all, conf_ref_sk = get_skipped_frames_sparse(conf_ref_all, conf_ref, t_scales, tD, n_frames_load, i, is_flow=True)
+            else:
+                real_B_all, real_B_sk = get_skipped_frames(real_B_all, real_B, t_scales, tD)
+                fake_B_all, fake_B_sk = get_skipped_frames(fake_B_all, fake_B, t_scales, tD)
+                flow_ref_all, conf_ref_all, flow_ref_sk, conf_ref_sk = get_skipped_flows(
+                    flowNet, flow_ref_all, conf_ref_all, real_B_sk, flow_ref, conf_ref, t_scales, tD)
+        return (real_B_all, fake_B_all, flow_ref_all, conf_ref_all), (real_B_sk, fake_B_sk, flow_ref_sk, conf_ref_sk)
+
+    def get_losses(self, loss_dict, loss_dict_T, t_scales):
+        """reference :249-264"""
+        loss_D = (loss_dict["D_fake"] + loss_dict["D_real"]) * 0.5
+        loss_G = loss_dict["G_GAN"] + loss_dict["G_GAN_Feat"] + loss_dict["G_VGG"]
+        loss_G = loss_G + loss_dict["G_Warp"] + loss_dict["F_Flow"] + loss_dict["F_Warp"] + loss_dict["W"]
+        loss_D_T = []
+        t_scales_act = min(t_scales, len(loss_dict_T))
+        for s in range(t_scales_act):
+            loss_G = loss_G + loss_dict_T[s]["G_T_GAN"] + loss_dict_T[s]["G_T_GAN_Feat"] + loss_dict_T[s]["G_T_Warp"]
+            loss_D_T.append((loss_dict_T[s]["D_T_fake"] + loss_dict_T[s]["D_T_real"]) * 0.5)
+        return loss_G, loss_D, loss_D_T, t_scales_act
+
+    def save(self, label):
+        self.save_network(self.netD, "D", label, self.gpu_ids)
+        for s in range(self.opt.n_scales_temporal):
+            self.save_network(getattr(self, "netD_T" + str(s)), "D_T" + str(s), label, self.gpu_ids)
+
+
+# --------------------------------------------------------------------------------------
+# temporal sub-sampling of the frame history (reference :274-328): pure indexing
+# --------------------------------------------------------------------------------------
+def get_skipped_frames(B_all, B, t_scales, tD):
+    """Append B to the history; for temporal scale s return the groups of tD frames spaced tD**s apart
+    that end at each of the newest frames (stacked along dim 0)."""
+    B_all = B if B_all is None else torch.cat([B_all.detach(), B], dim=1)
+    skipped = [None] * t_scales
+    total, new = B_all.size(1), B.size(1)
+    for s in range(t_scales):
+        step = tD ** s
+        span = step * (tD - 1)
+        n_groups = min(total - span, new)
+        groups = []
+        for t in range(0, max(n_groups, 0), tD):
+            end = total - t                       # one past the last frame of this group
+            groups.append(B_all[:, end - span - 1:end:step].contiguous())
+        if groups:
+            skipped[s] = groups[0] if len(groups) == 1 else torch.cat(groups)
+    keep = tD ** (t_scales - 1) * (tD - 1)
+    if total > keep:
+        B_all = B_all[:, -keep:]
+    return B_all, skipped
+
+
+def get_skipped_flows(flowNet, flow_ref_all, conf_ref_all, real_B, flow_ref, conf_ref, t_scales, tD):
+    """Scale 0 re-uses the consecutive-frame flows; coarser temporal scales re-run FlowNet on the
+    strided frames (reference :292-302)."""
+    flow_sk, conf_sk = [None] * t_scales, [None] * t_scales
+    flow_ref_all, flow = get_skipped_frames(flow_ref_all, flow_ref, 1, tD)
+    conf_ref_all, conf = get_skipped_frames(conf_ref_all, conf_ref, 1, tD)
+    if flow[0] is not None:
+        flow_sk[0], conf_sk[0] = flow[0][:, 1:], conf[0][:, 1:]
+    for s in range(1, t_scales):
+        if real_B[s] is not None and real_B[s].size(1) == tD:
+            flow_sk[s], conf_sk[s] = flowNet(real_B[s][:, 1:], real_B[s][:, :-1])
+    return flow_ref_all, conf_ref_all, flow_sk, conf_sk
+
+
+def get_skipped_frames_sparse(B_all, B, t_scales, tD, n_frames_load, i, is_flow=False):
+    """--sparse_D variant (reference :304-328): per-scale histories that only keep every tD**s-th frame."""
+    skipped = [None] * t_scales
+    _, _, ch, h, w = B.size()
+    for s in range(t_scales):
+        t_len = B_all[s].size(1) if B_all[s] is not None else 0
+        if t_len > 0 and (t_len % tD) == 0:
+            B_all[s] = B_all[s][:, (-tD + 1):]
+        if s == 0:
+            B_all[0] = B if B_all[0] is None else torch.cat([B_all[0].detach(), B], dim=1)
+        else:
+            step = tD ** s
+            start = 0 if i == 0 else step - ((i - 1) % step + 1)
+            if start < n_frames_load:
+                tmp = B[:, start::step].contiguous()
+                B_all[s] = tmp if B_all[s] is None else torch.cat([B_all[s].detach(), tmp], dim=1)
+        t_len = B_all[s].size(1) if B_all[s] is not None else 0
+        if t_len >= tD:
+            B_all[s] = B_all[s][:, (t_len % tD):]
+            skipped[s] = B_all[s].reshape(-1, tD, ch, h, w)
+            if is_flow:
+                skipped[s] = skipped[s][:, 1:]
+    return B_all, skipped

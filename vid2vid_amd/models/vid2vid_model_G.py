@@ -16,6 +16,7 @@ import torch
 from .. import lib as L
 from .. import networks
 from ..engine import Act, Plan
+from ..optim import FusedAdam
 from .base_model import BaseModel
 
 
@@ -158,7 +159,7 @@ class Vid2VidModelG(BaseModel):
                 beta1, beta2, lr = 0, 0.9, opt.lr / 2
             else:
                 beta1, beta2, lr = opt.beta1, 0.999, opt.lr
-            self.optimizer_G = torch.optim.Adam(params, lr=lr, betas=(beta1, beta2))
+            self.optimizer_G = FusedAdam(params, lr=lr, betas=(beta1, beta2))
 
     # ------------------------------------------------------------------ inference
     def _frame_plan(self, H, W, in_ch, has_inst, use_raw_only):
@@ -252,6 +253,95 @@ class Vid2VidModelG(BaseModel):
         elif not getattr(opt, "random_init_ok", False):
             raise RuntimeError("%s not found" % path)
         return netG
+
+    # ------------------------------------------------------------------ training
+    def encode_input(self, input_map, real_image=None, inst_map=None):
+        """One-hot labels + instance edges as the planar (B,T,C,H,W) tensor the reference returns
+        (reference :86-112); produced by the fused NHWC encoder + one layout pass, never by scatter_."""
+        opt, eng, dev = self.opt, self.engine, self.device
+        B, T, _, H, W = input_map.shape
+        if opt.label_nc != 0:
+            per = opt.label_nc + (1 if (opt.use_instance and inst_map is not None) else 0)
+            outs = []
+            for b in range(B):
+                lab = input_map[b, :, 0].to(dev, torch.float32).contiguous()
+                inst = inst_map[b, :, 0].to(dev, torch.float32).contiguous() if per != opt.label_nc else None
+                with torch.no_grad():
+                    x, _ = eng.encode_labels(lab, inst, T, H, W, opt.label_nc, (), False)
+                    outs.append(eng.unpack(x).view(1, T, per, H, W))
+            real_A = outs[0] if B == 1 else torch.cat(outs, 0)
+        else:
+            real_A = input_map.to(dev, torch.float32)
+            if opt.use_instance and inst_map is not None:
+                real_A = torch.cat([real_A, self.get_edges(inst_map.to(dev, torch.float32))], dim=2)
+        real_B = None if real_image is None else real_image.to(dev, torch.float32)
+        return real_A, real_B, None
+
+    def forward(self, input_A, input_B, inst_A, fake_B_prev, dummy_bs=0):
+        """n_frames_load frames with autograd (reference :114-137).  Returns the reference's 7-tuple."""
+        tG = self.opt.n_frames_G
+        if dummy_bs:
+            input_A, input_B, inst_A, fake_B_prev = [None if t is None else t[dummy_bs:] for t in
+                                                     (input_A, input_B, inst_A, fake_B_prev)]
+        self.engine.refresh_weights()
+        real_A_all, real_B_all, _ = self.encode_input(input_A, input_B, inst_A)
+        self.bs = real_A_all.shape[0]
+        is_first_frame = fake_B_prev is None
+        if is_first_frame:
+            with torch.no_grad():
+                fake_B_prev = self._first_frames_train(real_A_all, real_B_all)
+        fake_B, fake_B_raw, flow, weight = self.generate_frame_train(real_A_all, list(fake_B_prev), is_first_frame)
+        fake_B_prev = [B[:, -tG + 1:].detach() for B in fake_B]
+        fake_B = [B[:, tG - 1:] for B in fake_B]
+        return fake_B[0], fake_B_raw, flow, weight, real_A_all[:, tG - 1:], real_B_all[:, tG - 2:], fake_B_prev
+
+    def _first_frames_train(self, real_A_all, real_B_all):
+        """Pyramid (finest first) of the tG-1 frames preceding the first generated one, (B,tG-1,3,h,w)."""
+        opt, tG = self.opt, self.opt.n_frames_G
+        B, _, _, H, W = real_A_all.shape
+        if opt.no_first_img:
+            first = torch.zeros(B, tG - 1, opt.output_nc, H, W, dtype=torch.float32, device=self.device)
+        else:                       # isTrain: the real frames (reference :236-238)
+            first = real_B_all[:, :tG - 1].contiguous()
+        return self.build_pyr(first)
+
+    def generate_frame_train(self, real_A_all, fake_B_pyr, is_first_frame):
+        """Frame-sequential, coarse-to-fine generation with the reference's detach rules (:139-196)."""
+        opt, eng = self.opt, self.engine
+        tG, S = opt.n_frames_G, self.n_scales
+        with torch.no_grad():
+            real_A_pyr = self.build_pyr(real_A_all.contiguous())
+        per = real_A_all.shape[2]
+        fake_Bs_raw = flows = weights = None
+        for t in range(self.n_frames_load):
+            feat = flow_feat = fg_feat = None
+            for s in range(S):
+                si = S - 1 - s
+                real_As = real_A_pyr[si]
+                _, _, _, h, w = real_As.shape
+                x = eng.pack(real_As[:, t:t + tG].reshape(self.bs, -1, h, w).contiguous())
+                prevs = fake_B_pyr[si][:, t:t + tG - 1]
+                if (t % self.n_frames_bp) == 0:
+                    prevs = prevs.detach()
+                prev_nchw = prevs.reshape(self.bs, -1, h, w).contiguous()
+                mask = eng.fg_mask(x, (tG - 1) * per, opt.fg_labels) if opt.fg else None
+                use_raw_only = bool(opt.no_first_img and is_first_frame)
+                netG = getattr(self, "netG" + str(s))
+                fake_B, flow, weight, fake_B_raw, feat, flow_feat, fg_feat = netG.emit(
+                    eng, x, eng.pack(prev_nchw), prev_nchw, mask, feat, flow_feat, fg_feat, use_raw_only, tag="G%d" % s)
+                if s != S - 1 and not self.finetune_all:       # train the finest scale only (:181-186)
+                    fake_B, feat = fake_B.detach(), feat.detach()
+                    if flow is not None:
+                        flow, flow_feat = flow.detach(), flow_feat.detach()
+                    if fg_feat is not None:
+                        fg_feat = fg_feat.detach()
+                fake_B_pyr[si] = self.concat([fake_B_pyr[si], fake_B.unsqueeze(1)], dim=1)
+                if s == S - 1:
+                    fake_Bs_raw = self.concat([fake_Bs_raw, fake_B_raw.unsqueeze(1)], dim=1)
+                    if flow is not None:
+                        flows = self.concat([flows, flow.unsqueeze(1)], dim=1)
+                        weights = self.concat([weights, weight.unsqueeze(1)], dim=1)
+        return fake_B_pyr, fake_Bs_raw, flows, weights
 
     # ------------------------------------------------------------------ helpers used by train.py
     def compute_mask(self, real_As, ts, te=None):

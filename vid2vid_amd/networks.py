@@ -202,9 +202,11 @@ class BaseNetwork(nn.Module):
         prev3 = img_prev_nchw[:, -3:].contiguous() if do_warp else None
         if mask is not None:
             mask = mask.contiguous().float()
-        final, _ = eng.warp_blend(img_raw, flow if do_warp else None, weight if do_warp else None, prev3,
-                                  img_fg, mask if img_fg is not None else None)
-        return final, img_raw
+        res, _ = eng.warp_blend(img_raw, flow if do_warp else None, weight if do_warp else None, prev3,
+                                img_fg, mask if img_fg is not None else None)
+        if isinstance(res, tuple):          # training graph: (img_final, blended img_raw), inputs untouched
+            return res
+        return res, img_raw                 # inference: img_raw was blended in place
 
 
 class CompositeGenerator(BaseNetwork):

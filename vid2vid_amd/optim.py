@@ -1,0 +1,97 @@
+"""Fused Adam over flat parameter / gradient / moment buffers.
+
+Replaces the reference's `torch.optim.Adam` instances (models/vid2vid_model_G.py:84,
+models/vid2vid_model_D.py:86-91; stepped 2+T times per chunk by train.py:130-138).  All parameters of
+an optimizer are re-homed as views into ONE flat fp32 buffer, their `.grad`s as views into a second
+one; the HIP backward kernels accumulate straight into those views (autograd.py), so that
+
+    zero_grad()  = one hipMemsetAsync            (v2v_memset_zero)
+    all-reduce   = RCCL on the flat gradient     (parallel.GradSync, bucketed views of the same buffer)
+    step()       = one kernel launch             (v2v_adam_step)
+
+instead of ~400 tensors x (7 elementwise passes + launches).  Same update rule and defaults as
+torch.optim.Adam (no amsgrad); `param_groups[0]['lr']` is honoured so the reference's
+update_learning_rate (models/base_model.py:154-160) keeps working.
+"""
+import ctypes as C
+
+import torch
+
+
+class FlatBuffers:
+    """Re-homes parameters (and their gradients) into contiguous flat buffers.  Pure tensor-view
+    bookkeeping: works on any device (the gloo CPU tests use it as is)."""
+
+    def __init__(self, params, align=64):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatBuffers: no trainable parameters")
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("parameters must be fp32 (bf16 is a storage format of activations / packed weights)")
+            offs.append(total)
+            total += (p.numel() + align - 1) // align * align
+        self.numel = total
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = offs
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                view = self.flat_param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def rebind_grads(self):
+        """Re-attach `.grad` views (e.g. after a foreign zero_grad(set_to_none=True))."""
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, weight_decay=0.0, grad_sync=None):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("FusedAdam keeps one flat buffer: pass a single parameter list")
+        self.flat = FlatBuffers(self.param_groups[0]["params"])
+        self.exp_avg = torch.zeros_like(self.flat.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
+        self.step_count = 0
+        self.grad_sync = grad_sync          # parallel.GradSync or None (single process)
+
+    def zero_grad(self, set_to_none=False):
+        from .lib import lib, check
+        self.flat.rebind_grads()
+        g = self.flat.flat_grad
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if g.is_cuda else None
+        if not g.is_cuda:
+            raise RuntimeError("FusedAdam runs on the MI355X only")
+        check(lib.v2v_memset_zero(C.c_void_p(g.data_ptr()), g.numel() * 4, stream), "memset_zero")
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not used by vid2vid")
+        from .lib import lib, check
+        from .engine import bump_param_epoch
+        f = self.flat
+        if not f.flat_param.is_cuda:
+            raise RuntimeError("FusedAdam runs on the MI355X only")
+        f.rebind_grads()
+        gscale = 1.0
+        if self.grad_sync is not None:
+            gscale = self.grad_sync.all_reduce(f.flat_grad)  # RCCL sum, bucketed; returns 1/world
+        grp = self.param_groups[0]
+        self.step_count += 1
+        b1, b2 = grp["betas"]
+        check(lib.v2v_adam_step(C.c_void_p(f.flat_param.data_ptr()), C.c_void_p(f.flat_grad.data_ptr()),
+                                C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+                                f.numel, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
+                                float(grp["weight_decay"]), float(gscale), self.step_count,
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "adam_step")
+        bump_param_epoch()                                   # packed weight copies are now stale
+        return None
