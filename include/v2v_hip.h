@@ -266,6 +266,29 @@ int v2v_resample2d_forward(const float* img, const float* flow, float* out,
 int v2v_channelnorm_forward(const float* x, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
                             int32_t norm_deg, void* stream);
 
+/* ---- FlowNet2 glue (models/flownet2_pytorch/models.py:96-161, models/flownet.py:43-59) ---- */
+/* x1, x2 [B][3][HW] = (im1, im2 - rgb_mean) / rgb_max, rgb_mean per (b, c) over both frames (models.py:97-102).
+ * workspace: B*3*64 floats */
+int v2v_flownet_normalize(const float* im1, const float* im2, float* x1, float* x2, float* workspace,
+                          int32_t B, int32_t H, int32_t W, float rgb_max, void* stream);
+/* warped = Resample2d(img1, flow); out_norm = ChannelNorm(img0 - warped) (mode 0) or
+ * (sum_c (img0-warped)^2 < threshold) as 0/1 (mode 1, flownet.py:55).  img0 / img1: planar [B][>=C][HW] with the
+ * given batch strides (channel slices of the 6-channel x); warped / out_norm may be NULL. */
+int v2v_warp_diff_norm(const float* img0, int64_t batch_stride0, const float* img1, int64_t batch_stride1,
+                       const float* flow, float* warped, float* out_norm, int32_t B, int32_t C, int32_t H,
+                       int32_t W, int32_t mode, float threshold, void* stream);
+/* nn.Upsample to (OH, OW): bilinear (align_corners False) or nearest, result * out_scale */
+int v2v_resize_planar(const float* x, float* y, int64_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                      int32_t bilinear, float out_scale, void* stream);
+/* planar fp32 [N][C][HW] -> channels [c_offset, c_offset+C) of an NHWC buffer, y = leaky_relu(x*scale, slope) */
+int v2v_pack_channels_nhwc(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                           int32_t c_stride, int32_t c_offset, float scale, float leaky_slope,
+                           int32_t dtype, void* stream);
+/* torch.cat along channels on NHWC activations: dst[p][dst_offset + c] = src[p][src_offset + c], c < C */
+int v2v_concat_channels_nhwc(const void* src, int32_t src_stride, int32_t src_offset, void* dst,
+                             int32_t dst_stride, int32_t dst_offset, int32_t C, int64_t P,
+                             int32_t dtype, void* stream);
+
 /* ---- losses and optimizer (models/networks.py:731-812, models/vid2vid_model_D.py:199-213; torch.optim.Adam) ----
  * kind: 0 = mean((a - target)^2) (LSGAN GANLoss), 1 = mean(|a*m - b*m|) (L1Loss / MaskedL1Loss); result * weight.
  * NHWC mode (planar = 0): a, b are [P][c_stride] activations of `dtype`, mean over P*C real elements;

@@ -427,3 +427,133 @@ def resample2d(img, flow, kernel_size=1):
 def channelnorm(x):
     """channelnorm_kernel.cu:18-60: out[b,0,y,x] = sqrt(sum_c x[b,c,y,x]^2)."""
     return (x * x).sum(1, keepdim=True).sqrt()
+
+
+# --------------------------------------------------------------------------------------
+# FlowNet2 (models/flownet2_pytorch/models.py:96-161 and networks/*.py), batchNorm=False
+# --------------------------------------------------------------------------------------
+def _fconv(sd, key, x, stride=1):
+    """submodules.conv (:7-19): Conv2d(pad (k-1)//2) + LeakyReLU(0.1); parameters at <key>.0.*"""
+    w = sd[key + ".0.weight"]
+    return F.leaky_relu(F.conv2d(x, w, sd[key + ".0.bias"], stride=stride, padding=(w.shape[-1] - 1) // 2), 0.1)
+
+
+def _fdeconv(sd, key, x):
+    """submodules.deconv (:36-40): ConvTranspose2d(4, 2, 1) + LeakyReLU(0.1)"""
+    return F.leaky_relu(F.conv_transpose2d(x, sd[key + ".0.weight"], sd[key + ".0.bias"], stride=2, padding=1), 0.1)
+
+
+def _fpredict(sd, key, x):
+    return F.conv2d(x, sd[key + ".weight"], sd[key + ".bias"], padding=1)          # submodules.predict_flow (:33-34)
+
+
+def _fup(sd, key, x):
+    return F.conv_transpose2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=2, padding=1)
+
+
+def _fdecode(sd, p, c6, skips, with_inter):
+    """The predict_flow / upsampled_flow / deconv / cat ladder shared by FlowNetC (:111-129), FlowNetS (:69-87)
+    and FlowNetSD (:79-100, with inter_conv)."""
+    feat = c6
+    flow = _fpredict(sd, p + "predict_flow6", c6)
+    for lvl, skip in zip((5, 4, 3, 2), skips):
+        flow_up = _fup(sd, p + "upsampled_flow%d_to_%d" % (lvl + 1, lvl), flow)
+        feat = torch.cat((skip, _fdeconv(sd, p + "deconv%d" % lvl, feat), flow_up), 1)
+        head_in = feat
+        if with_inter:
+            k = p + "inter_conv%d.0" % lvl
+            head_in = F.conv2d(feat, sd[k + ".weight"], sd[k + ".bias"], padding=1)
+        flow = _fpredict(sd, p + "predict_flow%d" % lvl, head_in)
+    return flow
+
+
+def flownet_c(sd, x, p="flownetc."):
+    """FlowNetC.forward (networks/FlowNetC.py:71-131)"""
+    def stream(im):
+        c1 = _fconv(sd, p + "conv1", im, 2)
+        c2 = _fconv(sd, p + "conv2", c1, 2)
+        return c2, _fconv(sd, p + "conv3", c2, 2)
+    c2a, c3a = stream(x[:, 0:3])
+    _, c3b = stream(x[:, 3:])
+    corr = F.leaky_relu(correlation(c3a, c3b, 20, 1, 20, 1, 2), 0.1)
+    c3_1 = _fconv(sd, p + "conv3_1", torch.cat((_fconv(sd, p + "conv_redir", c3a), corr), 1))
+    c4 = _fconv(sd, p + "conv4_1", _fconv(sd, p + "conv4", c3_1, 2))
+    c5 = _fconv(sd, p + "conv5_1", _fconv(sd, p + "conv5", c4, 2))
+    c6 = _fconv(sd, p + "conv6_1", _fconv(sd, p + "conv6", c5, 2))
+    return _fdecode(sd, p, c6, (c5, c4, c3_1, c2a), False)
+
+
+def flownet_s(sd, x, p):
+    """FlowNetS.forward (networks/FlowNetS.py:60-93)"""
+    c2 = _fconv(sd, p + "conv2", _fconv(sd, p + "conv1", x, 2), 2)
+    c3 = _fconv(sd, p + "conv3_1", _fconv(sd, p + "conv3", c2, 2))
+    c4 = _fconv(sd, p + "conv4_1", _fconv(sd, p + "conv4", c3, 2))
+    c5 = _fconv(sd, p + "conv5_1", _fconv(sd, p + "conv5", c4, 2))
+    c6 = _fconv(sd, p + "conv6_1", _fconv(sd, p + "conv6", c5, 2))
+    return _fdecode(sd, p, c6, (c5, c4, c3, c2), False)
+
+
+def flownet_sd(sd, x, p="flownets_d."):
+    """FlowNetSD.forward (networks/FlowNetSD.py:67-107)"""
+    c0 = _fconv(sd, p + "conv0", x)
+    c1 = _fconv(sd, p + "conv1_1", _fconv(sd, p + "conv1", c0, 2))
+    c2 = _fconv(sd, p + "conv2_1", _fconv(sd, p + "conv2", c1, 2))
+    c3 = _fconv(sd, p + "conv3_1", _fconv(sd, p + "conv3", c2, 2))
+    c4 = _fconv(sd, p + "conv4_1", _fconv(sd, p + "conv4", c3, 2))
+    c5 = _fconv(sd, p + "conv5_1", _fconv(sd, p + "conv5", c4, 2))
+    c6 = _fconv(sd, p + "conv6_1", _fconv(sd, p + "conv6", c5, 2))
+    return _fdecode(sd, p, c6, (c5, c4, c3, c2), True)
+
+
+def flownet_fusion(sd, x, p="flownetfusion."):
+    """FlowNetFusion.forward (networks/FlowNetFusion.py:48-69)"""
+    def inter(key, t):
+        return F.conv2d(t, sd[p + key + ".0.weight"], sd[p + key + ".0.bias"], padding=1)
+    c0 = _fconv(sd, p + "conv0", x)
+    c1 = _fconv(sd, p + "conv1_1", _fconv(sd, p + "conv1", c0, 2))
+    c2 = _fconv(sd, p + "conv2_1", _fconv(sd, p + "conv2", c1, 2))
+    flow2 = _fpredict(sd, p + "predict_flow2", c2)
+    cat1 = torch.cat((c1, _fdeconv(sd, p + "deconv1", c2), _fup(sd, p + "upsampled_flow2_to_1", flow2)), 1)
+    flow1 = _fpredict(sd, p + "predict_flow1", inter("inter_conv1", cat1))
+    cat0 = torch.cat((c0, _fdeconv(sd, p + "deconv0", cat1), _fup(sd, p + "upsampled_flow1_to_0", flow1)), 1)
+    return _fpredict(sd, p + "predict_flow0", inter("inter_conv0", cat0))
+
+
+def flownet2(sd, im1, im2, div_flow=20.0, rgb_max=1.0):
+    """FlowNet2.forward (models/flownet2_pytorch/models.py:96-161) on im1, im2: (B,3,H,W)."""
+    inputs = torch.stack((im1, im2), dim=2)                                  # (B,3,2,H,W), flownet.py:53
+    rgb_mean = inputs.reshape(inputs.shape[0], 3, -1).mean(-1).view(-1, 3, 1, 1, 1)
+    xx = (inputs - rgb_mean) / rgb_max
+    x = torch.cat((xx[:, :, 0], xx[:, :, 1]), 1)
+    x1, x2 = x[:, :3], x[:, 3:]
+    up_bil = lambda t: F.interpolate(t, scale_factor=4, mode="bilinear", align_corners=False)
+    up_near = lambda t: F.interpolate(t, scale_factor=4, mode="nearest")
+    flow = up_bil(flownet_c(sd, x) * div_flow)
+    for p, up in (("flownets_1.", up_bil), ("flownets_2.", up_near)):
+        warped = resample2d(x2.contiguous(), flow)
+        nrm = channelnorm(x1 - warped)
+        flow = up(flownet_s(sd, torch.cat((x, warped, flow / div_flow, nrm), 1), p) * div_flow)
+    flow_s2 = flow
+    norm_s2 = channelnorm(flow_s2)
+    diff_s2 = channelnorm(x1 - resample2d(x2.contiguous(), flow_s2))
+    flow_sd = up_near(flownet_sd(sd, x) / div_flow)
+    norm_sd = channelnorm(flow_sd)
+    diff_sd = channelnorm(x1 - resample2d(x2.contiguous(), flow_sd))
+    cat3 = torch.cat((x1, flow_sd, flow_s2, norm_sd, norm_s2, diff_sd, diff_s2), 1)
+    return flownet_fusion(sd, cat3)
+
+
+def flow_and_conf(sd, im1, im2):
+    """FlowNet.compute_flow_and_conf (models/flownet.py:43-59) incl. the resize to multiples of 64."""
+    old_h, old_w = im1.shape[2], im1.shape[3]
+    new_h, new_w = old_h // 64 * 64, old_w // 64 * 64
+    if old_h != new_h:
+        im1 = F.interpolate(im1, size=(new_h, new_w), mode="bilinear", align_corners=False)
+        im2 = F.interpolate(im2, size=(new_h, new_w), mode="bilinear", align_corners=False)
+    flow = flownet2(sd, im1, im2)
+    d = im1 - resample2d(im2.contiguous(), flow)
+    conf = ((d * d).sum(1, keepdim=True) < 0.02).float()
+    if old_h != new_h:
+        flow = F.interpolate(flow, size=(old_h, old_w), mode="bilinear", align_corners=False) * old_h / new_h
+        conf = F.interpolate(conf, size=(old_h, old_w), mode="bilinear", align_corners=False)
+    return flow, conf

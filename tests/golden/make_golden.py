@@ -297,11 +297,69 @@ def golden_training():
     print({k: float(v) for k, v in arrays.items() if k.startswith("loss.")})
 
 
+def golden_flownet2():
+    """FlowNet2.forward (models/flownet2_pytorch/models.py:96-161) + FlowNet.compute_flow_and_conf
+    (models/flownet.py:43-59) executed from the reference's own Python on CPU.  The three CUDA-only
+    extensions cannot be built here (no nvcc; legacy ATen API), so the modules `resample2d_cuda`,
+    `channelnorm_cuda` and the `Correlation` layer are backed by the CPU restatements in
+    oracle/vid2vid_oracle.py (which follow the .cu files): this fixture pins the network COMPOSITION
+    (117 convs, upsampling, warping chain), not those three kernels ("parity unpinned").
+    Weights: tests/util.seeded_flownet2_weights (162.5 M values, regenerated from a seed by the tests)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))           # tests/
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))        # repo root
+    from util import seeded_flownet2_weights
+    from oracle import vid2vid_oracle as O
+
+    r2d = types.ModuleType("resample2d_cuda")
+    def r2d_forward(img, flow, out, ksize):
+        out.copy_(O.resample2d(img, flow, ksize))
+    r2d.forward = r2d_forward
+    cn = types.ModuleType("channelnorm_cuda")
+    def cn_forward(x, out, norm_deg):
+        assert norm_deg == 2
+        out.copy_(O.channelnorm(x))
+    cn.forward = cn_forward
+    sys.modules["resample2d_cuda"] = r2d
+    sys.modules["channelnorm_cuda"] = cn
+    sys.modules["correlation_cuda"] = types.ModuleType("correlation_cuda")
+    from models.flownet2_pytorch import models as f2
+    from models.flownet2_pytorch.networks.correlation_package import correlation as corr_mod
+
+    def corr_forward(self, a, b):        # legacy (non-static) autograd Function cannot run on torch >= 1.x
+        return O.correlation(a, b, self.pad_size, self.kernel_size, self.max_displacement, self.stride1, self.stride2)
+    corr_mod.Correlation.forward = corr_forward
+
+    net = f2.FlowNet2(fp16=False)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(seeded_flownet2_weights(shapes))
+    net.eval()
+    gen = torch.Generator().manual_seed(90)
+    B, H, W = 2, 64, 128
+    base = torch.nn.functional.interpolate(torch.randn(B, 3, 8, 16, generator=gen), size=(H, W), mode="bicubic",
+                                           align_corners=False)
+    im1 = torch.tanh(base)
+    im2 = torch.tanh(torch.roll(base, shifts=(1, 2), dims=(2, 3)) + 0.05 * torch.randn(B, 3, H, W, generator=gen))
+    with torch.no_grad():
+        data = torch.cat([im1.unsqueeze(2), im2.unsqueeze(2)], dim=2)
+        flow = net(data)
+        warped = O.resample2d(im2, flow)
+        ssd = ((im1 - warped) ** 2).sum(1, keepdim=True)
+        conf = (ssd < 0.02).float()
+    arrays = {"in.im1": im1.numpy(), "in.im2": im2.numpy(), "out.flow": flow.numpy(), "out.conf": conf.numpy(),
+              "out.ssd": ssd.numpy()}
+    arrays["keys"] = np.array(sorted(shapes.keys()))
+    arrays["shapes"] = np.array([",".join(str(d) for d in shapes[k]) for k in sorted(shapes.keys())])
+    save("flownet2_64x128", **arrays)
+    print("flow rms %.3f  max %.3f  conf mean %.3f" % (flow.pow(2).mean().sqrt(), flow.abs().max(), conf.mean()))
+
+
 def main():
     install_shims()
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     if only == "training":
         return golden_training()
+    if only == "flownet2":
+        return golden_flownet2()
     from models import networks
     golden_composite(networks)
     golden_composite_local(networks)
@@ -309,6 +367,7 @@ def main():
     golden_global(networks)
     golden_inference()
     golden_training()
+    golden_flownet2()
 
 
 if __name__ == "__main__":

@@ -142,3 +142,16 @@ def test_inference_lowering_census_512x256():
     finally:
         N.set_record_only(False)
         N._ENGINES.clear()
+
+
+def test_flownet2_checkpoint_keys_match_reference(golden):
+    """vid2vid_amd.flownet2.FlowNet2 exposes exactly the reference's state_dict keys / shapes, so
+    FlowNet2_checkpoint.pth.tar loads by name (models/flownet.py:19-20)."""
+    from vid2vid_amd.flownet2 import FlowNet2
+    g = golden("flownet2_64x128")
+    ref = {k: tuple(int(d) for d in s.split(",")) for k, s in zip(g["keys"], g["shapes"])}
+    with torch.device("meta"):
+        net = FlowNet2()
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert mine == ref
+    assert sum(int(np.prod(s)) for s in mine.values()) == 162518834

@@ -121,3 +121,21 @@ def test_resample2d_hand_cases():
 def test_channelnorm_hand_cases():
     x = torch.tensor([3.0, 4.0]).view(1, 2, 1, 1)
     assert O.channelnorm(x).item() == 5.0
+
+
+def test_flownet2_oracle_vs_reference_composition(golden):
+    """oracle.flownet2 against the reference's FlowNet2 Python executed on CPU (fixture by make_golden.py;
+    the three CUDA-only ops are the oracle's own restatements there, so this pins the composition)."""
+    import types
+    from oracle import vid2vid_oracle as O
+    from util import seeded_flownet2_weights, assert_close
+    g = golden("flownet2_64x128")
+    shapes = {k: tuple(int(d) for d in s.split(",")) for k, s in zip(g["keys"], g["shapes"])}
+    assert len(shapes) == 238 + 0 or len(shapes) > 200
+    sd = seeded_flownet2_weights(shapes)
+    assert sum(v.numel() for v in sd.values()) == 162518834         # models/flownet2_pytorch/models.py:17
+    im1, im2 = torch.from_numpy(g["in.im1"]), torch.from_numpy(g["in.im2"])
+    with torch.no_grad():
+        flow, conf = O.flow_and_conf(sd, im1, im2)
+    assert_close(flow, g["out.flow"], 1e-4, "flow")
+    assert (conf != torch.from_numpy(g["out.conf"])).float().mean().item() < 1e-3

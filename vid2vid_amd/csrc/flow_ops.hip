@@ -150,6 +150,203 @@ struct ChannelNormOp : Op {
     const char* name() const override { return "channelnorm"; }
 };
 
+
+// ---------------------------------------------------------------------------------------
+// FlowNet2 glue (models/flownet2_pytorch/models.py:96-161, models/flownet.py:43-59): the
+// reference strings these together from ~40 ATen calls per forward (mean, sub, div, cat, Upsample,
+// slicing); here each is one streaming kernel writing straight into the consumer's layout.
+// ---------------------------------------------------------------------------------------
+static inline unsigned fgrid(long long n, long long cap = 4096) {
+    long long b = ceil_div(n, 256);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// x = (inputs - rgb_mean) / rgb_max with rgb_mean over both frames and all pixels per (b, c)
+// (models.py:97-102).  im1, im2, x1, x2: [B][3][HW]  (x = cat(x1, x2) is only ever used through its halves).
+struct NormArgs { const float* im1; const float* im2; float* x1; float* x2; float* partials; int B; long long hw; float inv_rgb_max; int chunks; };
+
+__global__ __launch_bounds__(256) void flownet_mean_partial_kernel(const NormArgs a) {
+    __shared__ float sh[256];
+    const int plane = blockIdx.y;                 // b*3 + c
+    const long long per = (2 * a.hw + a.chunks - 1) / a.chunks;
+    const long long e0 = (long long)blockIdx.x * per;
+    long long e1 = e0 + per; if (e1 > 2 * a.hw) e1 = 2 * a.hw;
+    float s = 0.f;
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256)
+        s += e < a.hw ? a.im1[(long long)plane * a.hw + e] : a.im2[(long long)plane * a.hw + (e - a.hw)];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) a.partials[plane * a.chunks + blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void flownet_normalize_kernel(const NormArgs a) {
+    __shared__ float sh[256];
+    const int oplane = blockIdx.y;                // b*6 + j
+    const int b = oplane / 6, j = oplane - b * 6, c = j % 3;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.chunks; i += 256) s += a.partials[(b * 3 + c) * a.chunks + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+    const float mean = sh[0] / (float)(2 * a.hw);
+    const float* src = (j < 3 ? a.im1 : a.im2) + (long long)(b * 3 + c) * a.hw;
+    float* dst = (j < 3 ? a.x1 : a.x2) + (long long)(b * 3 + c) * a.hw;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < a.hw; e += (long long)gridDim.x * 256)
+        dst[e] = (src[e] - mean) * a.inv_rgb_max;
+}
+
+struct NormOp : Op {
+    NormArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(flownet_mean_partial_kernel, dim3((unsigned)a.chunks, (unsigned)(a.B * 3)), dim3(256), 0, s, a);
+        int rc = check_launch(); if (rc) return rc;
+        hipLaunchKernelGGL(flownet_normalize_kernel, dim3(fgrid(a.hw, 256), (unsigned)(a.B * 6)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "flownet_normalize"; }
+};
+
+// warped = Resample2d(img1, flow) (kernel_size 1); out_norm = ChannelNorm(img0 - warped)  [mode 0]
+// or (sum_c (img0 - warped)^2 < thr) as 0/1 (FlowNet.compute_flow_and_conf, flownet.py:55)  [mode 1]
+struct WarpDiffArgs { const float* img0; const float* img1; const float* flow; float* warped; float* out_norm;
+                      int B, C, H, W; long long bs0, bs1; int mode; float thr; };
+
+__global__ __launch_bounds__(256) void warp_diff_norm_kernel(const WarpDiffArgs a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long total = (long long)a.B * hw;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long b = e / hw, pix = e - b * hw;
+        const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);
+        const float dx = a.flow[(b * 2 + 0) * hw + pix], dy = a.flow[(b * 2 + 1) * hw + pix];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        const float alpha = xf - floorf(xf), beta = yf - floorf(yf);
+        const int xL = max(min((int)floorf(xf), a.W - 1), 0), xR = max(min((int)floorf(xf) + 1, a.W - 1), 0);
+        const int yT = max(min((int)floorf(yf), a.H - 1), 0), yB = max(min((int)floorf(yf) + 1, a.H - 1), 0);
+        float r = 0.f;
+        for (int c = 0; c < a.C; ++c) {
+            const float* ip = a.img1 + b * a.bs1 + c * hw;
+            float val = 0.f;                       // same operation order as resample2d_kernel
+            val += (1.f - alpha) * (1.f - beta) * ip[(long long)yT * a.W + xL];
+            val += alpha * (1.f - beta) * ip[(long long)yT * a.W + xR];
+            val += (1.f - alpha) * beta * ip[(long long)yB * a.W + xL];
+            val += alpha * beta * ip[(long long)yB * a.W + xR];
+            if (a.warped) a.warped[(b * a.C + c) * hw + pix] = val;
+            const float d = a.img0[b * a.bs0 + c * hw + pix] - val;
+            r += d * d;
+        }
+        if (a.out_norm) a.out_norm[e] = a.mode == 0 ? sqrtf(r) : (r < a.thr ? 1.f : 0.f);
+    }
+}
+
+struct WarpDiffOp : Op {
+    WarpDiffArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(warp_diff_norm_kernel, dim3(fgrid((long long)a.B * a.H * a.W)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "warp_diff_norm"; }
+};
+
+// nn.Upsample(scale_factor / size, mode = 'bilinear' (align_corners False) | 'nearest') on planar fp32,
+// times out_scale (models.py:49-61,105,117; flownet.py:49-50,56-58)
+struct ResizeArgs { const float* x; float* y; long long planes; int H, W, OH, OW, bilinear; float out_scale; };
+
+__global__ __launch_bounds__(256) void resize_planar_kernel(const ResizeArgs a) {
+    const long long total = a.planes * a.OH * a.OW;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float sh = (float)a.H / (float)a.OH, sw = (float)a.W / (float)a.OW;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int ox = (int)(e % a.OW);
+        const long long t = e / a.OW;
+        const int oy = (int)(t % a.OH);
+        const long long pl = t / a.OH;
+        const float* xp = a.x + pl * (long long)a.H * a.W;
+        float v;
+        if (a.bilinear) {
+            float fy = sh * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+            float fx = sw * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+            const int y0 = min((int)fy, a.H - 1), x0 = min((int)fx, a.W - 1);
+            const int y1 = min(y0 + 1, a.H - 1), x1 = min(x0 + 1, a.W - 1);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            v = (1.f - ly) * ((1.f - lx) * xp[(long long)y0 * a.W + x0] + lx * xp[(long long)y0 * a.W + x1]) +
+                ly * ((1.f - lx) * xp[(long long)y1 * a.W + x0] + lx * xp[(long long)y1 * a.W + x1]);
+        } else {
+            const int y0 = min((int)floorf((float)oy * sh), a.H - 1), x0 = min((int)floorf((float)ox * sw), a.W - 1);
+            v = xp[(long long)y0 * a.W + x0];
+        }
+        a.y[e] = v * a.out_scale;
+    }
+}
+
+struct ResizeOp : Op {
+    ResizeArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(resize_planar_kernel, dim3(fgrid(a.planes * a.OH * a.OW)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "resize_planar"; }
+};
+
+// planar fp32 [N][C][HW] -> channels [c_off, c_off+C) of an NHWC activation buffer, y = leaky(x*scale)
+struct PackAtArgs { const float* x; void* y; int N, C; long long hw; int c_stride, c_off; float scale, slope; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_at_kernel(const PackAtArgs a) {
+    T* y = reinterpret_cast<T*>(a.y);
+    const long long total = (long long)a.N * a.C * a.hw;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long pix = e % a.hw;
+        const long long nc = e / a.hw;
+        const long long n = nc / a.C;
+        const int c = (int)(nc - n * a.C);
+        float v = a.x[e] * a.scale;
+        v = v > 0.f ? v : v * a.slope;
+        store_act(y, (n * a.hw + pix) * a.c_stride + a.c_off + c, v);
+    }
+}
+
+struct PackAtOp : Op {
+    PackAtArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        const long long n = (long long)a.N * a.C * a.hw;
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(pack_at_kernel<bf16_t>, dim3(fgrid(n)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(pack_at_kernel<float>, dim3(fgrid(n)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "pack_channels_nhwc"; }
+};
+
+// torch.cat along channels of NHWC activations: dst[p][dst_off + c] = src[p][src_off + c]
+struct CopyChArgs { const void* src; void* dst; long long P; int C, src_stride, src_off, dst_stride, dst_off; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const CopyChArgs a) {
+    const T* src = reinterpret_cast<const T*>(a.src);
+    T* dst = reinterpret_cast<T*>(a.dst);
+    const long long total = a.P * a.C;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long p = e / a.C;
+        const int c = (int)(e - p * a.C);
+        dst[p * a.dst_stride + a.dst_off + c] = src[p * a.src_stride + a.src_off + c];
+    }
+}
+
+struct CopyChOp : Op {
+    CopyChArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(fgrid(a.P * a.C)), dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(fgrid(a.P * a.C)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "concat_channels_nhwc"; }
+};
+
 }  // namespace v2v
 
 using namespace v2v;
@@ -203,5 +400,50 @@ extern "C" int v2v_channelnorm_forward(const float* x, float* out, int32_t N, in
     if (norm_deg != 2) { set_error("channelnorm: the reference kernel implements norm_deg=2 only"); return V2V_EINVAL; }
     auto op = std::make_unique<ChannelNormOp>();
     op->a = ChannelNormArgs{x, out, N, C, (long long)H * W};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_flownet_normalize(const float* im1, const float* im2, float* x1, float* x2, float* workspace,
+                                     int32_t B, int32_t H, int32_t W, float rgb_max, void* stream) {
+    if (!im1 || !im2 || !x1 || !x2 || !workspace || B < 1 || rgb_max == 0.f) { set_error("flownet_normalize: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<NormOp>();
+    op->a = NormArgs{im1, im2, x1, x2, workspace, B, (long long)H * W, 1.f / rgb_max, 64};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_warp_diff_norm(const float* img0, int64_t batch_stride0, const float* img1, int64_t batch_stride1,
+                                  const float* flow, float* warped, float* out_norm, int32_t B, int32_t C, int32_t H,
+                                  int32_t W, int32_t mode, float threshold, void* stream) {
+    if (!img0 || !img1 || !flow || (!warped && !out_norm) || (mode != 0 && mode != 1)) { set_error("warp_diff_norm: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<WarpDiffOp>();
+    op->a = WarpDiffArgs{img0, img1, flow, warped, out_norm, B, C, H, W, batch_stride0, batch_stride1, mode, threshold};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_resize_planar(const float* x, float* y, int64_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                                 int32_t bilinear, float out_scale, void* stream) {
+    if (!x || !y || planes < 1 || H < 1 || W < 1 || OH < 1 || OW < 1) { set_error("resize_planar: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<ResizeOp>();
+    op->a = ResizeArgs{x, y, planes, H, W, OH, OW, bilinear, out_scale};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_pack_channels_nhwc(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                      int32_t c_stride, int32_t c_offset, float scale, float leaky_slope,
+                                      int32_t dtype, void* stream) {
+    if (!x || !y || c_offset < 0 || c_offset + C > c_stride) { set_error("pack_channels: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<PackAtOp>();
+    op->a = PackAtArgs{x, y, N, C, (long long)H * W, c_stride, c_offset, scale, leaky_slope}; op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_concat_channels_nhwc(const void* src, int32_t src_stride, int32_t src_offset, void* dst,
+                                        int32_t dst_stride, int32_t dst_offset, int32_t C, int64_t P,
+                                        int32_t dtype, void* stream) {
+    if (!src || !dst || C < 1 || P < 1 || src_offset + C > src_stride || dst_offset + C > dst_stride) {
+        set_error("concat_channels: bad argument"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<CopyChOp>();
+    op->a = CopyChArgs{src, dst, P, C, src_stride, src_offset, dst_stride, dst_offset}; op->dtype = dtype;
     return submit(std::move(op), stream);
 }

@@ -69,6 +69,11 @@ PROTOTYPES = {
     "v2v_reflect_pad_fold": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_warp_blend_backward": (C.c_int, [_P] * 15 + [_I] * 5 + [_P]),
     "v2v_resample_flow_backward": (C.c_int, [_P] * 7 + [_I] * 5 + [_P]),
+    "v2v_flownet_normalize": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "v2v_warp_diff_norm": (C.c_int, [_P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "v2v_resize_planar": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
+    "v2v_pack_channels_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "v2v_concat_channels_nhwc": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
     "v2v_loss_workspace_floats": (C.c_int, []),
     "v2v_loss_forward": (C.c_int, [_I, _P, _P, _P, _F, _F, _L, _I, _I, _L, _L, _L, _I, _P, _P, _I, _P]),
     "v2v_loss_backward": (C.c_int, [_I, _P, _P, _P, _F, _F, _L, _I, _I, _L, _L, _L, _I, _P, _P, _I, _P]),

@@ -1,0 +1,110 @@
+"""FlowNet wrapper on the MI355X backend (drop-in for the reference's models/flownet.py).
+
+`flowNet(im_t, im_prev) -> (flow (.., 2, H, W), conf (.., 1, H, W))`, 4-D or 5-D inputs, frozen and
+gradient-free exactly like the reference (:25-41).  The whole computation -- resize to multiples of
+64, FlowNet2, confidence = (||im1 - warp(im2, flow)||^2 < 0.02), resize back (:43-59) -- is recorded
+once per input shape and replayed as one hipGraph.
+"""
+import os
+
+import torch
+
+from ..engine import Plan, _ptr, _stream
+from ..flownet2 import FlowNet2
+from ..lib import lib, check
+from .base_model import BaseModel
+
+
+class _FlowPlan:
+    def __init__(self, model, B, H, W, use_graph=True):
+        eng = model.engine
+        self.eng, self.model = eng, model
+        dev = eng.device
+        self.im1 = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
+        self.im2 = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
+        self.flow = self.conf = None
+        if not eng.record_only:
+            self._emit()                       # sizes the shared scratch
+            torch.cuda.synchronize(dev)
+        self.plan = Plan()
+        eng.plan = self.plan
+        try:
+            with self.plan:
+                self._emit()
+        finally:
+            eng.plan = None
+        if use_graph and not eng.record_only:
+            self.plan.instantiate_graph()
+
+    def _resize(self, x, OH, OW, scale=1.0):
+        B, Cc, H, W = x.shape
+        out = self.eng.empty_f32(B, Cc, OH, OW)
+        check(lib.v2v_resize_planar(_ptr(x), _ptr(out), B * Cc, H, W, OH, OW, 1, float(scale), _stream()), "resize_planar")
+        self.eng.label("resize_planar")
+        return out
+
+    def _emit(self):
+        eng = self.eng
+        im1, im2 = self.im1, self.im2
+        B, _, H, W = im1.shape
+        nh, nw = H // 64 * 64, W // 64 * 64
+        if nh == 0 or nw == 0:
+            raise ValueError("FlowNet2 needs images of at least 64x64")
+        resized = (nh != H)                    # the reference tests the height only (flownet.py:48)
+        if resized:
+            im1, im2 = self._resize(im1, nh, nw), self._resize(im2, nh, nw)
+        flow = self.model.flowNet.emit(eng, im1, im2)
+        conf = eng.empty_f32(B, 1, im1.shape[2], im1.shape[3])
+        check(lib.v2v_warp_diff_norm(_ptr(im1), 3 * im1.shape[2] * im1.shape[3], _ptr(im2),
+                                     3 * im1.shape[2] * im1.shape[3], _ptr(flow), None, _ptr(conf),
+                                     B, 3, im1.shape[2], im1.shape[3], 1, 0.02, _stream()), "confidence")
+        eng.label("flow_confidence")
+        if resized:
+            flow = self._resize(flow, H, W, float(H) / float(nh))     # both components scaled by old_h/new_h (:57)
+            conf = self._resize(conf, H, W)
+        self.flow, self.conf = flow, conf
+
+
+class FlowNet(BaseModel):
+    def name(self):
+        return "FlowNet"
+
+    def initialize(self, opt):
+        BaseModel.initialize(self, opt)
+        self.flowNet = FlowNet2().to(self.device)
+        path = getattr(opt, "flownet2_checkpoint", "models/flownet2_pytorch/FlowNet2_checkpoint.pth.tar")
+        if os.path.isfile(path):
+            ck = torch.load(path, map_location="cpu")
+            self.flowNet.load_state_dict(ck["state_dict"] if "state_dict" in ck else ck)
+        elif not getattr(opt, "random_init_ok", False):
+            raise RuntimeError("%s not found (FlowNet2 weights are an external download)" % path)
+        for p in self.flowNet.parameters():
+            p.requires_grad_(False)
+        self._plans = {}
+
+    def forward(self, input_A, input_B, dummy_bs=0):
+        with torch.no_grad():
+            if dummy_bs:
+                input_A, input_B = input_A[dummy_bs:], input_B[dummy_bs:]
+            size = input_A.size()
+            assert len(size) in (4, 5)
+            if len(size) == 5:
+                b, n, c, h, w = size
+                flow, conf = self.compute_flow_and_conf(input_A.reshape(-1, c, h, w), input_B.reshape(-1, c, h, w))
+                return flow.view(b, n, 2, h, w), conf.view(b, n, 1, h, w)
+            return self.compute_flow_and_conf(input_A, input_B)
+
+    def compute_flow_and_conf(self, im1, im2):
+        assert im1.size(1) == 3 and im1.size() == im2.size()
+        B, _, H, W = im1.shape
+        key = (B, H, W, self.precision)
+        fp = self._plans.get(key)
+        if fp is None:
+            self.engine.refresh_weights()
+            fp = _FlowPlan(self, B, H, W, use_graph=getattr(self.opt, "use_graph", True))
+            self._plans[key] = fp
+        fp.im1.copy_(im1.to(self.device, torch.float32))
+        fp.im2.copy_(im2.to(self.device, torch.float32))
+        if not self.engine.record_only:
+            fp.plan.launch()
+        return fp.flow.clone(), fp.conf.clone()
