@@ -557,3 +557,101 @@ def flow_and_conf(sd, im1, im2):
         flow = F.interpolate(flow, size=(old_h, old_w), mode="bilinear", align_corners=False) * old_h / new_h
         conf = F.interpolate(conf, size=(old_h, old_w), mode="bilinear", align_corners=False)
     return flow, conf
+
+
+# --------------------------------------------------------------------------------------
+# training step: Vid2VidModelG.forward, Vid2VidModelD.forward, losses (differentiable: plain torch ops,
+# so torch.autograd of this restatement is the gradient oracle)
+# --------------------------------------------------------------------------------------
+def gan_loss(preds, target_is_real):
+    """GANLoss.__call__ for multiscale outputs (models/networks.py:764-771): sum over scales of
+    MSELoss(pred[-1], 1 or 0)."""
+    loss = 0
+    for feats in preds:
+        p = feats[-1]
+        loss = loss + F.mse_loss(p, torch.full_like(p, 1.0 if target_is_real else 0.0))
+    return loss
+
+
+def masked_l1(a, b, mask):
+    """MaskedL1Loss (models/networks.py:804-812)"""
+    m = mask.expand(-1, a.shape[1], -1, -1)
+    return F.l1_loss(a * m, b * m)
+
+
+def gan_and_fm_loss(pred_real, pred_fake, n_layers_D, num_D, lambda_feat):
+    """Vid2VidModelD.GAN_and_FM_loss (models/vid2vid_model_D.py:199-213)"""
+    loss_gan = gan_loss(pred_fake, True)
+    loss_fm = torch.zeros(())
+    fw, dw = 4.0 / (n_layers_D + 1), 1.0 / num_D
+    for i in range(min(len(pred_fake), num_D)):
+        for j in range(len(pred_fake[i]) - 1):
+            loss_fm = loss_fm + dw * fw * F.l1_loss(pred_fake[i][j], pred_real[i][j].detach()) * lambda_feat
+    return loss_gan, loss_fm
+
+
+def compute_loss_D(sdD, x_real, x_fake, n_layers_D, num_D, lambda_feat):
+    """compute_loss_D / compute_loss_D_T (models/vid2vid_model_D.py:168-197) on already concatenated inputs:
+    three discriminator passes (real, fake detached, fake)."""
+    pred_real = multiscale_discriminator(sdD, x_real, n_layers_D, num_D)
+    pred_fake = multiscale_discriminator(sdD, x_fake.detach(), n_layers_D, num_D)
+    l_real, l_fake = gan_loss(pred_real, True), gan_loss(pred_fake, False)
+    pred_fake = multiscale_discriminator(sdD, x_fake, n_layers_D, num_D)
+    l_gan, l_fm = gan_and_fm_loss(pred_real, pred_fake, n_layers_D, num_D, lambda_feat)
+    return l_real, l_fake, l_gan, l_fm
+
+
+def model_D_image_losses(sdD, t, n_layers_D=3, num_D=2, lambda_feat=10.0, lambda_F=10.0, lambda_T=10.0, n_scales_spatial=1):
+    """Vid2VidModelD.forward(scale_T=0, ...) (models/vid2vid_model_D.py:110-166) with --no_vgg.
+    t: dict of (n, ch, H, W) tensors real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight,
+    flow_ref, conf_ref.  Returns the dict keyed by loss_names."""
+    out = {"G_VGG": torch.zeros(()), "W": torch.zeros(())}
+    out["F_Flow"] = masked_l1(t["flow"], t["flow_ref"], t["conf_ref"]) * lambda_F / (2 ** (n_scales_spatial - 1))
+    real_B_warp = resample(t["real_B_prev"], t["flow"])
+    out["F_Warp"] = masked_l1(real_B_warp, t["real_B"], t["conf_ref"]) * lambda_T
+    real_AB = torch.cat((t["real_A"], t["real_B"]), 1)
+    l_real, l_fake, l_gan, l_fm = compute_loss_D(sdD, real_AB, torch.cat((t["real_A"], t["fake_B"]), 1),
+                                                 n_layers_D, num_D, lambda_feat)
+    warp_ref = resample(t["fake_B_prev"], t["flow_ref"]).detach()
+    out["G_Warp"] = masked_l1(t["fake_B"], warp_ref, t["conf_ref"]) * lambda_T
+    r2, f2, g2, m2 = compute_loss_D(sdD, real_AB, torch.cat((t["real_A"], t["fake_B_raw"]), 1), n_layers_D, num_D, lambda_feat)
+    out.update({"D_real": l_real + r2, "D_fake": l_fake + f2, "G_GAN": l_gan + g2, "G_GAN_Feat": l_fm + m2})
+    return out
+
+
+def model_D_temporal_losses(sdDT, real_B, fake_B, flow_ref, tD=3, n_layers_D=3, num_D=2, lambda_feat=10.0):
+    """Vid2VidModelD.forward(scale_T>0, ...) (:104-112) -> compute_loss_D_T (:181-197); inputs (n, tD, C, H, W)."""
+    n, _, _, H, W = real_B.shape
+    fr = (flow_ref / 20).reshape(n, -1, H, W)
+    l_real, l_fake, l_gan, l_fm = compute_loss_D(sdDT, torch.cat((real_B.reshape(n, -1, H, W), fr), 1),
+                                                 torch.cat((fake_B.reshape(n, -1, H, W), fr), 1), n_layers_D, num_D, lambda_feat)
+    return {"G_T_GAN": l_gan, "G_T_GAN_Feat": l_fm, "D_T_real": l_real, "D_T_fake": l_fake, "G_T_Warp": torch.zeros(())}
+
+
+def generate_frames_train(sds, real_A_all, real_B_all, fg, fg_labels, n_down, n_blocks, n_blocks_local, n_frames_load, tG=3):
+    """Vid2VidModelG.forward / generate_frame_train (models/vid2vid_model_G.py:114-196) for batch 1, first chunk
+    (real first frames), n_frames_bp = 1, finetune_all.  real_A_all (1,T,C,H,W) encoded labels, real_B_all (1,T,3,H,W).
+    Returns fake_B, fake_B_raw, flow, weight: (1, n_frames_load, ., H, W)."""
+    S = len(sds)
+    A_pyr = build_pyr(real_A_all, S)
+    B_pyr = build_pyr(real_B_all[:, :tG - 1], S)
+    fakes = [p for p in B_pyr]
+    raws, flows, weights = [], [], []
+    for t in range(n_frames_load):
+        feat = flow_feat = fg_feat = None
+        for s in range(S):
+            si = S - 1 - s
+            rA = A_pyr[si]
+            _, _, _, h, w = rA.shape
+            x = rA[:, t:t + tG].reshape(1, -1, h, w)
+            prev = fakes[si][:, t:t + tG - 1].detach().reshape(1, -1, h, w)       # n_frames_bp = 1 (:167-168)
+            mask = compute_mask(rA, t + tG - 1, fg_labels)[0].reshape(1, 1, h, w) if fg else None
+            if s == 0:
+                out = composite_generator(sds[0], x, prev, mask, n_down, n_blocks, fg)
+            else:
+                out = composite_local_generator(sds[s], x, prev, mask, feat, flow_feat, fg_feat, n_blocks_local, s, fg)
+            fake_B, flow, weight, raw, feat, flow_feat, fg_feat = out
+            fakes[si] = torch.cat([fakes[si], fake_B.unsqueeze(1)], 1)
+            if s == S - 1:
+                raws.append(raw.unsqueeze(1)); flows.append(flow.unsqueeze(1)); weights.append(weight.unsqueeze(1))
+    return fakes[0][:, tG - 1:], torch.cat(raws, 1), torch.cat(flows, 1), torch.cat(weights, 1)

@@ -139,3 +139,43 @@ def test_flownet2_oracle_vs_reference_composition(golden):
         flow, conf = O.flow_and_conf(sd, im1, im2)
     assert_close(flow, g["out.flow"], 1e-4, "flow")
     assert (conf != torch.from_numpy(g["out.conf"])).float().mean().item() < 1e-3
+
+
+def test_training_oracle_vs_reference(golden):
+    """Oracle training step (G forward, image + temporal D losses, gradients by autograd of the restatement)
+    against the fixture produced by the reference's own Vid2VidModelG/D on CPU."""
+    from oracle import vid2vid_oracle as O
+    from util import assert_close, sd_from_npz
+    g = golden("training_label2city_s2_32x64")
+    sds = {k: sd_from_npz(g, "sd%s." % k) for k in ("G0", "G1", "D", "DT0")}
+    for sd in sds.values():
+        for k, v in sd.items():
+            if v.is_floating_point():
+                v.requires_grad_(True)
+    lab, inst, B = [torch.from_numpy(g["in." + k]) for k in ("labels", "inst", "B")]
+    flow_ref, conf_ref = torch.from_numpy(g["in.flow_ref"]), torch.from_numpy(g["in.conf_ref"])
+    real_A = O.encode_input(lab, inst, 35)
+    assert_close(real_A[:, 2:], g["out.real_A"], 1e-6, "real_A")
+    fake_B, fake_B_raw, flow, weight = O.generate_frames_train([sds["G0"], sds["G1"]], real_A, B, True, [26], 2, 2, 1, 3)
+    for name, t in (("fake_B", fake_B), ("fake_B_raw", fake_B_raw), ("flow", flow), ("weight", weight)):
+        assert_close(t.detach(), g["out." + name], 1e-4, name)
+    real_Bp = B[:, 1:]
+    real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
+    fake_B_prev = torch.cat([real_B_prev[:, 0:1], fake_B[:, :-1].detach()], 1)       # compute_fake_B_prev (:332-336)
+    r4 = lambda t: t.reshape(-1, t.shape[2], t.shape[3], t.shape[4])
+    t = dict(real_B=r4(real_B), fake_B=r4(fake_B), fake_B_raw=r4(fake_B_raw), real_A=r4(real_A[:, 2:]),
+             real_B_prev=r4(real_B_prev), fake_B_prev=r4(fake_B_prev), flow=r4(flow), weight=r4(weight),
+             flow_ref=r4(flow_ref), conf_ref=r4(conf_ref))
+    losses = O.model_D_image_losses(sds["D"], t, n_scales_spatial=2)
+    lt = O.model_D_temporal_losses(sds["DT0"], real_B, fake_B, flow_ref[:, 1:])
+    for k, v in list(losses.items()) + list(lt.items()):
+        ref = float(g["loss." + k])
+        assert abs(float(v) - ref) <= 2e-4 * max(abs(ref), 1e-3), (k, float(v), ref)
+    loss_G = (losses["G_GAN"] + losses["G_GAN_Feat"] + losses["G_VGG"] + losses["G_Warp"] + losses["F_Flow"] +
+              losses["F_Warp"] + losses["W"] + lt["G_T_GAN"] + lt["G_T_GAN_Feat"] + lt["G_T_Warp"])
+    assert abs(float(loss_G) - float(g["loss.total_G"])) <= 2e-4 * float(g["loss.total_G"])
+    loss_G.backward()
+    for key in ("model_final_img.1.weight", "model_up_img.0.conv_block.1.weight", "model_down_seg.1.weight"):
+        assert_close(sds["G1"][key].grad, g["gradG.G1." + key], 1e-3, "dG1 " + key)
+    assert_close(sds["G0"]["model_res_img.0.conv_block.1.weight"].grad,
+                 g["gradG.G0.model_res_img.0.conv_block.1.weight"], 1e-3, "dG0 resblock")
