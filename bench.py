@@ -137,7 +137,8 @@ def main():
               if c["cin"] == 1024 and c["cout"] == 1024 and c["KH"] == 3]
         rb_tf = (sum(c["flops"] for _, c in rb) / (sum(ms for ms, _ in rb) * 1e-3) / 1e12) if rb else None
         peak = PEAK_TFLOPS[args.precision]
-        tiles = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "64x128", 6: "256x64"}
+        tiles = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "64x128", 6: "256x64", 7: "128x64,ring6",
+                 8: "128x128,ring4", 9: "64x64,ring3", 10: "64x64,ring2", 11: "128x64,ring2", 12: "64x128,ring3"}
         roofline = {
             "bound": "mfma",
             "kernel": "conv_igemm_kernel<%s,%s> (implicit-GEMM conv, tile config %d)" % (
@@ -153,7 +154,9 @@ def main():
         }
         if args.dump_ops:
             with open(args.dump_ops, "w") as f:
-                json.dump([dict(op=n_, label=l_, ms=ms) for n_, l_, ms in rows], f, indent=1)
+                tiles_by_label = {c["label"]: c["tile"] for c in fp.conv_log}
+                json.dump([dict(op=n_, label=l_, ms=ms, tile=tiles_by_label.get(l_) if n_ == KERNEL_FAMILY else None)
+                           for n_, l_, ms in rows], f, indent=1)
 
     # ---------------- CPU baseline (oracle port on the host cores), rank 0 at N=1 only ----------
     cpu = None

@@ -83,6 +83,15 @@ typedef struct v2v_conv_desc {
     float   act_param;      /* leaky slope                                                   */
     float   out_scale;      /* multiplies the activated value (flow heads: 20 * 2^scale)     */
     int32_t tile;           /* 0 = auto, else force tile config id (testing/tuning)          */
+    int32_t* fin_counter;   /* NULL, or >= 64 zero-initialised tickets: finalize the training-mode norm in-kernel */
+    const float* fin_gamma; /* [cout] or NULL (affine = False)                               */
+    const float* fin_beta;  /* [cout] or NULL                                                */
+    float*  fin_scale_shift;  /* [4][cout] fp32 out: scale, shift, mean, invstd (as v2v_bn_finalize) */
+    float*  fin_running_mean; /* [cout] or NULL: updated with fin_momentum                     */
+    float*  fin_running_var;  /* [cout] or NULL (unbiased variance)                            */
+    float   fin_eps;
+    float   fin_momentum;
+    int64_t fin_count;      /* N*OH*OW                                                       */
 } v2v_conv_desc;
 
 /* transposed = 1: out[s*i - pad + k] += in[i]*w[k] for any OH <= (H-1)*s - 2*pad + KH + (s-1)
@@ -135,6 +144,10 @@ typedef struct v2v_wgrad_desc {
 } v2v_wgrad_desc;
 int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d);
 int     v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream);
+
+/* In-kernel alternative (v2v_conv_desc.fin_*): the last workgroup to finish an N tile of v2v_conv2d reduces
+ * the partial rows and writes scale/shift itself (agent-scope release/acquire hand-off), which removes one
+ * launch per norm layer.  Same arithmetic and summation order as v2v_bn_finalize. */
 
 /* Training-mode BatchNorm2d / InstanceNorm2d(batch 1) statistics -> per-channel scale/shift
  * (get_norm_layer, models/networks.py:23-30).  partials: [rows][C][2]; count = N*OH*OW.

@@ -104,7 +104,7 @@ def test_conv2d_all_output_modes(case, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", list(range(1, 18)))
 def test_conv2d_every_tile_config(tile, prec):
     from vid2vid_amd import lib as L
     torch.manual_seed(tile)
@@ -282,3 +282,43 @@ def test_flownet2_native_ops():
     xd = x.to(DEV)
     lib.check(lib.lib.v2v_channelnorm_forward(P(xd), P(out), 2, 3, 21, 33, 2, s), "channelnorm")
     assert_close(out.cpu(), O.channelnorm(x), 1e-6, "channelnorm")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_in_kernel_norm_finalize_matches_bn_finalize(prec):
+    """The last-arriving workgroup's scale/shift (agent-scope release/acquire hand-off inside the conv kernel)
+    must equal the separate bn_finalize launch bit for bit, for every tile configuration, repeatedly
+    (uneven workgroup finishing order, consumer L1 warm -- the regime where a broken hand-off shows)."""
+    import ctypes as C
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.engine import _ptr, _stream
+    torch.manual_seed(5)
+    eng = _engine(prec)
+    cin, cout, H, W = 40, 200, 45, 77                        # ragged against every tile, several N tiles
+    conv = nn.Conv2d(cin, cout, 3).to(DEV)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    with torch.no_grad():
+        norm.weight.normal_(1, 0.2); norm.bias.normal_(0, 0.2)
+    xs = [eng.pack(torch.randn(2, cin, H, W, device=DEV) * (1.0 + i)) for i in range(3)]
+    mism = 0
+    for it, tile in enumerate(list(range(1, 18)) * 4):
+        x = xs[it % 3]                          # the statistics change every launch: a stale read cannot hide
+        eng.tile_override[(cin, cout, 3, 1, 0)] = tile
+        ss = torch.full((4 * cout,), float("nan"), device=DEV)
+        raw, rows, (N, OH, OW) = eng.conv(x, conv, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+        ref = torch.empty(4 * cout, device=DEV)
+        st = eng.scratch("stats", rows * cout * 2)
+        L.check(lib.v2v_bn_finalize(_ptr(st), rows, cout, N * OH * OW, _ptr(norm.weight.detach()), _ptr(norm.bias.detach()),
+                                    norm.eps, _ptr(ref), None, None, 0.1, _stream()), "bn_finalize")
+        torch.cuda.synchronize()
+        assert torch.isfinite(ss).all(), "tile %d: finalize did not run for every channel" % tile
+        mism += int((ss != ref).sum().item())
+        assert int(eng._fin_counter.abs().sum().item()) == 0, "tickets must be re-armed"
+    assert mism == 0
+    # and against torch's batch statistics
+    xr = eng.unpack(x).cpu()
+    y = F.conv2d(F.pad(xr, (1,) * 4, mode="reflect"), _round(conv.weight.detach().cpu(), prec), conv.bias.detach().cpu())
+    mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    assert_close(ss[2 * cout:3 * cout].cpu(), mean, 1e-3, "mean")
+    assert_close(ss[3 * cout:].cpu(), 1.0 / torch.sqrt(var + norm.eps), 1e-3, "invstd")

@@ -79,13 +79,13 @@ class ConvFn(torch.autograd.Function):
                 OW = (W + 2 * cfg.pad - pc.KW) // pc.stride + 1
             cs_raw = (cout + 3) // 4 * 4
             raw = torch.empty(N * OH * OW * cs_raw, dtype=torch.float32, device=eng.device)
-            raw, rows, shp = eng.conv(x, conv, cfg.pad_mode, cfg.pad, L.OUT_RAW_F32_NHWC, want_stats=True, out=raw,
-                                      label=cfg.label)
             ss = torch.empty(4 * cout, dtype=torch.float32, device=eng.device)
+            raw, rows, shp = eng.conv(x, conv, cfg.pad_mode, cfg.pad, L.OUT_RAW_F32_NHWC, want_stats=True, out=raw,
+                                      label=cfg.label, fin=(norm, ss) if eng.fused_finalize else None)
             a0 = None if add0_t is None else Act(add0_t, cout)
             a1 = None if add1_t is None else Act(add1_t, cout)
             y = eng.norm_apply(raw, rows, shp, cout, norm, cfg.act, cfg.act_param, add0=a0, add1=a1,
-                               label=cfg.label, ss=ss)
+                               label=cfg.label, ss=ss, finalized=eng.fused_finalize)
             ctx.shape = shp
             ctx.save_for_backward(x_t, raw, ss)
             return y.t

@@ -61,6 +61,10 @@ struct ConvKArgs {
     int dstep;           // +1 conv, -1 convT
     int ktot[4], kpad[4];
     long long woff[4];   // element offset of the class matrix inside w
+    // in-kernel norm finalize (last-arriving workgroup of an N tile), optional
+    int* fin_counter; const float* fin_gamma; const float* fin_beta; float* fin_out;
+    float* fin_rmean; float* fin_rvar;
+    float fin_eps, fin_momentum; double fin_inv_count, fin_unbias;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int ntot) {
@@ -99,16 +103,19 @@ template <> struct Mma<float> {
 };
 
 template <typename T, int BM, int BN, int WGM, int WGN, int NS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BKE = ElemTraits<T>::BKE;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int NW = WGM * WGN;             // waves per workgroup (4 or 8)
+    constexpr int LR = NW * 8;                // LDS rows written per loader round (one 1 KiB DMA per wave)
+    constexpr int RA = BM / LR, RB = BN / LR;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int D = NS - 1;                 // tiles in flight
     constexpr int LPT = RA + RB;              // LDS-DMA instructions per tile per wave
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(BM % LR == 0 && BN % LR == 0 && RA >= 1 && RB >= 1, "loader rounds");
     static_assert(TM >= 1 && TN >= 1, "wave tile");
     static_assert(NS >= 2 && LPT * (D - 1) <= 63, "vmcnt range");
     typedef typename Mma<T>::Frag Frag;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
     // ---------------- loader geometry ----------------
     // wave `wid`, lane l writes LDS row (wid*8 + l>>3) + 32*i, physical 16-byte slot l&7, which
     // must hold the LOGICAL slot (l&7) ^ swz(row): that is the slot this lane fetches.
-    const int lrow = wid * 8 + (lane >> 3);          // 0..31
+    const int lrow = wid * 8 + (lane >> 3);          // 0..LR-1
     const int lslot = (lane & 7) ^ ((lrow >> 1) & 7);
     const int koff = lslot * VEC;                    // element offset inside the 128-byte chunk
     char* const lds_wave = smem + wid * 8 * 128;     // wave-uniform part of the destination
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
         const int mcls = p.Mc[cls];
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int m = mt * BM + lrow + 32 * i;
+            const int m = mt * BM + lrow + LR * i;
             const bool ok = m < mcls;
             const int mm = ok ? m : 0;
             const int n = mm / hw;
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
     const char* wp[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const long long r = (long long)nt * BN + lrow + 32 * i;
+        const long long r = (long long)nt * BN + lrow + LR * i;
         wp[i] = p.w + ((long long)p.woff[cls] + r * kpad + koff) * (long long)sizeof(T);
     }
 
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 const char* src = ((aok >> i) & 1u) ? ap[i] + kcb : zp;
-                glds16(src, sbase + i * 32 * 128);
+                glds16(src, sbase + i * LR * 128);
             }
         } else {
             const bool kvalid = kth < nkh;
@@ -228,12 +235,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
                 bool ok = kvalid && ((rowvalid >> i) & 1u);
                 const char* src = tap_ptr(i, dh, dw, ok) + kc * (int)sizeof(T);
                 src = ok ? src : zp;
-                glds16(src, sbase + i * 32 * 128);
+                glds16(src, sbase + i * LR * 128);
             }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            glds16(wp[i] + (long long)issued * 128, sbase + BM * 128 + i * 32 * 128);
+            glds16(wp[i] + (long long)issued * 128, sbase + BM * 128 + i * LR * 128);
         // advance the K walk by one chunk
         if (fastk) {
             kcb += 128;
@@ -374,8 +381,74 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
                     s2 += red[(q * BN + tid) * 2 + 1];
                 }
                 float* dst = p.stats + ((long long)(cls * p.m_tiles + mt) * p.cout + ncol) * 2;
-                dst[0] = s1;
-                dst[1] = s2;
+                if (p.fin_counter != nullptr) {
+                    // 8-byte agent-scope (write-through, sc1) store: the (sum, sum^2) granule is what the last
+                    // workgroup reads back with agent-scope loads -- no L2 write-back fence is needed
+                    const unsigned long long bits = (unsigned long long)__float_as_uint(s1) |
+                                                    ((unsigned long long)__float_as_uint(s2) << 32);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    dst[0] = s1;
+                    dst[1] = s2;
+                }
+            }
+        }
+        if (p.fin_counter != nullptr) {
+            // ---- training-mode norm finalize by the LAST workgroup to finish this N tile ----
+            // (get_norm_layer, models/networks.py:23-30: batch statistics -> scale/shift; replaces a separate
+            // bn_finalize launch per layer).  Hand-off (cdna guide G16, "sc1 payload -> vmcnt(0) -> flag" form):
+            // the partial rows are 8-byte write-through agent-scope stores, every wave drains them, workgroup
+            // barrier, then ONE relaxed agent-scope ticket; the last arriver reads all rows back with agent-scope
+            // 8-byte loads in a fixed order (deterministic, independent of which workgroup happens to be last).
+            // No release/acquire fence: a release would write back the XCD L2's dirty conv output (+30 us measured).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(smem + 16384);
+            const int total = (int)gridDim.y * p.m_tiles;
+            if (tid == 0) {
+                const int tk = __hip_atomic_fetch_add(p.fin_counter + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = tk == total - 1 ? 1 : 0;
+                if (last) __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag) {
+                constexpr int NT = NW * 64, PH = NT / BN;
+                double* acc2 = reinterpret_cast<double*>(smem);      // [PH][BN][2], <= 8 KiB
+                const int c = tid % BN, ph = tid / BN;
+                const int ncol = nt * BN + c;
+                double s1 = 0.0, s2 = 0.0;
+                if (ncol < p.cout) {
+                    for (int r = ph; r < total; r += PH) {
+                        const unsigned long long bits = __hip_atomic_load(
+                            reinterpret_cast<const unsigned long long*>(p.stats + ((long long)r * p.cout + ncol) * 2),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
+                        s2 += (double)__uint_as_float((unsigned)(bits >> 32));
+                    }
+                }
+                acc2[(ph * BN + c) * 2 + 0] = s1;
+                acc2[(ph * BN + c) * 2 + 1] = s2;
+                __syncthreads();
+                if (ph == 0 && ncol < p.cout) {
+                    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) { s1 += acc2[(q * BN + c) * 2 + 0]; s2 += acc2[(q * BN + c) * 2 + 1]; }
+                    const double mean = s1 * p.fin_inv_count;
+                    double var = s2 * p.fin_inv_count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const double invstd = 1.0 / sqrt(var + (double)p.fin_eps);
+                    const double g = p.fin_gamma ? (double)p.fin_gamma[ncol] : 1.0;
+                    const double b = p.fin_beta ? (double)p.fin_beta[ncol] : 0.0;
+                    const double sc = g * invstd;
+                    p.fin_out[ncol] = (float)sc;
+                    p.fin_out[p.cout + ncol] = (float)(b - mean * sc);
+                    p.fin_out[2 * p.cout + ncol] = (float)mean;
+                    p.fin_out[3 * p.cout + ncol] = (float)invstd;
+                    if (p.fin_rmean) p.fin_rmean[ncol] = (1.f - p.fin_momentum) * p.fin_rmean[ncol] + p.fin_momentum * (float)mean;
+                    if (p.fin_rvar)  p.fin_rvar[ncol]  = (1.f - p.fin_momentum) * p.fin_rvar[ncol] + p.fin_momentum * (float)(var * p.fin_unbias);
+                }
             }
         }
     }
@@ -387,6 +460,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs p) {
 struct TileCfg { int id, BM, BN; };
 static const TileCfg kCfgs[] = {
     {1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {4, 128, 32}, {5, 64, 128}, {6, 256, 64},
+    {7, 128, 64}, {8, 128, 128},      // deeper LDS-DMA rings of 2 / 1
+    {9, 64, 64}, {10, 64, 64}, {11, 128, 64}, {12, 64, 128},   // occupancy / depth variants of 3, 2, 5
+    {13, 128, 64}, {14, 128, 128}, {15, 128, 128}, {16, 256, 64}, {17, 64, 128},   // 8-wave workgroups
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -508,7 +584,7 @@ static int launch_cfg(const ConvKArgs& k, int ncls, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid((unsigned)(k.m_tiles * k.n_tiles), (unsigned)ncls);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+    hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, k);
     return check_launch();
 }
 
@@ -521,6 +597,17 @@ static int launch_typed(int cfg, const ConvKArgs& k, int ncls, hipStream_t s) {
         case 4: return launch_cfg<T, 128, 32, 4, 1, 4>(k, ncls, s);    //  80 KiB (2 / CU)
         case 5: return launch_cfg<T, 64, 128, 2, 2, 4>(k, ncls, s);    //  96 KiB
         case 6: return launch_cfg<T, 256, 64, 4, 1, 3>(k, ncls, s);    // 120 KiB
+        case 7: return launch_cfg<T, 128, 64, 2, 2, 6>(k, ncls, s);    // 144 KiB
+        case 8: return launch_cfg<T, 128, 128, 2, 2, 4>(k, ncls, s);   // 128 KiB
+        case 9: return launch_cfg<T, 64, 64, 2, 2, 3>(k, ncls, s);     //  48 KiB (3 workgroups / CU)
+        case 10: return launch_cfg<T, 64, 64, 2, 2, 2>(k, ncls, s);    //  32 KiB (5 / CU)
+        case 11: return launch_cfg<T, 128, 64, 2, 2, 2>(k, ncls, s);   //  48 KiB (3 / CU)
+        case 12: return launch_cfg<T, 64, 128, 2, 2, 3>(k, ncls, s);   //  72 KiB (2 / CU)
+        case 13: return launch_cfg<T, 128, 64, 4, 2, 3>(k, ncls, s);   //  72 KiB, 8 waves (2 / CU)
+        case 14: return launch_cfg<T, 128, 128, 4, 2, 2>(k, ncls, s);  //  64 KiB, 8 waves (2 / CU)
+        case 15: return launch_cfg<T, 128, 128, 2, 4, 3>(k, ncls, s);  //  96 KiB, 8 waves
+        case 16: return launch_cfg<T, 256, 64, 4, 2, 2>(k, ncls, s);   //  80 KiB, 8 waves
+        case 17: return launch_cfg<T, 64, 128, 2, 4, 3>(k, ncls, s);   //  72 KiB, 8 waves (2 / CU)
     }
     set_error("conv: unknown tile config %d", cfg);
     return V2V_EINVAL;
@@ -598,6 +685,16 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op) {
         k.ktot[c] = g.ktot[c]; k.kpad[c] = g.kpad[c]; k.woff[c] = g.woff[c];
     }
     k.out_mode = d->out_mode; k.act = d->act; k.act_param = d->act_param; k.out_scale = d->out_scale;
+    if (d->fin_counter) {
+        if (!d->stats || !d->fin_scale_shift || d->fin_count <= 0 || d->out_mode != V2V_OUT_RAW_F32_NHWC) {
+            set_error("conv: in-kernel norm finalize needs stats, fin_scale_shift, fin_count and RAW output"); return V2V_EINVAL;
+        }
+        k.fin_counter = d->fin_counter; k.fin_gamma = d->fin_gamma; k.fin_beta = d->fin_beta; k.fin_out = d->fin_scale_shift;
+        k.fin_rmean = d->fin_running_mean; k.fin_rvar = d->fin_running_var;
+        k.fin_eps = d->fin_eps; k.fin_momentum = d->fin_momentum;
+        k.fin_inv_count = 1.0 / (double)d->fin_count;
+        k.fin_unbias = d->fin_count > 1 ? (double)d->fin_count / (double)(d->fin_count - 1) : 1.0;
+    }
     op->ncls = g.ncls;
     op->dtype = d->dtype;
     op->cfg = d->tile ? d->tile : choose_cfg(Mc, d->cout, g.ncls);

@@ -202,10 +202,15 @@ class Engine:
         self._scratch = {}       # name -> tensor (grown on demand, shared between layers)
         self._grids = {}
         self._zero_page = None
+        self._fin_counter = None
+        self._thrash = None
         self.plan = None        # Plan being recorded (for labels / keep-alive)
         self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
-        self.tile_override = {}  # (cin,cout,KH,stride,transposed) -> tile id (tuning)
+        self.tile_override = {}  # (cin,cout,KH,stride,transposed) -> tile id (tests / manual tuning)
+        self.autotune = False    # measure the tile configurations once per conv shape (plan build time)
+        self._tuned = {}         # (cin,cout,KH,stride,transposed,N,H,W,out_mode) -> tile id
         self.update_running_stats = False
+        self.fused_finalize = True   # norm statistics finalized by the conv kernel's last workgroup
 
     # ---------------- buffers ----------------
     def empty_act(self, N, H, W, C):
@@ -280,8 +285,10 @@ class Engine:
 
     # ---------------- primitive emitters ----------------
     def conv(self, x, mod, pad_mode=L.PAD_ZERO, pad_override=None, out_mode=L.OUT_RAW_F32_NHWC,
-             act=L.ACT_NONE, act_param=0.0, out_scale=1.0, want_stats=False, out=None, label=""):
-        """Emit one convolution.  Returns (out, stats_rows, (N,OH,OW))."""
+             act=L.ACT_NONE, act_param=0.0, out_scale=1.0, want_stats=False, out=None, label="", fin=None):
+        """Emit one convolution.  Returns (out, stats_rows, (N,OH,OW)).
+        fin = (norm module, ss tensor [4*cout]): finalize the training-mode norm statistics inside the conv
+        kernel (last-arriving workgroup), so no separate bn_finalize launch is needed."""
         pc = self.packed(mod, x.Cs)
         pad = pc.pad if pad_override is None else pad_override
         N, H, W = x.N, x.H, x.W
@@ -304,6 +311,9 @@ class Engine:
         d.dtype, d.out_mode, d.act = self.dtype, out_mode, act
         d.act_param, d.out_scale = act_param, out_scale
         d.tile = self.tile_override.get((pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed)), 0)
+        tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
+        if d.tile == 0 and tune_key in self._tuned:
+            d.tile = self._tuned[tune_key]
         if pc.cin != x.C:
             raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
         if out_mode == L.OUT_RAW_F32_NHWC:
@@ -332,9 +342,30 @@ class Engine:
                 check(rows or -1, "conv_stats_rows")
             st = self.scratch("stats", rows * pc.cout * 2)
             d.stats = st.data_ptr()
+            if fin is not None:
+                norm, ss = fin
+                gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
+                if self._fin_counter is None:
+                    self._fin_counter = torch.zeros(256, dtype=torch.int32, device=self.device)
+                d.fin_counter = self._fin_counter.data_ptr()
+                d.fin_gamma = None if gamma is None else gamma.data_ptr()
+                d.fin_beta = None if beta is None else beta.data_ptr()
+                d.fin_scale_shift = ss.data_ptr()
+                d.fin_running_mean = None if rm is None else rm.data_ptr()
+                d.fin_running_var = None if rv is None else rv.data_ptr()
+                d.fin_eps, d.fin_momentum, d.fin_count = eps, mom, N * OH * OW
+                for t in (gamma, beta, ss, self._fin_counter):
+                    if t is not None:
+                        self._keep(t)
         self._keep(pc.buf)
         if pc.bias is not None:
             self._keep(pc.bias)
+        if (self.autotune and d.tile == 0 and self.plan is None and not self.record_only
+                and not torch.is_grad_enabled()):
+            d.tile = self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout)
+            if want_stats:
+                rows = lib.v2v_conv_stats_rows(C.byref(d))
+                d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()
         check(lib.v2v_conv2d(C.byref(d), _stream()), "conv2d " + label)
         self.label(label)
         ntaps = pc.KH * pc.KW
@@ -344,34 +375,73 @@ class Engine:
                                   tile=lib.v2v_conv_tile_config(C.byref(d))))
         return out, rows, (N, OH, OW)
 
-    def norm_apply(self, raw, rows, shape, cout, norm, act, act_param, add0=None, add1=None, label="", ss=None):
-        """bn_finalize + bn_apply on the shared raw/statistics scratch (ss: caller-owned [4][C] statistics
-        buffer, kept for the backward pass on the training path)."""
-        N, OH, OW = shape
-        cs_raw = (cout + 3) // 4 * 4
+    def _autotune(self, d, want_stats, cout, reps=3):
+        """Time every tile configuration that fits this launch and return the fastest id.  Runs once per conv
+        shape while a frame plan is being built, never inside a timed region.  Each timed launch is preceded by
+        a 384 MB memset: at batch 1 a frame streams ~0.7 GB of weights, so every layer meets its weights COLD in
+        L2 / Infinity Cache -- back-to-back warm launches favour shallow LDS-DMA rings that stall on real frames."""
+        cands = [1, 2, 3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17] + ([4] if cout <= 32 else [])
+        st = _stream()
+        if self._thrash is None:
+            self._thrash = torch.empty(96 << 20, dtype=torch.float32, device=self.device)
+        best, best_ms = 0, float("inf")
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        for t in cands:
+            d.tile = t
+            if want_stats:
+                rows = lib.v2v_conv_stats_rows(C.byref(d))
+                if rows <= 0:
+                    continue
+                d.stats = self.scratch("stats", rows * cout * 2).data_ptr()
+            if lib.v2v_conv2d(C.byref(d), st) != 0:
+                continue
+            for r in range(reps):
+                self._thrash.zero_()
+                e0[r].record()
+                lib.v2v_conv2d(C.byref(d), st)
+                e1[r].record()
+            e1[-1].synchronize()
+            ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))[reps // 2]      # median
+            if ms < best_ms:
+                best, best_ms = t, ms
+        return best
+
+    def _norm_params(self, norm, N):
+        """(gamma, beta, eps, momentum, running_mean, running_var) of a training-mode norm layer
+        (get_norm_layer, models/networks.py:23-30; .eval() is never called in the reference)."""
         if isinstance(norm, nn.BatchNorm2d):
             gamma = norm.weight.detach() if norm.affine else None
             beta = norm.bias.detach() if norm.affine else None
             eps, mom = norm.eps, (norm.momentum if norm.momentum is not None else 0.1)
             rm = norm.running_mean if (self.update_running_stats and norm.track_running_stats) else None
             rv = norm.running_var if (self.update_running_stats and norm.track_running_stats) else None
-        elif isinstance(norm, nn.InstanceNorm2d):
+            return gamma, beta, eps, mom, rm, rv
+        if isinstance(norm, nn.InstanceNorm2d):
             if N != 1:
                 raise NotImplementedError("InstanceNorm2d path supports batch 1 (per-sample statistics)")
             gamma = norm.weight.detach() if norm.affine else None
             beta = norm.bias.detach() if norm.affine else None
-            eps, mom, rm, rv = norm.eps, 0.1, None, None
-        else:
-            raise NotImplementedError("norm layer %r" % type(norm))
+            return gamma, beta, norm.eps, 0.1, None, None
+        raise NotImplementedError("norm layer %r" % type(norm))
+
+    def norm_apply(self, raw, rows, shape, cout, norm, act, act_param, add0=None, add1=None, label="", ss=None,
+                   finalized=False):
+        """[bn_finalize +] bn_apply on the shared raw/statistics scratch (ss: caller-owned [4][C] statistics
+        buffer, kept for the backward pass on the training path; finalized: the conv kernel already wrote it)."""
+        N, OH, OW = shape
+        cs_raw = (cout + 3) // 4 * 4
         if ss is None:
             ss = self.scratch("scale_shift", 4 * cout)
-        st = self.scratch("stats", rows * cout * 2)
-        for t in (gamma, beta):
-            if t is not None:
-                self._keep(t)
-        check(lib.v2v_bn_finalize(_ptr(st), rows, cout, N * OH * OW, _ptr(gamma), _ptr(beta), eps,
-                                  _ptr(ss), _ptr(rm), _ptr(rv), mom, _stream()), "bn_finalize " + label)
-        self.label(label + ".norm")
+        if not finalized:
+            gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
+            st = self.scratch("stats", rows * cout * 2)
+            for t in (gamma, beta):
+                if t is not None:
+                    self._keep(t)
+            check(lib.v2v_bn_finalize(_ptr(st), rows, cout, N * OH * OW, _ptr(gamma), _ptr(beta), eps,
+                                      _ptr(ss), _ptr(rm), _ptr(rv), mom, _stream()), "bn_finalize " + label)
+            self.label(label + ".norm")
         y = self.empty_act(N, OH, OW, cout)
         check(lib.v2v_bn_apply(_ptr(raw), cs_raw, _ptr(ss),
                                _ptr(None if add0 is None else add0.t), _ptr(None if add1 is None else add1.t),
@@ -390,9 +460,11 @@ class Engine:
             return AG.conv_group(self, x, conv, pad_mode, pad_override, norm, act, act_param, add0, add1,
                                  head_nchw, out_scale, label)
         if norm is not None:
-            raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC, want_stats=True, label=label)
+            ss = self.scratch("scale_shift", 4 * conv.out_channels)
+            raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC, want_stats=True, label=label,
+                                       fin=(norm, ss) if self.fused_finalize else None)
             return self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param, add0=add0, add1=add1,
-                                   label=label)
+                                   label=label, ss=ss, finalized=self.fused_finalize)
         if add0 is not None or add1 is not None:
             raise NotImplementedError("residual adds need a norm layer in the group")
         out, _, _ = self.conv(x, conv, pad_mode, pad_override, L.OUT_F32_NCHW if head_nchw else L.OUT_ACT_NHWC,

@@ -33,6 +33,9 @@ class ConvDesc(C.Structure):
         ("dtype", C.c_int32), ("out_mode", C.c_int32), ("act", C.c_int32),
         ("act_param", C.c_float), ("out_scale", C.c_float),
         ("tile", C.c_int32),
+        ("fin_counter", C.c_void_p), ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p),
+        ("fin_scale_shift", C.c_void_p), ("fin_running_mean", C.c_void_p), ("fin_running_var", C.c_void_p),
+        ("fin_eps", C.c_float), ("fin_momentum", C.c_float), ("fin_count", C.c_int64),
     ]
 
 

@@ -24,7 +24,11 @@ class _FlowPlan:
         self.im2 = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
         self.flow = self.conf = None
         if not eng.record_only:
-            self._emit()                       # sizes the shared scratch
+            eng.autotune = bool(getattr(model.opt, "autotune", True))
+            try:
+                self._emit()                   # sizes the shared scratch, picks tile configurations
+            finally:
+                eng.autotune = False
             torch.cuda.synchronize(dev)
         self.plan = Plan()
         eng.plan = self.plan

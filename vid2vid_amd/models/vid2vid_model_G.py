@@ -44,7 +44,11 @@ class _FramePlan:
         self.out = {}
         # warm-up pass sizes the shared scratch, then the same code is recorded
         if not eng.record_only:
-            self._emit()
+            eng.autotune = bool(getattr(opt, "autotune", True))      # per-shape tile selection, measured once
+            try:
+                self._emit()
+            finally:
+                eng.autotune = False
             torch.cuda.synchronize(dev)
         self.plan = Plan()
         eng.plan = self.plan
