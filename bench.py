@@ -123,7 +123,7 @@ def main():
             convs = [r for r in rows if r[0] == KERNEL_FAMILY]
             assert len(convs) == len(fp.conv_log)
             for (name, label, ms), c in zip(convs, fp.conv_log):
-                key = (c["tile"],)
+                key = (c["tile"], c.get("splitk", 1), c.get("prefetch", 0))
                 a = acc.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
                 a["ms"] += ms; a["flops"] += c["flops"]; a["launches"] += 1
         total_ms = {}
@@ -137,12 +137,13 @@ def main():
               if c["cin"] == 1024 and c["cout"] == 1024 and c["KH"] == 3]
         rb_tf = (sum(c["flops"] for _, c in rb) / (sum(ms for ms, _ in rb) * 1e-3) / 1e12) if rb else None
         peak = PEAK_TFLOPS[args.precision]
-        tiles = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "64x128", 6: "256x64", 7: "128x64,ring6",
-                 8: "128x128,ring4", 9: "64x64,ring3", 10: "64x64,ring2", 11: "128x64,ring2", 12: "64x128,ring3"}
+        from vid2vid_amd.engine import TILE_CFGS
+        bm, bn, _ = TILE_CFGS.get(dom_tile[0], (0, 0, False))
+        tile_name = "%dx%d,splitK=%d,prefetch=%d" % (bm, bn, dom_tile[1], dom_tile[2])
         roofline = {
             "bound": "mfma",
             "kernel": "conv_igemm_kernel<%s,%s> (implicit-GEMM conv, tile config %d)" % (
-                "bf16" if args.precision == "bf16" else "f32", tiles.get(dom_tile[0], "?"), dom_tile[0]),
+                "bf16" if args.precision == "bf16" else "f32", tile_name, dom_tile[0]),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": None,
             "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
@@ -154,7 +155,7 @@ def main():
         }
         if args.dump_ops:
             with open(args.dump_ops, "w") as f:
-                tiles_by_label = {c["label"]: c["tile"] for c in fp.conv_log}
+                tiles_by_label = {c["label"]: (c["tile"], c.get("splitk", 1), c.get("prefetch", 0)) for c in fp.conv_log}
                 json.dump([dict(op=n_, label=l_, ms=ms, tile=tiles_by_label.get(l_) if n_ == KERNEL_FAMILY else None)
                            for n_, l_, ms in rows], f, indent=1)
 

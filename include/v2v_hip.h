@@ -92,7 +92,19 @@ typedef struct v2v_conv_desc {
     float   fin_eps;
     float   fin_momentum;
     int64_t fin_count;      /* N*OH*OW                                                       */
+    int32_t splitk;         /* 0/1 = off; S > 1: S workgroups share a tile along K (see below)        */
+    int32_t prefetch;       /* 0 = off; P > 0: weight-prefetch helper wave, P K-chunks ahead (see below) */
+    void*   slabs;          /* splitk > 1: v2v_conv_splitk_workspace() bytes of scratch              */
+    int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
 } v2v_conv_desc;
+
+/* splitk = S > 1: the S workgroups of a tile each reduce 1/S of the K chunks and publish an fp32 partial tile; the
+ * last to arrive sums the S partial tiles in slice order (deterministic, independent of arrival order) and runs the
+ * normal epilogue (bias, statistics, norm finalize, activation).  For small-M layers that cannot fill 256 CUs with
+ * LDS-read-efficient tiles.
+ * prefetch = P > 0: tile configurations with a helper instance launch one extra wave per workgroup that touches the
+ * weight lines P K-chunks (128 B per weight row each) ahead of the LDS-DMA loaders, so the batch-1 weight stream
+ * (every line a cold HBM miss) is an L2 hit when the loaders fetch it.  Bitwise neutral. */
 
 /* transposed = 1: out[s*i - pad + k] += in[i]*w[k] for any OH <= (H-1)*s - 2*pad + KH + (s-1)
  * (output_padding < s).  The same operator is the backward-data pass of a Conv2d (same weight tensor,
@@ -112,6 +124,8 @@ int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t ci
 
 /* Number of statistics rows (n_classes * m_tiles) the launch described by `d` writes. */
 int     v2v_conv_stats_rows(const v2v_conv_desc* d);
+/* Bytes of `slabs` scratch (and number of `sk_counter` ints via *tickets) the launch needs; 0 when splitk <= 1. */
+int64_t v2v_conv_splitk_workspace(const v2v_conv_desc* d, int32_t* tickets);
 /* Tile configuration id the launch would use (after auto selection). */
 int     v2v_conv_tile_config(const v2v_conv_desc* d);
 /* Launch.  nn.Conv2d / nn.ConvTranspose2d forward (models/networks.py:132-183 etc.), and -- with the

@@ -104,7 +104,7 @@ def test_conv2d_all_output_modes(case, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("tile", list(range(1, 18)))
+@pytest.mark.parametrize("tile", list(range(1, 24)))
 def test_conv2d_every_tile_config(tile, prec):
     from vid2vid_amd import lib as L
     torch.manual_seed(tile)
@@ -121,6 +121,85 @@ def test_conv2d_every_tile_config(tile, prec):
     assert_close(got, ref, 1e-4, "tile %d" % tile)
     st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
     assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "stats")
+
+
+# (tile, splitk, prefetch): split-K slices that start mid-tap, the prefetch helper wave on 4- and 8-wave tiles,
+# large wave tiles; cin chosen so that both the uniform tap walk (cs % chunk == 0) and the per-lane walk run
+SPLITK_CFGS = [(2, 2, 0), (2, 3, 12), (3, 4, 12), (13, 2, 12), (13, 1, 12), (17, 3, 12), (1, 2, 0), (5, 4, 12), (7, 1, 4),
+               (18, 4, 0), (19, 2, 0), (20, 3, 0), (21, 2, 0), (22, 4, 0), (23, 2, 0), (6, 2, 0), (16, 3, 0), (11, 6, 12)]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin", [136, 192])
+def test_conv2d_splitk_and_prefetch(cin, prec):
+    """Split-K (last-arriver reduction of fp32 slabs) and the weight-prefetch helper wave: every configuration
+    against torch on inputs that change every launch (a stale slab read cannot hide), tickets re-armed,
+    bitwise-reproducible, statistics + in-kernel norm finalize on the reduced tile."""
+    from vid2vid_amd import lib as L
+    torch.manual_seed(cin)
+    eng = _engine(prec)
+    cout, H, W = 200, 23, 41                    # M = 2*23*41 = 1886, ragged against every BM / BN
+    conv = nn.Conv2d(cin, cout, 3, padding=0)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    xs = [torch.randn(2, cin, H, W) * (1.0 + i) for i in range(3)]
+    refs = [F.conv2d(F.pad(_round(x, prec), (1,) * 4, mode="reflect"), _round(conv.weight.detach(), prec), conv.bias.detach())
+            for x in xs]
+    conv = conv.to(DEV)
+    xa = [eng.pack(x.to(DEV)) for x in xs]
+    for it, cfg in enumerate(SPLITK_CFGS * 2):
+        k = it % 3
+        eng.tile_override[(cin, cout, 3, 1, 0)] = cfg
+        ss = torch.full((4 * cout,), float("nan"), device=DEV)
+        raw, rows, (N, OH, OW) = eng.conv(xa[k], conv, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+        log = eng.conv_log[-1]
+        assert (log["tile"], log["splitk"]) == (cfg[0], cfg[1]), (cfg, log)
+        got = raw[:N * OH * OW * cout].view(N, OH, OW, cout).permute(0, 3, 1, 2).clone()
+        assert_close(got.cpu(), refs[k], 1e-4, "cfg %s" % (cfg,))
+        st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+        assert_close(st[:, 0], refs[k].sum((0, 2, 3)), 1e-3, "stats %s" % (cfg,))
+        mean = refs[k].mean((0, 2, 3))
+        assert_close(ss[2 * cout:3 * cout].cpu(), mean, 1e-3, "finalized mean %s" % (cfg,))
+        raw2, _, _ = eng.conv(xa[k], conv, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
+        got2 = raw2[:N * OH * OW * cout].view(N, OH, OW, cout).permute(0, 3, 1, 2)
+        assert torch.equal(got, got2), "cfg %s is not bit-reproducible" % (cfg,)
+        if eng._sk_counter is not None:
+            assert int(eng._sk_counter.abs().sum().item()) == 0, "split-K tickets must be re-armed"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_convtranspose_splitk(prec):
+    """4 output-parity classes x split-K (the 1-tap class has the fewest K chunks)."""
+    from vid2vid_amd import lib as L
+    torch.manual_seed(11)
+    eng = _engine(prec)
+    cin, cout, H, W = 256, 96, 13, 21
+    m = nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1)
+    x = torch.randn(1, cin, H, W)
+    ref = F.conv_transpose2d(_round(x, prec), _round(m.weight.detach(), prec), m.bias.detach(), stride=2, padding=1,
+                             output_padding=1)
+    m = m.to(DEV)
+    xa = eng.pack(x.to(DEV))
+    for cfg in [(3, 2, 12), (2, 2, 0), (13, 2, 12), (21, 2, 0)]:
+        eng.tile_override[(cin, cout, 3, 2, 1)] = cfg
+        out, _, _ = eng.conv(xa, m, L.PAD_ZERO, None, L.OUT_ACT_NHWC)
+        assert eng.conv_log[-1]["splitk"] == cfg[1]
+        assert_close(eng.unpack(out).cpu(), ref, 1e-4 if prec == "fp32" else 1e-2, "convT cfg %s" % (cfg,))
+
+
+def test_prefetch_is_bitwise_neutral():
+    from vid2vid_amd import lib as L
+    torch.manual_seed(3)
+    eng = _engine("bf16")
+    cin, cout, H, W = 256, 160, 20, 36
+    conv = nn.Conv2d(cin, cout, 3, padding=0).to(DEV)
+    xa = eng.pack(torch.randn(1, cin, H, W, device=DEV))
+    outs = []
+    for cfg in [(13, 1, 0), (13, 1, 12), (13, 1, 40)]:
+        eng.tile_override[(cin, cout, 3, 1, 0)] = cfg
+        raw, _, (N, OH, OW) = eng.conv(xa, conv, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
+        assert eng.conv_log[-1]["prefetch"] == cfg[2]
+        outs.append(raw[:N * OH * OW * cout].clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 CONVT_CASES = [(16, 8, 3, 1, 1, 9, 13), (64, 32, 3, 1, 1, 16, 32), (24, 16, 4, 1, 0, 11, 7), (128, 64, 3, 1, 1, 32, 64)]
@@ -302,7 +381,7 @@ def test_in_kernel_norm_finalize_matches_bn_finalize(prec):
         norm.weight.normal_(1, 0.2); norm.bias.normal_(0, 0.2)
     xs = [eng.pack(torch.randn(2, cin, H, W, device=DEV) * (1.0 + i)) for i in range(3)]
     mism = 0
-    for it, tile in enumerate(list(range(1, 18)) * 4):
+    for it, tile in enumerate(list(range(1, 24)) * 3):
         x = xs[it % 3]                          # the statistics change every launch: a stale read cannot hide
         eng.tile_override[(cin, cout, 3, 1, 0)] = tile
         ss = torch.full((4 * cout,), float("nan"), device=DEV)

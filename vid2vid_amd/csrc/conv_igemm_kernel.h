@@ -1,0 +1,601 @@
+// Implicit-GEMM convolution kernel template (see conv_igemm.hip for the design notes); included by the
+// per-dtype instantiation units conv_igemm_bf16.hip / conv_igemm_f32.hip and by the host side.
+#pragma once
+#include "v2v_internal.h"
+
+namespace v2v {
+
+struct ConvKArgs {
+    const char* in;
+    const char* w;
+    const char* zero_page;
+    const float* bias;
+    char* out;
+    float* stats;
+    int N, H, W, cin_stride;
+    int cout, cout_stride, cout_p;
+    int OH, OW;
+    int sm;              // input step per class-grid step (conv: stride, convT: 1)
+    int os;              // output step per class-grid step (conv: 1, convT: 2)
+    int pad_mode;
+    int Mc[4], OHc[4], OWc[4];   // rows per class and class grid (transposed: output pixels of parity class)
+    int m_tiles, n_tiles;
+    int out_mode, act;
+    float act_param, out_scale;
+    // per class (conv: class 0 only)
+    int nkh[4], nkw[4];
+    int dh0[4], dw0[4];  // first tap's input offset
+    int dstep;           // +1 conv, -1 convT
+    int ktot[4], kpad[4];
+    long long woff[4];   // element offset of the class matrix inside w
+    // in-kernel norm finalize (last-arriving workgroup of an N tile), optional
+    int* fin_counter; const float* fin_gamma; const float* fin_beta; float* fin_out;
+    float* fin_rmean; float* fin_rvar;
+    float fin_eps, fin_momentum; double fin_inv_count, fin_unbias;
+    // split-K: `splitk` workgroups share one output tile (K chunks [nk*s/S, nk*(s+1)/S)); each publishes its
+    // fp32 partial tile to `slabs`, the LAST one to arrive (ticket in sk_counter) sums them in slice order
+    int splitk; float* slabs; int* sk_counter;
+    // weight-stream prefetch: an extra (helper) wave touches the weight lines `pf_dist` K chunks ahead so that the
+    // LDS-DMA of the real loaders hits L2 instead of waiting for HBM; workgroups with (mt & pf_mask) != 0 skip it
+    int pf_dist, pf_mask;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int ntot) {
+    const int q = ntot >> 3, r = ntot & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// 16 bytes per lane, global -> LDS, asynchronous (counted by vmcnt).  `lds` must be
+// wave-uniform: the hardware writes lane l at lds + 16*l.
+__device__ __forceinline__ void glds16(const char* g, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 Frag;
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4 Frag;
+    // lane (i = l&31, half h = l>>5) holds k = 4h..4h+3 of an 8-deep step: MFMA j multiplies
+    // k in {j, 4+j}; A and B use the same convention so every k is covered exactly once.
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN, int WGM, int WGN, int NS, bool HELPER>
+__global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igemm_kernel(const ConvKArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int BKE = ElemTraits<T>::BKE;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NW = WGM * WGN;             // waves per workgroup (4 or 8)
+    constexpr int LR = NW * 8;                // LDS rows written per loader round (one 1 KiB DMA per wave)
+    constexpr int RA = BM / LR, RB = BN / LR;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int D = NS - 1;                 // tiles in flight
+    constexpr int LPT = RA + RB;              // LDS-DMA instructions per tile per wave
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(BM % LR == 0 && BN % LR == 0 && RA >= 1 && RB >= 1, "loader rounds");
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    static_assert(NS >= 2 && LPT * (D - 1) <= 63, "vmcnt range");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = HELPER && wid >= NW;   // prefetch wave (HELPER instances are launched with NW+1 waves)
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int cls = blockIdx.y;
+
+    const int tiles = p.m_tiles * p.n_tiles;
+    const int S = p.splitk;
+    const int lin_all = xcd_remap(blockIdx.x, tiles * S);   // a tile's K slices are neighbours on one XCD
+    const int lin = lin_all / S;
+    const int slice = lin_all - lin * S;
+    const int nt = lin / p.m_tiles;
+    const int mt = lin - nt * p.m_tiles;
+
+    const int nkh = p.nkh[cls], nkw = p.nkw[cls];
+    const int dh0 = p.dh0[cls], dw0 = p.dw0[cls], dstep = p.dstep;
+    const int kpad = p.kpad[cls];
+    const int nk_all = kpad / BKE;
+    const int kb = (int)(((long long)nk_all * slice) / S);            // this slice's first K chunk
+    const int nk = (int)(((long long)nk_all * (slice + 1)) / S) - kb; // and its chunk count
+    const int H = p.H, W = p.W, cs = p.cin_stride;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+    const char* const zp = p.zero_page;
+
+    // ---------------- loader geometry ----------------
+    // wave `wid`, lane l writes LDS row (wid*8 + l>>3) + 32*i, physical 16-byte slot l&7, which
+    // must hold the LOGICAL slot (l&7) ^ swz(row): that is the slot this lane fetches.
+    const int lrow = wid * 8 + (lane >> 3);          // 0..LR-1
+    const int lslot = (lane & 7) ^ ((lrow >> 1) & 7);
+    const int koff = lslot * VEC;                    // element offset inside the 128-byte chunk
+    char* const lds_wave = smem + wid * 8 * 128;     // wave-uniform part of the destination
+
+    int pixbase[RA], ohs[RA], ows[RA];
+    unsigned rowvalid = 0;
+    {
+        const int owc = p.OWc[cls];
+        const int hw = p.OHc[cls] * owc;
+        const int mcls = p.Mc[cls];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = mt * BM + lrow + LR * i;
+            const bool ok = m < mcls;
+            const int mm = ok ? m : 0;
+            const int n = mm / hw;
+            const int rem = mm - n * hw;
+            const int oi = rem / owc;
+            const int oj = rem - oi * owc;
+            pixbase[i] = n * H * W;
+            ohs[i] = oi * p.sm;
+            ows[i] = oj * p.sm;
+            rowvalid |= (ok ? 1u : 0u) << i;
+        }
+    }
+    const char* wp[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        long long r = (long long)nt * BN + lrow + LR * i;
+        r = r < p.cout_p ? r : p.cout_p - 1;         // BN = 256 tiles can overhang the packed rows (cout_p = 128-multiple)
+        wp[i] = p.w + ((long long)p.woff[cls] + r * kpad + koff) * (long long)sizeof(T) + (long long)kb * 128;
+    }
+
+    // resolves one tap for one row: source pointer of this lane's slot (channel 0 of the chunk)
+    auto tap_ptr = [&](int i, int dh, int dw, bool& ok) -> const char* {
+        int ih = ohs[i] + dh, iw = ows[i] + dw;
+        // branch-free: reflection is a select on a uniform flag, validity a bitwise AND
+        int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+        int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+        ih = reflect ? rh : ih;
+        iw = reflect ? rw : iw;
+        ok = (bool)((int)ok & (int)((unsigned)ih < (unsigned)H) & (int)((unsigned)iw < (unsigned)W));
+        ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+        iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        return p.in + ((long long)(pixbase[i] + ih * W + iw) * cs) * (long long)sizeof(T);
+    };
+
+    // ---- fast path (cs % BKE == 0): the tap is uniform over the workgroup ----
+    const bool fastk = (cs % BKE) == 0;
+    const char* ap[RA];
+    unsigned aok = 0;
+    int tap_h = 0, tap_w = 0, kcb = 0;               // uniform
+    const int row_bytes = cs * (int)sizeof(T);
+    if (kb > 0) {                                    // split-K: start the uniform walk at chunk kb
+        const int e0 = kb * BKE, tap0 = e0 / cs;
+        kcb = (e0 - tap0 * cs) * (int)sizeof(T);
+        tap_h = tap0 / nkw;
+        tap_w = tap0 - tap_h * nkw;
+    }
+    auto set_tap = [&]() {
+        const int dh = dh0 + tap_h * dstep, dw = dw0 + tap_w * dstep;
+        const bool tvalid = tap_h < nkh;
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            bool ok = tvalid && ((rowvalid >> i) & 1u);
+            ap[i] = tap_ptr(i, dh, dw, ok) + koff * (int)sizeof(T);
+            aok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    // ---- general path: per-lane (tap, channel) walk ----
+    int kc, kth, ktw;
+    {
+        const int k0 = koff + kb * BKE;
+        const int t = k0 / cs;
+        kc = k0 - t * cs;
+        kth = t / nkw;
+        ktw = t - kth * nkw;
+    }
+    const int nwrap = (BKE + cs - 1) / cs;           // tap wraps per chunk (1 when cs >= BKE)
+    if (fastk) set_tap();
+
+    int issued = 0;                                  // tiles issued so far (uniform)
+    auto issue = [&]() {
+        char* sbase = lds_wave + (issued % NS) * STAGE;
+        if (fastk) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const char* src = ((aok >> i) & 1u) ? ap[i] + kcb : zp;
+                glds16(src, sbase + i * LR * 128);
+            }
+        } else {
+            const bool kvalid = kth < nkh;
+            const int dh = dh0 + kth * dstep, dw = dw0 + ktw * dstep;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                bool ok = kvalid && ((rowvalid >> i) & 1u);
+                const char* src = tap_ptr(i, dh, dw, ok) + kc * (int)sizeof(T);
+                src = ok ? src : zp;
+                glds16(src, sbase + i * LR * 128);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            glds16(wp[i] + (long long)issued * 128, sbase + BM * 128 + i * LR * 128);
+        // advance the K walk by one chunk
+        if (fastk) {
+            kcb += 128;
+            if (kcb == row_bytes) {
+                kcb = 0;
+                if (++tap_w == nkw) { tap_w = 0; ++tap_h; }
+                set_tap();
+            }
+        } else {
+            kc += BKE;
+            for (int it = 0; it < nwrap; ++it) {
+                const bool wr = kc >= cs;
+                kc -= wr ? cs : 0;
+                ktw += wr ? 1 : 0;
+                const bool w2 = ktw == nkw;
+                ktw = w2 ? 0 : ktw;
+                kth += w2 ? 1 : 0;
+            }
+        }
+        ++issued;
+    };
+
+    // ---------------- fragment addressing ----------------
+    const int lr = lane & 31, hi = lane >> 5;
+    const int fx = (lr >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = ((s * 2 + hi) ^ fx) << 4;
+    const int a_row_off = (wm * WM + lr) * 128;
+    const int b_row_off = BM * 128 + (wn * WN + lr) * 128;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---------------- main loop ----------------
+    if (helper) {
+        // Prefetch wave: lane l touches weight row (nt*BN + l [+64 ...]) of chunk c with a 4-byte LDS-DMA into
+        // a dummy LDS line (no VGPR destination, nothing ever waits for it inside the loop); it only keeps
+        // step with the workgroup through the per-chunk barrier.
+        constexpr int PR = (BN + 63) / 64;
+        const bool pf_on = (mt & p.pf_mask) == 0;
+        char* const sink = smem + NS * STAGE;
+        const char* prow[PR];
+#pragma unroll
+        for (int i = 0; i < PR; ++i) {
+            long long r = (long long)nt * BN + lane + 64 * i;
+            r = r < p.cout_p ? r : p.cout_p - 1;
+            prow[i] = p.w + ((long long)p.woff[cls] + r * kpad) * (long long)sizeof(T) + (long long)kb * 128;
+        }
+        const int P = p.pf_dist;
+        if (pf_on)
+            for (int c = 0; c < P && c < nk; ++c)
+#pragma unroll
+                for (int i = 0; i < PR; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(prow[i] + (long long)c * 128),
+                                                     (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
+        for (int ks = 0; ks < nk; ++ks) {
+            __builtin_amdgcn_s_barrier();
+            if (pf_on && ks + P < nk)
+#pragma unroll
+                for (int i = 0; i < PR; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(prow[i] + (long long)(ks + P) * 128),
+                                                     (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
+        }
+    } else {
+        for (int t = 0; t < D && t < nk; ++t) issue();
+        for (int ks = 0; ks < nk; ++ks) {
+            // tile ks must have landed; in steady state tiles ks+1 .. ks+D-1 stay in flight
+            if (ks + D <= nk) wait_vmcnt<LPT * (D - 1)>();
+            else              wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();     // every wave's part of tile ks is in LDS, and every wave
+                                              // is done reading stage (ks-1)%NS, which is refilled now
+            if (ks + D < nk) issue();
+            const char* sb = smem + (ks % NS) * STAGE;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Frag fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const Frag*>(sb + a_row_off + i * 32 * 128 + foff[s]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *reinterpret_cast<const Frag*>(sb + b_row_off + j * 32 * 128 + foff[s]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+            }
+        }
+    }
+    __syncthreads();                      // LDS ring is free: reused for the statistics reduction
+
+    // ---------------- split-K hand-off ----------------
+    // (cdna guide 5 "in-launch split-K reduction", write-through form): every slice stores its fp32 partial
+    // tile with 16-byte sc1 stores, every storing wave drains them, workgroup barrier, ONE relaxed agent-scope
+    // ticket.  The slice that draws S-1 re-arms the ticket, reads all S slabs back with sc1 loads and sums them
+    // in SLICE order, so the result does not depend on which slice happened to be last.  No spin anywhere:
+    // nothing can hang.
+    if (S > 1) {
+        constexpr int NT = NW * 64;
+        constexpr unsigned SLAB = (unsigned)BM * BN * 4u;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const long long tile_id = (long long)cls * tiles + lin;
+        char* const sbase = reinterpret_cast<char*>(p.slabs) + tile_id * (long long)S * SLAB;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(S * SLAB), 0x00020000);
+        if (!helper) {
+            const unsigned my = (unsigned)slice * SLAB + (unsigned)tid * 16u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        u32x4 v;
+                        v[0] = __float_as_uint(acc[i][j][4 * q + 0]); v[1] = __float_as_uint(acc[i][j][4 * q + 1]);
+                        v[2] = __float_as_uint(acc[i][j][4 * q + 2]); v[3] = __float_as_uint(acc[i][j][4 * q + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, my + (unsigned)(((i * TN + j) * 4 + q) * NT * 16), 0, 16);
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem + 16384);
+        if (tid == 0) {
+            int* cnt = p.sk_counter + tile_id;
+            const int tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = tk == S - 1 ? 1 : 0;
+            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        if (!helper) {
+            // every slab, the reducer's own included, is read back in slice order 0..S-1: the sum is the same
+            // whichever slice arrives last, and no second accumulator set is live
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int sl = 0; sl < S; ++sl) {
+                const unsigned off = (unsigned)sl * SLAB + (unsigned)tid * 16u;
+                u32x4 v[TM][TN][4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            v[i][j][q] = __builtin_amdgcn_raw_buffer_load_b128(
+                                rsrc, off + (unsigned)(((i * TN + j) * 4 + q) * NT * 16), 0, 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[i][j][4 * q + 0] += __uint_as_float(v[i][j][q][0]); acc[i][j][4 * q + 1] += __uint_as_float(v[i][j][q][1]);
+                            acc[i][j][4 * q + 2] += __uint_as_float(v[i][j][q][2]); acc[i][j][4 * q + 3] += __uint_as_float(v[i][j][q][3]);
+                        }
+            }
+        }
+        __syncthreads();                  // the flag word is reused by the norm-finalize hand-off below
+    }
+
+    // ---------------- epilogue ----------------
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2]
+    const bool want_stats = p.stats != nullptr;
+    const int a_par = cls >> 1, b_par = cls & 1;
+    const int owc_e = p.OWc[cls];
+    const int hwc = p.OHc[cls] * owc_e;
+    const int mcls_e = p.Mc[cls];
+    const long long ohow = (long long)p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ncol = nt * BN + wn * WN + j * 32 + lr;
+        const bool nvalid = ncol < p.cout && !helper;
+        const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int m = mt * BM + row;
+                if (m < mcls_e && nvalid) {
+                    float v = acc[i][j][r] + bv;
+                    long long opix;   // output pixel index in [N][OH][OW]
+                    if (p.os == 1) {
+                        opix = m;
+                    } else {
+                        const int n = m / hwc;
+                        const int rem = m - n * hwc;
+                        const int oi = rem / owc_e;
+                        const int oj = rem - oi * owc_e;
+                        opix = ((long long)n * p.OH + (oi * 2 + a_par)) * p.OW + (oj * 2 + b_par);
+                    }
+                    if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
+                        s1 += v;
+                        s2 += v * v;
+                        reinterpret_cast<float*>(p.out)[opix * p.cout_stride + ncol] = v;
+                    } else {
+                        v = apply_act(v, p.act, p.act_param) * p.out_scale;
+                        if (p.out_mode == V2V_OUT_ACT_NHWC) {
+                            store_act(reinterpret_cast<T*>(p.out), opix * p.cout_stride + ncol, v);
+                        } else {
+                            const long long n = opix / ohow;
+                            const long long pix = opix - n * ohow;
+                            reinterpret_cast<float*>(p.out)[(n * p.cout + ncol) * ohow + pix] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hi == 0 && !helper) {
+                const int c = wn * WN + j * 32 + lr;
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = s2;
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int ncol = nt * BN + tid;
+            if (ncol < p.cout) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < WGM; ++q) {
+                    s1 += red[(q * BN + tid) * 2 + 0];
+                    s2 += red[(q * BN + tid) * 2 + 1];
+                }
+                float* dst = p.stats + ((long long)(cls * p.m_tiles + mt) * p.cout + ncol) * 2;
+                if (p.fin_counter != nullptr) {
+                    // 8-byte agent-scope (write-through, sc1) store: the (sum, sum^2) granule is what the last
+                    // workgroup reads back with agent-scope loads -- no L2 write-back fence is needed
+                    const unsigned long long bits = (unsigned long long)__float_as_uint(s1) |
+                                                    ((unsigned long long)__float_as_uint(s2) << 32);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    dst[0] = s1;
+                    dst[1] = s2;
+                }
+            }
+        }
+        if (p.fin_counter != nullptr) {
+            // ---- training-mode norm finalize by the LAST workgroup to finish this N tile ----
+            // (get_norm_layer, models/networks.py:23-30: batch statistics -> scale/shift; replaces a separate
+            // bn_finalize launch per layer).  Hand-off (cdna guide G16, "sc1 payload -> vmcnt(0) -> flag" form):
+            // the partial rows are 8-byte write-through agent-scope stores, every wave drains them, workgroup
+            // barrier, then ONE relaxed agent-scope ticket; the last arriver reads all rows back with agent-scope
+            // 8-byte loads in a fixed order (deterministic, independent of which workgroup happens to be last).
+            // No release/acquire fence: a release would write back the XCD L2's dirty conv output (+30 us measured).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(smem + 16384);
+            const int total = (int)gridDim.y * p.m_tiles;
+            if (tid == 0) {
+                const int tk = __hip_atomic_fetch_add(p.fin_counter + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = tk == total - 1 ? 1 : 0;
+                if (last) __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag) {
+                constexpr int NT = NW * 64, PH = NT / BN;
+                double* acc2 = reinterpret_cast<double*>(smem);      // [PH][BN][2], <= 8 KiB
+                const int c = tid % BN, ph = tid / BN;
+                const int ncol = nt * BN + c;
+                double s1 = 0.0, s2 = 0.0;
+                if (ncol < p.cout && ph < PH) {
+                    for (int r = ph; r < total; r += PH) {
+                        const unsigned long long bits = __hip_atomic_load(
+                            reinterpret_cast<const unsigned long long*>(p.stats + ((long long)r * p.cout + ncol) * 2),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
+                        s2 += (double)__uint_as_float((unsigned)(bits >> 32));
+                    }
+                }
+                if (ph < PH) {
+                    acc2[(ph * BN + c) * 2 + 0] = s1;
+                    acc2[(ph * BN + c) * 2 + 1] = s2;
+                }
+                __syncthreads();
+                if (ph == 0 && ncol < p.cout) {
+                    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) { s1 += acc2[(q * BN + c) * 2 + 0]; s2 += acc2[(q * BN + c) * 2 + 1]; }
+                    const double mean = s1 * p.fin_inv_count;
+                    double var = s2 * p.fin_inv_count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const double invstd = 1.0 / sqrt(var + (double)p.fin_eps);
+                    const double g = p.fin_gamma ? (double)p.fin_gamma[ncol] : 1.0;
+                    const double b = p.fin_beta ? (double)p.fin_beta[ncol] : 0.0;
+                    const double sc = g * invstd;
+                    p.fin_out[ncol] = (float)sc;
+                    p.fin_out[p.cout + ncol] = (float)(b - mean * sc);
+                    p.fin_out[2 * p.cout + ncol] = (float)mean;
+                    p.fin_out[3 * p.cout + ncol] = (float)invstd;
+                    if (p.fin_rmean) p.fin_rmean[ncol] = (1.f - p.fin_momentum) * p.fin_rmean[ncol] + p.fin_momentum * (float)mean;
+                    if (p.fin_rvar)  p.fin_rvar[ncol]  = (1.f - p.fin_momentum) * p.fin_rvar[ncol] + p.fin_momentum * (float)(var * p.fin_unbias);
+                }
+            }
+        }
+    }
+}
+
+// ---- conv launch ------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WGM, int WGN, int NS, bool HELPER>
+static int launch_cfg(const ConvKArgs& k, int ncls, hipStream_t s) {
+    const size_t lds = (size_t)NS * (BM + BN) * 128 + 256;    // + the prefetch wave's dummy LDS line
+    auto kern = conv_igemm_kernel<T, BM, BN, WGM, WGN, NS, HELPER>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(k.m_tiles * k.n_tiles * k.splitk), (unsigned)ncls);
+    hipLaunchKernelGGL(kern, grid, dim3((WGM * WGN + (HELPER ? 1 : 0)) * 64), lds, s, k);
+    return check_launch();
+}
+
+template <typename T>
+static inline int launch_typed(int cfg, const ConvKArgs& k, int ncls, hipStream_t s) {
+    switch (cfg) {
+        case 1: return launch_cfg<T, 128, 128, 2, 2, 3, false>(k, ncls, s);   //  96 KiB LDS
+        case 2: return k.pf_dist > 0 ? launch_cfg<T, 128, 64, 2, 2, 4, true>(k, ncls, s) : launch_cfg<T, 128, 64, 2, 2, 4, false>(k, ncls, s);    //  96 KiB
+        case 3: return k.pf_dist > 0 ? launch_cfg<T, 64, 64, 2, 2, 4, true>(k, ncls, s) : launch_cfg<T, 64, 64, 2, 2, 4, false>(k, ncls, s);     //  64 KiB (2 workgroups / CU)
+        case 4: return launch_cfg<T, 128, 32, 4, 1, 4, false>(k, ncls, s);    //  80 KiB (2 / CU)
+        case 5: return k.pf_dist > 0 ? launch_cfg<T, 64, 128, 2, 2, 4, true>(k, ncls, s) : launch_cfg<T, 64, 128, 2, 2, 4, false>(k, ncls, s);    //  96 KiB
+        case 6: return launch_cfg<T, 256, 64, 4, 1, 3, false>(k, ncls, s);    // 120 KiB
+        case 7: return k.pf_dist > 0 ? launch_cfg<T, 128, 64, 2, 2, 6, true>(k, ncls, s) : launch_cfg<T, 128, 64, 2, 2, 6, false>(k, ncls, s);    // 144 KiB
+        case 8: return launch_cfg<T, 128, 128, 2, 2, 4, false>(k, ncls, s);   // 128 KiB
+        case 9: return k.pf_dist > 0 ? launch_cfg<T, 64, 64, 2, 2, 3, true>(k, ncls, s) : launch_cfg<T, 64, 64, 2, 2, 3, false>(k, ncls, s);     //  48 KiB (3 workgroups / CU)
+        case 10: return launch_cfg<T, 64, 64, 2, 2, 2, false>(k, ncls, s);    //  32 KiB (5 / CU)
+        case 11: return k.pf_dist > 0 ? launch_cfg<T, 128, 64, 2, 2, 2, true>(k, ncls, s) : launch_cfg<T, 128, 64, 2, 2, 2, false>(k, ncls, s);   //  48 KiB (3 / CU)
+        case 12: return k.pf_dist > 0 ? launch_cfg<T, 64, 128, 2, 2, 3, true>(k, ncls, s) : launch_cfg<T, 64, 128, 2, 2, 3, false>(k, ncls, s);   //  72 KiB (2 / CU)
+        case 13: return k.pf_dist > 0 ? launch_cfg<T, 128, 64, 4, 2, 3, true>(k, ncls, s) : launch_cfg<T, 128, 64, 4, 2, 3, false>(k, ncls, s);   //  72 KiB, 8 waves (2 / CU)
+        case 14: return launch_cfg<T, 128, 128, 4, 2, 2, false>(k, ncls, s);  //  64 KiB, 8 waves (2 / CU)
+        case 15: return launch_cfg<T, 128, 128, 2, 4, 3, false>(k, ncls, s);  //  96 KiB, 8 waves
+        case 16: return launch_cfg<T, 256, 64, 4, 2, 2, false>(k, ncls, s);   //  80 KiB, 8 waves
+        case 17: return k.pf_dist > 0 ? launch_cfg<T, 64, 128, 2, 4, 3, true>(k, ncls, s) : launch_cfg<T, 64, 128, 2, 4, 3, false>(k, ncls, s);   //  72 KiB, 8 waves (2 / CU)
+        case 18: return launch_cfg<T, 256, 128, 4, 2, 3, false>(k, ncls, s);  // 144 KiB, 8 waves, wave tile 64x64
+        case 19: return launch_cfg<T, 256, 128, 2, 2, 3, false>(k, ncls, s);  // 144 KiB, 4 waves, wave tile 128x64
+        case 20: return launch_cfg<T, 128, 256, 2, 4, 3, false>(k, ncls, s);  // 144 KiB, 8 waves, wave tile 64x64
+        case 21: return launch_cfg<T, 128, 128, 2, 2, 2, false>(k, ncls, s);  //  64 KiB, 4 waves, wave tile 64x64 (2 / CU)
+        case 22: return launch_cfg<T, 256, 128, 4, 2, 2, false>(k, ncls, s);  //  96 KiB, 8 waves, wave tile 64x64
+        case 23: return launch_cfg<T, 128, 256, 2, 2, 3, false>(k, ncls, s);  // 144 KiB, 4 waves, wave tile 64x128
+    }
+    set_error("conv: unknown tile config %d", cfg);
+    return V2V_EINVAL;
+}
+
+
+static inline bool cfg_has_helper_impl(int cfg) {
+    switch (cfg) { case 2: case 3: case 5: case 7: case 9: case 11: case 12: case 13: case 17: return true; }
+    return false;
+}
+
+}  // namespace v2v

@@ -185,6 +185,23 @@ class Plan:
             pass
 
 
+# tile config id -> (BM, BN, has a prefetch-helper instance)   (csrc/conv_igemm_kernel.h launch_typed)
+TILE_CFGS = {1: (128, 128, False), 2: (128, 64, True), 3: (64, 64, True), 4: (128, 32, False), 5: (64, 128, True),
+             6: (256, 64, False), 7: (128, 64, True), 8: (128, 128, False), 9: (64, 64, True), 10: (64, 64, False),
+             11: (128, 64, True), 12: (64, 128, True), 13: (128, 64, True), 14: (128, 128, False),
+             15: (128, 128, False), 16: (256, 64, False), 17: (64, 128, True), 18: (256, 128, False),
+             19: (256, 128, False), 20: (128, 256, False), 21: (128, 128, False), 22: (256, 128, False),
+             23: (128, 256, False)}
+PREFETCH_DIST = 12          # K chunks (128 B of every weight row each) the helper wave runs ahead
+
+
+def _cfg3(v):
+    """tile_override / _tuned values: tile id, or (tile, splitk, prefetch)."""
+    if isinstance(v, (tuple, list)):
+        return int(v[0]), int(v[1]), int(v[2])
+    return int(v), 1, 0
+
+
 class Engine:
     """Emits v2v_* launches for one device / one activation dtype."""
 
@@ -203,6 +220,7 @@ class Engine:
         self._grids = {}
         self._zero_page = None
         self._fin_counter = None
+        self._sk_counter = None
         self._thrash = None
         self.plan = None        # Plan being recorded (for labels / keep-alive)
         self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
@@ -310,10 +328,10 @@ class Engine:
         d.OH, d.OW = OH, OW
         d.dtype, d.out_mode, d.act = self.dtype, out_mode, act
         d.act_param, d.out_scale = act_param, out_scale
-        d.tile = self.tile_override.get((pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed)), 0)
+        d.tile, d.splitk, d.prefetch = _cfg3(self.tile_override.get((pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed)), 0))
         tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
         if d.tile == 0 and tune_key in self._tuned:
-            d.tile = self._tuned[tune_key]
+            d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
         if pc.cin != x.C:
             raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
         if out_mode == L.OUT_RAW_F32_NHWC:
@@ -362,38 +380,79 @@ class Engine:
             self._keep(pc.bias)
         if (self.autotune and d.tile == 0 and self.plan is None and not self.record_only
                 and not torch.is_grad_enabled()):
-            d.tile = self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout)
+            self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout)
+            d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()
+        self._splitk_workspace(d)
         check(lib.v2v_conv2d(C.byref(d), _stream()), "conv2d " + label)
         self.label(label)
         ntaps = pc.KH * pc.KW
         self.conv_log.append(dict(label=label, N=N, H=H, W=W, OH=OH, OW=OW, cin=pc.cin, cout=pc.cout,
                                   KH=pc.KH, KW=pc.KW, stride=pc.stride, transposed=pc.transposed,
                                   flops=2.0 * N * (H * W if pc.transposed else OH * OW) * pc.cout * pc.cin * ntaps,
-                                  tile=lib.v2v_conv_tile_config(C.byref(d))))
+                                  tile=lib.v2v_conv_tile_config(C.byref(d)), splitk=max(int(d.splitk), 1),
+                                  prefetch=int(d.prefetch)))
         return out, rows, (N, OH, OW)
 
-    def _autotune(self, d, want_stats, cout, reps=3):
-        """Time every tile configuration that fits this launch and return the fastest id.  Runs once per conv
-        shape while a frame plan is being built, never inside a timed region.  Each timed launch is preceded by
-        a 384 MB memset: at batch 1 a frame streams ~0.7 GB of weights, so every layer meets its weights COLD in
-        L2 / Infinity Cache -- back-to-back warm launches favour shallow LDS-DMA rings that stall on real frames."""
-        cands = [1, 2, 3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17] + ([4] if cout <= 32 else [])
+    def _splitk_workspace(self, d):
+        """Attach the split-K slab scratch and ticket words to a descriptor (no-op for splitk <= 1)."""
+        if d.splitk <= 1:
+            d.splitk = 0
+            d.slabs = None
+            d.sk_counter = None
+            return True
+        tickets = C.c_int32(0)
+        nbytes = lib.v2v_conv_splitk_workspace(C.byref(d), C.byref(tickets))
+        if nbytes <= 0:
+            return False
+        if self._sk_counter is None or self._sk_counter.numel() < tickets.value:
+            if self.plan is not None and not self.record_only:
+                raise RuntimeError("split-K ticket buffer must not grow while a plan is recording")
+            self._sk_counter = torch.zeros(max(4096, tickets.value), dtype=torch.int32, device=self.device)
+        d.slabs = self.scratch("slabs", (nbytes + 3) // 4).data_ptr()
+        d.sk_counter = self._sk_counter.data_ptr()
+        self._keep(self._sk_counter)
+        return True
+
+    def _autotune(self, d, want_stats, cout, reps=5):
+        """Time every (tile, split-K, weight-prefetch) configuration that fits this launch; returns the fastest
+        triple.  Runs once per conv shape while a frame plan is being built, never inside a timed region.  Each
+        timed launch is preceded by a 384 MB memset: at batch 1 a frame streams ~0.8 GB of weights, so every layer
+        meets its weights COLD in L2 / Infinity Cache -- back-to-back warm launches favour shallow LDS-DMA rings
+        and no prefetch, which stall on real frames."""
+        M = d.N * (d.H * d.W if d.transposed else d.OH * d.OW)
+        ncls = 4 if (d.transposed and d.stride == 2) else 1
+        nk = (d.KH * d.KW * d.cin_stride * (2 if self.dtype == L.BF16 else 4)) // 128 // ncls
+        cands = []
+        for t, (bm, bn, helper) in sorted(TILE_CFGS.items()):
+            if t == 4 and cout > 32:
+                continue
+            tiles = -(-M // (bm * ncls)) * -(-cout // bn) * ncls
+            for S in (1, 2, 3, 4, 6, 8):
+                if S > 1 and (tiles * S > 1024 or nk // S < 4):
+                    continue
+                if S == 1 and t >= 18 and tiles < 96:
+                    continue            # large tiles that cannot fill the chip without split-K
+                cands.append((t, S, 0))
+                if helper:
+                    cands.append((t, S, PREFETCH_DIST))
         st = _stream()
         if self._thrash is None:
             self._thrash = torch.empty(96 << 20, dtype=torch.float32, device=self.device)
-        best, best_ms = 0, float("inf")
+        best, best_ms = (0, 1, 0), float("inf")
         e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
         e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-        for t in cands:
-            d.tile = t
+        for t, S, pf in cands:
+            d.tile, d.splitk, d.prefetch = t, S, pf
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 if rows <= 0:
                     continue
                 d.stats = self.scratch("stats", rows * cout * 2).data_ptr()
+            if not self._splitk_workspace(d):
+                continue
             if lib.v2v_conv2d(C.byref(d), st) != 0:
                 continue
             for r in range(reps):
@@ -404,7 +463,7 @@ class Engine:
             e1[-1].synchronize()
             ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))[reps // 2]      # median
             if ms < best_ms:
-                best, best_ms = t, ms
+                best, best_ms = (t, S, pf), ms
         return best
 
     def _norm_params(self, norm, N):

@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("fin_counter", C.c_void_p), ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p),
         ("fin_scale_shift", C.c_void_p), ("fin_running_mean", C.c_void_p), ("fin_running_var", C.c_void_p),
         ("fin_eps", C.c_float), ("fin_momentum", C.c_float), ("fin_count", C.c_int64),
+        ("splitk", C.c_int32), ("prefetch", C.c_int32), ("slabs", C.c_void_p), ("sk_counter", C.c_void_p),
     ]
 
 
@@ -59,6 +60,7 @@ PROTOTYPES = {
     "v2v_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_conv_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_tile_config": (C.c_int, [C.POINTER(ConvDesc)]),
+    "v2v_conv_splitk_workspace": (_L, [C.POINTER(ConvDesc), C.POINTER(_I)]),
     "v2v_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "v2v_conv_wgrad_workspace": (_L, [C.POINTER(WgradDesc)]),
     "v2v_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P]),
