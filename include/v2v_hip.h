@@ -96,6 +96,7 @@ typedef struct v2v_conv_desc {
     int32_t prefetch;       /* 0 = off; P > 0: weight-prefetch helper wave, P K-chunks ahead (see below) */
     void*   slabs;          /* splitk > 1: v2v_conv_splitk_workspace() bytes of scratch              */
     int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
+    int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA) */
 } v2v_conv_desc;
 
 /* splitk = S > 1: the S workgroups of a tile each reduce 1/S of the K chunks and publish an fp32 partial tile; the

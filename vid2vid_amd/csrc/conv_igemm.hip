@@ -44,6 +44,7 @@
 #include "conv_igemm_kernel.h"
 #include <cstdarg>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 
 namespace v2v {
@@ -82,10 +83,24 @@ static void convt_axis(int K, int pad, int stride, int par, int* k0, int* nk, in
 struct ConvGeom {
     int ncls;
     int nkh[4], nkw[4], kh0[4], kw0[4], dh0[4], dw0[4], ktot[4], kpad[4];
+    int wrow[4];         // row stride of the class matrix, elements (>= kpad)
     long long woff[4];
     long long total;
     int cout_p;
 };
+
+// Row stride of a packed weight matrix.  Rows whose byte length is an even number of 128-byte lines put the same
+// K chunk of every row of a tile at the same line index modulo a power of two: every workgroup of an XCD then
+// requests a chunk's 64-256 weight lines from the same few L2 channels at the same time.  One extra (zero) line
+// makes the line stride odd, which spreads consecutive rows over all channels.  Measured (profiles/r01_v4_ablate_*):
+// no effect on gfx950 (the L2 channel hash already spreads 2 KiB / 18 KiB strides), so it is OFF unless V2V_WPAD=1.
+static int weight_row_stride(int kpad, int dtype) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V2V_WPAD"); on = (e && e[0] == '1') ? 1 : 0; }
+    const int bke = dtype == V2V_BF16 ? 64 : 32;
+    const int lines = kpad / bke;
+    return (on && lines > 1 && (lines & 1) == 0) ? kpad + bke : kpad;
+}
 
 static int conv_geom(int cin_stride, int cout, int KH, int KW, int transposed, int stride, int pad, int dtype, ConvGeom* g) {
     const int bke = bke_of(dtype);
@@ -98,8 +113,9 @@ static int conv_geom(int cin_stride, int cout, int KH, int KW, int transposed, i
         g->dh0[0] = -pad; g->dw0[0] = -pad;
         g->ktot[0] = KH * KW * cin_stride;
         g->kpad[0] = (int)round_up(g->ktot[0], bke);
+        g->wrow[0] = weight_row_stride(g->kpad[0], dtype);
         g->woff[0] = 0;
-        off = (long long)g->cout_p * g->kpad[0];
+        off = (long long)g->cout_p * g->wrow[0];
     } else {
         g->ncls = stride == 1 ? 1 : 4;
         for (int c = 0; c < g->ncls; ++c) {
@@ -108,8 +124,9 @@ static int conv_geom(int cin_stride, int cout, int KH, int KW, int transposed, i
             convt_axis(KW, pad, stride, b, &g->kw0[c], &g->nkw[c], &g->dw0[c]);
             g->ktot[c] = g->nkh[c] * g->nkw[c] * cin_stride;
             g->kpad[c] = (int)round_up(g->ktot[c] > 0 ? g->ktot[c] : 1, bke);
+            g->wrow[c] = weight_row_stride(g->kpad[c], dtype);
             g->woff[c] = off;
-            off += (long long)g->cout_p * g->kpad[c];
+            off += (long long)g->cout_p * g->wrow[c];
         }
     }
     g->total = off;
@@ -121,7 +138,7 @@ struct PackArgs {
     const float* w; void* dst;
     int cin, cin_stride, cout, cout_p, KH, KW, transposed, kstep;
     int ncls;
-    int nkh[4], nkw[4], kh0[4], kw0[4], kpad[4];
+    int nkh[4], nkw[4], kh0[4], kw0[4], kpad[4], wrow[4];
     long long woff[4];
     long long total;
     int dtype;
@@ -135,9 +152,9 @@ __global__ void pack_weights_kernel(const PackArgs a) {
         for (int c = 1; c < 4; ++c)
             if (c < a.ncls && e >= a.woff[c]) cls = c;
         const long long le = e - a.woff[cls];
-        const int kp = a.kpad[cls];
+        const int kp = a.wrow[cls];
         const int co = (int)(le / kp);
-        const int k = (int)(le - (long long)co * kp);
+        const int k = (int)(le - (long long)co * kp);      // k >= kpad: the stride-padding line, zero
         const int t = k / a.cin_stride;
         const int c = k - t * a.cin_stride;
         float v = 0.f;
@@ -245,7 +262,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     const long long Mc = k.Mc[0];   // class 0 is the largest
     for (int c = 0; c < 4; ++c) {
         k.nkh[c] = g.nkh[c]; k.nkw[c] = g.nkw[c]; k.dh0[c] = g.dh0[c]; k.dw0[c] = g.dw0[c];
-        k.ktot[c] = g.ktot[c]; k.kpad[c] = g.kpad[c]; k.woff[c] = g.woff[c];
+        k.ktot[c] = g.ktot[c]; k.kpad[c] = g.kpad[c]; k.wrow[c] = g.wrow[c]; k.woff[c] = g.woff[c];
     }
     k.out_mode = d->out_mode; k.act = d->act; k.act_param = d->act_param; k.out_scale = d->out_scale;
     if (d->fin_counter) {
@@ -269,7 +286,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     k.splitk = d->splitk > 1 ? d->splitk : 1;
     int nk_min = k.kpad[0] / bke_of(d->dtype);
     for (int cc = 1; cc < g.ncls; ++cc) nk_min = std::min(nk_min, k.kpad[cc] / bke_of(d->dtype));
-    if (k.splitk > 16 || nk_min / k.splitk < 2) {
+    if (k.splitk > 1 && (k.splitk > 16 || nk_min / k.splitk < 2)) {
         set_error("conv: splitk %d needs >= 2 K chunks per slice (layer has %d)", k.splitk, nk_min); return V2V_EINVAL;
     }
     op->sk_tickets = g.ncls * k.m_tiles * k.n_tiles;
@@ -278,6 +295,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         if (launching && (!d->slabs || !d->sk_counter)) { set_error("conv: splitk needs slabs and sk_counter"); return V2V_EINVAL; }
         k.slabs = (float*)d->slabs; k.sk_counter = d->sk_counter;
     }
+    k.ablate = d->ablate;
     k.pf_dist = (d->prefetch > 0 && conv_cfg_has_helper(op->cfg)) ? d->prefetch : 0;
     k.pf_mask = (k.pf_dist > 0 && k.m_tiles >= 8) ? 3 : 0;      // 1 prefetching workgroup per 4 M tiles of an N column
     return 0;
@@ -307,7 +325,7 @@ extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int
     a.KH = KH; a.KW = KW; a.transposed = transposed; a.kstep = stride; a.ncls = g.ncls; a.total = g.total; a.dtype = dtype;
     for (int c = 0; c < 4; ++c) {
         a.nkh[c] = g.nkh[c]; a.nkw[c] = g.nkw[c]; a.kh0[c] = g.kh0[c]; a.kw0[c] = g.kw0[c];
-        a.kpad[c] = g.kpad[c]; a.woff[c] = g.woff[c];
+        a.kpad[c] = g.kpad[c]; a.wrow[c] = g.wrow[c]; a.woff[c] = g.woff[c];
     }
     return submit(std::move(op), stream);
 }

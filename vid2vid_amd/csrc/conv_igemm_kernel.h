@@ -26,7 +26,7 @@ struct ConvKArgs {
     int nkh[4], nkw[4];
     int dh0[4], dw0[4];  // first tap's input offset
     int dstep;           // +1 conv, -1 convT
-    int ktot[4], kpad[4];
+    int ktot[4], kpad[4], wrow[4];   // K extent (padded to the chunk) and row stride of the packed class matrix
     long long woff[4];   // element offset of the class matrix inside w
     // in-kernel norm finalize (last-arriving workgroup of an N tile), optional
     int* fin_counter; const float* fin_gamma; const float* fin_beta; float* fin_out;
@@ -38,6 +38,7 @@ struct ConvKArgs {
     // weight-stream prefetch: an extra (helper) wave touches the weight lines `pf_dist` K chunks ahead so that the
     // LDS-DMA of the real loaders hits L2 instead of waiting for HBM; workgroups with (mt & pf_mask) != 0 skip it
     int pf_dist, pf_mask;
+    int ablate;          // profiling ablations (v2v_conv_desc.ablate); results are WRONG when non-zero
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int ntot) {
@@ -154,7 +155,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
     for (int i = 0; i < RB; ++i) {
         long long r = (long long)nt * BN + lrow + LR * i;
         r = r < p.cout_p ? r : p.cout_p - 1;         // BN = 256 tiles can overhang the packed rows (cout_p = 128-multiple)
-        wp[i] = p.w + ((long long)p.woff[cls] + r * kpad + koff) * (long long)sizeof(T) + (long long)kb * 128;
+        wp[i] = p.w + ((long long)p.woff[cls] + r * p.wrow[cls] + koff) * (long long)sizeof(T) + (long long)kb * 128;
     }
 
     // resolves one tap for one row: source pointer of this lane's slot (channel 0 of the chunk)
@@ -212,7 +213,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
         if (fastk) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
-                const char* src = ((aok >> i) & 1u) ? ap[i] + kcb : zp;
+                const char* src = (((aok >> i) & 1u) && !(p.ablate & 1)) ? ap[i] + kcb : zp;
                 glds16(src, sbase + i * LR * 128);
             }
         } else {
@@ -222,13 +223,13 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
             for (int i = 0; i < RA; ++i) {
                 bool ok = kvalid && ((rowvalid >> i) & 1u);
                 const char* src = tap_ptr(i, dh, dw, ok) + kc * (int)sizeof(T);
-                src = ok ? src : zp;
+                src = (ok && !(p.ablate & 1)) ? src : zp;
                 glds16(src, sbase + i * LR * 128);
             }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            glds16(wp[i] + (long long)issued * 128, sbase + BM * 128 + i * LR * 128);
+            glds16(wp[i] + ((p.ablate & 2) ? 0ll : (long long)issued * 128), sbase + BM * 128 + i * LR * 128);
         // advance the K walk by one chunk
         if (fastk) {
             kcb += 128;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
         for (int i = 0; i < PR; ++i) {
             long long r = (long long)nt * BN + lane + 64 * i;
             r = r < p.cout_p ? r : p.cout_p - 1;
-            prow[i] = p.w + ((long long)p.woff[cls] + r * kpad) * (long long)sizeof(T) + (long long)kb * 128;
+            prow[i] = p.w + ((long long)p.woff[cls] + r * p.wrow[cls]) * (long long)sizeof(T) + (long long)kb * 128;
         }
         const int P = p.pf_dist;
         if (pf_on)
@@ -308,6 +309,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
                                               // is done reading stage (ks-1)%NS, which is refilled now
             if (ks + D < nk) issue();
             const char* sb = smem + (ks % NS) * STAGE;
+            if (p.ablate & 16) continue;      // loader-only ablation
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 Frag fa[TM], fb[TN];
@@ -420,7 +422,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int m = mt * BM + row;
-                if (m < mcls_e && nvalid) {
+                if (m < mcls_e && nvalid && !(p.ablate & 4)) {
                     float v = acc[i][j][r] + bv;
                     long long opix;   // output pixel index in [N][OH][OW]
                     if (p.os == 1) {

@@ -229,6 +229,7 @@ class Engine:
         self._tuned = {}         # (cin,cout,KH,stride,transposed,N,H,W,out_mode) -> tile id
         self.update_running_stats = False
         self.fused_finalize = True   # norm statistics finalized by the conv kernel's last workgroup
+        self.ablate = 0              # profiling ablations (scripts/conv_ablate.py); results are wrong when set
 
     # ---------------- buffers ----------------
     def empty_act(self, N, H, W, C):
@@ -328,6 +329,7 @@ class Engine:
         d.OH, d.OW = OH, OW
         d.dtype, d.out_mode, d.act = self.dtype, out_mode, act
         d.act_param, d.out_scale = act_param, out_scale
+        d.ablate = self.ablate
         d.tile, d.splitk, d.prefetch = _cfg3(self.tile_override.get((pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed)), 0))
         tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
         if d.tile == 0 and tune_key in self._tuned:

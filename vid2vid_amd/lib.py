@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("fin_scale_shift", C.c_void_p), ("fin_running_mean", C.c_void_p), ("fin_running_var", C.c_void_p),
         ("fin_eps", C.c_float), ("fin_momentum", C.c_float), ("fin_count", C.c_int64),
         ("splitk", C.c_int32), ("prefetch", C.c_int32), ("slabs", C.c_void_p), ("sk_counter", C.c_void_p),
+        ("ablate", C.c_int32),
     ]
 
 
