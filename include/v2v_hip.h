@@ -96,6 +96,7 @@ typedef struct v2v_conv_desc {
     int32_t prefetch;       /* 0 = off; P > 0: weight-prefetch helper wave, P K-chunks ahead (see below) */
     void*   slabs;          /* splitk > 1: v2v_conv_splitk_workspace() bytes of scratch              */
     int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
+    int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major */
     int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA) */
 } v2v_conv_desc;
 
@@ -121,7 +122,12 @@ int64_t v2v_conv_packed_elems(int32_t cin, int32_t cin_stride, int32_t cout, int
                               int32_t transposed, int32_t stride, int32_t pad, int32_t dtype);
 int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t cin_stride, int32_t cout,
                               int32_t KH, int32_t KW, int32_t transposed, int32_t stride, int32_t pad,
-                              int32_t dtype, void* stream);
+                              int32_t dtype, int32_t korder, void* stream);
+/* korder 0 (tap-major, above) is what the implicit-GEMM tile configurations (ids 1..23) read.  korder 1 is
+ * k = (chunk * KH*KW + tap) * E + c_in_chunk with E = elements per 128 bytes and channel c = chunk*E + c_in_chunk
+ * (channel-chunk outer, tap inner; Conv2d with cin_stride % E == 0 only; same element count): the layout of the
+ * LDS-resident-patch 3x3 kernel (tile ids 32..37, csrc/conv3x3_patch_kernel.h), which fetches the input patch of
+ * a channel chunk once and walks the 9 taps over it. */
 
 /* Number of statistics rows (n_classes * m_tiles) the launch described by `d` writes. */
 int     v2v_conv_stats_rows(const v2v_conv_desc* d);

@@ -202,6 +202,59 @@ def test_prefetch_is_bitwise_neutral():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33, 3), (34, 2), (36, 2),
+              (40, 1), (41, 1), (42, 1), (43, 1), (44, 1), (45, 1), (46, 1), (47, 1), (48, 1), (40, 2), (41, 3), (46, 2), (48, 2),
+              (50, 1), (51, 1), (52, 1), (53, 1), (54, 1), (55, 1), (50, 2), (51, 3), (53, 2), (52, 4)]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(128, 72, 24, 64, "reflect", 1), (192, 200, 19, 45, "reflect", 2), (128, 96, 33, 70, "zero", 1),
+                                  (64, 40, 9, 32, "reflect", 1), (256, 64, 4, 128, "zero", 2)])
+def test_conv3x3_patch_kernel(case, prec):
+    """LDS-resident-patch 3x3 kernel (tile ids 32..37, channel-chunk-major weights): every tile configuration, with
+    and without split-K, on aligned and ragged images, reflection and zero padding, batch > 1; output, per-tile
+    statistics and the in-kernel norm finalize against torch; inputs change every launch."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, mode, N = case
+    torch.manual_seed(cin + H)
+    eng = _engine(prec)
+    conv = nn.Conv2d(cin, cout, 3, padding=0 if mode == "reflect" else 1)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    xs = [torch.randn(N, cin, H, W) * (1.0 + i) for i in range(2)]
+    def ref_of(x):
+        xr = _round(x, prec)
+        if mode == "reflect":
+            xr = F.pad(xr, (1,) * 4, mode="reflect")
+        return F.conv2d(xr, _round(conv.weight.detach(), prec), conv.bias.detach(), padding=0 if mode == "reflect" else 1)
+    refs = [ref_of(x) for x in xs]
+    conv = conv.to(DEV)
+    xa = [eng.pack(x.to(DEV)) for x in xs]
+    pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
+    ncc = xa[0].Cs // (64 if prec == "bf16" else 32)
+    for it, (tile, S) in enumerate(PATCH_CFGS):
+        if S > ncc:
+            continue
+        k = it % 2
+        eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, S, 12 if (tile <= 37 and it % 3 == 0) else 0)
+        ss = torch.full((4 * cout,), float("nan"), device=DEV)
+        raw, rows, (n_, OH, OW) = eng.conv(xa[k], conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+        log = eng.conv_log[-1]
+        assert (log["tile"], log["splitk"]) == (tile, S), (tile, S, log)
+        got = raw[:n_ * OH * OW * cout].view(n_, OH, OW, cout).permute(0, 3, 1, 2).clone()
+        assert_close(got.cpu(), refs[k], 1e-4, "patch cfg %d S=%d" % (tile, S))
+        st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+        assert_close(st[:, 0], refs[k].sum((0, 2, 3)), 1e-3, "stats cfg %d" % tile)
+        assert_close(ss[2 * cout:3 * cout].cpu(), refs[k].mean((0, 2, 3)), 1e-3, "finalized mean cfg %d" % tile)
+        raw2, _, _ = eng.conv(xa[k], conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
+        assert torch.equal(got, raw2[:n_ * OH * OW * cout].view(n_, OH, OW, cout).permute(0, 3, 1, 2)), "not reproducible"
+    # activation epilogue through the same kernel
+    eng.tile_override[(cin, cout, 3, 1, 0)] = (32, 1, 0)
+    out, _, _ = eng.conv(xa[0], conv, pm, po, L.OUT_ACT_NHWC, L.ACT_LEAKY, 0.2)
+    assert_close(eng.unpack(out).cpu(), F.leaky_relu(refs[0], 0.2), 1e-4 if prec == "fp32" else 1e-2, "act")
+    if eng._sk_counter is not None:
+        assert int(eng._sk_counter.abs().sum().item()) == 0
+
+
 CONVT_CASES = [(16, 8, 3, 1, 1, 9, 13), (64, 32, 3, 1, 1, 16, 32), (24, 16, 4, 1, 0, 11, 7), (128, 64, 3, 1, 1, 32, 64)]
 
 

@@ -41,7 +41,7 @@
 //     enough to be LDS-read efficient (wave tile >= 64x64); `splitk` workgroups share a tile,
 //     publish fp32 partial tiles write-through (sc1) and the last arriver reduces them in slice
 //     order (deterministic) and runs the normal epilogue.
-#include "conv_igemm_kernel.h"
+#include "conv3x3_pp_kernel.h"
 #include <cstdarg>
 #include <cstring>
 #include <cstdlib>
@@ -142,6 +142,7 @@ struct PackArgs {
     long long woff[4];
     long long total;
     int dtype;
+    int korder, bke;     // korder 1: k = (chunk*ntaps + tap)*bke + c_in_chunk  (channel-chunk outer, tap inner)
 };
 
 __global__ void pack_weights_kernel(const PackArgs a) {
@@ -155,10 +156,18 @@ __global__ void pack_weights_kernel(const PackArgs a) {
         const int kp = a.wrow[cls];
         const int co = (int)(le / kp);
         const int k = (int)(le - (long long)co * kp);      // k >= kpad: the stride-padding line, zero
-        const int t = k / a.cin_stride;
-        const int c = k - t * a.cin_stride;
-        float v = 0.f;
         const int ntaps = a.nkh[cls] * a.nkw[cls];
+        int t, c;
+        if (a.korder == 1) {
+            const int chunk = k / (ntaps * a.bke), rem = k - chunk * ntaps * a.bke;
+            t = rem / a.bke;
+            c = chunk * a.bke + (rem - t * a.bke);
+            if (k >= a.kpad[cls]) t = ntaps;             // stride-padding line
+        } else {
+            t = k / a.cin_stride;
+            c = k - t * a.cin_stride;
+        }
+        float v = 0.f;
         if (co < a.cout && t < ntaps && c < a.cin) {
             const int th = t / a.nkw[cls], tw = t - th * a.nkw[cls];
             int kh, kw;
@@ -191,6 +200,10 @@ struct PackOp : Op {
 int launch_conv_bf16(int cfg, const ConvKArgs& k, int ncls, hipStream_t s);
 int launch_conv_f32(int cfg, const ConvKArgs& k, int ncls, hipStream_t s);
 bool conv_cfg_has_helper(int cfg);
+int launch_patch_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
+int launch_patch_f32(int cfg, const ConvKArgs& k, hipStream_t s);
+int launch_pp_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
+int launch_pp_f32(int cfg, const ConvKArgs& k, hipStream_t s);
 
 static int choose_cfg(long long Mc, int cout, int ncls) {
     if (cout <= 32) return 4;
@@ -209,6 +222,8 @@ struct ConvOp : Op {
     int ncls, cfg, dtype;
     long long slab_bytes; int sk_tickets;
     int launch(hipStream_t s) override {
+        if (cfg >= 50) return dtype == V2V_BF16 ? launch_pp_bf16(cfg, k, s) : launch_pp_f32(cfg, k, s);
+        if (cfg >= 32) return dtype == V2V_BF16 ? launch_patch_bf16(cfg, k, s) : launch_patch_f32(cfg, k, s);
         return dtype == V2V_BF16 ? launch_conv_bf16(cfg, k, ncls, s) : launch_conv_f32(cfg, k, ncls, s);
     }
     const char* name() const override { return "conv_igemm"; }
@@ -278,25 +293,47 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     op->ncls = g.ncls;
     op->dtype = d->dtype;
     op->cfg = d->tile ? d->tile : choose_cfg(Mc, d->cout, g.ncls);
-    const TileCfg* c = find_cfg(op->cfg);
-    if (!c) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
-    k.m_tiles = (int)ceil_div(Mc, c->BM);
-    k.n_tiles = (int)ceil_div(d->cout, c->BN);
+    int tile_bm, tile_bn;
+    if (op->cfg >= 32) {
+        // conv3x3_patch_kernel: 3x3 / stride 1 / pad 1 Conv2d, channel stride a multiple of the 128-byte chunk,
+        // weights packed channel-chunk outer (korder 1)
+        const PatchCfg* pc = op->cfg >= 50 ? find_pp_cfg(op->cfg) : find_patch_cfg(op->cfg);
+        if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
+        if (d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 ||
+            d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 1 ||
+            (long long)d->N * d->H * d->W * d->cin_stride * (d->dtype == V2V_BF16 ? 2 : 4) >= (1ll << 32)) {
+            set_error("conv: patch tile config %d needs a 3x3/s1/p1 Conv2d, cin_stride %% %d == 0 and korder-1 weights",
+                      op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
+        }
+        k.tiles_h = (int)ceil_div(d->OH, pc->TH);
+        k.tiles_w = (int)ceil_div(d->OW, pc->TW);
+        k.m_tiles = d->N * k.tiles_h * k.tiles_w;
+        k.n_tiles = (int)ceil_div(d->cout, pc->BN);
+        tile_bm = pc->TH * pc->TW; tile_bn = pc->BN;
+    } else {
+        if (d->w_korder != 0) { set_error("conv: tile config %d reads tap-major (korder 0) weights", op->cfg); return V2V_EINVAL; }
+        const TileCfg* c = find_cfg(op->cfg);
+        if (!c) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
+        k.m_tiles = (int)ceil_div(Mc, c->BM);
+        k.n_tiles = (int)ceil_div(d->cout, c->BN);
+        tile_bm = c->BM; tile_bn = c->BN;
+    }
     // ---- split-K / weight prefetch ----
     k.splitk = d->splitk > 1 ? d->splitk : 1;
     int nk_min = k.kpad[0] / bke_of(d->dtype);
     for (int cc = 1; cc < g.ncls; ++cc) nk_min = std::min(nk_min, k.kpad[cc] / bke_of(d->dtype));
+    if (op->cfg >= 32) nk_min = 2 * (d->cin_stride / bke_of(d->dtype));     // slices are whole channel chunks (>= 1 each)
     if (k.splitk > 1 && (k.splitk > 16 || nk_min / k.splitk < 2)) {
         set_error("conv: splitk %d needs >= 2 K chunks per slice (layer has %d)", k.splitk, nk_min); return V2V_EINVAL;
     }
     op->sk_tickets = g.ncls * k.m_tiles * k.n_tiles;
-    op->slab_bytes = k.splitk > 1 ? (long long)op->sk_tickets * k.splitk * c->BM * c->BN * 4 : 0;
+    op->slab_bytes = k.splitk > 1 ? (long long)op->sk_tickets * k.splitk * tile_bm * tile_bn * 4 : 0;
     if (k.splitk > 1) {
         if (launching && (!d->slabs || !d->sk_counter)) { set_error("conv: splitk needs slabs and sk_counter"); return V2V_EINVAL; }
         k.slabs = (float*)d->slabs; k.sk_counter = d->sk_counter;
     }
     k.ablate = d->ablate;
-    k.pf_dist = (d->prefetch > 0 && conv_cfg_has_helper(op->cfg)) ? d->prefetch : 0;
+    k.pf_dist = (d->prefetch > 0 && (conv_cfg_has_helper(op->cfg) || (op->cfg >= 32 && op->cfg <= 37))) ? d->prefetch : 0;
     k.pf_mask = (k.pf_dist > 0 && k.m_tiles >= 8) ? 3 : 0;      // 1 prefetching workgroup per 4 M tiles of an N column
     return 0;
 }
@@ -315,14 +352,18 @@ extern "C" int64_t v2v_conv_packed_elems(int32_t cin, int32_t cin_stride, int32_
 
 extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t cin_stride, int32_t cout,
                                      int32_t KH, int32_t KW, int32_t transposed, int32_t stride, int32_t pad,
-                                     int32_t dtype, void* stream) {
+                                     int32_t dtype, int32_t korder, void* stream) {
     if (!w || !dst) { set_error("pack: null pointer"); return V2V_EINVAL; }
+    if (korder != 0 && (korder != 1 || transposed || cin_stride % bke_of(dtype) != 0)) {
+        set_error("pack: korder 1 needs a Conv2d whose channel stride is a multiple of the 128-byte chunk"); return V2V_EINVAL;
+    }
     ConvGeom g;
     conv_geom(cin_stride, cout, KH, KW, transposed, stride, pad, dtype, &g);
     auto op = std::make_unique<PackOp>();
     PackArgs& a = op->a;
     a.w = w; a.dst = dst; a.cin = cin; a.cin_stride = cin_stride; a.cout = cout; a.cout_p = g.cout_p;
     a.KH = KH; a.KW = KW; a.transposed = transposed; a.kstep = stride; a.ncls = g.ncls; a.total = g.total; a.dtype = dtype;
+    a.korder = korder; a.bke = bke_of(dtype);
     for (int c = 0; c < 4; ++c) {
         a.nkh[c] = g.nkh[c]; a.nkw[c] = g.nkw[c]; a.kh0[c] = g.kh0[c]; a.kw0[c] = g.kw0[c];
         a.kpad[c] = g.kpad[c]; a.wrow[c] = g.wrow[c]; a.woff[c] = g.woff[c];

@@ -1,5 +1,7 @@
 // exact-fp32 instantiations of the implicit-GEMM conv template (v_mfma_f32_32x32x2_f32 path: the parity gate).
-#include "conv_igemm_kernel.h"
+#include "conv3x3_pp_kernel.h"
 namespace v2v {
 int launch_conv_f32(int cfg, const ConvKArgs& k, int ncls, hipStream_t s) { return launch_typed<float>(cfg, k, ncls, s); }
+int launch_patch_f32(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_patch_typed<float>(cfg, k, s); }
+int launch_pp_f32(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_pp_typed<float>(cfg, k, s); }
 }

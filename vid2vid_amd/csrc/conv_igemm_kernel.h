@@ -38,6 +38,7 @@ struct ConvKArgs {
     // weight-stream prefetch: an extra (helper) wave touches the weight lines `pf_dist` K chunks ahead so that the
     // LDS-DMA of the real loaders hits L2 instead of waiting for HBM; workgroups with (mt & pf_mask) != 0 skip it
     int pf_dist, pf_mask;
+    int tiles_h, tiles_w; // conv3x3_patch_kernel: output tiles per image (m_tiles = N * tiles_h * tiles_w)
     int ablate;          // profiling ablations (v2v_conv_desc.ablate); results are WRONG when non-zero
 };
 
@@ -75,6 +76,226 @@ template <> struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
     }
 };
+
+// Shared tail of the conv kernels: split-K hand-off, bias / activation / store, per-tile statistics and the in-kernel
+// norm finalize.  `pix_of(row)` maps a tile row (0..BM-1) to the output pixel index in [N][OH][OW], or < 0 when the
+// row lies outside the layer.  Every wave of the workgroup (the prefetch helper included) must call it: it contains
+// workgroup barriers.
+template <typename T, int BM, int BN, int WGM, int WGN, typename PixOf>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], char* smem,
+                                              const int tid, const int wm, const int wn, const bool helper,
+                                              const int cls, const int tiles, const int lin, const int slice, const int S,
+                                              const int nt, const int stat_row, PixOf pix_of) {
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NW = WGM * WGN;
+    const int lane = tid & 63;
+    const int lr = lane & 31, hi = lane >> 5;
+    // ---------------- split-K hand-off ----------------
+    // (cdna guide 5 "in-launch split-K reduction", write-through form): every slice stores its fp32 partial
+    // tile with 16-byte sc1 stores, every storing wave drains them, workgroup barrier, ONE relaxed agent-scope
+    // ticket.  The slice that draws S-1 re-arms the ticket, reads all S slabs back with sc1 loads and sums them
+    // in SLICE order, so the result does not depend on which slice happened to be last.  No spin anywhere:
+    // nothing can hang.
+    if (S > 1) {
+        constexpr int NT = NW * 64;
+        constexpr unsigned SLAB = (unsigned)BM * BN * 4u;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const long long tile_id = (long long)cls * tiles + lin;
+        char* const sbase = reinterpret_cast<char*>(p.slabs) + tile_id * (long long)S * SLAB;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(S * SLAB), 0x00020000);
+        if (!helper) {
+            const unsigned my = (unsigned)slice * SLAB + (unsigned)tid * 16u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        u32x4 v;
+                        v[0] = __float_as_uint(acc[i][j][4 * q + 0]); v[1] = __float_as_uint(acc[i][j][4 * q + 1]);
+                        v[2] = __float_as_uint(acc[i][j][4 * q + 2]); v[3] = __float_as_uint(acc[i][j][4 * q + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, my + (unsigned)(((i * TN + j) * 4 + q) * NT * 16), 0, 16);
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem + 16384);
+        if (tid == 0) {
+            int* cnt = p.sk_counter + tile_id;
+            const int tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = tk == S - 1 ? 1 : 0;
+            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        if (!helper) {
+            // every slab, the reducer's own included, is read back in slice order 0..S-1: the sum is the same
+            // whichever slice arrives last, and no second accumulator set is live
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int sl = 0; sl < S; ++sl) {
+                const unsigned off = (unsigned)sl * SLAB + (unsigned)tid * 16u;
+                u32x4 v[TM][TN][4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            v[i][j][q] = __builtin_amdgcn_raw_buffer_load_b128(
+                                rsrc, off + (unsigned)(((i * TN + j) * 4 + q) * NT * 16), 0, 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[i][j][4 * q + 0] += __uint_as_float(v[i][j][q][0]); acc[i][j][4 * q + 1] += __uint_as_float(v[i][j][q][1]);
+                            acc[i][j][4 * q + 2] += __uint_as_float(v[i][j][q][2]); acc[i][j][4 * q + 3] += __uint_as_float(v[i][j][q][3]);
+                        }
+            }
+        }
+        __syncthreads();                  // the flag word is reused by the norm-finalize hand-off below
+    }
+
+    // ---------------- epilogue ----------------
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2]
+    const bool want_stats = p.stats != nullptr;
+    const long long ohow = (long long)p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ncol = nt * BN + wn * WN + j * 32 + lr;
+        const bool nvalid = ncol < p.cout && !helper;
+        const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const long long opix = pix_of(row);      // output pixel index in [N][OH][OW], < 0: outside
+                if (opix >= 0 && nvalid && !(p.ablate & 4)) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
+                        s1 += v;
+                        s2 += v * v;
+                        reinterpret_cast<float*>(p.out)[opix * p.cout_stride + ncol] = v;
+                    } else {
+                        v = apply_act(v, p.act, p.act_param) * p.out_scale;
+                        if (p.out_mode == V2V_OUT_ACT_NHWC) {
+                            store_act(reinterpret_cast<T*>(p.out), opix * p.cout_stride + ncol, v);
+                        } else {
+                            const long long n = opix / ohow;
+                            const long long pix = opix - n * ohow;
+                            reinterpret_cast<float*>(p.out)[(n * p.cout + ncol) * ohow + pix] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hi == 0 && !helper) {
+                const int c = wn * WN + j * 32 + lr;
+                red[(wm * BN + c) * 2 + 0] = s1;
+                red[(wm * BN + c) * 2 + 1] = s2;
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int ncol = nt * BN + tid;
+            if (ncol < p.cout) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < WGM; ++q) {
+                    s1 += red[(q * BN + tid) * 2 + 0];
+                    s2 += red[(q * BN + tid) * 2 + 1];
+                }
+                float* dst = p.stats + ((long long)stat_row * p.cout + ncol) * 2;
+                if (p.fin_counter != nullptr) {
+                    // 8-byte agent-scope (write-through, sc1) store: the (sum, sum^2) granule is what the last
+                    // workgroup reads back with agent-scope loads -- no L2 write-back fence is needed
+                    const unsigned long long bits = (unsigned long long)__float_as_uint(s1) |
+                                                    ((unsigned long long)__float_as_uint(s2) << 32);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    dst[0] = s1;
+                    dst[1] = s2;
+                }
+            }
+        }
+        if (p.fin_counter != nullptr) {
+            // ---- training-mode norm finalize by the LAST workgroup to finish this N tile ----
+            // (get_norm_layer, models/networks.py:23-30: batch statistics -> scale/shift; replaces a separate
+            // bn_finalize launch per layer).  Hand-off (cdna guide G16, "sc1 payload -> vmcnt(0) -> flag" form):
+            // the partial rows are 8-byte write-through agent-scope stores, every wave drains them, workgroup
+            // barrier, then ONE relaxed agent-scope ticket; the last arriver reads all rows back with agent-scope
+            // 8-byte loads in a fixed order (deterministic, independent of which workgroup happens to be last).
+            // No release/acquire fence: a release would write back the XCD L2's dirty conv output (+30 us measured).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(smem + 16384);
+            const int total = (int)gridDim.y * p.m_tiles;
+            if (tid == 0) {
+                const int tk = __hip_atomic_fetch_add(p.fin_counter + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = tk == total - 1 ? 1 : 0;
+                if (last) __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag) {
+                constexpr int NT = NW * 64, PH = NT / BN;
+                double* acc2 = reinterpret_cast<double*>(smem);      // [PH][BN][2], <= 8 KiB
+                const int c = tid % BN, ph = tid / BN;
+                const int ncol = nt * BN + c;
+                double s1 = 0.0, s2 = 0.0;
+                if (ncol < p.cout && ph < PH) {
+                    for (int r = ph; r < total; r += PH) {
+                        const unsigned long long bits = __hip_atomic_load(
+                            reinterpret_cast<const unsigned long long*>(p.stats + ((long long)r * p.cout + ncol) * 2),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
+                        s2 += (double)__uint_as_float((unsigned)(bits >> 32));
+                    }
+                }
+                if (ph < PH) {
+                    acc2[(ph * BN + c) * 2 + 0] = s1;
+                    acc2[(ph * BN + c) * 2 + 1] = s2;
+                }
+                __syncthreads();
+                if (ph == 0 && ncol < p.cout) {
+                    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) { s1 += acc2[(q * BN + c) * 2 + 0]; s2 += acc2[(q * BN + c) * 2 + 1]; }
+                    const double mean = s1 * p.fin_inv_count;
+                    double var = s2 * p.fin_inv_count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const double invstd = 1.0 / sqrt(var + (double)p.fin_eps);
+                    const double g = p.fin_gamma ? (double)p.fin_gamma[ncol] : 1.0;
+                    const double b = p.fin_beta ? (double)p.fin_beta[ncol] : 0.0;
+                    const double sc = g * invstd;
+                    p.fin_out[ncol] = (float)sc;
+                    p.fin_out[p.cout + ncol] = (float)(b - mean * sc);
+                    p.fin_out[2 * p.cout + ncol] = (float)mean;
+                    p.fin_out[3 * p.cout + ncol] = (float)invstd;
+                    if (p.fin_rmean) p.fin_rmean[ncol] = (1.f - p.fin_momentum) * p.fin_rmean[ncol] + p.fin_momentum * (float)mean;
+                    if (p.fin_rvar)  p.fin_rvar[ncol]  = (1.f - p.fin_momentum) * p.fin_rvar[ncol] + p.fin_momentum * (float)(var * p.fin_unbias);
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int BM, int BN, int WGM, int WGN, int NS, bool HELPER>
 __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igemm_kernel(const ConvKArgs p) {
@@ -328,224 +549,18 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
     }
     __syncthreads();                      // LDS ring is free: reused for the statistics reduction
 
-    // ---------------- split-K hand-off ----------------
-    // (cdna guide 5 "in-launch split-K reduction", write-through form): every slice stores its fp32 partial
-    // tile with 16-byte sc1 stores, every storing wave drains them, workgroup barrier, ONE relaxed agent-scope
-    // ticket.  The slice that draws S-1 re-arms the ticket, reads all S slabs back with sc1 loads and sums them
-    // in SLICE order, so the result does not depend on which slice happened to be last.  No spin anywhere:
-    // nothing can hang.
-    if (S > 1) {
-        constexpr int NT = NW * 64;
-        constexpr unsigned SLAB = (unsigned)BM * BN * 4u;
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-        const long long tile_id = (long long)cls * tiles + lin;
-        char* const sbase = reinterpret_cast<char*>(p.slabs) + tile_id * (long long)S * SLAB;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(S * SLAB), 0x00020000);
-        if (!helper) {
-            const unsigned my = (unsigned)slice * SLAB + (unsigned)tid * 16u;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        u32x4 v;
-                        v[0] = __float_as_uint(acc[i][j][4 * q + 0]); v[1] = __float_as_uint(acc[i][j][4 * q + 1]);
-                        v[2] = __float_as_uint(acc[i][j][4 * q + 2]); v[3] = __float_as_uint(acc[i][j][4 * q + 3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, my + (unsigned)(((i * TN + j) * 4 + q) * NT * 16), 0, 16);
-                    }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem + 16384);
-        if (tid == 0) {
-            int* cnt = p.sk_counter + tile_id;
-            const int tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = tk == S - 1 ? 1 : 0;
-            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-            *flag = last;
-        }
-        __syncthreads();
-        if (!*flag) return;
-        if (!helper) {
-            // every slab, the reducer's own included, is read back in slice order 0..S-1: the sum is the same
-            // whichever slice arrives last, and no second accumulator set is live
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            for (int sl = 0; sl < S; ++sl) {
-                const unsigned off = (unsigned)sl * SLAB + (unsigned)tid * 16u;
-                u32x4 v[TM][TN][4];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            v[i][j][q] = __builtin_amdgcn_raw_buffer_load_b128(
-                                rsrc, off + (unsigned)(((i * TN + j) * 4 + q) * NT * 16), 0, 16);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc[i][j][4 * q + 0] += __uint_as_float(v[i][j][q][0]); acc[i][j][4 * q + 1] += __uint_as_float(v[i][j][q][1]);
-                            acc[i][j][4 * q + 2] += __uint_as_float(v[i][j][q][2]); acc[i][j][4 * q + 3] += __uint_as_float(v[i][j][q][3]);
-                        }
-            }
-        }
-        __syncthreads();                  // the flag word is reused by the norm-finalize hand-off below
-    }
-
-    // ---------------- epilogue ----------------
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2]
-    const bool want_stats = p.stats != nullptr;
-    const int a_par = cls >> 1, b_par = cls & 1;
-    const int owc_e = p.OWc[cls];
-    const int hwc = p.OHc[cls] * owc_e;
-    const int mcls_e = p.Mc[cls];
-    const long long ohow = (long long)p.OH * p.OW;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int ncol = nt * BN + wn * WN + j * 32 + lr;
-        const bool nvalid = ncol < p.cout && !helper;
-        const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int m = mt * BM + row;
-                if (m < mcls_e && nvalid && !(p.ablate & 4)) {
-                    float v = acc[i][j][r] + bv;
-                    long long opix;   // output pixel index in [N][OH][OW]
-                    if (p.os == 1) {
-                        opix = m;
-                    } else {
-                        const int n = m / hwc;
-                        const int rem = m - n * hwc;
-                        const int oi = rem / owc_e;
-                        const int oj = rem - oi * owc_e;
-                        opix = ((long long)n * p.OH + (oi * 2 + a_par)) * p.OW + (oj * 2 + b_par);
-                    }
-                    if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
-                        s1 += v;
-                        s2 += v * v;
-                        reinterpret_cast<float*>(p.out)[opix * p.cout_stride + ncol] = v;
-                    } else {
-                        v = apply_act(v, p.act, p.act_param) * p.out_scale;
-                        if (p.out_mode == V2V_OUT_ACT_NHWC) {
-                            store_act(reinterpret_cast<T*>(p.out), opix * p.cout_stride + ncol, v);
-                        } else {
-                            const long long n = opix / ohow;
-                            const long long pix = opix - n * ohow;
-                            reinterpret_cast<float*>(p.out)[(n * p.cout + ncol) * ohow + pix] = v;
-                        }
-                    }
-                }
-            }
-        }
-        if (want_stats) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (hi == 0 && !helper) {
-                const int c = wn * WN + j * 32 + lr;
-                red[(wm * BN + c) * 2 + 0] = s1;
-                red[(wm * BN + c) * 2 + 1] = s2;
-            }
-        }
-    }
-    if (want_stats) {
-        __syncthreads();
-        if (tid < BN) {
-            const int ncol = nt * BN + tid;
-            if (ncol < p.cout) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int q = 0; q < WGM; ++q) {
-                    s1 += red[(q * BN + tid) * 2 + 0];
-                    s2 += red[(q * BN + tid) * 2 + 1];
-                }
-                float* dst = p.stats + ((long long)(cls * p.m_tiles + mt) * p.cout + ncol) * 2;
-                if (p.fin_counter != nullptr) {
-                    // 8-byte agent-scope (write-through, sc1) store: the (sum, sum^2) granule is what the last
-                    // workgroup reads back with agent-scope loads -- no L2 write-back fence is needed
-                    const unsigned long long bits = (unsigned long long)__float_as_uint(s1) |
-                                                    ((unsigned long long)__float_as_uint(s2) << 32);
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    dst[0] = s1;
-                    dst[1] = s2;
-                }
-            }
-        }
-        if (p.fin_counter != nullptr) {
-            // ---- training-mode norm finalize by the LAST workgroup to finish this N tile ----
-            // (get_norm_layer, models/networks.py:23-30: batch statistics -> scale/shift; replaces a separate
-            // bn_finalize launch per layer).  Hand-off (cdna guide G16, "sc1 payload -> vmcnt(0) -> flag" form):
-            // the partial rows are 8-byte write-through agent-scope stores, every wave drains them, workgroup
-            // barrier, then ONE relaxed agent-scope ticket; the last arriver reads all rows back with agent-scope
-            // 8-byte loads in a fixed order (deterministic, independent of which workgroup happens to be last).
-            // No release/acquire fence: a release would write back the XCD L2's dirty conv output (+30 us measured).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int* flag = reinterpret_cast<int*>(smem + 16384);
-            const int total = (int)gridDim.y * p.m_tiles;
-            if (tid == 0) {
-                const int tk = __hip_atomic_fetch_add(p.fin_counter + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = tk == total - 1 ? 1 : 0;
-                if (last) __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-                *flag = last;
-            }
-            __syncthreads();
-            if (*flag) {
-                constexpr int NT = NW * 64, PH = NT / BN;
-                double* acc2 = reinterpret_cast<double*>(smem);      // [PH][BN][2], <= 8 KiB
-                const int c = tid % BN, ph = tid / BN;
-                const int ncol = nt * BN + c;
-                double s1 = 0.0, s2 = 0.0;
-                if (ncol < p.cout && ph < PH) {
-                    for (int r = ph; r < total; r += PH) {
-                        const unsigned long long bits = __hip_atomic_load(
-                            reinterpret_cast<const unsigned long long*>(p.stats + ((long long)r * p.cout + ncol) * 2),
-                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
-                        s2 += (double)__uint_as_float((unsigned)(bits >> 32));
-                    }
-                }
-                if (ph < PH) {
-                    acc2[(ph * BN + c) * 2 + 0] = s1;
-                    acc2[(ph * BN + c) * 2 + 1] = s2;
-                }
-                __syncthreads();
-                if (ph == 0 && ncol < p.cout) {
-                    s1 = 0.0; s2 = 0.0;
-#pragma unroll
-                    for (int q = 0; q < PH; ++q) { s1 += acc2[(q * BN + c) * 2 + 0]; s2 += acc2[(q * BN + c) * 2 + 1]; }
-                    const double mean = s1 * p.fin_inv_count;
-                    double var = s2 * p.fin_inv_count - mean * mean;
-                    if (var < 0.0) var = 0.0;
-                    const double invstd = 1.0 / sqrt(var + (double)p.fin_eps);
-                    const double g = p.fin_gamma ? (double)p.fin_gamma[ncol] : 1.0;
-                    const double b = p.fin_beta ? (double)p.fin_beta[ncol] : 0.0;
-                    const double sc = g * invstd;
-                    p.fin_out[ncol] = (float)sc;
-                    p.fin_out[p.cout + ncol] = (float)(b - mean * sc);
-                    p.fin_out[2 * p.cout + ncol] = (float)mean;
-                    p.fin_out[3 * p.cout + ncol] = (float)invstd;
-                    if (p.fin_rmean) p.fin_rmean[ncol] = (1.f - p.fin_momentum) * p.fin_rmean[ncol] + p.fin_momentum * (float)mean;
-                    if (p.fin_rvar)  p.fin_rvar[ncol]  = (1.f - p.fin_momentum) * p.fin_rvar[ncol] + p.fin_momentum * (float)(var * p.fin_unbias);
-                }
-            }
-        }
-    }
+    conv_epilogue<T, BM, BN, WGM, WGN>(p, acc, smem, tid, wm, wn, helper, cls, tiles, lin, slice, S, nt, cls * p.m_tiles + mt,
+        [&](int row) -> long long {
+            const int m = mt * BM + row;
+            if (m >= p.Mc[cls]) return -1;
+            if (p.os == 1) return m;
+            const int owc_e = p.OWc[cls], hwc = p.OHc[cls] * owc_e;
+            const int n = m / hwc;
+            const int rem = m - n * hwc;
+            const int oi = rem / owc_e;
+            const int oj = rem - oi * owc_e;
+            return ((long long)n * p.OH + (oi * 2 + (cls >> 1))) * p.OW + (oj * 2 + (cls & 1));
+        });
 }
 
 // ---- conv launch ------------------------------------------------------------------------

@@ -84,9 +84,10 @@ class PackedConv:
                   (stride s; pad p, or pad 0 behind a ReflectionPad2d), a ConvTranspose2d a stride-2 Conv2d.
     """
 
-    def __init__(self, eng, mod, cin_stride, role="fwd", reflect=False):
+    def __init__(self, eng, mod, cin_stride, role="fwd", reflect=False, korder=0):
         self.mod = mod
         self.role = role
+        self.korder = korder      # 0: tap-major K (implicit-GEMM tiles), 1: channel-chunk-major (patch kernel)
         mod_t = isinstance(mod, nn.ConvTranspose2d)
         w = mod.weight
         self.KH, self.KW = mod.kernel_size
@@ -126,7 +127,7 @@ class PackedConv:
             w32 = w32.float().contiguous()
         check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), self.cin, self.cin_stride, self.cout,
                                         self.KH, self.KW, int(self.transposed), self.stride, self.pad, self.dtype,
-                                        _stream()),
+                                        self.korder, _stream()),
               "conv_pack_weights")
         if self.role == "fwd":
             self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()
@@ -192,6 +193,12 @@ TILE_CFGS = {1: (128, 128, False), 2: (128, 64, True), 3: (64, 64, True), 4: (12
              15: (128, 128, False), 16: (256, 64, False), 17: (64, 128, True), 18: (256, 128, False),
              19: (256, 128, False), 20: (128, 256, False), 21: (128, 128, False), 22: (256, 128, False),
              23: (128, 256, False)}
+# LDS-resident-patch 3x3 kernel (csrc/conv3x3_patch_kernel.h): id -> (TH, TW, BN); weights in K order 1
+PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64), 36: (8, 32, 64), 37: (4, 32, 128),
+              40: (2, 64, 64), 41: (4, 64, 64), 42: (2, 64, 128), 43: (4, 32, 64), 44: (8, 32, 64), 45: (4, 32, 128),
+              46: (4, 64, 64), 47: (2, 64, 128), 48: (4, 64, 128),   # 40+: dedicated loader waves
+              # ping-pong wave groups (csrc/conv3x3_pp_kernel.h)
+              50: (4, 64, 128), 51: (4, 64, 64), 52: (2, 64, 128), 53: (8, 32, 128), 54: (8, 32, 64), 55: (4, 32, 128)}
 PREFETCH_DIST = 12          # K chunks (128 B of every weight row each) the helper wave runs ahead
 
 
@@ -288,11 +295,11 @@ class Engine:
         return self._grids[key]
 
     # ---------------- weights ----------------
-    def packed(self, mod, cin_stride, role="fwd", reflect=False):
-        key = (id(mod), cin_stride, role, reflect)
+    def packed(self, mod, cin_stride, role="fwd", reflect=False, korder=0):
+        key = (id(mod), cin_stride, role, reflect, korder)
         pc = self._packed.get(key)
         if pc is None:
-            pc = PackedConv(self, mod, cin_stride, role, reflect)
+            pc = PackedConv(self, mod, cin_stride, role, reflect, korder)
             self._packed[key] = pc
         elif self.plan is None:
             pc.refresh()          # eager (training) use: follow optimizer updates
@@ -318,7 +325,7 @@ class Engine:
             OH = (H + 2 * pad - pc.KH) // pc.stride + 1
             OW = (W + 2 * pad - pc.KW) // pc.stride + 1
         d = ConvDesc()
-        d.in_ = x.t.data_ptr(); d.w = pc.buf.data_ptr()
+        d.in_ = x.t.data_ptr(); d.w = pc.buf.data_ptr(); d.w_korder = 0
         d.zero_page = self.zero_page().data_ptr()
         self._keep(self._zero_page)
         d.bias = None if pc.bias is None else pc.bias.data_ptr()
@@ -334,6 +341,8 @@ class Engine:
         tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
         if d.tile == 0 and tune_key in self._tuned:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
+        if d.tile >= 32:
+            pc = self._use_korder1(d, mod, x.Cs)
         if pc.cin != x.C:
             raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
         if out_mode == L.OUT_RAW_F32_NHWC:
@@ -377,17 +386,18 @@ class Engine:
                 for t in (gamma, beta, ss, self._fin_counter):
                     if t is not None:
                         self._keep(t)
-        self._keep(pc.buf)
         if pc.bias is not None:
             self._keep(pc.bias)
         if (self.autotune and d.tile == 0 and self.plan is None and not self.record_only
                 and not torch.is_grad_enabled()):
-            self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout)
+            self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout, mod, x.Cs)
             d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
+            pc = self._use_korder1(d, mod, x.Cs) if d.tile >= 32 else self._use_korder0(d, mod, x.Cs)
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()
         self._splitk_workspace(d)
+        self._keep(pc.buf)
         check(lib.v2v_conv2d(C.byref(d), _stream()), "conv2d " + label)
         self.label(label)
         ntaps = pc.KH * pc.KW
@@ -397,6 +407,22 @@ class Engine:
                                   tile=lib.v2v_conv_tile_config(C.byref(d)), splitk=max(int(d.splitk), 1),
                                   prefetch=int(d.prefetch)))
         return out, rows, (N, OH, OW)
+
+    def _use_korder1(self, d, mod, cin_stride):
+        """Point the descriptor at the channel-chunk-major packing of `mod` (patch-kernel tile ids >= 32)."""
+        pc = self.packed(mod, cin_stride, korder=1)
+        d.w, d.w_korder = pc.buf.data_ptr(), 1
+        return pc
+
+    def _use_korder0(self, d, mod, cin_stride):
+        pc = self.packed(mod, cin_stride, korder=0)
+        d.w, d.w_korder = pc.buf.data_ptr(), 0
+        return pc
+
+    def patch_eligible(self, d):
+        bke = 64 if self.dtype == L.BF16 else 32
+        return (not d.transposed and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1
+                and d.cin_stride % bke == 0)
 
     def _splitk_workspace(self, d):
         """Attach the split-K slab scratch and ticket words to a descriptor (no-op for splitk <= 1)."""
@@ -418,7 +444,7 @@ class Engine:
         self._keep(self._sk_counter)
         return True
 
-    def _autotune(self, d, want_stats, cout, reps=5):
+    def _autotune(self, d, want_stats, cout, mod=None, cin_stride=0, reps=5):
         """Time every (tile, split-K, weight-prefetch) configuration that fits this launch; returns the fastest
         triple.  Runs once per conv shape while a frame plan is being built, never inside a timed region.  Each
         timed launch is preceded by a 384 MB memset: at batch 1 a frame streams ~0.8 GB of weights, so every layer
@@ -440,6 +466,20 @@ class Engine:
                 cands.append((t, S, 0))
                 if helper:
                     cands.append((t, S, PREFETCH_DIST))
+        if mod is not None and self.patch_eligible(d):
+            ncc = d.cin_stride // (64 if self.dtype == L.BF16 else 32)
+            for t, (th, tw, bn) in sorted(PATCH_CFGS.items()):
+                if tw == 64 and d.OW % 64 != 0 and d.OW > 32:
+                    pass                      # ragged tiles are legal, just wasteful; let the timing decide
+                tiles = d.N * -(-d.OH // th) * -(-d.OW // tw) * -(-cout // bn)
+                for S in (1, 2, 3, 4, 8):
+                    if S > 1 and (tiles * S > 1024 or ncc < S):
+                        continue
+                    if S == 1 and tiles < 64:
+                        continue
+                    cands.append((t, S, 0))
+                    if t <= 37:
+                        cands.append((t, S, PREFETCH_DIST))
         st = _stream()
         if self._thrash is None:
             self._thrash = torch.empty(96 << 20, dtype=torch.float32, device=self.device)
@@ -448,6 +488,8 @@ class Engine:
         e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
         for t, S, pf in cands:
             d.tile, d.splitk, d.prefetch = t, S, pf
+            if mod is not None:
+                (self._use_korder1 if t >= 32 else self._use_korder0)(d, mod, cin_stride)
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 if rows <= 0:

@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
         ("fin_scale_shift", C.c_void_p), ("fin_running_mean", C.c_void_p), ("fin_running_var", C.c_void_p),
         ("fin_eps", C.c_float), ("fin_momentum", C.c_float), ("fin_count", C.c_int64),
         ("splitk", C.c_int32), ("prefetch", C.c_int32), ("slabs", C.c_void_p), ("sk_counter", C.c_void_p),
-        ("ablate", C.c_int32),
+        ("w_korder", C.c_int32), ("ablate", C.c_int32),
     ]
 
 
@@ -58,7 +58,7 @@ LOSS_MSE_CONST, LOSS_L1 = 0, 1
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 PROTOTYPES = {
     "v2v_conv_packed_elems": (_L, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
-    "v2v_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_conv_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_tile_config": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_splitk_workspace": (_L, [C.POINTER(ConvDesc), C.POINTER(_I)]),
