@@ -255,6 +255,38 @@ def test_conv3x3_patch_kernel(case, prec):
         assert int(eng._sk_counter.abs().sum().item()) == 0
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(128, 3, 24, 64, "reflect", 1, "tanh"), (64, 2, 19, 45, "reflect", 2, "none"),
+                                  (128, 1, 33, 70, "zero", 1, "sigmoid"), (192, 4, 9, 32, "reflect", 1, "none"),
+                                  (64, 13, 17, 40, "reflect", 1, "none")])
+def test_conv7x7_head_kernel(case, prec):
+    """7x7 head kernel (tile id 60: LDS-resident halo patch + 16-wide MFMA) against torch and
+    against the implicit-GEMM kernel on the same packed weights."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, mode, N, actn = case
+    torch.manual_seed(cin + cout)
+    eng = _engine(prec)
+    conv = nn.Conv2d(cin, cout, 7, padding=0 if mode == "reflect" else 3)
+    x = torch.randn(N, cin, H, W)
+    xr = _round(x, prec)
+    if mode == "reflect":
+        xr = F.pad(xr, (3,) * 4, mode="reflect")
+    ref = F.conv2d(xr, _round(conv.weight.detach(), prec), conv.bias.detach(), padding=0 if mode == "reflect" else 3)
+    act = {"tanh": L.ACT_TANH, "sigmoid": L.ACT_SIGMOID, "none": L.ACT_NONE}[actn]
+    ref = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "none": lambda t: t}[actn](ref) * 20.0
+    conv = conv.to(DEV)
+    xa = eng.pack(x.to(DEV))
+    pm, po = (L.PAD_REFLECT, 3) if mode == "reflect" else (L.PAD_ZERO, None)
+    outs = {}
+    for tile in (60, 3):
+        eng.tile_override[(cin, cout, 7, 1, 0)] = tile
+        o, _, _ = eng.conv(xa, conv, pm, po, L.OUT_F32_NCHW, act, 0.0, 20.0)
+        assert eng.conv_log[-1]["tile"] == tile
+        outs[tile] = o.clone()
+        assert_close(o.cpu(), ref, 1e-4 if prec == "fp32" else 3e-3, "head tile %d" % tile)
+    assert_close(outs[60].cpu(), outs[3].cpu(), 1e-4 if prec == "fp32" else 2e-3, "head vs implicit GEMM")
+
+
 CONVT_CASES = [(16, 8, 3, 1, 1, 9, 13), (64, 32, 3, 1, 1, 16, 32), (24, 16, 4, 1, 0, 11, 7), (128, 64, 3, 1, 1, 32, 64)]
 
 

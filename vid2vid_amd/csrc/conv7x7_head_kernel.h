@@ -1,0 +1,167 @@
+// 7x7 stride-1 "head" convolution with <= 16 output channels (gfx950), NHWC input, planar fp32 NCHW output.
+//
+// The generator heads (models/networks.py:180-183 model_final_img / _flow / _w, :279 and the fg tower :151) are
+// Conv2d(C -> 3 | 2 | 1, k = 7) behind ReflectionPad2d(3).  As an implicit GEMM they waste >= 95 % of every MFMA
+// (N = 3 padded to 32 / 64) and re-fetch the activation tile 49 times; measured 118-187 us per head at 512x256 for
+// 2.5-4.9 GFLOP (profiles/r01_v9_*).  This kernel
+//   * brings the (TH+6) x (TW+6) pixel patch of a TH x TW tile into LDS once per 128-byte channel chunk (LDS-DMA, same
+//     row swizzle as conv3x3_patch_kernel.h) and walks the 49 taps over it: activations are read from HBM/L2 once;
+//   * uses the 16-wide MFMA (v_mfma_f32_16x16x32_bf16 / exact-fp32 v_mfma_f32_16x16x4_f32): 16 pixels x 16 output
+//     channels per instruction, so the padding waste is 16/cout instead of 64/cout;
+//   * takes the B fragments (16 channel rows x 64 B, wave-identical) straight from the tap-major packed weights of
+//     v2v_conv_pack_weights (korder 0; rows >= cout are zero) with one 16-byte load per lane per (tap, K half), one
+//     kernel row (14 fragments) in flight, each reused by the wave's 4 pixel groups.
+// (A first version that gave every lane one pixel and multiplied on the VALU -- v_dot2c_f32_bf16, then v_pk_fma_f32
+//  with weights through the scalar cache -- measured 172 / >187 us: 512 B of weights per tap do not fit the SGPR file
+//  and the scalar loads serialise.)
+#pragma once
+#include "conv_igemm_kernel.h"
+
+namespace v2v {
+
+// 16x16 MFMA on 16 bytes per lane of A (16 pixels x 64 B) and B (16 output channels x 64 B):
+//   bf16: v_mfma_f32_16x16x32_bf16, lane l holds A[l&15][8*(l>>4)..+8];
+//   fp32: four v_mfma_f32_16x16x4_f32 (exact fp32), lane l holds 4 consecutive k; MFMA j multiplies k in {j,4+j,8+j,12+j}.
+// C/D: col = lane&15 (output channel), row = (lane>>4)*4 + reg (pixel).
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+    typedef bf16x8 Frag;
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<float> {
+    typedef f32x4 Frag;
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, const T* __restrict__ w_ro) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int BKE = ElemTraits<T>::BKE;
+    constexpr int TH = 8, TW = 32, HALO = 3, KS = 7;
+    constexpr int PW = TW + 2 * HALO, PR = (TH + 2 * HALO) * PW;     // 38 x 14 = 532 patch rows
+    constexpr int NW = 4;
+    constexpr int NG = (PR + 7) / 8, GP = (NG + NW - 1) / NW;         // 67 pieces, 17 per wave
+    typedef typename Mma16<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x;
+    const int tpi = p.tiles_h * p.tiles_w;
+    const int n_img = mt / tpi;
+    const int trem = mt - n_img * tpi;
+    const int th = trem / p.tiles_w;
+    const int oh0 = th * TH, ow0 = (trem - th * p.tiles_w) * TW;
+    const int H = p.H, W = p.W, cs = p.cin_stride;
+    const int ncc = cs / BKE;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+
+    // patch loader geometry: piece g = k*NW + wid covers patch rows 8g..8g+7 (see conv3x3_patch_kernel.h)
+    unsigned pp[GP];
+    unsigned pok = 0;
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+        const int q = (k * NW + wid) * 8 + (lane >> 3);
+        const int ls = (lane & 7) ^ ((q >> 1) & 7);
+        const int pr = q / PW, pc = q - pr * PW;
+        int ih = oh0 + pr - HALO, iw = ow0 + pc - HALO;
+        bool ok = q < PR;
+        int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+        int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+        ih = reflect ? rh : ih;
+        iw = reflect ? rw : iw;
+        ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+        iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        pp[k] = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
+        pok |= (ok ? 1u : 0u) << k;
+    }
+
+    // wave `wid` owns tile rows 2*wid, 2*wid+1 = 4 groups of 16 consecutive pixels; lane l: pixel l&15, k-group l>>4
+    const int lp = lane & 15, kg = lane >> 4;
+    int qg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qg[g] = (2 * wid + (g >> 1)) * PW + (g & 1) * 16 + lp;
+    // weights: row (output channel) lp of the tap-major packed matrix; rows >= cout are zero
+    const T* const wlane = w_ro + p.woff[0] + (long long)lp * p.wrow[0] + kg * VEC;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { acc[g][0] = 0.f; acc[g][1] = 0.f; acc[g][2] = 0.f; acc[g][3] = 0.f; }
+
+    for (int cc = 0; cc < ncc; ++cc) {
+        if (cc > 0) __syncthreads();                                  // every wave is done with the previous chunk's patch
+#pragma unroll
+        for (int k = 0; k < GP; ++k) {
+            const char* src = ((pok >> k) & 1u) ? p.in + pp[k] + cc * 128 : p.zero_page;
+            glds16(src, smem + (k * NW + wid) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const T* const wcc = wlane + cc * BKE;
+        for (int dy = 0; dy < KS; ++dy) {
+            Frag bf[KS][2];                                           // one kernel row of weight fragments in flight
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    bf[dx][h] = *reinterpret_cast<const Frag*>(wcc + (long long)(dy * KS + dx) * cs + h * 4 * VEC);
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int q = qg[g] + dy * PW + dx;
+                    const char* const arow = smem + q * 128;
+                    const int ax = (q >> 1) & 7;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const Frag a = *reinterpret_cast<const Frag*>(arow + (((h * 4 + kg) ^ ax) << 4));
+                        Mma16<T>::run(a, bf[dx][h], acc[g]);
+                    }
+                }
+            }
+        }
+    }
+
+    if (lp < p.cout && !(p.ablate & 4)) {
+        const long long hw = (long long)H * W;
+        const float bv = p.bias ? p.bias[lp] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int oh = oh0 + 2 * wid + (g >> 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ow = ow0 + (g & 1) * 16 + kg * 4 + r;
+                if (oh < H && ow < W) {
+                    const float v = apply_act(acc[g][r] + bv, p.act, p.act_param) * p.out_scale;
+                    reinterpret_cast<float*>(p.out)[((long long)n_img * p.cout + lp) * hw + (long long)oh * W + ow] = v;
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static inline int launch_head_typed(const ConvKArgs& k, hipStream_t s) {
+    constexpr int PR = (8 + 6) * (32 + 6);
+    constexpr int GP = ((PR + 7) / 8 + 3) / 4;
+    const size_t lds = (size_t)GP * 4 * 1024;                         // 68 KiB: two workgroups per CU
+    auto kern = conv7x7_head_kernel<T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)k.m_tiles), dim3(256), lds, s, k, reinterpret_cast<const T*>(k.w));
+    return check_launch();
+}
+
+}  // namespace v2v

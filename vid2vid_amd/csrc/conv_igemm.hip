@@ -42,6 +42,7 @@
 //     publish fp32 partial tiles write-through (sc1) and the last arriver reduces them in slice
 //     order (deterministic) and runs the normal epilogue.
 #include "conv3x3_pp_kernel.h"
+#include "conv7x7_head_kernel.h"
 #include <cstdarg>
 #include <cstring>
 #include <cstdlib>
@@ -204,6 +205,8 @@ int launch_patch_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_patch_f32(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_pp_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_pp_f32(int cfg, const ConvKArgs& k, hipStream_t s);
+int launch_head_bf16(const ConvKArgs& k, hipStream_t s);
+int launch_head_f32(const ConvKArgs& k, hipStream_t s);
 
 static int choose_cfg(long long Mc, int cout, int ncls) {
     if (cout <= 32) return 4;
@@ -222,6 +225,7 @@ struct ConvOp : Op {
     int ncls, cfg, dtype;
     long long slab_bytes; int sk_tickets;
     int launch(hipStream_t s) override {
+        if (cfg == 60) return dtype == V2V_BF16 ? launch_head_bf16(k, s) : launch_head_f32(k, s);
         if (cfg >= 50) return dtype == V2V_BF16 ? launch_pp_bf16(cfg, k, s) : launch_pp_f32(cfg, k, s);
         if (cfg >= 32) return dtype == V2V_BF16 ? launch_patch_bf16(cfg, k, s) : launch_patch_f32(cfg, k, s);
         return dtype == V2V_BF16 ? launch_conv_bf16(cfg, k, ncls, s) : launch_conv_f32(cfg, k, ncls, s);
@@ -294,7 +298,21 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     op->dtype = d->dtype;
     op->cfg = d->tile ? d->tile : choose_cfg(Mc, d->cout, g.ncls);
     int tile_bm, tile_bn;
-    if (op->cfg >= 32) {
+    if (op->cfg == 60) {
+        // conv7x7_head_kernel: 7x7 / stride 1 / pad 3 Conv2d with <= 16 output channels written planar fp32
+        if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->cout > 16 ||
+            d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 0 || d->out_mode != V2V_OUT_F32_NCHW || d->stats ||
+            d->splitk > 1 ||
+            (long long)d->N * d->H * d->W * d->cin_stride * (d->dtype == V2V_BF16 ? 2 : 4) >= (1ll << 32)) {
+            set_error("conv: tile config 60 (7x7 head) needs a 7x7/s1/p3 Conv2d, cout <= 16, cin_stride %% %d == 0, planar fp32 output",
+                      bke_of(d->dtype)); return V2V_EINVAL;
+        }
+        k.tiles_h = (int)ceil_div(d->OH, 8);
+        k.tiles_w = (int)ceil_div(d->OW, 32);
+        k.m_tiles = d->N * k.tiles_h * k.tiles_w;
+        k.n_tiles = 1;
+        tile_bm = 256; tile_bn = 4;
+    } else if (op->cfg >= 32) {
         // conv3x3_patch_kernel: 3x3 / stride 1 / pad 1 Conv2d, channel stride a multiple of the 128-byte chunk,
         // weights packed channel-chunk outer (korder 1)
         const PatchCfg* pc = op->cfg >= 50 ? find_pp_cfg(op->cfg) : find_patch_cfg(op->cfg);

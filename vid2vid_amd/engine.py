@@ -341,7 +341,7 @@ class Engine:
         tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
         if d.tile == 0 and tune_key in self._tuned:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
-        if d.tile >= 32:
+        if 32 <= d.tile < 60:
             pc = self._use_korder1(d, mod, x.Cs)
         if pc.cin != x.C:
             raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
@@ -392,7 +392,7 @@ class Engine:
                 and not torch.is_grad_enabled()):
             self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout, mod, x.Cs)
             d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
-            pc = self._use_korder1(d, mod, x.Cs) if d.tile >= 32 else self._use_korder0(d, mod, x.Cs)
+            pc = self._use_korder1(d, mod, x.Cs) if 32 <= d.tile < 60 else self._use_korder0(d, mod, x.Cs)
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()
@@ -466,6 +466,10 @@ class Engine:
                 cands.append((t, S, 0))
                 if helper:
                     cands.append((t, S, PREFETCH_DIST))
+        bke_ = 64 if self.dtype == L.BF16 else 32
+        if (not d.transposed and d.KH == 7 and d.KW == 7 and d.stride == 1 and d.pad == 3 and cout <= 16
+                and d.cin_stride % bke_ == 0 and d.out_mode == L.OUT_F32_NCHW and not want_stats):
+            cands.append((60, 1, 0))          # conv7x7_head_kernel (LDS patch + 16-wide MFMA)
         if mod is not None and self.patch_eligible(d):
             ncc = d.cin_stride // (64 if self.dtype == L.BF16 else 32)
             for t, (th, tw, bn) in sorted(PATCH_CFGS.items()):
@@ -489,7 +493,7 @@ class Engine:
         for t, S, pf in cands:
             d.tile, d.splitk, d.prefetch = t, S, pf
             if mod is not None:
-                (self._use_korder1 if t >= 32 else self._use_korder0)(d, mod, cin_stride)
+                (self._use_korder1 if 32 <= t < 60 else self._use_korder0)(d, mod, cin_stride)
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 if rows <= 0:
