@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--scales", type=int, default=1, help="n_scales_spatial (3 with --width 2048 --height 1024 = BASELINE configs[4] geometry, inference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true")
@@ -71,14 +72,15 @@ def main():
     H, W = args.height, args.width
     torch.manual_seed(0)
     opt = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True,
-                   loadSize=W, precision=args.precision, gpu_ids=[local_rank])
+                   loadSize=W, precision=args.precision, gpu_ids=[local_rank], n_scales_spatial=args.scales)
     opt.use_graph = not args.no_graph
     sys.stdout.flush()
     _stdout = sys.stdout
     sys.stdout = sys.stderr                      # keep stdout for the single JSON line
     model = create_model(opt)
     with torch.no_grad():
-        model.netG0.model_final_flow[1].weight.mul_(0.1)     # flows of a few px
+        for si in range(args.scales):                        # flows of a few px
+            getattr(model, "netG%d" % si).model_final_flow[1].weight.mul_(0.1)
     tG = opt.n_frames_G
     L = 16                                       # resident sequence length, cycled
     lab, inst, frames = synthetic.label2city_sequence(L + tG, H, W, seed=1234 + rank, device=dev)
@@ -137,13 +139,19 @@ def main():
               if c["cin"] == 1024 and c["cout"] == 1024 and c["KH"] == 3]
         rb_tf = (sum(c["flops"] for _, c in rb) / (sum(ms for ms, _ in rb) * 1e-3) / 1e12) if rb else None
         peak = PEAK_TFLOPS[args.precision]
-        from vid2vid_amd.engine import TILE_CFGS
-        bm, bn, _ = TILE_CFGS.get(dom_tile[0], (0, 0, False))
-        tile_name = "%dx%d,splitK=%d,prefetch=%d" % (bm, bn, dom_tile[1], dom_tile[2])
+        from vid2vid_amd.engine import TILE_CFGS, PATCH_CFGS
+        if dom_tile[0] in PATCH_CFGS:
+            th_, tw_, bn = PATCH_CFGS[dom_tile[0]]
+            fam = "conv3x3_pp_kernel" if dom_tile[0] >= 50 else "conv3x3_patch_kernel"
+            tile_name = "%dx%d px x %d,splitK=%d" % (th_, tw_, bn, dom_tile[1])
+        else:
+            bm, bn, _ = TILE_CFGS.get(dom_tile[0], (0, 0, False))
+            fam = "conv_igemm_kernel"
+            tile_name = "%dx%d,splitK=%d,prefetch=%d" % (bm, bn, dom_tile[1], dom_tile[2])
         roofline = {
             "bound": "mfma",
-            "kernel": "conv_igemm_kernel<%s,%s> (implicit-GEMM conv, tile config %d)" % (
-                "bf16" if args.precision == "bf16" else "f32", tile_name, dom_tile[0]),
+            "kernel": "%s<%s,%s> (tile config %d)" % (
+                fam, "bf16" if args.precision == "bf16" else "f32", tile_name, dom_tile[0]),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": None,
             "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
@@ -193,9 +201,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "label2city %dx%d inference, n_scales_spatial=1, --fg --use_instance, ngf=128 n_blocks=9 "
-                                   "(411.3M params random-init, 2115 GFLOP/frame), batch 1 per sequence, 1 sequence per GPU"
-                                   % (W, H),
+            "config": {"workload": "label2city %dx%d inference, n_scales_spatial=%d, --fg --use_instance, ngf=128 n_blocks=9 "
+                                   "(%.1fM params random-init, %.0f GFLOP/frame), batch 1 per sequence, 1 sequence per GPU"
+                                   % (W, H, args.scales, sum(q.numel() for q in model.parameters()) / 1e6,
+                                      sum(c["flops"] for c in fp.conv_log) / 1e9),
                        "launches_per_frame": fp.plan.num_ops, "hipgraph": bool(opt.use_graph),
                        "parallelism": "replicas x%d (independent sequences, no collective)" % args.gpus,
                        "output_finite": finite},

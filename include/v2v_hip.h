@@ -178,7 +178,12 @@ int     v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream);
 int v2v_bn_finalize(const float* partials, int32_t rows, int32_t C, int64_t count,
                     const float* gamma, const float* beta, float eps,
                     float* scale_shift, float* running_mean, float* running_var, float momentum,
-                    void* stream);
+                    double* workspace, void* stream);
+/* workspace: NULL, or v2v_bn_finalize_groups(rows) * C * 2 doubles.  With a workspace, layers that leave more than 512
+ * statistics rows (large M) are reduced by a parallel two-stage tree (groups x C/64 workgroups, then one per 64
+ * channels) instead of one workgroup walking every row; the result is deterministic either way.  Returns 0 groups
+ * for rows <= 512 (single stage, the summation order the in-kernel finalize of v2v_conv2d reproduces). */
+int v2v_bn_finalize_groups(int32_t rows);
 
 /* y = act(raw * scale[c] + shift[c]) (+ add0) (+ add1);  raw fp32 NHWC [P][c_stride_raw],
  * y / add0 / add1 activation dtype NHWC [P][c_stride].  Channels >= C of y are written 0.

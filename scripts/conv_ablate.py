@@ -14,7 +14,7 @@ eng = Engine("cuda:0", L.BF16)
 SHAPES = [
     ("res1024 3x3 @32x64", 1024, 1024, 32, 64),
 ]
-CFGS = [(35, 1, 0), (50, 4, 0), (50, 2, 0), (51, 2, 0), (52, 2, 0), (53, 4, 0), (54, 2, 0)]
+CFGS = [(54, 2, 0), (56, 2, 0), (51, 2, 0), (57, 2, 0), (52, 2, 0), (55, 2, 0)]
 ABL = [0, 1, 2, 3, 4, 7, 16, 17, 18, 19, 23]
 REPS = 7
 THRASH = torch.empty(96 << 20, dtype=torch.float32, device="cuda:0")

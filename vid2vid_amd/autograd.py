@@ -85,7 +85,7 @@ class ConvFn(torch.autograd.Function):
             a0 = None if add0_t is None else Act(add0_t, cout)
             a1 = None if add1_t is None else Act(add1_t, cout)
             y = eng.norm_apply(raw, rows, shp, cout, norm, cfg.act, cfg.act_param, add0=a0, add1=a1,
-                               label=cfg.label, ss=ss, finalized=eng.fused_finalize)
+                               label=cfg.label, ss=ss, finalized=eng.fused_finalize and eng.last_finalized)
             ctx.shape = shp
             ctx.save_for_backward(x_t, raw, ss)
             return y.t

@@ -18,8 +18,9 @@
 //   RAW  tile j is read in LOAD_A(j) [2j] and LOAD_B(j) [2j+1].  Every wave waits for ITS share of tile j+1 (weights;
 //        and, being older in its in-order vmcnt queue, every patch piece issued up to tap 7) at the END of its
 //        LOAD(j), i.e. by phase 2j+1 at the latest; the barrier after that phase publishes it before LOAD_A(j+1).
-//        With DB = 2 slices in flight the count is exactly this step's own DMAs: vmcnt(np(tap) + LB).
-//   WAR  LOAD(j) refills weight stage (j+2)%3 = stage of tile j-1, last read in LOAD_B(j-1) [2j-1], whose ds_reads are
+//        The counted wait leaves the younger DMAs in flight: (DB-1) weight shares and the patch pieces of the last
+//        DB steps; taps >= 9-DB carry no patch pieces, so the wait of tap 8 retires the whole next patch.
+//   WAR  LOAD(j) refills weight stage (j+DB)%NSB = stage of tile j-1, last read in LOAD_B(j-1) [2j-1], whose ds_reads are
 //        drained (lgkmcnt(0)) before that phase's barrier.  The patch buffer of chunk c+1 is refilled from LOAD_A(9c)
 //        on; its previous contents (chunk c-1) were last read in LOAD_B(9c-1), one phase earlier.
 #pragma once
@@ -27,7 +28,7 @@
 
 namespace v2v {
 
-template <typename T, int TH, int TW, int BN>
+template <typename T, int TH, int TW, int BN, int NSB>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
@@ -38,14 +39,16 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvKArgs p) {
     constexpr int PATCH = GP * NW * 1024;
     constexpr int BST = BN * 128;
     constexpr int LB = BN / 8 / NW;                           // weight pieces per wave per slice
-    constexpr int NSB = 3, DB = 2;
-    constexpr int NPT = 8;                                    // taps 0..7 may carry next-chunk patch pieces
+    constexpr int DB = NSB - 1;                               // weight slices in flight (2 or 3)
+    constexpr int NPT = 9 - DB;                               // taps 0..NPT-1 may carry next-chunk patch pieces: the last
+                                                              // one must be forced by the wait of tap 8
     constexpr int PPT = (GP + NPT - 1) / NPT;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(TW % 32 == 0 && (TW & (TW - 1)) == 0, "a 32-row fragment must lie inside one tile row");
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile");
     static_assert(BN % (8 * NW) == 0 && LB >= 1, "weight loader rounds");
+    static_assert(NSB == 3 || NSB == 4, "weight ring depth");
     static_assert(2 * PATCH + NSB * BST <= 160 * 1024, "LDS");
     static_assert(2 * PATCH >= 32768, "epilogue scratch lives in the patch buffers");
     typedef typename Mma<T>::Frag Frag;
@@ -150,9 +153,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvKArgs p) {
     // ---------------- prologue: patch 0 and weight slices 0, 1; slice 0 (and the patch) must land ----------------
 #pragma unroll
     for (int k = 0; k < GP; ++k) issue_patch(k, 0, smem);
-    issue_w(0, 0);
-    issue_w(1, 1);
-    wait_vmcnt<LB>();
+#pragma unroll
+    for (int t = 0; t < DB; ++t) issue_w(t, t);
+    wait_vmcnt<(DB - 1) * LB>();
     __builtin_amdgcn_s_barrier();
 
     int step = 0, stage = 0, wstage = DB;
@@ -182,13 +185,21 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvKArgs p) {
                 for (int j = 0; j < TN; ++j)
                     fb[s][j] = *reinterpret_cast<const Frag*>(pb + j * 32 * 128 + foff[s]);
         }
+        // DMA order inside a step: weights first, then the next chunk's patch pieces.  The wait must retire weight
+        // slice step+1 (issued DB-1 steps ago); everything younger may stay in flight -- the patch pieces of the last
+        // DB-1 steps included, so a piece is only forced DB steps after it was issued (the in-order vmcnt would
+        // otherwise expose its full latency one step later although nobody reads it before the next chunk).
+        issue_w(step + DB, wstage);
         constexpr int k0 = patch::cmin(tap * PPT, GP), k1 = patch::cmin((tap + 1) * PPT, GP);
         if constexpr (tap < NPT) {
 #pragma unroll
             for (int k = k0; k < k1; ++k) issue_patch(k, cc + 1, pnext);
         }
-        issue_w(step + DB, wstage);
-        wait_vmcnt<(tap < NPT ? k1 - k0 : 0) + LB>();         // everything but this step's own DMAs: slice step+1 landed
+        constexpr int np0 = tap < NPT ? k1 - k0 : 0;
+        constexpr int tm1 = (tap + 8) % 9, tm2 = (tap + 7) % 9;
+        constexpr int np1 = tm1 < NPT ? patch::cmin((tm1 + 1) * PPT, GP) - patch::cmin(tm1 * PPT, GP) : 0;
+        constexpr int np2 = tm2 < NPT ? patch::cmin((tm2 + 1) * PPT, GP) - patch::cmin(tm2 * PPT, GP) : 0;
+        wait_vmcnt<(DB - 1) * LB + np0 + np1 + (DB == 3 ? np2 : 0)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: the stage may be refilled
         ++step;
         stage = stage + 1 == NSB ? 0 : stage + 1;
@@ -250,11 +261,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvKArgs p) {
         });
 }
 
-template <typename T, int TH, int TW, int BN>
+template <typename T, int TH, int TW, int BN, int NSB>
 static int launch_pp_cfg(const ConvKArgs& k, hipStream_t s) {
     constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + 7) / 8;
-    const size_t lds = (size_t)2 * GP * 8 * 1024 + (size_t)3 * BN * 128;
-    auto kern = conv3x3_pp_kernel<T, TH, TW, BN>;
+    const size_t lds = (size_t)2 * GP * 8 * 1024 + (size_t)NSB * BN * 128;
+    auto kern = conv3x3_pp_kernel<T, TH, TW, BN, NSB>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -268,6 +279,7 @@ static int launch_pp_cfg(const ConvKArgs& k, hipStream_t s) {
 // ping-pong tile configurations (ids 50..55)
 static const PatchCfg kPpCfgs[] = {
     {50, 4, 64, 128}, {51, 4, 64, 64}, {52, 2, 64, 128}, {53, 8, 32, 128}, {54, 8, 32, 64}, {55, 4, 32, 128},
+    {56, 8, 32, 64}, {57, 4, 64, 64},
 };
 static inline const PatchCfg* find_pp_cfg(int id) {
     for (const PatchCfg& c : kPpCfgs)
@@ -278,12 +290,14 @@ static inline const PatchCfg* find_pp_cfg(int id) {
 template <typename T>
 static inline int launch_pp_typed(int cfg, const ConvKArgs& k, hipStream_t s) {
     switch (cfg) {
-        case 50: return launch_pp_cfg<T, 4, 64, 128>(k, s);   // 256 px x 128, wave tile 64x64, 160 KiB
-        case 51: return launch_pp_cfg<T, 4, 64, 64>(k, s);    // 256 px x  64, wave tile 64x32
-        case 52: return launch_pp_cfg<T, 2, 64, 128>(k, s);   // 128 px x 128, wave tile 32x64
-        case 53: return launch_pp_cfg<T, 8, 32, 128>(k, s);   // 256 px x 128 for 32-wide tiles
-        case 54: return launch_pp_cfg<T, 8, 32, 64>(k, s);
-        case 55: return launch_pp_cfg<T, 4, 32, 128>(k, s);
+        case 50: return launch_pp_cfg<T, 4, 64, 128, 3>(k, s);   // 256 px x 128, wave tile 64x64, 160 KiB
+        case 51: return launch_pp_cfg<T, 4, 64, 64, 4>(k, s);    // 256 px x  64, wave tile 64x32, 4-deep weight ring
+        case 52: return launch_pp_cfg<T, 2, 64, 128, 4>(k, s);   // 128 px x 128, wave tile 32x64
+        case 53: return launch_pp_cfg<T, 8, 32, 128, 4>(k, s);   // 256 px x 128 for 32-wide tiles
+        case 54: return launch_pp_cfg<T, 8, 32, 64, 4>(k, s);
+        case 55: return launch_pp_cfg<T, 4, 32, 128, 4>(k, s);
+        case 56: return launch_pp_cfg<T, 8, 32, 64, 3>(k, s);    // as 54 with the 3-deep ring
+        case 57: return launch_pp_cfg<T, 4, 64, 64, 3>(k, s);    // as 51 with the 3-deep ring
     }
     set_error("conv: unknown ping-pong tile config %d", cfg);
     return V2V_EINVAL;

@@ -1,4 +1,5 @@
-// 7x7 stride-1 "head" convolution with <= 16 output channels (gfx950), NHWC input, planar fp32 NCHW output.
+// 7x7 stride-1 convolution with <= 32 output channels (gfx950), NHWC input; planar fp32 NCHW output with activation
+// (generator heads) or raw fp32 NHWC + per-tile statistics (fine-scale stems in front of a norm layer).
 //
 // The generator heads (models/networks.py:180-183 model_final_img / _flow / _w, :279 and the fg tower :151) are
 // Conv2d(C -> 3 | 2 | 1, k = 7) behind ReflectionPad2d(3).  As an implicit GEMM they waste >= 95 % of every MFMA
@@ -40,7 +41,7 @@ template <> struct Mma16<float> {
     }
 };
 
-template <typename T>
+template <typename T, int NT>
 __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, const T* __restrict__ w_ro) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BKE = ElemTraits<T>::BKE;
@@ -91,11 +92,14 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
     int qg[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) qg[g] = (2 * wid + (g >> 1)) * PW + (g & 1) * 16 + lp;
-    // weights: row (output channel) lp of the tap-major packed matrix; rows >= cout are zero
+    // weights: rows (output channels) lp, lp+16 of the tap-major packed matrix; rows >= cout are zero
     const T* const wlane = w_ro + p.woff[0] + (long long)lp * p.wrow[0] + kg * VEC;
-    f32x4 acc[4];
+    const long long wnt = 16ll * p.wrow[0];
+    f32x4 acc[4][NT];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { acc[g][0] = 0.f; acc[g][1] = 0.f; acc[g][2] = 0.f; acc[g][3] = 0.f; }
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { acc[g][n][0] = 0.f; acc[g][n][1] = 0.f; acc[g][n][2] = 0.f; acc[g][n][3] = 0.f; }
 
     for (int cc = 0; cc < ncc; ++cc) {
         if (cc > 0) __syncthreads();                                  // every wave is done with the previous chunk's patch
@@ -108,12 +112,14 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
         __syncthreads();
         const T* const wcc = wlane + cc * BKE;
         for (int dy = 0; dy < KS; ++dy) {
-            Frag bf[KS][2];                                           // one kernel row of weight fragments in flight
+            Frag bf[KS][2][NT];                                       // one kernel row of weight fragments in flight
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    bf[dx][h] = *reinterpret_cast<const Frag*>(wcc + (long long)(dy * KS + dx) * cs + h * 4 * VEC);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        bf[dx][h][n] = *reinterpret_cast<const Frag*>(wcc + n * wnt + (long long)(dy * KS + dx) * cs + h * 4 * VEC);
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
 #pragma unroll
@@ -124,27 +130,66 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const Frag a = *reinterpret_cast<const Frag*>(arow + (((h * 4 + kg) ^ ax) << 4));
-                        Mma16<T>::run(a, bf[dx][h], acc[g]);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) Mma16<T>::run(a, bf[dx][h][n], acc[g][n]);
                     }
                 }
             }
         }
     }
 
-    if (lp < p.cout && !(p.ablate & 4)) {
-        const long long hw = (long long)H * W;
-        const float bv = p.bias ? p.bias[lp] : 0.f;
+    // ---------------- epilogue: planar fp32 (+ activation) or raw fp32 NHWC + per-tile statistics ----------------
+    const bool raw_mode = p.out_mode == V2V_OUT_RAW_F32_NHWC;
+    const long long hw = (long long)H * W;
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        s1[n] = 0.f; s2[n] = 0.f;
+        const int co = n * 16 + lp;
+        const bool cvalid = co < p.cout;
+        const float bv = (p.bias && cvalid) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int oh = oh0 + 2 * wid + (g >> 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ow = ow0 + (g & 1) * 16 + kg * 4 + r;
-                if (oh < H && ow < W) {
-                    const float v = apply_act(acc[g][r] + bv, p.act, p.act_param) * p.out_scale;
-                    reinterpret_cast<float*>(p.out)[((long long)n_img * p.cout + lp) * hw + (long long)oh * W + ow] = v;
+                if (cvalid && oh < H && ow < W && !(p.ablate & 4)) {
+                    float v = acc[g][n][r] + bv;
+                    if (raw_mode) {
+                        s1[n] += v;
+                        s2[n] += v * v;
+                        reinterpret_cast<float*>(p.out)[(((long long)n_img * H + oh) * W + ow) * p.cout_stride + co] = v;
+                    } else {
+                        v = apply_act(v, p.act, p.act_param) * p.out_scale;
+                        reinterpret_cast<float*>(p.out)[((long long)n_img * p.cout + co) * hw + (long long)oh * W + ow] = v;
+                    }
                 }
             }
+        }
+    }
+    if (p.stats != nullptr) {
+        // lanes lp, lp+16, lp+32, lp+48 hold the same channel: fold the 4 k-groups, then the 4 waves through LDS
+        __syncthreads();                                              // the patch is dead: LDS becomes scratch
+        float* red = reinterpret_cast<float*>(smem);                  // [4 waves][16*NT][2]
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float a1 = s1[n], a2 = s2[n];
+            a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+            if (kg == 0) {
+                red[(wid * 16 * NT + n * 16 + lp) * 2 + 0] = a1;
+                red[(wid * 16 * NT + n * 16 + lp) * 2 + 1] = a2;
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * NT && tid < p.cout) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a1 += red[(w * 16 * NT + tid) * 2 + 0]; a2 += red[(w * 16 * NT + tid) * 2 + 1]; }
+            float* dst = p.stats + ((long long)mt * p.cout + tid) * 2;
+            dst[0] = a1;
+            dst[1] = a2;
         }
     }
 }
@@ -154,13 +199,16 @@ static inline int launch_head_typed(const ConvKArgs& k, hipStream_t s) {
     constexpr int PR = (8 + 6) * (32 + 6);
     constexpr int GP = ((PR + 7) / 8 + 3) / 4;
     const size_t lds = (size_t)GP * 4 * 1024;                         // 68 KiB: two workgroups per CU
-    auto kern = conv7x7_head_kernel<T>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv7x7_head_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv7x7_head_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)k.m_tiles), dim3(256), lds, s, k, reinterpret_cast<const T*>(k.w));
+    if (k.cout <= 16)
+        hipLaunchKernelGGL((conv7x7_head_kernel<T, 1>), dim3((unsigned)k.m_tiles), dim3(256), lds, s, k, reinterpret_cast<const T*>(k.w));
+    else
+        hipLaunchKernelGGL((conv7x7_head_kernel<T, 2>), dim3((unsigned)k.m_tiles), dim3(256), lds, s, k, reinterpret_cast<const T*>(k.w));
     return check_launch();
 }
 

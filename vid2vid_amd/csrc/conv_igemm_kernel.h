@@ -131,15 +131,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
         __syncthreads();
         if (!*flag) return;
         if (!helper) {
-            // every slab, the reducer's own included, is read back in slice order 0..S-1: the sum is the same
-            // whichever slice arrives last, and no second accumulator set is live
+            // S == 2: a + b is commutative, so the reducer adds the OTHER slice's slab to its own registers;
+            // S > 2: every slab, the reducer's own included, is read back and summed in slice order 0..S-1
+            if (S > 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
             for (int sl = 0; sl < S; ++sl) {
+                if (S == 2 && sl == slice) continue;
                 const unsigned off = (unsigned)sl * SLAB + (unsigned)tid * 16u;
                 u32x4 v[TM][TN][4];
 #pragma unroll

@@ -19,17 +19,47 @@ struct BnFinArgs {
     float* scale_shift; float* running_mean; float* running_var; float momentum;
 };
 
-// block = 256 threads = 64 channels x 4 row-phases
+// Stage 1 for layers with many statistics rows (large M: the fine scales of the 2048x1024 configs leave 4096-16384
+// rows; one workgroup reducing them serially, whether the conv kernel's last arriver or a 1-block finalize, measured
+// 0.6-1.0 ms, profiles/r01_v15_finalize_tail.txt): grid (C/64, G) blocks each reduce rows [g*rows/G, (g+1)*rows/G)
+// of 64 channels in a fixed order into fp64 (sum, sum^2) -> ws[g][C][2].  Deterministic (fixed tree).
+struct BnPartArgs { const float* partials; int rows; int C; int groups; double* ws; };
+
+__global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const BnPartArgs a) {
+    __shared__ double sh[4][64][2];
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int g = blockIdx.y;
+    const int r0 = (int)(((long long)a.rows * g) / a.groups), r1 = (int)(((long long)a.rows * (g + 1)) / a.groups);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < a.C) {
+        for (int r = r0 + ph; r < r1; r += 4) {
+            const float2 v = *reinterpret_cast<const float2*>(a.partials + ((long long)r * a.C + c) * 2);
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+    }
+    sh[ph][cx][0] = s1;
+    sh[ph][cx][1] = s2;
+    __syncthreads();
+    if (ph == 0 && c < a.C) {
+        a.ws[((long long)g * a.C + c) * 2 + 0] = ((sh[0][cx][0] + sh[1][cx][0]) + sh[2][cx][0]) + sh[3][cx][0];
+        a.ws[((long long)g * a.C + c) * 2 + 1] = ((sh[0][cx][1] + sh[1][cx][1]) + sh[2][cx][1]) + sh[3][cx][1];
+    }
+}
+
+// block = 256 threads = 64 channels x 4 row-phases; rows are fp32 pairs (conv epilogue) or fp64 pairs (stage 1)
+template <typename R>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinArgs a) {
     __shared__ double sh[4][64][2];
     const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
+    const R* rows_ = reinterpret_cast<const R*>(a.partials);
     double s1 = 0.0, s2 = 0.0;
     if (c < a.C) {
         for (int r = ph; r < a.rows; r += 4) {
-            const float2 v = *reinterpret_cast<const float2*>(a.partials + ((long long)r * a.C + c) * 2);
-            s1 += (double)v.x;
-            s2 += (double)v.y;
+            s1 += (double)rows_[((long long)r * a.C + c) * 2 + 0];
+            s2 += (double)rows_[((long long)r * a.C + c) * 2 + 1];
         }
     }
     sh[ph][cx][0] = s1;
@@ -56,11 +86,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinArgs a) {
 
 struct BnFinOp : Op {
     BnFinArgs a;
+    bool rows_f64 = false;
     int launch(hipStream_t s) override {
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(a.C, 64)), dim3(256), 0, s, a);
+        if (rows_f64) hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((unsigned)ceil_div(a.C, 64)), dim3(256), 0, s, a);
+        else          hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((unsigned)ceil_div(a.C, 64)), dim3(256), 0, s, a);
         return check_launch();
     }
     const char* name() const override { return "bn_finalize"; }
+};
+
+struct BnPartOp : Op {
+    BnPartArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3((unsigned)ceil_div(a.C, 64), (unsigned)a.groups), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "bn_partial_reduce"; }
 };
 
 struct BnApplyArgs {
@@ -350,14 +391,27 @@ static int bwd_blocks(long long P, long long* ppb) {
 
 using namespace v2v;
 
+extern "C" int v2v_bn_finalize_groups(int32_t rows) {
+    return rows > 512 ? (rows >= 64 * 128 ? 64 : (rows + 127) / 128) : 0;
+}
+
 extern "C" int v2v_bn_finalize(const float* partials, int32_t rows, int32_t C, int64_t count,
                                const float* gamma, const float* beta, float eps,
                                float* scale_shift, float* running_mean, float* running_var, float momentum,
-                               void* stream) {
+                               double* workspace, void* stream) {
     if (!partials || !scale_shift || rows <= 0 || C <= 0 || count <= 0) { set_error("bn_finalize: bad argument"); return V2V_EINVAL; }
+    const int groups = workspace ? v2v_bn_finalize_groups(rows) : 0;
+    if (groups > 0) {
+        auto p1 = std::make_unique<BnPartOp>();
+        p1->a.partials = partials; p1->a.rows = rows; p1->a.C = C; p1->a.groups = groups; p1->a.ws = workspace;
+        int rc = submit(std::move(p1), stream);
+        if (rc != 0) return rc;
+    }
     auto op = std::make_unique<BnFinOp>();
     BnFinArgs& a = op->a;
-    a.partials = partials; a.rows = rows; a.C = C;
+    a.partials = groups > 0 ? reinterpret_cast<const float*>(workspace) : partials;
+    a.rows = groups > 0 ? groups : rows; a.C = C;
+    op->rows_f64 = groups > 0;
     a.inv_count = 1.0 / (double)count;
     a.unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
     a.gamma = gamma; a.beta = beta; a.eps = eps;

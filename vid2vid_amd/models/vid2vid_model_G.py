@@ -67,7 +67,8 @@ class _FramePlan:
         eng.conv_log = []
         # encode_input (:86-112) + compute_mask (:322-330), fused, straight to NHWC
         if self.label_mode:
-            x0, mask0 = eng.encode_labels(self.labels, self.inst, tG, H, W, opt.label_nc, opt.fg_labels, opt.fg)
+            x0, mask0 = eng.encode_labels(self.labels, self.inst, tG, H, W, opt.label_nc, opt.fg_labels, opt.fg,
+                                          chunk_stride=S > 1)   # fine-scale stems (cout <= 32) use the LDS-patch 7x7 kernel
         else:
             x0, mask0 = eng.pack(self.raw_in), None
         xs, masks = [x0], [mask0]
