@@ -148,12 +148,33 @@ def main():
             bm, bn, _ = TILE_CFGS.get(dom_tile[0], (0, 0, False))
             fam = "conv_igemm_kernel"
             tile_name = "%dx%d,splitK=%d,prefetch=%d" % (bm, bn, dom_tile[1], dom_tile[2])
+        # HBM traffic of the dominant kernel: PMC counters of a separate rocprofv3 pass (scripts/gpu_visit3.sh `traffic`,
+        # scripts/pmc_traffic.py), committed under profiles/; only used when it was measured for this very configuration
+        traffic = None
+        try:
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+                tj = json.load(open(fn))
+                def dims(cfg):
+                    t_ = PATCH_CFGS.get(cfg[0])
+                    return (t_[0] * t_[1], t_[2], cfg[1]) if t_ else (cfg[0], 0, cfg[1])
+                if tj.get("cfg") and dims(tj["cfg"]) == dims(dom_tile) and tj.get("hbm_bytes_per_launch"):
+                    esz = 2 if args.precision == "bf16" else 4
+                    c0 = rb[0][1] if rb else None
+                    alg = None if c0 is None else (c0["N"] * c0["H"] * c0["W"] * c0["cin"] * esz + c0["cout"] * c0["cin"] * 9 * esz
+                                                   + c0["N"] * c0["OH"] * c0["OW"] * c0["cout"] * 4)
+                    traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": alg,
+                               "source": "profiles/" + os.path.basename(fn) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                               "passes, FETCH_SIZE x2 per the gfx950 correction; measured on the 1024->1024 3x3 layer)"}
+                    break
+        except Exception:
+            traffic = None
         roofline = {
             "bound": "mfma",
             "kernel": "%s<%s,%s> (tile config %d)" % (
                 fam, "bf16" if args.precision == "bf16" else "f32", tile_name, dom_tile[0]),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": None,
+            "traffic": traffic,
             "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
             "launches_per_frame": a["launches"] // nprof,
             "flop_per_launch": a["flops"] / a["launches"],

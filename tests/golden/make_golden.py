@@ -206,6 +206,43 @@ def golden_inference():
         save("inference_label2city_%s_32x64" % tag, **arrays)
 
 
+def golden_edge2face():
+    """BASELINE config C4 geometry (edge2face: label_nc = 0, input_nc = 15, no instance map, no fg tower;
+    scripts/face/test_512.sh): create_model(opt) -> inference over 3 generated frames, real first frames given."""
+    from options.test_options import TestOptions
+    from models import networks
+    from models.models import create_model
+    import tempfile
+    ck = tempfile.mkdtemp()
+    sys.argv = ["test.py", "--name", "g", "--label_nc", "0", "--input_nc", "15", "--loadSize", "64",
+                "--use_real_img", "--gpu_ids", "-1", "--checkpoints_dir", ck, "--ngf", "8", "--n_blocks", "2",
+                "--n_scales_spatial", "1", "--n_downsample_G", "2"]
+    opt = TestOptions().parse(save=False)
+    torch.manual_seed(77)
+    net = networks.define_G(45, 3, 6, opt.ngf, "composite", opt.n_downsample_G, opt.norm, 0, [], opt)
+    with torch.no_grad():
+        net.model_final_flow[1].weight.mul_(0.1)
+    os.makedirs(os.path.join(ck, "g"), exist_ok=True)
+    torch.save(net.state_dict(), os.path.join(ck, "g", "latest_net_G0.pth"))
+    model = create_model(opt)
+    gen = torch.Generator().manual_seed(78)
+    H, W, T = 32, 32, 5
+    A = torch.rand(1, T, 15, H, W, generator=gen)
+    A[:, :, 0] = (A[:, :, 0] < 0.05).float()                  # sparse binary edge channel + smooth maps
+    Bfirst = torch.tanh(torch.randn(1, 2, 3, H, W, generator=gen))
+    outs = []
+    model.fake_B_prev = None
+    for t in range(T - 2):
+        fake, real_A = model.inference(A[:, t:t + 3], Bfirst if t == 0 else None, None)
+        outs.append(fake.clone())
+        if t == 0:
+            last = real_A.clone()
+    arrays = sd_to_np(net.state_dict(), "sd0.")
+    arrays.update({"in.A": A.numpy(), "in.B": Bfirst.numpy(), "out.fake": torch.cat(outs).numpy(),
+                   "out.real_A_last": last.numpy()})
+    save("inference_edge2face_s1_32x32", **arrays)
+
+
 def golden_training():
     """One training chunk of the reference itself: Vid2VidModelG.forward (models/vid2vid_model_G.py:114-196),
     Vid2VidModelD.forward for the image and the temporal discriminators (models/vid2vid_model_D.py:93-213),
@@ -360,12 +397,15 @@ def main():
         return golden_training()
     if only == "flownet2":
         return golden_flownet2()
+    if only == "edge2face":
+        return golden_edge2face()
     from models import networks
     golden_composite(networks)
     golden_composite_local(networks)
     golden_discriminator(networks)
     golden_global(networks)
     golden_inference()
+    golden_edge2face()
     golden_training()
     golden_flownet2()
 

@@ -82,6 +82,22 @@ def test_inference_two_scales_matches_reference(golden):
     assert_close(fake, g["out.fake"], 1e-4, "inference S=2")
 
 
+def test_inference_edge2face_matches_reference(golden):
+    """Oracle pin for the raw multi-channel input path (BASELINE config C4 geometry: label_nc = 0, input_nc = 15)."""
+    g = golden("inference_edge2face_s1_32x32")
+    sds = [{k[len("sd0."):]: T(v) for k, v in g.items() if k.startswith("sd0.")}]
+    orc = O.InferenceOracle(sds, 0, False, False, [], 2, 2, 1)
+    A, B = T(g["in.A"]), T(g["in.B"])
+    outs = []
+    for t in range(A.shape[1] - 2):
+        fake, real_A = orc.step(A[:, t:t + 3], B if t == 0 else None, None)
+        outs.append(fake)
+        if t == 0:
+            assert torch.equal(real_A, T(g["out.real_A_last"]))
+    assert_close(torch.cat(outs), g["out.fake"], PIN, "edge2face inference")
+
+
+
 # ---- FlowNet2 native ops: no reference vectors exist (CUDA only) -> hand-computed cases ----
 def test_correlation_hand_cases():
     # 1x1 kernel, single channel: out[tj,ti](y,x) = f1(y,x)*f2(y+2tj, x+2ti) / C with zero padding

@@ -16,7 +16,9 @@ emitted launches either run immediately (eager) or are recorded into a `Plan` th
 replayed per frame as one native call / one hipGraph.  No torch compute op is on this path.
 """
 import ctypes as C
+import json
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -235,7 +237,17 @@ class Engine:
         self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
         self.tile_override = {}  # (cin,cout,KH,stride,transposed) -> tile id (tests / manual tuning)
         self.autotune = False    # measure the tile configurations once per conv shape (plan build time)
-        self._tuned = {}         # (cin,cout,KH,stride,transposed,N,H,W,out_mode) -> tile id
+        self._tuned = {}         # (cin,cout,KH,stride,transposed,N,H,W,out_mode,Cs) -> (tile, splitk, prefetch)
+        # optional persistent tuning cache (V2V_TUNE_CACHE=<json>): a profiling run can replay exactly the
+        # configurations a previous benchmark run selected instead of re-measuring them under the profiler
+        self._tune_cache_path = os.environ.get("V2V_TUNE_CACHE", "")
+        if self._tune_cache_path and os.path.exists(self._tune_cache_path):
+            try:
+                with open(self._tune_cache_path) as f:
+                    for k, v in json.load(f).get(str(dtype), {}).items():
+                        self._tuned[tuple(int(x) for x in k.split(","))] = tuple(v)
+            except (OSError, ValueError):
+                pass
         self.update_running_stats = False
         self.fused_finalize = True   # norm statistics finalized by the conv kernel's last workgroup (small layers)
         self.last_finalized = False  # did the last conv() finalize its statistics in-kernel?
@@ -397,6 +409,7 @@ class Engine:
         if (self.autotune and d.tile == 0 and self.plan is None and not self.record_only
                 and not torch.is_grad_enabled()):
             self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout, mod, x.Cs)
+            self._save_tune_cache()
             d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
             pc = self._use_korder1(d, mod, x.Cs) if 32 <= d.tile < 60 else self._use_korder0(d, mod, x.Cs)
             if want_stats:
@@ -413,6 +426,20 @@ class Engine:
                                   tile=lib.v2v_conv_tile_config(C.byref(d)), splitk=max(int(d.splitk), 1),
                                   prefetch=int(d.prefetch)))
         return out, rows, (N, OH, OW)
+
+    def _save_tune_cache(self):
+        if not self._tune_cache_path:
+            return
+        data = {}
+        if os.path.exists(self._tune_cache_path):
+            try:
+                with open(self._tune_cache_path) as f:
+                    data = json.load(f)
+            except (OSError, ValueError):
+                data = {}
+        data[str(self.dtype)] = {",".join(str(int(x)) for x in k): list(v) for k, v in self._tuned.items()}
+        with open(self._tune_cache_path, "w") as f:
+            json.dump(data, f)
 
     def _use_korder1(self, d, mod, cin_stride):
         """Point the descriptor at the channel-chunk-major packing of `mod` (patch-kernel tile ids >= 32)."""
