@@ -223,6 +223,23 @@ int v2v_avgpool3s2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W,
 int v2v_avgpool3s2_nhwc_backward(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t c_stride,
                                  int32_t dtype, void* stream);   /* H, W: the pooled layer's INPUT size */
 
+/* MaxPool2d(2, stride 2) on NHWC activations: the four pooling stages of torchvision's VGG19 `features` (indices 4, 9,
+ * 18, 27) inside Vgg19 (models/networks.py:840-870).  Floor output size; ties keep the first window element
+ * (ATen max_pool2d), which decides where the backward pass routes dY.  c_stride % (16 bytes) == 0. */
+int v2v_maxpool2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t c_stride,
+                      int32_t dtype, void* stream);
+int v2v_maxpool2_nhwc_backward(const void* dy, const void* x, void* dx, int32_t N, int32_t H, int32_t W,
+                               int32_t c_stride, int32_t dtype, void* stream);   /* H, W: the pooled layer's INPUT size */
+/* AvgPool2d(2, stride 2, count_include_pad=False), no padding, planar fp32 [planes][H][W]
+ * (VGGLoss.downsample, models/networks.py:782,785-786: applied while the width exceeds 1024). */
+int v2v_avgpool2_planar(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream);
+int v2v_avgpool2_planar_backward(const float* dy, float* dx, int64_t planes, int32_t H, int32_t W, void* stream);
+/* Planar fp32 one-hot (+ instance edge plane when inst != NULL) of ONE label frame:
+ * out[(label_nc + (inst != NULL))][H][W] = real_A[0][0, -1] of Vid2VidModelG.inference (models/vid2vid_model_G.py:209;
+ * encode_input :86-112, get_edges models/base_model.py:146-152). */
+int v2v_onehot_planar(const float* labels, const float* inst, float* out, int32_t H, int32_t W,
+                      int32_t label_nc, void* stream);
+
 /* encode_input (models/vid2vid_model_G.py:86-112) + get_edges (models/base_model.py:146-152)
  * + compute_mask (:322-330) for `T` frames, written straight to the NHWC stem input:
  *   out[h][w][t*(label_nc+use_inst) + c] = (label[t][h][w] == c),  edge in channel label_nc.

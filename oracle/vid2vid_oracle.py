@@ -601,11 +601,47 @@ def compute_loss_D(sdD, x_real, x_fake, n_layers_D, num_D, lambda_feat):
     return l_real, l_fake, l_gan, l_fm
 
 
-def model_D_image_losses(sdD, t, n_layers_D=3, num_D=2, lambda_feat=10.0, lambda_F=10.0, lambda_T=10.0, n_scales_spatial=1):
-    """Vid2VidModelD.forward(scale_T=0, ...) (models/vid2vid_model_D.py:110-166) with --no_vgg.
+# torchvision.models.vgg19().features, configuration 'E' (Simonyan & Zisserman 2014; torchvision is an external
+# dependency of the reference and absent here -- any version: the architecture has not changed): every conv is
+# Conv2d(3x3, padding 1) + ReLU, 'M' = MaxPool2d(2, 2).  Module indices: 0,2 | 4=M 5,7 | 9=M 10,12,14,16 | 18=M
+# 19,21,23,25 | 27=M 28.  Vgg19 (models/networks.py:840-870) cuts it into slices [0,2) [2,7) [7,12) [12,21) [21,30)
+# whose parameters are named slice<k>.<index>.*.
+_VGG_SLICES = [((0,), False), ((2, 5), True), ((7, 10), True), ((12, 14, 16, 19), True), ((21, 23, 25, 28), True)]
+_VGG_POOL_BEFORE = {5: True, 10: True, 19: True, 28: True}
+
+
+def vgg19_slices(sd, x):
+    """Vgg19.forward (models/networks.py:862-870): [h_relu1 .. h_relu5]."""
+    outs = []
+    for k, (idxs, _) in enumerate(_VGG_SLICES):
+        for idx in idxs:
+            if _VGG_POOL_BEFORE.get(idx):
+                x = F.max_pool2d(x, 2, 2)
+            x = F.relu(_conv(sd, "slice%d.%d" % (k + 1, idx), x, 1, 1))
+        outs.append(x)
+    return outs
+
+
+def vgg_loss(sd, x, y):
+    """VGGLoss.forward (models/networks.py:784-791): both inputs AvgPool2d(2,2)-ed while wider than 1024,
+    sum_i w_i * L1(vgg_i(x), vgg_i(y).detach())."""
+    while x.size(3) > 1024:
+        x, y = F.avg_pool2d(x, 2, 2, count_include_pad=False), F.avg_pool2d(y, 2, 2, count_include_pad=False)
+    xs, ys = vgg19_slices(sd, x), vgg19_slices(sd, y)
+    loss = 0
+    for w, a, b in zip([1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0], xs, ys):
+        loss = loss + w * F.l1_loss(a, b.detach())
+    return loss
+
+
+def model_D_image_losses(sdD, t, n_layers_D=3, num_D=2, lambda_feat=10.0, lambda_F=10.0, lambda_T=10.0, n_scales_spatial=1,
+                         sd_vgg=None):
+    """Vid2VidModelD.forward(scale_T=0, ...) (models/vid2vid_model_D.py:110-166); --no_vgg when sd_vgg is None.
     t: dict of (n, ch, H, W) tensors real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight,
     flow_ref, conf_ref.  Returns the dict keyed by loss_names."""
     out = {"G_VGG": torch.zeros(()), "W": torch.zeros(())}
+    if sd_vgg is not None:                                       # :136, :143-144
+        out["G_VGG"] = (vgg_loss(sd_vgg, t["fake_B"], t["real_B"]) + vgg_loss(sd_vgg, t["fake_B_raw"], t["real_B"])) * lambda_feat
     out["F_Flow"] = masked_l1(t["flow"], t["flow_ref"], t["conf_ref"]) * lambda_F / (2 ** (n_scales_spatial - 1))
     real_B_warp = resample(t["real_B_prev"], t["flow"])
     out["F_Warp"] = masked_l1(real_B_warp, t["real_B"], t["conf_ref"]) * lambda_T

@@ -155,3 +155,26 @@ def test_flownet2_checkpoint_keys_match_reference(golden):
     mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     assert mine == ref
     assert sum(int(np.prod(s)) for s in mine.values()) == 162518834
+
+
+def test_inference_lowering_census_edge2face_512():
+    """Record (not run) the per-frame plan of BASELINE config C4 (edge2face 512x512, input_nc=15, no fg tower) and
+    compare with SURVEY.md section 8(a7): 3434.4 GFLOP / frame, 365 M parameters."""
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models import create_model
+    if torch.cuda.is_available():
+        pytest.skip("dry-run census is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        opt = make_opt(label_nc=0, input_nc=15, use_instance=False, fg=False, use_real_img=True, random_init_ok=True,
+                       dataroot="datasets/face/", precision="bf16", gpu_ids=[])
+        m = create_model(opt)
+        assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 365.0) < 1.0
+        H = W = 512
+        fake, last = m.inference(torch.rand(1, 3, 15, H, W), torch.zeros(1, 2, 3, H, W), None)
+        assert fake.shape == (1, 3, H, W) and last.shape == (15, H, W)
+        assert abs(sum(c["flops"] for c in m._active_plan.conv_log) / 1e9 - 3434.4) < 1.0
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()

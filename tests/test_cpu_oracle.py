@@ -195,3 +195,22 @@ def test_training_oracle_vs_reference(golden):
         assert_close(sds["G1"][key].grad, g["gradG.G1." + key], 1e-3, "dG1 " + key)
     assert_close(sds["G0"]["model_res_img.0.conv_block.1.weight"].grad,
                  g["gradG.G0.model_res_img.0.conv_block.1.weight"], 1e-3, "dG0 resblock")
+
+
+def test_vgg_loss_oracle_vs_reference(golden):
+    """oracle.vgg19_slices / vgg_loss against the fixture produced by the reference's own VGGLoss / Vgg19 classes
+    (tests/golden/make_golden_vgg.py; torchvision's pretrained weights are a download -> seeded stand-in weights)."""
+    from util import seeded_vgg19_features, vgg19_slice_state_dict
+    g = golden("vgg_loss_32x64")
+    sd = vgg19_slice_state_dict(seeded_vgg19_features(int(g["seed"])))
+    x, y = T(g["in.x"]).requires_grad_(True), T(g["in.y"])
+    feats = O.vgg19_slices(sd, x)
+    for i, f in enumerate(feats):
+        assert_close(f.detach(), g["out.feat%d" % (i + 1)], PIN, "h_relu%d" % (i + 1))
+    loss = O.vgg_loss(sd, x, y)
+    assert abs(float(loss) - float(g["out.loss"])) <= 1e-5 * float(g["out.loss"])
+    loss.backward()
+    assert_close(x.grad, g["out.grad_x"], 1e-4, "d loss / d x")
+    gw = golden("vgg_loss_wide_64x1280")                    # > 1024 px wide: the AvgPool2d(2,2) branch
+    lw = O.vgg_loss(sd, T(gw["in.x"].astype(np.float32)), T(gw["in.y"].astype(np.float32)))
+    assert abs(float(lw) - float(gw["out.loss"])) <= 1e-5 * float(gw["out.loss"])

@@ -376,3 +376,58 @@ def test_fused_adam_matches_torch():
     p1.grad = torch.arange(5.0); p2.grad.copy_(torch.arange(5.0).to(DEV))
     o1.step(); o2.step()
     assert_close(p2.detach().cpu(), p1.detach(), 1e-6, "adam ttur")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 5, 16, 24), (2, 16, 17, 23), (1, 64, 8, 6), (1, 3, 2, 2)])
+def test_maxpool2_forward_backward(shape, prec):
+    """v2v_maxpool2_nhwc(+_backward) against F.max_pool2d autograd, incl. odd sizes (floor) and ties behind a ReLU
+    (ATen keeps the FIRST maximal element of a window; the gradient must go to the same one)."""
+    torch.manual_seed(5)
+    eng = _engine(prec)
+    x = torch.relu(torch.randn(*shape))                    # ~50 % exact zeros -> many all-zero windows (ties)
+    x = (x * 8).round() / 8                                 # exactly representable in bf16, more ties
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    r = ((torch.randn_like(yr) * 4).round() / 4)
+    (yr * r).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    y = eng.unpack(eng.maxpool2_nhwc(eng.pack(xg)))
+    assert torch.equal(y.detach().cpu(), yr.detach()), "forward"
+    (y * r.to(DEV)).sum().backward()
+    assert torch.equal(xg.grad.cpu(), xr.grad), "dX (argmax routing)"
+    with torch.no_grad():                                   # inference path (no autograd Function)
+        y2 = eng.unpack(eng.maxpool2_nhwc(eng.pack(x.to(DEV))))
+    assert torch.equal(y2.cpu(), yr.detach())
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 3, 9, 13)])
+def test_avgpool2_planar_forward_backward(shape):
+    torch.manual_seed(6)
+    eng = _engine("fp32")
+    x = torch.randn(*shape)
+    xr = x.clone().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 2, stride=2, count_include_pad=False)
+    r = torch.randn_like(yr)
+    (yr * r).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    y = eng.avgpool2_planar(xg)
+    assert_close(y.detach().cpu(), yr.detach(), 1e-6, "forward")
+    (y * r.to(DEV)).sum().backward()
+    assert_close(xg.grad.cpu(), xr.grad, 1e-6, "dX")
+    with torch.no_grad():
+        assert_close(eng.avgpool2_planar(x.to(DEV)).cpu(), yr.detach(), 1e-6, "forward (no grad)")
+
+
+def test_onehot_planar_matches_encode_input():
+    from oracle import vid2vid_oracle as O
+    torch.manual_seed(7)
+    eng = _engine("fp32")
+    H, W = 19, 37
+    lab = torch.randint(0, 35, (1, 1, 1, H, W)).float()
+    inst = torch.randint(0, 4, (1, 1, 1, H // 4 + 1, W // 4 + 1)).float().repeat_interleave(4, 3).repeat_interleave(4, 4)[..., :H, :W]
+    ref = O.encode_input(lab, inst.contiguous(), 35)[0, 0]
+    got = eng.onehot_planar(lab[0, 0, 0].to(DEV).contiguous(), inst[0, 0, 0].to(DEV).contiguous(), H, W, 35)
+    assert torch.equal(got.cpu(), ref)
+    got = eng.onehot_planar(lab[0, 0, 0].to(DEV).contiguous(), None, H, W, 35)
+    assert torch.equal(got.cpu(), ref[:35])

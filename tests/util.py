@@ -54,3 +54,37 @@ def seeded_flownet2_weights(shapes, seed=2024, flow_head_scale=1.0):
                 w *= flow_head_scale
         out[name] = torch.from_numpy(w)
     return out
+
+
+# torchvision.models.vgg19().features, configuration 'E': index -> out channels of the Conv2d(3x3, pad 1) there
+VGG19_FEATURE_CONVS = {0: (3, 64), 2: (64, 64), 5: (64, 128), 7: (128, 128), 10: (128, 256), 12: (256, 256),
+                       14: (256, 256), 16: (256, 256), 19: (256, 512), 21: (512, 512), 23: (512, 512), 25: (512, 512),
+                       28: (512, 512), 30: (512, 512), 32: (512, 512), 34: (512, 512)}
+
+
+def seeded_vgg19_features(seed=77, upto=30):
+    """Deterministic, host-independent stand-in for torchvision's pretrained vgg19 `features` state_dict (a download;
+    12.9 M values up to index 30 are too many for a fixture): numpy MT19937, one stream per tensor.  He-scaled uniform
+    weights (variance 2/fan_in keeps activations O(1) through 13 layers) and small non-zero biases.
+    Returns {'features.<idx>.weight' / '.bias': tensor}."""
+    out = {}
+    for idx, (cin, cout) in sorted(VGG19_FEATURE_CONVS.items()):
+        if idx >= upto:
+            continue
+        rs = np.random.RandomState(seed * 1000 + idx)
+        a = float(np.sqrt(3.0 * 2.0 / (cin * 9)))
+        out["features.%d.weight" % idx] = torch.from_numpy(rs.uniform(-a, a, size=(cout, cin, 3, 3)).astype(np.float32))
+        out["features.%d.bias" % idx] = torch.from_numpy(rs.uniform(-0.05, 0.05, size=(cout,)).astype(np.float32))
+    return out
+
+
+def vgg19_slice_state_dict(features_sd):
+    """torchvision 'features.<idx>.*' keys -> the reference Vgg19's 'slice<k>.<idx>.*' keys (models/networks.py:846-860)."""
+    cuts = [(0, 2), (2, 7), (7, 12), (12, 21), (21, 30)]
+    out = {}
+    for k, v in features_sd.items():
+        idx = int(k.split(".")[1])
+        for s, (lo, hi) in enumerate(cuts):
+            if lo <= idx < hi:
+                out["slice%d.%s" % (s + 1, k[len("features."):])] = v
+    return out

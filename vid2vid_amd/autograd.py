@@ -161,6 +161,7 @@ class ConvFn(torch.autograd.Function):
                 check(int(nbytes) or -1, "conv_wgrad_workspace " + cfg.label)
             d.workspace = eng.scratch("wgrad_ws", (nbytes + 3) // 4).data_ptr()
             check(lib.v2v_conv_wgrad(C.byref(d), st), "conv_wgrad " + cfg.label)
+            eng.log_backward("wgrad", cfg.label, conv, cfg.cin, cout, N, x.H * x.W if transposed else OH * OW)
         # ---- input ----
         dx = None
         if ctx.needs_input_grad[1]:
@@ -191,7 +192,9 @@ def _conv_backward_data(eng, cfg, conv, transposed, g, cout, x, N, OH, OW):
     d.transposed = int(pc.transposed)
     d.OH, d.OW = HO, WO
     d.dtype, d.out_mode, d.act, d.act_param, d.out_scale, d.tile = eng.dtype, L.OUT_ACT_NHWC, L.ACT_NONE, 0.0, 1.0, 0
+    eng.tune_backward_data(d, cfg.cin)
     check(lib.v2v_conv2d(C.byref(d), _stream()), "conv backward-data " + cfg.label)
+    eng.log_backward("bwd_data", cfg.label, conv, cfg.cin, cout, N, H * W if transposed else OH * OW)
     if not reflect:
         return out
     dx = torch.empty((N, H, W, x.Cs), dtype=eng.tdtype, device=eng.device)
@@ -293,6 +296,52 @@ class AvgPoolFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty((N, H, W, cs), dtype=dy.dtype, device=dy.device)
         check(lib.v2v_avgpool3s2_nhwc_backward(_ptr(dy), _ptr(dx), N, H, W, cs, eng.dtype, _stream()), "avgpool_backward")
+        return None, dx
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    """MaxPool2d(2, 2) on NHWC (torchvision VGG19 `features` 4 / 9 / 18 / 27 inside Vgg19, networks.py:840-870)."""
+
+    @staticmethod
+    def forward(ctx, eng, x):
+        N, H, W, cs = x.shape[0], x.shape[1], x.shape[2], x.stride(2)
+        y = torch.empty((N, H // 2, W // 2, cs), dtype=x.dtype, device=x.device)
+        check(lib.v2v_maxpool2_nhwc(_ptr(x), _ptr(y), N, H, W, cs, eng.dtype, _stream()), "maxpool2")
+        ctx.eng, ctx.dims = eng, (N, H, W, cs)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.eng
+        N, H, W, cs = ctx.dims
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty((N, H, W, cs), dtype=dy.dtype, device=dy.device)
+        check(lib.v2v_maxpool2_nhwc_backward(_ptr(dy), _ptr(x), _ptr(dx), N, H, W, cs, eng.dtype, _stream()),
+              "maxpool2_backward")
+        return None, dx
+
+
+class AvgPool2PlanarFn(torch.autograd.Function):
+    """AvgPool2d(2, stride 2, count_include_pad=False) on planar fp32 (VGGLoss.downsample, networks.py:782-786)."""
+
+    @staticmethod
+    def forward(ctx, eng, x):
+        x = x.contiguous().float()
+        H, W = x.shape[-2], x.shape[-1]
+        planes = x.numel() // (H * W)
+        y = torch.empty(tuple(x.shape[:-2]) + (H // 2, W // 2), dtype=torch.float32, device=x.device)
+        check(lib.v2v_avgpool2_planar(_ptr(x), _ptr(y), planes, H, W, _stream()), "avgpool2")
+        ctx.dims = (tuple(x.shape), planes, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, planes, H, W = ctx.dims
+        dy = dy.contiguous().float()
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        check(lib.v2v_avgpool2_planar_backward(_ptr(dy), _ptr(dx), planes, H, W, _stream()), "avgpool2_backward")
         return None, dx
 
 

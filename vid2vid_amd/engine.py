@@ -420,12 +420,39 @@ class Engine:
         check(lib.v2v_conv2d(C.byref(d), _stream()), "conv2d " + label)
         self.label(label)
         ntaps = pc.KH * pc.KW
+        if len(self.conv_log) >= 100000:          # eager (training) use without a consumer: keep the log bounded
+            del self.conv_log[:]
         self.conv_log.append(dict(label=label, N=N, H=H, W=W, OH=OH, OW=OW, cin=pc.cin, cout=pc.cout,
                                   KH=pc.KH, KW=pc.KW, stride=pc.stride, transposed=pc.transposed,
                                   flops=2.0 * N * (H * W if pc.transposed else OH * OW) * pc.cout * pc.cin * ntaps,
                                   tile=lib.v2v_conv_tile_config(C.byref(d)), splitk=max(int(d.splitk), 1),
                                   prefetch=int(d.prefetch)))
         return out, rows, (N, OH, OW)
+
+    def tune_backward_data(self, d, dx_channels):
+        """Tile selection for a backward-data launch (autograd._conv_backward_data): same measured search as the
+        forward convs (implicit-GEMM tiles x split-K; the operator is the forward kernel with role-swapped weights),
+        keyed separately (leading -1) in the same tuning table.  Measured only while `autotune` is on (the first
+        training steps of bench.py --mode train); later steps replay the selection."""
+        key = (-1, d.cin, d.cout, d.KH, d.stride, d.transposed, d.N, d.H, d.W, d.cin_stride, d.cout_stride, d.pad)
+        if key not in self._tuned:
+            if not (self.autotune and self.plan is None and not self.record_only):
+                d.tile, d.splitk, d.prefetch = 0, 0, 0
+                self._splitk_workspace(d)
+                return
+            self._tuned[key] = self._autotune(d, False, dx_channels)
+            self._save_tune_cache()
+        d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[key])
+        if not self._splitk_workspace(d):
+            d.tile, d.splitk, d.prefetch = 0, 0, 0
+            self._splitk_workspace(d)
+
+    def log_backward(self, kind, label, conv, cin, cout, N, pixels):
+        """Algorithmic FLOP of a backward launch (same count as its forward conv), for bench.py's training roofline."""
+        if len(self.conv_log) < 100000:
+            self.conv_log.append(dict(label=kind + ":" + label, kind=kind, cin=cin, cout=cout, KH=conv.kernel_size[0],
+                                      KW=conv.kernel_size[1], N=N, tile=-1, splitk=1, prefetch=0,
+                                      flops=2.0 * N * pixels * cout * cin * conv.kernel_size[0] * conv.kernel_size[1]))
 
     def _save_tune_cache(self):
         if not self._tune_cache_path:
@@ -804,6 +831,37 @@ class Engine:
             out = Act(t, x.C)
         check(lib.v2v_avgpool3s2_nhwc(_ptr(x.t), _ptr(out.t), x.N, x.H, x.W, x.Cs, self.dtype, _stream()), "avgpool_nhwc")
         self.label("avgpool3s2_nhwc")
+        return out
+
+    def maxpool2_nhwc(self, x):
+        """MaxPool2d(2, 2) (VGG19 features inside Vgg19, models/networks.py:840-870)."""
+        if self._training() and x.t.requires_grad:
+            from . import autograd as AG
+            return Act(AG.MaxPool2Fn.apply(self, x.t), x.C)
+        t = torch.empty((x.N, x.H // 2, x.W // 2, x.Cs), dtype=self.tdtype, device=self.device)
+        self._keep(t)
+        check(lib.v2v_maxpool2_nhwc(_ptr(x.t), _ptr(t), x.N, x.H, x.W, x.Cs, self.dtype, _stream()), "maxpool2_nhwc")
+        self.label("maxpool2_nhwc")
+        return Act(t, x.C)
+
+    def avgpool2_planar(self, x):
+        """AvgPool2d(2, stride 2, count_include_pad=False) on planar fp32 [..., H, W] (VGGLoss.downsample)."""
+        if self._training() and x.requires_grad:
+            from . import autograd as AG
+            return AG.AvgPool2PlanarFn.apply(self, x)
+        x = x.contiguous().float()
+        H, W = x.shape[-2], x.shape[-1]
+        out = self.empty_f32(*x.shape[:-2], H // 2, W // 2)
+        check(lib.v2v_avgpool2_planar(_ptr(x), _ptr(out), x.numel() // (H * W), H, W, _stream()), "avgpool2_planar")
+        self.label("avgpool2_planar")
+        return out
+
+    def onehot_planar(self, labels, inst, H, W, label_nc):
+        """Planar fp32 one-hot (+ edge plane) of one label frame: `real_A[0][0, -1]` (vid2vid_model_G.py:209)."""
+        per = label_nc + (1 if inst is not None else 0)
+        out = self.empty_f32(per, H, W)
+        check(lib.v2v_onehot_planar(_ptr(labels), _ptr(inst), _ptr(out), H, W, label_nc, _stream()), "onehot_planar")
+        self.label("onehot_planar")
         return out
 
     def avgpool_planar(self, x):

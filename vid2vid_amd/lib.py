@@ -90,6 +90,11 @@ PROTOTYPES = {
     "v2v_bn_apply": (C.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
     "v2v_avgpool3s2_planar": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "v2v_avgpool3s2_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_maxpool2_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_maxpool2_nhwc_backward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "v2v_avgpool2_planar": (C.c_int, [_P, _P, _L, _I, _I, _P]),
+    "v2v_avgpool2_planar_backward": (C.c_int, [_P, _P, _L, _I, _I, _P]),
+    "v2v_onehot_planar": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "v2v_encode_labels": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "v2v_fg_mask_nhwc": (C.c_int, [_P, _P, _L, _I, _I, _P, _I, _I, _P]),
     "v2v_pack_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -24,19 +24,23 @@ class _FlowPlan:
         self.im2 = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
         self.flow = self.conf = None
         if not eng.record_only:
+            prev_autotune = eng.autotune
             eng.autotune = bool(getattr(model.opt, "autotune", True))
             try:
                 self._emit()                   # sizes the shared scratch, picks tile configurations
             finally:
-                eng.autotune = False
+                eng.autotune = prev_autotune
             torch.cuda.synchronize(dev)
         self.plan = Plan()
         eng.plan = self.plan
+        n0 = len(eng.conv_log)
         try:
             with self.plan:
                 self._emit()
         finally:
             eng.plan = None
+        self.conv_flops = sum(c["flops"] for c in eng.conv_log[n0:])     # algorithmic FLOP of one replay (bench roofline)
+        self.n_convs = len(eng.conv_log) - n0
         if use_graph and not eng.record_only:
             self.plan.instantiate_graph()
 
@@ -85,6 +89,7 @@ class FlowNet(BaseModel):
         for p in self.flowNet.parameters():
             p.requires_grad_(False)
         self._plans = {}
+        self.flops_launched, self.convs_launched = 0.0, 0
 
     def forward(self, input_A, input_B, dummy_bs=0):
         with torch.no_grad():
@@ -111,4 +116,6 @@ class FlowNet(BaseModel):
         fp.im2.copy_(im2.to(self.device, torch.float32))
         if not self.engine.record_only:
             fp.plan.launch()
+            self.flops_launched += fp.conv_flops
+            self.convs_launched += fp.n_convs
         return fp.flow.clone(), fp.conf.clone()

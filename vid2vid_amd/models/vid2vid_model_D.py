@@ -26,9 +26,10 @@ class Vid2VidModelD(BaseModel):
         self.n_scales = opt.n_scales_spatial
         if opt.add_face_disc:
             raise NotImplementedError("--add_face_disc (pose recipes) is outside the MI355X hot path (SURVEY 8a13)")
-        if not opt.no_vgg:
-            raise NotImplementedError("VGG19 perceptual loss needs downloaded torchvision weights "
-                                      "(SURVEY 8f rank 1): train with --no_vgg")
+        if not opt.no_vgg:          # reference :66-67; the weights are torchvision's download -> a path option here
+            self.criterionVGG = networks.VGGLoss(self.device.index if self.device.type == "cuda" else -1,
+                                                 getattr(opt, "vgg19_checkpoint", "checkpoints/vgg19-dcbb9e9d.pth"),
+                                                 getattr(opt, "random_init_ok", False))
         if opt.gan_mode != "ls":
             raise NotImplementedError("only the LSGAN objective (--gan_mode ls, the reference default) is implemented")
 
@@ -160,6 +161,10 @@ class Vid2VidModelD(BaseModel):
 
         # ---- image GAN + feature matching (reference :133-147) ----
         loss_G_VGG = self._zero()
+        vgg_real = None
+        if not opt.no_vgg:
+            vgg_real = self.criterionVGG.features(real_B)            # shared by the fake_B and fake_B_raw terms
+            loss_G_VGG = self.criterionVGG(fake_B, real_B, vgg_real) * lambda_feat
         loss_D_real, loss_D_fake, loss_G_GAN, loss_G_GAN_Feat = self.compute_loss_D(self.netD, real_A, real_B, fake_B)
         with torch.no_grad():
             fake_B_warp_ref = eng.resample_flow(fake_B_prev.detach().contiguous(), flow_ref.contiguous())
@@ -170,6 +175,8 @@ class Vid2VidModelD(BaseModel):
             loss_G_GAN_Feat = loss_G_GAN_Feat + l_G_GAN_Feat
             loss_D_real = loss_D_real + l_D_real
             loss_D_fake = loss_D_fake + l_D_fake
+            if not opt.no_vgg:
+                loss_G_VGG = loss_G_VGG + self.criterionVGG(fake_B_raw, real_B, vgg_real) * lambda_feat
 
         loss_list = [loss_G_VGG, loss_G_GAN, loss_G_GAN_Feat, loss_D_real, loss_D_fake,
                      loss_G_Warp, loss_F_Flow, loss_F_Warp, loss_W]

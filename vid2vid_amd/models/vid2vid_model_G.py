@@ -44,11 +44,12 @@ class _FramePlan:
         self.out = {}
         # warm-up pass sizes the shared scratch, then the same code is recorded
         if not eng.record_only:
+            prev_autotune = eng.autotune
             eng.autotune = bool(getattr(opt, "autotune", True))      # per-shape tile selection, measured once
             try:
                 self._emit()
             finally:
-                eng.autotune = False
+                eng.autotune = prev_autotune
             torch.cuda.synchronize(dev)
         self.plan = Plan()
         eng.plan = self.plan
@@ -94,8 +95,12 @@ class _FramePlan:
             self.out["flow%d" % si], self.out["weight%d" % si], self.out["raw%d" % si] = flow, weight, raw
         self.out["fake_B"] = fake_B
         # real_A[0][0, -1]: encoded last label frame, returned for visualisation (:209)
-        last = Act(x0.t[..., (tG - 1) * per:], per)
-        self.out["real_A_last"] = eng.unpack(last)[0]
+        if self.label_mode:      # straight from the label map: coalesced planar writes, no NHWC -> NCHW transpose
+            self.out["real_A_last"] = eng.onehot_planar(self.labels[tG - 1], None if self.inst is None else self.inst[tG - 1],
+                                                        H, W, opt.label_nc)
+        else:
+            last = Act(x0.t[..., (tG - 1) * per:], per)
+            self.out["real_A_last"] = eng.unpack(last)[0]
         self.conv_log = list(eng.conv_log)
 
     def _roll(self, prev, fake_B):

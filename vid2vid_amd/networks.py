@@ -537,3 +537,124 @@ class MultiscaleDiscriminator(nn.Module):
         eng = get_engine(input.device)
         res = self.emit(eng, eng.pack(input.contiguous().float()))
         return [[eng.unpack(f) for f in feats] for feats in res]
+
+
+# --------------------------------------------------------------------------------------
+# VGG19 perceptual loss (models/networks.py:776-791, 840-870)
+# --------------------------------------------------------------------------------------
+# torchvision.models.vgg19().features (configuration 'E' of Simonyan & Zisserman; torchvision is an external
+# dependency of the reference, absent here): index -> module, 'M' = MaxPool2d(2, 2), every conv is
+# Conv2d(k=3, padding=1) followed by ReLU(inplace).  The reference cuts it at indices 2 / 7 / 12 / 21 / 30.
+_VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+_VGG19_SLICES = [(0, 2), (2, 7), (7, 12), (12, 21), (21, 30)]
+
+
+def _vgg19_feature_modules():
+    mods, cin = [], 3
+    for v in _VGG19_CFG:
+        if v == "M":
+            mods.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            mods += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return mods
+
+
+class Vgg19(nn.Module):
+    """Frozen VGG19 feature extractor with the reference's slice layout: parameters are named
+    `slice{1..5}.<features index>.{weight,bias}` exactly like models/networks.py:840-870, and `load_features`
+    accepts torchvision's own `vgg19` state_dict (`features.<index>.*`).  The pretrained weights are an external
+    download (torchvision model zoo) -- `VGGLoss` takes a path; random init is only for benchmarks / tests."""
+
+    def __init__(self, requires_grad=False):
+        super().__init__()
+        feats = _vgg19_feature_modules()
+        for k, (lo, hi) in enumerate(_VGG19_SLICES):
+            seq = nn.Sequential()
+            for x in range(lo, hi):
+                seq.add_module(str(x), feats[x])
+            setattr(self, "slice%d" % (k + 1), seq)
+        for m in self.modules():                      # torchvision's VGG._initialize_weights
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.constant_(m.bias, 0)
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def load_features(self, state_dict):
+        own = self.state_dict()
+        mapped = {}
+        for k, v in state_dict.items():
+            if k.startswith("features."):
+                idx = int(k.split(".")[1])
+                for s, (lo, hi) in enumerate(_VGG19_SLICES):
+                    if lo <= idx < hi:
+                        mapped["slice%d.%s" % (s + 1, k[len("features."):])] = v
+            elif k in own:
+                mapped[k] = v
+        self.load_state_dict(mapped)
+
+    def emit(self, eng, x, tag="vgg"):
+        """x: Act (NHWC, 3 channels).  Returns [h_relu1 .. h_relu5] as Acts."""
+        outs = []
+        for k in range(5):
+            mods = list(getattr(self, "slice%d" % (k + 1)))
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, nn.MaxPool2d):
+                    x = eng.maxpool2_nhwc(x)
+                    i += 1
+                else:                               # Conv2d + ReLU, bias and activation in the conv epilogue
+                    x = eng.conv_group(x, m, L.PAD_ZERO, None, None, L.ACT_RELU, 0.0, label="%s.s%d.%d" % (tag, k + 1, i))
+                    i += 2
+            outs.append(x)
+        return outs
+
+    def forward(self, X):
+        eng = get_engine(X.device)
+        return [eng.unpack(f) for f in self.emit(eng, eng.pack(X.contiguous().float()))]
+
+
+class VGGLoss(nn.Module):
+    """sum_i w_i * L1(vgg_i(x), vgg_i(y).detach()), w = 1/32, 1/16, 1/8, 1/4, 1; both inputs are average-pooled 2x
+    while wider than 1024 px (models/networks.py:776-791).  Returns a (1,1) fp32 tensor."""
+
+    def __init__(self, gpu_id=0, checkpoint="", random_init_ok=False):
+        super().__init__()
+        import os
+        self.vgg = Vgg19()
+        if checkpoint and os.path.isfile(checkpoint):
+            self.vgg.load_features(torch.load(checkpoint, map_location="cpu"))
+        elif not random_init_ok:
+            raise RuntimeError("VGG19 weights not found (%r): the reference downloads torchvision's pretrained vgg19; "
+                               "pass --vgg19_checkpoint <vgg19-dcbb9e9d.pth> or train with --no_vgg" % checkpoint)
+        if gpu_id is not None and gpu_id >= 0 and torch.cuda.is_available():
+            self.vgg.cuda(gpu_id)
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+    def _prep(self, eng, x):
+        x = x.contiguous().float()
+        while x.size(3) > 1024:
+            x = eng.avgpool2_planar(x)
+        return x
+
+    def features(self, x):
+        """VGG features of a target image batch (no gradient): computed once per frame and shared by the
+        fake_B and fake_B_raw terms (vid2vid_model_D.py:136,144 evaluate vgg(real_B) twice)."""
+        eng = get_engine(x.device)
+        with torch.no_grad():
+            return self.vgg.emit(eng, eng.pack(self._prep(eng, x)), tag="vgg.y")
+
+    def forward(self, x, y, y_feats=None):
+        from . import autograd as AG
+        eng = get_engine(x.device)
+        if y_feats is None:
+            y_feats = self.features(y)
+        x_feats = self.vgg.emit(eng, eng.pack(self._prep(eng, x)), tag="vgg.x")
+        loss = None
+        for i in range(len(x_feats)):
+            l = AG.l1_act(eng, x_feats[i], y_feats[i], weight=self.weights[i])
+            loss = l if loss is None else loss + l
+        return loss

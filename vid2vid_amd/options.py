@@ -26,6 +26,7 @@ _DEFAULTS = dict(
     # vid2vid_amd additions
     precision=None,           # 'fp32' | 'bf16' | None (None: bf16 iff opt.fp16)
     random_init_ok=False,     # allow create_model() without a G0 checkpoint (benchmarks / smoke)
+    vgg19_checkpoint="checkpoints/vgg19-dcbb9e9d.pth",   # torchvision's vgg19 state_dict (the reference downloads it)
 )
 
 

@@ -29,3 +29,18 @@ def label2city_sequence(T, H, W, seed=1234, n_labels=35, n_inst=20, fg_label=26,
     inst = torch.stack(insts).float().to(device)
     frames = torch.stack(imgs).unsqueeze(0).to(device)
     return lab, inst, frames
+
+
+def edge2face_sequence(T, H, W, seed=1234, input_nc=15, device="cpu"):
+    """Returns (A (1,T,input_nc,H,W), frames (1,T,3,H,W)) for the edge2face geometry: channel 0 sparse
+    binary edges (p = 0.02), channels 1.. smooth maps in [0,1]; 2 px/frame roll in x."""
+    gen = torch.Generator().manual_seed(seed)
+    edges = (torch.rand(1, H, W, generator=gen) < 0.02).float()
+    smooth = torch.sigmoid(F.interpolate(torch.randn(1, input_nc - 1, max(H // 16, 1), max(W // 16, 1), generator=gen),
+                                         size=(H, W), mode="bilinear", align_corners=False))[0]
+    a0 = torch.cat([edges, smooth], 0)
+    img0 = torch.tanh(F.interpolate(torch.randn(1, 3, max(H // 8, 1), max(W // 8, 1), generator=gen),
+                                    size=(H, W), mode="bilinear", align_corners=False))[0]
+    A = torch.stack([torch.roll(a0, 2 * t, dims=2) for t in range(T)]).unsqueeze(0).contiguous().to(device)
+    frames = torch.stack([torch.roll(img0, 2 * t, dims=2) for t in range(T)]).unsqueeze(0).contiguous().to(device)
+    return A, frames
