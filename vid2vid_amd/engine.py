@@ -72,8 +72,9 @@ _PARAM_EPOCH = [0]
 
 
 def bump_param_epoch():
-    """Called by optimizers that update parameters through a flat buffer (optim.FusedAdam): packed
-    weight copies are refreshed on next use."""
+    """Force every packed weight copy to be refreshed on next use (parameters changed behind torch's back by
+    something other than optim.FusedAdam, which bumps the per-buffer counter of its own parameters instead -- frozen
+    networks such as FlowNet2 / VGG19 are then never re-packed by a training step)."""
     _PARAM_EPOCH[0] += 1
 
 
@@ -121,7 +122,9 @@ class PackedConv:
     def refresh(self, force=False):
         """(Re)pack if the parameter changed (optimizer step / load_state_dict)."""
         w = self.mod.weight
-        ver = (w._version, w.data_ptr(), None if self.mod.bias is None else self.mod.bias._version, _PARAM_EPOCH[0])
+        box = getattr(w, "_v2v_epoch", None)       # optim.FlatBuffers: bumped by the fused optimizer that owns `w`
+        ver = (w._version, w.data_ptr(), None if self.mod.bias is None else self.mod.bias._version, _PARAM_EPOCH[0],
+               0 if box is None else box[0])
         if not force and ver == self.version:
             return
         w32 = w.detach()

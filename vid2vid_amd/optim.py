@@ -37,12 +37,16 @@ class FlatBuffers:
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets = offs
+        # update counter of THIS buffer: the fused optimizer writes flat_param from a HIP kernel (invisible to torch's
+        # tensor version counters), so packed weight copies (engine.PackedConv) watch this box through the parameter
+        self.epoch = [0]
         with torch.no_grad():
             for p, o in zip(self.params, offs):
                 view = self.flat_param[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+                p._v2v_epoch = self.epoch
 
     def rebind_grads(self):
         """Re-attach `.grad` views (e.g. after a foreign zero_grad(set_to_none=True))."""
@@ -77,7 +81,6 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("closures are not used by vid2vid")
         from .lib import lib, check
-        from .engine import bump_param_epoch
         f = self.flat
         if not f.flat_param.is_cuda:
             raise RuntimeError("FusedAdam runs on the MI355X only")
@@ -93,5 +96,5 @@ class FusedAdam(torch.optim.Optimizer):
                                 f.numel, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
                                 float(grp["weight_decay"]), float(gscale), self.step_count,
                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "adam_step")
-        bump_param_epoch()                                   # packed weight copies are now stale
+        f.epoch[0] += 1                                      # packed copies of THESE parameters are now stale
         return None
