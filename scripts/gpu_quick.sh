@@ -1,0 +1,31 @@
+#!/bin/bash
+# Short GPU visit for kernel iteration: probe, micro-benchmarks, the training-op parity tests, a short training bench.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+TAG=${1:-q}; shift
+WHAT=${*:-probe wgrad tests train}
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+if has probe; then timeout 60 scripts/probe_tr16.bin > gpurun_out/${TAG}_probe_tr16.txt 2>&1; head -20 gpurun_out/${TAG}_probe_tr16.txt; fi
+if has wgrad; then
+  timeout 300 python scripts/wgrad_bench.py > gpurun_out/${TAG}_wgrad.txt 2>&1; echo "wgrad rc=$?"; tail -12 gpurun_out/${TAG}_wgrad.txt
+  V2V_WGRAD_BF16=legacy timeout 300 python scripts/wgrad_bench.py > gpurun_out/${TAG}_wgrad_legacy.txt 2>&1; echo "wgrad(legacy) rc=$?"; tail -10 gpurun_out/${TAG}_wgrad_legacy.txt | cut -c1-110
+fi
+if has tests; then
+  timeout 600 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 180 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest.log | tail -20
+fi
+if has alltests; then
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 180 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest.log | tail -20
+fi
+if has train; then
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune_train.json timeout 600 python bench.py --mode train --steps 12 --warmup 3 --with-vgg > gpurun_out/${TAG}_train_512_vgg_bf16.json 2> gpurun_out/${TAG}_train_512_vgg_bf16.err; echo "train rc=$?"
+  cut -c1-250 gpurun_out/${TAG}_train_512_vgg_bf16.json; tail -2 gpurun_out/${TAG}_train_512_vgg_bf16.err
+fi
+if has trainprof; then
+  cd /tmp; export TMPDIR=/tmp
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune_train.json timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/proft_$TAG -o bench -- python $R/bench.py --mode train --steps 6 --warmup 3 --with-vgg > $R/gpurun_out/${TAG}_train_prof.json 2> $R/gpurun_out/${TAG}_train_prof.err; echo "rocprof train rc=$?"
+  python $R/scripts/rocprof_summary.py $(find /tmp/proft_$TAG -name "*.db" | head -1) "# visit $TAG: V2V_TUNE_CACHE=<selections of the preceding run> rocprofv3 --kernel-trace --stats -- python bench.py --mode train --steps 6 --warmup 3 --with-vgg (bf16, 512x256, 2 frames per chunk)" > $R/gpurun_out/${TAG}_train_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_train_prof.err
+  head -22 $R/gpurun_out/${TAG}_train_kernel_stats.txt | cut -c1-180
+  cd $R
+fi

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""v2v_conv_wgrad: bf16-MFMA kernel vs the exact-fp32 kernel on the same bf16-representable data (self-consistency
+beside the torch-autograd parity tests), and timings on the training step's heaviest layer shapes.
+    python scripts/wgrad_bench.py            (V2V_WGRAD_BF16=legacy python ... times the round-1 v1 bf16 path)"""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vid2vid_amd import lib as L
+from vid2vid_amd.lib import lib, WgradDesc, check
+
+dev = "cuda:0"
+zero = torch.zeros(256, dtype=torch.uint8, device=dev)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def run(dy, x, KH, stride, pad, pad_mode, dtype, reps=0):
+    """dy [N,OH,OW,R], x [N,H,W,Cc] (NHWC, given dtype) -> grad [R][Cc][KH][KH] fp32 (+ median ms)"""
+    N, OH, OW, R = dy.shape
+    _, H, W, Cc = x.shape
+    d = WgradDesc()
+    d.p, d.q = dy.data_ptr(), x.data_ptr()
+    d.N, d.OH, d.OW, d.QH, d.QW = N, OH, OW, H, W
+    d.rows, d.cols, d.p_stride, d.q_stride = R, Cc, dy.stride(2), x.stride(2)
+    d.KH = d.KW = KH
+    d.stride, d.pad, d.pad_mode = stride, pad, pad_mode
+    d.dtype, d.accumulate = dtype, 0
+    grad = torch.zeros(R, Cc, KH, KH, dtype=torch.float32, device=dev)
+    d.grad = grad.data_ptr()
+    d.zero_page = zero.data_ptr()
+    nbytes = lib.v2v_conv_wgrad_workspace(C.byref(d))
+    assert nbytes > 0, nbytes
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    d.workspace = ws.data_ptr()
+    check(lib.v2v_conv_wgrad(C.byref(d), st), "wgrad")
+    ms = None
+    if reps:
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        for r in range(reps):
+            e0[r].record(); lib.v2v_conv_wgrad(C.byref(d), st); e1[r].record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))[reps // 2]
+    torch.cuda.synchronize()
+    return grad, ms
+
+
+CASES = [  # R(cout) Cc(cin) K stride pad mode  N  OH  OW   (x is OH*stride.. sized)
+    (1024, 1024, 3, 1, 1, L.PAD_REFLECT, 1, 32, 64),     # ResnetBlock 1024 @512x256: 36 layers / frame
+    (512, 512, 3, 1, 1, L.PAD_REFLECT, 1, 32, 64),       # fg tower
+    (256, 128, 3, 2, 1, L.PAD_ZERO, 1, 128, 256),
+    (128, 108, 7, 1, 3, L.PAD_REFLECT, 1, 256, 512),      # stem (cin stride 112)
+    (64, 39, 4, 2, 2, L.PAD_ZERO, 2, 129, 257),            # D first layer
+    (200, 136, 3, 1, 1, L.PAD_ZERO, 1, 12, 20),
+    (3, 128, 7, 1, 3, L.PAD_REFLECT, 1, 64, 64),           # head: 3 rows
+    (72, 64, 3, 1, 1, L.PAD_ZERO, 2, 17, 23),
+]
+torch.manual_seed(0)
+worst = 0.0
+for (R, Cc, K, s, p, mode, N, OH, OW) in CASES:
+    H, W = (OH - 1) * s + K - 2 * p, (OW - 1) * s + K - 2 * p
+    Rs, Cs = (R + 7) // 8 * 8, (Cc + 7) // 8 * 8
+    dy = torch.zeros(N, OH, OW, Rs, device=dev); dy[..., :R] = torch.randn(N, OH, OW, R, device=dev)
+    x = torch.zeros(N, H, W, Cs, device=dev); x[..., :Cc] = torch.randn(N, H, W, Cc, device=dev)
+    dyb, xb = dy.bfloat16(), x.bfloat16()
+    ref, ms32 = run(dyb.float(), xb.float(), K, s, p, mode, L.F32, reps=5)
+    got, ms16 = run(dyb, xb, K, s, p, mode, L.BF16, reps=11)
+    rms = ref.pow(2).mean().sqrt().item()
+    err = (got - ref).abs().max().item() / (rms + 1e-12)
+    worst = max(worst, err)
+    flops = 2.0 * N * OH * OW * R * Cc * K * K
+    print("wgrad R=%4d C=%4d k%d s%d %dx%dx%d: bf16 %.3f ms (%.0f TFLOP/s)  fp32 %.3f ms (%.0f TFLOP/s)  max|diff|/rms %.2e"
+          % (R, Cc, K, s, N, OH, OW, ms16, flops / ms16 / 1e9, ms32, flops / ms32 / 1e9, err))
+print("worst", worst)
+assert worst < 2e-3, "bf16-MFMA wgrad disagrees with the exact-fp32 kernel on identical (bf16-representable) operands"

@@ -22,6 +22,7 @@
 // (deterministic, no atomics), optionally accumulating into an existing .grad buffer.
 #include "v2v_internal.h"
 #include <cstring>
+#include <cstdlib>
 
 namespace v2v {
 
@@ -180,6 +181,178 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 storage path on the bf16 matrix pipe: v_mfma_f32_32x32x16_bf16 (16x the rate of the exact-fp32 MFMA above).
+// The contraction index (pixels) is the SLOW index of both pixel-major operands, but the bf16 MFMA wants 8
+// consecutive k per lane -- the gfx950 transpose read ds_read_b64_tr_b16 delivers exactly that from a [k][channel]
+// LDS image: a 16-lane group reads one [4 pixels][16 channels] block (lane l of the group addresses pixel l/4,
+// channels 4*(l%4)..+3) and lane j receives the 4 pixels of channel j.  Two such reads give a lane its 8 k values;
+// lanes 0-31 cover pixels 0-7 of a 16-pixel step, lanes 32-63 pixels 8-15; A and B use the same assignment.
+// LDS image: row-major [BK pixels][BM or BN channels] staged by LDS-DMA with coalesced 16-byte lanes; the 16-byte
+// channel chunks of a row are XOR-permuted by the pixel's low bits (the lane picks its global source accordingly)
+// so that the 4 rows x 2 halves a 32-lane phase of a transpose read touches fall into 8 different 32-byte windows.
+// Accumulation stays fp32 in the MFMA accumulators; slabs / reduction / determinism as above.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short wg_v4s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ wg_v4s wg_tr_read(const char* lds) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_v4s*)lds);
+}
+
+// chunk swizzle of a [*][ROWB bytes] image: XOR applied to the 16-byte chunk index of pixel row k
+template <int ROWB> __device__ __forceinline__ int wg_swz(int k) {
+    if (ROWB >= 256) return (k & 3) << 2;          // 16+ chunks per row: 4 rows -> 4 different pairs of 32-byte windows
+    return ((k >> 1) & 1) << 2;                    // 128-byte rows: rows k, k+2 share a bank window -> split them
+}
+
+template <int BM, int BN, int BK, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradKArgs p) {
+    constexpr int ES = 2, VEC = 8;
+    constexpr int LPR_P = BM / VEC, LPR_Q = BN / VEC;       // lanes (= 16-byte chunks) per pixel row
+    constexpr int RPI_P = 64 / LPR_P, RPI_Q = 64 / LPR_Q;   // pixel rows per wave instruction (1 KiB)
+    constexpr int NI_P = BK / RPI_P / 4, NI_Q = BK / RPI_Q / 4;
+    constexpr int ROWB_P = BM * ES, ROWB_Q = BN * ES;
+    constexpr int PT_BYTES = BK * ROWB_P, QT_BYTES = BK * ROWB_Q;
+    constexpr int STAGE = PT_BYTES + QT_BYTES;
+    constexpr int D = NS - 1;
+    constexpr int LPT = NI_P + NI_Q;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && BK % 16 == 0, "tile");
+    static_assert(NI_P >= 1 && NI_Q >= 1 && (BK % (RPI_P * 4)) == 0 && (BK % (RPI_Q * 4)) == 0, "loader split");
+    static_assert(RPI_P % 4 == 0 && RPI_Q % 4 == 0, "swizzle needs the pixel's low bits to be lane constants");
+    static_assert(LPT * (D - 1) <= 63, "vmcnt range");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
+    const int split = blockIdx.y;
+    const int kbeg = split * p.kper;
+    const int kend = min(kbeg + p.kper, p.Kpix);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const char* const zp = p.zero_page;
+
+    // ---- loaders: lane -> (pixel row inside the instruction, LDS chunk slot); the slot holds channel chunk slot ^ swz(row)
+    const int p_row = lane / LPR_P;
+    const int p_cg = (lane % LPR_P) ^ wg_swz<ROWB_P>(p_row);
+    const int p_ch = mt * BM + p_cg * VEC;
+    const bool p_chok = p_ch < p.PCs;
+    const int q_row = lane / LPR_Q;
+    const int q_cg = (lane % LPR_Q) ^ wg_swz<ROWB_Q>(q_row);
+    const int q_col = nt * BN + q_cg * VEC;
+    const bool q_colok = q_col < p.ncols;
+    const int q_tap = q_colok ? q_col / p.QCs : 0;
+    const int q_c = q_col - q_tap * p.QCs;
+    const int q_dh = q_tap / p.KW - p.pad, q_dw = q_tap % p.KW - p.pad;
+    const int ohow = p.OH * p.OW;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+
+    int issued = 0;
+    auto issue = [&]() {
+        char* sbase = smem + (issued % NS) * STAGE;
+        const int k0 = kbeg + issued * BK;
+#pragma unroll
+        for (int j = 0; j < NI_P; ++j) {
+            const int q = wid + 4 * j;
+            const int pix = k0 + q * RPI_P + p_row;
+            const bool ok = p_chok && pix < kend;
+            const char* src = ok ? p.P + ((long long)pix * p.PCs + p_ch) * ES : zp;
+            wg_glds16(src, sbase + q * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NI_Q; ++j) {
+            const int q = wid + 4 * j;
+            const int pix = k0 + q * RPI_Q + q_row;
+            bool ok = q_colok && pix < kend;
+            const int pp = ok ? pix : 0;
+            const int n = pp / ohow;
+            const int rem = pp - n * ohow;
+            const int oi = rem / p.OW;
+            const int oj = rem - oi * p.OW;
+            int ih = oi * p.stride + q_dh, iw = oj * p.stride + q_dw;
+            int rh = ih < 0 ? -ih : ih;  rh = rh >= p.QH ? 2 * p.QH - 2 - rh : rh;
+            int rw = iw < 0 ? -iw : iw;  rw = rw >= p.QW ? 2 * p.QW - 2 - rw : rw;
+            ih = reflect ? rh : ih;
+            iw = reflect ? rw : iw;
+            ok = ok && ((unsigned)ih < (unsigned)p.QH) && ((unsigned)iw < (unsigned)p.QW);
+            ih = ih < 0 ? 0 : (ih >= p.QH ? p.QH - 1 : ih);
+            iw = iw < 0 ? 0 : (iw >= p.QW ? p.QW - 1 : iw);
+            const char* src = p.Q + ((((long long)n * p.QH + ih) * p.QW + iw) * p.QCs + q_c) * ES;
+            src = ok ? src : zp;
+            wg_glds16(src, sbase + PT_BYTES + q * 1024);
+        }
+        ++issued;
+    };
+
+    // ---- fragment addressing (bytes inside a stage), constant per lane: see the header comment
+    const int lr = lane & 31, hi = lane >> 5;
+    const int g16 = (lane >> 4) & 1, j16 = lane & 15;
+    const int frow = 8 * hi + (j16 >> 2);                    // pixel row of the first transpose read inside a 16-pixel step
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int c = wm * (BM / 2) + i * 32 + 16 * g16 + 4 * (j16 & 3);
+        a_off[i] = frow * ROWB_P + (((c >> 3) ^ wg_swz<ROWB_P>(frow)) << 4) + ((c & 7) << 1);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = wn * (BN / 2) + j * 32 + 16 * g16 + 4 * (j16 & 3);
+        b_off[j] = PT_BYTES + frow * ROWB_Q + (((c >> 3) ^ wg_swz<ROWB_Q>(frow)) << 4) + ((c & 7) << 1);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int t = 0; t < D && t < nk; ++t) issue();
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + D <= nk) wg_wait_vmcnt<LPT * (D - 1)>();
+        else              wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (ks + D < nk) issue();
+        const char* st = smem + (ks % NS) * STAGE;
+#pragma unroll
+        for (int k16 = 0; k16 < BK / 16; ++k16) {
+            union Frag { bf16x8 v; wg_v4s h[2]; };
+            Frag a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a[i].h[0] = wg_tr_read(st + a_off[i] + (k16 * 16) * ROWB_P);          // rows +4 keep the same swizzle (k & 3)
+                a[i].h[1] = wg_tr_read(st + a_off[i] + (k16 * 16 + 4) * ROWB_P);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                b[j].h[0] = wg_tr_read(st + b_off[j] + (k16 * 16) * ROWB_Q);
+                b[j].h[1] = wg_tr_read(st + b_off[j] + (k16 * 16 + 4) * ROWB_Q);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* slab = p.slab + (long long)split * p.Rp * p.Cp;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = nt * BN + wn * (BN / 2) + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * BM + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                slab[(long long)row * p.Cp + col] = acc[i][j][r];
+            }
+        }
+}
+
 struct WgradReduceArgs {
     const float* slab; float* grad;
     int splits, R, C, KHW, QCs, Rp, Cp, accumulate;
@@ -204,11 +377,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs
     }
 }
 
+// V2V_WGRAD_BF16=legacy: bf16 operands widened on the LDS read and multiplied on the exact-fp32 MFMA (the round-1 v1
+// kernel), kept for A/B measurements
+static bool legacy_bf16() {
+    static const int v = [] { const char* e = getenv("V2V_WGRAD_BF16"); return (e && !strcmp(e, "legacy")) ? 1 : 0; }();
+    return v != 0;
+}
+
 struct WgradOp : Op {
-    WgradKArgs k; WgradReduceArgs r; int dtype, splits;
+    WgradKArgs k; WgradReduceArgs r; int dtype, splits, bm;
     int launch(hipStream_t s) override {
         dim3 grid((unsigned)(k.m_tiles * k.n_tiles), (unsigned)splits);
-        if (dtype == V2V_BF16) {
+        if (dtype == V2V_BF16 && bm == 128) {
+            auto kern = conv_wgrad_bf16_kernel<128, 128, 32, 3>;
+            const size_t lds = 3 * (32 * 128 + 32 * 128) * 2;
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+        } else if (dtype == V2V_BF16 && !legacy_bf16()) {
+            auto kern = conv_wgrad_bf16_kernel<64, 128, 32, 3>;
+            const size_t lds = 3 * (32 * 64 + 32 * 128) * 2;
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+        } else if (dtype == V2V_BF16) {
             auto kern = conv_wgrad_kernel<bf16_t, 64, 128, 32, 3>;
             const size_t lds = 3 * (32 * 64 + 32 * 128) * 2;
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
@@ -233,11 +421,17 @@ struct WgradOp : Op {
     const char* name() const override { return "conv_wgrad"; }
 };
 
-static const int WG_BM = 64, WG_BN = 128, WG_BK = 32;
+static const int WG_BN = 128, WG_BK = 32;
+
+// row-tile height: 128 on the bf16 matrix pipe when the layer has more than 64 gradient rows, else 64
+static int wgrad_bm(const v2v_wgrad_desc* d) {
+    return (d->dtype == V2V_BF16 && d->rows > 64 && !legacy_bf16()) ? 128 : 64;
+}
 
 static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* splits, int* kper) {
     const long long kpix = (long long)d->N * d->OH * d->OW;
     const int ncols = d->KH * d->KW * d->q_stride;
+    const int WG_BM = wgrad_bm(d);
     *m_tiles = (int)ceil_div(d->rows, WG_BM);
     *n_tiles = (int)ceil_div(ncols, WG_BN);
     const long long tiles = (long long)*m_tiles * *n_tiles;
@@ -274,7 +468,7 @@ extern "C" int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d) {
     if (wgrad_check(d) != 0) return V2V_EINVAL;
     int mt, nt, sp, kp;
     wgrad_plan(d, &mt, &nt, &sp, &kp);
-    return (int64_t)sp * mt * WG_BM * nt * WG_BN * (int64_t)sizeof(float);
+    return (int64_t)sp * mt * wgrad_bm(d) * nt * WG_BN * (int64_t)sizeof(float);
 }
 
 extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
@@ -293,10 +487,10 @@ extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
     k.ncols = d->KH * d->KW * d->q_stride;
     k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.pad_mode = d->pad_mode;
     k.Kpix = d->N * d->OH * d->OW; k.kper = kp;
-    k.m_tiles = mt; k.n_tiles = nt; k.Rp = mt * WG_BM; k.Cp = nt * WG_BN;
+    k.m_tiles = mt; k.n_tiles = nt; k.Rp = mt * wgrad_bm(d); k.Cp = nt * WG_BN;
     WgradReduceArgs& r = op->r;
     r.slab = k.slab; r.grad = d->grad; r.splits = sp; r.R = d->rows; r.C = d->cols; r.KHW = d->KH * d->KW;
     r.QCs = d->q_stride; r.Rp = k.Rp; r.Cp = k.Cp; r.accumulate = d->accumulate;
-    op->dtype = d->dtype; op->splits = sp;
+    op->dtype = d->dtype; op->splits = sp; op->bm = wgrad_bm(d);
     return submit(std::move(op), stream);
 }

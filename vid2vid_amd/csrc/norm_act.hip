@@ -194,6 +194,7 @@ struct BnBwdRedArgs {
     float* partials;                                        // [nblk][C][2]
     long long P; int C, c_stride, c_stride_raw, act; float act_param; int mode;   // mode 1: sum of dy only
     long long ppb;                                          // pixels per block
+    int vec;                                                // strides / base pointers allow the 4-channel vector loads
 };
 
 __device__ __forceinline__ float act_grad_pre(float pre, int act, float param) {
@@ -204,41 +205,73 @@ __device__ __forceinline__ float act_grad_pre(float pre, int act, float param) {
     }
 }
 
+__device__ __forceinline__ void load4(const float* p, float v[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+// grid (pixel blocks, 64-channel slabs): a 2048-pixel x 1024-channel layer is 32 x 16 = 512 workgroups instead of the
+// 32 of a pixel-only split (which left 7/8 of the chip idle and cost 80 us per launch, profiles/r01_v17_train_*).
+// Thread (tx, ty) of the 16 x 16 block owns 4 consecutive channels (one 8- or 16-byte load per operand) and every 16th
+// pixel of the block; the 16 pixel-phases are added in a fixed order through LDS -> deterministic partial rows.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdRedArgs a) {
-    __shared__ float sh[256][2];
+    __shared__ float sh[16][64][2];
     const T* dy = reinterpret_cast<const T*>(a.dy);
     const long long p0 = (long long)blockIdx.x * a.ppb;
     long long p1 = p0 + a.ppb; if (p1 > a.P) p1 = a.P;
-    // threads: tx over channels (coalesced), ty over pixels; channels are walked in slabs of TX
-    const int TX = a.C >= 64 ? 64 : (a.C >= 32 ? 32 : 16);
-    const int TY = 256 / TX;
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    for (int c0 = 0; c0 < a.C; c0 += TX) {
-        const int c = c0 + tx;
-        float s1 = 0.f, s2 = 0.f;
-        if (c < a.C) {
-            float sc = 1.f, sf = 0.f, mean = 0.f, inv = 1.f;
-            if (a.mode == 0) { sc = a.stats[c]; sf = a.stats[a.C + c]; mean = a.stats[2 * a.C + c]; inv = a.stats[3 * a.C + c]; }
-            for (long long p = p0 + ty; p < p1; p += TY) {
-                float g = load_act(dy, p * a.c_stride + c);
-                if (a.mode == 0) {
-                    const float r = a.raw[p * a.c_stride_raw + c];
-                    g *= act_grad_pre(r * sc + sf, a.act, a.act_param);
-                    s2 += g * ((r - mean) * inv);
-                }
-                s1 += g;
-            }
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c0 = blockIdx.y * 64 + tx * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < a.C) {                       // channel strides are multiples of 4 and >= C: the 4-wide loads stay in the row
+        float sc[4], sf[4], mean[4], inv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q < a.C ? c0 + q : a.C - 1;
+            sc[q] = 1.f; sf[q] = 0.f; mean[q] = 0.f; inv[q] = 1.f;
+            if (a.mode == 0) { sc[q] = a.stats[c]; sf[q] = a.stats[a.C + c]; mean[q] = a.stats[2 * a.C + c]; inv[q] = a.stats[3 * a.C + c]; }
         }
-        sh[threadIdx.x][0] = s1; sh[threadIdx.x][1] = s2;
-        __syncthreads();
-        if (ty == 0 && c < a.C) {
+        for (long long p = p0 + ty; p < p1; p += 16) {
+            float g[4];
+            if (a.vec) load4(dy + p * a.c_stride + c0, g);
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = c0 + q < a.C ? load_act(dy, p * a.c_stride + c0 + q) : 0.f;
+            }
+            if (a.mode == 0) {
+                float r[4];
+                if (a.vec) load4(a.raw + p * a.c_stride_raw + c0, r);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[q] = c0 + q < a.C ? a.raw[p * a.c_stride_raw + c0 + q] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    g[q] *= act_grad_pre(r[q] * sc[q] + sf[q], a.act, a.act_param);
+                    s2[q] += g[q] * ((r[q] - mean[q]) * inv[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s1[q] += g[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sh[ty][tx * 4 + q][0] = s1[q]; sh[ty][tx * 4 + q][1] = s2[q]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.y * 64 + threadIdx.x;
+        if (c < a.C) {
             float t1 = 0.f, t2 = 0.f;
-            for (int q = 0; q < TY; ++q) { t1 += sh[q * TX + tx][0]; t2 += sh[q * TX + tx][1]; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { t1 += sh[q][threadIdx.x][0]; t2 += sh[q][threadIdx.x][1]; }
             float* dst = a.partials + ((long long)blockIdx.x * a.C + c) * 2;
             dst[0] = t1; dst[1] = t2;
         }
-        __syncthreads();
     }
 }
 
@@ -304,8 +337,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
 struct BnBwdOp : Op {
     BnBwdRedArgs r; BnBwdFinArgs f; BnBwdApplyArgs ap; int dtype, nblk; bool do_apply;
     int launch(hipStream_t s) override {
-        if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, s, r);
-        else                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, s, r);
+        const dim3 rgrid((unsigned)nblk, (unsigned)ceil_div(r.C, 64));
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, r);
+        else                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, s, r);
         int rc = check_launch(); if (rc) return rc;
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(f.C, 64)), dim3(256), 0, s, f);
         rc = check_launch(); if (rc) return rc;
@@ -453,7 +487,8 @@ extern "C" int v2v_bn_backward(const void* dy, const float* raw, int32_t c_strid
     op->dtype = dtype; op->nblk = nblk; op->do_apply = true;
     float* partials = workspace;                      // [nblk][C][2]
     float* coef = workspace + (long long)nblk * C * 2; // [2][C]
-    op->r = BnBwdRedArgs{dy, raw, stats, partials, P, C, c_stride, c_stride_raw, act, act_param, 0, ppb};
+    const int vec = (c_stride % 4 == 0 && c_stride_raw % 4 == 0 && (((uintptr_t)dy | (uintptr_t)raw) & 15) == 0) ? 1 : 0;
+    op->r = BnBwdRedArgs{dy, raw, stats, partials, P, C, c_stride, c_stride_raw, act, act_param, 0, ppb, vec};
     op->f = BnBwdFinArgs{partials, nblk, C, 1.0 / (double)P, dgamma, dbeta, coef, accumulate};
     op->ap = BnBwdApplyArgs{dy, raw, stats, coef, draw, P, C, c_stride, c_stride_raw, c_stride_out, act, act_param};
     return submit(std::move(op), stream);
@@ -465,7 +500,8 @@ extern "C" int v2v_channel_sum(const void* x, float* out, int32_t accumulate, fl
     auto op = std::make_unique<BnBwdOp>();
     long long ppb; const int nblk = bwd_blocks(P, &ppb);
     op->dtype = dtype; op->nblk = nblk; op->do_apply = false;
-    op->r = BnBwdRedArgs{x, nullptr, nullptr, workspace, P, C, c_stride, 0, V2V_ACT_NONE, 0.f, 1, ppb};
+    const int vec = (c_stride % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    op->r = BnBwdRedArgs{x, nullptr, nullptr, workspace, P, C, c_stride, 0, V2V_ACT_NONE, 0.f, 1, ppb, vec};
     op->f = BnBwdFinArgs{workspace, nblk, C, 1.0, nullptr, out, nullptr, accumulate};
     memset(&op->ap, 0, sizeof(op->ap));
     return submit(std::move(op), stream);
