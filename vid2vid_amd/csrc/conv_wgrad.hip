@@ -358,22 +358,33 @@ struct WgradReduceArgs {
     int splits, R, C, KHW, QCs, Rp, Cp, accumulate;
 };
 
-// one thread per slab column entry (coalesced slab reads); scattered 4-byte writes, once
+// Slabs [split][row][tap * QCs + c] -> gradient [row][c][tap] (PyTorch layout).  One workgroup per (row, 64-channel
+// chunk): for every tap the 64 lanes of a wave read 64 consecutive slab columns of each split (coalesced) and park the
+// sum in LDS at [c][tap]; the chunk's 64 * KHW gradient values are then contiguous in memory and are written (or
+// read-modify-written when accumulating into .grad) with consecutive lanes on consecutive addresses.  The v1 kernel
+// wrote 4 bytes every KHW * 4 bytes per lane (34 us per 1024x1024x3x3 layer, 10 % of the training step).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs a) {
-    const long long ncols = (long long)a.KHW * a.QCs;
-    const long long total = (long long)a.R * ncols;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    __shared__ float sh[64 * 50];
+    const int r = blockIdx.x, c0 = blockIdx.y * 64;
+    const int KHW = a.KHW, KP = KHW | 1;                       // odd LDS stride: conflict-free [c][tap] scatter
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long slab_sz = (long long)a.Rp * a.Cp;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int r = (int)(e / ncols);
-        const int col = (int)(e - (long long)r * ncols);
-        const int tap = col / a.QCs, c = col - tap * a.QCs;
-        if (c >= a.C) continue;
+    const int c = c0 + lane;
+    for (int tap = w; tap < KHW; tap += 4) {
         float s = 0.f;
-        const float* src = a.slab + (long long)r * a.Cp + col;
-        for (int k = 0; k < a.splits; ++k) s += src[(long long)k * slab_sz];
-        float* dst = a.grad + ((long long)r * a.C + c) * a.KHW + tap;
-        *dst = a.accumulate ? *dst + s : s;
+        if (c < a.C) {
+            const float* src = a.slab + (long long)r * a.Cp + (long long)tap * a.QCs + c;
+            for (int k = 0; k < a.splits; ++k) s += src[(long long)k * slab_sz];
+        }
+        sh[lane * KP + tap] = s;
+    }
+    __syncthreads();
+    const int nc = min(64, a.C - c0);
+    float* dst = a.grad + ((long long)r * a.C + c0) * KHW;
+    for (int i = threadIdx.x; i < nc * KHW; i += 256) {
+        const int cc = i / KHW, tap = i - cc * KHW;
+        const float v = sh[cc * KP + tap];
+        dst[i] = a.accumulate ? dst[i] + v : v;
     }
 }
 
@@ -412,10 +423,7 @@ struct WgradOp : Op {
         }
         int rc = check_launch();
         if (rc != 0) return rc;
-        const long long total = (long long)r.R * r.KHW * r.QCs;
-        long long blocks = ceil_div(total, 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, r);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)r.R, (unsigned)ceil_div(r.C, 64)), dim3(256), 0, s, r);
         return check_launch();
     }
     const char* name() const override { return "conv_wgrad"; }
@@ -435,7 +443,7 @@ static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* 
     *m_tiles = (int)ceil_div(d->rows, WG_BM);
     *n_tiles = (int)ceil_div(ncols, WG_BN);
     const long long tiles = (long long)*m_tiles * *n_tiles;
-    long long s = ceil_div(1024, tiles);                 // aim at ~4 workgroups per CU
+    long long s = ceil_div(512, tiles);                  // ~2 workgroups per CU: every split costs a slab write + read
     const long long smax = ceil_div(kpix, 8 * WG_BK);     // at least 8 chunks per split
     if (s > smax) s = smax;
     if (s < 1) s = 1;
@@ -454,6 +462,7 @@ static int wgrad_check(const v2v_wgrad_desc* d) {
         set_error("wgrad: channel strides must be multiples of %d and cover rows/cols", vec); return V2V_EINVAL;
     }
     if (d->stride != 1 && d->stride != 2) { set_error("wgrad: stride"); return V2V_EINVAL; }
+    if (d->KH * d->KW > 49 || d->KH < 1 || d->KW < 1) { set_error("wgrad: kernel window larger than 7x7"); return V2V_EINVAL; }
     if (d->pad_mode == V2V_PAD_REFLECT && (d->pad >= d->QH || d->pad >= d->QW)) { set_error("wgrad: reflect pad >= size"); return V2V_EINVAL; }
     if ((long long)d->N * d->OH * d->OW >= (1ll << 31) || (long long)d->N * d->QH * d->QW >= (1ll << 31)) { set_error("wgrad: too many pixels"); return V2V_EINVAL; }
     if (((uintptr_t)d->p | (uintptr_t)d->q | (uintptr_t)d->zero_page) & 15) { set_error("wgrad: operands must be 16-byte aligned"); return V2V_EINVAL; }

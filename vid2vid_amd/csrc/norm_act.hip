@@ -306,31 +306,56 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdFinArgs
 struct BnBwdApplyArgs {
     const void* dy; const float* raw; const float* stats; const float* coef; void* draw;
     long long P; int C, c_stride, c_stride_raw, c_stride_out, act; float act_param;
+    int vec;
 };
 
-// one thread per (pixel, 4-channel group); writes dRaw in the activation dtype, pad channels zero
+__device__ __forceinline__ void store4(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
+    uint2 t;
+    t.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+    t.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = t;
+}
+
+// grid (64-pixel blocks, 64-channel slabs), thread (tx, ty) of 16 x 16: 4 fixed channels (statistics and reduction
+// coefficients live in registers for the whole pixel walk), every 16th pixel; one vector load per operand and one
+// vector store per pixel.  Writes dRaw in the activation dtype, pad channels zero.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
     const T* dy = reinterpret_cast<const T*>(a.dy);
     T* out = reinterpret_cast<T*>(a.draw);
-    const int gpr = a.c_stride_out / 4;
-    const long long total = a.P * gpr;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += stride) {
-        const long long pix = v / gpr;
-        const int c0 = (int)(v - pix * gpr) * 4;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c0 = blockIdx.y * 64 + tx * 4;
+    if (c0 >= a.c_stride_out) return;
+    float sc[4], sf[4], mean[4], inv[4], k1[4], k2[4];
+    bool okc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        okc[q] = c0 + q < a.C;
+        const int c = okc[q] ? c0 + q : a.C - 1;
+        sc[q] = a.stats[c]; sf[q] = a.stats[a.C + c]; mean[q] = a.stats[2 * a.C + c]; inv[q] = a.stats[3 * a.C + c];
+        k1[q] = a.coef[c]; k2[q] = a.coef[a.C + c];
+    }
+    const long long p0 = (long long)blockIdx.x * 64;
+    long long p1 = p0 + 64; if (p1 > a.P) p1 = a.P;
+    for (long long p = p0 + ty; p < p1; p += 16) {
+        float g[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        if (c0 < a.C) {
+            if (a.vec) { load4(dy + p * a.c_stride + c0, g); load4(a.raw + p * a.c_stride_raw + c0, r); }
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (okc[q]) { g[q] = load_act(dy, p * a.c_stride + c0 + q); r[q] = a.raw[p * a.c_stride_raw + c0 + q]; }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c = c0 + q;
-            float o = 0.f;
-            if (c < a.C) {
-                const float sc = a.stats[c], sf = a.stats[a.C + c], mean = a.stats[2 * a.C + c], inv = a.stats[3 * a.C + c];
-                const float r = a.raw[pix * a.c_stride_raw + c];
-                const float g = load_act(dy, pix * a.c_stride + c) * act_grad_pre(r * sc + sf, a.act, a.act_param);
-                o = sc * (g - a.coef[c] - (r - mean) * inv * a.coef[a.C + c]);
-            }
-            store_act(out, pix * a.c_stride_out + c, o);
+            const float gg = g[q] * act_grad_pre(r[q] * sc[q] + sf[q], a.act, a.act_param);
+            o[q] = okc[q] ? sc[q] * (gg - k1[q] - (r[q] - mean[q]) * inv[q] * k2[q]) : 0.f;
         }
+        store4(out + p * a.c_stride_out + c0, o);
     }
 }
 
@@ -344,10 +369,9 @@ struct BnBwdOp : Op {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(f.C, 64)), dim3(256), 0, s, f);
         rc = check_launch(); if (rc) return rc;
         if (do_apply) {
-            long long blocks = ceil_div(ap.P * (ap.c_stride_out / 4), 256);
-            if (blocks > 4096) blocks = 4096;
-            if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, ap);
-            else                   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, ap);
+            const dim3 agrid((unsigned)ceil_div(ap.P, 64), (unsigned)ceil_div(ap.c_stride_out, 64));
+            if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), 0, s, ap);
+            else                   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, agrid, dim3(256), 0, s, ap);
             rc = check_launch();
         }
         return rc;
@@ -481,6 +505,7 @@ extern "C" int v2v_bn_backward(const void* dy, const float* raw, int32_t c_strid
                                int32_t act, float act_param, int32_t dtype, void* stream) {
     if (!dy || !raw || !stats || !draw || !workspace || P <= 0 || C <= 0) { set_error("bn_backward: bad argument"); return V2V_EINVAL; }
     if (c_stride_out % 4 != 0 || C > c_stride || C > c_stride_raw || C > c_stride_out) { set_error("bn_backward: strides"); return V2V_EINVAL; }
+    if ((uintptr_t)draw & 15) { set_error("bn_backward: draw must be 16-byte aligned"); return V2V_EINVAL; }
     if (act != V2V_ACT_NONE && act != V2V_ACT_RELU && act != V2V_ACT_LEAKY) { set_error("bn_backward: activation"); return V2V_EINVAL; }
     auto op = std::make_unique<BnBwdOp>();
     long long ppb; const int nblk = bwd_blocks(P, &ppb);
@@ -490,7 +515,7 @@ extern "C" int v2v_bn_backward(const void* dy, const float* raw, int32_t c_strid
     const int vec = (c_stride % 4 == 0 && c_stride_raw % 4 == 0 && (((uintptr_t)dy | (uintptr_t)raw) & 15) == 0) ? 1 : 0;
     op->r = BnBwdRedArgs{dy, raw, stats, partials, P, C, c_stride, c_stride_raw, act, act_param, 0, ppb, vec};
     op->f = BnBwdFinArgs{partials, nblk, C, 1.0 / (double)P, dgamma, dbeta, coef, accumulate};
-    op->ap = BnBwdApplyArgs{dy, raw, stats, coef, draw, P, C, c_stride, c_stride_raw, c_stride_out, act, act_param};
+    op->ap = BnBwdApplyArgs{dy, raw, stats, coef, draw, P, C, c_stride, c_stride_raw, c_stride_out, act, act_param, vec};
     return submit(std::move(op), stream);
 }
 

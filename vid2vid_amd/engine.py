@@ -313,13 +313,13 @@ class Engine:
         return self._grids[key]
 
     # ---------------- weights ----------------
-    def packed(self, mod, cin_stride, role="fwd", reflect=False, korder=0):
+    def packed(self, mod, cin_stride, role="fwd", reflect=False, korder=0, refresh=True):
         key = (id(mod), cin_stride, role, reflect, korder)
         pc = self._packed.get(key)
         if pc is None:
             pc = PackedConv(self, mod, cin_stride, role, reflect, korder)
             self._packed[key] = pc
-        elif self.plan is None:
+        elif self.plan is None and refresh:
             pc.refresh()          # eager (training) use: follow optimizer updates
         return pc
 
@@ -333,7 +333,7 @@ class Engine:
         """Emit one convolution.  Returns (out, stats_rows, (N,OH,OW)).
         fin = (norm module, ss tensor [4*cout]): finalize the training-mode norm statistics inside the conv
         kernel (last-arriving workgroup), so no separate bn_finalize launch is needed."""
-        pc = self.packed(mod, x.Cs)
+        pc = self.packed(mod, x.Cs, refresh=False)     # geometry now; the packing that the chosen tile reads is refreshed below
         pad = pc.pad if pad_override is None else pad_override
         N, H, W = x.N, x.H, x.W
         if pc.transposed:
@@ -361,6 +361,9 @@ class Engine:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
         if 32 <= d.tile < 60:
             pc = self._use_korder1(d, mod, x.Cs)
+        elif self.plan is None:
+            pc.refresh()               # eager use: follow optimizer updates (only the packing this launch reads)
+        d.bias = None if pc.bias is None else pc.bias.data_ptr()      # of the packing in use (aliases the parameter)
         if pc.cin != x.C:
             raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
         if out_mode == L.OUT_RAW_F32_NHWC:
@@ -415,6 +418,7 @@ class Engine:
             self._save_tune_cache()
             d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
             pc = self._use_korder1(d, mod, x.Cs) if 32 <= d.tile < 60 else self._use_korder0(d, mod, x.Cs)
+            d.bias = None if pc.bias is None else pc.bias.data_ptr()
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()

@@ -131,7 +131,6 @@ class Vid2VidModelD(BaseModel):
         scale_S = opt.n_scales_spatial
         if dummy_bs:
             tensors_list = [None if t is None else t[dummy_bs:] for t in tensors_list]
-        eng.refresh_weights()
         dev = self.device
 
         def dv(t):

@@ -293,7 +293,7 @@ class Vid2VidModelG(BaseModel):
         if dummy_bs:
             input_A, input_B, inst_A, fake_B_prev = [None if t is None else t[dummy_bs:] for t in
                                                      (input_A, input_B, inst_A, fake_B_prev)]
-        self.engine.refresh_weights()
+        # (packed weight copies follow the optimizer lazily: Engine.packed() refreshes the one a launch reads)
         real_A_all, real_B_all, _ = self.encode_input(input_A, input_B, inst_A)
         self.bs = real_A_all.shape[0]
         is_first_frame = fake_B_prev is None
