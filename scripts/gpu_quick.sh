@@ -10,6 +10,11 @@ if has wgrad; then
   timeout 300 python scripts/wgrad_bench.py > gpurun_out/${TAG}_wgrad.txt 2>&1; echo "wgrad rc=$?"; tail -12 gpurun_out/${TAG}_wgrad.txt
   V2V_WGRAD_BF16=legacy timeout 300 python scripts/wgrad_bench.py > gpurun_out/${TAG}_wgrad_legacy.txt 2>&1; echo "wgrad(legacy) rc=$?"; tail -10 gpurun_out/${TAG}_wgrad_legacy.txt | cut -c1-110
 fi
+if has wgradcfg; then
+  for c in ${WGCFGS:-0 6 7}; do
+    echo "== V2V_WGRAD_CFG=$c"; V2V_WGRAD_CFG=$c timeout 200 python scripts/wgrad_bench.py 2>&1 | grep -E "^wgrad|worst|Error|error" | head -9 | cut -c1-150
+  done > gpurun_out/${TAG}_wgrad_cfgs.txt 2>&1; cat gpurun_out/${TAG}_wgrad_cfgs.txt
+fi
 if has tests; then
   timeout 600 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 180 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest.log | tail -20

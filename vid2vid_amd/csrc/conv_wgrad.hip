@@ -196,6 +196,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 typedef short wg_v4s __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ int wg_xcd_remap(int bid, int ntot) {
+    const int q = ntot >> 3, r = ntot & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ wg_v4s wg_tr_read(const char* lds) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_v4s*)lds);
 }
@@ -206,41 +211,46 @@ template <int ROWB> __device__ __forceinline__ int wg_swz(int k) {
     return ((k >> 1) & 1) << 2;                    // 128-byte rows: rows k, k+2 share a bank window -> split them
 }
 
-template <int BM, int BN, int BK, int NS>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradKArgs p) {
+template <int BM, int BN, int BK, int NS, int NW, bool SWZ, bool XCD>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(const WgradKArgs p) {
     constexpr int ES = 2, VEC = 8;
+    constexpr int WGM = NW / 2;                              // waves as WGM (rows) x 2 (columns)
     constexpr int LPR_P = BM / VEC, LPR_Q = BN / VEC;       // lanes (= 16-byte chunks) per pixel row
     constexpr int RPI_P = 64 / LPR_P, RPI_Q = 64 / LPR_Q;   // pixel rows per wave instruction (1 KiB)
-    constexpr int NI_P = BK / RPI_P / 4, NI_Q = BK / RPI_Q / 4;
+    constexpr int NI_P = BK / RPI_P / NW, NI_Q = BK / RPI_Q / NW;
     constexpr int ROWB_P = BM * ES, ROWB_Q = BN * ES;
     constexpr int PT_BYTES = BK * ROWB_P, QT_BYTES = BK * ROWB_Q;
     constexpr int STAGE = PT_BYTES + QT_BYTES;
     constexpr int D = NS - 1;
     constexpr int LPT = NI_P + NI_Q;
-    constexpr int TM = BM / 64, TN = BN / 64;
-    static_assert(BM % 64 == 0 && BN % 64 == 0 && BK % 16 == 0, "tile");
-    static_assert(NI_P >= 1 && NI_Q >= 1 && (BK % (RPI_P * 4)) == 0 && (BK % (RPI_Q * 4)) == 0, "loader split");
-    static_assert(RPI_P % 4 == 0 && RPI_Q % 4 == 0, "swizzle needs the pixel's low bits to be lane constants");
+    constexpr int TM = BM / WGM / 32, TN = BN / 64;
+    static_assert(BM % (32 * WGM) == 0 && BN % 64 == 0 && BK % 16 == 0 && TM >= 1, "tile");
+    static_assert(NI_P >= 1 && NI_Q >= 1 && (BK % (RPI_P * NW)) == 0 && (BK % (RPI_Q * NW)) == 0, "loader split");
+    static_assert((NW * RPI_P) % 4 == 0 && (NW * RPI_Q) % 4 == 0, "swizzle needs the pixel's low bits to be per-wave lane constants");
     static_assert(LPT * (D - 1) <= 63, "vmcnt range");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
+    // the 8 XCDs take workgroups round-robin: give each XCD a contiguous run of tiles = (nearly) one row tile and all
+    // of its column tiles, so that its private L2 keeps one 128-row slice of P plus Q instead of streaming all of both
+    const int lin = XCD ? wg_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int mt = lin / p.n_tiles, nt = lin - mt * p.n_tiles;
     const int split = blockIdx.y;
     const int kbeg = split * p.kper;
     const int kend = min(kbeg + p.kper, p.Kpix);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const char* const zp = p.zero_page;
 
-    // ---- loaders: lane -> (pixel row inside the instruction, LDS chunk slot); the slot holds channel chunk slot ^ swz(row)
+    // ---- loaders: lane -> (pixel row inside the instruction, LDS chunk slot); the slot holds channel chunk slot ^ swz(row),
+    //      row = (wid + NW*j) * RPI + lane / LPR: its low two bits do not depend on j
     const int p_row = lane / LPR_P;
-    const int p_cg = (lane % LPR_P) ^ wg_swz<ROWB_P>(p_row);
+    const int p_cg = (lane % LPR_P) ^ (SWZ ? wg_swz<ROWB_P>(wid * RPI_P + p_row) : 0);
     const int p_ch = mt * BM + p_cg * VEC;
     const bool p_chok = p_ch < p.PCs;
     const int q_row = lane / LPR_Q;
-    const int q_cg = (lane % LPR_Q) ^ wg_swz<ROWB_Q>(q_row);
+    const int q_cg = (lane % LPR_Q) ^ (SWZ ? wg_swz<ROWB_Q>(wid * RPI_Q + q_row) : 0);
     const int q_col = nt * BN + q_cg * VEC;
     const bool q_colok = q_col < p.ncols;
     const int q_tap = q_colok ? q_col / p.QCs : 0;
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradKArgs p
         const int k0 = kbeg + issued * BK;
 #pragma unroll
         for (int j = 0; j < NI_P; ++j) {
-            const int q = wid + 4 * j;
+            const int q = wid + NW * j;
             const int pix = k0 + q * RPI_P + p_row;
             const bool ok = p_chok && pix < kend;
             const char* src = ok ? p.P + ((long long)pix * p.PCs + p_ch) * ES : zp;
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradKArgs p
         }
 #pragma unroll
         for (int j = 0; j < NI_Q; ++j) {
-            const int q = wid + 4 * j;
+            const int q = wid + NW * j;
             const int pix = k0 + q * RPI_Q + q_row;
             bool ok = q_colok && pix < kend;
             const int pp = ok ? pix : 0;
@@ -293,13 +303,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradKArgs p
     int a_off[TM], b_off[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int c = wm * (BM / 2) + i * 32 + 16 * g16 + 4 * (j16 & 3);
-        a_off[i] = frow * ROWB_P + (((c >> 3) ^ wg_swz<ROWB_P>(frow)) << 4) + ((c & 7) << 1);
+        const int c = wm * (BM / WGM) + i * 32 + 16 * g16 + 4 * (j16 & 3);
+        a_off[i] = frow * ROWB_P + (((c >> 3) ^ (SWZ ? wg_swz<ROWB_P>(frow) : 0)) << 4) + ((c & 7) << 1);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int c = wn * (BN / 2) + j * 32 + 16 * g16 + 4 * (j16 & 3);
-        b_off[j] = PT_BYTES + frow * ROWB_Q + (((c >> 3) ^ wg_swz<ROWB_Q>(frow)) << 4) + ((c & 7) << 1);
+        b_off[j] = PT_BYTES + frow * ROWB_Q + (((c >> 3) ^ (SWZ ? wg_swz<ROWB_Q>(frow) : 0)) << 4) + ((c & 7) << 1);
     }
 
     f32x16 acc[TM][TN];
@@ -347,16 +357,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradKArgs p
             const int col = nt * BN + wn * (BN / 2) + j * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = mt * BM + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int row = mt * BM + wm * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 slab[(long long)row * p.Cp + col] = acc[i][j][r];
             }
         }
 }
 
 struct WgradReduceArgs {
-    const float* slab; float* grad;
+    float* slab; float* grad;
     int splits, R, C, KHW, QCs, Rp, Cp, accumulate;
 };
+
+// slab[g] += slab[g + 8] + slab[g + 16] + ...  (g = blockIdx.y < 8): fixed order, one owner per element -> deterministic
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(float* slab, long long n, int splits) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float* base = slab + (long long)blockIdx.y * n + e;
+    float s = base[0];
+    for (int k = blockIdx.y + 8; k < splits; k += 8) s += slab[(long long)k * n + e];
+    base[0] = s;
+}
 
 // Slabs [split][row][tap * QCs + c] -> gradient [row][c][tap] (PyTorch layout).  One workgroup per (row, 64-channel
 // chunk): for every tap the 64 lanes of a wave read 64 consecutive slab columns of each split (coalesced) and park the
@@ -395,18 +415,45 @@ static bool legacy_bf16() {
     return v != 0;
 }
 
+template <int BM, int BN, int BK, int NS, int NW, bool SWZ, bool XCD = false>
+static void launch_wgrad_bf16(dim3 grid, hipStream_t s, const WgradKArgs& k) {
+    auto kern = conv_wgrad_bf16_kernel<BM, BN, BK, NS, NW, SWZ, XCD>;
+    const size_t lds = (size_t)NS * (BK * BM + BK * BN) * 2;
+    if (lds > 64 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, s, k);
+}
+
+// V2V_WGRAD_CFG=<n>: tile experiments on the >64-row layers (scripts/wgrad_bench.py); 0 = the shipped configuration
+static int wgrad_cfg() {
+    static const int v = [] { const char* e = getenv("V2V_WGRAD_CFG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 struct WgradOp : Op {
     WgradKArgs k; WgradReduceArgs r; int dtype, splits, bm;
+    void launch_bf16(dim3 grid, hipStream_t s) {
+        if (bm == 64) { launch_wgrad_bf16<64, 128, 32, 3, 4, true>(grid, s, k); return; }
+        switch (wgrad_cfg()) {
+            case 1:  launch_wgrad_bf16<128, 128, 64, 3, 4, true>(grid, s, k); break;
+            case 2:  launch_wgrad_bf16<128, 128, 32, 4, 4, true>(grid, s, k); break;
+            case 3:  launch_wgrad_bf16<256, 128, 32, 3, 8, true>(grid, s, k); break;
+            case 4:  launch_wgrad_bf16<128, 128, 32, 3, 4, false>(grid, s, k); break;
+            case 5:  launch_wgrad_bf16<256, 128, 32, 4, 8, true>(grid, s, k); break;
+            case 6:  launch_wgrad_bf16<128, 128, 32, 3, 4, true, true>(grid, s, k); break;
+            case 7:  launch_wgrad_bf16<256, 128, 32, 3, 8, true, true>(grid, s, k); break;
+            default: launch_wgrad_bf16<128, 128, 32, 3, 4, true>(grid, s, k); break;
+        }
+    }
     int launch(hipStream_t s) override {
         dim3 grid((unsigned)(k.m_tiles * k.n_tiles), (unsigned)splits);
-        if (dtype == V2V_BF16 && bm == 128) {
-            auto kern = conv_wgrad_bf16_kernel<128, 128, 32, 3>;
-            const size_t lds = 3 * (32 * 128 + 32 * 128) * 2;
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
-        } else if (dtype == V2V_BF16 && !legacy_bf16()) {
-            auto kern = conv_wgrad_bf16_kernel<64, 128, 32, 3>;
-            const size_t lds = 3 * (32 * 64 + 32 * 128) * 2;
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+        if (dtype == V2V_BF16 && !legacy_bf16()) {
+            launch_bf16(grid, s);
         } else if (dtype == V2V_BF16) {
             auto kern = conv_wgrad_kernel<bf16_t, 64, 128, 32, 3>;
             const size_t lds = 3 * (32 * 64 + 32 * 128) * 2;
@@ -423,7 +470,15 @@ struct WgradOp : Op {
         }
         int rc = check_launch();
         if (rc != 0) return rc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)r.R, (unsigned)ceil_div(r.C, 64)), dim3(256), 0, s, r);
+        WgradReduceArgs rr = r;
+        if (r.splits > 16) {          // many K splits (few tiles, many pixels): fold them 8-fold in place, in parallel
+            const long long n = (long long)r.Rp * r.Cp;
+            hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)ceil_div(n, 256), 8), dim3(256), 0, s, r.slab, n, r.splits);
+            rc = check_launch();
+            if (rc != 0) return rc;
+            rr.splits = 8;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)r.R, (unsigned)ceil_div(r.C, 64)), dim3(256), 0, s, rr);
         return check_launch();
     }
     const char* name() const override { return "conv_wgrad"; }
@@ -433,7 +488,8 @@ static const int WG_BN = 128, WG_BK = 32;
 
 // row-tile height: 128 on the bf16 matrix pipe when the layer has more than 64 gradient rows, else 64
 static int wgrad_bm(const v2v_wgrad_desc* d) {
-    return (d->dtype == V2V_BF16 && d->rows > 64 && !legacy_bf16()) ? 128 : 64;
+    if (!(d->dtype == V2V_BF16 && d->rows > 64 && !legacy_bf16())) return 64;
+    return (wgrad_cfg() == 3 || wgrad_cfg() == 5 || wgrad_cfg() == 7) ? 256 : 128;
 }
 
 static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* splits, int* kper) {
@@ -443,7 +499,7 @@ static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* 
     *m_tiles = (int)ceil_div(d->rows, WG_BM);
     *n_tiles = (int)ceil_div(ncols, WG_BN);
     const long long tiles = (long long)*m_tiles * *n_tiles;
-    long long s = ceil_div(512, tiles);                  // ~2 workgroups per CU: every split costs a slab write + read
+    long long s = ceil_div(1024, tiles);                 // ~4 workgroups per CU (512 measured slower: profiles/r01 q1 vs q2)
     const long long smax = ceil_div(kpix, 8 * WG_BK);     // at least 8 chunks per split
     if (s > smax) s = smax;
     if (s < 1) s = 1;
