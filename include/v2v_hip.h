@@ -381,6 +381,13 @@ int       v2v_plan_profile(v2v_plan* p, void* stream, float* ms, int32_t n);
 const char* v2v_plan_op_name(const v2v_plan* p, int32_t i);
 int       v2v_plan_set_label(v2v_plan* p, const char* label);   /* labels the last recorded op */
 const char* v2v_plan_op_label(const v2v_plan* p, int32_t i);
+/* Lanes = parallel branches of a recorded plan (0..7, thread-local; default 0).  Ops recorded after v2v_plan_set_lane(k)
+ * belong to lane k; v2v_plan_lane_wait(w, s) records the only kind of cross-lane edge: lane w continues after everything
+ * recorded so far on lane s (a lane's first use must be preceded by such a wait = the fork).  v2v_plan_instantiate_graph
+ * captures each lane on its own stream (parallel hipGraph paths, all joined into lane 0 at the end); eager replays run in
+ * recording order.  Outside a recording both calls are no-ops on the data path. */
+int       v2v_plan_set_lane(int32_t lane);
+int       v2v_plan_lane_wait(int32_t waiter, int32_t signal);
 
 /* recordable device-to-device copy (rolling fake_B_prev window, vid2vid_model_G.py:228) */
 int v2v_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);

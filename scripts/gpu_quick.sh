@@ -15,6 +15,20 @@ if has wgradcfg; then
     echo "== V2V_WGRAD_CFG=$c"; V2V_WGRAD_CFG=$c timeout 200 python scripts/wgrad_bench.py 2>&1 | grep -E "^wgrad|worst|Error|error" | head -9 | cut -c1-150
   done > gpurun_out/${TAG}_wgrad_cfgs.txt 2>&1; cat gpurun_out/${TAG}_wgrad_cfgs.txt
 fi
+if has lanes; then
+  V2V_LANES=1 timeout 600 python -m pytest tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 180 -k "inference or graph or full_size" > gpurun_out/${TAG}_pytest_lanes.log 2>&1; echo "pytest(lanes) rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_lanes.log | tail -8
+  LT=$R/gpurun_out/${TAG}_tune_lanes.json; rm -f $LT
+  V2V_LANES=0 V2V_TUNE_CACHE=$LT timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_lanes0.json 2> gpurun_out/${TAG}_bench_lanes0.err; echo "bench lanes=0 rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_lanes0.json
+  V2V_LANES=1 V2V_TUNE_CACHE=$LT timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_lanes1.json 2> gpurun_out/${TAG}_bench_lanes1.err; echo "bench lanes=1 rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_lanes1.json; tail -2 gpurun_out/${TAG}_bench_lanes1.err
+  V2V_LANES=0 V2V_TUNE_CACHE=$LT timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_lanes0b.json 2> gpurun_out/${TAG}_bench_lanes0b.err; echo "bench lanes=0 (again) rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_lanes0b.json
+  V2V_LANES=1 V2V_TUNE_CACHE=$LT timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_lanes1b.json 2> gpurun_out/${TAG}_bench_lanes1b.err; echo "bench lanes=1 (again) rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_lanes1b.json
+fi
+if has big; then
+  BT=$R/gpurun_out/${TAG}_tune_2048.json; rm -f $BT
+  V2V_LANES=0 V2V_TUNE_CACHE=$BT timeout 600 python bench.py --steps 10 --warmup 3 --width 2048 --height 1024 --scales 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_2048_lanes0.json 2> gpurun_out/${TAG}_bench_2048_lanes0.err; echo "bench2048 lanes=0 rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_2048_lanes0.json
+  V2V_LANES=1 V2V_TUNE_CACHE=$BT timeout 600 python bench.py --steps 10 --warmup 3 --width 2048 --height 1024 --scales 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_2048_bf16.json 2> gpurun_out/${TAG}_bench_2048_bf16.err; echo "bench2048 lanes=1 rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_2048_bf16.json; tail -2 gpurun_out/${TAG}_bench_2048_bf16.err
+fi
 if has tests; then
   timeout 600 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 180 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest.log | tail -20

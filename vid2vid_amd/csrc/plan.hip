@@ -11,6 +11,7 @@ namespace v2v {
 
 static thread_local char g_err[512] = "";
 static thread_local v2v_plan* g_recording = nullptr;
+static thread_local int g_lane = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -31,6 +32,7 @@ namespace v2v {
 
 int submit(std::unique_ptr<Op> op, void* stream) {
     if (g_recording) {
+        op->lane = g_lane;
         g_recording->ops.push_back(std::move(op));
         return 0;
     }
@@ -39,7 +41,36 @@ int submit(std::unique_ptr<Op> op, void* stream) {
 
 }  // namespace v2v
 
+namespace v2v {
+// Lanes: independent branches of the per-frame computation (the label / image / foreground towers and the image / flow
+// branches of CompositeGenerator, models/networks.py:203-232) are recorded on different lanes; when the plan becomes a
+// hipGraph each lane is captured on its own stream, so the branches are parallel graph paths and the tail of one
+// kernel overlaps the next kernels of the other branches.  A WaitOp is the only cross-lane edge: lane `waiter`
+// continues after everything recorded so far on lane `signal`.  Eager replays (v2v_plan_run / v2v_plan_profile) run
+// the ops in recording order on one stream, which is a valid topological order.
+struct WaitOp : Op {
+    int waiter = 0, signal = 0;
+    int launch(hipStream_t) override { return 0; }
+    const char* name() const override { return "lane_wait"; }
+};
+}  // namespace v2v
+
 using namespace v2v;
+
+extern "C" int v2v_plan_set_lane(int32_t lane) {
+    if (lane < 0 || lane >= 8) { set_error("plan: lane out of range"); return V2V_EINVAL; }
+    g_lane = lane;
+    return 0;
+}
+
+extern "C" int v2v_plan_lane_wait(int32_t waiter, int32_t signal) {
+    if (waiter < 0 || waiter >= 8 || signal < 0 || signal >= 8) { set_error("plan: lane out of range"); return V2V_EINVAL; }
+    if (!g_recording || waiter == signal) return 0;            // eager execution is ordered already
+    auto op = std::make_unique<WaitOp>();
+    op->waiter = waiter; op->signal = signal; op->lane = waiter;
+    g_recording->ops.push_back(std::move(op));
+    return 0;
+}
 
 extern "C" v2v_plan* v2v_plan_create(void) { return new v2v_plan(); }
 
@@ -92,9 +123,35 @@ extern "C" int v2v_plan_instantiate_graph(v2v_plan* p, void* stream) {
     if (e != hipSuccess) { set_error("plan: capture stream: %s", hipGetErrorString(e)); return (int)e; }
     e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { set_error("plan: begin capture: %s", hipGetErrorString(e)); hipStreamDestroy(cs); return (int)e; }
-    rc = v2v_plan_run(p, cs);
+    // lanes -> streams of the same capture: a lane joins when its first WaitOp makes it wait for an event of a lane
+    // that is already capturing; every lane is joined back into lane 0 before the capture ends
+    hipStream_t ls[8] = {cs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool joined[8] = {true, false, false, false, false, false, false, false};
+    std::vector<hipEvent_t> evs;
+    auto edge = [&](int waiter, int signal) -> int {
+        if (!joined[signal]) { set_error("plan: lane %d waits for lane %d, which has no work yet", waiter, signal); return V2V_EINVAL; }
+        if (!ls[waiter] && hipStreamCreateWithFlags(&ls[waiter], hipStreamNonBlocking) != hipSuccess) { set_error("plan: lane stream"); return V2V_EINVAL; }
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("plan: lane event"); return V2V_EINVAL; }
+        evs.push_back(ev);
+        hipError_t q = hipEventRecord(ev, ls[signal]);
+        if (q == hipSuccess) q = hipStreamWaitEvent(ls[waiter], ev, 0);
+        if (q != hipSuccess) { set_error("plan: lane edge: %s", hipGetErrorString(q)); return (int)q; }
+        joined[waiter] = true;
+        return 0;
+    };
+    rc = 0;
+    for (auto& op : p->ops) {
+        if (WaitOp* w = dynamic_cast<WaitOp*>(op.get())) { rc = edge(w->waiter, w->signal); }
+        else if (!joined[op->lane]) { set_error("plan: op '%s' recorded on lane %d before the lane was forked", op->name(), op->lane); rc = V2V_EINVAL; }
+        else rc = op->launch(ls[op->lane]);
+        if (rc != 0) break;
+    }
+    for (int k = 1; k < 8 && rc == 0; ++k)
+        if (joined[k]) rc = edge(0, k);
     hipError_t e2 = hipStreamEndCapture(cs, &p->graph);
-    hipStreamDestroy(cs);
+    for (int k = 0; k < 8; ++k) if (ls[k]) hipStreamDestroy(ls[k]);
+    for (auto ev : evs) hipEventDestroy(ev);
     if (rc != 0) return rc;
     if (e2 != hipSuccess) { set_error("plan: end capture: %s", hipGetErrorString(e2)); return (int)e2; }
     e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);

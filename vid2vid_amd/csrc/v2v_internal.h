@@ -62,6 +62,7 @@ struct Op {
     virtual int launch(hipStream_t s) = 0;
     virtual const char* name() const = 0;
     std::string label;
+    int lane = 0;          // plan lane (hipGraph branch) the op was recorded on; see plan.hip
 };
 
 // Either launches `op` now on `stream` or, when a plan is recording on this thread,

@@ -15,6 +15,7 @@ All tensors handed to the library are NHWC with a channel stride padded to 16 by
 emitted launches either run immediately (eager) or are recorded into a `Plan` that is then
 replayed per frame as one native call / one hipGraph.  No torch compute op is on this path.
 """
+import contextlib
 import ctypes as C
 import json
 import math
@@ -233,8 +234,10 @@ class Engine:
         self._scratch = {}       # name -> tensor (grown on demand, shared between layers)
         self._grids = {}
         self._zero_page = None
-        self._fin_counter = None
-        self._sk_counter = None
+        self._fin_counters = {}   # per plan lane: concurrent branches must not share ticket words
+        self._sk_counters = {}
+        self._lane = 0           # current plan lane (hipGraph branch); selects the scratch set
+        self.lanes_enabled = False   # set by the frame plan: emit independent towers / branches on parallel lanes
         self._thrash = None
         self.plan = None        # Plan being recorded (for labels / keep-alive)
         self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
@@ -275,7 +278,7 @@ class Engine:
     def scratch(self, name, numel, dtype=torch.float32):
         """Shared scratch (conv raw output, statistics): consumed by the next launch on the
         same stream, so one buffer per kind is enough."""
-        key = (name, dtype)
+        key = (name, dtype, self._lane)
         t = self._scratch.get(key)
         if t is None or t.numel() < numel:
             if self.plan is not None and t is not None and not self.record_only:
@@ -296,6 +299,38 @@ class Engine:
     def label(self, text):
         if self.plan is not None:
             self.plan.label(text)
+
+    @property
+    def _sk_counter(self):       # lane-0 split-K ticket words (tests check that kernels re-arm them)
+        return self._sk_counters.get(0)
+
+    @property
+    def _fin_counter(self):
+        return self._fin_counters.get(0)
+
+    # ---------------- plan lanes (parallel hipGraph branches) ----------------
+    @contextlib.contextmanager
+    def on_lane(self, k):
+        """Emit the enclosed launches on plan lane k: a branch that starts after everything emitted so far on the
+        current lane and runs concurrently with what the current lane emits next (include/v2v_hip.h, v2v_plan_set_lane).
+        Each lane has its own scratch set / ticket words.  Without `lanes_enabled` this is a no-op."""
+        parent = self._lane
+        if not self.lanes_enabled or k == parent:
+            yield
+            return
+        check(lib.v2v_plan_lane_wait(k, parent), "plan_lane_wait")       # fork
+        self._lane = k
+        check(lib.v2v_plan_set_lane(k), "plan_set_lane")
+        try:
+            yield
+        finally:
+            self._lane = parent
+            check(lib.v2v_plan_set_lane(parent), "plan_set_lane")
+
+    def join(self, k):
+        """The current lane continues after everything emitted so far on lane k."""
+        if self.lanes_enabled and k != self._lane:
+            check(lib.v2v_plan_lane_wait(self._lane, k), "plan_lane_wait")
 
     def zero_page(self):
         """256 zero bytes: source of padded / ragged lanes of the LDS-DMA loaders."""
@@ -398,16 +433,17 @@ class Engine:
             if fin is not None:
                 norm, ss = fin
                 gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
-                if self._fin_counter is None:
-                    self._fin_counter = torch.zeros(256, dtype=torch.int32, device=self.device)
-                d.fin_counter = self._fin_counter.data_ptr()
+                fin_counter = self._fin_counters.get(self._lane)
+                if fin_counter is None:
+                    fin_counter = self._fin_counters[self._lane] = torch.zeros(256, dtype=torch.int32, device=self.device)
+                d.fin_counter = fin_counter.data_ptr()
                 d.fin_gamma = None if gamma is None else gamma.data_ptr()
                 d.fin_beta = None if beta is None else beta.data_ptr()
                 d.fin_scale_shift = ss.data_ptr()
                 d.fin_running_mean = None if rm is None else rm.data_ptr()
                 d.fin_running_var = None if rv is None else rv.data_ptr()
                 d.fin_eps, d.fin_momentum, d.fin_count = eps, mom, N * OH * OW
-                for t in (gamma, beta, ss, self._fin_counter):
+                for t in (gamma, beta, ss, fin_counter):
                     if t is not None:
                         self._keep(t)
         if pc.bias is not None:
@@ -502,13 +538,14 @@ class Engine:
         nbytes = lib.v2v_conv_splitk_workspace(C.byref(d), C.byref(tickets))
         if nbytes <= 0:
             return False
-        if self._sk_counter is None or self._sk_counter.numel() < tickets.value:
+        skc = self._sk_counters.get(self._lane)
+        if skc is None or skc.numel() < tickets.value:
             if self.plan is not None and not self.record_only:
                 raise RuntimeError("split-K ticket buffer must not grow while a plan is recording")
-            self._sk_counter = torch.zeros(max(4096, tickets.value), dtype=torch.int32, device=self.device)
+            skc = self._sk_counters[self._lane] = torch.zeros(max(4096, tickets.value), dtype=torch.int32, device=self.device)
         d.slabs = self.scratch("slabs", (nbytes + 3) // 4).data_ptr()
-        d.sk_counter = self._sk_counter.data_ptr()
-        self._keep(self._sk_counter)
+        d.sk_counter = skc.data_ptr()
+        self._keep(skc)
         return True
 
     def _autotune(self, d, want_stats, cout, mod=None, cin_stride=0, reps=5):

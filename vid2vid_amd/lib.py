@@ -118,6 +118,8 @@ PROTOTYPES = {
     "v2v_plan_op_name": (C.c_char_p, [_P, _I]),
     "v2v_plan_set_label": (C.c_int, [_P, C.c_char_p]),
     "v2v_plan_op_label": (C.c_char_p, [_P, _I]),
+    "v2v_plan_set_lane": (C.c_int, [_I]),
+    "v2v_plan_lane_wait": (C.c_int, [_I, _I]),
     "v2v_memcpy_d2d": (C.c_int, [_P, _P, _L, _P]),
     "v2v_version": (C.c_int, []),
     "v2v_last_error": (C.c_char_p, []),

@@ -42,6 +42,17 @@ class _FramePlan:
         self.prev = [torch.zeros(tG - 1, opt.output_nc, H >> si, W >> si, dtype=torch.float32, device=dev)
                      for si in range(S)]
         self.out = {}
+        # independent towers / branches on parallel plan lanes (parallel hipGraph paths); opt.lanes or V2V_LANES
+        import os
+        self.lanes = bool(int(getattr(opt, "lanes", os.environ.get("V2V_LANES", "1")))) and use_graph
+        eng.lanes_enabled = self.lanes
+        try:
+            self._build(model, opt, eng, use_graph)
+        finally:
+            eng.lanes_enabled = False
+
+    def _build(self, model, opt, eng, use_graph):
+        dev = eng.device
         # warm-up pass sizes the shared scratch, then the same code is recorded
         if not eng.record_only:
             prev_autotune = eng.autotune

@@ -280,26 +280,55 @@ class CompositeGenerator(BaseNetwork):
 
     def emit(self, eng, x, prev, img_prev_nchw, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse,
              use_raw_only, tag="G0"):
-        """x: Act labels (NHWC), prev: Act previous frames (NHWC), img_prev_nchw: fp32 planar."""
-        seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
-        down = eng.run_sequential(self.model_down_img, prev, extra_add=seg, name=tag + ".down_img")
-        img_feat = eng.run_sequential(self.model_up_img,
-                                      eng.run_sequential(self.model_res_img, down, name=tag + ".res_img"),
-                                      name=tag + ".up_img")
-        img_raw = eng.run_sequential(self.model_final_img, img_feat, head_nchw=True, name=tag + ".final_img")
-        flow = weight = flow_feat = None
-        if not self.no_flow:
+        """x: Act labels (NHWC), prev: Act previous frames (NHWC), img_prev_nchw: fp32 planar.
+        The label tower, the image tower and the foreground tower are independent until they are summed / blended, and
+        so are the image and flow branches behind the sum (models/networks.py:203-232): with `eng.lanes_enabled` (frame
+        plans) they are emitted on parallel plan lanes = parallel hipGraph paths."""
+        lanes = eng.lanes_enabled
+        img_fg = img_fg_feat = None
+
+        def fg_tower():
+            f = eng.run_sequential(self.indv_down, x, name=tag + ".indv_down")
+            f = eng.run_sequential(self.indv_res, f, name=tag + ".indv_res")
+            feat = eng.run_sequential(self.indv_up, f, name=tag + ".indv_up")
+            return feat, eng.run_sequential(self.indv_final, feat, head_nchw=True, name=tag + ".indv_final")
+
+        def flow_branch(down):
             res_flow = eng.run_sequential(self.model_res_flow, down, name=tag + ".res_flow")
             flow_feat = eng.run_sequential(self.model_up_flow, res_flow, name=tag + ".up_flow")
             flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
                                       out_scale=self.flow_multiplier(), name=tag + ".final_flow")
             weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
-        img_fg = img_fg_feat = None
-        if self.use_fg_model:
-            f = eng.run_sequential(self.indv_down, x, name=tag + ".indv_down")
-            f = eng.run_sequential(self.indv_res, f, name=tag + ".indv_res")
-            img_fg_feat = eng.run_sequential(self.indv_up, f, name=tag + ".indv_up")
-            img_fg = eng.run_sequential(self.indv_final, img_fg_feat, head_nchw=True, name=tag + ".indv_final")
+            return flow, weight, flow_feat
+
+        if lanes:
+            with eng.on_lane(1):
+                seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
+            if self.use_fg_model:
+                with eng.on_lane(2):
+                    img_fg_feat, img_fg = fg_tower()
+            down = eng.run_sequential(self.model_down_img, prev, name=tag + ".down_img")
+            eng.join(1)
+            down = eng.add(down, seg)                    # the tower sum as its own launch (fused into the last norm otherwise)
+        else:
+            seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
+            down = eng.run_sequential(self.model_down_img, prev, extra_add=seg, name=tag + ".down_img")
+        flow = weight = flow_feat = None
+        if lanes and not self.no_flow:
+            with eng.on_lane(1):
+                flow, weight, flow_feat = flow_branch(down)
+        img_feat = eng.run_sequential(self.model_up_img,
+                                      eng.run_sequential(self.model_res_img, down, name=tag + ".res_img"),
+                                      name=tag + ".up_img")
+        img_raw = eng.run_sequential(self.model_final_img, img_feat, head_nchw=True, name=tag + ".final_img")
+        if not lanes and not self.no_flow:
+            flow, weight, flow_feat = flow_branch(down)
+        if not lanes and self.use_fg_model:
+            img_fg_feat, img_fg = fg_tower()
+        if lanes:
+            eng.join(1)
+            if self.use_fg_model:
+                eng.join(2)
         img_final, img_raw = self._tail(eng, img_raw, flow, weight, img_prev_nchw, img_fg, mask, use_raw_only)
         return img_final, flow, weight, img_raw, img_feat, flow_feat, img_fg_feat
 
@@ -366,21 +395,49 @@ class CompositeLocalGenerator(BaseNetwork):
 
     def emit(self, eng, x, prev, img_prev_nchw, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse,
              use_raw_only, tag="G1"):
-        seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
-        down = eng.run_sequential(self.model_down_img, prev, extra_add=seg, name=tag + ".down_img")
-        img_feat = eng.run_sequential(self.model_up_img, eng.add(down, img_feat_coarse), name=tag + ".up_img")
-        img_raw = eng.run_sequential(self.model_final_img, img_feat, head_nchw=True, name=tag + ".final_img")
-        flow = weight = flow_feat = None
-        if not self.no_flow:
+        """Same lane structure as CompositeGenerator.emit: label stem | image stem | foreground branch in parallel, then
+        image branch | flow branch (models/networks.py:296-325)."""
+        lanes = eng.lanes_enabled
+        img_fg = img_fg_feat = None
+
+        def fg_branch():
+            f = eng.run_sequential(self.indv_down, x, extra_add=img_fg_feat_coarse, name=tag + ".indv_down")
+            feat = eng.run_sequential(self.indv_up, f, name=tag + ".indv_up")
+            return feat, eng.run_sequential(self.indv_final, feat, head_nchw=True, name=tag + ".indv_final")
+
+        def flow_branch(down):
             flow_feat = eng.run_sequential(self.model_up_flow, eng.add(down, flow_feat_coarse), name=tag + ".up_flow")
             flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
                                       out_scale=self.flow_multiplier(), name=tag + ".final_flow")
             weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
-        img_fg = img_fg_feat = None
-        if self.use_fg_model:
-            f = eng.run_sequential(self.indv_down, x, extra_add=img_fg_feat_coarse, name=tag + ".indv_down")
-            img_fg_feat = eng.run_sequential(self.indv_up, f, name=tag + ".indv_up")
-            img_fg = eng.run_sequential(self.indv_final, img_fg_feat, head_nchw=True, name=tag + ".indv_final")
+            return flow, weight, flow_feat
+
+        if lanes:
+            with eng.on_lane(1):
+                seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
+            if self.use_fg_model:
+                with eng.on_lane(2):
+                    img_fg_feat, img_fg = fg_branch()
+            down = eng.run_sequential(self.model_down_img, prev, name=tag + ".down_img")
+            eng.join(1)
+            down = eng.add(down, seg)
+        else:
+            seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
+            down = eng.run_sequential(self.model_down_img, prev, extra_add=seg, name=tag + ".down_img")
+        flow = weight = flow_feat = None
+        if lanes and not self.no_flow:
+            with eng.on_lane(1):
+                flow, weight, flow_feat = flow_branch(down)
+        img_feat = eng.run_sequential(self.model_up_img, eng.add(down, img_feat_coarse), name=tag + ".up_img")
+        img_raw = eng.run_sequential(self.model_final_img, img_feat, head_nchw=True, name=tag + ".final_img")
+        if not lanes and not self.no_flow:
+            flow, weight, flow_feat = flow_branch(down)
+        if not lanes and self.use_fg_model:
+            img_fg_feat, img_fg = fg_branch()
+        if lanes:
+            eng.join(1)
+            if self.use_fg_model:
+                eng.join(2)
         img_final, img_raw = self._tail(eng, img_raw, flow, weight, img_prev_nchw, img_fg, mask, use_raw_only)
         return img_final, flow, weight, img_raw, img_feat, flow_feat, img_fg_feat
 
