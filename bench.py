@@ -415,6 +415,8 @@ def main():
                                    % (args.dataset, W, H, args.scales, "input_nc=15, no fg tower" if face else "--fg --use_instance", sum(q.numel() for q in model.parameters()) / 1e6,
                                       sum(c["flops"] for c in fp.conv_log) / 1e9),
                        "launches_per_frame": fp.plan.num_ops, "hipgraph": bool(opt.use_graph),
+                       "graph_lanes": 3 if getattr(fp, "lanes", False) else 1,
+                       "frame_tune": getattr(fp, "frame_tune_log", None),
                        "parallelism": "replicas x%d (independent sequences, no collective)" % args.gpus,
                        "output_finite": finite},
             "roofline": roofline,

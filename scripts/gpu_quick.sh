@@ -29,6 +29,19 @@ if has big; then
   V2V_LANES=0 V2V_TUNE_CACHE=$BT timeout 600 python bench.py --steps 10 --warmup 3 --width 2048 --height 1024 --scales 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_2048_lanes0.json 2> gpurun_out/${TAG}_bench_2048_lanes0.err; echo "bench2048 lanes=0 rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_2048_lanes0.json
   V2V_LANES=1 V2V_TUNE_CACHE=$BT timeout 600 python bench.py --steps 10 --warmup 3 --width 2048 --height 1024 --scales 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_2048_bf16.json 2> gpurun_out/${TAG}_bench_2048_bf16.err; echo "bench2048 lanes=1 rc=$?"; cut -c1-200 gpurun_out/${TAG}_bench_2048_bf16.json; tail -2 gpurun_out/${TAG}_bench_2048_bf16.err
 fi
+if has override; then
+  OT=$R/gpurun_out/${TAG}_tune_ov.json; rm -f $OT
+  V2V_TUNE_CACHE=$OT timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_ov_base.json 2>/dev/null; echo "base: $(cut -c60-130 gpurun_out/${TAG}_bench_ov_base.json)"
+  for ov in "1024,1024,3,1,0:55,1,0" "1024,1024,3,1,0:57,1,0" "1024,1024,3,1,0:53,1,0" "1024,1024,3,1,0:50,1,0" "1024,1024,3,1,0:55,1,0;512,512,3,1,0:55,1,0" "512,512,3,1,0:55,1,0" "512,512,3,1,0:57,1,0"; do
+    V2V_TILE_OVERRIDE="$ov" V2V_TUNE_CACHE=$OT timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_ov.json 2>/dev/null; echo "$ov: $(cut -c60-130 gpurun_out/${TAG}_bench_ov.json)"
+  done
+fi
+if has ftune; then
+  FT=$R/gpurun_out/${TAG}_tune_ft.json; rm -f $FT
+  V2V_TUNE_CACHE=$FT timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_ft.json 2> gpurun_out/${TAG}_bench_ft.err; echo "bench frame-tune rc=$?"; cut -c1-700 gpurun_out/${TAG}_bench_ft.json; grep "frame tune" gpurun_out/${TAG}_bench_ft.err
+  V2V_TUNE_CACHE=$FT timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_ft2.json 2> gpurun_out/${TAG}_bench_ft2.err; echo "bench replay rc=$?"; cut -c60-130 gpurun_out/${TAG}_bench_ft2.json
+  V2V_FRAME_TUNE=0 timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_noft.json 2> gpurun_out/${TAG}_bench_noft.err; echo "bench no frame-tune rc=$?"; cut -c60-130 gpurun_out/${TAG}_bench_noft.json
+fi
 if has tests; then
   timeout 600 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 180 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest.log | tail -20

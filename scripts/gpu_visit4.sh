@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-v}; shift
-WHAT=${*:-tests smoke bench traffic prof train trainprof train1024 face}
+WHAT=${*:-tests smoke bench traffic prof profeager train trainprof train1024 face big}
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 T0=$(date +%s)
 lap() { echo "[$(( $(date +%s) - T0 )) s] $1"; }
@@ -59,6 +59,17 @@ if has prof; then
   head -12 $R/gpurun_out/${TAG}_kernel_stats.txt | cut -c1-180
   cd $R
   lap prof
+fi
+if has profeager; then
+  # the same selections replayed WITHOUT the graph (one stream, kernels alone on the chip): per-kernel durations that
+  # the HIP-event figures of roofline.achieved must agree with
+  cd /tmp
+  V2V_TUNE_CACHE=$TUNE timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/profe_$TAG -o bench -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-graph > $R/gpurun_out/${TAG}_bench_prof_eager.json 2> $R/gpurun_out/${TAG}_bench_prof_eager.err; echo "rocprof(eager) rc=$?"
+  python $R/scripts/rocprof_summary.py $(find /tmp/profe_$TAG -name "*.db" | head -1) "# round 1, visit $TAG: V2V_TUNE_CACHE=<selections of the preceding bench run> rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-graph (bf16, 512x256; eager single-stream replay: every kernel alone on the chip)" > $R/gpurun_out/${TAG}_kernel_stats_eager.txt 2>> $R/gpurun_out/${TAG}_bench_prof_eager.err
+  head -8 $R/gpurun_out/${TAG}_kernel_stats_eager.txt | cut -c1-180
+  cut -c1-200 $R/gpurun_out/${TAG}_bench_prof_eager.json
+  cd $R
+  lap profeager
 fi
 TTUNE=$R/gpurun_out/${TAG}_tune_train.json
 if has train; then

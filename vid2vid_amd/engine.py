@@ -242,8 +242,14 @@ class Engine:
         self.plan = None        # Plan being recorded (for labels / keep-alive)
         self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
         self.tile_override = {}  # (cin,cout,KH,stride,transposed) -> tile id (tests / manual tuning)
+        # V2V_TILE_OVERRIDE="cin,cout,K,stride,transposed:tile,splitk,prefetch;..." pins configurations (experiments)
+        for item in os.environ.get("V2V_TILE_OVERRIDE", "").split(";"):
+            if ":" in item:
+                k, v = item.split(":")
+                self.tile_override[tuple(int(x) for x in k.split(","))] = tuple(int(x) for x in v.split(","))
         self.autotune = False    # measure the tile configurations once per conv shape (plan build time)
         self._tuned = {}         # (cin,cout,KH,stride,transposed,N,H,W,out_mode,Cs) -> (tile, splitk, prefetch)
+        self._tune_alts = {}     # same key -> runner-up configurations of the isolated search (this process only)
         # optional persistent tuning cache (V2V_TUNE_CACHE=<json>): a profiling run can replay exactly the
         # configurations a previous benchmark run selected instead of re-measuring them under the profiler
         self._tune_cache_path = os.environ.get("V2V_TUNE_CACHE", "")
@@ -451,6 +457,7 @@ class Engine:
         if (self.autotune and d.tile == 0 and self.plan is None and not self.record_only
                 and not torch.is_grad_enabled()):
             self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout, mod, x.Cs)
+            self._tune_alts[tune_key] = list(getattr(self, "_last_alts", []))
             self._save_tune_cache()
             d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
             pc = self._use_korder1(d, mod, x.Cs) if 32 <= d.tile < 60 else self._use_korder0(d, mod, x.Cs)
@@ -465,7 +472,7 @@ class Engine:
         ntaps = pc.KH * pc.KW
         if len(self.conv_log) >= 100000:          # eager (training) use without a consumer: keep the log bounded
             del self.conv_log[:]
-        self.conv_log.append(dict(label=label, N=N, H=H, W=W, OH=OH, OW=OW, cin=pc.cin, cout=pc.cout,
+        self.conv_log.append(dict(label=label, N=N, H=H, W=W, OH=OH, OW=OW, cin=pc.cin, cout=pc.cout, tune_key=tune_key,
                                   KH=pc.KH, KW=pc.KW, stride=pc.stride, transposed=pc.transposed,
                                   flops=2.0 * N * (H * W if pc.transposed else OH * OW) * pc.cout * pc.cin * ntaps,
                                   tile=lib.v2v_conv_tile_config(C.byref(d)), splitk=max(int(d.splitk), 1),
@@ -626,6 +633,14 @@ class Engine:
             ms = time_cfg(cfg[0], cfg[1], cfg[2], 11)
             if ms is not None and ms < best_ms:
                 best, best_ms = cfg, ms
+        # runners-up for the whole-frame search of the frame plan (models/vid2vid_model_G._FramePlan._frame_tune): the
+        # fastest few in isolation plus the fastest unsplit ones (split-K fills an idle chip; beside concurrent lanes it
+        # only adds slab traffic)
+        unsplit = [cfg for _, cfg in timed if cfg[1] <= 1]
+        alts = ([cfg for _, cfg in timed[:3]] + unsplit[:3]
+                + [cfg for _, cfg in timed if cfg[0] == best[0] and cfg[1] <= 2]          # the winner's tile, less split
+                + [cfg for cfg in unsplit if 50 <= cfg[0] < 60][:1])                        # the best unsplit ping-pong tile
+        self._last_alts = [c for i, c in enumerate(alts) if c != best and c not in alts[:i]][:7]
         return best
 
     def _norm_params(self, norm, N):

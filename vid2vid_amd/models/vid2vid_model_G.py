@@ -11,6 +11,8 @@ rolling window update; reference :198-229) to a recorded launch sequence over pr
 buffers, instantiates it as a hipGraph, and every later frame is: refresh the input buffers,
 one graph launch.  The reference issues ~240 framework ops per frame from Python instead.
 """
+import os
+
 import torch
 
 from .. import lib as L
@@ -43,7 +45,6 @@ class _FramePlan:
                      for si in range(S)]
         self.out = {}
         # independent towers / branches on parallel plan lanes (parallel hipGraph paths); opt.lanes or V2V_LANES
-        import os
         self.lanes = bool(int(getattr(opt, "lanes", os.environ.get("V2V_LANES", "1")))) and use_graph
         eng.lanes_enabled = self.lanes
         try:
@@ -62,6 +63,12 @@ class _FramePlan:
             finally:
                 eng.autotune = prev_autotune
             torch.cuda.synchronize(dev)
+        self._record(use_graph)
+        if use_graph and not eng.record_only and self.lanes and bool(int(getattr(opt, "frame_tune", os.environ.get("V2V_FRAME_TUNE", "1")))):
+            self._frame_tune(use_graph)
+
+    def _record(self, use_graph):
+        eng = self.eng
         self.plan = Plan()
         eng.plan = self.plan
         try:
@@ -71,6 +78,67 @@ class _FramePlan:
             eng.plan = None
         if use_graph and not eng.record_only:
             self.plan.instantiate_graph()
+
+    def _time_frames(self, n=8, reps=5):
+        """Median ms per replay of the current graph (buffers hold whatever they hold: the timing is data independent)."""
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                self.plan.launch()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) / n)
+        return sorted(ts)[len(ts) // 2]
+
+    def _frame_tune(self, use_graph, max_trials=120, min_gain=0.005, max_seconds=20.0):
+        """Whole-frame tile search.  The per-shape search (Engine._autotune) times every convolution alone on an idle
+        chip; inside the frame graph the lanes run beside each other, where e.g. split-K (which fills an idle chip) only
+        adds slab traffic.  Greedy pass over the conv shapes of this plan, heaviest first: swap in each runner-up of the
+        isolated search, re-record, keep it if the measured frame time drops by more than `min_gain`."""
+        eng = self.eng
+        work = {}
+        for c in self.conv_log:
+            k = c.get("tune_key")
+            if k in eng._tune_alts and eng._tune_alts[k]:
+                work[k] = work.get(k, 0.0) + c["flops"]
+        if not work or sum(work.values()) < 5e10:       # nothing to search / toy networks (tests): not worth the trials
+            return
+        import time
+        t_start = time.perf_counter()
+        best_ms = self._time_frames()
+        base_ms, trials, kept, swaps = best_ms, 0, 0, []
+        for k in sorted(work, key=lambda kk: -work[kk]):
+            for cand in eng._tune_alts[k]:
+                if trials >= max_trials or time.perf_counter() - t_start > max_seconds:
+                    trials = max(trials, max_trials)
+                    break
+                prev = eng._tuned[k]
+                if tuple(cand) == tuple(prev):
+                    continue
+                eng._tuned[k] = tuple(cand)
+                try:
+                    self._emit()                    # eager pass: sizes split-K slabs / statistics rows, packs weights
+                    torch.cuda.synchronize(eng.device)
+                    self._record(use_graph)
+                    ms = self._time_frames()
+                except RuntimeError:
+                    ms = float("inf")
+                trials += 1
+                if ms < best_ms * (1.0 - min_gain):
+                    best_ms, kept = ms, kept + 1
+                    swaps.append("%dx%d k%d s%d @%dx%d: %s -> %s" % (k[0], k[1], k[2], k[3], k[7], k[6], tuple(prev), tuple(cand)))
+                else:
+                    eng._tuned[k] = prev
+            if trials >= max_trials:
+                break
+        self._emit()
+        torch.cuda.synchronize(eng.device)
+        self._record(use_graph)                      # the plan of the final selection
+        eng._save_tune_cache()
+        self.frame_tune_log = dict(base_ms=round(base_ms, 4), tuned_ms=round(best_ms, 4), trials=trials, kept=kept, swaps=swaps)
+        print("frame tune: %.3f -> %.3f ms/frame (%d trials, %d swaps kept)" % (base_ms, best_ms, trials, kept))
 
     def _emit(self):
         m, eng, opt = self.model, self.eng, self.model.opt
