@@ -358,6 +358,11 @@ def main():
             "launches_per_frame": a["launches"] // nprof,
             "flop_per_launch": a["flops"] / a["launches"],
             "resblock_1024_tflops": None if rb_tf is None else round(rb_tf, 2),
+            # the kernel figures above time every launch ALONE on the chip (eager single-stream replay); in the graph the
+            # lanes share the chip, so the whole-frame rate is the utilisation actually reached in the timed region
+            "frame_in_graph": {"achieved": round(sum(c["flops"] for c in fp.conv_log) / (elapsed / args.steps) / 1e12, 2),
+                               "unit": "TFLOP/s", "frac": round(sum(c["flops"] for c in fp.conv_log) / (elapsed / args.steps) / 1e12 / peak, 4),
+                               "note": "all conv FLOP of a frame / measured ms_per_step (norms, pooling, warp included in the time)"},
             "frame_ms_eager_events": round(sum(ms for _, _, ms in rows), 3),
             "per_kernel_ms": {k: round(v, 3) for k, v in sorted(total_ms.items(), key=lambda kv: -kv[1])},
         }

@@ -250,6 +250,7 @@ class Engine:
         self.autotune = False    # measure the tile configurations once per conv shape (plan build time)
         self._tuned = {}         # (cin,cout,KH,stride,transposed,N,H,W,out_mode,Cs) -> (tile, splitk, prefetch)
         self._tune_alts = {}     # same key -> runner-up configurations of the isolated search (this process only)
+        self._tune_wide = {}     # same key -> the wider candidate list used for the heaviest shapes of a frame
         # optional persistent tuning cache (V2V_TUNE_CACHE=<json>): a profiling run can replay exactly the
         # configurations a previous benchmark run selected instead of re-measuring them under the profiler
         self._tune_cache_path = os.environ.get("V2V_TUNE_CACHE", "")
@@ -458,6 +459,7 @@ class Engine:
                 and not torch.is_grad_enabled()):
             self._tuned[tune_key] = self._autotune(d, want_stats, pc.cout, mod, x.Cs)
             self._tune_alts[tune_key] = list(getattr(self, "_last_alts", []))
+            self._tune_wide[tune_key] = list(getattr(self, "_last_wide", []))
             self._save_tune_cache()
             d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
             pc = self._use_korder1(d, mod, x.Cs) if 32 <= d.tile < 60 else self._use_korder0(d, mod, x.Cs)
@@ -641,6 +643,9 @@ class Engine:
                 + [cfg for _, cfg in timed if cfg[0] == best[0] and cfg[1] <= 2]          # the winner's tile, less split
                 + [cfg for cfg in unsplit if 50 <= cfg[0] < 60][:1])                        # the best unsplit ping-pong tile
         self._last_alts = [c for i, c in enumerate(alts) if c != best and c not in alts[:i]][:7]
+        # for the heaviest shapes of a frame the whole-frame search also walks every lightly split configuration that was
+        # not hopeless in isolation
+        self._last_wide = [cfg for ms, cfg in timed if cfg[1] <= 2 and ms <= 1.7 * timed[0][0] and cfg != best][:16]
         return best
 
     def _norm_params(self, norm, N):

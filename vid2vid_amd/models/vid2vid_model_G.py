@@ -92,7 +92,7 @@ class _FramePlan:
             ts.append(e0.elapsed_time(e1) / n)
         return sorted(ts)[len(ts) // 2]
 
-    def _frame_tune(self, use_graph, max_trials=120, min_gain=0.005, max_seconds=20.0):
+    def _frame_tune(self, use_graph, max_trials=160, min_gain=0.005, max_seconds=40.0):
         """Whole-frame tile search.  The per-shape search (Engine._autotune) times every convolution alone on an idle
         chip; inside the frame graph the lanes run beside each other, where e.g. split-K (which fills an idle chip) only
         adds slab traffic.  Greedy pass over the conv shapes of this plan, heaviest first: swap in each runner-up of the
@@ -109,30 +109,46 @@ class _FramePlan:
         t_start = time.perf_counter()
         best_ms = self._time_frames()
         base_ms, trials, kept, swaps = best_ms, 0, 0, []
-        for k in sorted(work, key=lambda kk: -work[kk]):
-            for cand in eng._tune_alts[k]:
-                if trials >= max_trials or time.perf_counter() - t_start > max_seconds:
-                    trials = max(trials, max_trials)
+        order = sorted(work, key=lambda kk: -work[kk])
+
+        def trial(k, cand):
+            nonlocal best_ms, trials, kept
+            prev = eng._tuned[k]
+            if tuple(cand) == tuple(prev):
+                return
+            eng._tuned[k] = tuple(cand)
+            try:
+                self._emit()                    # eager pass: sizes split-K slabs / statistics rows, packs weights
+                torch.cuda.synchronize(eng.device)
+                self._record(use_graph)
+                ms = self._time_frames()
+            except RuntimeError:
+                ms = float("inf")
+            trials += 1
+            if ms < best_ms * (1.0 - min_gain):
+                best_ms, kept = ms, kept + 1
+                swaps.append("%dx%d k%d s%d @%dx%d: %s -> %s" % (k[0], k[1], k[2], k[3], k[7], k[6], tuple(prev), tuple(cand)))
+            else:
+                eng._tuned[k] = prev
+
+        def out_of_budget():
+            return trials >= max_trials or time.perf_counter() - t_start > max_seconds
+
+        # pass 1: every shape, runners-up of its isolated search; the two heaviest shapes get the wide list
+        for rank, k in enumerate(order):
+            cands = list(eng._tune_alts[k])
+            if rank < 2:
+                cands += [c for c in eng._tune_wide.get(k, []) if c not in cands]
+            for cand in cands:
+                if out_of_budget():
                     break
-                prev = eng._tuned[k]
-                if tuple(cand) == tuple(prev):
-                    continue
-                eng._tuned[k] = tuple(cand)
-                try:
-                    self._emit()                    # eager pass: sizes split-K slabs / statistics rows, packs weights
-                    torch.cuda.synchronize(eng.device)
-                    self._record(use_graph)
-                    ms = self._time_frames()
-                except RuntimeError:
-                    ms = float("inf")
-                trials += 1
-                if ms < best_ms * (1.0 - min_gain):
-                    best_ms, kept = ms, kept + 1
-                    swaps.append("%dx%d k%d s%d @%dx%d: %s -> %s" % (k[0], k[1], k[2], k[3], k[7], k[6], tuple(prev), tuple(cand)))
-                else:
-                    eng._tuned[k] = prev
-            if trials >= max_trials:
-                break
+                trial(k, cand)
+        # pass 2: the heaviest shapes again, now beside the other layers' final choices
+        for k in order[:3]:
+            for cand in eng._tune_alts[k]:
+                if out_of_budget():
+                    break
+                trial(k, cand)
         self._emit()
         torch.cuda.synchronize(eng.device)
         self._record(use_graph)                      # the plan of the final selection
