@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--num-D", type=int, default=2, help="train: discriminator scales (3 with --width 1024 --scales 2 = configs[2])")
     ap.add_argument("--frames-total", type=int, default=6, help="train: n_frames_total of a sequence (scripts/street/train_512.sh)")
     ap.add_argument("--frames-per-gpu", type=int, default=2, help="train: max_frames_per_gpu = frames per chunk")
-    ap.add_argument("--with-vgg", action="store_true", help="train: include the VGG19 perceptual loss (random-init VGG19 weights)")
+    ap.add_argument("--with-vgg", action="store_true", help="train: (default) include the VGG19 perceptual loss, random-init VGG19 weights")
+    ap.add_argument("--no-vgg", action="store_true", help="train: the reference's --no_vgg recipe")
     ap.add_argument("--no-autotune", action="store_true", help="train: skip the per-shape tile search of the first chunks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
@@ -80,7 +81,7 @@ def run_train(args, dev, rank, world, local_rank):
     opt = make_opt(isTrain=True, label_nc=35, use_instance=True, fg=True, random_init_ok=True, loadSize=W,
                    precision=args.precision, gpu_ids=[local_rank], n_scales_spatial=S, num_D=args.num_D,
                    n_frames_total=args.frames_total, max_frames_per_gpu=args.frames_per_gpu,
-                   no_vgg=not args.with_vgg, niter_fix_global=0)
+                   no_vgg=args.no_vgg, niter_fix_global=0)
     _stdout = sys.stdout
     sys.stdout = sys.stderr
     models = create_model(opt)
@@ -199,7 +200,7 @@ def run_train(args, dev, rank, world, local_rank):
             "config": {"workload": "label2city %dx%d train, n_scales_spatial=%d num_D=%d n_scales_temporal=%d, --fg --use_instance%s, "
                                    "n_frames_total=%d, %d frames per chunk, niter_fix_global=0 (all scales train), G %.1fM + D %.1fM "
                                    "params random-init, FlowNet2 random-init, 1 sequence per GPU"
-                                   % (W, H, S, opt.num_D, t_scales, "" if args.with_vgg else " --no_vgg", n_frames_total,
+                                   % (W, H, S, opt.num_D, t_scales, " --no_vgg" if args.no_vgg else "", n_frames_total,
                                       n_frames_load, sum(q.numel() for q in modelG.module.parameters()) / 1e6,
                                       sum(q.numel() for q in modelD.module.parameters()) / 1e6),
                        "frames_per_step": n_frames_load, "active_temporal_scales_last_step": int(t_act),

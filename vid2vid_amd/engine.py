@@ -645,7 +645,9 @@ class Engine:
         self._last_alts = [c for i, c in enumerate(alts) if c != best and c not in alts[:i]][:7]
         # for the heaviest shapes of a frame the whole-frame search also walks every lightly split configuration that was
         # not hopeless in isolation
-        self._last_wide = [cfg for ms, cfg in timed if cfg[1] <= 2 and ms <= 1.7 * timed[0][0] and cfg != best][:16]
+        self._last_wide = ([cfg for ms, cfg in timed if 50 <= cfg[0] < 60 and cfg[1] <= 2 and cfg != best]      # every ping-pong tile
+                           + [cfg for ms, cfg in timed if not 50 <= cfg[0] < 60 and cfg[1] <= 2 and ms <= 1.7 * timed[0][0]
+                              and cfg != best][:10])
         return best
 
     def _norm_params(self, norm, N):
