@@ -11,7 +11,7 @@ if has wgrad; then
   V2V_WGRAD_BF16=legacy timeout 300 python scripts/wgrad_bench.py > gpurun_out/${TAG}_wgrad_legacy.txt 2>&1; echo "wgrad(legacy) rc=$?"; tail -10 gpurun_out/${TAG}_wgrad_legacy.txt | cut -c1-110
 fi
 if has wgradcfg; then
-  for c in ${WGCFGS:-0 6 7}; do
+  for c in ${WGCFGS:-0 8 9}; do
     echo "== V2V_WGRAD_CFG=$c"; V2V_WGRAD_CFG=$c timeout 200 python scripts/wgrad_bench.py 2>&1 | grep -E "^wgrad|worst|Error|error" | head -9 | cut -c1-150
   done > gpurun_out/${TAG}_wgrad_cfgs.txt 2>&1; cat gpurun_out/${TAG}_wgrad_cfgs.txt
 fi

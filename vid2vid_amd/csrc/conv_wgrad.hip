@@ -205,13 +205,20 @@ __device__ __forceinline__ wg_v4s wg_tr_read(const char* lds) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_v4s*)lds);
 }
 
+// the same read as inline asm (32-bit LDS byte address): see the ASMTR branch of conv_wgrad_bf16_kernel
+__device__ __forceinline__ wg_v4s wg_tr_read_asm(unsigned lds_addr) {
+    wg_v4s r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+    return r;
+}
+
 // chunk swizzle of a [*][ROWB bytes] image: XOR applied to the 16-byte chunk index of pixel row k
 template <int ROWB> __device__ __forceinline__ int wg_swz(int k) {
     if (ROWB >= 256) return (k & 3) << 2;          // 16+ chunks per row: 4 rows -> 4 different pairs of 32-byte windows
     return ((k >> 1) & 1) << 2;                    // 128-byte rows: rows k, k+2 share a bank window -> split them
 }
 
-template <int BM, int BN, int BK, int NS, int NW, bool SWZ, bool XCD>
+template <int BM, int BN, int BK, int NS, int NW, bool SWZ, bool XCD, bool ASMTR = false>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(const WgradKArgs p) {
     constexpr int ES = 2, VEC = 8;
     constexpr int WGM = NW / 2;                              // waves as WGM (rows) x 2 (columns)
@@ -331,6 +338,30 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(const WgradKAr
         for (int k16 = 0; k16 < BK / 16; ++k16) {
             union Frag { bf16x8 v; wg_v4s h[2]; };
             Frag a[TM], b[TN];
+            if constexpr (ASMTR) {
+                // UNVALIDATED variant (no GPU time was left in round 1; V2V_WGRAD_CFG=8/9).  With the builtin the compiler
+                // cannot prove that the transpose reads do not alias the LDS-DMA writes issued a few lines above (the
+                // intrinsic carries no memory operand) and puts `s_waitcnt vmcnt(0)` in front of the first read of every
+                // chunk -- each iteration then waits for the loads it has just issued and the NS-deep pipeline collapses
+                // (visible in the ISA of the shipped kernel; explains why tile / depth / swizzle / XCD variants all measured
+                // the same).  Reads as inline asm are invisible to that pass; the explicit lgkmcnt wait is tied to the
+                // fragment registers so that no MFMA can be scheduled above it.
+                const unsigned sb = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)st;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    a[i].h[0] = wg_tr_read_asm(sb + a_off[i] + (k16 * 16) * ROWB_P);
+                    a[i].h[1] = wg_tr_read_asm(sb + a_off[i] + (k16 * 16 + 4) * ROWB_P);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    b[j].h[0] = wg_tr_read_asm(sb + b_off[j] + (k16 * 16) * ROWB_Q);
+                    b[j].h[1] = wg_tr_read_asm(sb + b_off[j] + (k16 * 16 + 4) * ROWB_Q);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[i].h[0]), "+v"(a[i].h[1]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[j].h[0]), "+v"(b[j].h[1]));
+            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 a[i].h[0] = wg_tr_read(st + a_off[i] + (k16 * 16) * ROWB_P);          // rows +4 keep the same swizzle (k & 3)
@@ -340,6 +371,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(const WgradKAr
             for (int j = 0; j < TN; ++j) {
                 b[j].h[0] = wg_tr_read(st + b_off[j] + (k16 * 16) * ROWB_Q);
                 b[j].h[1] = wg_tr_read(st + b_off[j] + (k16 * 16 + 4) * ROWB_Q);
+            }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -415,9 +447,9 @@ static bool legacy_bf16() {
     return v != 0;
 }
 
-template <int BM, int BN, int BK, int NS, int NW, bool SWZ, bool XCD = false>
+template <int BM, int BN, int BK, int NS, int NW, bool SWZ, bool XCD = false, bool ASMTR = false>
 static void launch_wgrad_bf16(dim3 grid, hipStream_t s, const WgradKArgs& k) {
-    auto kern = conv_wgrad_bf16_kernel<BM, BN, BK, NS, NW, SWZ, XCD>;
+    auto kern = conv_wgrad_bf16_kernel<BM, BN, BK, NS, NW, SWZ, XCD, ASMTR>;
     const size_t lds = (size_t)NS * (BK * BM + BK * BN) * 2;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
@@ -447,6 +479,8 @@ struct WgradOp : Op {
             case 5:  launch_wgrad_bf16<256, 128, 32, 4, 8, true>(grid, s, k); break;
             case 6:  launch_wgrad_bf16<128, 128, 32, 3, 4, true, true>(grid, s, k); break;
             case 7:  launch_wgrad_bf16<256, 128, 32, 3, 8, true, true>(grid, s, k); break;
+            case 8:  launch_wgrad_bf16<128, 128, 32, 3, 4, true, false, true>(grid, s, k); break;    // asm transpose reads: UNVALIDATED
+            case 9:  launch_wgrad_bf16<256, 128, 32, 3, 8, true, false, true>(grid, s, k); break;
             default: launch_wgrad_bf16<128, 128, 32, 3, 4, true>(grid, s, k); break;
         }
     }
@@ -489,7 +523,7 @@ static const int WG_BN = 128, WG_BK = 32;
 // row-tile height: 128 on the bf16 matrix pipe when the layer has more than 64 gradient rows, else 64
 static int wgrad_bm(const v2v_wgrad_desc* d) {
     if (!(d->dtype == V2V_BF16 && d->rows > 64 && !legacy_bf16())) return 64;
-    return (wgrad_cfg() == 3 || wgrad_cfg() == 5 || wgrad_cfg() == 7) ? 256 : 128;
+    return (wgrad_cfg() == 3 || wgrad_cfg() == 5 || wgrad_cfg() == 7 || wgrad_cfg() == 9) ? 256 : 128;
 }
 
 static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* splits, int* kper) {
