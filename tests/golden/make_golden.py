@@ -158,14 +158,15 @@ def golden_global(networks):
     save("first_frame_nets_32x64", **arrays)
 
 
-def golden_inference():
+def golden_inference(cases=((1, "s1", 32, 64), (2, "s2", 32, 64))):
     """create_model(opt) -> Vid2VidModelG.inference over 3 generated frames, label2city flags
-    (test.py:25-41, models/vid2vid_model_G.py:198-229), n_scales_spatial = 1 and 2."""
+    (test.py:25-41, models/vid2vid_model_G.py:198-229), n_scales_spatial = 1 and 2 (and 3 at 64x128: the
+    BASELINE configs[4] scale count, `python make_golden.py inference_s3`)."""
     from options.test_options import TestOptions
     from models import networks
     from models.models import create_model
     import tempfile
-    for S, tag in ((1, "s1"), (2, "s2")):
+    for S, tag, H, W in cases:
         ck = tempfile.mkdtemp()
         argv = ["test.py", "--name", "g", "--label_nc", "35", "--loadSize", "64", "--use_instance", "--fg",
                 "--use_real_img", "--gpu_ids", "-1", "--checkpoints_dir", ck, "--ngf", "8", "--n_blocks", "2",
@@ -185,7 +186,7 @@ def golden_inference():
             torch.save(n.state_dict(), os.path.join(ck, "g", "latest_net_G%d.pth" % s))
         model = create_model(opt)
         gen = torch.Generator().manual_seed(60 + S)
-        H, W, T = 32, 64, 5
+        T = 5
         lab = synth_labels(gen, T, H, W, 35)
         inst = synth_labels(gen, T, H, W, 9)
         Bfirst = torch.tanh(torch.randn(1, 2, 3, H, W, generator=gen))
@@ -203,7 +204,7 @@ def golden_inference():
             arrays.update(sd_to_np(n.state_dict(), "sd%d." % s))
         arrays.update({"in.labels": lab.numpy(), "in.inst": inst.numpy(), "in.B": Bfirst.numpy(),
                        "out.fake": torch.cat(outs).numpy(), "out.real_A_last": last_label.numpy()})
-        save("inference_label2city_%s_32x64" % tag, **arrays)
+        save("inference_label2city_%s_%dx%d" % (tag, H, W), **arrays)
 
 
 def golden_edge2face():
@@ -399,12 +400,15 @@ def main():
         return golden_flownet2()
     if only == "edge2face":
         return golden_edge2face()
+    if only == "inference_s3":
+        return golden_inference(((3, "s3", 64, 128),))
     from models import networks
     golden_composite(networks)
     golden_composite_local(networks)
     golden_discriminator(networks)
     golden_global(networks)
     golden_inference()
+    golden_inference(((3, "s3", 64, 128),))
     golden_edge2face()
     golden_training()
     golden_flownet2()

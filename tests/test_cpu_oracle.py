@@ -214,3 +214,12 @@ def test_vgg_loss_oracle_vs_reference(golden):
     gw = golden("vgg_loss_wide_64x1280")                    # > 1024 px wide: the AvgPool2d(2,2) branch
     lw = O.vgg_loss(sd, T(gw["in.x"].astype(np.float32)), T(gw["in.y"].astype(np.float32)))
     assert abs(float(lw) - float(gw["out.loss"])) <= 1e-5 * float(gw["out.loss"])
+
+
+def test_inference_three_scales_matches_reference(golden):
+    """n_scales_spatial = 3 (the scale count of BASELINE configs[4]) at 64x128: reference -> oracle pin.  The HIP-path
+    check against this fixture is the first GPU test to add next round (no GPU time was left to validate it in round 1)."""
+    g = golden("inference_label2city_s3_64x128")
+    fake, lab = _run_inference(g, 3)
+    assert_close(fake, g["out.fake"], 1e-4, "inference S=3")
+    assert torch.equal(lab, T(g["out.real_A_last"]))
