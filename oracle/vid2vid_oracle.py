@@ -95,6 +95,94 @@ class _Walker:
 
 
 # --------------------------------------------------------------------------------------
+# first-frame generators with instance-wise feature encoding (models/networks.py:421-632)
+# Oracle only so far: the HIP lowering of these three is the next row to build.
+# --------------------------------------------------------------------------------------
+def global_with_z(sd, x, z, n_downsample_G, n_blocks, norm="instance"):
+    """Global_with_z.forward (models/networks.py:460-467); layers :430-458."""
+    zd = z
+    for _ in range(n_downsample_G):
+        zd = avgpool3s2(zd)
+    w = _Walker(sd, "model_downsample", norm)
+    h = w.stem7(torch.cat([x, z], 1))
+    for _ in range(n_downsample_G):
+        h = w.down3(h)
+    w = _Walker(sd, "model_resnet", norm)
+    h = torch.cat([h, zd], 1)
+    for _ in range(n_blocks):
+        h = w.resblock(h)
+    w = _Walker(sd, "model_upsample", norm)
+    h = torch.cat([h, zd], 1)
+    for _ in range(n_downsample_G):
+        h = w.up3(h)
+    return _Walker(sd, "model_upsample_conv", norm).head7(torch.cat([h, z], 1), "tanh")
+
+
+def local_with_z(sd, x, z, n_downsample_global, n_blocks_global, n_local_enhancers, n_blocks_local, norm="instance"):
+    """Local_with_z.forward (models/networks.py:512-552); layers :476-510."""
+    pyr = [x]
+    for _ in range(n_local_enhancers):
+        pyr.append(avgpool3s2(pyr[-1]))
+    z_local = z
+    for _ in range(n_local_enhancers):
+        z_local = avgpool3s2(z_local)
+    z_global = z_local
+    for _ in range(n_downsample_global):
+        z_global = avgpool3s2(z_global)
+    w = _Walker(sd, "model_downsample", norm)
+    h = w.stem7(torch.cat([pyr[-1], z_local], 1))
+    for _ in range(n_downsample_global):
+        h = w.down3(h)
+    w = _Walker(sd, "model_resnet", norm)
+    h = torch.cat([h, z_global], 1)
+    for _ in range(n_blocks_global):
+        h = w.resblock(h)
+    w = _Walker(sd, "model_upsample", norm)
+    h = torch.cat([h, z_global], 1)
+    for _ in range(n_downsample_global):
+        h = w.up3(h)
+    out_prev = h
+    for n in range(1, n_local_enhancers + 1):
+        inp = pyr[n_local_enhancers - n]
+        if n == n_local_enhancers:
+            inp = torch.cat([inp, z], 1)
+        w = _Walker(sd, "model%d_1" % n, norm)
+        comb = w.down3(w.stem7(inp)) + out_prev
+        if n == 1:
+            comb = torch.cat([comb, z_local], 1)
+        w = _Walker(sd, "model%d_2" % n, norm)
+        for _ in range(n_blocks_local):
+            comb = w.resblock(comb)
+        out_prev = w.up3(comb)
+    return _Walker(sd, "model_final", norm).head7(torch.cat([out_prev, z], 1), "tanh")
+
+
+def instance_mean(feat, inst):
+    """Instance-wise average pooling of Encoder.forward (models/networks.py:621-632): every pixel of an instance gets the
+    mean of its instance, per sample and channel.  inst: (B, 1, H, W) holding integer ids."""
+    out = feat.clone()
+    B, C = feat.shape[:2]
+    for b in range(B):
+        ids = inst[b, 0].long()
+        for i in torch.unique(ids):
+            m = ids == i
+            for j in range(C):
+                out[b, j][m] = feat[b, j][m].mean()
+    return out
+
+
+def encoder(sd, x, inst, n_downsampling=4, norm="instance"):
+    """Encoder.forward (models/networks.py:617-632); layers :600-615."""
+    w = _Walker(sd, "model", norm)
+    h = w.stem7(x)
+    for _ in range(n_downsampling):
+        h = w.down3(h)
+    for _ in range(n_downsampling):
+        h = w.up3(h)
+    return instance_mean(w.head7(h, "tanh"), inst)
+
+
+# --------------------------------------------------------------------------------------
 # warping (models/networks.py:79-115)
 # --------------------------------------------------------------------------------------
 def get_grid(b, rows, cols):

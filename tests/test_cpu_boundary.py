@@ -178,3 +178,61 @@ def test_inference_lowering_census_edge2face_512():
     finally:
         N.set_record_only(False)
         N._ENGINES.clear()
+
+
+def _face_opt(**kw):
+    import types
+    d = dict(fp16=False, n_blocks=2, n_blocks_local=1, n_local_enhancers=1, fg=True, no_flow=False, feat_num=4)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+FACE_NETS = (("sdG.", 501, (5, 3, 0, 8, "global_with_features", 2, "instance", 0, [])),
+             ("sdL.", 502, (5, 3, 0, 4, "local_with_features", 2, "instance", 0, [])),
+             ("sdE.", 503, (3, 4, 0, 4, "encoder", 2, "instance", 0, [])))
+
+
+def test_feature_encoding_nets_checkpoint_keys_and_seeded_init(golden):
+    """Global_with_z / Local_with_z / Encoder: state_dict keys == the reference's (checkpoint format)
+    and a seeded construction draws the reference's initial weights (same module creation order)."""
+    from vid2vid_amd import networks as N
+    g = golden("face_first_frame_nets_32x32")
+    for tag, seed, args in FACE_NETS:
+        torch.manual_seed(seed)
+        net = N.define_G(*args, _face_opt())
+        ref = sd_from_npz(g, tag)
+        sd = net.state_dict()
+        assert set(sd.keys()) == set(ref.keys()), tag
+        for k, v in sd.items():
+            if "running_" in k or "num_batches" in k:
+                continue                     # buffers were updated by the reference's forward pass
+            assert torch.allclose(v.float(), ref[k].float(), rtol=0, atol=1e-7), tag + k
+
+
+def test_feature_encoding_nets_lowering_records(golden):
+    """Record (not run) the lowering of Global_with_z / Local_with_z: every launch passes the library's argument checks
+    and the head produces the planar (1, 3, H, W) image.  (Numerical parity of this lowering: GPU test, next round.)"""
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.engine import Plan
+    if torch.cuda.is_available():
+        pytest.skip("dry-run lowering is a CPU-host check")
+    g = golden("face_first_frame_nets_32x32")
+    N.set_record_only(True)
+    try:
+        eng = N.get_engine("cpu")
+        x, z = torch.from_numpy(g["in.x"]), torch.from_numpy(g["in.z"])
+        for tag, seed, args in FACE_NETS[:2]:
+            net = N.define_G(*args, _face_opt())
+            net.load_state_dict(sd_from_npz(g, tag))
+            plan = Plan()
+            eng.plan = plan
+            try:
+                with plan:
+                    out = net.emit(eng, eng.pack(x), eng.pack(z))
+            finally:
+                eng.plan = None
+            assert tuple(out.shape) == (1, 3, 32, 32)
+            assert plan.num_ops > 20
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()

@@ -223,3 +223,17 @@ def test_inference_three_scales_matches_reference(golden):
     fake, lab = _run_inference(g, 3)
     assert_close(fake, g["out.fake"], 1e-4, "inference S=3")
     assert torch.equal(lab, T(g["out.real_A_last"]))
+
+
+def test_feature_encoding_first_frame_nets_match_reference(golden):
+    """Global_with_z / Local_with_z / Encoder: oracle restatements against the reference's own classes
+    (tests/golden/make_golden_face.py), incl. the instance-wise average pooling with a large id and a 1-pixel instance."""
+    g = golden("face_first_frame_nets_32x32")
+    x, z, inst, img = (T(g["in." + k]) for k in ("x", "z", "inst", "img"))
+    assert_close(O.global_with_z(sd_from_npz(g, "sdG."), x, z, 2, 2), g["out.global_with_z"], PIN, "Global_with_z")
+    assert_close(O.local_with_z(sd_from_npz(g, "sdL."), x, z, 2, 2, 1, 1), g["out.local_with_z"], PIN, "Local_with_z")
+    out = O.encoder(sd_from_npz(g, "sdE."), img, inst, 2)
+    assert_close(out, g["out.encoder"], PIN, "Encoder")
+    ids = inst[0, 0].long()
+    for i in torch.unique(ids):                                  # every instance is constant per channel
+        assert out[0, :, ids == i].std(dim=1, unbiased=False).max().item() < 1e-6

@@ -866,6 +866,22 @@ class Engine:
         self.label("widen_nhwc")
         return Act(wide, x.C)
 
+    def concat(self, a, b):
+        """torch.cat([a, b], dim=1) on NHWC activations (inference / plan path; the pad channels of the result are zero)."""
+        if (a.N, a.H, a.W) != (b.N, b.H, b.W):
+            raise RuntimeError("concat: spatial shapes differ")
+        if self._training() and (a.t.requires_grad or b.t.requires_grad):
+            raise NotImplementedError("concat has no backward: the feature-encoding first-frame generators are inference-only")
+        out = self.empty_act(a.N, a.H, a.W, a.C + b.C)
+        if out.Cs != a.C + b.C:
+            out.t.zero_()
+        P = a.N * a.H * a.W
+        check(lib.v2v_concat_channels_nhwc(_ptr(a.t), a.Cs, 0, _ptr(out.t), out.Cs, 0, a.C, P, self.dtype, _stream()), "concat")
+        self.label("concat_nhwc")
+        check(lib.v2v_concat_channels_nhwc(_ptr(b.t), b.Cs, 0, _ptr(out.t), out.Cs, a.C, b.C, P, self.dtype, _stream()), "concat")
+        self.label("concat_nhwc")
+        return out
+
     def pack(self, x_nchw):
         N, Cc, H, W = x_nchw.shape
         if self._training() and x_nchw.requires_grad:

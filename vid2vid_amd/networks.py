@@ -103,9 +103,13 @@ def define_G(input_nc, output_nc, prev_output_nc, ngf, which_model_netG, n_downs
     elif which_model_netG == "compositeLocal":
         netG = CompositeLocalGenerator(opt, input_nc, output_nc, prev_output_nc, ngf, n_downsampling,
                                        opt.n_blocks_local, opt.fg, opt.no_flow, norm_layer, scale=scale)
-    elif which_model_netG in ("global_with_features", "local_with_features", "encoder"):
-        # face first-frame generators: SURVEY.md section 8(f) rank 3 -- out of the hot path
-        raise NotImplementedError("generator [%s] is outside the MI355X hot path (SURVEY 8f)" % which_model_netG)
+    elif which_model_netG == "global_with_features":
+        netG = Global_with_z(input_nc, output_nc, opt.feat_num, ngf, n_downsampling, opt.n_blocks, norm_layer)
+    elif which_model_netG == "local_with_features":
+        netG = Local_with_z(input_nc, output_nc, opt.feat_num, ngf, n_downsampling, opt.n_blocks, opt.n_local_enhancers,
+                            opt.n_blocks_local, norm_layer)
+    elif which_model_netG == "encoder":
+        netG = Encoder(input_nc, output_nc, ngf, n_downsampling, norm_layer)
     else:
         raise NotImplementedError("Generator model name [%s] is not recognized" % which_model_netG)
     if len(gpu_ids) > 0 and gpu_ids[0] >= 0:
@@ -518,6 +522,129 @@ class LocalEnhancer(nn.Module):
                                    name="Gi.local%d_1" % n)
             out = eng.run_sequential(getattr(self, "model%d_2" % n), d, head_nchw=last, name="Gi.local%d_2" % n)
         return out
+
+
+# --------------------------------------------------------------------------------------
+# first-frame generators with instance-wise feature encoding (models/networks.py:421-632)
+# Parameter containers + lowering are composed from the validated primitives (concat, avgpool, conv groups); the lowering
+# has NOT been run on a GPU yet (round 1 ran out of GPU time): tests/test_gpu_golden.py gates its parity test behind
+# V2V_RUN_UNVALIDATED=1.  The oracle side is pinned (tests/golden/face_first_frame_nets_32x32.npz).
+# --------------------------------------------------------------------------------------
+class Global_with_z(nn.Module):
+    """models/networks.py:421-467: GlobalGenerator whose stem, residual trunk, up-sampling trunk and head each see the
+    feature map z (nz channels, average-pooled to the trunk's resolution) concatenated to their input."""
+
+    def __init__(self, input_nc, output_nc, nz, ngf=64, n_downsample_G=3, n_blocks=9, norm_layer=nn.BatchNorm2d,
+                 padding_type="reflect"):
+        super().__init__()
+        self.n_downsample_G = n_downsample_G
+        act = nn.ReLU(True)
+        cap = lambda c: min(1024, c)
+        down = _stem7(input_nc + nz, ngf, norm_layer)
+        down[-1] = act
+        for i in range(n_downsample_G):
+            down += _down3(cap(ngf * 2 ** i), cap(ngf * 2 ** (i + 1)), norm_layer)[:2] + [act]
+        top = cap(ngf * 2 ** n_downsample_G)
+        res = [ResnetBlock(top + nz, padding_type=padding_type, norm_layer=norm_layer) for _ in range(n_blocks)]
+        up = []
+        for i in range(n_downsample_G):
+            m = 2 ** (n_downsample_G - i)
+            cin = cap(ngf * m) + (nz * 2 if i == 0 else 0)
+            up += _up3(cin, cap(ngf * m // 2), norm_layer)[:2] + [act]
+        head = _head7(ngf + nz, output_nc, nn.Tanh())
+        self.model_downsample = nn.Sequential(*down)
+        self.model_resnet = nn.Sequential(*res)
+        self.model_upsample = nn.Sequential(*up)
+        self.model_upsample_conv = nn.Sequential(*head)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def emit(self, eng, x, z, tag="Gz"):
+        zd = z
+        for _ in range(self.n_downsample_G):
+            zd = eng.avgpool_nhwc(zd)
+        h = eng.run_sequential(self.model_downsample, eng.concat(x, z), name=tag + ".down")
+        h = eng.run_sequential(self.model_resnet, eng.concat(h, zd), name=tag + ".res")
+        h = eng.run_sequential(self.model_upsample, eng.concat(h, zd), name=tag + ".up")
+        return eng.run_sequential(self.model_upsample_conv, eng.concat(h, z), head_nchw=True, name=tag + ".head")
+
+    def forward(self, x, z):
+        eng = get_engine(x.device)
+        with torch.no_grad():
+            return self.emit(eng, eng.pack(x.contiguous().float()), eng.pack(z.contiguous().float()))
+
+
+class Local_with_z(nn.Module):
+    """models/networks.py:469-552."""
+
+    def __init__(self, input_nc, output_nc, nz, ngf=32, n_downsample_global=3, n_blocks_global=9, n_local_enhancers=1,
+                 n_blocks_local=3, norm_layer=nn.BatchNorm2d, padding_type="reflect"):
+        super().__init__()
+        self.n_local_enhancers = n_local_enhancers
+        self.n_downsample_global = n_downsample_global
+        g = Global_with_z(input_nc, output_nc, nz, ngf * (2 ** n_local_enhancers), n_downsample_global, n_blocks_global,
+                          norm_layer)                      # incl. its head, as the reference builds (and discards) it
+        self.model_downsample, self.model_resnet, self.model_upsample = g.model_downsample, g.model_resnet, g.model_upsample
+        for n in range(1, n_local_enhancers + 1):
+            nf = ngf * (2 ** (n_local_enhancers - n))
+            if n == n_local_enhancers:
+                input_nc += nz
+            down = _stem7(input_nc, nf, norm_layer) + _down3(nf, nf * 2, norm_layer)
+            cin = nf * 2 + (nz if n == 1 else 0)
+            up = [ResnetBlock(cin, padding_type=padding_type, norm_layer=norm_layer) for _ in range(n_blocks_local)]
+            up += _up3(cin, nf, norm_layer)
+            setattr(self, "model%d_1" % n, nn.Sequential(*down))
+            setattr(self, "model%d_2" % n, nn.Sequential(*up))
+        self.model_final = nn.Sequential(*_head7(ngf + nz, output_nc, nn.Tanh()))
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def emit(self, eng, x, z, tag="Lz"):
+        L = self.n_local_enhancers
+        pyr = [x]
+        for _ in range(L):
+            pyr.append(eng.avgpool_nhwc(pyr[-1]))
+        z_local = z
+        for _ in range(L):
+            z_local = eng.avgpool_nhwc(z_local)
+        z_global = z_local
+        for _ in range(self.n_downsample_global):
+            z_global = eng.avgpool_nhwc(z_global)
+        h = eng.run_sequential(self.model_downsample, eng.concat(pyr[-1], z_local), name=tag + ".gdown")
+        h = eng.run_sequential(self.model_resnet, eng.concat(h, z_global), name=tag + ".gres")
+        out = eng.run_sequential(self.model_upsample, eng.concat(h, z_global), name=tag + ".gup")
+        for n in range(1, L + 1):
+            inp = pyr[L - n]
+            if n == L:
+                inp = eng.concat(inp, z)
+            comb = eng.run_sequential(getattr(self, "model%d_1" % n), inp, extra_add=out, name="%s.l%d_1" % (tag, n))
+            if n == 1:
+                comb = eng.concat(comb, z_local)
+            out = eng.run_sequential(getattr(self, "model%d_2" % n), comb, name="%s.l%d_2" % (tag, n))
+        return eng.run_sequential(self.model_final, eng.concat(out, z), head_nchw=True, name=tag + ".final")
+
+    def forward(self, x, z):
+        eng = get_engine(x.device)
+        with torch.no_grad():
+            return self.emit(eng, eng.pack(x.contiguous().float()), eng.pack(z.contiguous().float()))
+
+
+class Encoder(nn.Module):
+    """models/networks.py:595-632: conv encoder-decoder followed by instance-wise average pooling of its output."""
+
+    def __init__(self, input_nc, output_nc, ngf=32, n_downsampling=4, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.output_nc = output_nc
+        model = _stem7(input_nc, ngf, norm_layer)
+        for i in range(n_downsampling):
+            model += _down3(ngf * 2 ** i, ngf * 2 ** (i + 1), norm_layer)
+        for i in range(n_downsampling):
+            m = 2 ** (n_downsampling - i)
+            model += _up3(ngf * m, int(ngf * m / 2), norm_layer)
+        model += _head7(ngf, output_nc, nn.Tanh())
+        self.model = nn.Sequential(*model)
+
+    def forward(self, input, inst):
+        raise NotImplementedError("Encoder: the instance-wise average pooling (models/networks.py:621-632, a segmented "
+                                  "mean over the instance map) has no HIP kernel yet -- SURVEY 8f rank 3, next round")
 
 
 # --------------------------------------------------------------------------------------
