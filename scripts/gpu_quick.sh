@@ -42,6 +42,17 @@ if has ftune; then
   V2V_TUNE_CACHE=$FT timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_ft2.json 2> gpurun_out/${TAG}_bench_ft2.err; echo "bench replay rc=$?"; cut -c60-130 gpurun_out/${TAG}_bench_ft2.json
   V2V_FRAME_TUNE=0 timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_noft.json 2> gpurun_out/${TAG}_bench_noft.err; echo "bench no frame-tune rc=$?"; cut -c60-130 gpurun_out/${TAG}_bench_noft.json
 fi
+if has pmcwgrad; then
+  # where do the wgrad kernel's cycles go (one counter group per pass; rocprofv3 refuses mixed trace domains)
+  cd /tmp; export TMPDIR=/tmp
+  for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU"; do
+    tag=$(echo $pass | cut -d' ' -f1)
+    V2V_WGRAD_CFG=${WGCFG:-0} timeout 300 rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmcw_$tag -o pmc -- python $R/scripts/wgrad_bench.py > $R/gpurun_out/${TAG}_pmcw_$tag.log 2>&1; echo "pmc $tag rc=$?"
+    python $R/scripts/pmc_summary.py $(find /tmp/pmcw_$tag -name "*.db" | head -1) "# V2V_WGRAD_CFG=${WGCFG:-0} rocprofv3 --kernel-trace --pmc $pass -- python scripts/wgrad_bench.py" > $R/gpurun_out/${TAG}_pmcw_$tag.txt 2>> $R/gpurun_out/${TAG}_pmcw_$tag.log
+    grep -h "wgrad" $R/gpurun_out/${TAG}_pmcw_$tag.txt | cut -c1-60,97- | head -6
+  done
+  cd $R
+fi
 if has tests; then
   timeout 600 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 180 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest.log | tail -20
