@@ -1,0 +1,142 @@
+"""Host-side logic of the training path against vectors produced by the REFERENCE's own functions
+(tests/golden/make_golden_skipped.py): the rolling frame history and the per-temporal-scale frame groups of
+models/vid2vid_model_D.py:274-328.  CPU only; no kernels involved (pure indexing)."""
+import json
+import os
+
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skipped_frames.json")
+
+
+def _flownet_stub(a, b):
+    return a - b / 2, a + b / 4
+
+
+def _rows(t):
+    return None if t is None else [list(map(float, row)) for row in t.reshape(t.shape[0], -1).tolist()]
+
+
+def test_skipped_frames_dense_and_sparse_match_reference():
+    from vid2vid_amd.models import vid2vid_model_D as M
+    cases = json.load(open(GOLDEN))["cases"]
+    assert len(cases) >= 6
+    for rec in cases:
+        t_scales, tD, nfl = rec["t_scales"], rec["tD"], rec["n_frames_load"]
+        real_all = flow_all = conf_all = None
+        for c, want in enumerate(rec["dense"]):
+            fr = torch.arange(c * nfl, (c + 1) * nfl, dtype=torch.float32).view(1, nfl, 1, 1, 1)
+            real_all, real_sk = M.get_skipped_frames(real_all, fr, t_scales, tD)
+            flow_all, conf_all, flow_sk, conf_sk = M.get_skipped_flows(_flownet_stub, flow_all, conf_all, real_sk, fr * 10,
+                                                                      fr * 100, t_scales, tD)
+            ctx = "dense t_scales=%d tD=%d nfl=%d chunk %d" % (t_scales, tD, nfl, c)
+            assert _rows(real_all) == want["all"], ctx
+            assert [_rows(t) for t in real_sk] == want["sk"], ctx
+            assert _rows(flow_all) == want["flow_all"], ctx
+            assert [_rows(t) for t in flow_sk] == want["flow_sk"], ctx
+            assert [_rows(t) for t in conf_sk] == want["conf_sk"], ctx
+        b_all, f_all = [None] * t_scales, [None] * t_scales
+        for c, want in enumerate(rec["sparse"]):
+            i = c * nfl
+            fr = torch.arange(i, i + nfl, dtype=torch.float32).view(1, nfl, 1, 1, 1)
+            b_all, b_sk = M.get_skipped_frames_sparse(b_all, fr, t_scales, tD, nfl, i)
+            f_all, f_sk = M.get_skipped_frames_sparse(f_all, fr * 10, t_scales, tD, nfl, i, is_flow=True)
+            ctx = "sparse t_scales=%d tD=%d nfl=%d chunk %d" % (t_scales, tD, nfl, c)
+            assert [_rows(t) for t in b_all] == want["all"], ctx
+            assert [_rows(t) for t in b_sk] == want["sk"], ctx
+            assert [_rows(t) for t in f_sk] == want["flow_sk"], ctx
+
+
+class _Rec:
+    """Recording stand-in for modelG / modelD / data_loader / visualizer (same as tests/golden/make_golden_schedule.py)."""
+
+    def __init__(self, log, name):
+        self.log, self.name = log, name
+        self.module = self
+        self.dataset = self
+
+    def __getattr__(self, attr):
+        def call(*a, **k):
+            self.log.append([self.name, attr] + [x if isinstance(x, (int, str, float)) else str(x) for x in a])
+        return call
+
+    def __len__(self):
+        return 37
+
+
+def _norm(log):
+    """numpy integers of the reference's np.loadtxt were recorded as strings: compare by value"""
+    return [[int(x) if isinstance(x, str) and x.lstrip("-").isdigit() else x for x in row] for row in log]
+
+
+def test_resume_and_schedule_helpers_match_reference_traces(tmp_path):
+    """init_params / update_models / save_models (models/models.py:104-163) over 24 option sets: same return tuple, same
+    calls on the models / data loader in the same order, same iter.txt contents as the reference's own functions."""
+    import types
+    import numpy as np
+    from vid2vid_amd.models import schedule as S
+    traces = json.load(open(os.path.join(os.path.dirname(GOLDEN), "schedule_traces.json")))
+    assert len(traces) == 24
+    for n, rec in enumerate(traces):
+        sc = rec["scenario"]
+        ck = str(tmp_path / ("c%d" % n))
+        os.makedirs(os.path.join(ck, "x"))
+        opt = types.SimpleNamespace(checkpoints_dir=ck, name="x", **{k: v for k, v in sc.items() if k != "iter"})
+        if sc["continue_train"]:
+            np.savetxt(os.path.join(ck, "x", "iter.txt"), sc["iter"], delimiter=",", fmt="%d")
+        log = []
+        G, D, loader, vis = _Rec(log, "G"), _Rec(log, "D"), _Rec(log, "loader"), _Rec(log, "vis")
+        ret = S.init_params(opt, G, D, loader)
+        assert [int(v) for v in ret[:-1]] == rec["init_ret"], sc
+        assert _norm(log) == _norm(rec["init_log"]), sc
+        for ep in rec["epochs"]:
+            del log[:]
+            S.update_models(opt, ep["epoch"], G, D, loader)
+            assert _norm(log) == _norm(ep["update_log"]), (sc, ep["epoch"])
+            del log[:]
+            S.save_models(opt, ep["epoch"], 3, 2000, vis, ret[-1], G, D, end_of_epoch=False)
+            S.save_models(opt, ep["epoch"], 3, 2001, vis, ret[-1], G, D, end_of_epoch=True)
+            assert _norm([l for l in log if l[0] != "vis"]) == _norm(ep["save_log"]), (sc, ep["epoch"])
+            itxt = open(ret[-1]).read().split() if os.path.exists(ret[-1]) else None
+            assert itxt == ep["iter_txt"], (sc, ep["epoch"])
+
+
+def test_basemodel_schedule_arithmetic_matches_reference():
+    """update_training_batch / update_learning_rate (models/base_model.py:154-181) against the reference's own methods
+    run on plain namespaces (tests/golden/make_golden_basemodel.py)."""
+    import types
+    from vid2vid_amd.models.base_model import BaseModel as B
+    ref = json.load(open(os.path.join(os.path.dirname(GOLDEN), "basemodel_schedule.json")))
+    for rec in ref["batch"]:
+        s = types.SimpleNamespace(n_gpus=rec["n_gpus"], n_frames_per_gpu=1, n_frames_load=rec["n_gpus"], n_frames_bp=1,
+                                  opt=types.SimpleNamespace(max_frames_per_gpu=rec["max_frames_per_gpu"],
+                                                            max_frames_backpropagate=rec["max_frames_backpropagate"]))
+        trace = []
+        for ratio in range(0, 5):
+            B.update_training_batch(s, ratio)
+            trace.append([s.n_frames_bp, s.n_frames_per_gpu, s.n_frames_load])
+        assert trace == rec["trace"], rec
+    for rec in ref["lr"]:
+        group = {"lr": rec["lr"]}
+        s = types.SimpleNamespace(opt=types.SimpleNamespace(lr=rec["lr"], niter=rec["niter"], niter_decay=rec["niter_decay"]),
+                                  old_lr=rec["lr"], optimizer_G=types.SimpleNamespace(param_groups=[group]))
+        for epoch, lr, old in rec["vals"]:
+            B.update_learning_rate(s, epoch, "G")
+            assert abs(group["lr"] - lr) <= 1e-15 and abs(s.old_lr - old) <= 1e-15
+
+
+def test_basemodel_tensor_helpers_match_reference():
+    """get_edges (models/base_model.py:146-152), compute_mask / compute_fake_B_prev (models/vid2vid_model_G.py:322-336)."""
+    import types
+    import numpy as np
+    from vid2vid_amd.models.base_model import BaseModel as B
+    from vid2vid_amd.models.vid2vid_model_G import Vid2VidModelG as G
+    g = dict(np.load(os.path.join(os.path.dirname(GOLDEN), "basemodel_helpers.npz")))
+    t = lambda k: torch.from_numpy(g[k])
+    assert torch.equal(B.get_edges(types.SimpleNamespace(), t("inst")), t("edges"))
+    ns = lambda labels: types.SimpleNamespace(opt=types.SimpleNamespace(fg_labels=labels))
+    assert torch.equal(G.compute_mask(ns([2]), t("real_As"), 1), t("m1"))
+    assert torch.equal(G.compute_mask(ns([0, 3, 5]), t("real_As"), 1, 3), t("m2"))
+    assert torch.equal(G.compute_fake_B_prev(None, t("rb_prev"), None, t("fake")), t("p1"))
+    assert torch.equal(G.compute_fake_B_prev(None, t("rb_prev"), [t("last")], t("fake")), t("p2"))
+    assert torch.equal(G.compute_fake_B_prev(None, t("rb_prev"), [t("last")], t("fake")[:, :1]), t("p3"))
