@@ -76,3 +76,30 @@ def test_single_process_is_a_noop():
     gs = GradSync()
     t = torch.arange(10.0)
     assert gs.all_reduce(t) == 1.0 and torch.equal(t, torch.arange(10.0))
+
+
+def test_fused_adam_state_dict_roundtrip():
+    """Optimizer-state checkpoint (extension over the reference, which saves none): moments, step count and
+    hyper-parameters survive a save / load into a freshly built optimizer; a different network definition is refused."""
+    import io
+    import pytest
+    import torch
+    from vid2vid_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Conv2d(5, 2, 1))
+    opt = FusedAdam(list(net.parameters()), lr=1e-3, betas=(0.5, 0.999))
+    opt.exp_avg.normal_()
+    opt.exp_avg_sq.uniform_()
+    opt.step_count = 17
+    opt.param_groups[0]["lr"] = 2.5e-4
+    buf = io.BytesIO()
+    torch.save(opt.state_dict(), buf)
+    buf.seek(0)
+    net2 = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Conv2d(5, 2, 1))
+    opt2 = FusedAdam(list(net2.parameters()), lr=1e-3, betas=(0.9, 0.999))
+    opt2.load_state_dict(torch.load(buf))
+    assert opt2.step_count == 17 and opt2.param_groups[0]["lr"] == 2.5e-4 and opt2.param_groups[0]["betas"] == (0.5, 0.999)
+    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    other = FusedAdam(list(torch.nn.Conv2d(3, 4, 3).parameters()))
+    with pytest.raises(ValueError):
+        other.load_state_dict(opt.state_dict())

@@ -67,6 +67,26 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_sync = grad_sync          # parallel.GradSync or None (single process)
 
+    # ---- checkpointing (an extension: the reference never saves optimizer state) ----
+    def state_dict(self):
+        """Flat moments + step count + hyper-parameters.  The layout is the parameter order of this optimizer
+        (FlatBuffers.offsets), so a checkpoint is valid for the same network definition."""
+        grp = self.param_groups[0]
+        return {"step": self.step_count, "exp_avg": self.exp_avg.detach().cpu().clone(),
+                "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(), "numel": self.flat.numel,
+                "hyper": {k: grp[k] for k in ("lr", "betas", "eps", "weight_decay")}}
+
+    def load_state_dict(self, state):
+        if int(state["numel"]) != self.flat.numel:
+            raise ValueError("FusedAdam checkpoint holds %d values, this optimizer %d (different network definition)"
+                             % (int(state["numel"]), self.flat.numel))
+        self.step_count = int(state["step"])
+        with torch.no_grad():
+            self.exp_avg.copy_(state["exp_avg"])
+            self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        for k, v in state.get("hyper", {}).items():
+            self.param_groups[0][k] = tuple(v) if k == "betas" else v
+
     def zero_grad(self, set_to_none=False):
         from .lib import lib, check
         self.flat.rebind_grads()
