@@ -339,13 +339,11 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(const WgradKAr
             union Frag { bf16x8 v; wg_v4s h[2]; };
             Frag a[TM], b[TN];
             if constexpr (ASMTR) {
-                // UNVALIDATED variant (no GPU time was left in round 1; V2V_WGRAD_CFG=8/9).  With the builtin the compiler
-                // cannot prove that the transpose reads do not alias the LDS-DMA writes issued a few lines above (the
-                // intrinsic carries no memory operand) and puts `s_waitcnt vmcnt(0)` in front of the first read of every
-                // chunk -- each iteration then waits for the loads it has just issued and the NS-deep pipeline collapses
-                // (visible in the ISA of the shipped kernel; explains why tile / depth / swizzle / XCD variants all measured
-                // the same).  Reads as inline asm are invisible to that pass; the explicit lgkmcnt wait is tied to the
-                // fragment registers so that no MFMA can be scheduled above it.
+                // V2V_WGRAD_CFG=8/9.  With the builtin the compiler cannot prove that the transpose reads do not alias the
+                // LDS-DMA writes issued a few lines above (the intrinsic carries no memory operand) and puts `s_waitcnt vmcnt(0)`
+                // in front of the first read of every chunk.  Reads as inline asm are invisible to that pass; the explicit
+                // lgkmcnt wait is tied to the fragment registers so that no MFMA can be scheduled above it.  Measured: same
+                // results, same time (profiles/r01_q14_wgrad_asm_tr_variant.txt) -- other resident workgroups hide that wait.
                 const unsigned sb = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)st;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -479,7 +477,7 @@ struct WgradOp : Op {
             case 5:  launch_wgrad_bf16<256, 128, 32, 4, 8, true>(grid, s, k); break;
             case 6:  launch_wgrad_bf16<128, 128, 32, 3, 4, true, true>(grid, s, k); break;
             case 7:  launch_wgrad_bf16<256, 128, 32, 3, 8, true, true>(grid, s, k); break;
-            case 8:  launch_wgrad_bf16<128, 128, 32, 3, 4, true, false, true>(grid, s, k); break;    // asm transpose reads: UNVALIDATED
+            case 8:  launch_wgrad_bf16<128, 128, 32, 3, 4, true, false, true>(grid, s, k); break;    // asm transpose reads (same speed)
             case 9:  launch_wgrad_bf16<256, 128, 32, 3, 8, true, false, true>(grid, s, k); break;
             default: launch_wgrad_bf16<128, 128, 32, 3, 4, true>(grid, s, k); break;
         }
