@@ -236,3 +236,36 @@ def test_feature_encoding_nets_lowering_records(golden):
     finally:
         N.set_record_only(False)
         N._ENGINES.clear()
+
+
+def test_plan_lanes_record_fork_and_join_edges():
+    """Frame plans record the generator's independent towers / branches on lanes (parallel hipGraph paths): the recorded
+    op list of the 512x256 label2city frame carries the fork / join edges (lane_wait) and the same 79 convolutions, and a
+    linear plan (opt.lanes = 0) carries none."""
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models import create_model
+    if torch.cuda.is_available():
+        pytest.skip("dry-run census is a CPU-host check")
+    counts = {}
+    for lanes in (1, 0):
+        N.set_record_only(True)
+        try:
+            opt = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True,
+                           precision="bf16", gpu_ids=[], ngf=16, n_blocks=2)
+            opt.lanes = lanes
+            m = create_model(opt)
+            H, W = 64, 128
+            A = torch.randint(0, 35, (1, 3, 1, H, W)).float()
+            m.inference(A, torch.zeros(1, 2, 3, H, W), torch.randint(0, 9, (1, 3, 1, H, W)).float())
+            plan = m._active_plan.plan
+            names = [lib.v2v_plan_op_name(plan.h, i).decode() for i in range(plan.num_ops)]
+            counts[lanes] = (names.count("lane_wait"), names.count("conv_igemm"), names.count("add_nhwc"))
+        finally:
+            N.set_record_only(False)
+            N._ENGINES.clear()
+    assert counts[1][0] == 6 and counts[0][0] == 0          # fork seg, fork fg, join seg, fork flow, join flow, join fg
+    assert counts[1][1] == counts[0][1]                     # same convolutions either way
+    assert counts[1][2] == counts[0][2] + 1                 # the tower sum is its own launch when the towers run in parallel
+    assert lib.v2v_plan_set_lane(9) != 0 and lib.v2v_plan_lane_wait(0, 8) != 0 and lib.v2v_plan_set_lane(0) == 0
