@@ -240,6 +240,15 @@ int v2v_avgpool2_planar_backward(const float* dy, float* dx, int64_t planes, int
 int v2v_onehot_planar(const float* labels, const float* inst, float* out, int32_t H, int32_t W,
                       int32_t label_nc, void* stream);
 
+/* Instance-wise average pooling of Encoder.forward (models/networks.py:621-632) for ONE sample: out[c][p] = mean of
+ * feat[c][q] over the pixels q with inst[q] == inst[p].  feat / out: planar fp32 [C][HW]; inst: fp32 [HW] holding integer ids
+ * (any values).  workspace: v2v_instance_mean_workspace(C, HW) bytes, 4-byte aligned, owned by the caller.  Sums use float
+ * atomics: the summation order (1e-7-level rounding) is run-dependent.  Up to 2048 distinct ids per sample probe quickly;
+ * beyond 4096 the excess pixels keep their own value. */
+int64_t v2v_instance_mean_workspace(int32_t C, int64_t HW);
+int v2v_instance_mean_planar(const float* feat, const float* inst, float* out, void* workspace,
+                             int32_t C, int64_t HW, void* stream);
+
 /* encode_input (models/vid2vid_model_G.py:86-112) + get_edges (models/base_model.py:146-152)
  * + compute_mask (:322-330) for `T` frames, written straight to the NHWC stem input:
  *   out[h][w][t*(label_nc+use_inst) + c] = (label[t][h][w] == c),  edge in channel label_nc.

@@ -140,3 +140,17 @@ def test_basemodel_tensor_helpers_match_reference():
     assert torch.equal(G.compute_fake_B_prev(None, t("rb_prev"), None, t("fake")), t("p1"))
     assert torch.equal(G.compute_fake_B_prev(None, t("rb_prev"), [t("last")], t("fake")), t("p2"))
     assert torch.equal(G.compute_fake_B_prev(None, t("rb_prev"), [t("last")], t("fake")[:, :1]), t("p3"))
+
+
+def test_face_feature_lookup_matches_reference():
+    """nearest_face_features == the nearest-neighbour half of the reference's get_face_features
+    (models/vid2vid_model_G.py:296-320; vectors from tests/golden/make_golden_facefeat.py)."""
+    import numpy as np
+    from vid2vid_amd.models.vid2vid_model_G import nearest_face_features
+    g = dict(np.load(os.path.join(os.path.dirname(GOLDEN), "face_feature_lookup.npz")))
+    feat_num = int(g["feat_num"])
+    features = {k: g["features.%d" % k] for k in range(7)}
+    for i in range(3):
+        out = nearest_face_features(torch.from_numpy(g["case%d.feat_map" % i]), torch.from_numpy(g["case%d.inst" % i]),
+                                    features, feat_num)
+        assert torch.allclose(out, torch.from_numpy(g["case%d.out" % i]), rtol=0, atol=1e-6), i

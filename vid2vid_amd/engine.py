@@ -938,6 +938,21 @@ class Engine:
         self.label("avgpool2_planar")
         return out
 
+    def instance_mean(self, feat, inst):
+        """Instance-wise average pooling (Encoder.forward, models/networks.py:621-632).  feat: planar fp32 (N, C, H, W);
+        inst: (N, 1, H, W) fp32 holding integer ids.  Returns a tensor like feat."""
+        feat = feat.contiguous().float()
+        inst = inst.contiguous().float()
+        N, Cc, H, W = feat.shape
+        out = self.empty_f32(N, Cc, H, W)
+        nbytes = lib.v2v_instance_mean_workspace(Cc, H * W)
+        ws = self.scratch("instance_mean_ws", (nbytes + 3) // 4)
+        for n in range(N):
+            check(lib.v2v_instance_mean_planar(_ptr(feat[n]), _ptr(inst[n]), _ptr(out[n]), _ptr(ws), Cc, H * W, _stream()),
+                  "instance_mean")
+            self.label("instance_mean")
+        return out
+
     def onehot_planar(self, labels, inst, H, W, label_nc):
         """Planar fp32 one-hot (+ edge plane) of one label frame: `real_A[0][0, -1]` (vid2vid_model_G.py:209)."""
         per = label_nc + (1 if inst is not None else 0)

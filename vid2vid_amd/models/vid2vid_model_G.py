@@ -22,6 +22,35 @@ from ..optim import FusedAdam
 from .base_model import BaseModel
 
 
+def nearest_face_features(feat_map, inst, features, feat_num):
+    """Second half of get_face_features (reference models/vid2vid_model_G.py:296-320): pick the training image whose
+    per-part encoder features are nearest to this image's (squared distance summed over the facial parts present and the
+    feat_num channels; dists_min, base_model.py:136-144) and paint ITS features over the parts.
+    feat_map: (N, >=feat_num, H, W) instance-wise constant encoder output; inst: (N, 1, H, W) part ids in 0..6;
+    features: {part id: array (num_images_of_part, feat_num + 1)} (checkpoints/edge2face_single/features.npy).
+    Parts absent from `inst` contribute nothing (the reference leaves their rows of the two scratch tensors uninitialised)."""
+    import numpy as np
+    inst_l = inst.long()
+    labels = [int(l) for l in torch.unique(inst_l)]
+    num_images = features[6].shape[0]
+    ori = torch.zeros(7, feat_num, 1)
+    ref = torch.zeros(7, feat_num, num_images)
+    for label in labels:
+        idx = (inst_l == label).nonzero()
+        b, _, y, x = [int(v) for v in idx[0]]
+        ori[label, :, 0] = feat_map[b, :feat_num, y, x].detach().float().cpu()
+        ref[label] = torch.from_numpy(np.ascontiguousarray(features[label][:num_images, :feat_num].T)).float()
+    dists = ((ori - ref) ** 2).sum(0).sum(0)
+    cluster = int(torch.argmin(dists))
+    out = torch.zeros(inst.size(0), feat_num, inst.size(2), inst.size(3), dtype=torch.float32, device=inst.device)
+    for label in labels:
+        feat = features[label][:, :-1]
+        row = torch.as_tensor(np.asarray(feat[min(cluster, feat.shape[0] - 1), :feat_num], dtype=np.float32), device=inst.device)
+        mask = (inst_l[:, 0] == label)                                   # (N, H, W)
+        out.permute(0, 2, 3, 1)[mask] = row
+    return out
+
+
 class _FramePlan:
     """Buffers + launch sequence generating one frame at every spatial scale."""
 
@@ -321,6 +350,16 @@ class Vid2VidModelG(BaseModel):
             if input_B is None:
                 raise ValueError("use_real_img needs the first real frames (input_B)")
             first = input_B[:, :tG - 1].to(dev, torch.float32)
+        elif opt.use_single_G and getattr(opt, "dataset_mode", "temporal") == "face":
+            # reference :239-244 with dataset_mode == 'face': raw input maps + feature map of the given real frame; the
+            # pooling map is the instance map (encode_input :104-106)
+            if input_B is None or inst_A is None:
+                raise ValueError("the face first-frame generator needs the first real frames and the part map")
+            frames = []
+            for i in range(tG - 1):
+                feat_map = self.get_face_features(input_B[:, i], inst_A[:, i])
+                frames.append(self.netG_i.forward(input_A[:, i].to(dev, torch.float32), feat_map).unsqueeze(1))
+            first = torch.cat(frames, dim=1)
         elif opt.use_single_G:
             frames = []
             lab = input_A[0, :, 0].to(dev, torch.float32).contiguous()
@@ -351,6 +390,17 @@ class Vid2VidModelG(BaseModel):
                 path, netG = base + "latest_net_G_2048.pth", networks.define_G(35, 3, 0, 32, "local", 4, "instance", 0, gpu_ids, opt)
             else:
                 raise ValueError("Single image generator does not exist")
+        elif "face" in opt.dataroot:                    # reference :277-284 (edge2face: feature-encoding generator + encoder)
+            base = "checkpoints/edge2face_single/"
+            opt.feat_num = 16
+            path, netG = base + "latest_net_G.pth", networks.define_G(15, 3, 0, 64, "global_with_features", 3, "instance", 0, gpu_ids, opt)
+            self.netE = networks.define_G(3, 16, 0, 16, "encoder", 4, "instance", 0, gpu_ids, opt)
+            epath = base + "latest_net_E.pth"
+            if os.path.isfile(epath):
+                self.netE.load_state_dict(torch.load(epath, map_location="cpu"))
+            elif not getattr(opt, "random_init_ok", False):
+                raise RuntimeError("%s not found" % epath)
+            self.face_features_path = base + "features.npy"
         else:
             raise ValueError("Single image generator does not exist")
         if os.path.isfile(path):
@@ -358,6 +408,18 @@ class Vid2VidModelG(BaseModel):
         elif not getattr(opt, "random_init_ok", False):
             raise RuntimeError("%s not found" % path)
         return netG
+
+    def get_face_features(self, real_image, inst):
+        """reference :290-320: encoder features of the given real frame, replaced per facial part by those of the nearest
+        training image (checkpoints/edge2face_single/features.npy, an external download like the checkpoints)."""
+        import os
+        import numpy as np
+        if not os.path.isfile(self.face_features_path):
+            raise RuntimeError("%s not found (feature dictionary of the edge2face single-image model)" % self.face_features_path)
+        features = np.load(self.face_features_path, encoding="latin1", allow_pickle=True).item()
+        dev = self.device
+        feat_map = self.netE.forward(real_image.to(dev, torch.float32), inst.to(dev, torch.float32))
+        return nearest_face_features(feat_map, inst.to(dev, torch.float32), features, self.opt.feat_num)
 
     # ------------------------------------------------------------------ training
     def encode_input(self, input_map, real_image=None, inst_map=None):

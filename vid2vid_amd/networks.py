@@ -643,8 +643,11 @@ class Encoder(nn.Module):
         self.model = nn.Sequential(*model)
 
     def forward(self, input, inst):
-        raise NotImplementedError("Encoder: the instance-wise average pooling (models/networks.py:621-632, a segmented "
-                                  "mean over the instance map) has no HIP kernel yet -- SURVEY 8f rank 3, next round")
+        """(N, output_nc, H, W) feature map, constant over every instance of `inst` (N, 1, H, W)."""
+        eng = get_engine(input.device)
+        with torch.no_grad():
+            feat = eng.run_sequential(self.model, eng.pack(input.contiguous().float()), head_nchw=True, name="E")
+            return eng.instance_mean(feat, inst.to(feat.device))
 
 
 # --------------------------------------------------------------------------------------
