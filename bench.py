@@ -239,20 +239,9 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    # N > 1: rank 0 runs the tile searches (per-shape + whole-frame), the other ranks replay its selections through the tuning
-    # cache -> the same kernels on every GPU instead of N independent (noisy) searches
-    release_tuning = None
-    if world > 1 and not os.environ.get("V2V_TUNE_CACHE"):
-        import tempfile
-        cache = os.path.join(tempfile.gettempdir(), "v2v_tune_%s.json" % os.environ.get("MASTER_PORT", "0"))
-        os.environ["V2V_TUNE_CACHE"] = cache
-        if rank == 0 and os.path.exists(cache):
-            os.remove(cache)
-        dist.barrier()                                   # no stale file from an earlier job
-        if rank == 0:
-            release_tuning = dist.barrier                # called below, once rank 0's plan is built and saved
-        else:
-            dist.barrier()                               # wait for rank 0's selections
+    # N > 1: rank 0 runs the tile searches, the other ranks replay its selections (vid2vid_amd/parallel.py)
+    from vid2vid_amd import parallel
+    release_tuning = parallel.shared_tuning_cache(rank, world)
     face = args.dataset == "edge2face"
     if face:      # scripts/face/test_512.sh geometry: 15 raw input maps per frame, no instance map, no fg tower
         opt = make_opt(label_nc=0, input_nc=15, use_instance=False, fg=False, use_real_img=True, random_init_ok=True,
@@ -285,9 +274,8 @@ def main():
 
     model.fake_B_prev = None
     step(0)                                      # builds the frame plan (tile searches, graph): never inside the timed region
-    if release_tuning is not None:
-        torch.cuda.synchronize(dev)
-        release_tuning()
+    torch.cuda.synchronize(dev)
+    release_tuning()                             # N > 1, rank 0: the other ranks may now build with its selections
     model.fake_B_prev = None
     for t in range(args.warmup):
         step(t)

@@ -103,3 +103,47 @@ def test_fused_adam_state_dict_roundtrip():
     other = FusedAdam(list(torch.nn.Conv2d(3, 4, 3).parameters()))
     with pytest.raises(ValueError):
         other.load_state_dict(opt.state_dict())
+
+
+def _tuning_worker(rank, world, port, q):
+    import json
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.pop("V2V_TUNE_CACHE", None)
+    from vid2vid_amd.parallel import init_distributed, shared_tuning_cache
+    init_distributed("gloo")
+    release = shared_tuning_cache(rank, world)           # ranks > 0 block in here until rank 0 releases
+    path = os.environ["V2V_TUNE_CACHE"]
+    if rank == 0:
+        assert not os.path.exists(path)                  # a stale file of an earlier job was removed
+        time.sleep(0.5)                                  # "tile search"
+        with open(path, "w") as f:
+            json.dump({"1": {"1,2,3": [55, 1, 0]}}, f)
+        release()
+        seen = True
+    else:
+        seen = os.path.exists(path) and json.load(open(path))["1"]["1,2,3"] == [55, 1, 0]
+        release()                                        # no-op
+    dist.barrier()                                       # the timing barrier of bench.py: every rank gets here
+    dist.destroy_process_group()
+    q.put((rank, "ok" if seen else "rank %d did not see rank 0's selections" % rank))
+
+
+def test_shared_tuning_cache_world2(tmp_path):
+    """bench.py --gpus N: rank 0 searches tile configurations, the other ranks start only after its selections are on disk."""
+    import tempfile
+    port = _free_port()
+    stale = os.path.join(tempfile.gettempdir(), "v2v_tune_%d.json" % port)
+    open(stale, "w").write("{}")                         # must be removed by rank 0 before anybody reads it
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tuning_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    if os.path.exists(stale):
+        os.remove(stale)
+    assert res == [(0, "ok"), (1, "ok")]

@@ -87,3 +87,24 @@ def frame_ranks(n_gpus_gen, world):
     if n_gpus_gen <= 0 or n_gpus_gen >= world:
         return list(range(world)), list(range(world))
     return list(range(n_gpus_gen)), list(range(n_gpus_gen, world))
+
+
+def shared_tuning_cache(rank, world):
+    """N > 1 inference replicas: rank 0 runs the tile searches (per-shape + whole-frame), the other ranks replay its
+    selections through the tuning cache (`V2V_TUNE_CACHE`) -- the same kernels on every GPU instead of N independent, noisy
+    searches.  Call BEFORE the first engine exists.  Ranks > 0 return only after rank 0 has called the returned `release()`
+    (rank 0 calls it once its plan is built, i.e. once the cache file is complete); on ranks > 0 and in a single process
+    `release` is a no-op.  Does nothing when the user already set V2V_TUNE_CACHE."""
+    if world <= 1 or os.environ.get("V2V_TUNE_CACHE"):
+        return lambda: None
+    import tempfile
+    cache = os.path.join(tempfile.gettempdir(), "v2v_tune_%s.json" % os.environ.get("MASTER_PORT", "0"))
+    os.environ["V2V_TUNE_CACHE"] = cache
+    if rank == 0 and os.path.exists(cache):
+        os.remove(cache)
+    dist.barrier()                                   # no stale file from an earlier job
+    if rank == 0:
+        return dist.barrier                          # released by the caller once rank 0's selections are on disk
+    dist.barrier()                                   # wait for rank 0's selections
+    return lambda: None
+
