@@ -145,6 +145,12 @@ int     v2v_conv_tile_config(const v2v_conv_desc* d);
  *   dX of ConvTranspose2d(w[cin][cout], stride 2, p)   = Conv2d of dY with `w` read as a Conv2d weight
  *       [cout'=cin][cin'=cout], stride 2, pad p. */
 int     v2v_conv2d(const v2v_conv_desc* d, void* stream);
+/* Grouped launch: two convolutions of IDENTICAL geometry, modes and tile configuration (tile ids 70..79, the
+ * second-schedule ping-pong 3x3 kernels) as ONE launch -- block z picks its member's tensors.  The twin chains of
+ * CompositeGenerator (label / image towers, image / flow branches: models/networks.py:203-232) each fill only half
+ * of the 256 CUs at batch 1; paired they fill the chip without split-K.  Each member keeps its own output, statistics,
+ * finalize tickets and split-K scratch; results are bitwise those of two v2v_conv2d calls. */
+int     v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, void* stream);
 
 /* Weight gradient:  G[r][c][kh][kw] (+)= sum_{n,oi,oj} P[n][oi][oj][r] * Q[n][oi*s+kh-pad][oj*s+kw-pad][c]
  *   Conv2d:           P = dY (rows = cout), Q = X  (cols = cin)  -> dW[cout][cin][KH][KW]
@@ -191,6 +197,12 @@ int v2v_bn_finalize_groups(int32_t rows);
 int v2v_bn_apply(const float* raw, int32_t c_stride_raw, const float* scale_shift,
                  const void* add0, const void* add1, void* y, int64_t P, int32_t C, int32_t c_stride,
                  int32_t act, float act_param, int32_t dtype, void* stream);
+/* Two bn_apply passes of identical geometry as ONE launch (block y picks its member): the norm + activation
+ * (+ residual) passes behind a v2v_conv2d_pair.  Bitwise the result of two v2v_bn_apply calls. */
+int v2v_bn_apply_pair(const float* raw_a, const float* scale_shift_a, const void* add0_a, const void* add1_a, void* y_a,
+                      const float* raw_b, const float* scale_shift_b, const void* add0_b, const void* add1_b, void* y_b,
+                      int32_t c_stride_raw, int64_t P, int32_t C, int32_t c_stride,
+                      int32_t act, float act_param, int32_t dtype, void* stream);
 
 /* Backward of bn_finalize + bn_apply (autograd of training-mode BatchNorm2d/InstanceNorm2d + ReLU /
  * LeakyReLU in the reference):  g = dY*act'(raw*scale+shift);  dbeta (+)= sum g;  dgamma (+)= sum g*xhat;

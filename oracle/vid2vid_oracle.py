@@ -414,6 +414,7 @@ class InferenceOracle:
         self.n_down, self.n_blocks, self.n_blocks_local, self.tG = n_downsample_G, n_blocks, n_blocks_local, tG
         self.no_first_img, self.align_corners = no_first_img, align_corners
         self.fake_B_prev = None
+        self.last = {}
 
     def step(self, input_A, input_B, inst_A):
         tG, S = self.tG, self.S
@@ -447,7 +448,9 @@ class InferenceOracle:
                     out = composite_local_generator(self.sds[s], x, prev, mask, feat, flow_feat, fg_feat,
                                                     self.n_blocks_local, s, self.fg, use_raw_only=raw_only,
                                                     align_corners=self.align_corners)
-                fake_B, _, _, _, feat, flow_feat, fg_feat = out
+                fake_B, flow_s, weight_s, raw_s, feat, flow_feat, fg_feat = out
+                # per-scale heads of the newest frame (si = 0 finest), for the full-width parity checks
+                self.last["flow%d" % si], self.last["weight%d" % si], self.last["raw%d" % si] = flow_s, weight_s, raw_s
                 self.fake_B_prev[si] = torch.cat([self.fake_B_prev[si][1:], fake_B])
             return fake_B, pyr[0][0, -1]
 

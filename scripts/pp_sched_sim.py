@@ -1,0 +1,89 @@
+"""Hazard check of the ping-pong conv schedule (old: DMA issue in LOAD; new: DMA issue in MMA)."""
+import itertools, sys
+
+def cmin(a,b): return a if a<b else b
+
+def simulate(GP, LB, DB, ncc, new, NPT=None, verbose=False):
+    NSB = DB + 1
+    if NPT is None: NPT = 9 - DB
+    PPT = (GP + NPT - 1)//NPT
+    nsteps = ncc*9
+    def npieces(tap):
+        if tap >= NPT: return 0
+        return cmin((tap+1)*PPT, GP) - cmin(tap*PPT, GP)
+    assert sum(npieces(t) for t in range(9)) == GP, (GP, NPT, PPT)
+    # per-group program as list of (phase, action)
+    # data items: ('W', tile) uses stage tile%NSB ; ('P', chunk) uses patch buffer chunk%2
+    errors = []
+    landed_phase = {}   # (group, item) -> phase at which the wave's wait guarantees it (end of that phase)
+    issue_phase = {}    # (group, item, piece) -> phase issued
+    read_phase = {}     # (group, 'W', tile) / (group,'P',chunk) -> last phase read
+    for grp in (0, 1):
+        outstanding = []    # list of items in issue order (each piece separately)
+        cnt = {}
+        def issue(item, n, phase):
+            for _ in range(n):
+                k = cnt.get(item, 0); cnt[item] = k + 1
+                outstanding.append((item, k))
+                issue_phase.setdefault((grp, item), []).append(phase)
+        def wait(N, phase):
+            while len(outstanding) > N:
+                it, k = outstanding.pop(0)
+                landed_phase[(grp, it, k)] = phase
+        # prologue at phase -1
+        issue(('P', 0), GP, -1)
+        for t in range(DB): issue(('W', t), LB, -1)
+        wait((DB-1)*LB, -1)
+        for j in range(nsteps):
+            tap, c = j % 9, j // 9
+            pl = 2*j + (0 if grp == 0 else 1)           # LOAD(j) phase
+            pm = 2*j + 1 + (0 if grp == 0 else 1)       # MMA(j) phase
+            # group B executes MMA(j-1) before LOAD(j): phases are increasing either way, so process in phase order
+            def do_issue(phase, jj):
+                tp = jj % 9; cc = jj // 9
+                issue(('W', jj + DB), LB, phase)        # tail duplicates beyond nsteps are harmless
+                if tp < NPT: issue(('P', cc + 1), npieces(tp), phase)
+            def wait_count(jj):
+                tp = jj % 9
+                np0 = npieces(tp); np1 = npieces((tp+8)%9); np2 = npieces((tp+7)%9)
+                if not new:
+                    return (DB-1)*LB + np0 + np1 + (np2 if DB == 3 else 0)
+                return (DB-2)*LB + np1 + (np2 if DB == 3 else 0)
+            # LOAD(j)
+            read_phase[(grp, ('W', j))] = pl
+            read_phase[(grp, ('P', c))] = pl
+            if not new: do_issue(pl, j)
+            wait(wait_count(j), pl)
+            if new: do_issue(pm, j)
+    # check RAW: every reader group reads item at phase pr: all pieces of both groups must have landed at phase < pr
+    for (grp, item), pr in read_phase.items():
+        for g2 in (0, 1):
+            n = GP if item[0] == 'P' else LB
+            for k in range(n):
+                lp = landed_phase.get((g2, item, k))
+                if lp is None or lp >= pr:
+                    errors.append("RAW: group %d reads %s at phase %d, group %d piece %d landed at %s" % (grp, item, pr, g2, k, lp))
+    # check WAR: item X overwrites the buffer of older item Y (same stage): all issues of X must be in a phase > last read of Y
+    last_read = {}
+    for (grp, item), pr in read_phase.items():
+        last_read[item] = max(last_read.get(item, -10), pr)
+    for (grp, item), phases in issue_phase.items():
+        if item[0] == 'W':
+            old = ('W', item[1] - NSB)
+        else:
+            old = ('P', item[1] - 2)
+        if old in last_read:
+            for ph in phases:
+                if ph <= last_read[old]:
+                    errors.append("WAR: group %d issues %s at phase %d, %s last read at phase %d" % (grp, item, ph, old, last_read[old]))
+    return errors
+
+ok = True
+for new in (False, True):
+    for DB in (2, 3):
+        for GP in (3, 5, 6, 9):
+            for LB in (1, 2):
+                e = simulate(GP, LB, DB, 3, new)
+                print("new=%d DB=%d GP=%d LB=%d: %s" % (new, DB, GP, LB, "OK" if not e else "%d errors, e.g. %s" % (len(e), e[0])))
+                ok &= not e
+sys.exit(0 if ok else 1)

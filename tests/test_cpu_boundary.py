@@ -255,6 +255,7 @@ def test_plan_lanes_record_fork_and_join_edges():
             opt = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True,
                            precision="bf16", gpu_ids=[], ngf=16, n_blocks=2)
             opt.lanes = lanes
+            opt.twin = 0                    # the paired launches of the twin chains have their own test below
             m = create_model(opt)
             H, W = 64, 128
             A = torch.randint(0, 35, (1, 3, 1, H, W)).float()
@@ -269,3 +270,62 @@ def test_plan_lanes_record_fork_and_join_edges():
     assert counts[1][1] == counts[0][1]                     # same convolutions either way
     assert counts[1][2] == counts[0][2] + 1                 # the tower sum is its own launch when the towers run in parallel
     assert lib.v2v_plan_set_lane(9) != 0 and lib.v2v_plan_lane_wait(0, 8) != 0 and lib.v2v_plan_set_lane(0) == 0
+
+
+def test_twin_chains_record_paired_launches():
+    """With opt.twin (the default) the ResnetBlock chains of the label / image towers and of the image / flow branches are
+    recorded as v2v_conv2d_pair / v2v_bn_apply_pair launches: the 512x256 label2city frame keeps its census of 79
+    convolutions / 2115 GFLOP while 36 of them (the 1024 -> 1024 layers) travel as 18 launches, and the library's argument
+    checks accept every descriptor pair."""
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models import create_model
+    if torch.cuda.is_available():
+        pytest.skip("dry-run census is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        ops = {}
+        for twin in (1, 0):
+            opt = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True,
+                           precision="bf16", gpu_ids=[])
+            opt.twin = twin
+            m = create_model(opt)
+            H, W = 256, 512
+            A = torch.randint(0, 35, (1, 3, 1, H, W)).float()
+            m.inference(A, torch.zeros(1, 2, 3, H, W), torch.randint(0, 20, (1, 3, 1, H, W)).float())
+            fp = m._active_plan
+            assert len(fp.conv_log) == 79 and abs(sum(c["flops"] for c in fp.conv_log) / 1e9 - 2115.0) < 0.5
+            names = [lib.v2v_plan_op_name(fp.plan.h, i).decode() for i in range(fp.plan.num_ops)]
+            ops[twin] = (names.count("conv_igemm"), names.count("bn_apply"), sum(1 for c in fp.conv_log if c.get("pair")))
+            N._ENGINES.clear()
+        assert ops[1][2] == 36 and ops[0][2] == 0
+        assert ops[1][0] == ops[0][0] - 18 and ops[1][1] == ops[0][1] - 18
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_three_scale_narrow_towers_lowering_records(precision):
+    """n_scales_spatial = 3 at the widths of tests/golden/inference_label2city_s3_64x128.npz (ngf 8 -> 4 -> 2: towers with
+    2, 4 and 6 channels, not multiples of the 4-wide vector loads): every launch of the frame passes the library's argument
+    checks (round 1 never recorded this configuration and its norm kernel rejected C = 2 on the GPU)."""
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models import create_model
+    if torch.cuda.is_available():
+        pytest.skip("dry-run census is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        opt = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True, ngf=8, n_blocks=2,
+                       n_blocks_local=1, n_scales_spatial=3, n_downsample_G=2, loadSize=128, precision=precision, gpu_ids=[])
+        m = create_model(opt)
+        H, W = 64, 128
+        A = torch.randint(0, 35, (1, 3, 1, H, W)).float()
+        fake, lab = m.inference(A, torch.zeros(1, 2, 3, H, W), torch.randint(0, 9, (1, 3, 1, H, W)).float())
+        assert fake.shape == (1, 3, H, W) and lab.shape == (36, H, W)
+        assert m._active_plan.plan.num_ops > 200
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()

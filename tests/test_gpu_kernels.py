@@ -204,7 +204,9 @@ def test_prefetch_is_bitwise_neutral():
 
 PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33, 3), (34, 2), (36, 2),
               (40, 1), (41, 1), (42, 1), (43, 1), (44, 1), (45, 1), (46, 1), (47, 1), (48, 1), (40, 2), (41, 3), (46, 2), (48, 2),
-              (50, 1), (51, 1), (52, 1), (53, 1), (54, 1), (55, 1), (56, 1), (57, 1), (50, 2), (51, 3), (53, 2), (52, 4), (56, 2)]
+              (50, 1), (51, 1), (52, 1), (53, 1), (54, 1), (55, 1), (56, 1), (57, 1), (50, 2), (51, 3), (53, 2), (52, 4), (56, 2),
+              # ping-pong, second schedule (csrc/conv3x3_pp2_kernel.h): LDS-DMA issued between the MFMAs
+              (70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2), (73, 3), (75, 2)]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -253,6 +255,63 @@ def test_conv3x3_patch_kernel(case, prec):
     assert_close(eng.unpack(out).cpu(), F.leaky_relu(refs[0], 0.2), 1e-4 if prec == "fp32" else 1e-2, "act")
     if eng._sk_counter is not None:
         assert int(eng._sk_counter.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(128, 72, 24, 64, "reflect", 1), (192, 200, 19, 45, "reflect", 2), (256, 64, 32, 64, "zero", 1)])
+def test_conv2d_pair_equals_two_launches(case, prec):
+    """v2v_conv2d_pair / v2v_bn_apply_pair (paired launches of the twin chains): two convolutions of the same geometry
+    with different inputs and weights as ONE launch -- raw outputs, per-tile statistics, the in-kernel norm finalize and
+    the normalise + ReLU + residual pass must be BITWISE what two single launches of the same tile produce, for every
+    second-schedule tile, unsplit and split-K, and both must match torch."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, mode, N = case
+    torch.manual_seed(cin * 3 + W)
+    eng = _engine(prec)
+    pad = 0 if mode == "reflect" else 1
+    convs = [nn.Conv2d(cin, cout, 3, padding=pad) for _ in range(2)]
+    norms = [nn.BatchNorm2d(cout).to(DEV) for _ in range(2)]
+    with torch.no_grad():
+        for n in norms:
+            n.weight.normal_(1.0, 0.1); n.bias.normal_(0.0, 0.1)
+    xs = [torch.randn(N, cin, H, W) * (1.0 + i) for i in range(2)]
+    res = [torch.randn(N, cout, H, W) for _ in range(2)]
+    def ref_of(x, conv):
+        xr = _round(x, prec)
+        if mode == "reflect":
+            xr = F.pad(xr, (1,) * 4, mode="reflect")
+        return F.conv2d(xr, _round(conv.weight.detach(), prec), conv.bias.detach(), padding=pad)
+    refs = [ref_of(x, c) for x, c in zip(xs, convs)]
+    convs = [c.to(DEV) for c in convs]
+    xa = [eng.pack(x.to(DEV)) for x in xs]
+    ra = [eng.pack(r.to(DEV)) for r in res]
+    pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
+    ncc = xa[0].Cs // (64 if prec == "bf16" else 32)
+    assert eng.pair_eligible(xa[0], convs[0], xa[1], convs[1])
+    for tile, S in [(70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2)]:
+        if 2 * S > ncc:
+            continue
+        eng.pair_override = (tile, S)
+        ya, yb = eng.conv_group_pair(xa[0], convs[0], norms[0], xa[1], convs[1], norms[1], pm, po, L.ACT_RELU, 0.0,
+                                     adds_a=(ra[0], None), adds_b=(ra[1], None), labels=("a", "b"))
+        assert eng.conv_log[-1]["tile"] == tile and eng.conv_log[-1]["pair"]
+        raws = []
+        for k, sset in ((0, 0), (1, 1)):
+            with eng.scratch_set(sset):
+                raw = eng.scratch("raw", N * H * W * cout)[:N * H * W * cout].view(N, H, W, cout).permute(0, 3, 1, 2).clone()
+            assert_close(raw.cpu(), refs[k], 1e-4, "pair member %d tile %d S=%d" % (k, tile, S))
+            raws.append(raw)
+        # the same two layers as single launches of the same tile: bitwise equal raw output and activations
+        eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, S, 0)
+        for k, y_pair in ((0, ya), (1, yb)):
+            y1 = eng.conv_group(xa[k], convs[k], pm, po, norms[k], L.ACT_RELU, 0.0, add0=ra[k], label="single")
+            raw1 = eng.scratch("raw", N * H * W * cout)[:N * H * W * cout].view(N, H, W, cout).permute(0, 3, 1, 2)
+            assert torch.equal(raw1, raws[k]), "raw output of pair member %d differs from a single launch (tile %d S=%d)" % (k, tile, S)
+            assert torch.equal(y1.t, y_pair.t), "normalised output of pair member %d differs (tile %d S=%d)" % (k, tile, S)
+            ref_y = F.relu(F.batch_norm(refs[k], None, None, norms[k].weight.detach().cpu(), norms[k].bias.detach().cpu(), True, 0.1, 1e-5)) + _round(res[k], prec)
+            assert_close(eng.unpack(y_pair).cpu(), ref_y, 1e-4 if prec == "fp32" else 2e-2, "pair member %d norm+relu+residual" % k)
+    for key, t in list(eng._fin_counters.items()) + list(eng._sk_counters.items()):
+        assert int(t.abs().sum().item()) == 0, "tickets of %s must be re-armed" % (key,)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

@@ -42,6 +42,7 @@
 //     publish fp32 partial tiles write-through (sc1) and the last arriver reduces them in slice
 //     order (deterministic) and runs the normal epilogue.
 #include "conv3x3_pp_kernel.h"
+#include "conv3x3_pp2_kernel.h"
 #include "conv7x7_head_kernel.h"
 #include <cstdarg>
 #include <cstring>
@@ -205,6 +206,8 @@ int launch_patch_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_patch_f32(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_pp_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_pp_f32(int cfg, const ConvKArgs& k, hipStream_t s);
+int launch_pp2_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
+int launch_pp2_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s);
 int launch_head_f32(const ConvKArgs& k, hipStream_t s);
 
@@ -224,7 +227,9 @@ struct ConvOp : Op {
     ConvKArgs k;
     int ncls, cfg, dtype;
     long long slab_bytes; int sk_tickets;
+    int groups = 1;      // 2: grouped launch (v2v_conv2d_pair), second member's tensors in k.g1
     int launch(hipStream_t s) override {
+        if (cfg >= 70) return dtype == V2V_BF16 ? launch_pp2_bf16(cfg, k, groups, s) : launch_pp2_f32(cfg, k, groups, s);
         if (cfg == 60) return dtype == V2V_BF16 ? launch_head_bf16(k, s) : launch_head_f32(k, s);
         if (cfg >= 50) return dtype == V2V_BF16 ? launch_pp_bf16(cfg, k, s) : launch_pp_f32(cfg, k, s);
         if (cfg >= 32) return dtype == V2V_BF16 ? launch_patch_bf16(cfg, k, s) : launch_patch_f32(cfg, k, s);
@@ -316,7 +321,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     } else if (op->cfg >= 32) {
         // conv3x3_patch_kernel: 3x3 / stride 1 / pad 1 Conv2d, channel stride a multiple of the 128-byte chunk,
         // weights packed channel-chunk outer (korder 1)
-        const PatchCfg* pc = op->cfg >= 50 ? find_pp_cfg(op->cfg) : find_patch_cfg(op->cfg);
+        const PatchCfg* pc = op->cfg >= 70 ? find_pp2_cfg(op->cfg) : op->cfg >= 50 ? find_pp_cfg(op->cfg) : find_patch_cfg(op->cfg);
         if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
         if (d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 ||
             d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 1 ||
@@ -407,6 +412,41 @@ extern "C" int v2v_conv_tile_config(const v2v_conv_desc* d) {
     ConvOp op;
     if (build_conv(d, &op, false) != 0) return V2V_EINVAL;
     return op.cfg;
+}
+
+extern "C" int v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, void* stream) {
+    auto op = std::make_unique<ConvOp>();
+    ConvOp ob;
+    int rc = build_conv(a, op.get());
+    if (rc == 0) rc = build_conv(b, &ob);
+    if (rc != 0) return rc;
+    if (op->cfg < 70 || op->cfg >= 80 || ob.cfg != op->cfg) {
+        set_error("conv pair: both members need the same grouped-launch tile config (70..79), got %d / %d", op->cfg, ob.cfg);
+        return V2V_EINVAL;
+    }
+    const bool same =
+        a->N == b->N && a->H == b->H && a->W == b->W && a->cin == b->cin && a->cin_stride == b->cin_stride &&
+        a->cout == b->cout && a->cout_stride == b->cout_stride && a->KH == b->KH && a->KW == b->KW && a->stride == b->stride &&
+        a->pad == b->pad && a->pad_mode == b->pad_mode && a->transposed == b->transposed && a->OH == b->OH && a->OW == b->OW &&
+        a->dtype == b->dtype && a->out_mode == b->out_mode && a->act == b->act && a->act_param == b->act_param &&
+        a->out_scale == b->out_scale && a->splitk == b->splitk && a->w_korder == b->w_korder && a->ablate == b->ablate &&
+        (a->bias != nullptr) == (b->bias != nullptr) && (a->stats != nullptr) == (b->stats != nullptr) &&
+        (a->fin_counter != nullptr) == (b->fin_counter != nullptr) && a->fin_eps == b->fin_eps &&
+        a->fin_momentum == b->fin_momentum && a->fin_count == b->fin_count &&
+        (a->fin_gamma != nullptr) == (b->fin_gamma != nullptr) && (a->fin_beta != nullptr) == (b->fin_beta != nullptr) &&
+        (a->fin_running_mean != nullptr) == (b->fin_running_mean != nullptr) &&
+        (a->fin_running_var != nullptr) == (b->fin_running_var != nullptr);
+    if (!same) { set_error("conv pair: the two members must have identical geometry, modes and optional-operand sets"); return V2V_EINVAL; }
+    if (a->out == b->out || (a->stats && a->stats == b->stats) || (a->fin_counter && a->fin_counter == b->fin_counter) ||
+        (a->fin_scale_shift && a->fin_scale_shift == b->fin_scale_shift) || (a->splitk > 1 && (a->slabs == b->slabs || a->sk_counter == b->sk_counter))) {
+        set_error("conv pair: the members must not share outputs, statistics, tickets or split-K scratch"); return V2V_EINVAL;
+    }
+    ConvGroupPtrs& g = op->k.g1;
+    g.in = ob.k.in; g.w = ob.k.w; g.bias = ob.k.bias; g.out = ob.k.out; g.stats = ob.k.stats;
+    g.fin_counter = ob.k.fin_counter; g.fin_gamma = ob.k.fin_gamma; g.fin_beta = ob.k.fin_beta; g.fin_out = ob.k.fin_out;
+    g.fin_rmean = ob.k.fin_rmean; g.fin_rvar = ob.k.fin_rvar; g.slabs = ob.k.slabs; g.sk_counter = ob.k.sk_counter;
+    op->groups = 2;
+    return submit(std::move(op), stream);
 }
 
 extern "C" int v2v_conv2d(const v2v_conv_desc* d, void* stream) {

@@ -5,6 +5,14 @@
 
 namespace v2v {
 
+// Tensors of the SECOND member of a grouped launch (v2v_conv2d_pair; gridDim.z == 2): same geometry as the first,
+// its own operands, statistics / finalize outputs, tickets and split-K scratch.
+struct ConvGroupPtrs {
+    const char* in; const char* w; const float* bias; char* out; float* stats;
+    int* fin_counter; const float* fin_gamma; const float* fin_beta; float* fin_out; float* fin_rmean; float* fin_rvar;
+    float* slabs; int* sk_counter;
+};
+
 struct ConvKArgs {
     const char* in;
     const char* w;
@@ -40,6 +48,7 @@ struct ConvKArgs {
     int pf_dist, pf_mask;
     int tiles_h, tiles_w; // conv3x3_patch_kernel: output tiles per image (m_tiles = N * tiles_h * tiles_w)
     int ablate;          // profiling ablations (v2v_conv_desc.ablate); results are WRONG when non-zero
+    ConvGroupPtrs g1;    // grouped launch (conv3x3_pp2_kernel): operands of block z == 1
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int ntot) {

@@ -108,10 +108,14 @@ struct BnApplyArgs {
     const float* raw; int c_stride_raw; const float* scale_shift;
     const void* add0; const void* add1; void* y;
     long long P; int C; int c_stride; int act; float act_param;
+    // second member of a paired launch (v2v_bn_apply_pair, gridDim.y == 2): same geometry, its own tensors
+    const float* raw1; const float* scale_shift1; const void* add0_1; const void* add1_1; void* y1;
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a_in) {
+    BnApplyArgs a = a_in;
+    if (blockIdx.y != 0) { a.raw = a_in.raw1; a.scale_shift = a_in.scale_shift1; a.add0 = a_in.add0_1; a.add1 = a_in.add1_1; a.y = a_in.y1; }
     constexpr int VEC = ElemTraits<T>::VEC;
     const int vpr = a.c_stride / VEC;                       // vectors per pixel row
     const long long nvec = a.P * vpr;
@@ -127,10 +131,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
         for (int q = 0; q < VEC / 4; ++q) {
             const int c = c0 + q * 4;
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f), sc = r, sh = r;
-            if (c < a.C) {   // C and c_stride_raw are multiples of 4 by construction of the callers
+            if (c < a.C) {   // c_stride_raw is a multiple of 4 and >= C: the 4-wide raw load stays inside the pixel's row
                 r = *reinterpret_cast<const float4*>(a.raw + pix * a.c_stride_raw + c);
-                sc = *reinterpret_cast<const float4*>(a.scale_shift + c);
-                sh = *reinterpret_cast<const float4*>(a.scale_shift + a.C + c);
+                if ((a.C & 3) == 0) {
+                    sc = *reinterpret_cast<const float4*>(a.scale_shift + c);
+                    sh = *reinterpret_cast<const float4*>(a.scale_shift + a.C + c);
+                } else {     // C % 4 != 0 (2-channel test towers, 1027-channel --label_feat trunks): [2][C] rows are unaligned
+                    sc.x = a.scale_shift[c]; sh.x = a.scale_shift[a.C + c];
+                    if (c + 1 < a.C) { sc.y = a.scale_shift[c + 1]; sh.y = a.scale_shift[a.C + c + 1]; }
+                    if (c + 2 < a.C) { sc.z = a.scale_shift[c + 2]; sh.z = a.scale_shift[a.C + c + 2]; }
+                    if (c + 3 < a.C) { sc.w = a.scale_shift[c + 3]; sh.w = a.scale_shift[a.C + c + 3]; }
+                }
             }
             o[q * 4 + 0] = apply_act(r.x * sc.x + sh.x, a.act, a.act_param);
             o[q * 4 + 1] = apply_act(r.y * sc.y + sh.y, a.act, a.act_param);
@@ -164,15 +175,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
 }
 
 struct BnApplyOp : Op {
-    BnApplyArgs a; int dtype;
+    BnApplyArgs a; int dtype; int members = 1;
     int launch(hipStream_t s) override {
         const int vec = dtype == V2V_BF16 ? 8 : 4;
         long long nvec = a.P * (a.c_stride / vec);
         long long blocks = ceil_div(nvec, 256);
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
-        if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-        else                   hipLaunchKernelGGL(bn_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        const dim3 grid((unsigned)blocks, (unsigned)members);
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, a);
         return check_launch();
     }
     const char* name() const override { return "bn_apply"; }
@@ -482,8 +494,8 @@ extern "C" int v2v_bn_apply(const float* raw, int32_t c_stride_raw, const float*
                             int32_t act, float act_param, int32_t dtype, void* stream) {
     const int vec = dtype == V2V_BF16 ? 8 : 4;
     if (!raw || !scale_shift || !y || P <= 0) { set_error("bn_apply: bad argument"); return V2V_EINVAL; }
-    if (c_stride % vec != 0 || C % 4 != 0 || c_stride_raw % 4 != 0 || C > c_stride || C > c_stride_raw) {
-        set_error("bn_apply: channel counts must be multiples of 4 (C=%d stride=%d raw=%d)", C, c_stride, c_stride_raw);
+    if (c_stride % vec != 0 || c_stride_raw % 4 != 0 || C < 1 || C > c_stride || C > c_stride_raw) {
+        set_error("bn_apply: channel strides must be multiples of the vector width (C=%d stride=%d raw=%d)", C, c_stride, c_stride_raw);
         return V2V_EINVAL;
     }
     auto op = std::make_unique<BnApplyOp>();
@@ -491,7 +503,31 @@ extern "C" int v2v_bn_apply(const float* raw, int32_t c_stride_raw, const float*
     a.raw = raw; a.c_stride_raw = c_stride_raw; a.scale_shift = scale_shift;
     a.add0 = add0; a.add1 = add1; a.y = y; a.P = P; a.C = C; a.c_stride = c_stride;
     a.act = act; a.act_param = act_param;
+    a.raw1 = nullptr; a.scale_shift1 = nullptr; a.add0_1 = nullptr; a.add1_1 = nullptr; a.y1 = nullptr;
     op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_bn_apply_pair(const float* raw_a, const float* scale_shift_a, const void* add0_a, const void* add1_a, void* y_a,
+                                 const float* raw_b, const float* scale_shift_b, const void* add0_b, const void* add1_b, void* y_b,
+                                 int32_t c_stride_raw, int64_t P, int32_t C, int32_t c_stride,
+                                 int32_t act, float act_param, int32_t dtype, void* stream) {
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    if (!raw_a || !scale_shift_a || !y_a || !raw_b || !scale_shift_b || !y_b || P <= 0 || y_a == y_b) { set_error("bn_apply_pair: bad argument"); return V2V_EINVAL; }
+    if ((add0_a != nullptr) != (add0_b != nullptr) || (add1_a != nullptr) != (add1_b != nullptr)) {
+        set_error("bn_apply_pair: both members need the same set of residual operands"); return V2V_EINVAL;
+    }
+    if (c_stride % vec != 0 || c_stride_raw % 4 != 0 || C < 1 || C > c_stride || C > c_stride_raw) {
+        set_error("bn_apply_pair: channel strides must be multiples of the vector width (C=%d stride=%d raw=%d)", C, c_stride, c_stride_raw);
+        return V2V_EINVAL;
+    }
+    auto op = std::make_unique<BnApplyOp>();
+    BnApplyArgs& a = op->a;
+    a.raw = raw_a; a.c_stride_raw = c_stride_raw; a.scale_shift = scale_shift_a;
+    a.add0 = add0_a; a.add1 = add1_a; a.y = y_a; a.P = P; a.C = C; a.c_stride = c_stride;
+    a.act = act; a.act_param = act_param;
+    a.raw1 = raw_b; a.scale_shift1 = scale_shift_b; a.add0_1 = add0_b; a.add1_1 = add1_b; a.y1 = y_b;
+    op->dtype = dtype; op->members = 2;
     return submit(std::move(op), stream);
 }
 

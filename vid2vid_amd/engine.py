@@ -205,7 +205,16 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               46: (4, 64, 64), 47: (2, 64, 128), 48: (4, 64, 128),   # 40+: dedicated loader waves
               # ping-pong wave groups (csrc/conv3x3_pp_kernel.h)
               50: (4, 64, 128), 51: (4, 64, 64), 52: (2, 64, 128), 53: (8, 32, 128), 54: (8, 32, 64), 55: (4, 32, 128),
-              56: (8, 32, 64), 57: (4, 64, 64)}
+              56: (8, 32, 64), 57: (4, 64, 64),
+              # ping-pong, second schedule: LDS-DMA issued between the MFMAs; the only tiles v2v_conv2d_pair accepts
+              # (csrc/conv3x3_pp2_kernel.h)
+              70: (8, 32, 64), 71: (8, 32, 128), 72: (8, 32, 64), 73: (4, 64, 64), 74: (4, 64, 64), 75: (4, 32, 128)}
+PAIR_TILES = (70, 71, 72, 73, 74, 75)
+
+
+def is_patch_tile(t):
+    """Tile ids of the LDS-patch 3x3 kernels (weights in K order 1): patch 32-48, ping-pong 50-57, ping-pong 2 70-79."""
+    return 32 <= t < 60 or 70 <= t < 80
 FUSE_FINALIZE_MAX_PIXELS = 32768   # larger layers leave thousands of statistics rows: parallel two-stage finalize instead
 PREFETCH_DIST = 12          # K chunks (128 B of every weight row each) the helper wave runs ahead
 
@@ -237,6 +246,11 @@ class Engine:
         self._fin_counters = {}   # per plan lane: concurrent branches must not share ticket words
         self._sk_counters = {}
         self._lane = 0           # current plan lane (hipGraph branch); selects the scratch set
+        self._sset = 0           # scratch sub-set inside a lane: member 1 of a paired launch owns its own raw / stats / tickets
+        self.twin_enabled = False    # set by the frame plan: twin chains (label / image towers, image / flow branches) as paired launches
+        self.pair_override = None    # (tile, splitk) forced for every paired launch (experiments: V2V_PAIR_TILE="70,1")
+        if os.environ.get("V2V_PAIR_TILE"):
+            self.pair_override = tuple(int(v) for v in os.environ["V2V_PAIR_TILE"].split(","))
         self.lanes_enabled = False   # set by the frame plan: emit independent towers / branches on parallel lanes
         self._thrash = None
         self.plan = None        # Plan being recorded (for labels / keep-alive)
@@ -285,7 +299,7 @@ class Engine:
     def scratch(self, name, numel, dtype=torch.float32):
         """Shared scratch (conv raw output, statistics): consumed by the next launch on the
         same stream, so one buffer per kind is enough."""
-        key = (name, dtype, self._lane)
+        key = (name, dtype, self._lane, self._sset)
         t = self._scratch.get(key)
         if t is None or t.numel() < numel:
             if self.plan is not None and t is not None and not self.record_only:
@@ -309,11 +323,21 @@ class Engine:
 
     @property
     def _sk_counter(self):       # lane-0 split-K ticket words (tests check that kernels re-arm them)
-        return self._sk_counters.get(0)
+        return self._sk_counters.get((0, 0))
 
     @property
     def _fin_counter(self):
-        return self._fin_counters.get(0)
+        return self._fin_counters.get((0, 0))
+
+    @contextlib.contextmanager
+    def scratch_set(self, k):
+        """Scratch sub-set k of the current lane (raw conv output, statistics, tickets, split-K slabs): the second member
+        of a paired launch must not share them with the first."""
+        prev, self._sset = self._sset, k
+        try:
+            yield
+        finally:
+            self._sset = prev
 
     # ---------------- plan lanes (parallel hipGraph branches) ----------------
     @contextlib.contextmanager
@@ -401,7 +425,7 @@ class Engine:
         tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
         if d.tile == 0 and tune_key in self._tuned:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
-        if 32 <= d.tile < 60:
+        if is_patch_tile(d.tile):
             pc = self._use_korder1(d, mod, x.Cs)
         elif self.plan is None:
             pc.refresh()               # eager use: follow optimizer updates (only the packing this launch reads)
@@ -440,9 +464,9 @@ class Engine:
             if fin is not None:
                 norm, ss = fin
                 gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
-                fin_counter = self._fin_counters.get(self._lane)
+                fin_counter = self._fin_counters.get((self._lane, self._sset))
                 if fin_counter is None:
-                    fin_counter = self._fin_counters[self._lane] = torch.zeros(256, dtype=torch.int32, device=self.device)
+                    fin_counter = self._fin_counters[(self._lane, self._sset)] = torch.zeros(256, dtype=torch.int32, device=self.device)
                 d.fin_counter = fin_counter.data_ptr()
                 d.fin_gamma = None if gamma is None else gamma.data_ptr()
                 d.fin_beta = None if beta is None else beta.data_ptr()
@@ -462,7 +486,7 @@ class Engine:
             self._tune_wide[tune_key] = list(getattr(self, "_last_wide", []))
             self._save_tune_cache()
             d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
-            pc = self._use_korder1(d, mod, x.Cs) if 32 <= d.tile < 60 else self._use_korder0(d, mod, x.Cs)
+            pc = self._use_korder1(d, mod, x.Cs) if is_patch_tile(d.tile) else self._use_korder0(d, mod, x.Cs)
             d.bias = None if pc.bias is None else pc.bias.data_ptr()
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
@@ -480,6 +504,212 @@ class Engine:
                                   tile=lib.v2v_conv_tile_config(C.byref(d)), splitk=max(int(d.splitk), 1),
                                   prefetch=int(d.prefetch)))
         return out, rows, (N, OH, OW)
+
+    # ---------------- paired launches (twin chains) ----------------
+    def pair_eligible(self, xa, ma, xb, mb):
+        """Can two 3x3 / stride 1 / pad 1 convolutions run as ONE v2v_conv2d_pair launch?  Identical geometry, channel
+        stride a whole 128-byte chunk (the LDS-patch kernels' requirement), both behind a training-mode norm."""
+        if self._training() or not isinstance(ma, nn.Conv2d) or not isinstance(mb, nn.Conv2d):
+            return False
+        bke = 64 if self.dtype == L.BF16 else 32
+        same = (ma.in_channels == mb.in_channels and ma.out_channels == mb.out_channels and ma.kernel_size == mb.kernel_size
+                and ma.stride == mb.stride and (ma.bias is None) == (mb.bias is None)
+                and tuple(xa.t.shape) == tuple(xb.t.shape) and xa.Cs == xb.Cs and xa.C == xb.C)
+        return bool(same and ma.kernel_size == (3, 3) and ma.stride == (1, 1) and xa.Cs % bke == 0)
+
+    def _pair_desc(self, x, mod, pad_mode, pad, tile3, fin, label):
+        """Descriptor of one member of a paired launch: raw fp32 NHWC output + statistics (+ in-kernel finalize) on the
+        CURRENT scratch sub-set."""
+        pc = self._use_korder1_pc(mod, x.Cs)
+        N, H, W = x.N, x.H, x.W
+        d = ConvDesc()
+        d.in_ = x.t.data_ptr(); d.w = pc.buf.data_ptr(); d.w_korder = 1
+        d.zero_page = self.zero_page().data_ptr()
+        self._keep(self._zero_page)
+        d.bias = None if pc.bias is None else pc.bias.data_ptr()
+        d.N, d.H, d.W = N, H, W
+        d.cin, d.cin_stride, d.cout = pc.cin, x.Cs, pc.cout
+        d.KH, d.KW, d.stride, d.pad, d.pad_mode = 3, 3, 1, pad, pad_mode
+        d.transposed = 0
+        d.OH, d.OW = H, W
+        d.dtype, d.out_mode, d.act = self.dtype, L.OUT_RAW_F32_NHWC, L.ACT_NONE
+        d.act_param, d.out_scale = 0.0, 1.0
+        d.ablate = self.ablate
+        d.tile, d.splitk, d.prefetch = tile3
+        if pc.cin != x.C:
+            raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
+        cs = (pc.cout + 3) // 4 * 4
+        d.cout_stride = cs
+        raw = self.scratch("raw", N * H * W * cs)
+        d.out = raw.data_ptr()
+        d.stats = None
+        rows = lib.v2v_conv_stats_rows(C.byref(d))
+        if rows <= 0:
+            check(rows or -1, "conv_stats_rows")
+        d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()
+        finalized = fin is not None and N * H * W <= FUSE_FINALIZE_MAX_PIXELS
+        if finalized:
+            norm, ss = fin
+            gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
+            key = (self._lane, self._sset)
+            fin_counter = self._fin_counters.get(key)
+            if fin_counter is None:
+                fin_counter = self._fin_counters[key] = torch.zeros(256, dtype=torch.int32, device=self.device)
+            d.fin_counter = fin_counter.data_ptr()
+            d.fin_gamma = None if gamma is None else gamma.data_ptr()
+            d.fin_beta = None if beta is None else beta.data_ptr()
+            d.fin_scale_shift = ss.data_ptr()
+            d.fin_running_mean = None if rm is None else rm.data_ptr()
+            d.fin_running_var = None if rv is None else rv.data_ptr()
+            d.fin_eps, d.fin_momentum, d.fin_count = eps, mom, N * H * W
+            for t in (gamma, beta, ss, fin_counter):
+                if t is not None:
+                    self._keep(t)
+        if pc.bias is not None:
+            self._keep(pc.bias)
+        if not self._splitk_workspace(d):
+            raise RuntimeError("conv pair %s: split-K %d does not fit this layer" % (label, tile3[1]))
+        self._keep(pc.buf)
+        return d, raw, rows, finalized, pc
+
+    def _use_korder1_pc(self, mod, cin_stride):
+        pc = self.packed(mod, cin_stride, korder=1, refresh=False)
+        if self.plan is None:
+            pc.refresh()
+        return pc
+
+    def conv_pair(self, xa, ma, xb, mb, pad_mode, pad, fins, labels):
+        """Two convolutions of identical geometry as ONE launch (include/v2v_hip.h, v2v_conv2d_pair).  Member b works on
+        scratch sub-set 1 of the current lane.  Returns ((raw, rows, finalized), (raw, rows, finalized)), shape."""
+        N, H, W = xa.N, xa.H, xa.W
+        key = (-2, ma.in_channels, ma.out_channels, N, H, W, xa.Cs)
+        if self.pair_override is not None:
+            tile3 = (self.pair_override[0], self.pair_override[1], 0)
+        elif key in self._tuned:
+            tile3 = _cfg3(self._tuned[key])
+        elif self.autotune and self.plan is None and not self.record_only and not torch.is_grad_enabled():
+            tile3 = self._tuned[key] = self._autotune_pair(xa, ma, xb, mb, pad_mode, pad, fins, key)
+            self._save_tune_cache()
+        else:
+            tile3 = (70 if W % 64 else 73, 1, 0)
+        da, rawa, rowsa, fina, pca = self._pair_desc(xa, ma, pad_mode, pad, tile3, fins[0], labels[0])
+        with self.scratch_set(1):
+            db, rawb, rowsb, finb, pcb = self._pair_desc(xb, mb, pad_mode, pad, tile3, fins[1], labels[1])
+        check(lib.v2v_conv2d_pair(C.byref(da), C.byref(db), _stream()), "conv2d_pair " + labels[0])
+        self.label(labels[0] + " + " + labels[1])
+        for lbl, pc in ((labels[0], pca), (labels[1], pcb)):
+            self.conv_log.append(dict(label=lbl, N=N, H=H, W=W, OH=H, OW=W, cin=pc.cin, cout=pc.cout, tune_key=key,
+                                      KH=3, KW=3, stride=1, transposed=False, pair=True,
+                                      flops=2.0 * N * H * W * pc.cout * pc.cin * 9,
+                                      tile=tile3[0], splitk=max(int(tile3[1]), 1), prefetch=0))
+        return ((rawa, rowsa, fina), (rawb, rowsb, finb)), (N, H, W)
+
+    def _autotune_pair(self, xa, ma, xb, mb, pad_mode, pad, fins, key, reps=7):
+        """Measured choice of (tile, split-K) for a paired launch: every second-schedule ping-pong tile, unsplit and
+        split 2 (cold weights: a 384 MB memset between launches, as _autotune)."""
+        ncc = xa.Cs // (64 if self.dtype == L.BF16 else 32)
+        if self._thrash is None:
+            self._thrash = torch.empty(96 << 20, dtype=torch.float32, device=self.device)
+        st = _stream()
+        best, best_ms, alts = None, float("inf"), []
+        for t in PAIR_TILES:
+            th, tw, bn = PATCH_CFGS[t]
+            tiles = xa.N * -(-xa.H // th) * -(-xa.W // tw) * -(-ma.out_channels // bn)
+            for S in (1, 2):
+                if S > 1 and (ncc < 2 * S or tiles * S * 2 > 1024):
+                    continue
+                try:
+                    da = self._pair_desc(xa, ma, pad_mode, pad, (t, S, 0), fins[0], "tune")[0]
+                    with self.scratch_set(1):
+                        db = self._pair_desc(xb, mb, pad_mode, pad, (t, S, 0), fins[1], "tune")[0]
+                except RuntimeError:
+                    continue
+                if lib.v2v_conv2d_pair(C.byref(da), C.byref(db), st) != 0:
+                    continue
+                e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+                e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+                for r in range(reps):
+                    self._thrash.zero_()
+                    e0[r].record()
+                    lib.v2v_conv2d_pair(C.byref(da), C.byref(db), st)
+                    e1[r].record()
+                e1[-1].synchronize()
+                ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))[reps // 2]
+                alts.append((ms, (t, S, 0)))
+                if ms < best_ms:
+                    best, best_ms = (t, S, 0), ms
+        if best is None:
+            raise RuntimeError("no paired-launch tile fits this layer")
+        alts.sort()
+        self._tune_alts[key] = [c for _, c in alts if c != best][:5]
+        self._tune_wide[key] = []
+        self.pair_tune_log = getattr(self, "pair_tune_log", {})
+        self.pair_tune_log[key] = [(round(ms * 1e3, 1), c[0], c[1]) for ms, c in alts]
+        return best
+
+    def conv_group_pair(self, xa, conva, norma, xb, convb, normb, pad_mode, pad_override, act, act_param,
+                        adds_a=(None, None), adds_b=(None, None), labels=("", "")):
+        """Two [pad] conv + norm [+ act] [+ residuals] groups of identical geometry: ONE paired conv launch (statistics
+        finalized in-kernel) + ONE paired normalise / activate / add launch.  Returns (Act a, Act b)."""
+        cout = conva.out_channels
+        ssa = self.scratch("scale_shift", 4 * cout)
+        with self.scratch_set(1):
+            ssb = self.scratch("scale_shift", 4 * cout)
+        pad = conva.padding[0] if pad_override is None else pad_override
+        fins = ((norma, ssa), (normb, ssb)) if self.fused_finalize else (None, None)
+        (ra, rb), shp = self.conv_pair(xa, conva, xb, convb, pad_mode, pad, fins, labels)
+        N, OH, OW = shp
+        cs_raw = (cout + 3) // 4 * 4
+        for (raw, rows, fin), norm, ss, k, lbl in ((ra, norma, ssa, 0, labels[0]), (rb, normb, ssb, 1, labels[1])):
+            if not fin:                                       # large layers: parallel two-stage finalize per member
+                with self.scratch_set(k):
+                    gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
+                    st = self.scratch("stats", rows * cout * 2)
+                    for t in (gamma, beta):
+                        if t is not None:
+                            self._keep(t)
+                    groups = lib.v2v_bn_finalize_groups(rows)
+                    ws = self.scratch("bn_ws", groups * cout * 2, torch.float64) if groups > 0 else None
+                    check(lib.v2v_bn_finalize(_ptr(st), rows, cout, N * OH * OW, _ptr(gamma), _ptr(beta), eps,
+                                              _ptr(ss), _ptr(rm), _ptr(rv), mom, _ptr(ws), _stream()), "bn_finalize " + lbl)
+                    self.label(lbl + ".norm")
+        ya, yb = self.empty_act(N, OH, OW, cout), self.empty_act(N, OH, OW, cout)
+        a0, a1 = adds_a
+        b0, b1 = adds_b
+        check(lib.v2v_bn_apply_pair(_ptr(ra[0]), _ptr(ssa), _ptr(None if a0 is None else a0.t), _ptr(None if a1 is None else a1.t), _ptr(ya.t),
+                                    _ptr(rb[0]), _ptr(ssb), _ptr(None if b0 is None else b0.t), _ptr(None if b1 is None else b1.t), _ptr(yb.t),
+                                    cs_raw, N * OH * OW, cout, ya.Cs, act, act_param, self.dtype, _stream()),
+              "bn_apply_pair " + labels[0])
+        self.label(labels[0] + ".apply + " + labels[1] + ".apply")
+        return ya, yb
+
+    def run_resblocks_twin(self, blocks_a, xa, blocks_b, xb, name_a, name_b, first_index=0):
+        """Two chains of ResnetBlocks of identical shape (models/networks.py:554-593) in lock step: every convolution pair
+        is one launch that fills the chip (csrc/conv3x3_pp2_kernel.h), every normalise / residual pair one launch.
+        Falls back to two independent chains when the pair is not eligible."""
+        blocks_a, blocks_b = list(blocks_a), list(blocks_b)
+        assert len(blocks_a) == len(blocks_b)
+        for k, (ba, bb) in enumerate(zip(blocks_a, blocks_b)):
+            ma, mb = list(ba.conv_block), list(bb.conv_block)
+            def take(mods, j):
+                pad_mode, pad_override = L.PAD_ZERO, None
+                if isinstance(mods[j], nn.ReflectionPad2d):
+                    pad_mode, pad_override = L.PAD_REFLECT, int(mods[j].padding[0]); j += 1
+                return pad_mode, pad_override, mods[j], mods[j + 1], j + 2
+            pm, po, c1a, n1a, ja = take(ma, 0)
+            _, _, c1b, n1b, jb = take(mb, 0)
+            na, nb = "%s.%d" % (name_a, first_index + k), "%s.%d" % (name_b, first_index + k)
+            if not self.pair_eligible(xa, c1a, xb, c1b):
+                xa = self.run_resblock(ba, xa, None, na)
+                xb = self.run_resblock(bb, xb, None, nb)
+                continue
+            act, act_param = self._act_code(ma[ja]); ja += 1; jb += 1
+            ha, hb = self.conv_group_pair(xa, c1a, n1a, xb, c1b, n1b, pm, po, act, act_param, labels=(na + ".c1", nb + ".c1"))
+            pm, po, c2a, n2a, _ = take(ma, ja)
+            _, _, c2b, n2b, _ = take(mb, jb)
+            xa, xb = self.conv_group_pair(ha, c2a, n2a, hb, c2b, n2b, pm, po, L.ACT_NONE, 0.0,
+                                          adds_a=(xa, None), adds_b=(xb, None), labels=(na + ".c2", nb + ".c2"))
+        return xa, xb
 
     def tune_backward_data(self, d, dx_channels):
         """Tile selection for a backward-data launch (autograd._conv_backward_data): same measured search as the
@@ -547,11 +777,11 @@ class Engine:
         nbytes = lib.v2v_conv_splitk_workspace(C.byref(d), C.byref(tickets))
         if nbytes <= 0:
             return False
-        skc = self._sk_counters.get(self._lane)
+        skc = self._sk_counters.get((self._lane, self._sset))
         if skc is None or skc.numel() < tickets.value:
             if self.plan is not None and not self.record_only:
                 raise RuntimeError("split-K ticket buffer must not grow while a plan is recording")
-            skc = self._sk_counters[self._lane] = torch.zeros(max(4096, tickets.value), dtype=torch.int32, device=self.device)
+            skc = self._sk_counters[(self._lane, self._sset)] = torch.zeros(max(4096, tickets.value), dtype=torch.int32, device=self.device)
         d.slabs = self.scratch("slabs", (nbytes + 3) // 4).data_ptr()
         d.sk_counter = skc.data_ptr()
         self._keep(skc)
@@ -600,7 +830,7 @@ class Engine:
         def time_cfg(t, S, pf, reps):
             d.tile, d.splitk, d.prefetch = t, S, pf
             if mod is not None:
-                (self._use_korder1 if 32 <= t < 60 else self._use_korder0)(d, mod, cin_stride)
+                (self._use_korder1 if is_patch_tile(t) else self._use_korder0)(d, mod, cin_stride)
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 if rows <= 0:
@@ -641,12 +871,13 @@ class Engine:
         unsplit = [cfg for _, cfg in timed if cfg[1] <= 1]
         alts = ([cfg for _, cfg in timed[:3]] + unsplit[:3]
                 + [cfg for _, cfg in timed if cfg[0] == best[0] and cfg[1] <= 2]          # the winner's tile, less split
-                + [cfg for cfg in unsplit if 50 <= cfg[0] < 60][:1])                        # the best unsplit ping-pong tile
+                + [cfg for cfg in unsplit if 50 <= cfg[0] < 60 or cfg[0] >= 70][:1])         # the best unsplit ping-pong tile
         self._last_alts = [c for i, c in enumerate(alts) if c != best and c not in alts[:i]][:7]
         # for the heaviest shapes of a frame the whole-frame search also walks every lightly split configuration that was
         # not hopeless in isolation
-        self._last_wide = ([cfg for ms, cfg in timed if 50 <= cfg[0] < 60 and cfg[1] <= 2 and cfg != best]      # every ping-pong tile
-                           + [cfg for ms, cfg in timed if not 50 <= cfg[0] < 60 and cfg[1] <= 2 and ms <= 1.7 * timed[0][0]
+        pp_ = lambda t: 50 <= t < 60 or t >= 70
+        self._last_wide = ([cfg for ms, cfg in timed if pp_(cfg[0]) and cfg[1] <= 2 and cfg != best]      # every ping-pong tile
+                           + [cfg for ms, cfg in timed if not pp_(cfg[0]) and cfg[1] <= 2 and ms <= 1.7 * timed[0][0]
                               and cfg != best][:10])
         return best
 
@@ -659,6 +890,8 @@ class Engine:
             eps, mom = norm.eps, (norm.momentum if norm.momentum is not None else 0.1)
             rm = norm.running_mean if (self.update_running_stats and norm.track_running_stats) else None
             rv = norm.running_var if (self.update_running_stats and norm.track_running_stats) else None
+            if rm is not None and self.plan is None:
+                norm._v2v_batches = getattr(norm, "_v2v_batches", 0) + 1     # -> num_batches_tracked at save time
             return gamma, beta, eps, mom, rm, rv
         if isinstance(norm, nn.InstanceNorm2d):
             if N != 1:

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "v2v_conv_tile_config": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_splitk_workspace": (_L, [C.POINTER(ConvDesc), C.POINTER(_I)]),
     "v2v_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
+    "v2v_conv2d_pair": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _P]),
     "v2v_conv_wgrad_workspace": (_L, [C.POINTER(WgradDesc)]),
     "v2v_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P]),
     "v2v_bn_backward_rows": (C.c_int, [_L]),
@@ -88,6 +89,7 @@ PROTOTYPES = {
     "v2v_bn_finalize": (C.c_int, [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P, _F, _P, _P]),
     "v2v_bn_finalize_groups": (C.c_int, [_I]),
     "v2v_bn_apply": (C.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
+    "v2v_bn_apply_pair": (C.c_int, [_P] * 10 + [_I, _L, _I, _I, _I, _F, _I, _P]),
     "v2v_avgpool3s2_planar": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "v2v_avgpool3s2_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "v2v_maxpool2_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -35,13 +35,22 @@ class BaseModel(torch.nn.Module):
             prec = "bf16" if getattr(opt, "fp16", False) else networks.get_precision()
         self.precision = prec
         networks.set_precision(prec)
+        if self.isTrain:
+            # the reference's norms run in training mode everywhere and update running_mean / running_var /
+            # num_batches_tracked on every forward (networks.py:23-30); a checkpoint saved here must carry the same buffers
+            self.engine.update_running_stats = True
 
     def Tensor(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
     @property
     def engine(self):
-        return get_engine(self.device)
+        # the model's OWN precision, not the process-wide default: an fp32 and a bf16 model may coexist
+        return get_engine(self.device, networks._PREC_CODE[self.precision])
+
+    def bind_precision(self):
+        """Call at the end of initialize(): pins every network this model owns to the model's precision."""
+        networks.bind_precision(self, self.precision)
 
     # ---------------- checkpoints: '<epoch>_net_<label>.pth' ----------------
     def _ckpt_path(self, label, epoch, save_dir=""):
@@ -49,6 +58,11 @@ class BaseModel(torch.nn.Module):
 
     def save_network(self, network, network_label, epoch_label, gpu_ids=None):
         os.makedirs(self.save_dir, exist_ok=True)
+        for m in network.modules():            # forwards counted on the host (engine._norm_params), written at save time
+            nb = getattr(m, "_v2v_batches", 0)
+            if nb and getattr(m, "num_batches_tracked", None) is not None:
+                m.num_batches_tracked.add_(nb)
+                m._v2v_batches = 0
         state = {k: v.detach().cpu() for k, v in network.state_dict().items()}
         torch.save(state, self._ckpt_path(network_label, epoch_label))
 
@@ -104,6 +118,8 @@ class BaseModel(torch.nn.Module):
             t = pyr[-1].contiguous().float()
             if nearest:
                 pyr.append(t[..., ::2, ::2].contiguous())
+            elif self.engine.record_only:          # CPU dry run (plan recording only): shapes, no values
+                pyr.append(t.new_zeros(*t.shape[:-2], (t.shape[-2] - 1) // 2 + 1, (t.shape[-1] - 1) // 2 + 1))
             else:
                 pyr.append(self.engine.avgpool_planar(t))
         return pyr
@@ -134,8 +150,12 @@ class BaseModel(torch.nn.Module):
         params = []
         for s in range(self.n_scales):
             params += list(getattr(self, "netG" + str(s)).parameters())
-        from ..optim import FusedAdam
-        self.optimizer_G = FusedAdam(params, lr=self.old_lr, betas=(self.opt.beta1, 0.999))
+        # The reference builds a NEW torch.optim.Adam here (base_model.py:162-168) while train.py keeps stepping the
+        # optimizer it captured at start-up (train.py:29), so its coarse scales receive gradients that nobody applies.
+        # Here the captured optimizer object is rebuilt IN PLACE over all scales (fresh moments, same lr / betas as the
+        # reference's new Adam): whoever holds a reference to it -- train.py, parallel.GradSync -- now trains every scale,
+        # and no second flat buffer ever aliases live parameters.
+        self.optimizer_G.rebuild(params, lr=self.old_lr, betas=(self.opt.beta1, 0.999))
         self.finetune_all = True
         print("------------ Now finetuning all scales -----------")
 

@@ -90,6 +90,7 @@ class FlowNet(BaseModel):
             p.requires_grad_(False)
         self._plans = {}
         self.flops_launched, self.convs_launched = 0.0, 0
+        self.bind_precision()
 
     def forward(self, input_A, input_B, dummy_bs=0):
         with torch.no_grad():

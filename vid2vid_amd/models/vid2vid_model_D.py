@@ -66,6 +66,7 @@ class Vid2VidModelD(BaseModel):
         for s in range(opt.n_scales_temporal):
             params = list(getattr(self, "netD_T" + str(s)).parameters())
             setattr(self, "optimizer_D_T" + str(s), FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999)))
+        self.bind_precision()
 
     # ------------------------------------------------------------------ losses
     def _zero(self):

@@ -75,11 +75,15 @@ class _FramePlan:
         self.out = {}
         # independent towers / branches on parallel plan lanes (parallel hipGraph paths); opt.lanes or V2V_LANES
         self.lanes = bool(int(getattr(opt, "lanes", os.environ.get("V2V_LANES", "1")))) and use_graph
+        # twin chains (label / image towers, image / flow branches) as paired launches; opt.twin or V2V_TWIN
+        self.twin = bool(int(getattr(opt, "twin", os.environ.get("V2V_TWIN", "1"))))
         eng.lanes_enabled = self.lanes
+        eng.twin_enabled = self.twin
         try:
             self._build(model, opt, eng, use_graph)
         finally:
             eng.lanes_enabled = False
+            eng.twin_enabled = False
 
     def _build(self, model, opt, eng, use_graph):
         dev = eng.device
@@ -156,7 +160,9 @@ class _FramePlan:
             trials += 1
             if ms < best_ms * (1.0 - min_gain):
                 best_ms, kept = ms, kept + 1
-                swaps.append("%dx%d k%d s%d @%dx%d: %s -> %s" % (k[0], k[1], k[2], k[3], k[7], k[6], tuple(prev), tuple(cand)))
+                what = ("pair %dx%d k3 s1 @%dx%d" % (k[1], k[2], k[5], k[4])) if k[0] == -2 else \
+                       ("%dx%d k%d s%d @%dx%d" % (k[0], k[1], k[2], k[3], k[7], k[6]))
+                swaps.append("%s: %s -> %s" % (what, tuple(prev), tuple(cand)))
             else:
                 eng._tuned[k] = prev
 
@@ -294,6 +300,7 @@ class Vid2VidModelG(BaseModel):
             else:
                 beta1, beta2, lr = opt.beta1, 0.999, opt.lr
             self.optimizer_G = FusedAdam(params, lr=lr, betas=(beta1, beta2))
+        self.bind_precision()
 
     # ------------------------------------------------------------------ inference
     def _frame_plan(self, H, W, in_ch, has_inst, use_raw_only):
@@ -336,7 +343,9 @@ class Vid2VidModelG(BaseModel):
             self._active_plan = fp
             self.fake_B_prev = fp.prev
             fp.run()
-            return fp.out["fake_B"], fp.out["real_A_last"]
+            # fresh tensors per frame, as the reference returns them (the plan's output buffers are overwritten by the
+            # next replay; a caller collecting a clip must not see every entry alias the last frame)
+            return fp.out["fake_B"].clone(), fp.out["real_A_last"].clone()
 
     def generate_first_frame(self, input_A, input_B, inst_A=None):
         """Pyramid of the tG-1 frames that precede the first generated one (reference :231-251)."""

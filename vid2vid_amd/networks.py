@@ -69,6 +69,23 @@ def get_engine(device=None, precision=None):
     return _ENGINES[key]
 
 
+_PREC_CODE = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16}
+
+
+def bind_precision(root, precision):
+    """Pin every sub-module of `root` (a model or a network) to ONE precision, so that two models of different
+    precision can live in one process (bench.py checks the bf16 model against an fp32 model and the oracle):
+    `module_engine` then resolves the engine from the module instead of the process-wide default."""
+    code = _PREC_CODE[precision] if isinstance(precision, str) else precision
+    for m in root.modules():
+        m._v2v_precision = code
+
+
+def module_engine(mod, device):
+    """Engine of (device, the precision `mod` was bound to | the process-wide default)."""
+    return get_engine(device, getattr(mod, "_v2v_precision", None))
+
+
 # --------------------------------------------------------------------------------------
 # init / factories  (models/networks.py:15-68)
 # --------------------------------------------------------------------------------------
@@ -177,7 +194,7 @@ class ResnetBlock(nn.Module):
         self.conv_block = nn.Sequential(*blk)
 
     def forward(self, x):
-        eng = get_engine(x.device)
+        eng = module_engine(self, x.device)
         a = eng.pack(x.contiguous().float())
         return eng.unpack(eng.run_resblock(self, a, None, "resblock"))
 
@@ -185,7 +202,7 @@ class ResnetBlock(nn.Module):
 class BaseNetwork(nn.Module):
     def _engine(self, ref):
         dev = ref.t.device if isinstance(ref, Act) else ref.device
-        return get_engine(dev)
+        return module_engine(self, dev)
 
     @staticmethod
     def _as_act(eng, x):
@@ -195,7 +212,7 @@ class BaseNetwork(nn.Module):
 
     def resample(self, image, flow):
         """BaseNetwork.resample (models/networks.py:108-115) on planar fp32 tensors."""
-        eng = get_engine(image.device)
+        eng = module_engine(self, image.device)
         return eng.resample_flow(image.contiguous().float(), flow.contiguous().float())
 
     def _tail(self, eng, img_raw, flow, weight, img_prev_nchw, img_fg, mask, use_raw_only):
@@ -305,7 +322,29 @@ class CompositeGenerator(BaseNetwork):
             weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
             return flow, weight, flow_feat
 
-        if lanes:
+        twin = eng.twin_enabled and not eng._training()
+        res_flow_done = None
+        if twin:
+            # twin chains as paired launches (engine.run_resblocks_twin): the towers' stems / down-convs stay on their own
+            # lanes, their ResnetBlock chains (identical shapes, different weights) advance in lock step on lane 0, and so do
+            # model_res_img / model_res_flow, which both start from the tower sum
+            def split(seq):
+                mods = list(seq)
+                k = next((i for i, m in enumerate(mods) if hasattr(m, "conv_block")), len(mods))
+                return mods[:k], mods[k:]
+            head_seg, blocks_seg = split(self.model_down_seg)
+            head_img, blocks_img = split(self.model_down_img)
+            with eng.on_lane(1):
+                seg = eng.run_sequential(head_seg, x, name=tag + ".down_seg")
+            if self.use_fg_model and lanes:
+                with eng.on_lane(2):
+                    img_fg_feat, img_fg = fg_tower()
+            img = eng.run_sequential(head_img, prev, name=tag + ".down_img")
+            eng.join(1)
+            seg, img = eng.run_resblocks_twin(blocks_seg, seg, blocks_img, img, tag + ".down_seg", tag + ".down_img",
+                                              first_index=len(head_seg))
+            down = eng.add(img, seg)
+        elif lanes:
             with eng.on_lane(1):
                 seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
             if self.use_fg_model:
@@ -318,18 +357,35 @@ class CompositeGenerator(BaseNetwork):
             seg = eng.run_sequential(self.model_down_seg, x, name=tag + ".down_seg")
             down = eng.run_sequential(self.model_down_img, prev, extra_add=seg, name=tag + ".down_img")
         flow = weight = flow_feat = None
-        if lanes and not self.no_flow:
+        res_img_out = None
+        if twin and not self.no_flow:
+            res_img_out, res_flow_done = eng.run_resblocks_twin(self.model_res_img, down, self.model_res_flow, down,
+                                                                tag + ".res_img", tag + ".res_flow")
+
+        def flow_tail(res_flow):
+            flow_feat = eng.run_sequential(self.model_up_flow, res_flow, name=tag + ".up_flow")
+            flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
+                                      out_scale=self.flow_multiplier(), name=tag + ".final_flow")
+            weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
+            return flow, weight, flow_feat
+
+        if res_flow_done is not None:
+            with eng.on_lane(1):
+                flow, weight, flow_feat = flow_tail(res_flow_done)
+        elif lanes and not self.no_flow:
             with eng.on_lane(1):
                 flow, weight, flow_feat = flow_branch(down)
-        img_feat = eng.run_sequential(self.model_up_img,
-                                      eng.run_sequential(self.model_res_img, down, name=tag + ".res_img"),
-                                      name=tag + ".up_img")
+        if res_img_out is None:
+            res_img_out = eng.run_sequential(self.model_res_img, down, name=tag + ".res_img")
+        img_feat = eng.run_sequential(self.model_up_img, res_img_out, name=tag + ".up_img")
         img_raw = eng.run_sequential(self.model_final_img, img_feat, head_nchw=True, name=tag + ".final_img")
-        if not lanes and not self.no_flow:
-            flow, weight, flow_feat = flow_branch(down)
-        if not lanes and self.use_fg_model:
+        if twin and self.use_fg_model and not lanes:
             img_fg_feat, img_fg = fg_tower()
-        if lanes:
+        if not lanes and not self.no_flow and flow is None:
+            flow, weight, flow_feat = flow_branch(down)
+        if not lanes and self.use_fg_model and img_fg is None:
+            img_fg_feat, img_fg = fg_tower()
+        if lanes or twin:
             eng.join(1)
             if self.use_fg_model:
                 eng.join(2)
@@ -340,7 +396,7 @@ class CompositeGenerator(BaseNetwork):
         """Same signature / return tuple as the reference (models/networks.py:203-232).  `input`,
         `img_prev`, `mask` are NCHW fp32 device tensors; feature maps are returned as NHWC `Act`
         handles (they only ever feed the next scale's forward)."""
-        eng = get_engine(input.device)
+        eng = module_engine(self, input.device)
         img_prev = img_prev.contiguous().float()
         return self.emit(eng, self._as_act(eng, input), eng.pack(img_prev), img_prev, mask,
                          img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only)
@@ -446,7 +502,7 @@ class CompositeLocalGenerator(BaseNetwork):
         return img_final, flow, weight, img_raw, img_feat, flow_feat, img_fg_feat
 
     def forward(self, input, img_prev, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only):
-        eng = get_engine(input.device)
+        eng = module_engine(self, input.device)
         img_prev = img_prev.contiguous().float()
         return self.emit(eng, self._as_act(eng, input), eng.pack(img_prev), img_prev, mask,
                          img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse, use_raw_only)
@@ -480,7 +536,7 @@ class GlobalGenerator(nn.Module):
     def forward(self, input, feat=None):
         if feat is not None:
             input = torch.cat([input, feat], dim=1)
-        eng = get_engine(input.device)
+        eng = module_engine(self, input.device)
         return self.emit(eng, eng.pack(input.contiguous().float()))
 
 
@@ -508,7 +564,7 @@ class LocalEnhancer(nn.Module):
     def forward(self, input, feat_map=None):
         if feat_map is not None:
             input = torch.cat([input, feat_map], dim=1)
-        eng = get_engine(input.device)
+        eng = module_engine(self, input.device)
         return self.emit(eng, eng.pack(input.contiguous().float()))
 
     def emit(self, eng, x):
@@ -568,7 +624,7 @@ class Global_with_z(nn.Module):
         return eng.run_sequential(self.model_upsample_conv, eng.concat(h, z), head_nchw=True, name=tag + ".head")
 
     def forward(self, x, z):
-        eng = get_engine(x.device)
+        eng = module_engine(self, x.device)
         with torch.no_grad():
             return self.emit(eng, eng.pack(x.contiguous().float()), eng.pack(z.contiguous().float()))
 
@@ -622,7 +678,7 @@ class Local_with_z(nn.Module):
         return eng.run_sequential(self.model_final, eng.concat(out, z), head_nchw=True, name=tag + ".final")
 
     def forward(self, x, z):
-        eng = get_engine(x.device)
+        eng = module_engine(self, x.device)
         with torch.no_grad():
             return self.emit(eng, eng.pack(x.contiguous().float()), eng.pack(z.contiguous().float()))
 
@@ -644,7 +700,7 @@ class Encoder(nn.Module):
 
     def forward(self, input, inst):
         """(N, output_nc, H, W) feature map, constant over every instance of `inst` (N, 1, H, W)."""
-        eng = get_engine(input.device)
+        eng = module_engine(self, input.device)
         with torch.no_grad():
             feat = eng.run_sequential(self.model, eng.pack(input.contiguous().float()), head_nchw=True, name="E")
             return eng.instance_mean(feat, inst.to(feat.device))
@@ -721,7 +777,7 @@ class MultiscaleDiscriminator(nn.Module):
 
     def forward(self, input):
         """NCHW fp32 in; list[num_D] of list of NCHW fp32 feature maps out (reference layout)."""
-        eng = get_engine(input.device)
+        eng = module_engine(self, input.device)
         res = self.emit(eng, eng.pack(input.contiguous().float()))
         return [[eng.unpack(f) for f in feats] for feats in res]
 
@@ -800,7 +856,7 @@ class Vgg19(nn.Module):
         return outs
 
     def forward(self, X):
-        eng = get_engine(X.device)
+        eng = module_engine(self, X.device)
         return [eng.unpack(f) for f in self.emit(eng, eng.pack(X.contiguous().float()))]
 
 
@@ -830,13 +886,13 @@ class VGGLoss(nn.Module):
     def features(self, x):
         """VGG features of a target image batch (no gradient): computed once per frame and shared by the
         fake_B and fake_B_raw terms (vid2vid_model_D.py:136,144 evaluate vgg(real_B) twice)."""
-        eng = get_engine(x.device)
+        eng = module_engine(self, x.device)
         with torch.no_grad():
             return self.vgg.emit(eng, eng.pack(self._prep(eng, x)), tag="vgg.y")
 
     def forward(self, x, y, y_feats=None):
         from . import autograd as AG
-        eng = get_engine(x.device)
+        eng = module_engine(self, x.device)
         if y_feats is None:
             y_feats = self.features(y)
         x_feats = self.vgg.emit(eng, eng.pack(self._prep(eng, x)), tag="vgg.x")

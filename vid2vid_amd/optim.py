@@ -67,6 +67,24 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.grad_sync = grad_sync          # parallel.GradSync or None (single process)
 
+    def rebuild(self, params, lr=None, betas=None):
+        """Re-home a (larger) parameter list in fresh flat buffers IN PLACE: same optimizer object, same grad_sync,
+        zeroed moments and step count (what constructing a new Adam would give).  Parameters that lived in the old
+        flat buffer are copied over by FlatBuffers (their .data views move to the new one), so the old buffer is simply
+        dropped -- nothing keeps stepping memory that no parameter views (update_fixed_params)."""
+        params = [p for p in params]
+        grp = self.param_groups[0]
+        grp["params"] = params
+        if lr is not None:
+            grp["lr"] = lr
+        if betas is not None:
+            grp["betas"] = tuple(betas)
+        self.flat = FlatBuffers(params)
+        self.exp_avg = torch.zeros_like(self.flat.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
+        self.step_count = 0
+        self.state.clear()
+
     # ---- checkpointing (an extension: the reference never saves optimizer state, SURVEY 8f rank 4) ----
     def state_dict(self):
         """Flat moments + step count + hyper-parameters.  The layout is the parameter order of this optimizer
