@@ -413,6 +413,13 @@ int       v2v_plan_lane_wait(int32_t waiter, int32_t signal);
 /* recordable device-to-device copy (rolling fake_B_prev window, vid2vid_model_G.py:228) */
 int v2v_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);
 
+/* Dry run (process-wide switch, returns the previous setting): every entry point still validates its arguments and
+ * plans still record, but NOTHING is launched -- v2v_* launch calls outside a recording and v2v_plan_run return 0
+ * immediately.  For CPU hosts without a GPU: the test-suite drives the reference's own train.py / test.py control flow
+ * through the model API this way.  Not a compute path: outputs are never written. */
+int         v2v_set_dry_run(int32_t on);
+int         v2v_get_dry_run(void);
+
 /* library / device info */
 int         v2v_version(void);
 const char* v2v_last_error(void);

@@ -47,3 +47,24 @@ if has twinbench; then
   done
   lap twinbench
 fi
+if has ablate; then
+  timeout 300 python scripts/pp2_ablate.py > gpurun_out/${TAG}_pp2_ablate.txt 2>&1; echo "pp2 ablate rc=$?"
+  cat gpurun_out/${TAG}_pp2_ablate.txt | cut -c1-160
+  lap ablate
+fi
+if has pairtest; then
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "conv2d_pair" > gpurun_out/${TAG}_pairtest.log 2>&1; echo "pair test rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_pairtest.log | cut -c1-300 | tail -20
+  lap pairtest
+fi
+if has benchnew; then
+  rm -f gpurun_out/${TAG}_tune.json
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune.json timeout 900 python bench.py --steps 30 --warmup 5 --retune --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
+  cut -c1-3000 gpurun_out/${TAG}_bench.json; tail -5 gpurun_out/${TAG}_bench.err
+  lap benchnew
+fi
+if has allkernels; then
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short --timeout 300 > gpurun_out/${TAG}_allkernels.log 2>&1; echo "kernel tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|Error" gpurun_out/${TAG}_allkernels.log | cut -c1-300 | tail -30
+  lap allkernels
+fi

@@ -78,12 +78,82 @@ def simulate(GP, LB, DB, ncc, new, NPT=None, verbose=False):
                     errors.append("WAR: group %d issues %s at phase %d, %s last read at phase %d" % (grp, item, ph, old, last_read[old]))
     return errors
 
+if __name__ != "__main__" or len(sys.argv) > 1:
+    _RUN_PP = False
+else:
+    _RUN_PP = True
 ok = True
-for new in (False, True):
+for new in ((False, True) if _RUN_PP else ()):
     for DB in (2, 3):
         for GP in (3, 5, 6, 9):
             for LB in (1, 2):
                 e = simulate(GP, LB, DB, 3, new)
                 print("new=%d DB=%d GP=%d LB=%d: %s" % (new, DB, GP, LB, "OK" if not e else "%d errors, e.g. %s" % (len(e), e[0])))
                 ok &= not e
-sys.exit(0 if ok else 1)
+if _RUN_PP:
+    sys.exit(0 if ok else 1)
+
+
+def simulate_pp3(GP, LB, D, ncc, wait_fn=None):
+    """Single-phase schedule of conv3x3_pp3_kernel: every wave runs  B_j | MFMA(j) || ds_read(j+1) || DMA issue W(j+D), P |
+    vmcnt wait  per iteration j, ONE barrier per step, weight ring of D stages (slice j+D refills the stage of slice j)."""
+    NPT = 9 - D
+    PPT = (GP + NPT - 1) // NPT
+    nsteps = ncc * 9
+    def npieces(tap):
+        if tap >= NPT: return 0
+        return cmin((tap + 1) * PPT, GP) - cmin(tap * PPT, GP)
+    assert sum(npieces(t) for t in range(9)) == GP
+    def pending(tap):
+        return (D - 2) * LB + sum(npieces((tap - u + 18) % 9) for u in range(0, D - 1))
+    if wait_fn is None:
+        wait_fn = pending
+    errors, outstanding, cnt = [], [], {}
+    landed, issued, last_read = {}, {}, {}
+    def issue(item, n, phase):
+        for _ in range(n):
+            k = cnt.get(item, 0); cnt[item] = k + 1
+            outstanding.append((item, k))
+            issued.setdefault(item, []).append(phase)
+    def wait(N, phase):
+        while len(outstanding) > N:
+            it, k = outstanding.pop(0)
+            landed[(it, k)] = phase
+    def read(item, n, phase):
+        for k in range(n):
+            lp = landed.get((item, k))
+            if lp is None or lp >= phase:
+                errors.append("RAW: %s piece %d read at phase %s, landed %s" % (item, k, phase, lp))
+        last_read[item] = phase
+    issue(('P', 0), GP, -1)
+    for t in range(D): issue(('W', t), LB, -1)
+    wait((D - 1) * LB, -1)
+    read(('W', 0), LB, -0.5); read(('P', 0), GP, -0.5)
+    wait((D - 2) * LB, -0.5)
+    for j in range(nsteps):
+        tap, c = j % 9, j // 9
+        for item, old in ((('W', j + D), ('W', j)),):
+            if old in last_read and last_read[old] >= j:
+                errors.append("WAR: %s issued at phase %d, %s last read at %s" % (item, j, old, last_read[old]))
+        issue(('W', j + D), LB, j)
+        if tap < NPT and npieces(tap):
+            old = ('P', c - 1)
+            if old in last_read and last_read[old] >= j:
+                errors.append("WAR: patch %d issued at phase %d, %s last read at %s" % (c + 1, j, old, last_read[old]))
+            issue(('P', c + 1), npieces(tap), j)
+        if j + 1 < nsteps:
+            read(('W', j + 1), LB, j)
+            read(('P', (j + 1) // 9), GP, j)
+        wait(wait_fn(tap), j)
+    return errors
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pp3":
+    ok = True
+    for D in (3, 4, 5):
+        for GP in (3, 5, 6, 7, 9):
+            for LB in (1, 2):
+                e = simulate_pp3(GP, LB, D, 3)
+                print("pp3 D=%d GP=%d LB=%d: %s" % (D, GP, LB, "OK" if not e else "%d errors, e.g. %s" % (len(e), e[0])))
+                ok &= not e
+    sys.exit(0 if ok else 1)

@@ -147,3 +147,53 @@ def test_shared_tuning_cache_world2(tmp_path):
     if os.path.exists(stale):
         os.remove(stale)
     assert res == [(0, "ok"), (1, "ok")]
+
+
+def test_update_fixed_params_rebuilds_the_captured_optimizer_in_place():
+    """train.py captures optimizer_G once (train.py:29); update_fixed_params (base_model.py:162-168) must
+    not leave that object stepping a flat buffer no parameter views.  After the call the SAME optimizer object owns every
+    scale: each parameter's storage and gradient live inside its (new) flat buffers, values are preserved, moments are
+    fresh, and the gradient synchroniser attached by parallel.sync_optimizers is still attached."""
+    import torch
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models.vid2vid_model_G import Vid2VidModelG
+    if torch.cuda.is_available():
+        pytest.skip("record-only construction is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        opt = make_opt(isTrain=True, label_nc=35, use_instance=True, fg=True, ngf=8, n_blocks=2, n_blocks_local=1,
+                       n_scales_spatial=2, n_downsample_G=2, loadSize=64, niter_fix_global=3, no_vgg=True, random_init_ok=True,
+                       precision="fp32", gpu_ids=[], n_gpus_gen=1)
+        G = Vid2VidModelG(); G.initialize(opt)
+        captured = G.optimizer_G                         # what create_optimizer() hands to train.py
+        marker = object()
+        captured.grad_sync = marker
+        n_fine = sum(p.numel() for p in G.netG1.parameters())
+        assert not G.finetune_all and sum(p.numel() for p in captured.flat.params) == n_fine
+        def snapshot():
+            return {"%d.%s" % (i, k): v.detach().clone() for i, net in enumerate((G.netG0, G.netG1)) for k, v in net.state_dict().items()}
+        before = snapshot()
+        old_flat = captured.flat.flat_param
+        captured.exp_avg.fill_(1.0); captured.step_count = 7
+        G.update_fixed_params()
+        assert G.optimizer_G is captured and G.finetune_all and captured.grad_sync is marker
+        flat, fgrad = captured.flat.flat_param, captured.flat.flat_grad
+        assert flat.data_ptr() != old_flat.data_ptr()
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        glo, ghi = fgrad.data_ptr(), fgrad.data_ptr() + fgrad.numel() * 4
+        params = list(G.netG0.parameters()) + list(G.netG1.parameters())
+        assert len(captured.flat.params) == len(params)
+        for p in params:
+            assert lo <= p.data_ptr() < hi and glo <= p.grad.data_ptr() < ghi
+        after = snapshot()
+        for k, v in before.items():
+            assert torch.equal(after[k], v), k
+        assert captured.step_count == 0 and float(captured.exp_avg.abs().sum()) == 0.0
+        assert captured.param_groups[0]["lr"] == G.old_lr and captured.param_groups[0]["betas"] == (opt.beta1, 0.999)
+        # a write through the captured optimizer's flat buffer IS a write to the coarse-scale parameters
+        flat.add_(1.0)
+        assert torch.allclose(next(G.netG0.parameters()), before["0." + next(iter(G.netG0.state_dict()))] + 1.0)
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()

@@ -259,6 +259,7 @@ def test_conv3x3_patch_kernel(case, prec):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(128, 72, 24, 64, "reflect", 1), (192, 200, 19, 45, "reflect", 2), (256, 64, 32, 64, "zero", 1)])
+@torch.no_grad()
 def test_conv2d_pair_equals_two_launches(case, prec):
     """v2v_conv2d_pair / v2v_bn_apply_pair (paired launches of the twin chains): two convolutions of the same geometry
     with different inputs and weights as ONE launch -- raw outputs, per-tile statistics, the in-kernel norm finalize and

@@ -66,9 +66,14 @@ constexpr int pending_at(int tap, int GP, int LB, int DB) {
 }
 }  // namespace pp2
 
-template <typename T, int TH, int TW, int BN, int NSB>
+// ABL = 1: ablation instance (tile id 79 only; v2v_conv_desc.ablate, results are WRONG when a bit is set):
+//   1 activation tiles from the zero page, 2 weight tiles from one hot line, 4 no output stores, 16 loaders only,
+//   32 no fragment ds_reads, 64 no MFMAs, 128 no LDS-DMA in the main loop, 256 no vmcnt wait in the main loop.
+// ABL = 0 (production tiles): the ablation word is ignored and every test on it folds away.
+template <typename T, int TH, int TW, int BN, int NSB, int ABL = 0>
 __global__ __launch_bounds__(512) void conv3x3_pp2_kernel(const ConvKArgs p_in) {
     const ConvKArgs p = select_group(p_in);
+    const int ab = ABL ? p.ablate : 0;
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PR = (TH + 2) * PW;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp2_kernel(const ConvKArgs p_in) 
     }
     auto issue_patch = [&](int k, int cc_local, char* buf) {
         const int cg = cc_local < ncc ? cc_local : ncc - 1;    // tail: a harmless reload keeps the DMA counts uniform
-        const char* src = (((pok >> k) & 1u) && !(p.ablate & 1)) ? p.in + pp[k] + (ccb + cg) * 128 : zp;
+        const char* src = (((pok >> k) & 1u) && !(ab & 1)) ? p.in + pp[k] + (ccb + cg) * 128 : zp;
         glds16(src, buf + (k * NW + wid) * 1024);
     };
 
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp2_kernel(const ConvKArgs p_in) 
     }
     auto issue_w_piece = [&](int i, int step, int stage) {
         const int sg = step < nsteps ? step : nsteps - 1;      // tail duplicate into a free stage
-        glds16(wp[i] + ((p.ablate & 2) ? 0ll : (long long)sg * 128), bring + stage * BST + wid * 1024 + i * NW * 1024);
+        glds16(wp[i] + ((ab & 2) ? 0ll : (long long)sg * 128), bring + stage * BST + wid * 1024 + i * NW * 1024);
     };
 
     // ---------------- fragment addressing ----------------
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp2_kernel(const ConvKArgs p_in) 
     // patch) landed
     auto load_phase = [&](auto tc) {
         constexpr int tap = decltype(tc)::value;
-        if (!(p.ablate & 16)) {
+        if (!(ab & (16 | 32))) {
             const char* const pb = bring + stage * BST + b_row_off;
             constexpr int tq = (tap / 3) * PW + (tap % 3);
 #pragma unroll
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp2_kernel(const ConvKArgs p_in) 
                 for (int j = 0; j < TN; ++j)
                     fb[s][j] = *reinterpret_cast<const Frag*>(pb + j * 32 * 128 + foff[s]);
         }
-        wait_vmcnt<pp2::pending_at(tap, GP, LB, DB)>();
+        if (!(ab & 256)) wait_vmcnt<pp2::pending_at(tap, GP, LB, DB)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers: the stage may be refilled
         stage = stage + 1 == NSB ? 0 : stage + 1;
         if constexpr (tap == 8) {
@@ -243,11 +248,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp2_kernel(const ConvKArgs p_in) 
         char* const pnext = smem + ((mcc + 1) & 1) * PATCH;
         auto dma = [&](auto dc) {
             constexpr int d = decltype(dc)::value;
+            if (ab & 128) return;
             if constexpr (d < LB) issue_w_piece(d, mstep + DB, mwstage);
             else                  issue_patch(k0 + d - LB, mcc + 1, pnext);
         };
         constexpr int IN_GAPS = pp2::cmin(NDMA, (NMMA - 1) / GAP);     // pieces that find a gap between two MFMAs
-        if (p.ablate & 16) {
+        if (ab & (16 | 64)) {
             static_for<NDMA>(dma);
         } else {
             __builtin_amdgcn_s_setprio(1);
@@ -307,18 +313,18 @@ __global__ __launch_bounds__(512) void conv3x3_pp2_kernel(const ConvKArgs p_in) 
     __syncthreads();
 
     conv_epilogue<T, BM, BN, WGM, WGN>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt,
-        [&](int row) -> long long {
+        [&](int row) -> int {                  // TW is a power of two; N*OH*OW < 2^31 (host check)
             const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
             if (oh >= H || ow >= W) return -1;
-            return ((long long)n_img * H + oh) * W + ow;
+            return (n_img * H + oh) * W + ow;
         });
 }
 
-template <typename T, int TH, int TW, int BN, int NSB>
+template <typename T, int TH, int TW, int BN, int NSB, int ABL = 0>
 static int launch_pp2_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
     constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + 7) / 8;
     const size_t lds = (size_t)2 * GP * 8 * 1024 + (size_t)NSB * BN * 128;
-    auto kern = conv3x3_pp2_kernel<T, TH, TW, BN, NSB>;
+    auto kern = conv3x3_pp2_kernel<T, TH, TW, BN, NSB, ABL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -332,6 +338,7 @@ static int launch_pp2_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
 // second-schedule ping-pong tile configurations (ids 70..75)
 static const PatchCfg kPp2Cfgs[] = {
     {70, 8, 32, 64}, {71, 8, 32, 128}, {72, 8, 32, 64}, {73, 4, 64, 64}, {74, 4, 64, 64}, {75, 4, 32, 128},
+    {78, 8, 32, 128}, {79, 8, 32, 64},     // ablation instances of 71 / 70 (scripts/pp2_ablate.py)
 };
 static inline const PatchCfg* find_pp2_cfg(int id) {
     for (const PatchCfg& c : kPp2Cfgs)
@@ -348,6 +355,8 @@ static inline int launch_pp2_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 73: return launch_pp2_cfg<T, 4, 64, 64, 5>(k, groups, s);    // 256 px x  64 for 64-wide tiles, 152 KiB
         case 74: return launch_pp2_cfg<T, 4, 64, 64, 4>(k, groups, s);
         case 75: return launch_pp2_cfg<T, 4, 32, 128, 5>(k, groups, s);   // 128 px x 128, wave tile 32x64
+        case 78: return launch_pp2_cfg<T, 8, 32, 128, 4, 1>(k, groups, s);
+        case 79: return launch_pp2_cfg<T, 8, 32, 64, 5, 1>(k, groups, s);
     }
     set_error("conv: unknown ping-pong (schedule 2) tile config %d", cfg);
     return V2V_EINVAL;

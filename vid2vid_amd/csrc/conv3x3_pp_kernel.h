@@ -254,10 +254,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvKArgs p) {
     __syncthreads();
 
     conv_epilogue<T, BM, BN, WGM, WGN>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt,
-        [&](int row) -> long long {
+        [&](int row) -> int {                  // TW is a power of two; N*OH*OW < 2^31 (host check)
             const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
             if (oh >= H || ow >= W) return -1;
-            return ((long long)n_img * H + oh) * W + ow;
+            return (n_img * H + oh) * W + ow;
         });
 }
 

@@ -270,6 +270,10 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     k.OH = d->OH; k.OW = d->OW;
     k.pad_mode = d->pad_mode;
     if ((long long)d->N * d->H * d->W >= (1ll << 31) || (long long)d->N * d->OH * d->OW >= (1ll << 31)) { set_error("conv: too many pixels"); return V2V_EINVAL; }
+    // the epilogue addresses the output with 32-bit element offsets
+    if ((long long)d->N * d->OH * d->OW * (d->out_mode == V2V_OUT_F32_NCHW ? d->cout : d->cout_stride) >= (1ll << 31)) {
+        set_error("conv: output of 2^31 elements or more"); return V2V_EINVAL;
+    }
     if (d->transposed) {
         // class (a,b) owns output pixels (os*i + a, os*j + b); its grid is ceil((OH-a)/os) x ceil((OW-b)/os)
         k.sm = 1; k.os = d->stride; k.dstep = -1;

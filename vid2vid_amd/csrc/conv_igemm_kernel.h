@@ -178,48 +178,108 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
 
     // ---------------- epilogue ----------------
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    //
+    // Round 2: the first version of this block evaluated pix_of(), three output-mode branches, the activation switch and
+    // 64-bit index arithmetic PER ELEMENT (~350 instructions x 32-64 elements per lane, 60 KB of straight-line code for
+    // the 256 px x 64 tile) -- a fixed ~35 us per launch, a third of the 1024 -> 1024 layer's 93 us
+    // (profiles/r02_a3_pp2_ablate.txt: the kernel with an empty main loop took 43 us whatever the K extent).  Now the
+    // row -> pixel map is evaluated once per row into registers, the mode / activation dispatch is hoisted out of the
+    // element loops, and element offsets are 32-bit (the host rejects outputs of 2^31 elements or more).  Same
+    // arithmetic per element, bitwise identical results.
     float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2]
     const bool want_stats = p.stats != nullptr;
-    const long long ohow = (long long)p.OH * p.OW;
+    int opx[TM][16];                               // output pixel index of this lane's rows, < 0: outside the layer
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int ncol = nt * BN + wn * WN + j * 32 + lr;
-        const bool nvalid = ncol < p.cout && !helper;
-        const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int r = 0; r < 16; ++r) {
+            const int o = pix_of(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+            opx[i][r] = (helper || (p.ablate & 4)) ? -1 : o;
+        }
+    const unsigned cs_out = (unsigned)p.cout_stride;
+    if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
+        float* const out = reinterpret_cast<float*>(p.out);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const long long opix = pix_of(row);      // output pixel index in [N][OH][OW], < 0: outside
-                if (opix >= 0 && nvalid && !(p.ablate & 4)) {
-                    float v = acc[i][j][r] + bv;
-                    if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
+        for (int j = 0; j < TN; ++j) {
+            const int ncol = nt * BN + wn * WN + j * 32 + lr;
+            const bool nvalid = ncol < p.cout && !helper;
+            const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (opx[i][r] >= 0 && nvalid) {
+                        const float v = acc[i][j][r] + bv;
                         s1 += v;
                         s2 += v * v;
-                        reinterpret_cast<float*>(p.out)[opix * p.cout_stride + ncol] = v;
-                    } else {
-                        v = apply_act(v, p.act, p.act_param) * p.out_scale;
-                        if (p.out_mode == V2V_OUT_ACT_NHWC) {
-                            store_act(reinterpret_cast<T*>(p.out), opix * p.cout_stride + ncol, v);
-                        } else {
-                            const long long n = opix / ohow;
-                            const long long pix = opix - n * ohow;
-                            reinterpret_cast<float*>(p.out)[(n * p.cout + ncol) * ohow + pix] = v;
-                        }
+                        out[(unsigned)opx[i][r] * cs_out + (unsigned)ncol] = v;
                     }
+            if (want_stats) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (hi == 0 && !helper) {
+                    const int c = wn * WN + j * 32 + lr;
+                    red[(wm * BN + c) * 2 + 0] = s1;
+                    red[(wm * BN + c) * 2 + 1] = s2;
                 }
             }
         }
-        if (want_stats) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (hi == 0 && !helper) {
-                const int c = wn * WN + j * 32 + lr;
-                red[(wm * BN + c) * 2 + 0] = s1;
-                red[(wm * BN + c) * 2 + 1] = s2;
+    } else if (p.out_mode == V2V_OUT_ACT_NHWC) {
+        T* const out = reinterpret_cast<T*>(p.out);
+        // NONE / RELU / LEAKY (every norm-less hidden layer) as one select with hoisted conditions: bit for bit apply_act()
+        const bool simple = p.act == V2V_ACT_NONE || p.act == V2V_ACT_RELU || p.act == V2V_ACT_LEAKY;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ncol = nt * BN + wn * WN + j * 32 + lr;
+            const bool nvalid = ncol < p.cout && !helper;
+            const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
+            if (simple) {
+                const bool is_none = p.act == V2V_ACT_NONE, is_relu = p.act == V2V_ACT_RELU;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (opx[i][r] >= 0 && nvalid) {
+                            float v = acc[i][j][r] + bv;
+                            const float neg = is_relu ? 0.f : v * p.act_param;
+                            v = (is_none || v > 0.f) ? v : neg;
+                            store_act(out, (unsigned)opx[i][r] * cs_out + (unsigned)ncol, v * p.out_scale);
+                        }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (opx[i][r] >= 0 && nvalid)
+                            store_act(out, (unsigned)opx[i][r] * cs_out + (unsigned)ncol,
+                                      apply_act(acc[i][j][r] + bv, p.act, p.act_param) * p.out_scale);
             }
+        }
+    } else {                                       // planar fp32 NCHW (API-facing heads)
+        float* const out = reinterpret_cast<float*>(p.out);
+        const unsigned ohow = (unsigned)(p.OH * p.OW);
+        if (p.N > 1) {                             // pixel index -> n * cout * OH*OW + pixel-in-image
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (opx[i][r] >= 0) {
+                        const unsigned n = (unsigned)opx[i][r] / ohow;
+                        opx[i][r] = (int)(n * (unsigned)p.cout * ohow + ((unsigned)opx[i][r] - n * ohow));
+                    }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ncol = nt * BN + wn * WN + j * 32 + lr;
+            const bool nvalid = ncol < p.cout && !helper;
+            const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (opx[i][r] >= 0 && nvalid)
+                        out[(unsigned)opx[i][r] + (unsigned)ncol * ohow] = apply_act(acc[i][j][r] + bv, p.act, p.act_param) * p.out_scale;
         }
     }
     if (want_stats) {
@@ -562,7 +622,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
     __syncthreads();                      // LDS ring is free: reused for the statistics reduction
 
     conv_epilogue<T, BM, BN, WGM, WGN>(p, acc, smem, tid, wm, wn, helper, cls, tiles, lin, slice, S, nt, cls * p.m_tiles + mt,
-        [&](int row) -> long long {
+        [&](int row) -> int {                  // N*OH*OW < 2^31 (host check)
             const int m = mt * BM + row;
             if (m >= p.Mc[cls]) return -1;
             if (p.os == 1) return m;
@@ -571,7 +631,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
             const int rem = m - n * hwc;
             const int oi = rem / owc_e;
             const int oj = rem - oi * owc_e;
-            return ((long long)n * p.OH + (oi * 2 + (cls >> 1))) * p.OW + (oj * 2 + (cls & 1));
+            return (n * p.OH + (oi * 2 + (cls >> 1))) * p.OW + (oj * 2 + (cls & 1));
         });
 }
 

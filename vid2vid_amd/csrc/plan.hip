@@ -12,6 +12,7 @@ namespace v2v {
 static thread_local char g_err[512] = "";
 static thread_local v2v_plan* g_recording = nullptr;
 static thread_local int g_lane = 0;
+static int g_dry_run = 0;        // v2v_set_dry_run: validate arguments, never launch (CPU-host drop-in tests)
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -36,6 +37,7 @@ int submit(std::unique_ptr<Op> op, void* stream) {
         g_recording->ops.push_back(std::move(op));
         return 0;
     }
+    if (g_dry_run) return 0;     // every entry point has validated its arguments by now; nothing may execute
     return op->launch(reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -98,6 +100,7 @@ extern "C" int v2v_plan_num_ops(const v2v_plan* p) { return p ? (int)p->ops.size
 
 extern "C" int v2v_plan_run(v2v_plan* p, void* stream) {
     if (!p) return V2V_EINVAL;
+    if (g_dry_run) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     for (auto& op : p->ops) {
         int rc = op->launch(s);
@@ -202,7 +205,9 @@ extern "C" const char* v2v_plan_op_label(const v2v_plan* p, int32_t i) {
     return p->ops[i]->label.c_str();
 }
 
-extern "C" int v2v_version(void) { return 100; }
+extern "C" int v2v_set_dry_run(int32_t on) { const int prev = g_dry_run; g_dry_run = on ? 1 : 0; return prev; }
+extern "C" int v2v_get_dry_run(void) { return g_dry_run; }
+extern "C" int v2v_version(void) { return 101; }
 extern "C" const char* v2v_last_error(void) { return g_err; }
 
 extern "C" int v2v_device_info(int32_t* cus, int32_t* lds_per_cu, int64_t* hbm_bytes, char* arch, int32_t arch_len) {

@@ -209,6 +209,7 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               # ping-pong, second schedule: LDS-DMA issued between the MFMAs; the only tiles v2v_conv2d_pair accepts
               # (csrc/conv3x3_pp2_kernel.h)
               70: (8, 32, 64), 71: (8, 32, 128), 72: (8, 32, 64), 73: (4, 64, 64), 74: (4, 64, 64), 75: (4, 32, 128)}
+ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75)
 
 

@@ -125,6 +125,8 @@ PROTOTYPES = {
     "v2v_plan_set_lane": (C.c_int, [_I]),
     "v2v_plan_lane_wait": (C.c_int, [_I, _I]),
     "v2v_memcpy_d2d": (C.c_int, [_P, _P, _L, _P]),
+    "v2v_set_dry_run": (C.c_int, [_I]),
+    "v2v_get_dry_run": (C.c_int, []),
     "v2v_version": (C.c_int, []),
     "v2v_last_error": (C.c_char_p, []),
     "v2v_device_info": (C.c_int, [C.POINTER(_I), C.POINTER(_I), C.POINTER(_L), C.c_char_p, _I]),
