@@ -464,7 +464,7 @@ def main():
         from vid2vid_amd.engine import TILE_CFGS, PATCH_CFGS
         if dom[0] in PATCH_CFGS:
             th_, tw_, bn = PATCH_CFGS[dom[0]]
-            fam = "conv3x3_pp2_kernel" if dom[0] >= 70 else "conv3x3_pp_kernel" if dom[0] >= 50 else "conv3x3_patch_kernel"
+            fam = "conv3x3_pp3_kernel" if dom[0] >= 80 else "conv3x3_pp2_kernel" if dom[0] >= 70 else "conv3x3_pp_kernel" if dom[0] >= 50 else "conv3x3_patch_kernel"
             tile_name = "%dx%d px x %d,splitK=%d%s" % (th_, tw_, bn, dom[1], ",paired launch (2 convolutions)" if dom[2] == 2 else "")
         else:
             bm, bn, _ = TILE_CFGS.get(dom[0], (0, 0, False))

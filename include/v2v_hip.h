@@ -145,8 +145,8 @@ int     v2v_conv_tile_config(const v2v_conv_desc* d);
  *   dX of ConvTranspose2d(w[cin][cout], stride 2, p)   = Conv2d of dY with `w` read as a Conv2d weight
  *       [cout'=cin][cin'=cout], stride 2, pad p. */
 int     v2v_conv2d(const v2v_conv_desc* d, void* stream);
-/* Grouped launch: two convolutions of IDENTICAL geometry, modes and tile configuration (tile ids 70..79, the
- * second-schedule ping-pong 3x3 kernels) as ONE launch -- block z picks its member's tensors.  The twin chains of
+/* Grouped launch: two convolutions of IDENTICAL geometry, modes and tile configuration (tile ids 70..89: the
+ * second-schedule ping-pong and the single-phase 3x3 kernels) as ONE launch -- block z picks its member's tensors.  The twin chains of
  * CompositeGenerator (label / image towers, image / flow branches: models/networks.py:203-232) each fill only half
  * of the 256 CUs at batch 1; paired they fill the chip without split-K.  Each member keeps its own output, statistics,
  * finalize tickets and split-K scratch; results are bitwise those of two v2v_conv2d calls. */

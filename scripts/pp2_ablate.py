@@ -13,6 +13,7 @@ import torch.nn as nn
 from vid2vid_amd import lib as L
 from vid2vid_amd.engine import Engine
 
+TILES = [int(t) for t in sys.argv[1:]] or [89, 88, 79]
 DEV = "cuda:0"
 eng = Engine(DEV, L.BF16)
 cin = cout = 1024
@@ -38,8 +39,10 @@ def run(tile, S, ab):
 
 with torch.no_grad():
     # launch + event overhead of an (almost) empty kernel, for reference
-    for tile in (79, 78):
-        print("== tile %d (%s), 1024->1024 3x3 @64x32 bf16, warm, median of 9" % (tile, "256 px x 64, wave tile 64x32" if tile == 79 else "256 px x 128, wave tile 64x64"))
+    for tile in TILES:
+        print("== tile %d (%s, %s), 1024->1024 3x3 @64x32 bf16, warm, median of 9" % (
+            tile, "256 px x 64, wave tile 64x32" if tile in (79, 89) else "256 px x 128, wave tile 64x64",
+            "single-phase pp3" if tile >= 80 else "ping-pong pp2"))
         for S in (1, 2):
             for ab, what in ABL:
                 for _ in range(3):

@@ -206,7 +206,9 @@ PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33
               (40, 1), (41, 1), (42, 1), (43, 1), (44, 1), (45, 1), (46, 1), (47, 1), (48, 1), (40, 2), (41, 3), (46, 2), (48, 2),
               (50, 1), (51, 1), (52, 1), (53, 1), (54, 1), (55, 1), (56, 1), (57, 1), (50, 2), (51, 3), (53, 2), (52, 4), (56, 2),
               # ping-pong, second schedule (csrc/conv3x3_pp2_kernel.h): LDS-DMA issued between the MFMAs
-              (70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2), (73, 3), (75, 2)]
+              (70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2), (73, 3), (75, 2),
+              # single-phase software-pipelined schedule (csrc/conv3x3_pp3_kernel.h)
+              (80, 1), (81, 1), (82, 1), (83, 1), (84, 1), (85, 1), (80, 2), (81, 2), (83, 3), (84, 2), (85, 2), (82, 4)]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -289,7 +291,8 @@ def test_conv2d_pair_equals_two_launches(case, prec):
     pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
     ncc = xa[0].Cs // (64 if prec == "bf16" else 32)
     assert eng.pair_eligible(xa[0], convs[0], xa[1], convs[1])
-    for tile, S in [(70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2)]:
+    for tile, S in [(70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2),
+                    (80, 1), (81, 1), (82, 1), (83, 1), (84, 1), (85, 1), (80, 2), (81, 2)]:
         if 2 * S > ncc:
             continue
         eng.pair_override = (tile, S)

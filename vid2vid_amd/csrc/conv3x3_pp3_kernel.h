@@ -1,0 +1,349 @@
+// 3x3 stride-1 convolution, LDS-resident input patch -- SINGLE-PHASE software-pipelined schedule (gfx950).
+//
+// Why a third schedule.  scripts/pp2_ablate.py on the instrumented ping-pong kernel (profiles/r02_a4_pp2_ablate.txt, the
+// 1024 -> 1024 layer, 256 px x 64 tile, 144 tap steps) decomposes its 106 us as: the 16 MFMAs of a step need 213 ns of
+// matrix pipe per SIMD; the two barriers of a step cost ~146 ns; a LOAD phase (12 ds_read_b128 per wave: address VALU,
+// 192 LDS cycles, the read latency, all of it between two barriers) costs ~190 ns and there are two per step --
+// 600 ns per step, 36 % of the time in the matrix pipe.  Moving the LDS-DMA issue into the MMA phase (conv3x3_pp2_kernel)
+// changed nothing: the DMA was never the problem, the exposed start-up / drain latency of the fragment reads is.
+//
+// Here every wave keeps TWO register sets of fragments.  Iteration j multiplies step j from set `cur` while it issues the
+// ds_reads of step j+1 into set `nxt` and its share of the LDS-DMA of step j+D between those MFMAs; ONE barrier per step:
+//
+//      B_j | for m in MFMAs(j): mfma(cur) ; a few ds_read(j+1 -> nxt) / one DMA piece | vmcnt, lgkmcnt(0) | swap
+//
+// so the read latency hides behind the matrix pipe instead of behind a barrier.  Tile = TH x TW pixels x BN channels,
+// 8 waves as 4(M) x 2(N), two waves per SIMD (both in the same code, the pipe alternates between them).
+//
+// Hazards (checked by scripts/pp_sched_sim.py pp3 for every (GP, LB, D) in use; phase j = between B_j and B_j+1):
+//   RAW  the reads of step j+1 are issued after B_j; every wave retired ITS share of weight slice j+1 (and, at tap 7,
+//        of the whole next patch) with the counted wait at the end of iteration j-1, before arriving at B_j.  At the end
+//        of iteration j slice j+2 (issued in iteration j+2-D) must have landed; younger and allowed in flight: slices
+//        j+3 .. j+D and the patch pieces of iterations j+2-D .. j  ->  vmcnt((D-2)*LB + sum_{u=0..D-2} np(tap-u)); taps
+//        >= 9-D carry no patch pieces, so the wait of tap 7 retires the next chunk's patch before its first read (tap 8).
+//   WAR  slice j+D refills the stage of slice j (ring of D stages), whose reads were drained (lgkmcnt(0)) before B_j;
+//        the patch buffer of chunk c+1 held chunk c-1, last read in iteration 9c-2, and is refilled from iteration 9c on.
+#pragma once
+#include "conv3x3_pp2_kernel.h"
+
+namespace v2v {
+
+namespace pp3 {
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int np_at(int tap, int GP, int NPT) {
+    const int ppt = (GP + NPT - 1) / NPT;
+    return tap < NPT ? cmin((tap + 1) * ppt, GP) - cmin(tap * ppt, GP) : 0;
+}
+constexpr int pending_at(int tap, int GP, int LB, int D) {
+    int x = (D - 2) * LB;
+    for (int u = 0; u < D - 1; ++u) x += np_at((tap - u + 18) % 9, GP, 9 - D);
+    return x;
+}
+}  // namespace pp3
+
+// ABL = 1: ablation instance (scripts/pp2_ablate.py): 1 / 2 hot operands, 4 no stores, 32 no fragment ds_reads,
+// 64 no MFMAs, 128 no LDS-DMA in the main loop, 256 no vmcnt wait in the main loop.  Results are wrong when set.
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0>
+__global__ __launch_bounds__(512) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
+    const ConvKArgs p = select_group(p_in);
+    const int ab = ABL ? p.ablate : 0;
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int BM = TH * TW;
+    constexpr int PW = TW + 2, PR = (TH + 2) * PW;
+    constexpr int NW = 8, WGM = 4, WGN = 2;
+    constexpr int NG = (PR + 7) / 8;
+    constexpr int GP = (NG + NW - 1) / NW;                    // patch pieces per wave per chunk
+    constexpr int PATCH = GP * NW * 1024;
+    constexpr int BST = BN * 128;
+    constexpr int LB = BN / 8 / NW;                           // weight pieces per wave per slice
+    constexpr int NSB = D;                                    // weight ring: slice j+D refills the stage of slice j
+    constexpr int NPT = 9 - D;                                // taps 0..NPT-1 carry next-chunk patch pieces
+    constexpr int PPT = (GP + NPT - 1) / NPT;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NMMA = 4 * TM * TN;                         // MFMAs of one step
+    constexpr int NRD = 4 * (TM + TN);                        // fragment reads of one step
+    static_assert(TW % 32 == 0 && (TW & (TW - 1)) == 0, "a 32-row fragment must lie inside one tile row");
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile");
+    static_assert(BN % (8 * NW) == 0 && LB >= 1, "weight loader rounds");
+    static_assert(D >= 3 && D <= 5, "weight slices in flight");
+    static_assert(2 * PATCH + NSB * BST <= 160 * 1024, "LDS");
+    static_assert(2 * PATCH >= 32768, "epilogue scratch lives in the patch buffers");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const bring = smem + 2 * PATCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int cls = 0;
+
+    const int tiles = p.m_tiles * p.n_tiles;
+    const int S = p.splitk;
+    const int lin_all = xcd_remap(blockIdx.x, tiles * S);
+    const int lin = lin_all / S;
+    const int slice = lin_all - lin * S;
+    const int nt = lin / p.m_tiles;
+    const int mt = lin - nt * p.m_tiles;
+    const int tpi = p.tiles_h * p.tiles_w;
+    const int n_img = mt / tpi;
+    const int trem = mt - n_img * tpi;
+    const int th = trem / p.tiles_w;
+    const int oh0 = th * TH, ow0 = (trem - th * p.tiles_w) * TW;
+
+    const int H = p.H, W = p.W, cs = p.cin_stride;
+    const int ncc_all = cs * (int)sizeof(T) / 128;
+    const int ccb = (int)(((long long)ncc_all * slice) / S);
+    const int ncc = (int)(((long long)ncc_all * (slice + 1)) / S) - ccb;
+    const int nsteps = ncc * 9;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+    const char* const zp = p.zero_page;
+
+    // ---------------- patch loader geometry (as conv3x3_pp_kernel) ----------------
+    unsigned pp[GP];
+    unsigned pok = 0;
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+        const int q = (k * NW + wid) * 8 + (lane >> 3);
+        const int ls = (lane & 7) ^ ((q >> 1) & 7);
+        const int pr = q / PW, pc = q - pr * PW;
+        int ih = oh0 + pr - 1, iw = ow0 + pc - 1;
+        bool ok = q < PR;
+        int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+        int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+        ih = reflect ? rh : ih;
+        iw = reflect ? rw : iw;
+        ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+        iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        pp[k] = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
+        pok |= (ok ? 1u : 0u) << k;
+    }
+    auto issue_patch = [&](int k, int cc_local, char* buf) {
+        const int cg = cc_local < ncc ? cc_local : ncc - 1;    // tail: a harmless reload keeps the DMA counts uniform
+        const char* src = (((pok >> k) & 1u) && !(ab & 1)) ? p.in + pp[k] + (ccb + cg) * 128 : zp;
+        glds16(src, buf + (k * NW + wid) * 1024);
+    };
+
+    // ---------------- weight loader geometry ----------------
+    const int lrow = wid * 8 + (lane >> 3);
+    const int lslot = (lane & 7) ^ ((lrow >> 1) & 7);         // (64*i >> 1) & 7 == 0
+    const char* wp[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        long long r = (long long)nt * BN + lrow + NW * 8 * i;
+        r = r < p.cout_p ? r : p.cout_p - 1;
+        wp[i] = p.w + ((long long)p.woff[0] + r * p.wrow[0] + lslot * VEC) * (long long)sizeof(T) + (long long)ccb * 9 * 128;
+    }
+    auto issue_w_piece = [&](int i, int step, int stage) {
+        const int sg = step < nsteps ? step : nsteps - 1;      // tail duplicate into a free stage
+        glds16(wp[i] + ((ab & 2) ? 0ll : (long long)sg * 128), bring + stage * BST + wid * 1024 + i * NW * 1024);
+    };
+
+    // ---------------- fragment addressing ----------------
+    const int lr = lane & 31, hi = lane >> 5;
+    int qb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m0 = wm * WM + i * 32;
+        qb[i] = (m0 / TW) * PW + (m0 % TW) + lr;
+    }
+    int foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = ((s * 2 + hi) ^ ((lr >> 1) & 7)) << 4;
+    const int b_row_off = (wn * WN + lr) * 128;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Frag fa[2][4][TM], fb[2][4][TN];                         // two register sets: multiply one, fill the other
+
+    // fragment read q of a step (0 .. NRD-1: the A reads i-major, then the B reads) into set `PARN`
+    // aaddr[i]: byte address of patch row (qb[i] + tap offset) with its swizzle term ax[i]; pb: weight stage + row
+    auto read_frag = [&](auto qc, auto parc, const char* (&arow)[TM], int (&ax)[TM], const char* pb) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int PARN = decltype(parc)::value;
+        if constexpr (q < 4 * TM) {
+            constexpr int i = q / 4, s = q % 4;
+            fa[PARN][s][i] = *reinterpret_cast<const Frag*>(arow[i] + (((s * 2 + hi) ^ ax[i]) << 4));
+        } else {
+            constexpr int s = (q - 4 * TM) / TN, j = (q - 4 * TM) % TN;
+            fb[PARN][s][j] = *reinterpret_cast<const Frag*>(pb + j * 32 * 128 + foff[s]);
+        }
+    };
+
+    // ---------------- prologue: patch 0 and weight slices 0 .. D-1; step 0's fragments into set 0 ----------------
+#pragma unroll
+    for (int k = 0; k < GP; ++k) issue_patch(k, 0, smem);
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+#pragma unroll
+        for (int i = 0; i < LB; ++i) issue_w_piece(i, t, t);
+    wait_vmcnt<(D - 1) * LB>();                              // the patch and slice 0 have landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    {
+        const char* arow[TM]; int ax[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { arow[i] = smem + qb[i] * 128; ax[i] = (qb[i] >> 1) & 7; }
+        const char* const pb = bring + b_row_off;
+        if (!(ab & 32))
+            static_for<NRD>([&](auto qc) { read_frag(qc, std::integral_constant<int, 0>{}, arow, ax, pb); });
+    }
+    wait_vmcnt<(D - 2) * LB>();                              // slice 1: published by B_0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    int step = 0, stage = 0, cc = 0;                          // step being multiplied, its weight stage, its chunk
+    const char* pa = smem;                                    // patch buffer of chunk cc
+    char* pn = smem + PATCH;                                  // the other one (chunk cc+1 streams in)
+
+    // iteration: multiply step `step` (tap TAP) from set PAR, fill set 1-PAR with step+1, issue the DMA of step+D
+    auto iteration = [&](auto tc, auto pc) {
+        constexpr int TAP = decltype(tc)::value;
+        constexpr int PAR = decltype(pc)::value;
+        constexpr int NT = (TAP + 1) % 9;                    // tap of the step whose fragments are read now
+        constexpr int tq = (NT / 3) * PW + (NT % 3);
+        constexpr int k0 = pp3::cmin(TAP * PPT, GP);
+        constexpr int npz = pp3::np_at(TAP, GP, NPT);
+        constexpr int NDMA = LB + npz;
+        // issue slots: after MFMA m (m = 0 .. NMMA-2).  The reads go first (their latency then hides behind the remaining
+        // MFMAs), RPS per slot; the DMA pieces follow, one per slot
+        constexpr int RSLOTS = (NMMA * 5) / 8 > 0 ? (NMMA * 5) / 8 : 1;
+        constexpr int RPS = (NRD + RSLOTS - 1) / RSLOTS;
+        constexpr int RUSED = (NRD + RPS - 1) / RPS;          // slots that actually carry reads
+
+        __builtin_amdgcn_s_barrier();                        // B_step: slice step+1 (and at tap 8 the next patch) is visible,
+                                                             // the stage of slice `step` and its fragment reads are retired
+        const char* arow[TM]; int ax[TM];
+        {
+            const char* const pbuf = TAP == 8 ? pn : pa;     // step+1 belongs to the next chunk at tap 8
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int qv = qb[i];
+                asm volatile("" : "+v"(qv));               // opaque: no hoisting of 9 x TM address sets out of the chunk loop
+                const int q = qv + tq;
+                arow[i] = pbuf + q * 128;
+                ax[i] = (q >> 1) & 7;
+            }
+        }
+        const int nstage = stage + 1 == NSB ? 0 : stage + 1;
+        const char* const pb = bring + nstage * BST + b_row_off;
+        auto dma = [&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if (ab & 128) return;
+            if constexpr (d < LB) issue_w_piece(d, step + D, stage);       // slice step+D refills the stage of slice `step`
+            else                  issue_patch(k0 + d - LB, cc + 1, pn);
+        };
+        auto reads_of_slot = [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if (ab & 32) return;
+            static_for<RPS>([&](auto rc) {
+                constexpr int q = m * RPS + decltype(rc)::value;
+                if constexpr (q < NRD) read_frag(std::integral_constant<int, q>{}, std::integral_constant<int, 1 - PAR>{}, arow, ax, pb);
+            });
+        };
+        static_for<NMMA>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int s = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+            if (!(ab & 64)) Mma<T>::run(fa[PAR][s][i], fb[PAR][s][j], acc[i][j]);
+            if constexpr (m < RUSED) {
+                __builtin_amdgcn_sched_barrier(0);
+                reads_of_slot(mc);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (m - RUSED < NDMA && m < NMMA - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma(std::integral_constant<int, m - RUSED>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        // whatever found no slot (short MFMA sequences with many pieces)
+        constexpr int DMA_IN_SLOTS = pp3::cmin(NDMA, NMMA - 1 - RUSED > 0 ? NMMA - 1 - RUSED : 0);
+        static_for<NDMA - DMA_IN_SLOTS>([&](auto dc) { dma(std::integral_constant<int, DMA_IN_SLOTS + decltype(dc)::value>{}); });
+        if (!(ab & 256)) wait_vmcnt<pp3::pending_at(TAP, GP, LB, D)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set 1-PAR is complete; the reads of slice step+1 are retired
+        ++step;
+        stage = nstage;
+        if constexpr (TAP == 8) {
+            ++cc;
+            const char* t = pa; pa = pn; pn = const_cast<char*>(t);
+        }
+    };
+    auto chunk = [&](auto par0c) {
+        constexpr int P0 = decltype(par0c)::value;
+        iteration(std::integral_constant<int, 0>{}, std::integral_constant<int, P0>{});
+        iteration(std::integral_constant<int, 1>{}, std::integral_constant<int, 1 - P0>{});
+        iteration(std::integral_constant<int, 2>{}, std::integral_constant<int, P0>{});
+        iteration(std::integral_constant<int, 3>{}, std::integral_constant<int, 1 - P0>{});
+        iteration(std::integral_constant<int, 4>{}, std::integral_constant<int, P0>{});
+        iteration(std::integral_constant<int, 5>{}, std::integral_constant<int, 1 - P0>{});
+        iteration(std::integral_constant<int, 6>{}, std::integral_constant<int, P0>{});
+        iteration(std::integral_constant<int, 7>{}, std::integral_constant<int, 1 - P0>{});
+        iteration(std::integral_constant<int, 8>{}, std::integral_constant<int, P0>{});
+    };
+    // 9 taps per chunk: the register-set parity flips from chunk to chunk
+    int c = 0;
+    for (; c + 1 < ncc; c += 2) {
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+    }
+    if (c < ncc) chunk(std::integral_constant<int, 0>{});
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail duplicates must land before the LDS is reused
+    __syncthreads();
+
+    conv_epilogue<T, BM, BN, WGM, WGN>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt,
+        [&](int row) -> int {                  // TW is a power of two; N*OH*OW < 2^31 (host check)
+            const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
+            if (oh >= H || ow >= W) return -1;
+            return (n_img * H + oh) * W + ow;
+        });
+}
+
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0>
+static int launch_pp3_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
+    constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + 7) / 8;
+    const size_t lds = (size_t)2 * GP * 8 * 1024 + (size_t)D * BN * 128;
+    auto kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(k.m_tiles * k.n_tiles * k.splitk), 1u, (unsigned)groups);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, k);
+    return check_launch();
+}
+
+// single-phase tile configurations (ids 80..89)
+static const PatchCfg kPp3Cfgs[] = {
+    {80, 8, 32, 64}, {81, 8, 32, 128}, {82, 8, 32, 64}, {83, 4, 64, 64}, {84, 4, 32, 128}, {85, 4, 64, 128},
+    {88, 8, 32, 128}, {89, 8, 32, 64},     // ablation instances of 81 / 80
+};
+static inline const PatchCfg* find_pp3_cfg(int id) {
+    for (const PatchCfg& c : kPp3Cfgs)
+        if (c.id == id) return &c;
+    return nullptr;
+}
+
+template <typename T>
+static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipStream_t s) {
+    switch (cfg) {
+        case 80: return launch_pp3_cfg<T, 8, 32, 64, 4>(k, groups, s);    // 256 px x  64, wave tile 64x32, 4 slices in flight, 128 KiB
+        case 81: return launch_pp3_cfg<T, 8, 32, 128, 4>(k, groups, s);   // 256 px x 128, wave tile 64x64, 160 KiB
+        case 82: return launch_pp3_cfg<T, 8, 32, 64, 5>(k, groups, s);    // as 80, 5 slices in flight, 136 KiB
+        case 83: return launch_pp3_cfg<T, 4, 64, 64, 4>(k, groups, s);    // 256 px x  64 for 64-wide tiles, 144 KiB
+        case 84: return launch_pp3_cfg<T, 4, 32, 128, 4>(k, groups, s);   // 128 px x 128, wave tile 32x64
+        case 85: return launch_pp3_cfg<T, 4, 64, 128, 3>(k, groups, s);   // 256 px x 128 for 64-wide tiles, 3 slices, 160 KiB
+        case 88: return launch_pp3_cfg<T, 8, 32, 128, 4, 1>(k, groups, s);
+        case 89: return launch_pp3_cfg<T, 8, 32, 64, 4, 1>(k, groups, s);
+    }
+    set_error("conv: unknown single-phase tile config %d", cfg);
+    return V2V_EINVAL;
+}
+
+}  // namespace v2v

@@ -43,6 +43,7 @@
 //     order (deterministic) and runs the normal epilogue.
 #include "conv3x3_pp_kernel.h"
 #include "conv3x3_pp2_kernel.h"
+#include "conv3x3_pp3_kernel.h"
 #include "conv7x7_head_kernel.h"
 #include <cstdarg>
 #include <cstring>
@@ -208,6 +209,8 @@ int launch_pp_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_pp_f32(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_pp2_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp2_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
+int launch_pp3_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
+int launch_pp3_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s);
 int launch_head_f32(const ConvKArgs& k, hipStream_t s);
 
@@ -229,6 +232,7 @@ struct ConvOp : Op {
     long long slab_bytes; int sk_tickets;
     int groups = 1;      // 2: grouped launch (v2v_conv2d_pair), second member's tensors in k.g1
     int launch(hipStream_t s) override {
+        if (cfg >= 80) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, groups, s) : launch_pp3_f32(cfg, k, groups, s);
         if (cfg >= 70) return dtype == V2V_BF16 ? launch_pp2_bf16(cfg, k, groups, s) : launch_pp2_f32(cfg, k, groups, s);
         if (cfg == 60) return dtype == V2V_BF16 ? launch_head_bf16(k, s) : launch_head_f32(k, s);
         if (cfg >= 50) return dtype == V2V_BF16 ? launch_pp_bf16(cfg, k, s) : launch_pp_f32(cfg, k, s);
@@ -325,7 +329,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     } else if (op->cfg >= 32) {
         // conv3x3_patch_kernel: 3x3 / stride 1 / pad 1 Conv2d, channel stride a multiple of the 128-byte chunk,
         // weights packed channel-chunk outer (korder 1)
-        const PatchCfg* pc = op->cfg >= 70 ? find_pp2_cfg(op->cfg) : op->cfg >= 50 ? find_pp_cfg(op->cfg) : find_patch_cfg(op->cfg);
+        const PatchCfg* pc = op->cfg >= 80 ? find_pp3_cfg(op->cfg) : op->cfg >= 70 ? find_pp2_cfg(op->cfg) : op->cfg >= 50 ? find_pp_cfg(op->cfg) : find_patch_cfg(op->cfg);
         if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
         if (d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 ||
             d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 1 ||
@@ -424,8 +428,8 @@ extern "C" int v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, v
     int rc = build_conv(a, op.get());
     if (rc == 0) rc = build_conv(b, &ob);
     if (rc != 0) return rc;
-    if (op->cfg < 70 || op->cfg >= 80 || ob.cfg != op->cfg) {
-        set_error("conv pair: both members need the same grouped-launch tile config (70..79), got %d / %d", op->cfg, ob.cfg);
+    if (op->cfg < 70 || op->cfg >= 90 || ob.cfg != op->cfg) {
+        set_error("conv pair: both members need the same grouped-launch tile config (70..89), got %d / %d", op->cfg, ob.cfg);
         return V2V_EINVAL;
     }
     const bool same =

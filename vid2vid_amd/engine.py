@@ -208,14 +208,16 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               56: (8, 32, 64), 57: (4, 64, 64),
               # ping-pong, second schedule: LDS-DMA issued between the MFMAs; the only tiles v2v_conv2d_pair accepts
               # (csrc/conv3x3_pp2_kernel.h)
-              70: (8, 32, 64), 71: (8, 32, 128), 72: (8, 32, 64), 73: (4, 64, 64), 74: (4, 64, 64), 75: (4, 32, 128)}
-ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
-PAIR_TILES = (70, 71, 72, 73, 74, 75)
+              70: (8, 32, 64), 71: (8, 32, 128), 72: (8, 32, 64), 73: (4, 64, 64), 74: (4, 64, 64), 75: (4, 32, 128),
+              # single-phase software-pipelined schedule (csrc/conv3x3_pp3_kernel.h): two fragment register sets, ONE barrier per step
+              80: (8, 32, 64), 81: (8, 32, 128), 82: (8, 32, 64), 83: (4, 64, 64), 84: (4, 32, 128), 85: (4, 64, 128)}
+ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
+PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85)
 
 
 def is_patch_tile(t):
     """Tile ids of the LDS-patch 3x3 kernels (weights in K order 1): patch 32-48, ping-pong 50-57, ping-pong 2 70-79."""
-    return 32 <= t < 60 or 70 <= t < 80
+    return 32 <= t < 60 or 70 <= t < 90
 FUSE_FINALIZE_MAX_PIXELS = 32768   # larger layers leave thousands of statistics rows: parallel two-stage finalize instead
 PREFETCH_DIST = 12          # K chunks (128 B of every weight row each) the helper wave runs ahead
 
@@ -237,6 +239,10 @@ class Engine:
         self.record_only = record_only
         if self.device.type != "cuda" and not record_only:
             raise RuntimeError("vid2vid_amd runs on MI355X only (got device %s); there is no CPU path" % device)
+        if record_only:
+            # dry run: every v2v_* call still validates its arguments, nothing is ever launched (include/v2v_hip.h,
+            # v2v_set_dry_run) -- lets the CPU test-suite drive whole training / inference control flows
+            lib.v2v_set_dry_run(1)
         self.dtype = dtype
         self.tdtype = _TORCH_DTYPE[dtype]
         self.align_corners = align_corners
@@ -592,7 +598,7 @@ class Engine:
             tile3 = self._tuned[key] = self._autotune_pair(xa, ma, xb, mb, pad_mode, pad, fins, key)
             self._save_tune_cache()
         else:
-            tile3 = (70 if W % 64 else 73, 1, 0)
+            tile3 = (80 if W % 64 else 83, 1, 0)
         da, rawa, rowsa, fina, pca = self._pair_desc(xa, ma, pad_mode, pad, tile3, fins[0], labels[0])
         with self.scratch_set(1):
             db, rawb, rowsb, finb, pcb = self._pair_desc(xb, mb, pad_mode, pad, tile3, fins[1], labels[1])
@@ -934,7 +940,7 @@ class Engine:
         """One fused [pad] conv [norm] [act] [+ residuals] group.  Returns an Act, or the planar fp32 NCHW
         tensor when head_nchw.  With autograd recording on (training) it is a v2v custom op
         (autograd.ConvFn: same launches, tensors saved for the HIP backward kernels)."""
-        if self.plan is None and torch.is_grad_enabled() and not self.record_only:
+        if self.plan is None and torch.is_grad_enabled():
             from . import autograd as AG
             return AG.conv_group(self, x, conv, pad_mode, pad_override, norm, act, act_param, add0, add1,
                                  head_nchw, out_scale, label)
@@ -1042,7 +1048,7 @@ class Engine:
 
     # ---------------- other ops ----------------
     def _training(self):
-        return self.plan is None and torch.is_grad_enabled() and not self.record_only
+        return self.plan is None and torch.is_grad_enabled()      # (dry-run engines build the autograd graph too)
 
     def add(self, a, b):
         if a.t.shape != b.t.shape:

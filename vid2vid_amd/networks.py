@@ -53,6 +53,7 @@ def set_record_only(flag):
     """CPU dry-run mode for the test-suite: engines on a CPU device may RECORD plans (argument
     validation, layer census) but can never execute anything.  Not a compute fallback."""
     _RECORD_ONLY["value"] = bool(flag)
+    L.lib.v2v_set_dry_run(1 if flag else 0)
 
 
 def get_engine(device=None, precision=None):

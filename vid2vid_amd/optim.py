@@ -110,7 +110,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat.rebind_grads()
         g = self.flat.flat_grad
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if g.is_cuda else None
-        if not g.is_cuda:
+        if not g.is_cuda and not lib.v2v_get_dry_run():
             raise RuntimeError("FusedAdam runs on the MI355X only")
         check(lib.v2v_memset_zero(C.c_void_p(g.data_ptr()), g.numel() * 4, stream), "memset_zero")
 
@@ -120,7 +120,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("closures are not used by vid2vid")
         from .lib import lib, check
         f = self.flat
-        if not f.flat_param.is_cuda:
+        if not f.flat_param.is_cuda and not lib.v2v_get_dry_run():
             raise RuntimeError("FusedAdam runs on the MI355X only")
         f.rebind_grads()
         gscale = 1.0
@@ -133,6 +133,6 @@ class FusedAdam(torch.optim.Optimizer):
                                 C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
                                 f.numel, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
                                 float(grp["weight_decay"]), float(gscale), self.step_count,
-                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "adam_step")
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream) if f.flat_param.is_cuda else None), "adam_step")
         f.epoch[0] += 1                                      # packed copies of THESE parameters are now stale
         return None
