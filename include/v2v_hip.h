@@ -251,6 +251,8 @@ int v2v_avgpool2_planar_backward(const float* dy, float* dx, int64_t planes, int
  * encode_input :86-112, get_edges models/base_model.py:146-152). */
 int v2v_onehot_planar(const float* labels, const float* inst, float* out, int32_t H, int32_t W,
                       int32_t label_nc, void* stream);
+int v2v_onehot_planar_u8(const uint8_t* labels, const int32_t* inst, float* out, int32_t H, int32_t W,
+                         int32_t label_nc, void* stream);
 
 /* Instance-wise average pooling of Encoder.forward (models/networks.py:621-632) for ONE sample: out[c][p] = mean of
  * feat[c][q] over the pixels q with inst[q] == inst[p].  feat / out: planar fp32 [C][HW]; inst: fp32 [HW] holding integer ids
@@ -269,6 +271,11 @@ int v2v_instance_mean_planar(const float* feat, const float* inst, float* out, v
 int v2v_encode_labels(const float* labels, const float* inst, void* out, float* mask,
                       int32_t T, int32_t H, int32_t W, int32_t label_nc, int32_t c_stride,
                       const int32_t* fg_labels_dev, int32_t n_fg, int32_t dtype, void* stream);
+/* The same with the label map as uint8 and the instance map as int32 (what a loader holds before the
+ * reference multiplies by 255 and casts to float, data/temporal_dataset.py:60-70): 4x less host-to-device traffic. */
+int v2v_encode_labels_u8(const uint8_t* labels, const int32_t* inst, void* out, float* mask,
+                         int32_t T, int32_t H, int32_t W, int32_t label_nc, int32_t c_stride,
+                         const int32_t* fg_labels_dev, int32_t n_fg, int32_t dtype, void* stream);
 
 /* compute_mask on an NHWC (possibly AvgPool'ed) label tensor: mask[p] = clamp(sum_i x[p][base_ch+fg[i]],0,1) */
 int v2v_fg_mask_nhwc(const void* x, float* mask, int64_t P, int32_t c_stride, int32_t base_ch,
@@ -409,6 +416,14 @@ const char* v2v_plan_op_label(const v2v_plan* p, int32_t i);
  * recording order.  Outside a recording both calls are no-ops on the data path. */
 int       v2v_plan_set_lane(int32_t lane);
 int       v2v_plan_lane_wait(int32_t waiter, int32_t signal);
+
+/* Visualisation conversions on the device (util/util.py:48-89 of the reference does them in numpy after a D2H copy of
+ * the fp32 planes): x is planar fp32 [C][H][W]; out is uint8 [H][W][C] (tensor2im, C <= 3; normalize: (x+1)/2*255, else
+ * x*255, clipped, truncated) or uint8 [H][W][3] (tensor2label: argmax over C > 1 planes or the stored id for C == 1,
+ * coloured through cmap[n_label][3]).  Integer-exact against the reference's numpy arithmetic. */
+int v2v_tensor2im(const float* x, uint8_t* out, int32_t C, int32_t H, int32_t W, int32_t normalize, void* stream);
+int v2v_tensor2label(const float* x, uint8_t* out, const uint8_t* cmap, int32_t n_label, int32_t C, int32_t H, int32_t W,
+                     void* stream);
 
 /* recordable device-to-device copy (rolling fake_B_prev window, vid2vid_model_G.py:228) */
 int v2v_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);

@@ -19,6 +19,7 @@ ap.add_argument("--k", type=int, default=3)
 ap.add_argument("--H", type=int, default=32)
 ap.add_argument("--W", type=int, default=64)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--pair", action="store_true", help="paired launch (v2v_conv2d_pair) of two layers of this shape")
 a = ap.parse_args()
 cfg = tuple(int(v) for v in a.cfg.split(","))
 eng = Engine("cuda:0", L.BF16)
@@ -28,8 +29,16 @@ x = eng.pack(torch.randn(1, a.cin, a.H, a.W, device="cuda:0"))
 ss = torch.zeros(4 * a.cout, device="cuda:0")
 eng.tile_override[(a.cin, a.cout, a.k, 1, 0)] = cfg
 thrash = torch.empty(96 << 20, dtype=torch.float32, device="cuda:0")
-for _ in range(a.reps):
-    thrash.zero_()
-    eng.conv(x, mod, L.PAD_REFLECT, a.k // 2, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+mod2 = nn.Conv2d(a.cin, a.cout, a.k, padding=0).to("cuda:0")
+x2 = eng.pack(torch.randn(1, a.cin, a.H, a.W, device="cuda:0"))
+ss2 = torch.zeros(4 * a.cout, device="cuda:0")
+eng.pair_override = (cfg[0], cfg[1])
+with torch.no_grad():
+    for _ in range(a.reps):
+        thrash.zero_()
+        if a.pair:
+            eng.conv_pair(x, mod, x2, mod2, L.PAD_REFLECT, a.k // 2, ((norm, ss), (norm, ss2)), ("a", "b"))
+        else:
+            eng.conv(x, mod, L.PAD_REFLECT, a.k // 2, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
 torch.cuda.synchronize()
 print("ran %d launches of %s" % (a.reps, eng.conv_log[-1]))

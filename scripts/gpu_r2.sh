@@ -68,3 +68,25 @@ if has allkernels; then
   grep -E "^(FAILED|ERROR)|passed|failed|Error" gpurun_out/${TAG}_allkernels.log | cut -c1-300 | tail -30
   lap allkernels
 fi
+if has prof2; then
+  # tile selections of profiles/tune_cache.json are replayed by default: the profile describes the benchmarked kernels
+  DOM=${DOM:-82,1,2}; NEEDLE=${NEEDLE:-conv3x3_pp3_kernelIDF16bLi8ELi32ELi64ELi5}
+  cd /tmp
+  timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_prof.json 2> $R/gpurun_out/${TAG}_bench_prof.err; echo "rocprof rc=$?"
+  DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
+  python $R/scripts/rocprof_summary.py $DB "# round 2, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline (bf16, 512x256; tile selections replayed from profiles/tune_cache.json, no autotune launches in this trace; kernels run inside the 3-lane frame graph)" > $R/gpurun_out/${TAG}_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_bench_prof.err
+  head -14 $R/gpurun_out/${TAG}_kernel_stats.txt | cut -c1-200
+  python $R/scripts/in_graph_json.py $DB $NEEDLE $DOM $R/gpurun_out/${TAG}_in_graph.json
+  cut -c1-300 $R/gpurun_out/${TAG}_bench_prof.json
+  CFG2=$(echo $DOM | cut -d, -f1,2)
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/tr_f -o pmc -- python $R/scripts/conv_layer_run.py --pair --cfg $CFG2,0 > $R/gpurun_out/${TAG}_traffic_fetch.log 2>&1; echo "traffic fetch rc=$?"
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/tr_w -o pmc -- python $R/scripts/conv_layer_run.py --pair --cfg $CFG2,0 > $R/gpurun_out/${TAG}_traffic_write.log 2>&1; echo "traffic write rc=$?"
+  python $R/scripts/pmc_traffic.py $(find /tmp/tr_f -name "*.db" | head -1) $(find /tmp/tr_w -name "*.db" | head -1) $DOM $R/gpurun_out/${TAG}_traffic.json | cut -c1-400
+  cd $R
+  lap prof2
+fi
+if has benchfinal; then
+  timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_final.json 2> gpurun_out/${TAG}_bench_final.err; echo "bench(final, committed tune cache) rc=$?"
+  cut -c1-400 gpurun_out/${TAG}_bench_final.json; tail -3 gpurun_out/${TAG}_bench_final.err
+  lap benchfinal
+fi

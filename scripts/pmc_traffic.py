@@ -3,7 +3,7 @@
 scripts/conv_layer_run.py) -> profiles/<tag>_traffic.json, read by bench.py for roofline.traffic.
 FETCH_SIZE is doubled (gfx950 rocprofv3 reports half of the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM
 section); WRITE_SIZE is taken as reported (uncalibrated).  Units of both counters: KiB.
-    python scripts/pmc_traffic.py <fetch.db> <write.db> <cfg> <out.json>"""
+    python scripts/pmc_traffic.py <fetch.db> <write.db> <tile,splitk,members> <out.json>"""
 import json
 import sqlite3
 import sys

@@ -154,3 +154,13 @@ def test_face_feature_lookup_matches_reference():
         out = nearest_face_features(torch.from_numpy(g["case%d.feat_map" % i]), torch.from_numpy(g["case%d.inst" % i]),
                                     features, feat_num)
         assert torch.allclose(out, torch.from_numpy(g["case%d.out" % i]), rtol=0, atol=1e-6), i
+
+
+def test_label_colormaps_match_reference(golden):
+    """vid2vid_amd.visual.labelcolormap == the reference's util.labelcolormap (util/util.py:156-181) for the two Cityscapes
+    tables and the generated bit-interleaved map (fixture made by tests/golden/make_golden_visual.py from the reference)."""
+    import numpy as np
+    from vid2vid_amd import visual
+    g = golden("visual_util")
+    for n in (35, 20, 12):
+        assert np.array_equal(visual.labelcolormap(n), g["lab%d.cmap" % n]), n

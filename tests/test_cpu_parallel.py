@@ -21,7 +21,7 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    from vid2vid_amd.parallel import init_distributed, GradSync, frame_ranks
+    from vid2vid_amd.parallel import init_distributed, GradSync
     from vid2vid_amd.optim import FlatBuffers
     r, w, _ = init_distributed("gloo")
     assert (r, w) == (rank, world)
@@ -49,9 +49,6 @@ def _worker(rank, world, port, q):
         expect = sum(float(rk + 1) * (i + 1) for rk in range(world))
         assert torch.allclose(p.grad, torch.full_like(p.grad, expect))
         assert torch.allclose(p.grad * scale, torch.full_like(p.grad, expect / world))
-    g, d = frame_ranks(1, world)
-    assert g == [0] and d == [1]
-    assert frame_ranks(-1, world) == ([0, 1], [0, 1])
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))
@@ -116,7 +113,7 @@ def _tuning_worker(rank, world, port, q):
     release = shared_tuning_cache(rank, world)           # ranks > 0 block in here until rank 0 releases
     path = os.environ["V2V_TUNE_CACHE"]
     if rank == 0:
-        assert not os.path.exists(path)                  # a stale file of an earlier job was removed
+        assert not os.path.exists(path)                  # nothing measured yet
         time.sleep(0.5)                                  # "tile search"
         with open(path, "w") as f:
             json.dump({"1": {"1,2,3": [55, 1, 0]}}, f)

@@ -604,3 +604,28 @@ def test_in_kernel_norm_finalize_matches_bn_finalize(prec):
     mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
     assert_close(ss[2 * cout:3 * cout].cpu(), mean, 1e-3, "mean")
     assert_close(ss[3 * cout:].cpu(), 1.0 / torch.sqrt(var + norm.eps), 1e-3, "invstd")
+
+
+def test_visualisation_kernels_equal_reference_numpy(golden):
+    """On-GPU tensor2im / tensor2label against the uint8 arrays the REFERENCE's util.tensor2im / tensor2label
+    produced on CPU (tests/golden/make_golden_visual.py): exact integer equality, including the clip, the truncating cast,
+    the 5-D / single-plane conventions, argmax ties and both Cityscapes palettes; AsyncImageWriter round trip."""
+    import numpy as np
+    from vid2vid_amd import visual
+    g = golden("visual_util")
+    d = lambda k: torch.from_numpy(g[k]).to(DEV)
+    assert np.array_equal(visual.to_numpy(visual.tensor2im(d("im.x"))), g["im.norm"])
+    assert np.array_equal(visual.to_numpy(visual.tensor2im(d("im.x").abs(), normalize=False)), g["im.raw"])
+    assert np.array_equal(visual.to_numpy(visual.tensor2im(d("w.x"), normalize=False)), g["w.raw"])
+    assert np.array_equal(visual.to_numpy(visual.tensor2im(d("seq.x"))), g["seq.norm"])
+    for n in (35, 20, 12):
+        assert np.array_equal(visual.to_numpy(visual.tensor2label(d("lab%d.x" % n), n)), g["lab%d.rgb" % n]), n
+        assert np.array_equal(visual.to_numpy(visual.tensor2label(d("lab%d.ids" % n), n)), g["lab%d.ids_rgb" % n]), n
+    import os, tempfile
+    from PIL import Image
+    tmp = tempfile.mkdtemp()
+    w = visual.AsyncImageWriter()
+    for i in range(4):
+        w.save(visual.tensor2label(d("lab35.x"), 35), os.path.join(tmp, "l%d.png" % i))
+    w.close()
+    assert np.array_equal(np.asarray(Image.open(os.path.join(tmp, "l3.png"))), g["lab35.rgb"])

@@ -378,6 +378,70 @@ def test_fused_adam_matches_torch():
     assert_close(p2.detach().cpu(), p1.detach(), 1e-6, "adam ttur")
 
 
+def test_fused_adam_grad_scale_is_the_mean_of_summed_gradients():
+    """v2v_adam_step(grad_scale = 1/world): the all-reduced SUM of the ranks' gradients is turned into the mean inside the
+    optimizer kernel (parallel.GradSync) -- equal to torch.optim.Adam stepped on the averaged gradients."""
+    import ctypes as C
+    from vid2vid_amd.lib import lib, check
+    from vid2vid_amd.optim import FusedAdam
+    torch.manual_seed(77)
+    world = 4
+    ref_p = nn.Parameter(torch.randn(1000))
+    dev_p = nn.Parameter(ref_p.detach().clone().to(DEV))
+    ref_opt = torch.optim.Adam([ref_p], lr=2e-4, betas=(0.5, 0.999))
+    opt = FusedAdam([dev_p], lr=2e-4, betas=(0.5, 0.999))
+
+    class FakeSync:                       # what GradSync.all_reduce returns after summing `world` ranks
+        world, force_collective = 1, False
+        def wait_pending(self): pass
+        def all_reduce(self, flat): return 1.0 / world
+
+    opt.grad_sync = FakeSync()
+    for it in range(3):
+        per_rank = [torch.randn(1000) for _ in range(world)]
+        ref_opt.zero_grad(); opt.zero_grad()
+        ref_p.grad = sum(per_rank) / world
+        dev_p.grad.add_(sum(per_rank).to(DEV))            # the buffer holds the SUM after the all-reduce
+        ref_opt.step(); opt.step()
+    assert_close(dev_p.detach().cpu(), ref_p.detach(), 1e-6, "adam with grad_scale = 1/world")
+
+
+def test_single_rank_rccl_overlapped_optimizer_step():
+    """The multi-GPU path on the one GPU there is: a world-size-1 `nccl` (= RCCL) process group, parallel.sync_optimizers
+    with the collective forced on.  FusedAdam.step enqueues the bucketed RCCL all-reduce and the Adam kernel on the side
+    stream behind the compute stream's backward work and returns; parameters read after parallel.wait_pending() equal a
+    plain (un-synchronised) FusedAdam's; zero_grad of the next step waits for the overlapped step by itself."""
+    import os, socket
+    import torch.distributed as dist
+    from vid2vid_amd import parallel
+    from vid2vid_amd.optim import FusedAdam
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(3)
+        shapes = [(64, 32, 3, 3), (64,), (300, 70)]
+        a = [nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+        b = [nn.Parameter(p.detach().clone()) for p in a]
+        oa, ob = FusedAdam(a, lr=1e-3, betas=(0.5, 0.999)), FusedAdam(b, lr=1e-3, betas=(0.5, 0.999))
+        gs = parallel.sync_optimizers([oa], bucket_bytes=16 << 10, force_collective=True)     # several buckets
+        assert len(gs.buckets(oa.flat.flat_grad)) > 2 and dist.get_backend() == "nccl"
+        for it in range(3):
+            oa.zero_grad(); ob.zero_grad()
+            for p, q in zip(a, b):
+                g = torch.randn_like(p)
+                p.grad.add_(g); q.grad.add_(g)
+            oa.step(); ob.step()
+            assert len(gs._pending) == 1                  # enqueued, not waited for
+        parallel.wait_pending()
+        torch.cuda.synchronize()
+        for p, q in zip(a, b):
+            assert torch.equal(p.detach(), q.detach()), "world 1: the all-reduce is the identity"
+    finally:
+        parallel._ACTIVE_SYNCS.clear()
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", [(1, 5, 16, 24), (2, 16, 17, 23), (1, 64, 8, 6), (1, 3, 2, 2)])
 def test_maxpool2_forward_backward(shape, prec):

@@ -17,39 +17,48 @@ static inline unsigned grid_for(long long n, int threads = 256, long long cap = 
 // encode_input + get_edges + compute_mask
 // ---------------------------------------------------------------------------------------
 struct EncodeArgs {
-    const float* labels; const float* inst; void* out; float* mask;
+    const void* labels; const void* inst; void* out; float* mask;
     int T, H, W, label_nc, c_stride; const int* fg; int n_fg;
 };
 
-template <typename T>
+// One thread per (pixel, 16-byte vector of output channels).  A vector spans at most two label frames (36 channels per
+// frame, 4 or 8 channels per vector): their labels are loaded ONCE per thread, the instance-edge test runs only for a
+// vector that holds an edge channel, and the vector leaves as ONE 16-byte store (round 1 issued 8 two-byte stores per
+// thread and re-read the label per channel: 45 us for the 33 MB output at 512x256, 7x off the HBM rate).
+// LT / IT: element types of the label / instance maps -- float (the reference's loader hands integers encoded as
+// floats, data/temporal_dataset.py:60-70) or uint8 / int32 (4x less host-to-device traffic for labels).
+template <typename T, typename LT, typename IT>
 __global__ __launch_bounds__(256) void encode_labels_kernel(const EncodeArgs a) {
-    // one thread per (pixel, 16-byte vector of output channels)
     constexpr int VEC = ElemTraits<T>::VEC;
     const int vpr = a.c_stride / VEC;
     const long long hw = (long long)a.H * a.W;
     const long long nvec = hw * vpr;
     const int per_frame = a.label_nc + (a.inst ? 1 : 0);
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const LT* labels = reinterpret_cast<const LT*>(a.labels);
+    const IT* inst = reinterpret_cast<const IT*>(a.inst);
     T* out = reinterpret_cast<T*>(a.out);
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         const long long pix = v / vpr;
         const int c0 = (int)(v - pix * vpr) * VEC;
-        const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);
+        const int t0 = c0 / per_frame, t1 = (c0 + VEC - 1) / per_frame;
+        const int lab0 = t0 < a.T ? (int)labels[t0 * hw + pix] : -1;
+        const int lab1 = (t1 != t0 && t1 < a.T) ? (int)labels[t1 * hw + pix] : -1;
         float o[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             const int ch = c0 + q;
+            const int t = ch >= (t0 + 1) * per_frame ? t1 : t0;
+            const int c = ch - t * per_frame;
             float val = 0.f;
-            const int t = ch / per_frame;
             if (t < a.T) {
-                const int c = ch - t * per_frame;
                 if (c < a.label_nc) {
-                    const int lab = (int)a.labels[t * hw + pix];
-                    val = (lab == c) ? 1.f : 0.f;
+                    val = ((t == t0 ? lab0 : lab1) == c) ? 1.f : 0.f;
                 } else {
                     // instance-boundary edge: 4-neighbour inequality (models/base_model.py:146-152)
-                    const float* ip = a.inst + t * hw;
-                    const float ctr = ip[pix];
+                    const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);
+                    const IT* ip = inst + t * hw;
+                    const IT ctr = ip[pix];
                     bool e = false;
                     if (x > 0)       e = e || (ip[pix - 1] != ctr);
                     if (x < a.W - 1) e = e || (ip[pix + 1] != ctr);
@@ -60,11 +69,20 @@ __global__ __launch_bounds__(256) void encode_labels_kernel(const EncodeArgs a) 
             }
             o[q] = val;
         }
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) store_act(out, pix * a.c_stride + c0 + q, o[q]);
+        const long long e0 = pix * a.c_stride + c0;
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(out + e0) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            uint4 pk;                                  // 0.0 / 1.0 are exact in bf16
+            pk.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16_bits(o[4]) | ((unsigned)f32_to_bf16_bits(o[5]) << 16);
+            pk.w = (unsigned)f32_to_bf16_bits(o[6]) | ((unsigned)f32_to_bf16_bits(o[7]) << 16);
+            *reinterpret_cast<uint4*>(out + e0) = pk;
+        }
         if (a.mask && c0 == 0) {
             // compute_mask (models/vid2vid_model_G.py:322-330) on the last frame
-            const int lab = (int)a.labels[(long long)(a.T - 1) * hw + pix];
+            const int lab = (int)labels[(long long)(a.T - 1) * hw + pix];
             float m = 0.f;
             for (int i = 0; i < a.n_fg; ++i) m += (a.fg[i] == lab) ? 1.f : 0.f;
             a.mask[pix] = fminf(fmaxf(m, 0.f), 1.f);
@@ -73,12 +91,18 @@ __global__ __launch_bounds__(256) void encode_labels_kernel(const EncodeArgs a) 
 }
 
 struct EncodeOp : Op {
-    EncodeArgs a; int dtype;
+    EncodeArgs a; int dtype; int in_u8 = 0;
     int launch(hipStream_t s) override {
         const int vec = dtype == V2V_BF16 ? 8 : 4;
         const long long nvec = (long long)a.H * a.W * (a.c_stride / vec);
-        if (dtype == V2V_BF16) hipLaunchKernelGGL(encode_labels_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, s, a);
-        else                   hipLaunchKernelGGL(encode_labels_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, a);
+        const dim3 g(grid_for(nvec)), b(256);
+        if (in_u8) {
+            if (dtype == V2V_BF16) hipLaunchKernelGGL((encode_labels_kernel<bf16_t, unsigned char, int>), g, b, 0, s, a);
+            else                   hipLaunchKernelGGL((encode_labels_kernel<float, unsigned char, int>), g, b, 0, s, a);
+        } else {
+            if (dtype == V2V_BF16) hipLaunchKernelGGL((encode_labels_kernel<bf16_t, float, float>), g, b, 0, s, a);
+            else                   hipLaunchKernelGGL((encode_labels_kernel<float, float, float>), g, b, 0, s, a);
+        }
         return check_launch();
     }
     const char* name() const override { return "encode_labels"; }
@@ -716,9 +740,25 @@ extern "C" int v2v_encode_labels(const float* labels, const float* inst, void* o
     if (!labels || !out || c_stride % vec != 0 || need > c_stride || (mask && n_fg > 0 && !fg_labels_dev)) {
         set_error("encode_labels: bad argument"); return V2V_EINVAL;
     }
+    if (((uintptr_t)out & 15) != 0) { set_error("encode_labels: output must be 16-byte aligned"); return V2V_EINVAL; }
     auto op = std::make_unique<EncodeOp>();
     op->a = EncodeArgs{labels, inst, out, mask, T, H, W, label_nc, c_stride, fg_labels_dev, n_fg};
     op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_encode_labels_u8(const uint8_t* labels, const int32_t* inst, void* out, float* mask,
+                                    int32_t T, int32_t H, int32_t W, int32_t label_nc, int32_t c_stride,
+                                    const int32_t* fg_labels_dev, int32_t n_fg, int32_t dtype, void* stream) {
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    const int need = T * (label_nc + (inst ? 1 : 0));
+    if (!labels || !out || c_stride % vec != 0 || need > c_stride || label_nc > 256 || (mask && n_fg > 0 && !fg_labels_dev) ||
+        ((uintptr_t)out & 15) != 0 || ((uintptr_t)inst & 3) != 0) {
+        set_error("encode_labels_u8: bad argument"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<EncodeOp>();
+    op->a = EncodeArgs{labels, inst, out, mask, T, H, W, label_nc, c_stride, fg_labels_dev, n_fg};
+    op->dtype = dtype; op->in_u8 = 1;
     return submit(std::move(op), stream);
 }
 

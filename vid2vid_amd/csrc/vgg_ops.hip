@@ -154,31 +154,37 @@ struct AvgPool2Op : Op {
 // `real_A[0][0, -1]` of Vid2VidModelG.inference (models/vid2vid_model_G.py:209) produced straight from the label map:
 // 4 bytes read per pixel, (label_nc + 1) * 4 written, fully coalesced along w (the NHWC -> NCHW unpack it replaces
 // moved the same bytes with 72-byte-strided reads).
-struct OneHotArgs { const float* labels; const float* inst; float* out; int H, W, label_nc; };
+struct OneHotArgs { const void* labels; const void* inst; float* out; int H, W, label_nc; };
 
+// LT / IT: float (the reference's float-encoded integers) or uint8 / int32 (v2v_onehot_planar_u8)
+template <typename LT, typename IT>
 __global__ __launch_bounds__(256) void onehot_planar_kernel(const OneHotArgs a) {
     const long long hw = (long long)a.H * a.W;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const LT* labels = reinterpret_cast<const LT*>(a.labels);
+    const IT* inst = reinterpret_cast<const IT*>(a.inst);
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += stride) {
-        const int lab = (int)a.labels[p];
+        const int lab = (int)labels[p];
         for (int c = 0; c < a.label_nc; ++c) a.out[(long long)c * hw + p] = (c == lab) ? 1.f : 0.f;
-        if (a.inst) {
+        if (inst) {
             const int y = (int)(p / a.W), x = (int)(p - (long long)y * a.W);
-            const float v = a.inst[p];
+            const IT v = inst[p];
             bool e = false;
-            if (x > 0)       e |= a.inst[p - 1] != v;
-            if (x + 1 < a.W) e |= a.inst[p + 1] != v;
-            if (y > 0)       e |= a.inst[p - a.W] != v;
-            if (y + 1 < a.H) e |= a.inst[p + a.W] != v;
+            if (x > 0)       e |= inst[p - 1] != v;
+            if (x + 1 < a.W) e |= inst[p + 1] != v;
+            if (y > 0)       e |= inst[p - a.W] != v;
+            if (y + 1 < a.H) e |= inst[p + a.W] != v;
             a.out[(long long)a.label_nc * hw + p] = e ? 1.f : 0.f;
         }
     }
 }
 
 struct OneHotOp : Op {
-    OneHotArgs a;
+    OneHotArgs a; int in_u8 = 0;
     int launch(hipStream_t s) override {
-        hipLaunchKernelGGL(onehot_planar_kernel, dim3(grid_for((long long)a.H * a.W)), dim3(256), 0, s, a);
+        const dim3 g(grid_for((long long)a.H * a.W)), b(256);
+        if (in_u8) hipLaunchKernelGGL((onehot_planar_kernel<unsigned char, int>), g, b, 0, s, a);
+        else       hipLaunchKernelGGL((onehot_planar_kernel<float, float>), g, b, 0, s, a);
         return check_launch();
     }
     const char* name() const override { return "onehot_planar"; }
@@ -225,5 +231,13 @@ extern "C" int v2v_onehot_planar(const float* labels, const float* inst, float* 
     if (!labels || !out || H <= 0 || W <= 0 || label_nc <= 0) { set_error("onehot_planar: bad argument"); return V2V_EINVAL; }
     auto op = std::make_unique<OneHotOp>();
     op->a = OneHotArgs{labels, inst, out, H, W, label_nc};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_onehot_planar_u8(const uint8_t* labels, const int32_t* inst, float* out, int32_t H, int32_t W,
+                                    int32_t label_nc, void* stream) {
+    if (!labels || !out || H <= 0 || W <= 0 || label_nc <= 0 || label_nc > 256) { set_error("onehot_planar_u8: bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<OneHotOp>();
+    op->a = OneHotArgs{labels, inst, out, H, W, label_nc}; op->in_u8 = 1;
     return submit(std::move(op), stream);
 }

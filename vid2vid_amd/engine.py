@@ -1090,8 +1090,16 @@ class Engine:
         if want_mask:
             fg = torch.tensor(list(fg_labels), dtype=torch.int32, device=self.device)
             self._keep(fg)
-        check(lib.v2v_encode_labels(_ptr(labels), _ptr(inst), _ptr(out.t), _ptr(mask), T, H, W, label_nc,
-                                    out.Cs, _ptr(fg), 0 if fg is None else fg.numel(), self.dtype, _stream()),
+        if labels.dtype == torch.uint8:              # uint8 label map + int32 instance map
+            if inst is not None and inst.dtype != torch.int32:
+                raise TypeError("uint8 label maps go with int32 instance maps")
+            fn = lib.v2v_encode_labels_u8
+        else:
+            if labels.dtype != torch.float32 or (inst is not None and inst.dtype != torch.float32):
+                raise TypeError("label / instance maps must be fp32-encoded integers, or uint8 + int32")
+            fn = lib.v2v_encode_labels
+        check(fn(_ptr(labels), _ptr(inst), _ptr(out.t), _ptr(mask), T, H, W, label_nc,
+                 out.Cs, _ptr(fg), 0 if fg is None else fg.numel(), self.dtype, _stream()),
               "encode_labels")
         self.label("encode_labels")
         return out, mask
@@ -1197,7 +1205,8 @@ class Engine:
         """Planar fp32 one-hot (+ edge plane) of one label frame: `real_A[0][0, -1]` (vid2vid_model_G.py:209)."""
         per = label_nc + (1 if inst is not None else 0)
         out = self.empty_f32(per, H, W)
-        check(lib.v2v_onehot_planar(_ptr(labels), _ptr(inst), _ptr(out), H, W, label_nc, _stream()), "onehot_planar")
+        fn = lib.v2v_onehot_planar_u8 if labels.dtype == torch.uint8 else lib.v2v_onehot_planar
+        check(fn(_ptr(labels), _ptr(inst), _ptr(out), H, W, label_nc, _stream()), "onehot_planar")
         self.label("onehot_planar")
         return out
 

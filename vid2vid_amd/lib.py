@@ -97,9 +97,13 @@ PROTOTYPES = {
     "v2v_avgpool2_planar": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "v2v_avgpool2_planar_backward": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "v2v_onehot_planar": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "v2v_onehot_planar_u8": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "v2v_instance_mean_workspace": (_L, [_I, _L]),
     "v2v_instance_mean_planar": (C.c_int, [_P, _P, _P, _P, _I, _L, _P]),
+    "v2v_tensor2im": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "v2v_tensor2label": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "v2v_encode_labels": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "v2v_encode_labels_u8": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "v2v_fg_mask_nhwc": (C.c_int, [_P, _P, _L, _I, _I, _P, _I, _I, _P]),
     "v2v_pack_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_unpack_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

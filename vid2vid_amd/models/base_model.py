@@ -58,6 +58,8 @@ class BaseModel(torch.nn.Module):
 
     def save_network(self, network, network_label, epoch_label, gpu_ids=None):
         os.makedirs(self.save_dir, exist_ok=True)
+        from .. import parallel
+        parallel.wait_pending()
         for m in network.modules():            # forwards counted on the host (engine._norm_params), written at save time
             nb = getattr(m, "_v2v_batches", 0)
             if nb and getattr(m, "num_batches_tracked", None) is not None:

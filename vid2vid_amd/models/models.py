@@ -21,6 +21,8 @@ class RankModel(nn.Module):
         self.module = model
 
     def forward(self, *inputs, **kwargs):
+        from .. import parallel
+        parallel.wait_pending()          # optimizer steps overlapped with the previous backward passes (parallel.GradSync)
         return self.module(*inputs, **kwargs)
 
 

@@ -54,7 +54,7 @@ def nearest_face_features(feat_map, inst, features, feat_num):
 class _FramePlan:
     """Buffers + launch sequence generating one frame at every spatial scale."""
 
-    def __init__(self, model, H, W, in_ch, has_inst, use_raw_only, use_graph=True):
+    def __init__(self, model, H, W, in_ch, has_inst, use_raw_only, use_graph=True, u8=False):
         opt, eng = model.opt, model.engine
         self.model, self.eng = model, eng
         self.H, self.W, self.use_raw_only = H, W, use_raw_only
@@ -63,8 +63,10 @@ class _FramePlan:
         dev = eng.device
         # ---- static inputs ----
         if self.label_mode:
-            self.labels = torch.zeros(tG, H, W, dtype=torch.float32, device=dev)
-            self.inst = torch.zeros(tG, H, W, dtype=torch.float32, device=dev) if has_inst else None
+            # fp32-encoded integers (the reference loader's format), or uint8 labels + int32 instance ids (SURVEY 8f-2:
+            # a quarter of the host-to-device bytes for the label maps; same one-hot / edge tensors bit for bit)
+            self.labels = torch.zeros(tG, H, W, dtype=torch.uint8 if u8 else torch.float32, device=dev)
+            self.inst = torch.zeros(tG, H, W, dtype=torch.int32 if u8 else torch.float32, device=dev) if has_inst else None
             self.raw_in = None
         else:
             self.labels = self.inst = None
@@ -303,13 +305,13 @@ class Vid2VidModelG(BaseModel):
         self.bind_precision()
 
     # ------------------------------------------------------------------ inference
-    def _frame_plan(self, H, W, in_ch, has_inst, use_raw_only):
-        key = (H, W, in_ch, has_inst, use_raw_only, self.precision)
+    def _frame_plan(self, H, W, in_ch, has_inst, use_raw_only, u8=False):
+        key = (H, W, in_ch, has_inst, use_raw_only, self.precision, u8)
         fp = self._plans.get(key)
         if fp is None:
             self.engine.refresh_weights()
             fp = _FramePlan(self, H, W, in_ch, has_inst, use_raw_only,
-                            use_graph=getattr(self.opt, "use_graph", True))
+                            use_graph=getattr(self.opt, "use_graph", True), u8=u8)
             self._plans[key] = fp
         return fp
 
@@ -324,13 +326,14 @@ class Vid2VidModelG(BaseModel):
             self.is_first_frame = not hasattr(self, "fake_B_prev") or self.fake_B_prev is None
             use_raw_only = bool(opt.no_first_img and self.is_first_frame)
             has_inst = bool(opt.use_instance and inst_A is not None and opt.label_nc != 0)
-            fp = self._frame_plan(H, W, in_ch, has_inst, use_raw_only)
+            u8 = bool(opt.label_nc != 0 and input_A.dtype == torch.uint8)
+            fp = self._frame_plan(H, W, in_ch, has_inst, use_raw_only, u8)
             dev = self.device
-            # ---- stage inputs (H2D or D2D) into the plan's static buffers ----
+            # ---- stage inputs (H2D or D2D) into the plan's static buffers; pinned host tensors copy asynchronously ----
             if fp.label_mode:
-                fp.labels.copy_(input_A[0, :tG, 0].to(dev, torch.float32, non_blocking=True))
+                fp.labels.copy_(input_A[0, :tG, 0].to(dev, fp.labels.dtype, non_blocking=True))
                 if has_inst:
-                    fp.inst.copy_(inst_A[0, :tG, 0].to(dev, torch.float32, non_blocking=True))
+                    fp.inst.copy_(inst_A[0, :tG, 0].to(dev, fp.inst.dtype, non_blocking=True))
             else:
                 fp.raw_in.copy_(input_A[0, :tG].reshape(1, tG * in_ch, H, W).to(dev, torch.float32, non_blocking=True))
             if self.is_first_frame:

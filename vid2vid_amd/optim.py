@@ -107,6 +107,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         from .lib import lib, check
+        if self.grad_sync is not None:
+            self.grad_sync.wait_pending()            # an overlapped step of the previous chunk still reads the gradients
         self.flat.rebind_grads()
         g = self.flat.flat_grad
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if g.is_cuda else None
@@ -123,16 +125,24 @@ class FusedAdam(torch.optim.Optimizer):
         if not f.flat_param.is_cuda and not lib.v2v_get_dry_run():
             raise RuntimeError("FusedAdam runs on the MI355X only")
         f.rebind_grads()
-        gscale = 1.0
-        if self.grad_sync is not None:
-            gscale = self.grad_sync.all_reduce(f.flat_grad)  # RCCL sum, bucketed; returns 1/world
         grp = self.param_groups[0]
         self.step_count += 1
         b1, b2 = grp["betas"]
-        check(lib.v2v_adam_step(C.c_void_p(f.flat_param.data_ptr()), C.c_void_p(f.flat_grad.data_ptr()),
-                                C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
-                                f.numel, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
-                                float(grp["weight_decay"]), float(gscale), self.step_count,
-                                C.c_void_p(torch.cuda.current_stream().cuda_stream) if f.flat_param.is_cuda else None), "adam_step")
+        step_no = self.step_count
+
+        def adam(gscale, stream):
+            sptr = None
+            if f.flat_param.is_cuda:
+                sptr = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+            check(lib.v2v_adam_step(C.c_void_p(f.flat_param.data_ptr()), C.c_void_p(f.flat_grad.data_ptr()),
+                                    C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+                                    f.numel, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
+                                    float(grp["weight_decay"]), float(gscale), step_no, sptr), "adam_step")
+
+        gs = self.grad_sync
+        if gs is not None and f.flat_param.is_cuda and (gs.world > 1 or gs.force_collective):
+            gs.run_overlapped(f.flat_grad, adam)     # RCCL all-reduce + Adam on the side stream, behind this backward pass
+        else:
+            adam(gs.all_reduce(f.flat_grad) if gs is not None else 1.0, None)
         f.epoch[0] += 1                                      # packed copies of THESE parameters are now stale
         return None

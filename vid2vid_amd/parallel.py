@@ -40,11 +40,25 @@ def init_distributed(backend=None):
 
 
 class GradSync:
-    """Bucketed in-place all-reduce (mean) of a flat gradient buffer."""
+    """Bucketed in-place all-reduce (sum) of a flat gradient buffer, overlapped with the NEXT backward pass.
 
-    def __init__(self, group=None, bucket_bytes=64 << 20):
+    train.py runs three backward passes per chunk back to back (loss_G -> optimizer_G.step, loss_D -> optimizer_D.step,
+    loss_D_T[s] -> optimizer_D_T[s].step, train.py:86-93).  On a GPU `FusedAdam.step` does not wait for the collective:
+    the all-reduce of optimizer k and its Adam kernel are enqueued on a SIDE stream behind an event of the compute stream,
+    which goes straight on to the next loss's backward -- G's 1.66 GB of fp32 gradients (~19 ms as a ring over 153 GB/s
+    xGMI links) travel while the discriminators' backward passes run.  The compute stream waits for the side stream only
+    where the updated parameters (or the gradient buffer) are next touched: the next forward of any model
+    (models.RankModel.forward -> wait_pending) and that optimizer's next zero_grad.  Gradients are NOT all-reduced
+    layer by layer inside a backward pass: the HIP backward kernels accumulate straight into the flat gradient views over
+    several frames and scales, so a bucket is only complete when its backward pass ends.
+    On CPU tensors (gloo tests) everything runs in order on the host."""
+
+    def __init__(self, group=None, bucket_bytes=64 << 20, force_collective=False):
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.force_collective = force_collective     # run the collective even for a world of 1 (single-GPU RCCL test)
+        self._stream = None
+        self._pending = []                           # events of enqueued (all-reduce + Adam) pairs
 
     @property
     def world(self):
@@ -55,56 +69,97 @@ class GradSync:
         return [flat[o:min(o + self.bucket_elems, n)] for o in range(0, n, self.bucket_elems)]
 
     def all_reduce(self, flat):
-        """Sum `flat` over the ranks in place; returns the factor (1/world) that turns the sum into the mean
-        the reference's DataParallel implies (losses are averaged over replicas, train.py:65).  The factor is
+        """Sum `flat` over the ranks in place, on the CURRENT stream; returns the factor (1/world) that turns the sum into
+        the mean the reference's DataParallel implies (losses are averaged over replicas, train.py:65).  The factor is
         applied inside the fused optimizer kernel (v2v_adam_step grad_scale): no extra pass over the buffer."""
         world = self.world
-        if world == 1:
+        if world == 1 and not (self.force_collective and dist.is_initialized()):
             return 1.0
         works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets(flat)]
         for w in works:
             w.wait()
         return 1.0 / world
 
+    # ---- overlap with the following backward pass (GPU only) ----
+    def side_stream(self, device):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def run_overlapped(self, flat, fn):
+        """Enqueue all_reduce(flat) followed by fn(grad_scale, stream) on the side stream, ordered after everything already
+        on the current stream; returns immediately.  fn launches the optimizer kernel on the stream it is handed."""
+        cur = torch.cuda.current_stream(flat.device)
+        side = self.side_stream(flat.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            scale = self.all_reduce(flat)
+            fn(scale, side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._pending.append(ev)
+
+    def wait_pending(self, device=None):
+        """The current stream waits for every enqueued (all-reduce + optimizer) pair: call before parameters or gradient
+        buffers are read or written again."""
+        if not self._pending:
+            return
+        cur = torch.cuda.current_stream(device)
+        for ev in self._pending:
+            cur.wait_event(ev)
+        self._pending = []
+
     def broadcast(self, flat, src=0):
         if self.world > 1:
             dist.broadcast(flat, src=src, group=self.group)
 
 
-def sync_optimizers(optimizers, group=None, bucket_bytes=64 << 20):
+_ACTIVE_SYNCS = []
+
+
+def sync_optimizers(optimizers, group=None, bucket_bytes=64 << 20, force_collective=False):
     """Attach a GradSync to each FusedAdam and make every rank start from rank 0's parameters."""
-    gs = GradSync(group, bucket_bytes)
+    gs = GradSync(group, bucket_bytes, force_collective)
     for opt in optimizers:
         opt.grad_sync = gs
         gs.broadcast(opt.flat.flat_param)
+    _ACTIVE_SYNCS.append(gs)
     return gs
 
 
-def frame_ranks(n_gpus_gen, world):
-    """Optional role split kept from the reference's `n_gpus_gen` flag (README.md:175-177): ranks
-    [0, n_gpus_gen) generate, the rest discriminate.  With pure data parallelism (the default, and the
-    right choice with 288 GB per GPU) every rank does both."""
-    if n_gpus_gen <= 0 or n_gpus_gen >= world:
-        return list(range(world)), list(range(world))
-    return list(range(n_gpus_gen)), list(range(n_gpus_gen, world))
+def wait_pending():
+    """Called by models.RankModel.forward (and by checkpoint saving): optimizer steps that were enqueued on the side stream
+    must have finished before any parameter is read on the compute stream."""
+    for gs in _ACTIVE_SYNCS:
+        gs.wait_pending()
 
 
 def shared_tuning_cache(rank, world):
     """N > 1 inference replicas: rank 0 runs the tile searches (per-shape + whole-frame), the other ranks replay its
-    selections through the tuning cache (`V2V_TUNE_CACHE`) -- the same kernels on every GPU instead of N independent, noisy
-    searches.  Call BEFORE the first engine exists.  Ranks > 0 return only after rank 0 has called the returned `release()`
-    (rank 0 calls it once its plan is built, i.e. once the cache file is complete); on ranks > 0 and in a single process
-    `release` is a no-op.  Does nothing when the user already set V2V_TUNE_CACHE."""
+    selections through their own tuning cache file (`V2V_TUNE_CACHE`) -- the same kernels on every GPU instead of N
+    independent, noisy searches.  Call BEFORE the first engine exists.  Ranks > 0 return only after rank 0 has called the
+    returned `release()` (rank 0 calls it once its plan is built): the selections travel by `broadcast_object_list`, so
+    ranks on other nodes get them too and no predictable shared path is involved (each rank writes a private temp file).
+    On ranks > 0 and in a single process `release` is a no-op.  Does nothing when the user already set V2V_TUNE_CACHE."""
     if world <= 1 or os.environ.get("V2V_TUNE_CACHE"):
         return lambda: None
+    import json
     import tempfile
-    cache = os.path.join(tempfile.gettempdir(), "v2v_tune_%s.json" % os.environ.get("MASTER_PORT", "0"))
+    fd, cache = tempfile.mkstemp(prefix="v2v_tune_rank%d_" % rank, suffix=".json")
+    os.close(fd)
+    os.remove(cache)                                 # the engine treats a missing file as "measure"
     os.environ["V2V_TUNE_CACHE"] = cache
-    if rank == 0 and os.path.exists(cache):
-        os.remove(cache)
-    dist.barrier()                                   # no stale file from an earlier job
     if rank == 0:
-        return dist.barrier                          # released by the caller once rank 0's selections are on disk
-    dist.barrier()                                   # wait for rank 0's selections
+        def release():
+            data = None
+            if os.path.exists(cache):
+                with open(cache) as f:
+                    data = json.load(f)
+            dist.broadcast_object_list([data], src=0)
+        return release
+    box = [None]
+    dist.broadcast_object_list(box, src=0)           # blocks until rank 0 releases
+    if box[0] is not None:
+        with open(cache, "w") as f:
+            json.dump(box[0], f)
     return lambda: None
-
