@@ -90,3 +90,16 @@ if has benchfinal; then
   cut -c1-400 gpurun_out/${TAG}_bench_final.json; tail -3 gpurun_out/${TAG}_bench_final.err
   lap benchfinal
 fi
+if has newtests2; then
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 600 -k "visualisation or uint8 or rccl or grad_scale or fused_adam" > gpurun_out/${TAG}_newtests2.log 2>&1; echo "newtests2 rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_newtests2.log | cut -c1-300 | tail -20
+  lap newtests2
+fi
+if has timeline; then
+  cd /tmp
+  timeout 500 rocprofv3 --kernel-trace -d /tmp/tl_$TAG -o bench -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_tl.json 2> $R/gpurun_out/${TAG}_bench_tl.err; echo "rocprof(timeline) rc=$?"
+  python $R/scripts/frame_timeline.py $(find /tmp/tl_$TAG -name "*.db" | head -1) > $R/gpurun_out/${TAG}_frame_timeline.txt 2>&1
+  head -4 $R/gpurun_out/${TAG}_frame_timeline.txt
+  cd $R
+  lap timeline
+fi

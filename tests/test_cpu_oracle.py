@@ -139,6 +139,35 @@ def test_channelnorm_hand_cases():
     assert O.channelnorm(x).item() == 5.0
 
 
+def test_native_ops_two_independent_restatements_agree():
+    """VERDICT r1 missing #7: the vectorised restatements (oracle/vid2vid_oracle.py) against the scalar-loop transliteration
+    of the .cu files' flat index arithmetic (oracle/native_ops_scalar.py: padded NHWC rInput copies, indx1 / indx2 / tindx,
+    per-lane channel walk + shuffle-down reduction) on FlowNetC's geometry (pad 20, displacement 20, stride2 2 -> 441
+    channels, FlowNetC.py:31), a 3x3-kernel / stride-2 geometry, flows that leave the image on every side, and > 32
+    channels (second round of the per-lane channel walk).  Tolerance 1e-6: only the fp32 summation order differs."""
+    import numpy as np
+    from oracle import native_ops_scalar as S2
+    rs = np.random.RandomState(11)
+    for (c, h, w, pad, k, disp, s1, s2) in [(5, 6, 7, 20, 1, 20, 1, 2), (40, 4, 5, 4, 1, 4, 1, 2), (3, 9, 10, 3, 3, 2, 2, 1)]:
+        a, b = rs.randn(2, c, h, w).astype(np.float32), rs.randn(2, c, h, w).astype(np.float32)
+        got = O.correlation(T(a), T(b), pad, k, disp, s1, s2).numpy()
+        ref = S2.correlation_forward(a, b, pad, k, disp, s1, s2)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (c, h, w, pad, k, disp, s1, s2)
+    img = rs.randn(2, 3, 7, 9).astype(np.float32)
+    flow = (rs.randn(2, 2, 7, 9) * 3.0).astype(np.float32)           # +-10 px on a 7x9 image: leaves it on every side
+    flow[0, :, 0, 0] = (-0.25, -0.75)                                 # negative fractional position at the corner
+    flow[0, :, 6, 8] = (0.5, 0.5)                                     # half a pixel beyond the bottom-right corner
+    flow[1, :, 3, 4] = (2.0, -1.0)                                    # integer displacement: alpha = beta = 0
+    got = O.resample2d(T(img), T(flow)).numpy()
+    ref = S2.resample2d_forward(img, flow)
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    x = rs.randn(2, 3, 5, 6).astype(np.float32)
+    assert np.abs(O.channelnorm(T(x)).numpy() - S2.channelnorm_forward(x)).max() <= 1e-6
+    x2 = rs.randn(1, 2, 4, 4).astype(np.float32)                      # the 2-channel (flow) use, models.py:137,150
+    assert np.abs(O.channelnorm(T(x2)).numpy() - S2.channelnorm_forward(x2)).max() <= 1e-6
+
+
 def test_flownet2_oracle_vs_reference_composition(golden):
     """oracle.flownet2 against the reference's FlowNet2 Python executed on CPU (fixture by make_golden.py;
     the three CUDA-only ops are the oracle's own restatements there, so this pins the composition)."""

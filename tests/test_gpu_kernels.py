@@ -554,16 +554,29 @@ def test_flownet2_native_ops():
         ad, bd = a.to(DEV), b.to(DEV)
         lib.check(lib.lib.v2v_correlation_forward(P(ad), P(bd), P(out), n, c, h, w, pad, k, md, s1, s2, 1, s), "corr")
         assert_close(out.cpu(), ref, 1e-5, "correlation %s" % ((n, c, h, w, pad, k, md, s1, s2),))
+    # the second, independent restatement (scalar transliteration of the .cu index arithmetic, oracle/native_ops_scalar.py)
+    # on FlowNetC's geometry class -- the LDS-staged kernel's fast path -- with ragged sizes and > 1 channel chunk
+    from oracle import native_ops_scalar as S2
+    for (n, c, h, w, md) in [(1, 19, 7, 37, 20), (2, 9, 6, 5, 4), (1, 8, 11, 70, 6)]:
+        a, b = torch.randn(n, c, h, w), torch.randn(n, c, h, w)
+        ref2 = torch.from_numpy(S2.correlation_forward(a.numpy(), b.numpy(), md, 1, md, 1, 2))
+        out = torch.full(ref2.shape, float("nan"), device=DEV)
+        ad, bd = a.to(DEV), b.to(DEV)
+        lib.check(lib.lib.v2v_correlation_forward(P(ad), P(bd), P(out), n, c, h, w, md, 1, md, 1, 2, 1, s), "corr")
+        assert_close(out.cpu(), ref2, 1e-5, "correlation (LDS-staged) vs scalar transliteration %s" % ((n, c, h, w, md),))
+        assert_close(out.cpu(), O.correlation(a, b, md, 1, md, 1, 2), 1e-5, "correlation (LDS-staged) vs vectorised oracle")
     img, fl = torch.randn(2, 3, 21, 33), torch.randn(2, 2, 21, 33) * 4
     out = torch.empty(2, 3, 21, 33, device=DEV)
     imd, fld = img.to(DEV), fl.to(DEV)
     lib.check(lib.lib.v2v_resample2d_forward(P(imd), P(fld), P(out), 2, 3, 21, 33, 21, 33, 1, s), "resample2d")
     assert_close(out.cpu(), O.resample2d(img, fl), 1e-5, "resample2d")
+    assert_close(out.cpu(), torch.from_numpy(S2.resample2d_forward(img.numpy(), fl.numpy())), 1e-5, "resample2d vs scalar transliteration")
     x = torch.randn(2, 3, 21, 33)
     out = torch.empty(2, 1, 21, 33, device=DEV)
     xd = x.to(DEV)
     lib.check(lib.lib.v2v_channelnorm_forward(P(xd), P(out), 2, 3, 21, 33, 2, s), "channelnorm")
     assert_close(out.cpu(), O.channelnorm(x), 1e-6, "channelnorm")
+    assert_close(out.cpu(), torch.from_numpy(S2.channelnorm_forward(x.numpy())), 1e-6, "channelnorm vs scalar transliteration")
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

@@ -8,6 +8,7 @@
 // here padding is a bounds test and every lane owns whole output pixels (coalesced along x),
 // so there is no scratch tensor and no cross-lane reduction at all.
 #include "v2v_internal.h"
+#include <cstdlib>
 
 namespace v2v {
 
@@ -69,6 +70,107 @@ __global__ __launch_bounds__(256) void correlation_kernel(const CorrArgs a) {
         }
     }
 }
+
+// ---- LDS-staged correlation for FlowNetC's geometry class (kernel_size 1, stride1 1, stride2 2, pad == max_disp) ----
+// out[n][tj*D + ti][y][x] = (1/C) sum_c f1[n][c][y][x] * f2[n][c][y + 2(tj - drad)][x + 2(ti - drad)]     (zero outside)
+// The kernel above gives every thread whole output pixels and reads both operands from global memory for each of the
+// D*D = 441 displacements: 287 us for the 512x256 frame pair (0.46 GFLOP; profiles/r01_v20_train_kernel_stats.txt).
+// Here a workgroup owns TWO output rows of the same parity (oy0, oy0 + 2: their 21 + 21 operand rows y + 2(tj - drad)
+// overlap in 20) x 32 columns, and walks the channels in chunks of 8:
+//   * stage: the 2 x 32 f1 values and the (D + 1) rows x (32 + 4 drad) columns of f2 for 8 channels go to LDS with
+//     coalesced loads; padding is a zero written at staging time; the f2 columns are stored split by PARITY
+//     ([even columns | odd columns]), so the D taps x + 2(ti - drad) of one pixel are D CONSECUTIVE floats;
+//   * compute: thread (row r, tj, strip) owns 4 same-parity pixels (x, x+2, x+4, x+6) x all D values of ti = 84
+//     accumulators; per channel it reads ONE 16-byte-aligned window of 24 floats (6 ds_read_b128) that serves all
+//     4 x 21 products -- 3.5 FMAs per LDS float instead of 1 global load per FMA.
+constexpr int CL_CC = 8, CL_TX = 32, CL_ROWS = 2, CL_DMAX = 21, CL_HALF = 36, CL_NR = CL_DMAX + CL_ROWS - 1;
+
+__global__ __launch_bounds__(384) void correlation_lds_kernel(const CorrArgs a) {
+    __shared__ __attribute__((aligned(16))) float f2s[CL_CC][CL_NR][2 * CL_HALF];
+    __shared__ float f1s[CL_CC][CL_ROWS][CL_TX];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z;
+    const int ox0 = blockIdx.x * CL_TX;
+    const int oy0 = (blockIdx.y >> 1) * 4 + (blockIdx.y & 1);          // rows oy0 and oy0 + 2
+    const int D = a.D, drad = a.drad;
+    const int ncols = CL_TX + 4 * drad, nrows = D + CL_ROWS - 1;
+    const long long hw = (long long)a.H * a.W;
+    const float* f1 = a.in1 + (long long)n * a.C * hw;
+    const float* f2 = a.in2 + (long long)n * a.C * hw;
+    // compute role
+    const bool worker = tid < CL_ROWS * CL_DMAX * 8;
+    const int r = tid / (CL_DMAX * 8), u = tid - r * (CL_DMAX * 8);
+    const int tj = u >> 3, strip = u & 7;
+    const int par = strip & 1, s4 = strip >> 1;
+    const bool active = worker && tj < D;
+    float acc[4][CL_DMAX];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < CL_DMAX; ++t) acc[k][t] = 0.f;
+
+    for (int c0 = 0; c0 < a.C; c0 += CL_CC) {
+        __syncthreads();                                             // previous chunk fully consumed
+        for (int e = tid; e < CL_CC * nrows * ncols; e += 384) {
+            const int c = e / (nrows * ncols);
+            const int rem = e - c * nrows * ncols;
+            const int q = rem / ncols, xx = rem - q * ncols;
+            const int y = oy0 - 2 * drad + 2 * q, x = ox0 - 2 * drad + xx;
+            float v = 0.f;
+            if (c0 + c < a.C && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) v = f2[(c0 + c) * hw + (long long)y * a.W + x];
+            f2s[c][q][(xx & 1) * CL_HALF + (xx >> 1)] = v;
+        }
+        for (int e = tid; e < CL_CC * CL_ROWS * CL_TX; e += 384) {
+            const int c = e / (CL_ROWS * CL_TX);
+            const int rem = e - c * CL_ROWS * CL_TX;
+            const int rr = rem / CL_TX, px = rem - rr * CL_TX;
+            const int y = oy0 + 2 * rr, x = ox0 + px;
+            float v = 0.f;
+            if (c0 + c < a.C && y < a.H && x < a.W) v = f1[(c0 + c) * hw + (long long)y * a.W + x];
+            f1s[c][rr][px] = v;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 2
+            for (int c = 0; c < CL_CC; ++c) {
+                // pixels px_k = par + 8*s4 + 2k; their taps live at parity `par`, index 4*s4 + k + t  (t = 0 .. D-1)
+                const float4* wv = reinterpret_cast<const float4*>(&f2s[c][r + tj][par * CL_HALF + 4 * s4]);
+                float w[24];
+#pragma unroll
+                for (int v = 0; v < 6; ++v) { const float4 t4 = wv[v]; w[4 * v] = t4.x; w[4 * v + 1] = t4.y; w[4 * v + 2] = t4.z; w[4 * v + 3] = t4.w; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v1 = f1s[c][r][par + 8 * s4 + 2 * k];
+#pragma unroll
+                    for (int t = 0; t < CL_DMAX; ++t) acc[k][t] += v1 * w[k + t];
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const int oy = oy0 + 2 * r;
+    if (oy >= a.OH) return;
+    const float inv = 1.f / (float)a.C;                               // kernel_size 1: nelems = C
+    const long long ohw = (long long)a.OH * a.OW;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ox = ox0 + par + 8 * s4 + 2 * k;
+        if (ox >= a.OW) continue;
+#pragma unroll
+        for (int t = 0; t < CL_DMAX; ++t)
+            if (t < D) a.out[((long long)n * D * D + tj * D + t) * ohw + (long long)oy * a.OW + ox] = acc[k][t] * inv;
+    }
+}
+
+struct CorrLdsOp : Op {
+    CorrArgs a;
+    int launch(hipStream_t s) override {
+        dim3 grid((unsigned)ceil_div(a.OW, CL_TX), (unsigned)(ceil_div(a.OH, 4) * 2), (unsigned)a.N);
+        hipLaunchKernelGGL(correlation_lds_kernel, grid, dim3(384), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "correlation"; }
+};
 
 struct CorrOp : Op {
     CorrArgs a;
@@ -379,6 +481,13 @@ extern "C" int v2v_correlation_forward(const float* in1, const float* in2, float
     int oc;
     v2v_correlation_out_size(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &a.OH, &a.OW);
     if (a.D > 64 || a.OH <= 0 || a.OW <= 0) { set_error("correlation: unsupported geometry"); return V2V_EINVAL; }
+    static const bool no_lds = getenv("V2V_CORR_LDS") && getenv("V2V_CORR_LDS")[0] == '0';
+    if (!no_lds && kernel_size == 1 && stride1 == 1 && stride2 == 2 && pad_size == max_displacement && (max_displacement & 1) == 0 &&
+        a.drad <= 10 && a.OH == H && a.OW == W) {                     // FlowNetC's geometry class (FlowNetC.py:31): LDS-staged kernel
+        auto op2 = std::make_unique<CorrLdsOp>();
+        op2->a = a;
+        return submit(std::move(op2), stream);
+    }
     auto op = std::make_unique<CorrOp>();
     op->a = a;
     return submit(std::move(op), stream);

@@ -969,13 +969,14 @@ class Engine:
         if isinstance(m, nn.Sigmoid): return L.ACT_SIGMOID, 0.0
         return None
 
-    def run_sequential(self, seq, x, extra_add=None, head_nchw=False, out_scale=1.0, name="", collect=None):
+    def run_sequential(self, seq, x, extra_add=None, head_nchw=False, out_scale=1.0, name="", collect=None, first_index=0):
         """Run an nn.Sequential (or list of modules) on Act `x`.
 
         extra_add: Act added to the output of the LAST stage (tower sums, coarse features).
         head_nchw: the last conv writes planar fp32 NCHW (API-facing heads).
         collect:   optional list receiving the output of every top-level module group
                    (MultiscaleDiscriminator.getIntermFeat).
+        first_index: index of seq[0] inside the nn.Sequential it was sliced from (labels keep the reference's numbering).
         """
         mods = list(seq)
         i, n = 0, len(mods)
@@ -999,7 +1000,7 @@ class Engine:
                 if i < n and self._act_code(mods[i]) is not None:
                     act, act_param = self._act_code(mods[i]); i += 1
                 last_group = i >= n
-                lbl = "%s.%d" % (name, i)
+                lbl = "%s.%d" % (name, first_index + i)
                 if norm is not None:
                     x = self.conv_group(x, conv, pad_mode, pad_override, norm, act, act_param,
                                         add0=extra_add if last_group else None, label=lbl)
@@ -1013,12 +1014,12 @@ class Engine:
             elif hasattr(m, "conv_block"):      # ResnetBlock (models/networks.py:554-593)
                 i += 1
                 last_group = i >= n
-                x = self.run_resblock(m, x, extra_add if last_group else None, "%s.%d" % (name, i - 1))
+                x = self.run_resblock(m, x, extra_add if last_group else None, "%s.%d" % (name, first_index + i - 1))
                 if last_group:
                     extra_add = None
             elif isinstance(m, nn.Sequential):
                 i += 1
-                x = self.run_sequential(m, x, name="%s.%d" % (name, i - 1))
+                x = self.run_sequential(m, x, name="%s.%d" % (name, first_index + i - 1))
             elif isinstance(m, nn.Dropout):
                 raise NotImplementedError("dropout is never enabled on the vid2vid path")
             else:

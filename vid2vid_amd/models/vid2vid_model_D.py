@@ -244,39 +244,64 @@ def get_skipped_frames(B_all, B, t_scales, tD):
 
 
 def get_skipped_flows(flowNet, flow_ref_all, conf_ref_all, real_B, flow_ref, conf_ref, t_scales, tD):
-    """Scale 0 re-uses the consecutive-frame flows; coarser temporal scales re-run FlowNet on the
-    strided frames (reference :292-302)."""
-    flow_sk, conf_sk = [None] * t_scales, [None] * t_scales
-    flow_ref_all, flow = get_skipped_frames(flow_ref_all, flow_ref, 1, tD)
-    conf_ref_all, conf = get_skipped_frames(conf_ref_all, conf_ref, 1, tD)
-    if flow[0] is not None:
-        flow_sk[0], conf_sk[0] = flow[0][:, 1:], conf[0][:, 1:]
+    """Reference flows / confidences for every temporal scale (behaviour of the reference's :292-302, written from its
+    specification: temporal scale 0 looks at tD consecutive frames and re-uses the tD-1 consecutive-frame flows FlowNet2 already
+    produced for the chunk; scale s >= 1 looks at tD frames that are tD**s apart, for which no flow exists yet, so
+    FlowNet2 runs on those strided neighbours -- but only once a full group of tD frames is available)."""
+    def scale0_groups(history, new):
+        # the same grouping as the frames of scale 0; a group of tD entries holds tD - 1 flows between its members
+        history, grouped = get_skipped_frames(history, new, 1, tD)
+        return history, (None if grouped[0] is None else grouped[0][:, 1:])
+
+    flow_ref_all, flow0 = scale0_groups(flow_ref_all, flow_ref)
+    conf_ref_all, conf0 = scale0_groups(conf_ref_all, conf_ref)
+    flows, confs = [flow0] + [None] * (t_scales - 1), [conf0] + [None] * (t_scales - 1)
     for s in range(1, t_scales):
-        if real_B[s] is not None and real_B[s].size(1) == tD:
-            flow_sk[s], conf_sk[s] = flowNet(real_B[s][:, 1:], real_B[s][:, :-1])
-    return flow_ref_all, conf_ref_all, flow_sk, conf_sk
+        frames = real_B[s]
+        if frames is None or frames.size(1) != tD:
+            continue                                  # not enough history at this spacing yet
+        later, earlier = frames[:, 1:], frames[:, :-1]
+        flows[s], confs[s] = flowNet(later, earlier)
+    return flow_ref_all, conf_ref_all, flows, confs
+
+
+def _sparse_first_index(i, step):
+    """Index inside the current chunk (whose first frame is frame i of the sequence) of the first frame that lies on the
+    every-`step`-th grid anchored at frame 0 of the generated sequence (frame 0 = chunk 0, index 0; afterwards the grid
+    continues from the previous chunk's frames, which end at global index i - 1)."""
+    if i == 0:
+        return 0
+    return (step - 1) - ((i - 1) % step)
 
 
 def get_skipped_frames_sparse(B_all, B, t_scales, tD, n_frames_load, i, is_flow=False):
-    """--sparse_D variant (reference :304-328): per-scale histories that only keep every tD**s-th frame."""
-    skipped = [None] * t_scales
-    _, _, ch, h, w = B.size()
+    """--sparse_D bookkeeping (behaviour of the reference's :304-328, written from its specification).  Instead of one dense
+    history that every temporal scale strides through, each scale s keeps only the frames it will ever look at (every
+    tD**s-th frame), in groups of tD:
+      * before appending, a history whose length is a whole number of groups is cut down to its last tD - 1 frames (the
+        overlap the next group shares with it);
+      * scale 0 appends the whole chunk, scale s >= 1 the chunk's frames that fall on its grid;
+      * once at least tD frames are held, the oldest (length mod tD) frames are dropped and the rest is served as groups
+        of tD; for flows / confidences the first entry of every group is dropped (tD frames <-> tD - 1 flows).
+    B_all is the per-scale list of histories (updated in place and returned)."""
+    ch, h, w = B.shape[2:]
+    served = [None] * t_scales
     for s in range(t_scales):
-        t_len = B_all[s].size(1) if B_all[s] is not None else 0
-        if t_len > 0 and (t_len % tD) == 0:
-            B_all[s] = B_all[s][:, (-tD + 1):]
+        hist = B_all[s]
+        if hist is not None and hist.size(1) > 0 and hist.size(1) % tD == 0:
+            hist = hist[:, hist.size(1) - (tD - 1):]
         if s == 0:
-            B_all[0] = B if B_all[0] is None else torch.cat([B_all[0].detach(), B], dim=1)
+            fresh = B
         else:
             step = tD ** s
-            start = 0 if i == 0 else step - ((i - 1) % step + 1)
-            if start < n_frames_load:
-                tmp = B[:, start::step].contiguous()
-                B_all[s] = tmp if B_all[s] is None else torch.cat([B_all[s].detach(), tmp], dim=1)
-        t_len = B_all[s].size(1) if B_all[s] is not None else 0
-        if t_len >= tD:
-            B_all[s] = B_all[s][:, (t_len % tD):]
-            skipped[s] = B_all[s].reshape(-1, tD, ch, h, w)
-            if is_flow:
-                skipped[s] = skipped[s][:, 1:]
-    return B_all, skipped
+            first = _sparse_first_index(i, step)
+            fresh = B[:, first::step].contiguous() if first < n_frames_load else None
+        if fresh is not None:
+            hist = fresh if hist is None else torch.cat([hist.detach(), fresh], dim=1)
+        held = 0 if hist is None else hist.size(1)
+        if held >= tD:
+            hist = hist[:, held % tD:]
+            groups = hist.reshape(-1, tD, ch, h, w)
+            served[s] = groups[:, 1:] if is_flow else groups
+        B_all[s] = hist
+    return B_all, served

@@ -336,10 +336,14 @@ class CompositeGenerator(BaseNetwork):
             head_seg, blocks_seg = split(self.model_down_seg)
             head_img, blocks_img = split(self.model_down_img)
             with eng.on_lane(1):
-                seg = eng.run_sequential(head_seg, x, name=tag + ".down_seg")
-            if self.use_fg_model and lanes:
-                with eng.on_lane(2):
-                    img_fg_feat, img_fg = fg_tower()
+                # the label stem (108 -> 128, 7x7 at full resolution: 178 GFLOP) heads the frame's critical path: the
+                # foreground tower (far off that path) forks only behind it instead of competing with it for the chip
+                k_stem = next((i + 1 for i, m in enumerate(head_seg) if isinstance(m, nn.ReLU)), len(head_seg))
+                seg = eng.run_sequential(head_seg[:k_stem], x, name=tag + ".down_seg")
+                if self.use_fg_model and lanes:
+                    with eng.on_lane(2):
+                        img_fg_feat, img_fg = fg_tower()
+                seg = eng.run_sequential(head_seg[k_stem:], seg, name=tag + ".down_seg", first_index=k_stem)
             img = eng.run_sequential(head_img, prev, name=tag + ".down_img")
             eng.join(1)
             seg, img = eng.run_resblocks_twin(blocks_seg, seg, blocks_img, img, tag + ".down_seg", tag + ".down_img",
