@@ -417,7 +417,7 @@ def main():
             n32 = max(args.steps // 2, 5)
             fp32_line = {"value": round(n32 / el32, 3), "unit": "frames/s", "ms_per_step": round(el32 / n32 * 1e3, 4),
                          "steps": n32, "dtype": "fp32 (v_mfma_f32_32x32x2_f32, exact)",
-                         "frac_of_fp32_mfma_peak": round(sum(c["flops"] for c in model32._active_plan.conv_log) / (el32 / n32) / 1e12 / PEAK_TFLOPS["fp32"], 4)}
+                         "frac_of_fp32_mfma_peak": round(sum(c["flops"] for c in model32._active_plan.conv_log if not c.get("onehot")) / (el32 / n32) / 1e12 / PEAK_TFLOPS["fp32"], 4)}
             del model32
             torch.cuda.empty_cache()
 
@@ -432,10 +432,11 @@ def main():
     if rank == 0:
         # one entry per LAUNCH: the two members of a paired launch (v2v_conv2d_pair) are one kernel
         launches, i = [], 0
-        while i < len(fp.conv_log):
-            c = fp.conv_log[i]
+        mfma_log = [c for c in fp.conv_log if not c.get("onehot")]       # one-hot stems are gather-sums, not conv2d launches
+        while i < len(mfma_log):
+            c = mfma_log[i]
             if c.get("pair"):
-                c2 = fp.conv_log[i + 1]
+                c2 = mfma_log[i + 1]
                 launches.append(dict(c, flops=c["flops"] + c2["flops"], label=c["label"] + " + " + c2["label"], members=2))
                 i += 2
             else:
@@ -497,7 +498,7 @@ def main():
                     break
         except Exception:
             pass
-        frame_flops = sum(c["flops"] for c in fp.conv_log)
+        frame_flops = sum(c["flops"] for c in mfma_log)          # executed MFMA work (gather-sum stems excluded)
         roofline = {
             "bound": "mfma",
             "kernel": "%s<%s,%s> (tile config %d)" % (fam, "bf16" if args.precision == "bf16" else "f32", tile_name, dom[0]),
@@ -511,7 +512,7 @@ def main():
             "resblock_1024_tflops": None if rb_tf is None else round(rb_tf, 2),
             "frame_in_graph": {"achieved": round(frame_flops / (elapsed / args.steps) / 1e12, 2),
                                "unit": "TFLOP/s", "frac": round(frame_flops / (elapsed / args.steps) / 1e12 / peak, 4),
-                               "note": "all conv FLOP of a frame / measured ms_per_step (norms, pooling, warp included in the time)"},
+                               "note": "all MFMA conv FLOP executed per frame / measured ms_per_step (norms, pooling, warp, gather-sum stems included in the time)"},
             "frame_ms_eager_events": round(sum(ms for _, _, ms in rows), 3),
             "per_kernel_ms": {k: round(v, 3) for k, v in sorted(total_ms.items(), key=lambda kv: -kv[1])},
         }
@@ -530,9 +531,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%s %dx%d inference, n_scales_spatial=%d, %s, ngf=128 n_blocks=9 "
-                                   "(%.1fM params random-init, %.0f GFLOP/frame), batch 1 per sequence, 1 sequence per GPU"
+                                   "(%.1fM params random-init, %.0f GFLOP/frame as dense convolutions%s), batch 1 per sequence, 1 sequence per GPU"
                                    % (args.dataset, W, H, args.scales, "input_nc=15, no fg tower" if face else "--fg --use_instance", sum(q.numel() for q in model.parameters()) / 1e6,
-                                      sum(c["flops"] for c in fp.conv_log) / 1e9),
+                                      sum(c["flops"] for c in fp.conv_log) / 1e9,
+                                      (", of which the %d one-hot label stems (%.0f GFLOP dense) run as exact weight gather-sums"
+                                       % (sum(1 for c in fp.conv_log if c.get("onehot")), sum(c["flops"] for c in fp.conv_log if c.get("onehot")) / 1e9))
+                                      if any(c.get("onehot") for c in fp.conv_log) else ""),
                        "launches_per_frame": fp.plan.num_ops, "hipgraph": bool(opt.use_graph),
                        "graph_lanes": 3 if getattr(fp, "lanes", False) else 1,
                        "paired_launches": bool(getattr(fp, "twin", False)),

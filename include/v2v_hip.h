@@ -425,6 +425,26 @@ int v2v_tensor2im(const float* x, uint8_t* out, int32_t C, int32_t H, int32_t W,
 int v2v_tensor2label(const float* x, uint8_t* out, const uint8_t* cmap, int32_t n_label, int32_t C, int32_t H, int32_t W,
                      void* stream);
 
+/* 7x7 stem convolution over one-hot label input as a weight gather-sum.  Replaces, for label-map input,
+ * encode_input (models/vid2vid_model_G.py:86-112) + ReflectionPad2d(3) + Conv2d(T*(label_nc+1), cout, 7) at the head of
+ * the label and foreground towers (models/networks.py:128-133, 153-156): per output pixel and tap exactly one label
+ * plane per frame is 1, so the convolution is T gathered weight rows (+ the edge row where the instance map has an
+ * edge) per tap -- 1/36 of the dense operations, same sums.  Output: raw fp32 NHWC [H][W][cout_stride] (bias added)
+ * + optional per-tile statistics rows [v2v_onehot_conv_stats_rows(H,W)][cout][2] for v2v_bn_finalize, exactly like
+ * v2v_conv2d with V2V_OUT_RAW_F32_NHWC.  labels / inst: [T][H][W] fp32-encoded integers (in_u8 = 0) or uint8 / int32
+ * (in_u8 = 1); inst may be NULL (no edge plane; the layer then has T*label_nc input channels).  Labels outside
+ * [0, label_nc) select no plane.
+ * table: v2v_onehot_conv_table_bytes(cin, cout, dtype, slice) bytes, filled by v2v_onehot_conv_pack_weights from the
+ * layer's fp32 [cout][cin][7][7] weight (cin = T * (label_nc + (inst ? 1 : 0))).  cout <= 128.
+ * slice: output channels per workgroup, 32 or 64, 0 = default; the same value must be given to all three calls. */
+int64_t v2v_onehot_conv_table_bytes(int32_t cin, int32_t cout, int32_t dtype, int32_t slice);
+int     v2v_onehot_conv_pack_weights(const float* w, void* table, int32_t cin, int32_t cout, int32_t dtype, int32_t slice,
+                                     void* stream);
+int     v2v_onehot_conv_stats_rows(int32_t H, int32_t W);
+int     v2v_onehot_conv7x7(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
+                           float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
+                           int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, void* stream);
+
 /* recordable device-to-device copy (rolling fake_B_prev window, vid2vid_model_G.py:228) */
 int v2v_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);
 

@@ -103,3 +103,27 @@ if has timeline; then
   cd $R
   lap timeline
 fi
+if has stem; then
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "onehot_stem or flownet2_native" > gpurun_out/${TAG}_stemtest.log 2>&1; echo "stem/native tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_stemtest.log | cut -c1-300 | tail -20
+  timeout 300 python scripts/stem_bench.py bf16 > gpurun_out/${TAG}_stem_bench.txt 2>&1; echo "stem bench rc=$?"
+  cat gpurun_out/${TAG}_stem_bench.txt | cut -c1-200
+  lap stem
+fi
+if has ubench; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value scripts/ubench/valu_rate.hip -o /tmp/valu_rate && timeout 120 /tmp/valu_rate > gpurun_out/${TAG}_valu_rate.txt 2>&1; echo "ubench rc=$?"
+  cat gpurun_out/${TAG}_valu_rate.txt
+  lap ubench
+fi
+if has stemtest; then
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "onehot_stem or flownet2_native" > gpurun_out/${TAG}_stemtest.log 2>&1; echo "stem/native tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_stemtest.log | cut -c1-300 | tail -20
+  lap stemtest
+fi
+if has stemab; then
+  for oh in 1 0 1 0; do
+    V2V_ONEHOT_STEM=$oh timeout 500 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_oh$oh.json 2> gpurun_out/${TAG}_bench_oh$oh.err; echo "bench onehot=$oh rc=$?"
+    cut -c1-200 gpurun_out/${TAG}_bench_oh$oh.json
+  done
+  lap stemab
+fi

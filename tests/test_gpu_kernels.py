@@ -495,6 +495,57 @@ def test_encode_labels_and_mask(prec):
     assert_close(m2, ref_m.reshape(m2.shape), 1e-6 if prec == "fp32" else 2e-2, "coarse fg mask")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(64, 37, 70, True, 0), (128, 40, 96, True, 64), (128, 40, 96, False, 32), (48, 19, 33, True, 64),
+                                  (100, 64, 64, False, 0)])
+@torch.no_grad()
+def test_onehot_stem_equals_dense_conv_on_the_encoding(case, prec):
+    """csrc/onehot_stem.hip: the 7x7 reflection-padded stem over encoded label maps as a weight gather-sum.  Checked
+    against the definition (oracle encode_input + ReflectionPad2d(3) + conv in fp64) and against this library's own dense
+    path on the materialised encoding; fp32-encoded and uint8 / int32 maps give the same bits."""
+    from oracle import vid2vid_oracle as O
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, check
+    cout, H, W, use_inst, slice_ = case
+    torch.manual_seed(31 + cout)
+    eng = _engine(prec)
+    eng.onehot_slice = slice_
+    T, nc = 3, 35
+    lab = torch.randint(0, nc, (T, H // 3 + 1, W // 5 + 1)).repeat_interleave(3, 1).repeat_interleave(5, 2)[:, :H, :W].float()
+    lab[0, :2, :3] = 200.0                                # out-of-range ids: no plane is hot (scatter_ would fault; encode drops them)
+    lab_ok = lab.clone(); lab_ok[0, :2, :3] = 0.0
+    inst = torch.randint(0, 4, (T, H // 4 + 1, W // 4 + 1)).repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :H, :W].float()
+    per = nc + (1 if use_inst else 0)
+    conv = nn.Conv2d(T * per, cout, 7, padding=0).to(DEV)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    enc = O.encode_input(lab_ok.view(1, T, 1, H, W), inst.view(1, T, 1, H, W) if use_inst else None, nc).reshape(1, T * per, H, W)
+    enc[0, 0:nc, :2, :3] = 0.0                             # the dropped pixels of frame 0
+    w = _round(conv.weight.detach().cpu(), prec)
+    ref = F.conv2d(F.pad(enc.double(), (3, 3, 3, 3), mode="reflect"), w.double(), conv.bias.detach().cpu().double())
+    for u8 in (False, True):
+        labels = lab.to(DEV).to(torch.uint8) if u8 else lab.to(DEV)
+        insts = None if not use_inst else (inst.to(DEV).to(torch.int32) if u8 else inst.to(DEV))
+        x, _ = eng.encode_labels(labels, insts, T, H, W, nc, (), False)
+        assert eng.onehot_eligible(x, conv, L.PAD_REFLECT, 3)
+        raw, rows, shp = eng.onehot_conv(x, conv, label="stem")
+        cs = (cout + 3) // 4 * 4
+        got = raw[:H * W * cs].view(H, W, cs)[..., :cout].permute(2, 0, 1).cpu()
+        assert_close(got, ref[0].float(), 2e-6, "onehot stem vs definition (%s, u8=%s)" % (prec, u8))
+        st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).cpu().double().sum(0)
+        assert_close(st[:, 0].float(), ref[0].sum((1, 2)).float(), 1e-5, "stats: sum")
+        assert_close(st[:, 1].float(), (ref[0] ** 2).sum((1, 2)).float(), 1e-5, "stats: sum of squares")
+        if u8:
+            assert torch.equal(got, first)
+        first = got
+    # whole group (norm + ReLU) vs this library's dense convolution on the materialised encoding
+    y1 = eng.unpack(eng.conv_group(x, conv, L.PAD_REFLECT, 3, norm, L.ACT_RELU, 0.0, label="stem")).cpu()
+    assert eng.conv_log[-1].get("onehot")
+    eng.onehot_stem = False
+    y0 = eng.unpack(eng.conv_group(x, conv, L.PAD_REFLECT, 3, norm, L.ACT_RELU, 0.0, label="stem")).cpu()
+    assert not eng.conv_log[-1].get("onehot")
+    assert_close(y1, y0, 1e-5 if prec == "fp32" else 3e-2, "stem group: gather-sum vs dense")
+
+
 def test_avgpool_planar_and_add():
     from oracle import vid2vid_oracle as O
     torch.manual_seed(6)

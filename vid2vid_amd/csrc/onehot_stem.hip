@@ -13,65 +13,103 @@
 // is T gathered weight rows (plus a rare edge row) per tap: 36x fewer operations, exact in fp32.  The one-hot
 // tensor is never read -- for n_scales_spatial = 1 it is not even materialised.
 //
-// Workgroup = 256 threads = TH x TW = 8 x 32 output pixels, thread = pixel, COUT fp32 accumulators in registers.
-// Per tap the [T*per][COUT] weight slab goes to LDS (register-staged so that rows can be PADDED by 16 bytes: lanes that
-// read different rows then hit different banks; lanes that read the same row -- the common case, labels are piecewise
-// constant -- broadcast), double buffered; labels and edges of the tile + 3-pixel halo (reflection applied) sit in LDS as
-// bytes.  Epilogue: raw fp32 NHWC output + the per-tile (sum, sum^2) statistics row of the training-mode norm that
-// follows, reduced over the 64 lanes by recursive halving (deterministic, no atomics).
+// Workgroup = 256 threads = 8 x 32 output pixels x one SLICE of CS = 32 or 64 output channels (gridDim.y slices),
+// thread = pixel, CS fp32 accumulators in registers.  The packed table is [49 taps][slices][blob]: a blob is the slice's
+// [T*per + 1][CS] weight rows (the extra row is zero: out-of-range labels and "no edge" point there, the inner loop has
+// no branches), each row PADDED by 16 bytes in global memory already, so that one tap's blob goes to LDS with plain
+// LDS-DMA (global_load_lds_dwordx4, no registers), double buffered, one barrier per tap, and lanes that read different
+// rows hit different banks (lanes that read the same row -- labels are piecewise constant -- broadcast).  The tile's
+// labels / edges (+ 3-pixel halo, reflection applied) sit in LDS as ready-made 16-bit row offsets.
+// bf16 rows are accumulated with v_dot2c_f32_bf16 against the constant pairs (1, 0) / (0, 1): unpack + fp32 add in one
+// VALU instruction (scripts/ubench/valu_rate.hip: 4.4 cycles vs 4.1 + 2.5 for shift/and + v_add_f32; v_pk_add_f32 is
+// slower than two v_add_f32 on gfx950).  The selectors live in SGPRs: as INLINE constants the assembler's "1.0" is not
+// what the bf16 operand decodes (measured: wrong sums).
+// Epilogue: raw fp32 NHWC output (coalesced through LDS) + the per-tile (sum, sum^2) statistics row of the
+// training-mode norm that follows (fixed summation order, no atomics).
 #include "v2v_internal.h"
 
 namespace v2v {
 
 struct OneHotConvArgs {
     const void* labels; const void* inst;     // [T][H][W] float or uint8 / int32
-    const void* table;                        // [49][T*per][COUT] activation dtype
+    const char* table;                        // [49][slices][blob bytes]
     const float* bias;                        // [cout] or NULL
     float* out; float* stats;                 // raw fp32 NHWC [H][W][cout_stride]; [tiles][cout][2] or NULL
-    int T, H, W, label_nc, per, cout, cout_stride, tiles_w, in_u8;
+    int T, H, W, label_nc, per, cout, cout_stride, tiles_w, in_u8, blob;
+    unsigned sel_lo, sel_hi;                  // bf16 pairs (1, 0) and (0, 1)
 };
 
-constexpr int OS_TH = 8, OS_TW = 32, OS_PH = OS_TH + 6, OS_PW = OS_TW + 6;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot_sel(unsigned v, unsigned sel, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, v), __builtin_bit_cast(bf16x2_t, sel), acc, false);
+}
+// LDS-DMA as inline assembly, not __builtin_amdgcn_global_load_lds: the waitcnt pass cannot tell the two table buffers
+// apart (run-time offsets) and puts s_waitcnt vmcnt(0) in front of every row read while the next tap's DMA is in flight,
+// which serialises copy and compute.  The kernel orders DMA and reads itself (vmcnt(0) + barrier once per tap).
+__device__ __forceinline__ void os_glds16(const char* g, unsigned lds_addr) {      // lds_addr: wave-uniform LDS byte address
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
 
-template <typename T, int COUT>
-__global__ __launch_bounds__(256) void onehot_conv7x7_kernel(const OneHotConvArgs a) {
+constexpr int OS_TH = 8, OS_TW = 32, OS_PH = OS_TH + 6, OS_PW = OS_TW + 6, OS_PHW = OS_PH * OS_PW;
+constexpr size_t OS_EPI_LDS = (256 * 33 + 8 * 32 * 2) * sizeof(float);    // epilogue tile + partial sums
+
+__host__ __device__ constexpr int os_rowb(int cs, int es) { return cs * es + 16; }
+__host__ __device__ inline int os_blob(int rows, int cs, int es) { return ((rows + 1) * os_rowb(cs, es) + 1023) / 1024 * 1024; }
+
+// NT: frames per input (n_frames_G), 0 = run-time loop
+template <typename T, int CS, int NT>
+__global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(const OneHotConvArgs a) {
     constexpr int ES = (int)sizeof(T);
-    constexpr int ROWB = COUT * ES + 16;                   // padded row: 4 banks of skew per row
-    constexpr int VPR = COUT * ES / 16;                    // 16-byte vectors per row
-    constexpr int EPV = 16 / ES;                           // elements per vector
+    constexpr int ROWB = os_rowb(CS, ES);
+    constexpr int VPR = CS * ES / 16;                      // 16-byte vectors per row
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int rows = a.T * a.per;
-    const int slab = rows * ROWB;
+    const int nT = NT ? NT : a.T;
+    const int rows = nT * a.per;
+    const unsigned zero_off = (unsigned)rows * ROWB;       // the appended all-zero row
     char* const tb0 = smem;
-    char* const tb1 = smem + slab;
-    unsigned char* const lab_s = reinterpret_cast<unsigned char*>(smem + 2 * slab);          // [T][PH][PW]
-    unsigned char* const edg_s = lab_s + a.T * OS_PH * OS_PW;                                 // [T][PH][PW]
+    char* const tb1 = smem + a.blob;
+    unsigned short* const off_s = reinterpret_cast<unsigned short*>(smem + 2 * a.blob);     // [T][PH][PW] row offsets
+    unsigned short* const eoff_s = off_s + nT * OS_PHW;                                      // edge-row offset or zero_off
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int c0 = blockIdx.y * CS;                        // this workgroup's channel slice [c0, c0 + CS)
     const int ty = blockIdx.x / a.tiles_w, tx = blockIdx.x - ty * a.tiles_w;
     const int oh0 = ty * OS_TH, ow0 = tx * OS_TW;
     const int py = tid >> 5, px = tid & 31;
     const int H = a.H, W = a.W;
     const long long hw = (long long)H * W;
+    const int npieces = a.blob >> 10;
+    const char* const tslice = a.table + (long long)blockIdx.y * a.blob;
+    const long long tap_stride = (long long)gridDim.y * a.blob;
 
-    // ---- labels / edges of the tile + halo, reflection applied (ReflectionPad2d(3) of the encoded tensor) ----
-    for (int e = tid; e < a.T * OS_PH * OS_PW; e += 256) {
-        const int t = e / (OS_PH * OS_PW);
-        const int rem = e - t * OS_PH * OS_PW;
+    auto issue = [&](int tap, char* dst) {                 // wave w: pieces w, w + 4, ...
+        const char* src = tslice + tap * tap_stride + lane * 16;
+        const unsigned d = lds_addr_of(dst);
+        for (int p = wid; p < npieces; p += 4) os_glds16(src + p * 1024, d + p * 1024);
+    };
+    issue(0, tb0);
+
+    // ---- row offsets of the tile + halo, reflection applied (ReflectionPad2d(3) of the encoded tensor) ----
+    for (int e = tid; e < nT * OS_PHW; e += 256) {
+        const int t = e / OS_PHW;
+        const int rem = e - t * OS_PHW;
         const int qy = rem / OS_PW, qx = rem - qy * OS_PW;
         int y = oh0 + qy - 3, x = ow0 + qx - 3;
         y = y < 0 ? -y : y;  y = y >= H ? 2 * H - 2 - y : y;
         x = x < 0 ? -x : x;  x = x >= W ? 2 * W - 2 - x : x;
         y = y < 0 ? 0 : (y >= H ? H - 1 : y);              // tile overhang beyond the mirror: any valid pixel, output is masked
         x = x < 0 ? 0 : (x >= W ? W - 1 : x);
-        const long long p = (long long)t * hw + (long long)y * W + x;
+        const long long q = (long long)y * W + x;
+        const long long p = (long long)t * hw + q;
         int lab;
         bool edge = false;
         if (a.in_u8) {
             lab = reinterpret_cast<const unsigned char*>(a.labels)[p];
             if (a.inst) {
                 const int* ip = reinterpret_cast<const int*>(a.inst) + (long long)t * hw;
-                const long long q = (long long)y * W + x;
                 const int ctr = ip[q];
                 if (x > 0)     edge |= ip[q - 1] != ctr;
                 if (x < W - 1) edge |= ip[q + 1] != ctr;
@@ -82,7 +120,6 @@ __global__ __launch_bounds__(256) void onehot_conv7x7_kernel(const OneHotConvArg
             lab = (int)reinterpret_cast<const float*>(a.labels)[p];
             if (a.inst) {
                 const float* ip = reinterpret_cast<const float*>(a.inst) + (long long)t * hw;
-                const long long q = (long long)y * W + x;
                 const float ctr = ip[q];
                 if (x > 0)     edge |= ip[q - 1] != ctr;
                 if (x < W - 1) edge |= ip[q + 1] != ctr;
@@ -90,25 +127,14 @@ __global__ __launch_bounds__(256) void onehot_conv7x7_kernel(const OneHotConvArg
                 if (y < H - 1) edge |= ip[q + W] != ctr;
             }
         }
-        lab_s[e] = (unsigned char)((unsigned)lab < (unsigned)a.label_nc ? lab : 255);       // 255: no plane is hot
-        edg_s[e] = edge ? 1 : 0;
+        off_s[e] = (unsigned short)((unsigned)lab < (unsigned)a.label_nc ? (unsigned)(t * a.per + lab) * ROWB : zero_off);
+        eoff_s[e] = (unsigned short)(edge ? (unsigned)(t * a.per + a.label_nc) * ROWB : zero_off);
     }
 
-    // ---- weight slab staging: [rows][COUT] of one tap -> padded LDS rows ----
-    const int nvec = rows * VPR;
-    auto stage = [&](int tap, char* dst) {
-        const char* src = reinterpret_cast<const char*>(a.table) + (long long)tap * rows * COUT * ES;
-        for (int v = tid; v < nvec; v += 256) {
-            const int r = v / VPR, j = v - r * VPR;
-            const uint4 val = *reinterpret_cast<const uint4*>(src + (long long)v * 16);
-            *reinterpret_cast<uint4*>(dst + r * ROWB + j * 16) = val;
-        }
-    };
-    stage(0, tb0);
-
-    float acc[COUT];
+    float acc[CS];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    for (int c = 0; c < CS; ++c) acc[c] = 0.f;
+    const unsigned sel_lo = a.sel_lo, sel_hi = a.sel_hi;
 
     auto add_row = [&](const char* rowp) {
 #pragma unroll
@@ -118,143 +144,134 @@ __global__ __launch_bounds__(256) void onehot_conv7x7_kernel(const OneHotConvArg
                 acc[j * 4 + 0] += __uint_as_float(v.x); acc[j * 4 + 1] += __uint_as_float(v.y);
                 acc[j * 4 + 2] += __uint_as_float(v.z); acc[j * 4 + 3] += __uint_as_float(v.w);
             } else {
-                acc[j * 8 + 0] += __uint_as_float(v.x << 16); acc[j * 8 + 1] += __uint_as_float(v.x & 0xffff0000u);
-                acc[j * 8 + 2] += __uint_as_float(v.y << 16); acc[j * 8 + 3] += __uint_as_float(v.y & 0xffff0000u);
-                acc[j * 8 + 4] += __uint_as_float(v.z << 16); acc[j * 8 + 5] += __uint_as_float(v.z & 0xffff0000u);
-                acc[j * 8 + 6] += __uint_as_float(v.w << 16); acc[j * 8 + 7] += __uint_as_float(v.w & 0xffff0000u);
+                acc[j * 8 + 0] = dot_sel(v.x, sel_lo, acc[j * 8 + 0]); acc[j * 8 + 1] = dot_sel(v.x, sel_hi, acc[j * 8 + 1]);
+                acc[j * 8 + 2] = dot_sel(v.y, sel_lo, acc[j * 8 + 2]); acc[j * 8 + 3] = dot_sel(v.y, sel_hi, acc[j * 8 + 3]);
+                acc[j * 8 + 4] = dot_sel(v.z, sel_lo, acc[j * 8 + 4]); acc[j * 8 + 5] = dot_sel(v.z, sel_hi, acc[j * 8 + 5]);
+                acc[j * 8 + 6] = dot_sel(v.w, sel_lo, acc[j * 8 + 6]); acc[j * 8 + 7] = dot_sel(v.w, sel_hi, acc[j * 8 + 7]);
             }
         }
     };
 
+    const int q0 = py * OS_PW + px;
     for (int tap = 0; tap < 49; ++tap) {
-        __syncthreads();                                   // slab `tap` staged (and labels, first round); buffer of tap-1 free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab `tap` (issued a whole tap ago)
+        __syncthreads();                                   // slab `tap` complete (+ offsets, first round); buffer of tap-1 free
         char* const cur = (tap & 1) ? tb1 : tb0;
-        if (tap + 1 < 49) stage(tap + 1, (tap & 1) ? tb0 : tb1);
+        if (tap + 1 < 49) issue(tap + 1, (tap & 1) ? tb0 : tb1);
         const int dy = tap / 7, dx = tap - dy * 7;
-        const int q = (py + dy) * OS_PW + (px + dx);
-        for (int t = 0; t < a.T; ++t) {
-            const int lab = lab_s[t * OS_PH * OS_PW + q];
-            if (lab != 255) add_row(cur + (t * a.per + lab) * ROWB);
-            if (a.inst && edg_s[t * OS_PH * OS_PW + q]) add_row(cur + (t * a.per + a.label_nc) * ROWB);
+        const int q = q0 + dy * OS_PW + dx;
+        if constexpr (NT > 0) {
+            unsigned o[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[t] = off_s[t * OS_PHW + q];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) add_row(cur + o[t]);
+            if (a.inst) {
+                unsigned e[NT];
+                bool any = false;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { e[t] = eoff_s[t * OS_PHW + q]; any |= e[t] != zero_off; }
+                if (__builtin_amdgcn_ballot_w64(any) != 0) {      // wave-uniform: most waves see no edge pixel at this tap
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) add_row(cur + e[t]);
+                }
+            }
+        } else {
+            for (int t = 0; t < nT; ++t) {
+                add_row(cur + off_s[t * OS_PHW + q]);
+                if (a.inst) {
+                    const unsigned e = eoff_s[t * OS_PHW + q];
+                    if (__builtin_amdgcn_ballot_w64(e != zero_off) != 0) add_row(cur + e);
+                }
+            }
         }
     }
 
-    // ---- epilogue: bias, raw fp32 NHWC store, per-tile statistics ----
-    const int oh = oh0 + py, ow = ow0 + px;
-    const bool valid = oh < H && ow < W;
+    // ---- epilogue: bias, then 32-channel chunks through LDS: coalesced raw fp32 NHWC store + per-tile statistics ----
     if (a.bias) {
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] += c < a.cout ? a.bias[c] : 0.f;
+        for (int c = 0; c < CS; ++c) acc[c] += c0 + c < a.cout ? a.bias[c0 + c] : 0.f;
     }
-    if (valid) {
-        float* op = a.out + ((long long)oh * W + ow) * a.cout_stride;
-        if (a.cout == COUT && (a.cout_stride & 3) == 0) {
+    __syncthreads();                                       // the table buffers are free
+    float* const tile = reinterpret_cast<float*>(smem);    // [256 pixels][33]: stride 33 keeps the per-pixel writes conflict-free
+    float* const red = tile + 256 * 33;                    // [8 parts][32][2]
+    const bool valid = oh0 + py < H && ow0 + px < W;
 #pragma unroll
-            for (int j = 0; j < COUT / 4; ++j)
-                *reinterpret_cast<float4*>(op + j * 4) = make_float4(acc[j * 4], acc[j * 4 + 1], acc[j * 4 + 2], acc[j * 4 + 3]);
-        } else {
+    for (int k = 0; k < CS / 32; ++k) {
 #pragma unroll
-            for (int c = 0; c < COUT; ++c)
-                if (c < a.cout) op[c] = acc[c];
-        }
-    }
-    if (a.stats == nullptr) return;
-    // recursive halving over the 64 lanes: after step m each lane keeps half of its channel range, summed with its partner's
-    // copy of that half; after 6 steps lane l owns COUT / 64 channels, summed over the wave in a fixed tree order
-    float s1[COUT / 2], s2[COUT / 2];
-    const int lane = tid & 63;
-    {
-        const bool up = (lane & 32) != 0;
+        for (int i = 0; i < 32; ++i) tile[tid * 33 + i] = valid ? acc[k * 32 + i] : 0.f;
+        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < COUT / 2; ++c) {
-            const float lo = valid ? acc[c] : 0.f, hi = valid ? acc[c + COUT / 2] : 0.f;
-            const float keep = up ? hi : lo, send = up ? lo : hi;
-            const float got = __shfl_xor(send, 32);
-            const float got2 = __shfl_xor(send * send, 32);
-            s1[c] = keep + got;
-            s2[c] = keep * keep + got2;
-        }
-    }
-    int width = COUT / 2;
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        if (width >= 2) {
-            const bool up = (lane & m) != 0;
-            const int half = width / 2;
-#pragma unroll
-            for (int c = 0; c < COUT / 4; ++c) {
-                if (c < half) {
-                    const float k1 = up ? s1[c + half] : s1[c], k2 = up ? s2[c + half] : s2[c];
-                    const float t1 = up ? s1[c] : s1[c + half], t2 = up ? s2[c] : s2[c + half];
-                    s1[c] = k1 + __shfl_xor(t1, m);
-                    s2[c] = k2 + __shfl_xor(t2, m);
-                }
+        for (int it = 0; it < 8; ++it) {                   // 8 lanes x float4 = the 128 bytes of one pixel's chunk
+            const int idx = it * 256 + tid;
+            const int p = idx >> 3, c4 = (idx & 7) * 4;
+            const int oh = oh0 + (p >> 5), ow = ow0 + (p & 31);
+            const int c = c0 + k * 32 + c4;
+            if (oh < H && ow < W && c < a.cout) {
+                float* op = a.out + ((long long)oh * W + ow) * a.cout_stride + c;
+                const float* tp = tile + p * 33 + c4;
+                if (c + 4 <= a.cout && (a.cout_stride & 3) == 0) *reinterpret_cast<float4*>(op) = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                else for (int e = 0; e < 4 && c + e < a.cout; ++e) op[e] = tp[e];
             }
-            width = half;
-        } else {                                           // fewer channels than lanes left: plain butterfly on the one value
-            s1[0] += __shfl_xor(s1[0], m);
-            s2[0] += __shfl_xor(s2[0], m);
         }
-    }
-    // channel owned by this lane's surviving slot k (k < width): the halving picked the upper half at every step whose
-    // lane bit was set, halves being COUT/2, COUT/4, ...
-    __syncthreads();                                       // the table buffers are free: per-wave partials live there
-    float* red = reinterpret_cast<float*>(smem);           // [4 waves][COUT][2]
-    {
-        int base = 0, span = COUT;
-        for (int m = 32; m >= 1 && span > 1; m >>= 1) {
-            span >>= 1;
-            if (lane & m) base += span;
+        if (a.stats) {                                     // thread (channel tid & 31, part tid >> 5): 32 pixels in order
+            const int c = tid & 31, part = tid >> 5;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) { const float v = tile[(part * 32 + i) * 33 + c]; s1 += v; s2 += v * v; }
+            red[(part * 32 + c) * 2] = s1;
+            red[(part * 32 + c) * 2 + 1] = s2;
         }
-        // with COUT >= 64 every lane ends with span = COUT / 64 >= 1 channels [base, base + span)
-        const int wv = tid >> 6;
-        constexpr int LEFT = COUT / 64 > 0 ? COUT / 64 : 1;
-        const bool owner = COUT >= 64 || (lane & ((64 / COUT) - 1)) == 0;     // COUT < 64: duplicates after the butterfly tail
+        __syncthreads();
+        if (a.stats && tid < 32 && c0 + k * 32 + tid < a.cout) {
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LEFT; ++k)
-            if (owner) { red[((wv * COUT) + base + k) * 2] = s1[k]; red[((wv * COUT) + base + k) * 2 + 1] = s2[k]; }
-    }
-    __syncthreads();
-    if (tid < COUT && tid < a.cout) {
-        const float t1 = ((red[(0 * COUT + tid) * 2] + red[(1 * COUT + tid) * 2]) + red[(2 * COUT + tid) * 2]) + red[(3 * COUT + tid) * 2];
-        const float t2 = ((red[(0 * COUT + tid) * 2 + 1] + red[(1 * COUT + tid) * 2 + 1]) + red[(2 * COUT + tid) * 2 + 1]) + red[(3 * COUT + tid) * 2 + 1];
-        float* dst = a.stats + ((long long)blockIdx.x * a.cout + tid) * 2;
-        dst[0] = t1;
-        dst[1] = t2;
+            for (int part = 0; part < 8; ++part) { t1 += red[(part * 32 + tid) * 2]; t2 += red[(part * 32 + tid) * 2 + 1]; }
+            float* dst = a.stats + ((long long)blockIdx.x * a.cout + c0 + k * 32 + tid) * 2;
+            dst[0] = t1;
+            dst[1] = t2;
+        }
     }
 }
 
 struct OneHotConvOp : Op {
-    OneHotConvArgs a; int dtype, coutp, tiles;
-    template <typename T, int COUT> int go(hipStream_t s) {
-        const size_t lds = (size_t)2 * a.T * a.per * (COUT * sizeof(T) + 16) + (size_t)2 * a.T * OS_PH * OS_PW;
-        auto kern = onehot_conv7x7_kernel<T, COUT>;
+    OneHotConvArgs a; int dtype, cs, slices, tiles;
+    template <typename T, int CS, int NT> int go(hipStream_t s) {
+        size_t lds = (size_t)2 * a.blob + (size_t)2 * a.T * OS_PHW * sizeof(unsigned short);
+        if (lds < OS_EPI_LDS) lds = OS_EPI_LDS;
+        auto kern = onehot_conv7x7_kernel<T, CS, NT>;
         static bool attr_done = false;
         if (!attr_done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 4096);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), (lds + 15) / 16 * 16, s, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)slices), dim3(256), (lds + 15) / 16 * 16, s, a);
         return check_launch();
     }
+    template <typename T, int CS> int go_t(hipStream_t s) { return a.T == 3 ? go<T, CS, 3>(s) : go<T, CS, 0>(s); }
     int launch(hipStream_t s) override {
-        if (dtype == V2V_BF16) return coutp == 128 ? go<bf16_t, 128>(s) : go<bf16_t, 64>(s);
-        return coutp == 128 ? go<float, 128>(s) : go<float, 64>(s);
+        if (dtype == V2V_BF16) return cs == 64 ? go_t<bf16_t, 64>(s) : go_t<bf16_t, 32>(s);
+        return cs == 64 ? go_t<float, 64>(s) : go_t<float, 32>(s);
     }
     const char* name() const override { return "onehot_conv7x7"; }
 };
 
-// weights [cout][cin][7][7] fp32 -> table [49][cin][coutp] of the activation dtype (pad columns zero)
-struct OneHotPackArgs { const float* w; void* tab; int cin, cout, coutp, dtype; };
+// weights [cout][cin][7][7] fp32 -> table [49][slices][blob]; blob rows [cin + 1][cs] + 16 bytes of pad per row, zero-filled
+struct OneHotPackArgs { const float* w; char* tab; int cin, cout, cs, slices, blob, dtype; };
 
 __global__ __launch_bounds__(256) void onehot_pack_kernel(const OneHotPackArgs a) {
-    const long long total = 49ll * a.cin * a.coutp;
+    const int es = a.dtype == V2V_BF16 ? 2 : 4;
+    const int per_blob = a.blob / es;                      // elements, pads included
+    const int rowe = a.cs + 16 / es;
+    const long long total = 49ll * a.slices * per_blob;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int co = (int)(e % a.coutp);
-        const long long r = e / a.coutp;
-        const int ci = (int)(r % a.cin), tap = (int)(r / a.cin);
-        const float v = co < a.cout ? a.w[((long long)co * a.cin + ci) * 49 + tap] : 0.f;
+        const int within = (int)(e % per_blob);
+        const long long b = e / per_blob;
+        const int sl = (int)(b % a.slices), tap = (int)(b / a.slices);
+        const int r = within / rowe, c = within - r * rowe;
+        const int co = sl * a.cs + c;
+        const float v = (r < a.cin && c < a.cs && co < a.cout) ? a.w[((long long)co * a.cin + r) * 49 + tap] : 0.f;
         if (a.dtype == V2V_BF16) reinterpret_cast<unsigned short*>(a.tab)[e] = f32_to_bf16_bits(v);
         else                     reinterpret_cast<float*>(a.tab)[e] = v;
     }
@@ -269,23 +286,34 @@ struct OneHotPackOp : Op {
     const char* name() const override { return "onehot_pack_weights"; }
 };
 
-static int coutp_of(int cout) { return cout <= 64 ? 64 : 128; }
+// slice width: 0 = default (64 channels for bf16 layers wider than 64, else 32), or 32 / 64 as given
+static int slice_of(int cout, int dtype, int slice) {
+    if (slice == 32 || slice == 64) return slice;
+    return (dtype == V2V_BF16 && cout > 64) ? 64 : 32;
+}
+static bool onehot_args_ok(int cin, int cout, int dtype, int slice) {
+    return cin >= 1 && cout >= 1 && cout <= 128 && (dtype == V2V_F32 || dtype == V2V_BF16) && (slice == 0 || slice == 32 || slice == 64);
+}
 
 }  // namespace v2v
 
 using namespace v2v;
 
-extern "C" int64_t v2v_onehot_conv_table_elems(int32_t cin, int32_t cout) {
-    if (cin < 1 || cout < 1 || cout > 128) return V2V_EINVAL;
-    return 49ll * cin * coutp_of(cout);
+extern "C" int64_t v2v_onehot_conv_table_bytes(int32_t cin, int32_t cout, int32_t dtype, int32_t slice) {
+    if (!onehot_args_ok(cin, cout, dtype, slice)) return V2V_EINVAL;
+    const int cs = slice_of(cout, dtype, slice), es = dtype == V2V_BF16 ? 2 : 4;
+    const int blob = os_blob(cin, cs, es);
+    if ((cin + 1) * os_rowb(cs, es) > 65535) return V2V_EINVAL;        // 16-bit row offsets
+    return 49ll * ceil_div(cout, cs) * blob;
 }
 
-extern "C" int v2v_onehot_conv_pack_weights(const float* w, void* table, int32_t cin, int32_t cout, int32_t dtype, void* stream) {
-    if (!w || !table || cin < 1 || cout < 1 || cout > 128 || (dtype != V2V_F32 && dtype != V2V_BF16)) {
-        set_error("onehot_conv_pack_weights: bad argument (cout <= 128)"); return V2V_EINVAL;
+extern "C" int v2v_onehot_conv_pack_weights(const float* w, void* table, int32_t cin, int32_t cout, int32_t dtype, int32_t slice, void* stream) {
+    if (!w || !table || !onehot_args_ok(cin, cout, dtype, slice)) {
+        set_error("onehot_conv_pack_weights: bad argument (cout <= 128, slice 0 / 32 / 64)"); return V2V_EINVAL;
     }
+    const int cs = slice_of(cout, dtype, slice), es = dtype == V2V_BF16 ? 2 : 4;
     auto op = std::make_unique<OneHotPackOp>();
-    op->a = OneHotPackArgs{w, table, cin, cout, coutp_of(cout), dtype};
+    op->a = OneHotPackArgs{w, reinterpret_cast<char*>(table), cin, cout, cs, (int)ceil_div(cout, cs), os_blob(cin, cs, es), dtype};
     return submit(std::move(op), stream);
 }
 
@@ -296,19 +324,23 @@ extern "C" int v2v_onehot_conv_stats_rows(int32_t H, int32_t W) {
 
 extern "C" int v2v_onehot_conv7x7(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
                                   float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
-                                  int32_t cout, int32_t cout_stride, int32_t dtype, void* stream) {
-    if (!labels || !table || !out || T < 1 || H < 4 || W < 4 || label_nc < 1 || label_nc > 254 || cout < 1 || cout > 128 ||
-        cout_stride < cout || (dtype != V2V_F32 && dtype != V2V_BF16)) {
-        set_error("onehot_conv7x7: bad argument (cout <= 128, label_nc <= 254, image at least 4x4 for the 3-pixel mirror)"); return V2V_EINVAL;
+                                  int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, void* stream) {
+    if (!labels || !table || !out || T < 1 || H < 4 || W < 4 || label_nc < 1 || cout_stride < cout || !onehot_args_ok(1, cout, dtype, slice)) {
+        set_error("onehot_conv7x7: bad argument (cout <= 128, slice 0 / 32 / 64, image at least 4x4 for the 3-pixel mirror)"); return V2V_EINVAL;
     }
     if (((uintptr_t)table | (uintptr_t)out) & 15) { set_error("onehot_conv7x7: table / output must be 16-byte aligned"); return V2V_EINVAL; }
     const int per = label_nc + (inst ? 1 : 0);
-    const int coutp = coutp_of(cout);
-    const size_t lds = (size_t)2 * T * per * (coutp * (dtype == V2V_BF16 ? 2 : 4) + 16) + (size_t)2 * T * OS_PH * OS_PW;
-    if (lds > 156 * 1024) { set_error("onehot_conv7x7: T * (label_nc + 1) = %d weight rows do not fit the LDS", T * per); return V2V_EINVAL; }
+    const int cs = slice_of(cout, dtype, slice), es = dtype == V2V_BF16 ? 2 : 4;
+    const int rows = T * per;
+    const int blob = os_blob(rows, cs, es);
+    const size_t lds = (size_t)2 * blob + (size_t)2 * T * OS_PHW * sizeof(unsigned short);
+    if ((rows + 1) * os_rowb(cs, es) > 65535 || lds > 156 * 1024) {
+        set_error("onehot_conv7x7: T * (label_nc + 1) = %d weight rows do not fit the LDS", rows); return V2V_EINVAL;
+    }
     auto op = std::make_unique<OneHotConvOp>();
-    op->a = OneHotConvArgs{labels, inst, table, bias, out, stats, T, H, W, label_nc, per, cout, cout_stride,
-                           (int)ceil_div(W, OS_TW), in_u8};
-    op->dtype = dtype; op->coutp = coutp; op->tiles = (int)(ceil_div(H, OS_TH) * ceil_div(W, OS_TW));
+    op->a = OneHotConvArgs{labels, inst, reinterpret_cast<const char*>(table), bias, out, stats, T, H, W, label_nc, per, cout, cout_stride,
+                           (int)ceil_div(W, OS_TW), in_u8, blob, 0x00003f80u, 0x3f800000u};
+    op->dtype = dtype; op->cs = cs; op->slices = (int)ceil_div(cout, cs);
+    op->tiles = (int)(ceil_div(H, OS_TH) * ceil_div(W, OS_TW));
     return submit(std::move(op), stream);
 }

@@ -51,10 +51,11 @@ def pad_channels(c, dtype):
 
 class Act:
     """NHWC activation: tensor [N,H,W,Cs] (Cs = padded channel stride), C real channels."""
-    __slots__ = ("t", "C")
+    __slots__ = ("t", "C", "onehot")
 
-    def __init__(self, t, C):
+    def __init__(self, t, C, onehot=None):
         self.t, self.C = t, C
+        self.onehot = onehot      # LabelSource when this Act is the one-hot encoding of label maps (encode_labels)
 
     def detach(self):
         return Act(self.t.detach(), self.C)
@@ -67,6 +68,15 @@ class Act:
     def W(self): return self.t.shape[2]
     @property
     def Cs(self): return self.t.stride(2)      # true channel stride (a channel-sliced view keeps its parent's)
+
+
+class LabelSource:
+    """The label / instance maps an encoded one-hot Act was built from: [T][H][W] fp32-encoded integers or uint8 / int32.
+    A 7x7 stem convolution over such an Act runs as a weight gather-sum on the maps (csrc/onehot_stem.hip)."""
+    __slots__ = ("labels", "inst", "T", "label_nc")
+
+    def __init__(self, labels, inst, T, label_nc):
+        self.labels, self.inst, self.T, self.label_nc = labels, inst, T, label_nc
 
 
 _PARAM_EPOCH = [0]
@@ -137,6 +147,37 @@ class PackedConv:
               "conv_pack_weights")
         if self.role == "fwd":
             self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()
+        self.version = ver
+
+
+class PackedOneHot:
+    """Gather table [49][cin][64 | 128] of a 7x7 stem Conv2d (csrc/onehot_stem.hip), refreshed like PackedConv."""
+
+    def __init__(self, eng, mod, slice_):
+        self.mod = mod
+        self.cout, self.cin = mod.weight.shape[0], mod.weight.shape[1]
+        self.dtype, self.slice = eng.dtype, slice_
+        n = lib.v2v_onehot_conv_table_bytes(self.cin, self.cout, self.dtype, slice_)
+        if n <= 0:
+            raise RuntimeError("onehot_conv_table_bytes(%d, %d) failed" % (self.cin, self.cout))
+        self.buf = torch.empty(n, dtype=torch.uint8, device=eng.device)
+        self.bias = None
+        self.version = None
+        self.refresh()
+
+    def refresh(self, force=False):
+        w = self.mod.weight
+        box = getattr(w, "_v2v_epoch", None)
+        ver = (w._version, w.data_ptr(), None if self.mod.bias is None else self.mod.bias._version, _PARAM_EPOCH[0],
+               0 if box is None else box[0])
+        if not force and ver == self.version:
+            return
+        w32 = w.detach()
+        if w32.dtype != torch.float32 or not w32.is_contiguous():
+            w32 = w32.float().contiguous()
+        check(lib.v2v_onehot_conv_pack_weights(_ptr(w32), _ptr(self.buf), self.cin, self.cout, self.dtype, self.slice, _stream()),
+              "onehot_conv_pack_weights")
+        self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()
         self.version = ver
 
 
@@ -247,6 +288,10 @@ class Engine:
         self.tdtype = _TORCH_DTYPE[dtype]
         self.align_corners = align_corners
         self._packed = {}        # id(module) -> PackedConv
+        self._packed_onehot = {} # id(module) -> PackedOneHot (7x7 stems fed by label maps)
+        # stems over encoded label maps as a weight gather-sum (csrc/onehot_stem.hip); V2V_ONEHOT_STEM=0: dense conv on the encoding
+        self.onehot_stem = bool(int(os.environ.get("V2V_ONEHOT_STEM", "1")))
+        self.onehot_slice = int(os.environ.get("V2V_ONEHOT_SLICE", "0"))      # output channels per workgroup: 32 / 64, 0 = default
         self._scratch = {}       # name -> tensor (grown on demand, shared between layers)
         self._grids = {}
         self._zero_page = None
@@ -399,6 +444,47 @@ class Engine:
     def refresh_weights(self, force=False):
         for pc in self._packed.values():
             pc.refresh(force)
+        for pc in self._packed_onehot.values():
+            pc.refresh(force)
+
+    # ---------------- one-hot stem (label-map input) ----------------
+    def onehot_eligible(self, x, conv, pad_mode, pad_override):
+        """7x7 / stride 1 / ReflectionPad2d(3) Conv2d straight on an encoded label Act, inference only."""
+        src = x.onehot
+        return (self.onehot_stem and src is not None and isinstance(conv, nn.Conv2d) and conv.kernel_size == (7, 7)
+                and conv.stride == (1, 1) and conv.groups == 1 and pad_mode == L.PAD_REFLECT
+                and (conv.padding[0] if pad_override is None else pad_override) == 3
+                and conv.out_channels <= 128 and conv.in_channels == x.C and x.N == 1 and x.H >= 4 and x.W >= 4
+                and not (self.plan is None and torch.is_grad_enabled()))
+
+    def onehot_conv(self, x, conv, want_stats=True, label=""):
+        """Raw fp32 NHWC output + statistics rows of the stem convolution, computed from the label maps behind `x`.
+        Returns (raw, rows, (N, OH, OW)) like conv(..., OUT_RAW_F32_NHWC, want_stats=True)."""
+        src = x.onehot
+        pk = self._packed_onehot.get((id(conv), self.onehot_slice))
+        if pk is None:
+            pk = self._packed_onehot[(id(conv), self.onehot_slice)] = PackedOneHot(self, conv, self.onehot_slice)
+        elif self.plan is None:
+            pk.refresh()
+        H, W, cout = x.H, x.W, conv.out_channels
+        cs = (cout + 3) // 4 * 4
+        raw = self.scratch("raw", H * W * cs)
+        rows = lib.v2v_onehot_conv_stats_rows(H, W) if want_stats else 0
+        st = self.scratch("stats", rows * cout * 2) if want_stats else None
+        self._keep(pk.buf)
+        if pk.bias is not None:
+            self._keep(pk.bias)
+        check(lib.v2v_onehot_conv7x7(_ptr(src.labels), _ptr(src.inst), int(src.labels.dtype == torch.uint8), _ptr(pk.buf),
+                                     _ptr(pk.bias), _ptr(raw), _ptr(st), src.T, H, W, src.label_nc, cout, cs, self.dtype,
+                                     pk.slice, _stream()), "onehot_conv7x7 " + label)
+        self.label(label)
+        if len(self.conv_log) >= 100000:
+            del self.conv_log[:]
+        # flops: those of the dense convolution this launch replaces (the frame's nominal 2115 GFLOP census), flagged
+        self.conv_log.append(dict(label=label, N=1, H=H, W=W, OH=H, OW=W, cin=conv.in_channels, cout=cout, tune_key=None,
+                                  KH=7, KW=7, stride=1, transposed=False, onehot=True,
+                                  flops=2.0 * H * W * cout * conv.in_channels * 49, tile=(0, 0), splitk=1, prefetch=0))
+        return raw, rows, (1, H, W)
 
     # ---------------- primitive emitters ----------------
     def conv(self, x, mod, pad_mode=L.PAD_ZERO, pad_override=None, out_mode=L.OUT_RAW_F32_NHWC,
@@ -944,6 +1030,9 @@ class Engine:
             from . import autograd as AG
             return AG.conv_group(self, x, conv, pad_mode, pad_override, norm, act, act_param, add0, add1,
                                  head_nchw, out_scale, label)
+        if norm is not None and self.onehot_eligible(x, conv, pad_mode, pad_override):
+            raw, rows, shp = self.onehot_conv(x, conv, label=label)
+            return self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param, add0=add0, add1=add1, label=label)
         if norm is not None:
             ss = self.scratch("scale_shift", 4 * conv.out_channels)
             raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC, want_stats=True, label=label,
@@ -1103,6 +1192,7 @@ class Engine:
                  out.Cs, _ptr(fg), 0 if fg is None else fg.numel(), self.dtype, _stream()),
               "encode_labels")
         self.label("encode_labels")
+        out.onehot = LabelSource(labels, inst, T, label_nc)
         return out, mask
 
     def widen(self, x, stride):
