@@ -127,3 +127,25 @@ if has stemab; then
   done
   lap stemab
 fi
+if has trainprof; then
+  timeout 900 python bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_train.json 2> gpurun_out/${TAG}_train.err; echo "train bench rc=$?"
+  cut -c1-600 gpurun_out/${TAG}_train.json; tail -3 gpurun_out/${TAG}_train.err
+  cd /tmp
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_train_tune.json timeout 900 python $R/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1   # fills the tile cache: no autotune launches in the trace
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_train_tune.json timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/trp_$TAG -o train -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_train_prof.json 2> $R/gpurun_out/${TAG}_train_prof.err; echo "rocprof(train) rc=$?"
+  python $R/scripts/rocprof_summary.py $(find /tmp/trp_$TAG -name "*.db" | head -1) "# round 2, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --mode train --steps 6 --warmup 2 (bf16 512x256, VGG on)" > $R/gpurun_out/${TAG}_train_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_train_prof.err
+  head -45 $R/gpurun_out/${TAG}_train_kernel_stats.txt | cut -c1-220
+  cd $R
+  lap trainprof
+fi
+if has trainab; then
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short --timeout 300 -x > gpurun_out/${TAG}_allkernels.log 2>&1; echo "kernel tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|Error" gpurun_out/${TAG}_allkernels.log | cut -c1-300 | tail -10
+  timeout 600 python bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_train.json 2> gpurun_out/${TAG}_train.err; echo "train bench rc=$?"
+  cut -c1-220 gpurun_out/${TAG}_train.json
+  V2V_WGRAD_WGS=512 timeout 600 python bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_train_wg512.json 2> gpurun_out/${TAG}_train_wg512.err; echo "train bench (wgrad 512 WGs) rc=$?"
+  cut -c1-220 gpurun_out/${TAG}_train_wg512.json
+  V2V_BN_BWD_FUSED=0 timeout 600 python bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_train_nofuse.json 2> gpurun_out/${TAG}_train_nofuse.err; echo "train bench (separate bn_bwd_finalize) rc=$?"
+  cut -c1-220 gpurun_out/${TAG}_train_nofuse.json
+  lap trainab
+fi

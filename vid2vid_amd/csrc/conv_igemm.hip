@@ -186,9 +186,88 @@ __global__ void pack_weights_kernel(const PackArgs a) {
     }
 }
 
+// Tiled variant for kernels of up to 16 taps (1x1, 3x3, 4x4: everything but the 7x7 stems / heads).  The kernel above
+// walks the DESTINATION and gathers 4 bytes every KH*KW*4 bytes per lane with two 64-bit divisions per element: 28 us per
+// call, 353 calls = 7.3 ms = 10 % of a training step (profiles/r02_a14_train_kernel_stats.txt), since every optimizer
+// step re-packs every layer for its forward and backward-data operators.  Here a workgroup owns 8 rows x 64 channels
+// x all taps: the source runs are contiguous ([c0..c0+63][KH][KW] of a row for a Conv2d weight, [co0..co0+7][KH][KW] of
+// a channel for a ConvTranspose2d-layout read), go through LDS, and leave as 64-element contiguous runs per (row, tap).
+constexpr int PK_TCO = 8, PK_TC = 64, PK_MAXT = 16;
+
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const PackArgs a) {
+    __shared__ float sh[PK_TCO * PK_MAXT * (PK_TC + PK_MAXT)];
+    const int c0 = blockIdx.x * PK_TC, co0 = blockIdx.y * PK_TCO;
+    const int KHW = a.KH * a.KW;
+    const int LS = PK_TC + KHW;                              // LDS row stride: bank = tap * KHW + channel, distinct over a wave's run
+    const int tid = threadIdx.x;
+    // ---- read: contiguous source runs -> sh[(row * KHW + full tap) * LS + channel]
+    if (!a.transposed) {
+        const int nc = min(PK_TC, a.cin - c0);
+        const int run = nc > 0 ? nc * KHW : 0;
+        for (int r = 0; r < PK_TCO; ++r) {
+            const int co = co0 + r;
+            if (co >= a.cout) break;
+            const float* src = a.w + ((long long)co * a.cin + c0) * KHW;
+            for (int i = tid; i < run; i += 256) {
+                const int cl = i / KHW, f = i - cl * KHW;
+                sh[(r * KHW + f) * LS + cl] = src[i];
+            }
+        }
+    } else {
+        const int nr = min(PK_TCO, a.cout - co0);
+        const int run = nr > 0 ? nr * KHW : 0;
+        for (int cl = 0; cl < PK_TC; ++cl) {
+            const int c = c0 + cl;
+            if (c >= a.cin) break;
+            const float* src = a.w + ((long long)c * a.cout + co0) * KHW;
+            for (int i = tid; i < run; i += 256) {
+                const int r = i / KHW, f = i - r * KHW;
+                sh[(r * KHW + f) * LS + cl] = src[i];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- write: per class, 64-channel runs per (row, tap)
+    for (int cls = 0; cls < a.ncls; ++cls) {
+        const int nkw = a.nkw[cls], nt = a.nkh[cls] * nkw;
+        const int wrow = a.wrow[cls];
+        const int n = PK_TCO * nt * PK_TC;
+        for (int j = tid; j < n; j += 256) {
+            const int cl = j & (PK_TC - 1);
+            const int rt = j >> 6;
+            const int r = rt / nt, t = rt - r * nt;
+            const int co = co0 + r, c = c0 + cl;
+            if (co >= a.cout_p || c >= a.cin_stride) continue;
+            const int th = t / nkw, tw = t - th * nkw;
+            const int kh = a.transposed ? a.kh0[cls] + a.kstep * th : th;
+            const int kw = a.transposed ? a.kw0[cls] + a.kstep * tw : tw;
+            const float v = (co < a.cout && c < a.cin) ? sh[(r * KHW + kh * a.KW + kw) * LS + cl] : 0.f;
+            const int k = a.korder == 1 ? ((c / a.bke) * nt + t) * a.bke + (c % a.bke) : t * a.cin_stride + c;
+            const long long e = a.woff[cls] + (long long)co * wrow + k;
+            if (a.dtype == V2V_BF16) reinterpret_cast<unsigned short*>(a.dst)[e] = f32_to_bf16_bits(v);
+            else                     reinterpret_cast<float*>(a.dst)[e] = v;
+        }
+        if (blockIdx.x == 0) {                               // the zero lines behind a row's taps (K padded to the tile depth)
+            const int ktot = nt * a.cin_stride, npad = wrow - ktot;
+            for (int j = tid; j < PK_TCO * npad; j += 256) {
+                const int r = j / npad, k = ktot + (j - r * npad);
+                if (co0 + r >= a.cout_p) continue;
+                const long long e = a.woff[cls] + (long long)(co0 + r) * wrow + k;
+                if (a.dtype == V2V_BF16) reinterpret_cast<unsigned short*>(a.dst)[e] = 0;
+                else                     reinterpret_cast<float*>(a.dst)[e] = 0.f;
+            }
+        }
+    }
+}
+
 struct PackOp : Op {
     PackArgs a;
     int launch(hipStream_t s) override {
+        if (a.KH * a.KW <= PK_MAXT) {
+            const dim3 grid((unsigned)ceil_div(a.cin_stride, PK_TC), (unsigned)ceil_div(a.cout_p, PK_TCO));
+            hipLaunchKernelGGL(pack_weights_tiled_kernel, grid, dim3(256), 0, s, a);
+            return check_launch();
+        }
         const int threads = 256;
         long long blocks = ceil_div(a.total, threads);
         if (blocks > 4096) blocks = 4096;

@@ -531,7 +531,8 @@ static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* 
     *m_tiles = (int)ceil_div(d->rows, WG_BM);
     *n_tiles = (int)ceil_div(ncols, WG_BN);
     const long long tiles = (long long)*m_tiles * *n_tiles;
-    long long s = ceil_div(1024, tiles);                 // ~4 workgroups per CU (512 measured slower: profiles/r01 q1 vs q2)
+    static const int target = [] { const char* e = getenv("V2V_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    long long s = ceil_div(target, tiles);               // ~4 workgroups per CU (512 measured slower: profiles/r01 q1 vs q2)
     const long long smax = ceil_div(kpix, 8 * WG_BK);     // at least 8 chunks per split
     if (s > smax) s = smax;
     if (s < 1) s = 1;

@@ -207,6 +207,9 @@ struct BnBwdRedArgs {
     long long P; int C, c_stride, c_stride_raw, act; float act_param; int mode;   // mode 1: sum of dy only
     long long ppb;                                          // pixels per block
     int vec;                                                // strides / base pointers allow the 4-channel vector loads
+    // finalize by the last-arriving workgroup of a 64-channel slab (replaces the bn_bwd_finalize launch: 434 launches of
+    // ~10 us per training step, profiles/r02_a14_train_kernel_stats.txt); ticket == NULL: partial rows only
+    int* ticket; double inv_count; float* dgamma; float* dbeta; float* coef; int accumulate;
 };
 
 __device__ __forceinline__ float act_grad_pre(float pre, int act, float param) {
@@ -282,8 +285,46 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdRedArgs a
 #pragma unroll
             for (int q = 0; q < 16; ++q) { t1 += sh[q][threadIdx.x][0]; t2 += sh[q][threadIdx.x][1]; }
             float* dst = a.partials + ((long long)blockIdx.x * a.C + c) * 2;
-            dst[0] = t1; dst[1] = t2;
+            if (a.ticket != nullptr) {       // 8-byte write-through agent-scope store, read back below with agent-scope loads
+                const unsigned long long bits = (unsigned long long)__float_as_uint(t1) | ((unsigned long long)__float_as_uint(t2) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else { dst[0] = t1; dst[1] = t2; }
         }
+    }
+    if (a.ticket == nullptr) return;
+    // ---- the last workgroup of this channel slab sums the rows in a fixed order (same arithmetic as bn_bwd_finalize_kernel:
+    //      4 row phases in double, then ((p0 + p1) + p2) + p3) -> deterministic, independent of which workgroup is last ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int last_flag;
+    if (threadIdx.x == 0) {
+        const int tk = __hip_atomic_fetch_add(a.ticket + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == (int)gridDim.x - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(a.ticket + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    double* shd = reinterpret_cast<double*>(&sh[0][0][0]);       // [4][64][2] doubles = 4 KiB of the 8 KiB
+    const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx;
+    double d1 = 0.0, d2 = 0.0;
+    if (c < a.C) {
+        for (int r = ph; r < (int)gridDim.x; r += 4) {
+            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.partials + ((long long)r * a.C + c) * 2),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
+            d2 += (double)__uint_as_float((unsigned)(bits >> 32));
+        }
+    }
+    shd[(ph * 64 + cx) * 2] = d1; shd[(ph * 64 + cx) * 2 + 1] = d2;
+    __syncthreads();
+    if (ph == 0 && c < a.C) {
+        d1 = ((shd[(0 * 64 + cx) * 2] + shd[(1 * 64 + cx) * 2]) + shd[(2 * 64 + cx) * 2]) + shd[(3 * 64 + cx) * 2];
+        d2 = ((shd[(0 * 64 + cx) * 2 + 1] + shd[(1 * 64 + cx) * 2 + 1]) + shd[(2 * 64 + cx) * 2 + 1]) + shd[(3 * 64 + cx) * 2 + 1];
+        if (a.dbeta)  a.dbeta[c]  = (a.accumulate ? a.dbeta[c] : 0.f) + (float)d1;
+        if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + (float)d2;
+        if (a.coef) { a.coef[c] = (float)(d1 * a.inv_count); a.coef[a.C + c] = (float)(d2 * a.inv_count); }
     }
 }
 
@@ -378,8 +419,10 @@ struct BnBwdOp : Op {
         if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, r);
         else                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, s, r);
         int rc = check_launch(); if (rc) return rc;
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(f.C, 64)), dim3(256), 0, s, f);
-        rc = check_launch(); if (rc) return rc;
+        if (r.ticket == nullptr) {
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(f.C, 64)), dim3(256), 0, s, f);
+            rc = check_launch(); if (rc) return rc;
+        }
         if (do_apply) {
             const dim3 agrid((unsigned)ceil_div(ap.P, 64), (unsigned)ceil_div(ap.c_stride_out, 64));
             if (dtype == V2V_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, agrid, dim3(256), 0, s, ap);
@@ -448,6 +491,34 @@ struct ActBwdOp : Op {
     }
     const char* name() const override { return "act_backward"; }
 };
+
+// Self-re-arming ticket words for the fused finalize: one device buffer for the process, handed out round-robin (an op
+// keeps its 64 words for life; two ops can only share words when 1024 ops apart, far beyond anything in flight together).
+static int* take_tickets(int n) {
+    constexpr int POOL = 1 << 16;
+    static int* pool = nullptr;
+    static bool failed = false;
+    static unsigned next = 0;
+    if (failed || n > 64) return nullptr;
+    if (pool == nullptr) {
+        if (hipMalloc(reinterpret_cast<void**>(&pool), POOL * sizeof(int)) != hipSuccess || hipMemset(pool, 0, POOL * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError(); pool = nullptr; failed = true; return nullptr;      // no device (dry run): separate finalize launch
+        }
+    }
+    const unsigned at = __atomic_fetch_add(&next, 64u, __ATOMIC_RELAXED) % POOL;
+    return pool + at;
+}
+
+static void fuse_finalize(BnBwdOp* op) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V2V_BN_BWD_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
+    op->r.ticket = nullptr;
+    if (!on || v2v_get_dry_run()) return;
+    int* t = take_tickets((int)ceil_div(op->f.C, 64));
+    if (t == nullptr) return;
+    op->r.ticket = t; op->r.inv_count = op->f.inv_count; op->r.dgamma = op->f.dgamma; op->r.dbeta = op->f.dbeta;
+    op->r.coef = op->f.coef; op->r.accumulate = op->f.accumulate;
+}
 
 static int bwd_blocks(long long P, long long* ppb) {
     long long nblk = ceil_div(P, 64);
@@ -552,6 +623,7 @@ extern "C" int v2v_bn_backward(const void* dy, const float* raw, int32_t c_strid
     op->r = BnBwdRedArgs{dy, raw, stats, partials, P, C, c_stride, c_stride_raw, act, act_param, 0, ppb, vec};
     op->f = BnBwdFinArgs{partials, nblk, C, 1.0 / (double)P, dgamma, dbeta, coef, accumulate};
     op->ap = BnBwdApplyArgs{dy, raw, stats, coef, draw, P, C, c_stride, c_stride_raw, c_stride_out, act, act_param, vec};
+    fuse_finalize(op.get());
     return submit(std::move(op), stream);
 }
 
@@ -565,6 +637,7 @@ extern "C" int v2v_channel_sum(const void* x, float* out, int32_t accumulate, fl
     op->r = BnBwdRedArgs{x, nullptr, nullptr, workspace, P, C, c_stride, 0, V2V_ACT_NONE, 0.f, 1, ppb, vec};
     op->f = BnBwdFinArgs{workspace, nblk, C, 1.0, nullptr, out, nullptr, accumulate};
     memset(&op->ap, 0, sizeof(op->ap));
+    fuse_finalize(op.get());
     return submit(std::move(op), stream);
 }
 
