@@ -56,6 +56,8 @@ extern "C" {
 #define V2V_OUT_RAW_F32_NHWC 0  /* fp32 NHWC, pre-norm; optional per-tile statistics */
 #define V2V_OUT_ACT_NHWC     1  /* activation dtype NHWC, after bias/act/scale        */
 #define V2V_OUT_F32_NCHW     2  /* fp32 planar NCHW (API-facing heads)                */
+#define V2V_OUT_NORM_ACT_NHWC 3 /* activation dtype NHWC after the training-mode norm (batch statistics of THIS launch),
+                                 * activation and residual adds -- see "fused norm" below                            */
 
 /* Descriptor of one convolution / transposed convolution launch.  POD, passed by pointer,
  * copied by the callee before it returns. */
@@ -98,7 +100,21 @@ typedef struct v2v_conv_desc {
     int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
     int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major */
     int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA) */
+    const void* res0;       /* V2V_OUT_NORM_ACT_NHWC: NULL or a residual [N][OH][OW][cout_stride] (activation dtype) added after the activation */
+    const void* res1;       /* second residual, NULL or as res0                                                   */
 } v2v_conv_desc;
+
+/* Fused norm (out_mode V2V_OUT_NORM_ACT_NHWC): conv + BatchNorm2d / InstanceNorm2d in training mode + activation
+ * (+ residuals) in ONE launch -- what [pad, conv, norm, relu] and the tail of a ResnetBlock are in the reference
+ * (models/networks.py:571-593).  The statistics need every output pixel, so the workgroups that share an output-channel
+ * tile meet at a spin barrier between the main loop and the store: each publishes its tile's (sum, sum^2) row, waits for
+ * the others, derives scale / shift from all rows in a fixed order (same arithmetic as the in-kernel finalize), and
+ * applies it to the accumulators it still holds in registers.  No fp32 raw tensor, no bn_apply launch.
+ * Requirements, checked by the library: tile ids 80..89, splitk <= 1, cout == cout_stride, `stats`, `fin_counter`
+ * (>= 256 zero ints, re-armed in-kernel) and `fin_scale_shift` given, and ALL workgroups of the launch co-resident:
+ * m_tiles * n_tiles (* 2 for v2v_conv2d_pair) <= the number of compute units.  Two such launches must never run
+ * concurrently on one device (each could hold half of the CUs and wait for the rest): issue them from one stream / one
+ * plan lane only.  A barrier that does not complete within ~30 ms gives up and the outputs are NaN. */
 
 /* splitk = S > 1: the S workgroups of a tile each reduce 1/S of the K chunks and publish an fp32 partial tile; the
  * last to arrive sums the S partial tiles in slice order (deterministic, independent of arrival order) and runs the
@@ -133,6 +149,8 @@ int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t ci
 int     v2v_conv_stats_rows(const v2v_conv_desc* d);
 /* Bytes of `slabs` scratch (and number of `sk_counter` ints via *tickets) the launch needs; 0 when splitk <= 1. */
 int64_t v2v_conv_splitk_workspace(const v2v_conv_desc* d, int32_t* tickets);
+/* Largest m_tiles * n_tiles (* 2 for a pair) a V2V_OUT_NORM_ACT_NHWC launch may have on this device (= its CU count). */
+int     v2v_conv_fused_norm_max_workgroups(void);
 /* Tile configuration id the launch would use (after auto selection). */
 int     v2v_conv_tile_config(const v2v_conv_desc* d);
 /* Launch.  nn.Conv2d / nn.ConvTranspose2d forward (models/networks.py:132-183 etc.), and -- with the

@@ -72,7 +72,7 @@ if has prof2; then
   # tile selections of profiles/tune_cache.json are replayed by default: the profile describes the benchmarked kernels
   DOM=${DOM:-82,1,2}; NEEDLE=${NEEDLE:-conv3x3_pp3_kernelIDF16bLi8ELi32ELi64ELi5}
   cd /tmp
-  timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_prof.json 2> $R/gpurun_out/${TAG}_bench_prof.err; echo "rocprof rc=$?"
+  timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train-line > $R/gpurun_out/${TAG}_bench_prof.json 2> $R/gpurun_out/${TAG}_bench_prof.err; echo "rocprof rc=$?"
   DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
   python $R/scripts/rocprof_summary.py $DB "# round 2, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline (bf16, 512x256; tile selections replayed from profiles/tune_cache.json, no autotune launches in this trace; kernels run inside the 3-lane frame graph)" > $R/gpurun_out/${TAG}_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_bench_prof.err
   head -14 $R/gpurun_out/${TAG}_kernel_stats.txt | cut -c1-200
@@ -97,7 +97,7 @@ if has newtests2; then
 fi
 if has timeline; then
   cd /tmp
-  timeout 500 rocprofv3 --kernel-trace -d /tmp/tl_$TAG -o bench -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_tl.json 2> $R/gpurun_out/${TAG}_bench_tl.err; echo "rocprof(timeline) rc=$?"
+  timeout 500 rocprofv3 --kernel-trace -d /tmp/tl_$TAG -o bench -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-train-line > $R/gpurun_out/${TAG}_bench_tl.json 2> $R/gpurun_out/${TAG}_bench_tl.err; echo "rocprof(timeline) rc=$?"
   python $R/scripts/frame_timeline.py $(find /tmp/tl_$TAG -name "*.db" | head -1) > $R/gpurun_out/${TAG}_frame_timeline.txt 2>&1
   head -4 $R/gpurun_out/${TAG}_frame_timeline.txt
   cd $R
@@ -122,7 +122,7 @@ if has stemtest; then
 fi
 if has stemab; then
   for oh in 1 0 1 0; do
-    V2V_ONEHOT_STEM=$oh timeout 500 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_oh$oh.json 2> gpurun_out/${TAG}_bench_oh$oh.err; echo "bench onehot=$oh rc=$?"
+    V2V_ONEHOT_STEM=$oh timeout 500 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_oh$oh.json 2> gpurun_out/${TAG}_bench_oh$oh.err; echo "bench onehot=$oh rc=$?"
     cut -c1-200 gpurun_out/${TAG}_bench_oh$oh.json
   done
   lap stemab
@@ -148,4 +148,34 @@ if has trainab; then
   V2V_BN_BWD_FUSED=0 timeout 600 python bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_train_nofuse.json 2> gpurun_out/${TAG}_train_nofuse.err; echo "train bench (separate bn_bwd_finalize) rc=$?"
   cut -c1-220 gpurun_out/${TAG}_train_nofuse.json
   lap trainab
+fi
+if has benchdefault; then
+  timeout 900 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench (defaults) rc=$?"
+  python - <<PY
+import json
+j = json.load(open("gpurun_out/${TAG}_bench_default.json"))
+print("value", j["value"], "ms", j["ms_per_step"], "fp32", j.get("fp32", {}).get("value"), "host_fed", j.get("host_fed"), "\ntrain", j.get("train"), "\ncpu", j.get("cpu_baseline"))
+PY
+  tail -3 gpurun_out/${TAG}_bench_default.err
+  timeout 600 python bench.py --mode train --steps 8 --warmup 2 > gpurun_out/${TAG}_train.json 2> gpurun_out/${TAG}_train.err; echo "train bench rc=$?"
+  python -c "import json; j=json.load(open('gpurun_out/${TAG}_train.json')); print(j['value'], j['ms_per_step'], j['flownet2'])"
+  lap benchdefault
+fi
+if has fusedab; then
+  timeout 120 python scripts/dbg_fused.py 2>&1 | grep -v amdgpu.ids | cut -c1-300
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -x -k "fused_norm or conv2d_pair" > gpurun_out/${TAG}_fusedtest.log 2>&1; echo "fused norm tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_fusedtest.log | cut -c1-300 | tail -12
+  timeout 900 python -m pytest tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 600 -k "not full_size" > gpurun_out/${TAG}_golden.log 2>&1; echo "golden rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_golden.log | cut -c1-300 | tail -8
+  for fu in 1 0 1 0; do
+    V2V_FUSED_NORM=$fu timeout 500 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_fu$fu.json 2> gpurun_out/${TAG}_bench_fu$fu.err; echo "bench fused_norm=$fu rc=$?"
+    cut -c1-200 gpurun_out/${TAG}_bench_fu$fu.json
+  done
+  lap fusedab
+fi
+if has fusedtest; then
+  timeout 120 python scripts/dbg_fused.py 2>&1 | grep -v amdgpu.ids | grep "diff" | cut -c1-300
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short --timeout 300 > gpurun_out/${TAG}_allkernels.log 2>&1; echo "kernel tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_allkernels.log | cut -c1-300 | tail -12
+  lap fusedtest
 fi

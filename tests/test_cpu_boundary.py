@@ -274,7 +274,7 @@ def test_plan_lanes_record_fork_and_join_edges():
 
 def test_twin_chains_record_paired_launches():
     """With opt.twin (the default) the ResnetBlock chains of the label / image towers and of the image / flow branches are
-    recorded as v2v_conv2d_pair / v2v_bn_apply_pair launches: the 512x256 label2city frame keeps its census of 79
+    recorded as v2v_conv2d_pair launches with the norm fused in (V2V_OUT_NORM_ACT_NHWC): the 512x256 label2city frame keeps its census of 79
     convolutions / 2115 GFLOP while 36 of them (the 1024 -> 1024 layers) travel as 18 launches, and the library's argument
     checks accept every descriptor pair."""
     from vid2vid_amd import networks as N
@@ -297,10 +297,14 @@ def test_twin_chains_record_paired_launches():
             fp = m._active_plan
             assert len(fp.conv_log) == 79 and abs(sum(c["flops"] for c in fp.conv_log) / 1e9 - 2115.0) < 0.5
             names = [lib.v2v_plan_op_name(fp.plan.h, i).decode() for i in range(fp.plan.num_ops)]
-            ops[twin] = (names.count("conv_igemm"), names.count("bn_apply"), sum(1 for c in fp.conv_log if c.get("pair")))
+            ops[twin] = (names.count("conv_igemm"), names.count("bn_apply"), sum(1 for c in fp.conv_log if c.get("pair")),
+                         sum(1 for c in fp.conv_log if c.get("fused_norm")))
             N._ENGINES.clear()
         assert ops[1][2] == 36 and ops[0][2] == 0
-        assert ops[1][0] == ops[0][0] - 18 and ops[1][1] == ops[0][1] - 18
+        # 36 convolutions in 18 launches; their norm / ReLU / residual passes run inside those launches (fused norm: the
+        # 256 workgroups of a pair are all resident on the 256 CUs), so 36 bn_apply launches disappear
+        assert ops[1][3] == 36 and ops[0][3] == 0
+        assert ops[1][0] == ops[0][0] - 18 and ops[1][1] == ops[0][1] - 36
     finally:
         N.set_record_only(False)
         N._ENGINES.clear()

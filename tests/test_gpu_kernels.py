@@ -271,6 +271,7 @@ def test_conv2d_pair_equals_two_launches(case, prec):
     cin, cout, H, W, mode, N = case
     torch.manual_seed(cin * 3 + W)
     eng = _engine(prec)
+    eng.fused_norm = False            # this test reads the raw fp32 outputs; the fused variant has its own test below
     pad = 0 if mode == "reflect" else 1
     convs = [nn.Conv2d(cin, cout, 3, padding=pad) for _ in range(2)]
     norms = [nn.BatchNorm2d(cout).to(DEV) for _ in range(2)]
@@ -315,6 +316,60 @@ def test_conv2d_pair_equals_two_launches(case, prec):
             ref_y = F.relu(F.batch_norm(refs[k], None, None, norms[k].weight.detach().cpu(), norms[k].bias.detach().cpu(), True, 0.1, 1e-5)) + _round(res[k], prec)
             assert_close(eng.unpack(y_pair).cpu(), ref_y, 1e-4 if prec == "fp32" else 2e-2, "pair member %d norm+relu+residual" % k)
     for key, t in list(eng._fin_counters.items()) + list(eng._sk_counters.items()):
+        assert int(t.abs().sum().item()) == 0, "tickets of %s must be re-armed" % (key,)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(128, 72, 24, 64, "reflect", 1), (192, 200, 19, 45, "reflect", 2), (256, 64, 32, 64, "zero", 1),
+                                  (1024, 1024, 32, 64, "reflect", 1)])
+@torch.no_grad()
+def test_fused_norm_pair_equals_conv_plus_bn_apply(case, prec):
+    """V2V_OUT_NORM_ACT_NHWC (include/v2v_hip.h, "fused norm"): conv + training-mode BatchNorm + ReLU + residual in one
+    paired launch, the workgroups of a channel tile meeting at a spin barrier.  Against the unfused pair (raw fp32 output,
+    in-kernel finalize, bn_apply launch): same scale / shift / mean / invstd record and running statistics bit for bit,
+    same activations; repeated launches (ticket re-arm) and the last case is the 1024 -> 1024 layer of the 512x256 frame
+    at its full size (256 workgroups = every CU)."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, mode, N = case
+    torch.manual_seed(cin + 7 * W)
+    eng = _engine(prec)
+    pad = 0 if mode == "reflect" else 1
+    convs = [nn.Conv2d(cin, cout, 3, padding=pad).to(DEV) for _ in range(2)]
+    norms_f = [nn.BatchNorm2d(cout).to(DEV) for _ in range(2)]
+    for n in norms_f:
+        n.weight.normal_(1.0, 0.1); n.bias.normal_(0.0, 0.1)
+    norms_u = [nn.BatchNorm2d(cout).to(DEV) for _ in range(2)]
+    for a, b in zip(norms_f, norms_u):
+        b.load_state_dict(a.state_dict())
+    eng.update_running_stats = True
+    xa = [eng.pack((torch.randn(N, cin, H, W) * (1.0 + i)).to(DEV)) for i in range(2)]
+    ra = [eng.pack(torch.randn(N, cout, H, W).to(DEV)) for _ in range(2)]
+    pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
+    for tile in (80, 81, 82, 83, 84, 85):
+        eng.pair_override = (tile, 1)
+        if not eng.fused_norm_fits((tile, 1, 0), N, H, W, cout):
+            continue
+        for rep in range(3):                                       # the barrier tickets must re-arm themselves
+            eng.fused_norm = True
+            yf = eng.conv_group_pair(xa[0], convs[0], norms_f[0], xa[1], convs[1], norms_f[1], pm, po, L.ACT_RELU, 0.0,
+                                     adds_a=(ra[0], None), adds_b=(ra[1], None), labels=("a", "b"))
+            assert eng.conv_log[-1]["fused_norm"] and eng.conv_log[-1]["tile"] == tile
+            ssf = []
+            for sset in (0, 1):
+                with eng.scratch_set(sset):
+                    ssf.append(eng.scratch("scale_shift", 4 * cout)[:4 * cout].clone())
+            eng.fused_norm = False
+            yu = eng.conv_group_pair(xa[0], convs[0], norms_u[0], xa[1], convs[1], norms_u[1], pm, po, L.ACT_RELU, 0.0,
+                                     adds_a=(ra[0], None), adds_b=(ra[1], None), labels=("a", "b"))
+            assert not eng.conv_log[-1]["fused_norm"]
+            for k, sset in ((0, 0), (1, 1)):
+                with eng.scratch_set(sset):
+                    ssu = eng.scratch("scale_shift", 4 * cout)[:4 * cout]
+                assert torch.isfinite(yf[k].t.float()).all(), "fused norm barrier gave up (tile %d)" % tile
+                assert torch.equal(ssf[k], ssu), "scale / shift / mean / invstd record differs (tile %d member %d)" % (tile, k)
+                assert torch.equal(norms_f[k].running_mean, norms_u[k].running_mean) and torch.equal(norms_f[k].running_var, norms_u[k].running_var)
+                assert_close(yf[k].t.float().cpu(), yu[k].t.float().cpu(), 1e-6 if prec == "fp32" else 8e-3, "fused vs unfused activations, tile %d member %d" % (tile, k))
+    for key, t in list(eng._fin_counters.items()):
         assert int(t.abs().sum().item()) == 0, "tickets of %s must be re-armed" % (key,)
 
 

@@ -42,6 +42,7 @@ __device__ __forceinline__ ConvKArgs select_group(const ConvKArgs& p) {
         q.in = p.g1.in; q.w = p.g1.w; q.bias = p.g1.bias; q.out = p.g1.out; q.stats = p.g1.stats;
         q.fin_counter = p.g1.fin_counter; q.fin_gamma = p.g1.fin_gamma; q.fin_beta = p.g1.fin_beta; q.fin_out = p.g1.fin_out;
         q.fin_rmean = p.g1.fin_rmean; q.fin_rvar = p.g1.fin_rvar; q.slabs = p.g1.slabs; q.sk_counter = p.g1.sk_counter;
+        q.res0 = p.g1.res0; q.res1 = p.g1.res1;
     }
     return q;
 }

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp3_kernel(const ConvKArgs p_in) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail duplicates must land before the LDS is reused
     __syncthreads();
 
-    conv_epilogue<T, BM, BN, WGM, WGN>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt,
+    conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt,
         [&](int row) -> int {                  // TW is a power of two; N*OH*OW < 2^31 (host check)
             const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
             if (oh >= H || ow >= W) return -1;

@@ -376,8 +376,17 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.ktot[c] = g.ktot[c]; k.kpad[c] = g.kpad[c]; k.wrow[c] = g.wrow[c]; k.woff[c] = g.woff[c];
     }
     k.out_mode = d->out_mode; k.act = d->act; k.act_param = d->act_param; k.out_scale = d->out_scale;
+    if (d->out_mode == V2V_OUT_NORM_ACT_NHWC) {
+        if ((launching && (!d->fin_counter || !d->stats || !d->fin_scale_shift || d->fin_count <= 0)) || d->splitk > 1 || d->transposed ||
+            d->cout != d->cout_stride || d->tile < 80 || d->tile >= 88 || d->cout > 128 * 64) {
+            set_error("conv: fused norm needs tile 80..87, splitk <= 1, cout == cout_stride, stats, fin_counter (256 ints), fin_scale_shift, fin_count");
+            return V2V_EINVAL;
+        }
+        k.res0 = (const char*)d->res0; k.res1 = (const char*)d->res1;
+    }
     if (d->fin_counter) {
-        if (!d->stats || !d->fin_scale_shift || d->fin_count <= 0 || d->out_mode != V2V_OUT_RAW_F32_NHWC) {
+        if (!d->stats || !d->fin_scale_shift || d->fin_count <= 0 ||
+            (d->out_mode != V2V_OUT_RAW_F32_NHWC && d->out_mode != V2V_OUT_NORM_ACT_NHWC)) {
             set_error("conv: in-kernel norm finalize needs stats, fin_scale_shift, fin_count and RAW output"); return V2V_EINVAL;
         }
         k.fin_counter = d->fin_counter; k.fin_gamma = d->fin_gamma; k.fin_beta = d->fin_beta; k.fin_out = d->fin_scale_shift;
@@ -501,6 +510,29 @@ extern "C" int v2v_conv_tile_config(const v2v_conv_desc* d) {
     return op.cfg;
 }
 
+// Fused norm: the spin barrier needs every workgroup of the launch on the chip at once (one workgroup per CU at these
+// LDS sizes).  No device (dry run on a CPU host): the MI355X's 256 CUs are assumed.
+static int device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else { (void)hipGetLastError(); cus = 256; }
+    }
+    return cus;
+}
+
+static int fused_norm_resident(const ConvOp* op) {
+    const long long wgs = (long long)op->k.m_tiles * op->k.n_tiles * op->groups;
+    if (wgs > device_cus()) {
+        set_error("conv: fused norm needs all %lld workgroups resident at once, the device has %d compute units", wgs, device_cus());
+        return V2V_EINVAL;
+    }
+    return 0;
+}
+
+extern "C" int v2v_conv_fused_norm_max_workgroups(void) { return device_cus(); }
+
 extern "C" int v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, void* stream) {
     auto op = std::make_unique<ConvOp>();
     ConvOp ob;
@@ -532,7 +564,15 @@ extern "C" int v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, v
     g.in = ob.k.in; g.w = ob.k.w; g.bias = ob.k.bias; g.out = ob.k.out; g.stats = ob.k.stats;
     g.fin_counter = ob.k.fin_counter; g.fin_gamma = ob.k.fin_gamma; g.fin_beta = ob.k.fin_beta; g.fin_out = ob.k.fin_out;
     g.fin_rmean = ob.k.fin_rmean; g.fin_rvar = ob.k.fin_rvar; g.slabs = ob.k.slabs; g.sk_counter = ob.k.sk_counter;
+    g.res0 = ob.k.res0; g.res1 = ob.k.res1;
     op->groups = 2;
+    if (a->out_mode == V2V_OUT_NORM_ACT_NHWC) {
+        if ((a->res0 != nullptr) != (b->res0 != nullptr) || (a->res1 != nullptr) != (b->res1 != nullptr)) {
+            set_error("conv pair: the members must have the same residual operands"); return V2V_EINVAL;
+        }
+        rc = fused_norm_resident(op.get());
+        if (rc != 0) return rc;
+    }
     return submit(std::move(op), stream);
 }
 
@@ -540,5 +580,9 @@ extern "C" int v2v_conv2d(const v2v_conv_desc* d, void* stream) {
     auto op = std::make_unique<ConvOp>();
     int rc = build_conv(d, op.get());
     if (rc != 0) return rc;
+    if (d->out_mode == V2V_OUT_NORM_ACT_NHWC) {
+        rc = fused_norm_resident(op.get());
+        if (rc != 0) return rc;
+    }
     return submit(std::move(op), stream);
 }

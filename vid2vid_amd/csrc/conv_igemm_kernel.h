@@ -11,6 +11,7 @@ struct ConvGroupPtrs {
     const char* in; const char* w; const float* bias; char* out; float* stats;
     int* fin_counter; const float* fin_gamma; const float* fin_beta; float* fin_out; float* fin_rmean; float* fin_rvar;
     float* slabs; int* sk_counter;
+    const char* res0; const char* res1;
 };
 
 struct ConvKArgs {
@@ -48,6 +49,7 @@ struct ConvKArgs {
     int pf_dist, pf_mask;
     int tiles_h, tiles_w; // conv3x3_patch_kernel: output tiles per image (m_tiles = N * tiles_h * tiles_w)
     int ablate;          // profiling ablations (v2v_conv_desc.ablate); results are WRONG when non-zero
+    const char* res0; const char* res1;   // V2V_OUT_NORM_ACT_NHWC: residuals added after the activation (or NULL)
     ConvGroupPtrs g1;    // grouped launch (conv3x3_pp2_kernel): operands of block z == 1
 };
 
@@ -90,7 +92,7 @@ template <> struct Mma<float> {
 // norm finalize.  `pix_of(row)` maps a tile row (0..BM-1) to the output pixel index in [N][OH][OW], or < 0 when the
 // row lies outside the layer.  Every wave of the workgroup (the prefetch helper included) must call it: it contains
 // workgroup barriers.
-template <typename T, int BM, int BN, int WGM, int WGN, typename PixOf>
+template <typename T, int BM, int BN, int WGM, int WGN, bool FUSED_NORM = false, typename PixOf = void>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], char* smem,
                                               const int tid, const int wm, const int wn, const bool helper,
                                               const int cls, const int tiles, const int lin, const int slice, const int S,
@@ -197,6 +199,189 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             opx[i][r] = (helper || (p.ablate & 4)) ? -1 : o;
         }
     const unsigned cs_out = (unsigned)p.cout_stride;
+    if constexpr (FUSED_NORM) {
+        if (p.out_mode == V2V_OUT_NORM_ACT_NHWC) {
+            // ---- conv + training-mode norm + activation (+ residuals) in one launch (include/v2v_hip.h, "fused norm") ----
+            // 1. this tile's (sum, sum^2) per output channel -> its statistics row (agent-scope store)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ncol = nt * BN + wn * WN + j * 32 + lr;
+                const bool nvalid = ncol < p.cout;
+                const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (opx[i][r] >= 0 && nvalid) {
+                            const float v = acc[i][j][r] + bv;
+                            s1 += v;
+                            s2 = __builtin_fmaf(v, v, s2);          // explicit: the raw and the fused-norm paths must round alike
+                        }
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (hi == 0) {
+                    const int c = wn * WN + j * 32 + lr;
+                    red[(wm * BN + c) * 2 + 0] = s1;
+                    red[(wm * BN + c) * 2 + 1] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid < BN) {
+                const int ncol = nt * BN + tid;
+                if (ncol < p.cout) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < WGM; ++q) { s1 += red[(q * BN + tid) * 2 + 0]; s2 += red[(q * BN + tid) * 2 + 1]; }
+                    const unsigned long long bits = (unsigned long long)__float_as_uint(s1) | ((unsigned long long)__float_as_uint(s2) << 32);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.stats + ((long long)stat_row * p.cout + ncol) * 2), bits,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // 2. while the other workgroups of this channel tile arrive: park the pre-norm values (fp32) in LDS in pixel-major
+            //    order and fetch this thread's share of the residuals, so that the work behind the barrier is one short,
+            //    vectorised pass (the first version normalised in the MFMA layout with 2-byte stores: +8 us per launch)
+            constexpr int NTH = NW * 64, PH = NTH / BN;
+            constexpr int VEC = ElemTraits<T>::VEC;
+            constexpr int CPR = BN / VEC;                            // 16-byte output chunks per pixel row of the tile
+            constexpr int NV = BM * CPR / NTH;                       // chunks per thread
+            static_assert(BM * CPR % NTH == 0 && NV >= 1, "fused norm: tile / thread split");
+            static_assert(20480 + BM * BN * 4 <= 160 * 1024, "fused norm: staging tile");
+            float* const stg = reinterpret_cast<float*>(smem + 20480);     // [BM][BN] fp32, behind acc2 / ssl / flag
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int c = wn * WN + j * 32 + lr;
+                const int ncol = nt * BN + c;
+                const float bv = (p.bias != nullptr && ncol < p.cout) ? p.bias[ncol] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stg[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * BN + c] = acc[i][j][r] + bv;
+            }
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            u32x4 rv0[NV], rv1[NV];
+            int vpix[NV];
+            const T* const res0 = reinterpret_cast<const T*>(p.res0);
+            const T* const res1 = reinterpret_cast<const T*>(p.res1);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int v = tid + q * NTH;
+                const int row = v / CPR, ch = (v - row * CPR) * VEC;
+                const int o = pix_of(row);
+                vpix[q] = (o >= 0 && nt * BN + ch < p.cout) ? o : -1;        // cout % VEC == 0 (host check): whole chunks
+                rv0[q] = u32x4{0u, 0u, 0u, 0u}; rv1[q] = rv0[q];
+                if (vpix[q] >= 0) {
+                    const unsigned e = (unsigned)o * cs_out + (unsigned)(nt * BN + ch);
+                    if (res0) rv0[q] = *reinterpret_cast<const u32x4*>(res0 + e);
+                    if (res1) rv1[q] = *reinterpret_cast<const u32x4*>(res1 + e);
+                }
+            }
+            // 3. spin barrier of the workgroups that share this output-channel tile (all resident: host check)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int total = (int)gridDim.y * p.m_tiles;
+            int* const flag = reinterpret_cast<int*>(smem + 16384);
+            if (tid == 0) {
+                int* const arrive = p.fin_counter + nt;
+                int ok = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1 ? 1 : 0;
+                for (int it = 0; !ok && it < (1 << 20); ++it) {    // bounded (~1 s): a barrier that cannot complete gives up
+                    __builtin_amdgcn_s_sleep(1);
+                    ok = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total ? 1 : 0;
+                }
+                *flag = ok;
+            }
+            __syncthreads();
+            const bool barrier_ok = *flag != 0;
+            // 4. scale / shift from all rows, fixed order: the arithmetic of the in-kernel finalize below, in every workgroup
+            double* acc2 = reinterpret_cast<double*>(smem);          // [PH][BN][2], <= 8 KiB
+            float* ssl = reinterpret_cast<float*>(smem + 12288);     // [2][BN] scale, shift
+            {
+                const int c = tid % BN, ph = tid / BN;
+                const int ncol = nt * BN + c;
+                double s1 = 0.0, s2 = 0.0;
+                if (ncol < p.cout && ph < PH) {
+                    for (int r = ph; r < total; r += PH) {
+                        const unsigned long long bits = __hip_atomic_load(
+                            reinterpret_cast<const unsigned long long*>(p.stats + ((long long)r * p.cout + ncol) * 2),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
+                        s2 += (double)__uint_as_float((unsigned)(bits >> 32));
+                    }
+                }
+                if (ph < PH) { acc2[(ph * BN + c) * 2 + 0] = s1; acc2[(ph * BN + c) * 2 + 1] = s2; }
+                __syncthreads();
+                if (ph == 0) {
+                    float fsc = 0.f, fsh = 0.f;
+                    if (ncol < p.cout) {
+                        s1 = 0.0; s2 = 0.0;
+#pragma unroll
+                        for (int q = 0; q < PH; ++q) { s1 += acc2[(q * BN + c) * 2 + 0]; s2 += acc2[(q * BN + c) * 2 + 1]; }
+                        const double mean = s1 * p.fin_inv_count;
+                        double var = s2 * p.fin_inv_count - mean * mean;
+                        if (var < 0.0) var = 0.0;
+                        const double invstd = 1.0 / sqrt(var + (double)p.fin_eps);
+                        const double g = p.fin_gamma ? (double)p.fin_gamma[ncol] : 1.0;
+                        const double b = p.fin_beta ? (double)p.fin_beta[ncol] : 0.0;
+                        const double sc = g * invstd;
+                        fsc = (float)sc; fsh = (float)(b - mean * sc);
+                        if (!barrier_ok) fsc = fsh = __uint_as_float(0x7fc00000u);      // poison: the caller sees NaN, not stale data
+                        if (stat_row == 0) {             // one writer per channel tile: the [4][cout] record and the running statistics
+                            p.fin_out[ncol] = fsc;
+                            p.fin_out[p.cout + ncol] = fsh;
+                            p.fin_out[2 * p.cout + ncol] = (float)mean;
+                            p.fin_out[3 * p.cout + ncol] = (float)invstd;
+                            if (p.fin_rmean) p.fin_rmean[ncol] = (1.f - p.fin_momentum) * p.fin_rmean[ncol] + p.fin_momentum * (float)mean;
+                            if (p.fin_rvar)  p.fin_rvar[ncol]  = (1.f - p.fin_momentum) * p.fin_rvar[ncol] + p.fin_momentum * (float)(var * p.fin_unbias);
+                        }
+                    }
+                    ssl[c] = fsc; ssl[BN + c] = fsh;
+                }
+            }
+            __syncthreads();
+            // everyone has read the rows: the last to leave re-arms both tickets for the next launch / graph replay
+            if (tid == 0) {
+                int* const depart = p.fin_counter + 128 + nt;
+                const int tk = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == total - 1) {
+                    __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // 5. normalise, activate, add the residuals, 16-byte stores (bn_apply_kernel's arithmetic, element for element)
+            T* const out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if (vpix[q] < 0) continue;
+                const int v = tid + q * NTH;
+                const int row = v / CPR, ch = (v - row * CPR) * VEC;
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    o[e] = apply_act(stg[row * BN + ch + e] * ssl[ch + e] + ssl[BN + ch + e], p.act, p.act_param);
+                const unsigned eo = (unsigned)vpix[q] * cs_out + (unsigned)(nt * BN + ch);
+                if constexpr (VEC == 4) {
+                    if (res0) { o[0] += __uint_as_float(rv0[q][0]); o[1] += __uint_as_float(rv0[q][1]); o[2] += __uint_as_float(rv0[q][2]); o[3] += __uint_as_float(rv0[q][3]); }
+                    if (res1) { o[0] += __uint_as_float(rv1[q][0]); o[1] += __uint_as_float(rv1[q][1]); o[2] += __uint_as_float(rv1[q][2]); o[3] += __uint_as_float(rv1[q][3]); }
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + eo) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    if (res0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[2 * e] += __uint_as_float(rv0[q][e] << 16); o[2 * e + 1] += __uint_as_float(rv0[q][e] & 0xffff0000u); }
+                    }
+                    if (res1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[2 * e] += __uint_as_float(rv1[q][e] << 16); o[2 * e + 1] += __uint_as_float(rv1[q][e] & 0xffff0000u); }
+                    }
+                    u32x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (unsigned)f32_to_bf16_bits(o[2 * e]) | ((unsigned)f32_to_bf16_bits(o[2 * e + 1]) << 16);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + eo) = pk;
+                }
+            }
+            return;
+        }
+    }
     if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
         float* const out = reinterpret_cast<float*>(p.out);
 #pragma unroll
@@ -212,7 +397,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                     if (opx[i][r] >= 0 && nvalid) {
                         const float v = acc[i][j][r] + bv;
                         s1 += v;
-                        s2 += v * v;
+                        s2 = __builtin_fmaf(v, v, s2);          // explicit: the raw and the fused-norm paths must round alike
                         out[(unsigned)opx[i][r] * cs_out + (unsigned)ncol] = v;
                     }
             if (want_stats) {

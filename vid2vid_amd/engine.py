@@ -292,6 +292,10 @@ class Engine:
         # stems over encoded label maps as a weight gather-sum (csrc/onehot_stem.hip); V2V_ONEHOT_STEM=0: dense conv on the encoding
         self.onehot_stem = bool(int(os.environ.get("V2V_ONEHOT_STEM", "1")))
         self.onehot_slice = int(os.environ.get("V2V_ONEHOT_SLICE", "0"))      # output channels per workgroup: 32 / 64, 0 = default
+        # conv + norm + activation + residuals in one launch (spin barrier between the workgroups of a channel tile) for
+        # the paired ResnetBlock convolutions; V2V_FUSED_NORM=0: raw fp32 output + bn_apply launch
+        self.fused_norm = bool(int(os.environ.get("V2V_FUSED_NORM", "1")))
+        self._fused_norm_wgs = None
         self._scratch = {}       # name -> tensor (grown on demand, shared between layers)
         self._grids = {}
         self._zero_page = None
@@ -610,9 +614,10 @@ class Engine:
                 and tuple(xa.t.shape) == tuple(xb.t.shape) and xa.Cs == xb.Cs and xa.C == xb.C)
         return bool(same and ma.kernel_size == (3, 3) and ma.stride == (1, 1) and xa.Cs % bke == 0)
 
-    def _pair_desc(self, x, mod, pad_mode, pad, tile3, fin, label):
+    def _pair_desc(self, x, mod, pad_mode, pad, tile3, fin, label, fused=None):
         """Descriptor of one member of a paired launch: raw fp32 NHWC output + statistics (+ in-kernel finalize) on the
-        CURRENT scratch sub-set."""
+        CURRENT scratch sub-set.  fused = (act, act_param, res0, res1, y): the norm, activation and residual adds run in
+        the conv kernel (V2V_OUT_NORM_ACT_NHWC) and `y` (an Act) receives the result; no raw tensor."""
         pc = self._use_korder1_pc(mod, x.Cs)
         N, H, W = x.N, x.H, x.W
         d = ConvDesc()
@@ -633,14 +638,23 @@ class Engine:
             raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
         cs = (pc.cout + 3) // 4 * 4
         d.cout_stride = cs
-        raw = self.scratch("raw", N * H * W * cs)
-        d.out = raw.data_ptr()
+        if fused is not None:
+            act, act_param, res0, res1, y = fused
+            raw = None
+            d.out_mode, d.act, d.act_param = L.OUT_NORM_ACT_NHWC, act, act_param
+            d.cout_stride = y.Cs
+            d.out = y.t.data_ptr()
+            d.res0 = None if res0 is None else res0.t.data_ptr()
+            d.res1 = None if res1 is None else res1.t.data_ptr()
+        else:
+            raw = self.scratch("raw", N * H * W * cs)
+            d.out = raw.data_ptr()
         d.stats = None
         rows = lib.v2v_conv_stats_rows(C.byref(d))
         if rows <= 0:
             check(rows or -1, "conv_stats_rows")
         d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()
-        finalized = fin is not None and N * H * W <= FUSE_FINALIZE_MAX_PIXELS
+        finalized = fin is not None and (fused is not None or N * H * W <= FUSE_FINALIZE_MAX_PIXELS)
         if finalized:
             norm, ss = fin
             gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
@@ -671,9 +685,22 @@ class Engine:
             pc.refresh()
         return pc
 
-    def conv_pair(self, xa, ma, xb, mb, pad_mode, pad, fins, labels):
+    def fused_norm_fits(self, tile3, N, H, W, cout, members=2):
+        """V2V_OUT_NORM_ACT_NHWC (include/v2v_hip.h, "fused norm"): single-phase tiles, no split-K, every workgroup of the
+        launch resident at once."""
+        t, S = tile3[0], max(int(tile3[1]), 1)
+        if not (self.fused_norm and self.fused_finalize and 80 <= t < 88 and S == 1 and cout % vec_of(self.dtype) == 0):
+            return False
+        th, tw, bn = PATCH_CFGS[t]
+        if self._fused_norm_wgs is None:
+            self._fused_norm_wgs = int(lib.v2v_conv_fused_norm_max_workgroups())
+        return members * N * -(-H // th) * -(-W // tw) * -(-cout // bn) <= self._fused_norm_wgs
+
+    def conv_pair(self, xa, ma, xb, mb, pad_mode, pad, fins, labels, fuse=None):
         """Two convolutions of identical geometry as ONE launch (include/v2v_hip.h, v2v_conv2d_pair).  Member b works on
-        scratch sub-set 1 of the current lane.  Returns ((raw, rows, finalized), (raw, rows, finalized)), shape."""
+        scratch sub-set 1 of the current lane.  Returns ((raw, rows, finalized), (raw, rows, finalized)), shape.
+        fuse = (act, act_param, adds_a, adds_b, ya, yb): when the selected tile allows it the norm / activation /
+        residual adds run inside the launch and ya / yb receive the results (raw is then None)."""
         N, H, W = xa.N, xa.H, xa.W
         key = (-2, ma.in_channels, ma.out_channels, N, H, W, xa.Cs)
         if self.pair_override is not None:
@@ -681,23 +708,27 @@ class Engine:
         elif key in self._tuned:
             tile3 = _cfg3(self._tuned[key])
         elif self.autotune and self.plan is None and not self.record_only and not torch.is_grad_enabled():
-            tile3 = self._tuned[key] = self._autotune_pair(xa, ma, xb, mb, pad_mode, pad, fins, key)
+            tile3 = self._tuned[key] = self._autotune_pair(xa, ma, xb, mb, pad_mode, pad, fins, key, fuse=fuse)
             self._save_tune_cache()
         else:
             tile3 = (80 if W % 64 else 83, 1, 0)
-        da, rawa, rowsa, fina, pca = self._pair_desc(xa, ma, pad_mode, pad, tile3, fins[0], labels[0])
+        fa = fb = None
+        if fuse is not None and fins[0] is not None and self.fused_norm_fits(tile3, N, H, W, ma.out_channels):
+            act, act_param, adds_a, adds_b, ya, yb = fuse
+            fa, fb = (act, act_param, adds_a[0], adds_a[1], ya), (act, act_param, adds_b[0], adds_b[1], yb)
+        da, rawa, rowsa, fina, pca = self._pair_desc(xa, ma, pad_mode, pad, tile3, fins[0], labels[0], fused=fa)
         with self.scratch_set(1):
-            db, rawb, rowsb, finb, pcb = self._pair_desc(xb, mb, pad_mode, pad, tile3, fins[1], labels[1])
+            db, rawb, rowsb, finb, pcb = self._pair_desc(xb, mb, pad_mode, pad, tile3, fins[1], labels[1], fused=fb)
         check(lib.v2v_conv2d_pair(C.byref(da), C.byref(db), _stream()), "conv2d_pair " + labels[0])
         self.label(labels[0] + " + " + labels[1])
         for lbl, pc in ((labels[0], pca), (labels[1], pcb)):
             self.conv_log.append(dict(label=lbl, N=N, H=H, W=W, OH=H, OW=W, cin=pc.cin, cout=pc.cout, tune_key=key,
-                                      KH=3, KW=3, stride=1, transposed=False, pair=True,
+                                      KH=3, KW=3, stride=1, transposed=False, pair=True, fused_norm=fa is not None,
                                       flops=2.0 * N * H * W * pc.cout * pc.cin * 9,
                                       tile=tile3[0], splitk=max(int(tile3[1]), 1), prefetch=0))
         return ((rawa, rowsa, fina), (rawb, rowsb, finb)), (N, H, W)
 
-    def _autotune_pair(self, xa, ma, xb, mb, pad_mode, pad, fins, key, reps=7):
+    def _autotune_pair(self, xa, ma, xb, mb, pad_mode, pad, fins, key, reps=7, fuse=None):
         """Measured choice of (tile, split-K) for a paired launch: every second-schedule ping-pong tile, unsplit and
         split 2 (cold weights: a 384 MB memset between launches, as _autotune)."""
         ncc = xa.Cs // (64 if self.dtype == L.BF16 else 32)
@@ -711,10 +742,14 @@ class Engine:
             for S in (1, 2):
                 if S > 1 and (ncc < 2 * S or tiles * S * 2 > 1024):
                     continue
+                fa = fb = None
+                if fuse is not None and fins[0] is not None and self.fused_norm_fits((t, S, 0), xa.N, xa.H, xa.W, ma.out_channels):
+                    act, act_param, adds_a, adds_b, ya, yb = fuse         # timed as it will run: norm / act / adds in the launch
+                    fa, fb = (act, act_param, adds_a[0], adds_a[1], ya), (act, act_param, adds_b[0], adds_b[1], yb)
                 try:
-                    da = self._pair_desc(xa, ma, pad_mode, pad, (t, S, 0), fins[0], "tune")[0]
+                    da = self._pair_desc(xa, ma, pad_mode, pad, (t, S, 0), fins[0], "tune", fused=fa)[0]
                     with self.scratch_set(1):
-                        db = self._pair_desc(xb, mb, pad_mode, pad, (t, S, 0), fins[1], "tune")[0]
+                        db = self._pair_desc(xb, mb, pad_mode, pad, (t, S, 0), fins[1], "tune", fused=fb)[0]
                 except RuntimeError:
                     continue
                 if lib.v2v_conv2d_pair(C.byref(da), C.byref(db), st) != 0:
@@ -728,6 +763,8 @@ class Engine:
                     e1[r].record()
                 e1[-1].synchronize()
                 ms = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))[reps // 2]
+                if fuse is not None and fa is None:
+                    ms += 0.012                  # the bn_apply_pair launch the unfused variant still needs (~6 us + its gap)
                 alts.append((ms, (t, S, 0)))
                 if ms < best_ms:
                     best, best_ms = (t, S, 0), ms
@@ -750,8 +787,12 @@ class Engine:
             ssb = self.scratch("scale_shift", 4 * cout)
         pad = conva.padding[0] if pad_override is None else pad_override
         fins = ((norma, ssa), (normb, ssb)) if self.fused_finalize else (None, None)
-        (ra, rb), shp = self.conv_pair(xa, conva, xb, convb, pad_mode, pad, fins, labels)
-        N, OH, OW = shp
+        N, OH, OW = xa.N, xa.H, xa.W
+        ya, yb = self.empty_act(N, OH, OW, cout), self.empty_act(N, OH, OW, cout)
+        (ra, rb), shp = self.conv_pair(xa, conva, xb, convb, pad_mode, pad, fins, labels,
+                                       fuse=(act, act_param, adds_a, adds_b, ya, yb))
+        if ra[0] is None:                 # norm + activation + residuals ran inside the conv launch
+            return ya, yb
         cs_raw = (cout + 3) // 4 * 4
         for (raw, rows, fin), norm, ss, k, lbl in ((ra, norma, ssa, 0, labels[0]), (rb, normb, ssb, 1, labels[1])):
             if not fin:                                       # large layers: parallel two-stage finalize per member
@@ -766,7 +807,6 @@ class Engine:
                     check(lib.v2v_bn_finalize(_ptr(st), rows, cout, N * OH * OW, _ptr(gamma), _ptr(beta), eps,
                                               _ptr(ss), _ptr(rm), _ptr(rv), mom, _ptr(ws), _stream()), "bn_finalize " + lbl)
                     self.label(lbl + ".norm")
-        ya, yb = self.empty_act(N, OH, OW, cout), self.empty_act(N, OH, OW, cout)
         a0, a1 = adds_a
         b0, b1 = adds_b
         check(lib.v2v_bn_apply_pair(_ptr(ra[0]), _ptr(ssa), _ptr(None if a0 is None else a0.t), _ptr(None if a1 is None else a1.t), _ptr(ya.t),

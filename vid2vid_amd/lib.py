@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libv2v_hip.so")
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-OUT_RAW_F32_NHWC, OUT_ACT_NHWC, OUT_F32_NCHW = 0, 1, 2
+OUT_RAW_F32_NHWC, OUT_ACT_NHWC, OUT_F32_NCHW, OUT_NORM_ACT_NHWC = 0, 1, 2, 3
 
 
 class ConvDesc(C.Structure):
@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("fin_eps", C.c_float), ("fin_momentum", C.c_float), ("fin_count", C.c_int64),
         ("splitk", C.c_int32), ("prefetch", C.c_int32), ("slabs", C.c_void_p), ("sk_counter", C.c_void_p),
         ("w_korder", C.c_int32), ("ablate", C.c_int32),
+        ("res0", C.c_void_p), ("res1", C.c_void_p),
     ]
 
 
@@ -61,6 +62,7 @@ PROTOTYPES = {
     "v2v_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_conv_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_tile_config": (C.c_int, [C.POINTER(ConvDesc)]),
+    "v2v_conv_fused_norm_max_workgroups": (C.c_int, []),
     "v2v_conv_splitk_workspace": (_L, [C.POINTER(ConvDesc), C.POINTER(_I)]),
     "v2v_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "v2v_conv2d_pair": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _P]),
