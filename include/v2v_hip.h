@@ -452,16 +452,34 @@ int v2v_tensor2label(const float* x, uint8_t* out, const uint8_t* cmap, int32_t 
  * v2v_conv2d with V2V_OUT_RAW_F32_NHWC.  labels / inst: [T][H][W] fp32-encoded integers (in_u8 = 0) or uint8 / int32
  * (in_u8 = 1); inst may be NULL (no edge plane; the layer then has T*label_nc input channels).  Labels outside
  * [0, label_nc) select no plane.
- * table: v2v_onehot_conv_table_bytes(cin, cout, dtype, slice) bytes, filled by v2v_onehot_conv_pack_weights from the
- * layer's fp32 [cout][cin][7][7] weight (cin = T * (label_nc + (inst ? 1 : 0))).  cout <= 128.
+ * table: v2v_onehot_conv_table_bytes(cin, cout, dtype, slice, T, label_nc) bytes, filled by v2v_onehot_conv_pack_weights
+ * from the layer's fp32 [cout][cin][7][7] weight (cin = T * (label_nc + (inst ? 1 : 0))).  cout <= 128.  With a bf16 table the
+ * instance-edge planes are not gathered row by row (an edge pixel anywhere in a wave made all 64 lanes add the row): they
+ * are a [pixels][49 T] x [49 T][cout] product of 0 / 1 edge bits with the edge rows on the matrix pipe, added in the epilogue.
  * slice: output channels per workgroup, 32 or 64, 0 = default; the same value must be given to all three calls. */
-int64_t v2v_onehot_conv_table_bytes(int32_t cin, int32_t cout, int32_t dtype, int32_t slice);
+int64_t v2v_onehot_conv_table_bytes(int32_t cin, int32_t cout, int32_t dtype, int32_t slice, int32_t T, int32_t label_nc);
 int     v2v_onehot_conv_pack_weights(const float* w, void* table, int32_t cin, int32_t cout, int32_t dtype, int32_t slice,
-                                     void* stream);
+                                     int32_t T, int32_t label_nc, void* stream);
 int     v2v_onehot_conv_stats_rows(int32_t H, int32_t W);
 int     v2v_onehot_conv7x7(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
                            float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
                            int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, void* stream);
+/* Same launch + the training-mode norm statistics finalized by the last workgroup of each channel slice (what
+ * v2v_conv_desc.fin_* does for v2v_conv2d): scale_shift receives [4][cout] = scale, shift, mean, invstd. */
+typedef struct v2v_onehot_norm {
+    int32_t* counter;          /* >= 4 zero-initialised ints, re-armed in-kernel                  */
+    const float* gamma;        /* [cout] or NULL                                                  */
+    const float* beta;         /* [cout] or NULL                                                  */
+    float* scale_shift;        /* [4][cout] out                                                   */
+    float* running_mean;       /* [cout] or NULL                                                  */
+    float* running_var;        /* [cout] or NULL                                                  */
+    float eps, momentum;
+    int64_t count;             /* H*W                                                             */
+} v2v_onehot_norm;
+int     v2v_onehot_conv7x7_norm(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
+                                float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
+                                int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, const v2v_onehot_norm* fin,
+                                void* stream);
 
 /* recordable device-to-device copy (rolling fake_B_prev window, vid2vid_model_G.py:228) */
 int v2v_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);

@@ -179,3 +179,7 @@ if has fusedtest; then
   grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_allkernels.log | cut -c1-300 | tail -12
   lap fusedtest
 fi
+if has overhead; then
+  timeout 300 python scripts/frame_overhead.py 2>/dev/null | tee gpurun_out/${TAG}_frame_overhead.txt
+  lap overhead
+fi

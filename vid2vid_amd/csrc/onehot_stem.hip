@@ -37,9 +37,17 @@ struct OneHotConvArgs {
     float* out; float* stats;                 // raw fp32 NHWC [H][W][cout_stride]; [tiles][cout][2] or NULL
     int T, H, W, label_nc, per, cout, cout_stride, tiles_w, in_u8, blob;
     unsigned sel_lo, sel_hi;                  // bf16 pairs (1, 0) and (0, 1)
+    // bf16 only: the instance-edge planes as a small dense GEMM on the matrix pipe (see edge_mfma below)
+    const char* etab;                         // [slices][CS / 32][ksteps][64 lanes][8] bf16 B fragments, or NULL: edge rows in the tap loop
+    int ksteps, xoff;                         // ceil(49 T / 16); LDS byte offset of the edge bits / k -> offset table / flag
+    // training-mode norm finalize by the last workgroup of a channel slice (as v2v_conv2d's fin_*), optional
+    int* fin_counter; const float* fin_gamma; const float* fin_beta; float* fin_out; float* fin_rmean; float* fin_rvar;
+    float fin_eps, fin_momentum; double fin_inv_count, fin_unbias;
 };
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float dot_sel(unsigned v, unsigned sel, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, v), __builtin_bit_cast(bf16x2_t, sel), acc, false);
 }
@@ -54,10 +62,20 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 }
 
 constexpr int OS_TH = 8, OS_TW = 32, OS_PH = OS_TH + 6, OS_PW = OS_TW + 6, OS_PHW = OS_PH * OS_PW;
-constexpr size_t OS_EPI_LDS = (256 * 33 + 8 * 32 * 2) * sizeof(float);    // epilogue tile + partial sums
+constexpr size_t OS_EPI_LDS = (256 * 33 + 8 * 32 * 2 + 4) * sizeof(float);    // epilogue tile + partial sums + finalize flag
 
 __host__ __device__ constexpr int os_rowb(int cs, int es) { return cs * es + 16; }
 __host__ __device__ inline int os_blob(int rows, int cs, int es) { return ((rows + 1) * os_rowb(cs, es) + 1023) / 1024 * 1024; }
+// LDS: [2 table blobs][row offsets][edge-row offsets] reused by the epilogue tile, then at `xoff` what must survive into the
+// epilogue: edge bits, k -> offset table, flag
+inline int os_ksteps(int T) { return (49 * T + 15) / 16; }
+inline size_t os_xoff(int T, int blob) {
+    size_t m = (size_t)2 * blob + (size_t)2 * T * OS_PHW * sizeof(unsigned short);
+    if (m < OS_EPI_LDS) m = OS_EPI_LDS;
+    return (m + 15) / 16 * 16;
+}
+inline size_t os_xbytes(int T, int ksteps) { return (size_t)((T * OS_PHW + 15) & ~15) + (size_t)ksteps * 32 + 16; }
+inline size_t os_etab_bytes(int slices, int cs, int ksteps) { return (size_t)slices * (cs / 32) * ksteps * 64 * 16; }
 
 // NT: frames per input (n_frames_G), 0 = run-time loop
 template <typename T, int CS, int NT>
@@ -73,6 +91,11 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
     char* const tb1 = smem + a.blob;
     unsigned short* const off_s = reinterpret_cast<unsigned short*>(smem + 2 * a.blob);     // [T][PH][PW] row offsets
     unsigned short* const eoff_s = off_s + nT * OS_PHW;                                      // edge-row offset or zero_off
+    const bool use_emfma = ES == 2 && a.etab != nullptr && a.inst != nullptr;
+    unsigned char* const ebit_s = reinterpret_cast<unsigned char*>(smem + a.xoff);           // [T][PH][PW] 0 / 1 (kept through the epilogue)
+    unsigned short* const koff_s = reinterpret_cast<unsigned short*>(smem + a.xoff + ((nT * OS_PHW + 15) & ~15));
+    int* const eflag = reinterpret_cast<int*>(koff_s + a.ksteps * 16);
+    bool any_e = false;
 
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     const int c0 = blockIdx.y * CS;                        // this workgroup's channel slice [c0, c0 + CS)
@@ -91,6 +114,8 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
         for (int p = wid; p < npieces; p += 4) os_glds16(src + p * 1024, d + p * 1024);
     };
     issue(0, tb0);
+    if (use_emfma && tid == 0) *eflag = 0;
+    __syncthreads();
 
     // ---- row offsets of the tile + halo, reflection applied (ReflectionPad2d(3) of the encoded tensor) ----
     for (int e = tid; e < nT * OS_PHW; e += 256) {
@@ -129,6 +154,14 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
         }
         off_s[e] = (unsigned short)((unsigned)lab < (unsigned)a.label_nc ? (unsigned)(t * a.per + lab) * ROWB : zero_off);
         eoff_s[e] = (unsigned short)(edge ? (unsigned)(t * a.per + a.label_nc) * ROWB : zero_off);
+        if (use_emfma) { ebit_s[e] = edge ? 1 : 0; any_e |= edge; }
+    }
+    if (use_emfma) {
+        for (int k = tid; k < a.ksteps * 16; k += 256) {    // k = t * 49 + tap -> offset of edge bit (t, dy, dx) relative to a pixel's q0
+            const int t = k / 49, tap = k - t * 49;
+            koff_s[k] = (unsigned short)(t < nT ? t * OS_PHW + (tap / 7) * OS_PW + (tap % 7) : 0xffff);
+        }
+        if (__builtin_amdgcn_ballot_w64(any_e) != 0 && lane == 0) *eflag = 1;     // benign race: every writer stores 1
     }
 
     float acc[CS];
@@ -166,7 +199,7 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
             for (int t = 0; t < NT; ++t) o[t] = off_s[t * OS_PHW + q];
 #pragma unroll
             for (int t = 0; t < NT; ++t) add_row(cur + o[t]);
-            if (a.inst) {
+            if (a.inst && !use_emfma) {
                 unsigned e[NT];
                 bool any = false;
 #pragma unroll
@@ -179,7 +212,7 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
         } else {
             for (int t = 0; t < nT; ++t) {
                 add_row(cur + off_s[t * OS_PHW + q]);
-                if (a.inst) {
+                if (a.inst && !use_emfma) {
                     const unsigned e = eoff_s[t * OS_PHW + q];
                     if (__builtin_amdgcn_ballot_w64(e != zero_off) != 0) add_row(cur + e);
                 }
@@ -196,11 +229,59 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
     float* const tile = reinterpret_cast<float*>(smem);    // [256 pixels][33]: stride 33 keeps the per-pixel writes conflict-free
     float* const red = tile + 256 * 33;                    // [8 parts][32][2]
     const bool valid = oh0 + py < H && ow0 + px < W;
+    const bool ragged = oh0 + OS_TH > H || ow0 + OS_TW > W;
+    const bool do_emfma = use_emfma && *eflag != 0;        // no edge pixel in the tile + halo: nothing to add
 #pragma unroll
     for (int k = 0; k < CS / 32; ++k) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) tile[tid * 33 + i] = valid ? acc[k * 32 + i] : 0.f;
+        for (int i = 0; i < 32; ++i) tile[tid * 33 + i] = acc[k * 32 + i];
+        if constexpr (ES == 2) {
+            if (do_emfma) {
+                // edge planes of this 32-channel chunk: E[pixel][c] = sum_k e[pixel][k] W_edge[k][c], k = (frame, tap), as
+                // v_mfma_f32_32x32x16_bf16: A = 0 / 1 edge bits of the wave's 2 x 32 pixels gathered from LDS, B = the packed
+                // edge-row fragments (global, L2-resident), C added to the pixel-major tile (one owner lane per element)
+                f32x16_t cm[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cm[m][r] = 0.f;
+                const int kg = lane >> 5;
+                const char* bsrc = a.etab + (((long long)blockIdx.y * (CS / 32) + k) * a.ksteps * 64 + lane) * 16;
+                const int qm0 = (2 * wid) * OS_PW + (lane & 31);
+                for (int ks = 0; ks < a.ksteps; ++ks) {
+                    const bf16x8_t bfrag = *reinterpret_cast<const bf16x8_t*>(bsrc + (long long)ks * 64 * 16);
+                    const uint4 ko = *reinterpret_cast<const uint4*>(koff_s + ks * 16 + kg * 8);
+                    const unsigned kk[8] = {ko.x & 0xffffu, ko.x >> 16, ko.y & 0xffffu, ko.y >> 16, ko.z & 0xffffu, ko.z >> 16, ko.w & 0xffffu, ko.w >> 16};
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int qm = qm0 + m * OS_PW;
+                        unsigned w4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned lo = kk[2 * j] != 0xffffu && ebit_s[kk[2 * j] + qm] ? 0x3f80u : 0u;
+                            const unsigned hi = kk[2 * j + 1] != 0xffffu && ebit_s[kk[2 * j + 1] + qm] ? 0x3f800000u : 0u;
+                            w4[j] = lo | hi;
+                        }
+                        const uint4 au = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        cm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, au), bfrag, cm[m], 0, 0, 0);
+                    }
+                }
+                __syncthreads();                           // every thread's own accumulators are in the tile
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int prow = 8 * (r >> 2) + 4 * kg + (r & 3);          // C layout of the 32x32 MFMA: row, col = lane & 31
+                        tile[(wid * 64 + m * 32 + prow) * 33 + (lane & 31)] += cm[m][r];
+                    }
+            }
+        }
         __syncthreads();
+        if (!valid) {                                      // pixels beyond the image: out of the statistics
+#pragma unroll
+            for (int i = 0; i < 32; ++i) tile[tid * 33 + i] = 0.f;
+        }
+        if (ragged) __syncthreads();                       // (uniform: the tile overhangs the image)
 #pragma unroll
         for (int it = 0; it < 8; ++it) {                   // 8 lanes x float4 = the 128 bytes of one pixel's chunk
             const int idx = it * 256 + tid;
@@ -228,8 +309,63 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
 #pragma unroll
             for (int part = 0; part < 8; ++part) { t1 += red[(part * 32 + tid) * 2]; t2 += red[(part * 32 + tid) * 2 + 1]; }
             float* dst = a.stats + ((long long)blockIdx.x * a.cout + c0 + k * 32 + tid) * 2;
-            dst[0] = t1;
-            dst[1] = t2;
+            if (a.fin_counter != nullptr) {          // read back by the finalizing workgroup: agent-scope write-through store
+                const unsigned long long bits = (unsigned long long)__float_as_uint(t1) | ((unsigned long long)__float_as_uint(t2) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                dst[0] = t1;
+                dst[1] = t2;
+            }
+        }
+    }
+    if (a.stats == nullptr || a.fin_counter == nullptr) return;
+    // ---- norm finalize by the LAST workgroup of this channel slice (get_norm_layer, models/networks.py:23-30): replaces a
+    //      512-row single-workgroup bn_finalize launch (34 us on the frame's critical path, profiles/r02_a22_frame_timeline*) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(red + 8 * 32 * 2);
+    if (tid == 0) {
+        const int tk = __hip_atomic_fetch_add(a.fin_counter + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == (int)gridDim.x - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(a.fin_counter + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    constexpr int PH = 256 / CS;
+    double* const acc2 = reinterpret_cast<double*>(smem);        // [PH][CS][2] <= 8 KiB
+    {
+        const int c = tid % CS, ph = tid / CS;
+        const int ncol = c0 + c;
+        double s1 = 0.0, s2 = 0.0;
+        if (ncol < a.cout) {
+            for (int r = ph; r < (int)gridDim.x; r += PH) {
+                const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.stats + ((long long)r * a.cout + ncol) * 2),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
+                s2 += (double)__uint_as_float((unsigned)(bits >> 32));
+            }
+        }
+        acc2[(ph * CS + c) * 2 + 0] = s1;
+        acc2[(ph * CS + c) * 2 + 1] = s2;
+        __syncthreads();
+        if (ph == 0 && ncol < a.cout) {
+            s1 = 0.0; s2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < PH; ++q) { s1 += acc2[(q * CS + c) * 2 + 0]; s2 += acc2[(q * CS + c) * 2 + 1]; }
+            const double mean = s1 * a.fin_inv_count;
+            double var = s2 * a.fin_inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double invstd = 1.0 / sqrt(var + (double)a.fin_eps);
+            const double g = a.fin_gamma ? (double)a.fin_gamma[ncol] : 1.0;
+            const double b = a.fin_beta ? (double)a.fin_beta[ncol] : 0.0;
+            const double sc = g * invstd;
+            a.fin_out[ncol] = (float)sc;
+            a.fin_out[a.cout + ncol] = (float)(b - mean * sc);
+            a.fin_out[2 * a.cout + ncol] = (float)mean;
+            a.fin_out[3 * a.cout + ncol] = (float)invstd;
+            if (a.fin_rmean) a.fin_rmean[ncol] = (1.f - a.fin_momentum) * a.fin_rmean[ncol] + a.fin_momentum * (float)mean;
+            if (a.fin_rvar)  a.fin_rvar[ncol]  = (1.f - a.fin_momentum) * a.fin_rvar[ncol] + a.fin_momentum * (float)(var * a.fin_unbias);
         }
     }
 }
@@ -237,8 +373,7 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
 struct OneHotConvOp : Op {
     OneHotConvArgs a; int dtype, cs, slices, tiles;
     template <typename T, int CS, int NT> int go(hipStream_t s) {
-        size_t lds = (size_t)2 * a.blob + (size_t)2 * a.T * OS_PHW * sizeof(unsigned short);
-        if (lds < OS_EPI_LDS) lds = OS_EPI_LDS;
+        const size_t lds = (size_t)a.xoff + os_xbytes(a.T, a.ksteps);
         auto kern = onehot_conv7x7_kernel<T, CS, NT>;
         static bool attr_done = false;
         if (!attr_done) {
@@ -277,19 +412,44 @@ __global__ __launch_bounds__(256) void onehot_pack_kernel(const OneHotPackArgs a
     }
 }
 
+// edge-row B fragments for the bf16 matrix pipe: etab[slice][n-tile][kstep][lane][j] = W[co][t * per + label_nc][tap] with
+// co = slice * cs + ntile * 32 + (lane & 31), k = kstep * 16 + (lane >> 5) * 8 + j = t * 49 + tap (zero beyond 49 T)
+struct OneHotEdgePackArgs { const float* w; unsigned short* etab; int cin, cout, cs, slices, ksteps, T, per, label_nc; };
+
+__global__ __launch_bounds__(256) void onehot_edge_pack_kernel(const OneHotEdgePackArgs a) {
+    const long long total = (long long)a.slices * (a.cs / 32) * a.ksteps * 64 * 8;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        long long r = e >> 9;
+        const int ks = (int)(r % a.ksteps); r /= a.ksteps;
+        const int ntile = (int)(r % (a.cs / 32)), sl = (int)(r / (a.cs / 32));
+        const int co = sl * a.cs + ntile * 32 + (lane & 31);
+        const int k = ks * 16 + (lane >> 5) * 8 + j;
+        const int t = k / 49, tap = k - t * 49;
+        float v = 0.f;
+        if (t < a.T && co < a.cout) v = a.w[((long long)co * a.cin + t * a.per + a.label_nc) * 49 + tap];
+        a.etab[e] = f32_to_bf16_bits(v);
+    }
+}
+
 struct OneHotPackOp : Op {
-    OneHotPackArgs a;
+    OneHotPackArgs a; OneHotEdgePackArgs e; bool edges;
     int launch(hipStream_t s) override {
         hipLaunchKernelGGL(onehot_pack_kernel, dim3(1024), dim3(256), 0, s, a);
+        int rc = check_launch();
+        if (rc != 0 || !edges) return rc;
+        hipLaunchKernelGGL(onehot_edge_pack_kernel, dim3(256), dim3(256), 0, s, e);
         return check_launch();
     }
     const char* name() const override { return "onehot_pack_weights"; }
 };
 
-// slice width: 0 = default (64 channels for bf16 layers wider than 64, else 32), or 32 / 64 as given
+// slice width: 0 = default = 32 channels (measured: 153 us vs 181 us for the 108 -> 128 stem with 64-channel slices,
+// profiles/r02_a23_stem_bench.txt: 68 VGPRs -> 6 waves per SIMD hide the LDS latency of the row gathers), or 32 / 64 as given
 static int slice_of(int cout, int dtype, int slice) {
-    if (slice == 32 || slice == 64) return slice;
-    return (dtype == V2V_BF16 && cout > 64) ? 64 : 32;
+    (void)cout; (void)dtype;
+    return slice == 64 ? 64 : 32;
 }
 static bool onehot_args_ok(int cin, int cout, int dtype, int slice) {
     return cin >= 1 && cout >= 1 && cout <= 128 && (dtype == V2V_F32 || dtype == V2V_BF16) && (slice == 0 || slice == 32 || slice == 64);
@@ -299,21 +459,30 @@ static bool onehot_args_ok(int cin, int cout, int dtype, int slice) {
 
 using namespace v2v;
 
-extern "C" int64_t v2v_onehot_conv_table_bytes(int32_t cin, int32_t cout, int32_t dtype, int32_t slice) {
-    if (!onehot_args_ok(cin, cout, dtype, slice)) return V2V_EINVAL;
+// the edge planes ride the matrix pipe when the layer has them (cin == T * (label_nc + 1)) and the table is bf16
+static bool has_edge_tab(int cin, int dtype, int T, int label_nc) { return dtype == V2V_BF16 && T >= 1 && cin == T * (label_nc + 1); }
+
+extern "C" int64_t v2v_onehot_conv_table_bytes(int32_t cin, int32_t cout, int32_t dtype, int32_t slice, int32_t T, int32_t label_nc) {
+    if (!onehot_args_ok(cin, cout, dtype, slice) || T < 1 || label_nc < 1 || (cin != T * label_nc && cin != T * (label_nc + 1))) return V2V_EINVAL;
     const int cs = slice_of(cout, dtype, slice), es = dtype == V2V_BF16 ? 2 : 4;
     const int blob = os_blob(cin, cs, es);
     if ((cin + 1) * os_rowb(cs, es) > 65535) return V2V_EINVAL;        // 16-bit row offsets
-    return 49ll * ceil_div(cout, cs) * blob;
+    const int slices = (int)ceil_div(cout, cs);
+    return 49ll * slices * blob + (has_edge_tab(cin, dtype, T, label_nc) ? (int64_t)os_etab_bytes(slices, cs, os_ksteps(T)) : 0);
 }
 
-extern "C" int v2v_onehot_conv_pack_weights(const float* w, void* table, int32_t cin, int32_t cout, int32_t dtype, int32_t slice, void* stream) {
-    if (!w || !table || !onehot_args_ok(cin, cout, dtype, slice)) {
-        set_error("onehot_conv_pack_weights: bad argument (cout <= 128, slice 0 / 32 / 64)"); return V2V_EINVAL;
+extern "C" int v2v_onehot_conv_pack_weights(const float* w, void* table, int32_t cin, int32_t cout, int32_t dtype, int32_t slice,
+                                            int32_t T, int32_t label_nc, void* stream) {
+    if (!w || !table || !onehot_args_ok(cin, cout, dtype, slice) || T < 1 || label_nc < 1 || (cin != T * label_nc && cin != T * (label_nc + 1))) {
+        set_error("onehot_conv_pack_weights: bad argument (cout <= 128, slice 0 / 32 / 64, cin = T * label_nc or T * (label_nc + 1))"); return V2V_EINVAL;
     }
     const int cs = slice_of(cout, dtype, slice), es = dtype == V2V_BF16 ? 2 : 4;
+    const int slices = (int)ceil_div(cout, cs), blob = os_blob(cin, cs, es);
     auto op = std::make_unique<OneHotPackOp>();
-    op->a = OneHotPackArgs{w, reinterpret_cast<char*>(table), cin, cout, cs, (int)ceil_div(cout, cs), os_blob(cin, cs, es), dtype};
+    op->a = OneHotPackArgs{w, reinterpret_cast<char*>(table), cin, cout, cs, slices, blob, dtype};
+    op->edges = has_edge_tab(cin, dtype, T, label_nc);
+    op->e = OneHotEdgePackArgs{w, reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(table) + 49ll * slices * blob),
+                               cin, cout, cs, slices, os_ksteps(T), T, label_nc + 1, label_nc};
     return submit(std::move(op), stream);
 }
 
@@ -322,9 +491,9 @@ extern "C" int v2v_onehot_conv_stats_rows(int32_t H, int32_t W) {
     return (int)(ceil_div(H, OS_TH) * ceil_div(W, OS_TW));
 }
 
-extern "C" int v2v_onehot_conv7x7(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
-                                  float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
-                                  int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, void* stream) {
+static int onehot_conv_submit(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
+                              float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
+                              int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, const v2v_onehot_norm* fin, void* stream) {
     if (!labels || !table || !out || T < 1 || H < 4 || W < 4 || label_nc < 1 || cout_stride < cout || !onehot_args_ok(1, cout, dtype, slice)) {
         set_error("onehot_conv7x7: bad argument (cout <= 128, slice 0 / 32 / 64, image at least 4x4 for the 3-pixel mirror)"); return V2V_EINVAL;
     }
@@ -333,14 +502,43 @@ extern "C" int v2v_onehot_conv7x7(const void* labels, const void* inst, int32_t 
     const int cs = slice_of(cout, dtype, slice), es = dtype == V2V_BF16 ? 2 : 4;
     const int rows = T * per;
     const int blob = os_blob(rows, cs, es);
-    const size_t lds = (size_t)2 * blob + (size_t)2 * T * OS_PHW * sizeof(unsigned short);
-    if ((rows + 1) * os_rowb(cs, es) > 65535 || lds > 156 * 1024) {
+    const int ksteps = os_ksteps(T);
+    const size_t lds = os_xoff(T, blob) + os_xbytes(T, ksteps);
+    if ((rows + 1) * os_rowb(cs, es) > 65535 || lds > 156 * 1024 || (size_t)T * OS_PHW + 49 * OS_PW > 65535) {
         set_error("onehot_conv7x7: T * (label_nc + 1) = %d weight rows do not fit the LDS", rows); return V2V_EINVAL;
     }
     auto op = std::make_unique<OneHotConvOp>();
     op->a = OneHotConvArgs{labels, inst, reinterpret_cast<const char*>(table), bias, out, stats, T, H, W, label_nc, per, cout, cout_stride,
-                           (int)ceil_div(W, OS_TW), in_u8, blob, 0x00003f80u, 0x3f800000u};
+                           (int)ceil_div(W, OS_TW), in_u8, blob, 0x00003f80u, 0x3f800000u,
+                           (inst && has_edge_tab(rows, dtype, T, label_nc))
+                               ? reinterpret_cast<const char*>(table) + 49ll * ceil_div(cout, cs) * blob : nullptr,
+                           ksteps, (int)os_xoff(T, blob),
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.0, 0.0};
+    if (fin != nullptr) {
+        if (!stats || !fin->counter || !fin->scale_shift || fin->count <= 0) {
+            set_error("onehot_conv7x7: in-kernel norm finalize needs stats, counter (>= 4 zero ints), scale_shift and count"); return V2V_EINVAL;
+        }
+        OneHotConvArgs& a = op->a;
+        a.fin_counter = fin->counter; a.fin_gamma = fin->gamma; a.fin_beta = fin->beta; a.fin_out = fin->scale_shift;
+        a.fin_rmean = fin->running_mean; a.fin_rvar = fin->running_var; a.fin_eps = fin->eps; a.fin_momentum = fin->momentum;
+        a.fin_inv_count = 1.0 / (double)fin->count;
+        a.fin_unbias = fin->count > 1 ? (double)fin->count / (double)(fin->count - 1) : 1.0;
+    }
     op->dtype = dtype; op->cs = cs; op->slices = (int)ceil_div(cout, cs);
     op->tiles = (int)(ceil_div(H, OS_TH) * ceil_div(W, OS_TW));
     return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_onehot_conv7x7(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
+                                  float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
+                                  int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, void* stream) {
+    return onehot_conv_submit(labels, inst, in_u8, table, bias, out, stats, T, H, W, label_nc, cout, cout_stride, dtype, slice, nullptr, stream);
+}
+
+extern "C" int v2v_onehot_conv7x7_norm(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
+                                       float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
+                                       int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, const v2v_onehot_norm* fin,
+                                       void* stream) {
+    if (!fin) { set_error("onehot_conv7x7_norm: fin is NULL"); return V2V_EINVAL; }
+    return onehot_conv_submit(labels, inst, in_u8, table, bias, out, stats, T, H, W, label_nc, cout, cout_stride, dtype, slice, fin, stream);
 }

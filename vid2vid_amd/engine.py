@@ -153,11 +153,11 @@ class PackedConv:
 class PackedOneHot:
     """Gather table [49][cin][64 | 128] of a 7x7 stem Conv2d (csrc/onehot_stem.hip), refreshed like PackedConv."""
 
-    def __init__(self, eng, mod, slice_):
+    def __init__(self, eng, mod, slice_, T, label_nc):
         self.mod = mod
         self.cout, self.cin = mod.weight.shape[0], mod.weight.shape[1]
-        self.dtype, self.slice = eng.dtype, slice_
-        n = lib.v2v_onehot_conv_table_bytes(self.cin, self.cout, self.dtype, slice_)
+        self.dtype, self.slice, self.T, self.label_nc = eng.dtype, slice_, T, label_nc
+        n = lib.v2v_onehot_conv_table_bytes(self.cin, self.cout, self.dtype, slice_, T, label_nc)
         if n <= 0:
             raise RuntimeError("onehot_conv_table_bytes(%d, %d) failed" % (self.cin, self.cout))
         self.buf = torch.empty(n, dtype=torch.uint8, device=eng.device)
@@ -175,7 +175,8 @@ class PackedOneHot:
         w32 = w.detach()
         if w32.dtype != torch.float32 or not w32.is_contiguous():
             w32 = w32.float().contiguous()
-        check(lib.v2v_onehot_conv_pack_weights(_ptr(w32), _ptr(self.buf), self.cin, self.cout, self.dtype, self.slice, _stream()),
+        check(lib.v2v_onehot_conv_pack_weights(_ptr(w32), _ptr(self.buf), self.cin, self.cout, self.dtype, self.slice,
+                                               self.T, self.label_nc, _stream()),
               "onehot_conv_pack_weights")
         self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()
         self.version = ver
@@ -461,13 +462,14 @@ class Engine:
                 and conv.out_channels <= 128 and conv.in_channels == x.C and x.N == 1 and x.H >= 4 and x.W >= 4
                 and not (self.plan is None and torch.is_grad_enabled()))
 
-    def onehot_conv(self, x, conv, want_stats=True, label=""):
+    def onehot_conv(self, x, conv, want_stats=True, label="", fin=None):
         """Raw fp32 NHWC output + statistics rows of the stem convolution, computed from the label maps behind `x`.
-        Returns (raw, rows, (N, OH, OW)) like conv(..., OUT_RAW_F32_NHWC, want_stats=True)."""
+        Returns (raw, rows, (N, OH, OW)) like conv(..., OUT_RAW_F32_NHWC, want_stats=True).  fin = (norm, ss): the
+        statistics are finalized in the kernel (last workgroup of each channel slice), no bn_finalize launch."""
         src = x.onehot
         pk = self._packed_onehot.get((id(conv), self.onehot_slice))
         if pk is None:
-            pk = self._packed_onehot[(id(conv), self.onehot_slice)] = PackedOneHot(self, conv, self.onehot_slice)
+            pk = self._packed_onehot[(id(conv), self.onehot_slice)] = PackedOneHot(self, conv, self.onehot_slice, src.T, src.label_nc)
         elif self.plan is None:
             pk.refresh()
         H, W, cout = x.H, x.W, conv.out_channels
@@ -478,9 +480,31 @@ class Engine:
         self._keep(pk.buf)
         if pk.bias is not None:
             self._keep(pk.bias)
-        check(lib.v2v_onehot_conv7x7(_ptr(src.labels), _ptr(src.inst), int(src.labels.dtype == torch.uint8), _ptr(pk.buf),
-                                     _ptr(pk.bias), _ptr(raw), _ptr(st), src.T, H, W, src.label_nc, cout, cs, self.dtype,
-                                     pk.slice, _stream()), "onehot_conv7x7 " + label)
+        if fin is not None and want_stats:
+            norm, ss = fin
+            gamma, beta, eps, mom, rm, rv = self._norm_params(norm, 1)
+            key = (self._lane, self._sset)
+            fin_counter = self._fin_counters.get(key)
+            if fin_counter is None:
+                fin_counter = self._fin_counters[key] = torch.zeros(512, dtype=torch.int32, device=self.device)
+            fn = L.OneHotNorm()
+            fn.counter = fin_counter.data_ptr() + 4 * 256              # words 256..: clear of the conv kernels' per-tile tickets (0..255)
+            fn.gamma = None if gamma is None else gamma.data_ptr()
+            fn.beta = None if beta is None else beta.data_ptr()
+            fn.scale_shift = ss.data_ptr()
+            fn.running_mean = None if rm is None else rm.data_ptr()
+            fn.running_var = None if rv is None else rv.data_ptr()
+            fn.eps, fn.momentum, fn.count = eps, mom, H * W
+            for t in (gamma, beta, ss, fin_counter):
+                if t is not None:
+                    self._keep(t)
+            check(lib.v2v_onehot_conv7x7_norm(_ptr(src.labels), _ptr(src.inst), int(src.labels.dtype == torch.uint8), _ptr(pk.buf),
+                                              _ptr(pk.bias), _ptr(raw), _ptr(st), src.T, H, W, src.label_nc, cout, cs, self.dtype,
+                                              pk.slice, C.byref(fn), _stream()), "onehot_conv7x7_norm " + label)
+        else:
+            check(lib.v2v_onehot_conv7x7(_ptr(src.labels), _ptr(src.inst), int(src.labels.dtype == torch.uint8), _ptr(pk.buf),
+                                         _ptr(pk.bias), _ptr(raw), _ptr(st), src.T, H, W, src.label_nc, cout, cs, self.dtype,
+                                         pk.slice, _stream()), "onehot_conv7x7 " + label)
         self.label(label)
         if len(self.conv_log) >= 100000:
             del self.conv_log[:]
@@ -563,7 +587,7 @@ class Engine:
                 gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
                 fin_counter = self._fin_counters.get((self._lane, self._sset))
                 if fin_counter is None:
-                    fin_counter = self._fin_counters[(self._lane, self._sset)] = torch.zeros(256, dtype=torch.int32, device=self.device)
+                    fin_counter = self._fin_counters[(self._lane, self._sset)] = torch.zeros(512, dtype=torch.int32, device=self.device)
                 d.fin_counter = fin_counter.data_ptr()
                 d.fin_gamma = None if gamma is None else gamma.data_ptr()
                 d.fin_beta = None if beta is None else beta.data_ptr()
@@ -661,7 +685,7 @@ class Engine:
             key = (self._lane, self._sset)
             fin_counter = self._fin_counters.get(key)
             if fin_counter is None:
-                fin_counter = self._fin_counters[key] = torch.zeros(256, dtype=torch.int32, device=self.device)
+                fin_counter = self._fin_counters[key] = torch.zeros(512, dtype=torch.int32, device=self.device)
             d.fin_counter = fin_counter.data_ptr()
             d.fin_gamma = None if gamma is None else gamma.data_ptr()
             d.fin_beta = None if beta is None else beta.data_ptr()
@@ -1071,8 +1095,11 @@ class Engine:
             return AG.conv_group(self, x, conv, pad_mode, pad_override, norm, act, act_param, add0, add1,
                                  head_nchw, out_scale, label)
         if norm is not None and self.onehot_eligible(x, conv, pad_mode, pad_override):
-            raw, rows, shp = self.onehot_conv(x, conv, label=label)
-            return self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param, add0=add0, add1=add1, label=label)
+            ss = self.scratch("scale_shift", 4 * conv.out_channels)
+            fin = (norm, ss) if self.fused_finalize else None
+            raw, rows, shp = self.onehot_conv(x, conv, label=label, fin=fin)
+            return self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param, add0=add0, add1=add1, label=label,
+                                   ss=ss, finalized=fin is not None)
         if norm is not None:
             ss = self.scratch("scale_shift", 4 * conv.out_channels)
             raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC, want_stats=True, label=label,

@@ -42,6 +42,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class OneHotNorm(C.Structure):
+    """struct v2v_onehot_norm"""
+    _fields_ = [
+        ("counter", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("scale_shift", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+        ("count", C.c_int64),
+    ]
+
+
 class WgradDesc(C.Structure):
     """struct v2v_wgrad_desc"""
     _fields_ = [
@@ -104,10 +113,11 @@ PROTOTYPES = {
     "v2v_instance_mean_planar": (C.c_int, [_P, _P, _P, _P, _I, _L, _P]),
     "v2v_tensor2im": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "v2v_tensor2label": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "v2v_onehot_conv_table_bytes": (_L, [_I, _I, _I, _I]),
-    "v2v_onehot_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "v2v_onehot_conv_table_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
+    "v2v_onehot_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_onehot_conv_stats_rows": (C.c_int, [_I, _I]),
     "v2v_onehot_conv7x7": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_onehot_conv7x7_norm": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(OneHotNorm), _P]),
     "v2v_encode_labels": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "v2v_encode_labels_u8": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "v2v_fg_mask_nhwc": (C.c_int, [_P, _P, _L, _I, _I, _P, _I, _I, _P]),
