@@ -512,7 +512,7 @@ def main():
             c = mfma_log[i]
             if c.get("pair"):
                 c2 = mfma_log[i + 1]
-                launches.append(dict(c, flops=c["flops"] + c2["flops"], label=c["label"] + " + " + c2["label"], members=2))
+                launches.append(dict(c, flops=c["flops"] + c2["flops"], label=c["label"] + " + " + c2["label"], members=2))     # (keeps fused_norm)
                 i += 2
             else:
                 launches.append(dict(c, members=1))
@@ -541,7 +541,8 @@ def main():
         if dom[0] in PATCH_CFGS:
             th_, tw_, bn = PATCH_CFGS[dom[0]]
             fam = "conv3x3_pp3_kernel" if dom[0] >= 80 else "conv3x3_pp2_kernel" if dom[0] >= 70 else "conv3x3_pp_kernel" if dom[0] >= 50 else "conv3x3_patch_kernel"
-            tile_name = "%dx%d px x %d,splitK=%d%s" % (th_, tw_, bn, dom[1], ",paired launch (2 convolutions)" if dom[2] == 2 else "")
+            tile_name = "%dx%d px x %d,splitK=%d%s%s" % (th_, tw_, bn, dom[1], ",paired launch (2 convolutions)" if dom[2] == 2 else "",
+                                                           ",norm+act+residual fused" if (rb and rb[0][1].get("fused_norm")) else "")
         else:
             bm, bn, _ = TILE_CFGS.get(dom[0], (0, 0, False))
             fam = "conv_igemm_kernel"
@@ -553,8 +554,11 @@ def main():
             import glob
             esz = 2 if args.precision == "bf16" else 4
             c0 = rb[0][1] if rb else None
+            # input + weights + output: fp32 raw (4 B) for conv + bn_apply, or with the norm fused in the activation dtype plus the
+            # residual the second convolution of a ResnetBlock adds (the measured launch is that second one)
+            fused_ = bool(c0 and c0.get("fused_norm"))
             alg = None if c0 is None else c0["members"] * (c0["N"] * c0["H"] * c0["W"] * c0["cin"] * esz + c0["cout"] * c0["cin"] * 9 * esz
-                                                            + c0["N"] * c0["OH"] * c0["OW"] * c0["cout"] * 4)
+                                                            + c0["N"] * c0["OH"] * c0["OW"] * c0["cout"] * (2 * esz if fused_ else 4))
             for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
                 tj = json.load(open(fn))
                 if list(tj.get("cfg", [])) == [dom[0], dom[1], dom[2]] and tj.get("hbm_bytes_per_launch"):

@@ -20,6 +20,7 @@ ap.add_argument("--H", type=int, default=32)
 ap.add_argument("--W", type=int, default=64)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--pair", action="store_true", help="paired launch (v2v_conv2d_pair) of two layers of this shape")
+ap.add_argument("--fused", action="store_true", help="with --pair: norm + ReLU + residual inside the launch (V2V_OUT_NORM_ACT_NHWC), as the frame runs it")
 a = ap.parse_args()
 cfg = tuple(int(v) for v in a.cfg.split(","))
 eng = Engine("cuda:0", L.BF16)
@@ -33,10 +34,17 @@ mod2 = nn.Conv2d(a.cin, a.cout, a.k, padding=0).to("cuda:0")
 x2 = eng.pack(torch.randn(1, a.cin, a.H, a.W, device="cuda:0"))
 ss2 = torch.zeros(4 * a.cout, device="cuda:0")
 eng.pair_override = (cfg[0], cfg[1])
+norm2 = nn.BatchNorm2d(a.cout).to("cuda:0")
+r1 = eng.pack(torch.randn(1, a.cout, a.H, a.W, device="cuda:0"))
+r2 = eng.pack(torch.randn(1, a.cout, a.H, a.W, device="cuda:0"))
 with torch.no_grad():
     for _ in range(a.reps):
         thrash.zero_()
-        if a.pair:
+        if a.pair and a.fused:        # every second conv of a ResnetBlock pair: + residual (the first has ReLU and no residual)
+            eng.conv_group_pair(x, mod, norm, x2, mod2, norm2, L.PAD_REFLECT, a.k // 2, L.ACT_NONE, 0.0,
+                                adds_a=(r1, None), adds_b=(r2, None), labels=("a", "b"))
+            assert eng.conv_log[-1].get("fused_norm")
+        elif a.pair:
             eng.conv_pair(x, mod, x2, mod2, L.PAD_REFLECT, a.k // 2, ((norm, ss), (norm, ss2)), ("a", "b"))
         else:
             eng.conv(x, mod, L.PAD_REFLECT, a.k // 2, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))

@@ -79,8 +79,8 @@ if has prof2; then
   python $R/scripts/in_graph_json.py $DB $NEEDLE $DOM $R/gpurun_out/${TAG}_in_graph.json
   cut -c1-300 $R/gpurun_out/${TAG}_bench_prof.json
   CFG2=$(echo $DOM | cut -d, -f1,2)
-  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/tr_f -o pmc -- python $R/scripts/conv_layer_run.py --pair --cfg $CFG2,0 > $R/gpurun_out/${TAG}_traffic_fetch.log 2>&1; echo "traffic fetch rc=$?"
-  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/tr_w -o pmc -- python $R/scripts/conv_layer_run.py --pair --cfg $CFG2,0 > $R/gpurun_out/${TAG}_traffic_write.log 2>&1; echo "traffic write rc=$?"
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/tr_f -o pmc -- python $R/scripts/conv_layer_run.py --pair --fused --cfg $CFG2,0 > $R/gpurun_out/${TAG}_traffic_fetch.log 2>&1; echo "traffic fetch rc=$?"
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/tr_w -o pmc -- python $R/scripts/conv_layer_run.py --pair --fused --cfg $CFG2,0 > $R/gpurun_out/${TAG}_traffic_write.log 2>&1; echo "traffic write rc=$?"
   python $R/scripts/pmc_traffic.py $(find /tmp/tr_f -name "*.db" | head -1) $(find /tmp/tr_w -name "*.db" | head -1) $DOM $R/gpurun_out/${TAG}_traffic.json | cut -c1-400
   cd $R
   lap prof2
