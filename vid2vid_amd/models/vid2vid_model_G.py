@@ -261,6 +261,11 @@ class Vid2VidModelG(BaseModel):
         self.n_scales = opt.n_scales_spatial
         self.use_single_G = opt.use_single_G
         self.split_gpus = (opt.n_gpus_gen < len(opt.gpu_ids)) and (opt.batchSize == 1)
+        if self.split_gpus:
+            # reference :37-45 moves D / FlowNet2 to the GPUs behind n_gpus_gen because a chunk does not fit a 32 GB device; a rank
+            # here owns one 288 GB GPU and holds G, D and FlowNet2 itself: the option is accepted, not acted on
+            print("vid2vid_amd: n_gpus_gen < len(gpu_ids) (generator / discriminator device split) is not needed on 288 GB GPUs "
+                  "and is ignored: every rank trains G and D on its own GPU")
 
         input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
         netG_input_nc = input_nc * opt.n_frames_G
