@@ -456,7 +456,12 @@ int v2v_tensor2label(const float* x, uint8_t* out, const uint8_t* cmap, int32_t 
  * from the layer's fp32 [cout][cin][7][7] weight (cin = T * (label_nc + (inst ? 1 : 0))).  cout <= 128.  With a bf16 table the
  * instance-edge planes are not gathered row by row (an edge pixel anywhere in a wave made all 64 lanes add the row): they
  * are a [pixels][49 T] x [49 T][cout] product of 0 / 1 edge bits with the edge rows on the matrix pipe, added in the epilogue.
- * slice: output channels per workgroup, 32 or 64, 0 = default; the same value must be given to all three calls. */
+ * slice: output channels per workgroup, 32 or 64, 0 = default; the same value must be given to all three calls.
+ * in_u8 = 2: `labels` is the [T][H][W] byte map of v2v_label_codes (label | edge << 7, 127 = no plane) and `inst` only says
+ * whether the layer has edge planes (any non-NULL pointer): the per-workgroup staging then reads one byte per halo entry. */
+int     v2v_label_codes(const void* labels, const void* inst, int32_t in_u8, uint8_t* codes, int32_t T, int32_t H, int32_t W,
+                        int32_t label_nc, void* stream);
+/* (declarations of the stem entry points follow) */
 int64_t v2v_onehot_conv_table_bytes(int32_t cin, int32_t cout, int32_t dtype, int32_t slice, int32_t T, int32_t label_nc);
 int     v2v_onehot_conv_pack_weights(const float* w, void* table, int32_t cin, int32_t cout, int32_t dtype, int32_t slice,
                                      int32_t T, int32_t label_nc, void* stream);

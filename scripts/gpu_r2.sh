@@ -183,3 +183,10 @@ if has overhead; then
   timeout 300 python scripts/frame_overhead.py 2>/dev/null | tee gpurun_out/${TAG}_frame_overhead.txt
   lap overhead
 fi
+if has codesab; then
+  for v in 1 0 3 1 0 3; do
+    V2V_LABEL_CODES=$v timeout 500 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_codes$v.json 2> gpurun_out/${TAG}_bench_codes$v.err; echo "bench label_codes=$v rc=$?"
+    cut -c1-200 gpurun_out/${TAG}_bench_codes$v.json
+  done
+  lap codesab
+fi

@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
         const long long p = (long long)t * hw + q;
         int lab;
         bool edge = false;
-        if (a.in_u8) {
+        if (a.in_u8 == 2) {                                 // v2v_label_codes: label | edge << 7, 127 = no label plane
+            const int code = reinterpret_cast<const unsigned char*>(a.labels)[p];
+            lab = (code & 127) == 127 ? -1 : (code & 127);
+            edge = (code & 128) != 0;
+        } else if (a.in_u8) {
             lab = reinterpret_cast<const unsigned char*>(a.labels)[p];
             if (a.inst) {
                 const int* ip = reinterpret_cast<const int*>(a.inst) + (long long)t * hw;
@@ -445,6 +449,51 @@ struct OneHotPackOp : Op {
     const char* name() const override { return "onehot_pack_weights"; }
 };
 
+// label | edge << 7 per (frame, pixel): the stems' staging then is one byte per halo entry instead of a label load and five
+// instance-map loads in every one of the 2048 workgroups (512 tiles x 4 slices)
+struct LabelCodeArgs { const void* labels; const void* inst; unsigned char* codes; int T, H, W, label_nc, in_u8; };
+
+__global__ __launch_bounds__(256) void label_codes_kernel(const LabelCodeArgs a) {
+    const long long hw = (long long)a.H * a.W, total = hw * a.T;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long long t = e / hw, q = e - t * hw;
+    const int y = (int)(q / a.W), x = (int)(q - (long long)y * a.W);
+    int lab;
+    bool edge = false;
+    if (a.in_u8) {
+        lab = reinterpret_cast<const unsigned char*>(a.labels)[e];
+        if (a.inst) {
+            const int* ip = reinterpret_cast<const int*>(a.inst) + t * hw;
+            const int ctr = ip[q];
+            if (x > 0)       edge |= ip[q - 1] != ctr;
+            if (x < a.W - 1) edge |= ip[q + 1] != ctr;
+            if (y > 0)       edge |= ip[q - a.W] != ctr;
+            if (y < a.H - 1) edge |= ip[q + a.W] != ctr;
+        }
+    } else {
+        lab = (int)reinterpret_cast<const float*>(a.labels)[e];
+        if (a.inst) {
+            const float* ip = reinterpret_cast<const float*>(a.inst) + t * hw;
+            const float ctr = ip[q];
+            if (x > 0)       edge |= ip[q - 1] != ctr;
+            if (x < a.W - 1) edge |= ip[q + 1] != ctr;
+            if (y > 0)       edge |= ip[q - a.W] != ctr;
+            if (y < a.H - 1) edge |= ip[q + a.W] != ctr;
+        }
+    }
+    a.codes[e] = (unsigned char)(((unsigned)lab < (unsigned)a.label_nc ? lab : 127) | (edge ? 128 : 0));
+}
+
+struct LabelCodeOp : Op {
+    LabelCodeArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(label_codes_kernel, dim3((unsigned)ceil_div((long long)a.T * a.H * a.W, 256)), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "label_codes"; }
+};
+
 // slice width: 0 = default = 32 channels (measured: 153 us vs 181 us for the 108 -> 128 stem with 64-channel slices,
 // profiles/r02_a23_stem_bench.txt: 68 VGPRs -> 6 waves per SIMD hide the LDS latency of the row gathers), or 32 / 64 as given
 static int slice_of(int cout, int dtype, int slice) {
@@ -486,6 +535,16 @@ extern "C" int v2v_onehot_conv_pack_weights(const float* w, void* table, int32_t
     return submit(std::move(op), stream);
 }
 
+extern "C" int v2v_label_codes(const void* labels, const void* inst, int32_t in_u8, uint8_t* codes, int32_t T, int32_t H, int32_t W,
+                               int32_t label_nc, void* stream) {
+    if (!labels || !codes || T < 1 || H < 1 || W < 1 || label_nc < 1 || label_nc > 126 || (in_u8 != 0 && in_u8 != 1)) {
+        set_error("label_codes: bad argument (label_nc <= 126)"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<LabelCodeOp>();
+    op->a = LabelCodeArgs{labels, inst, codes, T, H, W, label_nc, in_u8};
+    return submit(std::move(op), stream);
+}
+
 extern "C" int v2v_onehot_conv_stats_rows(int32_t H, int32_t W) {
     if (H < 1 || W < 1) return V2V_EINVAL;
     return (int)(ceil_div(H, OS_TH) * ceil_div(W, OS_TW));
@@ -494,7 +553,8 @@ extern "C" int v2v_onehot_conv_stats_rows(int32_t H, int32_t W) {
 static int onehot_conv_submit(const void* labels, const void* inst, int32_t in_u8, const void* table, const float* bias,
                               float* out, float* stats, int32_t T, int32_t H, int32_t W, int32_t label_nc,
                               int32_t cout, int32_t cout_stride, int32_t dtype, int32_t slice, const v2v_onehot_norm* fin, void* stream) {
-    if (!labels || !table || !out || T < 1 || H < 4 || W < 4 || label_nc < 1 || cout_stride < cout || !onehot_args_ok(1, cout, dtype, slice)) {
+    if (!labels || !table || !out || T < 1 || H < 4 || W < 4 || label_nc < 1 || cout_stride < cout || !onehot_args_ok(1, cout, dtype, slice) ||
+        in_u8 < 0 || in_u8 > 2 || (in_u8 == 2 && label_nc > 126)) {
         set_error("onehot_conv7x7: bad argument (cout <= 128, slice 0 / 32 / 64, image at least 4x4 for the 3-pixel mirror)"); return V2V_EINVAL;
     }
     if (((uintptr_t)table | (uintptr_t)out) & 15) { set_error("onehot_conv7x7: table / output must be 16-byte aligned"); return V2V_EINVAL; }

@@ -34,8 +34,15 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_HAS_GPU = []
+
+
 def _stream():
-    if not torch.cuda.is_available():
+    """hipStream_t of torch's current stream.  (torch.cuda.is_available() re-reads the environment on every call: 4400 calls =
+    ~8 ms of a 75 ms host-bound training chunk, scripts/host_profile_train.py -- its answer cannot change, so it is asked once.)"""
+    if not _HAS_GPU:
+        _HAS_GPU.append(torch.cuda.is_available())
+    if not _HAS_GPU[0]:
         return None          # record-only dry runs on a CPU host never launch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -73,10 +80,11 @@ class Act:
 class LabelSource:
     """The label / instance maps an encoded one-hot Act was built from: [T][H][W] fp32-encoded integers or uint8 / int32.
     A 7x7 stem convolution over such an Act runs as a weight gather-sum on the maps (csrc/onehot_stem.hip)."""
-    __slots__ = ("labels", "inst", "T", "label_nc")
+    __slots__ = ("labels", "inst", "T", "label_nc", "codes")
 
     def __init__(self, labels, inst, T, label_nc):
         self.labels, self.inst, self.T, self.label_nc = labels, inst, T, label_nc
+        self.codes = None         # [T][H][W] uint8 label | edge << 7 (Engine.label_codes): what the stem kernels stage from
 
 
 _PARAM_EPOCH = [0]
@@ -453,14 +461,29 @@ class Engine:
             pc.refresh(force)
 
     # ---------------- one-hot stem (label-map input) ----------------
-    def onehot_eligible(self, x, conv, pad_mode, pad_override):
-        """7x7 / stride 1 / ReflectionPad2d(3) Conv2d straight on an encoded label Act, inference only."""
-        src = x.onehot
-        return (self.onehot_stem and src is not None and isinstance(conv, nn.Conv2d) and conv.kernel_size == (7, 7)
-                and conv.stride == (1, 1) and conv.groups == 1 and pad_mode == L.PAD_REFLECT
-                and (conv.padding[0] if pad_override is None else pad_override) == 3
-                and conv.out_channels <= 128 and conv.in_channels == x.C and x.N == 1 and x.H >= 4 and x.W >= 4
+    def onehot_conv_ok(self, conv, cin, H, W, pad_mode=L.PAD_REFLECT, pad=3):
+        """A 7x7 / stride 1 / ReflectionPad2d(3) Conv2d that can run as the gather-sum on label maps (inference only)."""
+        return (self.onehot_stem and isinstance(conv, nn.Conv2d) and conv.kernel_size == (7, 7)
+                and conv.stride == (1, 1) and conv.groups == 1 and pad_mode == L.PAD_REFLECT and pad == 3
+                and conv.out_channels <= 128 and conv.in_channels == cin and H >= 4 and W >= 4
                 and not (self.plan is None and torch.is_grad_enabled()))
+
+    def onehot_eligible(self, x, conv, pad_mode, pad_override):
+        """... straight on an encoded label Act."""
+        return (x.onehot is not None and x.N == 1
+                and self.onehot_conv_ok(conv, x.C, x.H, x.W, pad_mode, conv.padding[0] if pad_override is None else pad_override))
+
+    def label_codes(self, src, H, W):
+        """One byte per (frame, pixel): label | instance-edge << 7 (v2v_label_codes), shared by every stem of the frame."""
+        if src.label_nc > 126:
+            return None
+        codes = torch.empty((src.T, H, W), dtype=torch.uint8, device=self.device)
+        self._keep(codes)
+        check(lib.v2v_label_codes(_ptr(src.labels), _ptr(src.inst), int(src.labels.dtype == torch.uint8), _ptr(codes), src.T, H, W,
+                                  src.label_nc, _stream()), "label_codes")
+        self.label("label_codes")
+        src.codes = codes
+        return codes
 
     def onehot_conv(self, x, conv, want_stats=True, label="", fin=None):
         """Raw fp32 NHWC output + statistics rows of the stem convolution, computed from the label maps behind `x`.
@@ -480,6 +503,10 @@ class Engine:
         self._keep(pk.buf)
         if pk.bias is not None:
             self._keep(pk.bias)
+        if src.codes is not None:
+            lab_ptr, in_mode = _ptr(src.codes), 2
+        else:
+            lab_ptr, in_mode = _ptr(src.labels), int(src.labels.dtype == torch.uint8)
         if fin is not None and want_stats:
             norm, ss = fin
             gamma, beta, eps, mom, rm, rv = self._norm_params(norm, 1)
@@ -498,11 +525,11 @@ class Engine:
             for t in (gamma, beta, ss, fin_counter):
                 if t is not None:
                     self._keep(t)
-            check(lib.v2v_onehot_conv7x7_norm(_ptr(src.labels), _ptr(src.inst), int(src.labels.dtype == torch.uint8), _ptr(pk.buf),
+            check(lib.v2v_onehot_conv7x7_norm(lab_ptr, _ptr(src.inst), in_mode, _ptr(pk.buf),
                                               _ptr(pk.bias), _ptr(raw), _ptr(st), src.T, H, W, src.label_nc, cout, cs, self.dtype,
                                               pk.slice, C.byref(fn), _stream()), "onehot_conv7x7_norm " + label)
         else:
-            check(lib.v2v_onehot_conv7x7(_ptr(src.labels), _ptr(src.inst), int(src.labels.dtype == torch.uint8), _ptr(pk.buf),
+            check(lib.v2v_onehot_conv7x7(lab_ptr, _ptr(src.inst), in_mode, _ptr(pk.buf),
                                          _ptr(pk.bias), _ptr(raw), _ptr(st), src.T, H, W, src.label_nc, cout, cs, self.dtype,
                                          pk.slice, _stream()), "onehot_conv7x7 " + label)
         self.label(label)
@@ -1231,7 +1258,7 @@ class Engine:
         check(lib.v2v_memcpy_d2d(_ptr(dst), _ptr(src), nbytes, _stream()), "memcpy_d2d")
         self.label("memcpy_d2d")
 
-    def encode_labels(self, labels, inst, T, H, W, label_nc, fg_labels, want_mask, chunk_stride=False):
+    def encode_labels(self, labels, inst, T, H, W, label_nc, fg_labels, want_mask, chunk_stride=False, source=None):
         """chunk_stride: pad the channel stride to a whole 128-byte K chunk (108 -> 128 channels) so that the
         narrow fine-scale 7x7 stems (cout <= 32) can run on the LDS-patch kernel (tile 60)."""
         per = label_nc + (1 if inst is not None else 0)
@@ -1259,7 +1286,7 @@ class Engine:
                  out.Cs, _ptr(fg), 0 if fg is None else fg.numel(), self.dtype, _stream()),
               "encode_labels")
         self.label("encode_labels")
-        out.onehot = LabelSource(labels, inst, T, label_nc)
+        out.onehot = source if source is not None else LabelSource(labels, inst, T, label_nc)
         return out, mask
 
     def widen(self, x, stride):

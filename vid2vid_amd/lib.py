@@ -116,6 +116,7 @@ PROTOTYPES = {
     "v2v_onehot_conv_table_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "v2v_onehot_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_onehot_conv_stats_rows": (C.c_int, [_I, _I]),
+    "v2v_label_codes": (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "v2v_onehot_conv7x7": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_onehot_conv7x7_norm": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(OneHotNorm), _P]),
     "v2v_encode_labels": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),

@@ -200,8 +200,19 @@ class _FramePlan:
         eng.conv_log = []
         # encode_input (:86-112) + compute_mask (:322-330), fused, straight to NHWC
         if self.label_mode:
+            from ..engine import LabelSource
+            src = LabelSource(self.labels, self.inst, tG, opt.label_nc)
+            netG_fine = getattr(m, "netG" + str(S - 1))
+            stems = netG_fine.label_stems() if hasattr(netG_fine, "label_stems") else []
+            per_ = opt.label_nc + (1 if self.inst is not None else 0)
+            gather = bool(stems) and all(eng.onehot_conv_ok(c, tG * per_, H, W) for c in stems)
+            early = gather and os.environ.get("V2V_LABEL_CODES", "1") != "0"     # (A/B switch)
+            if early:
+                eng.label_codes(src, H, W)                   # one byte per pixel: what the gather-sum stems stage from
+            # (writing the one-hot tensor on the foreground tower's lane instead of in front of the towers was measured: -1.5 %,
+            # it delays that tower and competes with the label stem; profiles/r02_a29_label_codes_ab.txt)
             x0, mask0 = eng.encode_labels(self.labels, self.inst, tG, H, W, opt.label_nc, opt.fg_labels, opt.fg,
-                                          chunk_stride=S > 1)   # fine-scale stems (cout <= 32) use the LDS-patch 7x7 kernel
+                                          chunk_stride=S > 1, source=src)   # fine-scale stems (cout <= 32): LDS-patch 7x7 kernel
         else:
             x0, mask0 = eng.pack(self.raw_in), None
         xs, masks = [x0], [mask0]
