@@ -190,3 +190,10 @@ if has codesab; then
   done
   lap codesab
 fi
+if has otherconfigs; then
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune_2048.json timeout 900 python bench.py --width 2048 --height 1024 --scales 3 --steps 20 --warmup 4 --no-cpu-baseline --no-train-line --retune > gpurun_out/${TAG}_bench_2048_s3.json 2> gpurun_out/${TAG}_bench_2048_s3.err; echo "bench 2048x1024 S=3 rc=$?"
+  cut -c1-700 gpurun_out/${TAG}_bench_2048_s3.json; tail -2 gpurun_out/${TAG}_bench_2048_s3.err
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune_face.json timeout 900 python bench.py --dataset edge2face --width 512 --height 512 --steps 30 --warmup 5 --no-cpu-baseline --no-train-line --retune > gpurun_out/${TAG}_bench_face.json 2> gpurun_out/${TAG}_bench_face.err; echo "bench edge2face 512x512 rc=$?"
+  cut -c1-700 gpurun_out/${TAG}_bench_face.json; tail -2 gpurun_out/${TAG}_bench_face.err
+  lap otherconfigs
+fi
