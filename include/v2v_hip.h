@@ -102,7 +102,15 @@ typedef struct v2v_conv_desc {
     int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA) */
     const void* res0;       /* V2V_OUT_NORM_ACT_NHWC: NULL or a residual [N][OH][OW][cout_stride] (activation dtype) added after the activation */
     const void* res1;       /* second residual, NULL or as res0                                                   */
+    int32_t act_split;      /* 0, or first output channel of a SECOND head merged into this launch (see "merged heads")  */
+    int32_t act_b;          /* activation of channels >= act_split                                                */
+    float   act_param_b;
+    float   out_scale_b;
 } v2v_conv_desc;
+
+/* Merged heads (tile 60, V2V_OUT_F32_NCHW, act_split > 0): model_final_flow (2 channels, no activation, x 20) and
+ * model_final_w (1 channel, sigmoid) read the same tensor (models/networks.py:181-183, 224-226); with their weights
+ * concatenated along cout they are one launch whose channels >= act_split use act_b / act_param_b / out_scale_b. */
 
 /* Fused norm (out_mode V2V_OUT_NORM_ACT_NHWC): conv + BatchNorm2d / InstanceNorm2d in training mode + activation
  * (+ residuals) in ONE launch -- what [pad, conv, norm, relu] and the tail of a ResnetBlock are in the reference

@@ -197,3 +197,21 @@ if has otherconfigs; then
   cut -c1-700 gpurun_out/${TAG}_bench_face.json; tail -2 gpurun_out/${TAG}_bench_face.err
   lap otherconfigs
 fi
+if has clsab; then
+  for v in 1 0; do
+    V2V_MERGE_HEADS=0 V2V_CLS_ORDER=$v V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune_cls$v.json timeout 600 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line --retune > gpurun_out/${TAG}_bench_cls$v.json 2> gpurun_out/${TAG}_bench_cls$v.err; echo "bench cls_order=$v rc=$?"
+    cut -c1-200 gpurun_out/${TAG}_bench_cls$v.json; grep "frame tune" gpurun_out/${TAG}_bench_cls$v.err | tail -1
+  done
+  lap clsab
+fi
+if has headsab; then
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -x -k "merged_heads or head_kernel or conv_transpose or convtranspose" > gpurun_out/${TAG}_headstest.log 2>&1; echo "heads tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_headstest.log | cut -c1-300 | tail -8
+  timeout 900 python -m pytest tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 600 -k "not full_size" > gpurun_out/${TAG}_golden.log 2>&1; echo "golden rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_golden.log | cut -c1-300 | tail -8
+  for v in 1 0 1 0; do
+    V2V_MERGE_HEADS=$v timeout 500 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_mh$v.json 2> gpurun_out/${TAG}_bench_mh$v.err; echo "bench merge_heads=$v rc=$?"
+    cut -c1-200 gpurun_out/${TAG}_bench_mh$v.json
+  done
+  lap headsab
+fi

@@ -406,6 +406,34 @@ def test_conv7x7_head_kernel(case, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(128, 40, 96), (64, 33, 70)])
+@torch.no_grad()
+def test_merged_heads_equal_separate_heads(case, prec):
+    """Engine.head_pair: model_final_flow (2 channels, no activation, x 20) and model_final_w (1 channel, sigmoid) read the
+    same tensor (models/networks.py:181-183) and run as ONE 7x7 head launch with per-channel epilogues -- bit for bit the
+    two separate launches."""
+    C_, H, W = case
+    torch.manual_seed(C_ + W)
+    eng = _engine(prec)
+    x = eng.pack(torch.randn(1, C_, H, W).to(DEV))
+    seq_flow = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(C_, 2, 7)).to(DEV)
+    seq_w = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(C_, 1, 7), nn.Sigmoid()).to(DEV)
+    eng.merge_heads = True
+    for co in (1, 2):
+        eng.tile_override[(C_, co, 7, 1, 0)] = (60, 1, 0)          # the separate heads on the same kernel as the merged one
+    both = eng.head_pair(x, seq_flow, 20.0, seq_w, 1.0, label="heads")
+    assert both is not None and both[0].shape == (1, 2, H, W) and both[1].shape == (1, 1, H, W)
+    flow = eng.run_sequential(seq_flow, x, head_nchw=True, out_scale=20.0, name="flow")
+    wgt = eng.run_sequential(seq_w, x, head_nchw=True, name="w")
+    assert torch.equal(both[0], flow) and torch.equal(both[1], wgt)
+    xr = F.pad(_round(eng.unpack(x).cpu(), prec), (3,) * 4, mode="reflect")
+    ref_f = 20.0 * F.conv2d(xr, _round(seq_flow[1].weight.detach().cpu(), prec), seq_flow[1].bias.detach().cpu())
+    ref_w = torch.sigmoid(F.conv2d(xr, _round(seq_w[1].weight.detach().cpu(), prec), seq_w[1].bias.detach().cpu()))
+    assert_close(both[0].cpu(), ref_f, 1e-4, "merged heads: flow")
+    assert_close(both[1].cpu(), ref_w, 1e-4, "merged heads: weight")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(128, 32, 40, 70), (64, 16, 33, 64), (128, 24, 16, 96)])
 def test_conv7x7_raw_stats_kernel(case, prec):
     """Tile 60 as a stem: raw fp32 NHWC output + per-tile statistics (cout <= 32, two 16-wide N tiles), followed by

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
         const int co = n * 16 + lp;
         const bool cvalid = co < p.cout;
         const float bv = (p.bias && cvalid) ? p.bias[co] : 0.f;
+        // two heads merged into one launch (model_final_flow + model_final_w): the second head's channels have their own epilogue
+        const bool second = p.act_split > 0 && co >= p.act_split;
+        const int act = second ? p.act_b : p.act;
+        const float act_param = second ? p.act_param_b : p.act_param, out_scale = second ? p.out_scale_b : p.out_scale;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int oh = oh0 + 2 * wid + (g >> 1);
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
                         s2[n] += v * v;
                         reinterpret_cast<float*>(p.out)[(((long long)n_img * H + oh) * W + ow) * p.cout_stride + co] = v;
                     } else {
-                        v = apply_act(v, p.act, p.act_param) * p.out_scale;
+                        v = apply_act(v, act, act_param) * out_scale;
                         reinterpret_cast<float*>(p.out)[((long long)n_img * p.cout + co) * hw + (long long)oh * W + ow] = v;
                     }
                 }

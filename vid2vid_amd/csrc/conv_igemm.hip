@@ -376,6 +376,12 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.ktot[c] = g.ktot[c]; k.kpad[c] = g.kpad[c]; k.wrow[c] = g.wrow[c]; k.woff[c] = g.woff[c];
     }
     k.out_mode = d->out_mode; k.act = d->act; k.act_param = d->act_param; k.out_scale = d->out_scale;
+    if (d->act_split != 0) {
+        if (d->act_split < 0 || d->act_split >= d->cout || d->tile != 60 || d->out_mode != V2V_OUT_F32_NCHW) {
+            set_error("conv: act_split (merged heads) needs tile 60, planar fp32 output and 0 < act_split < cout"); return V2V_EINVAL;
+        }
+        k.act_split = d->act_split; k.act_b = d->act_b; k.act_param_b = d->act_param_b; k.out_scale_b = d->out_scale_b;
+    }
     if (d->out_mode == V2V_OUT_NORM_ACT_NHWC) {
         if ((launching && (!d->fin_counter || !d->stats || !d->fin_scale_shift || d->fin_count <= 0)) || d->splitk > 1 || d->transposed ||
             d->cout != d->cout_stride || d->tile < 80 || d->tile >= 88 || d->cout > 128 * 64) {
@@ -453,6 +459,10 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.slabs = (float*)d->slabs; k.sk_counter = d->sk_counter;
     }
     k.ablate = d->ablate;
+    {
+        static const int rev = [] { const char* e = getenv("V2V_CLS_ORDER"); return (e && e[0] == '0') ? 0 : 1; }();
+        k.cls_rev = rev;
+    }
     k.pf_dist = (d->prefetch > 0 && (conv_cfg_has_helper(op->cfg) || (op->cfg >= 32 && op->cfg <= 37))) ? d->prefetch : 0;
     k.pf_mask = (k.pf_dist > 0 && k.m_tiles >= 8) ? 3 : 0;      // 1 prefetching workgroup per 4 M tiles of an N column
     return 0;

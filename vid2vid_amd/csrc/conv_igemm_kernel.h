@@ -49,6 +49,8 @@ struct ConvKArgs {
     int pf_dist, pf_mask;
     int tiles_h, tiles_w; // conv3x3_patch_kernel: output tiles per image (m_tiles = N * tiles_h * tiles_w)
     int ablate;          // profiling ablations (v2v_conv_desc.ablate); results are WRONG when non-zero
+    int cls_rev;         // dispatch the parity classes of a transposed convolution in descending order of their tap count
+    int act_split, act_b; float act_param_b, out_scale_b;   // conv7x7_head_kernel: channels >= act_split (> 0) use this activation / scale
     const char* res0; const char* res1;   // V2V_OUT_NORM_ACT_NHWC: residuals added after the activation (or NULL)
     ConvGroupPtrs g1;    // grouped launch (conv3x3_pp2_kernel): operands of block z == 1
 };
@@ -579,7 +581,9 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool helper = HELPER && wid >= NW;   // prefetch wave (HELPER instances are launched with NW+1 waves)
     const int wm = wid / WGN, wn = wid % WGN;
-    const int cls = blockIdx.y;
+    // heaviest parity class first (ConvTranspose2d 3x3 / stride 2: classes of 1, 2, 2, 4 taps; workgroups are dispatched in
+    // blockIdx order, so the long ones must not start last)
+    const int cls = p.cls_rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
 
     const int tiles = p.m_tiles * p.n_tiles;
     const int S = p.splitk;

@@ -158,6 +158,32 @@ class PackedConv:
         self.version = ver
 
 
+class MergedConv:
+    """Two Conv2d heads of identical geometry reading the same input (model_final_flow / model_final_w,
+    models/networks.py:181-183) presented as ONE layer with the output channels concatenated: what PackedConv / Engine.conv
+    need of an nn.Conv2d, with `weight` / `bias` assembled from the two source layers on every read (eager use re-packs;
+    a recorded plan packs once, like every other layer)."""
+
+    def __init__(self, a, b):
+        if (a.kernel_size, a.stride, a.padding, a.in_channels, a.groups) != (b.kernel_size, b.stride, b.padding, b.in_channels, b.groups):
+            raise ValueError("merged heads must have the same geometry")
+        self.a, self.b = a, b
+        self.kernel_size, self.stride, self.padding, self.groups = a.kernel_size, a.stride, a.padding, a.groups
+        self.in_channels, self.out_channels = a.in_channels, a.out_channels + b.out_channels
+        self.output_padding = (0, 0)
+
+    @property
+    def weight(self):
+        return torch.cat([self.a.weight.detach(), self.b.weight.detach()], 0)
+
+    @property
+    def bias(self):
+        if self.a.bias is None and self.b.bias is None:
+            return None
+        z = lambda m: m.bias.detach() if m.bias is not None else torch.zeros(m.out_channels, device=m.weight.device)
+        return torch.cat([z(self.a), z(self.b)], 0)
+
+
 class PackedOneHot:
     """Gather table [49][cin][64 | 128] of a 7x7 stem Conv2d (csrc/onehot_stem.hip), refreshed like PackedConv."""
 
@@ -305,6 +331,9 @@ class Engine:
         # the paired ResnetBlock convolutions; V2V_FUSED_NORM=0: raw fp32 output + bn_apply launch
         self.fused_norm = bool(int(os.environ.get("V2V_FUSED_NORM", "1")))
         self._fused_norm_wgs = None
+        # model_final_flow + model_final_w (same input) as one 7x7 head launch; V2V_MERGE_HEADS=0: one launch each
+        self.merge_heads = bool(int(os.environ.get("V2V_MERGE_HEADS", "1")))
+        self._merged_heads = {}
         self._scratch = {}       # name -> tensor (grown on demand, shared between layers)
         self._grids = {}
         self._zero_page = None
@@ -543,7 +572,7 @@ class Engine:
 
     # ---------------- primitive emitters ----------------
     def conv(self, x, mod, pad_mode=L.PAD_ZERO, pad_override=None, out_mode=L.OUT_RAW_F32_NHWC,
-             act=L.ACT_NONE, act_param=0.0, out_scale=1.0, want_stats=False, out=None, label="", fin=None):
+             act=L.ACT_NONE, act_param=0.0, out_scale=1.0, want_stats=False, out=None, label="", fin=None, act_b=None):
         """Emit one convolution.  Returns (out, stats_rows, (N,OH,OW)).
         fin = (norm module, ss tensor [4*cout]): finalize the training-mode norm statistics inside the conv
         kernel (last-arriving workgroup), so no separate bn_finalize launch is needed."""
@@ -568,11 +597,15 @@ class Engine:
         d.OH, d.OW = OH, OW
         d.dtype, d.out_mode, d.act = self.dtype, out_mode, act
         d.act_param, d.out_scale = act_param, out_scale
+        if act_b is not None:          # (first channel, activation, parameter, scale) of the second head of a merged pair
+            d.act_split, d.act_b, d.act_param_b, d.out_scale_b = act_b
         d.ablate = self.ablate
         d.tile, d.splitk, d.prefetch = _cfg3(self.tile_override.get((pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed)), 0))
         tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
         if d.tile == 0 and tune_key in self._tuned:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
+        if act_b is not None:
+            d.tile, d.splitk, d.prefetch = 60, 1, 0          # per-channel epilogues exist in the 7x7 head kernel only
         if is_patch_tile(d.tile):
             pc = self._use_korder1(d, mod, x.Cs)
         elif self.plan is None:
@@ -650,7 +683,7 @@ class Engine:
                                   KH=pc.KH, KW=pc.KW, stride=pc.stride, transposed=pc.transposed,
                                   flops=2.0 * N * (H * W if pc.transposed else OH * OW) * pc.cout * pc.cin * ntaps,
                                   tile=lib.v2v_conv_tile_config(C.byref(d)), splitk=max(int(d.splitk), 1),
-                                  prefetch=int(d.prefetch)))
+                                  prefetch=int(d.prefetch), convs=2 if act_b is not None else 1))    # merged heads: two reference layers
         return out, rows, (N, OH, OW)
 
     # ---------------- paired launches (twin chains) ----------------
@@ -1142,6 +1175,37 @@ class Engine:
         out, _, _ = self.conv(x, conv, pad_mode, pad_override, L.OUT_F32_NCHW if head_nchw else L.OUT_ACT_NHWC,
                               act, act_param, out_scale if head_nchw else 1.0, label=label)
         return out
+
+    def head_pair(self, x, seq_a, scale_a, seq_b, scale_b, label=""):
+        """Two API-facing heads on the same input ([ReflectionPad2d(3), Conv2d(C, n, 7) [, act]] each: model_final_flow and
+        model_final_w, models/networks.py:181-183) as ONE launch writing one planar fp32 tensor; returns the two channel
+        ranges as views.  None when the pair does not qualify (the caller then emits them one by one)."""
+        def parse(seq):
+            mods = list(seq)
+            if not (len(mods) in (2, 3) and isinstance(mods[0], nn.ReflectionPad2d) and isinstance(mods[1], nn.Conv2d)):
+                return None
+            act = (L.ACT_NONE, 0.0) if len(mods) == 2 else self._act_code(mods[2])
+            return None if act is None else (int(mods[0].padding[0]), mods[1], act)
+        pa, pb = parse(seq_a), parse(seq_b)
+        if (not self.merge_heads or pa is None or pb is None or self._training() or pa[0] != pb[0]
+                or pa[1].kernel_size != (7, 7) or pa[1].out_channels + pb[1].out_channels > 16):
+            return None
+        key = (id(pa[1]), id(pb[1]))
+        merged = self._merged_heads.get(key)
+        if merged is None:
+            try:
+                merged = self._merged_heads[key] = MergedConv(pa[1], pb[1])
+            except ValueError:
+                return None
+        bke = 64 if self.dtype == L.BF16 else 32
+        if x.Cs % bke != 0:                       # the 7x7 head kernel reads whole 128-byte channel chunks
+            if x.H * x.W < 65536:
+                return None
+            x = self.widen(x, (x.Cs + bke - 1) // bke * bke)
+        ca = pa[1].out_channels
+        out, _, _ = self.conv(x, merged, L.PAD_REFLECT, pa[0], L.OUT_F32_NCHW, pa[2][0], pa[2][1], scale_a, label=label,
+                              act_b=(ca, pb[2][0], pb[2][1], scale_b))
+        return out[:, :ca], out[:, ca:]
 
     # ---------------- nn.Sequential lowering ----------------
     @staticmethod

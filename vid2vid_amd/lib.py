@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("splitk", C.c_int32), ("prefetch", C.c_int32), ("slabs", C.c_void_p), ("sk_counter", C.c_void_p),
         ("w_korder", C.c_int32), ("ablate", C.c_int32),
         ("res0", C.c_void_p), ("res1", C.c_void_p),
+        ("act_split", C.c_int32), ("act_b", C.c_int32), ("act_param_b", C.c_float), ("out_scale_b", C.c_float),
     ]
 
 

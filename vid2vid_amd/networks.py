@@ -322,12 +322,19 @@ class CompositeGenerator(BaseNetwork):
             feat = eng.run_sequential(self.indv_up, f, name=tag + ".indv_up")
             return feat, eng.run_sequential(self.indv_final, feat, head_nchw=True, name=tag + ".indv_final")
 
+        def flow_heads(flow_feat):
+            both = eng.head_pair(flow_feat, self.model_final_flow, self.flow_multiplier(), self.model_final_w, 1.0,
+                                 label=tag + ".final_flow+w")        # the flow branch ends the frame's critical path: one launch
+            if both is not None:
+                return both
+            flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
+                                      out_scale=self.flow_multiplier(), name=tag + ".final_flow")
+            return flow, eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
+
         def flow_branch(down):
             res_flow = eng.run_sequential(self.model_res_flow, down, name=tag + ".res_flow")
             flow_feat = eng.run_sequential(self.model_up_flow, res_flow, name=tag + ".up_flow")
-            flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
-                                      out_scale=self.flow_multiplier(), name=tag + ".final_flow")
-            weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
+            flow, weight = flow_heads(flow_feat)
             return flow, weight, flow_feat
 
         twin = eng.twin_enabled and not eng._training()
@@ -376,9 +383,7 @@ class CompositeGenerator(BaseNetwork):
 
         def flow_tail(res_flow):
             flow_feat = eng.run_sequential(self.model_up_flow, res_flow, name=tag + ".up_flow")
-            flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
-                                      out_scale=self.flow_multiplier(), name=tag + ".final_flow")
-            weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
+            flow, weight = flow_heads(flow_feat)
             return flow, weight, flow_feat
 
         if res_flow_done is not None:
@@ -479,6 +484,10 @@ class CompositeLocalGenerator(BaseNetwork):
 
         def flow_branch(down):
             flow_feat = eng.run_sequential(self.model_up_flow, eng.add(down, flow_feat_coarse), name=tag + ".up_flow")
+            both = eng.head_pair(flow_feat, self.model_final_flow, self.flow_multiplier(), self.model_final_w, 1.0,
+                                 label=tag + ".final_flow+w")
+            if both is not None:
+                return both[0], both[1], flow_feat
             flow = eng.run_sequential(self.model_final_flow, flow_feat, head_nchw=True,
                                       out_scale=self.flow_multiplier(), name=tag + ".final_flow")
             weight = eng.run_sequential(self.model_final_w, flow_feat, head_nchw=True, name=tag + ".final_w")
