@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const PackArgs 
     const int KHW = a.KH * a.KW;
     const int LS = PK_TC + KHW;                              // LDS row stride: bank = tap * KHW + channel, distinct over a wave's run
     const int tid = threadIdx.x;
-    // ---- read: contiguous source runs -> sh[(row * KHW + full tap) * LS + channel]
+    // ---- read: contiguous source runs (16-byte loads) -> sh[(row * KHW + full tap) * LS + channel]
     if (!a.transposed) {
         const int nc = min(PK_TC, a.cin - c0);
         const int run = nc > 0 ? nc * KHW : 0;
@@ -208,44 +208,68 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const PackArgs 
             const int co = co0 + r;
             if (co >= a.cout) break;
             const float* src = a.w + ((long long)co * a.cin + c0) * KHW;
-            for (int i = tid; i < run; i += 256) {
-                const int cl = i / KHW, f = i - cl * KHW;
-                sh[(r * KHW + f) * LS + cl] = src[i];
+            const bool al = (((unsigned long long)src) & 15) == 0;
+            for (int i4 = tid * 4; i4 < run; i4 += 1024) {
+                float v[4];
+                if (al && i4 + 4 <= run) { const float4 t = *reinterpret_cast<const float4*>(src + i4); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+                else { for (int q = 0; q < 4; ++q) v[q] = i4 + q < run ? src[i4 + q] : 0.f; }
+                int cl = i4 / KHW, f = i4 - cl * KHW;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i4 + q < run) sh[(r * KHW + f) * LS + cl] = v[q];
+                    if (++f == KHW) { f = 0; ++cl; }
+                }
             }
         }
     } else {
         const int nr = min(PK_TCO, a.cout - co0);
         const int run = nr > 0 ? nr * KHW : 0;
-        for (int cl = 0; cl < PK_TC; ++cl) {
+        // one channel per group of threads: 256 threads cover 256 / ceil(run) channels per pass
+        const int tpc = run <= 32 ? 32 : run <= 64 ? 64 : 128;           // threads per channel (run <= 8 * 16 = 128)
+        const int cpp = 256 / tpc;
+        for (int cb = 0; cb < PK_TC; cb += cpp) {
+            const int cl = cb + tid / tpc, i = tid % tpc;
             const int c = c0 + cl;
-            if (c >= a.cin) break;
-            const float* src = a.w + ((long long)c * a.cout + co0) * KHW;
-            for (int i = tid; i < run; i += 256) {
+            if (cl < PK_TC && c < a.cin && i < run) {
                 const int r = i / KHW, f = i - r * KHW;
-                sh[(r * KHW + f) * LS + cl] = src[i];
+                sh[(r * KHW + f) * LS + cl] = a.w[((long long)c * a.cout + co0) * KHW + i];
             }
         }
     }
     __syncthreads();
-    // ---- write: per class, 64-channel runs per (row, tap)
+    // ---- write: per class, 8-channel vectors (one 16-byte store for bf16, two for fp32) per (row, tap)
     for (int cls = 0; cls < a.ncls; ++cls) {
         const int nkw = a.nkw[cls], nt = a.nkh[cls] * nkw;
         const int wrow = a.wrow[cls];
-        const int n = PK_TCO * nt * PK_TC;
+        const int n = PK_TCO * nt * (PK_TC / 8);
         for (int j = tid; j < n; j += 256) {
-            const int cl = j & (PK_TC - 1);
-            const int rt = j >> 6;
+            const int c8 = (j & 7) * 8;
+            const int rt = j >> 3;
             const int r = rt / nt, t = rt - r * nt;
-            const int co = co0 + r, c = c0 + cl;
+            const int co = co0 + r, c = c0 + c8;
             if (co >= a.cout_p || c >= a.cin_stride) continue;
             const int th = t / nkw, tw = t - th * nkw;
             const int kh = a.transposed ? a.kh0[cls] + a.kstep * th : th;
             const int kw = a.transposed ? a.kw0[cls] + a.kstep * tw : tw;
-            const float v = (co < a.cout && c < a.cin) ? sh[(r * KHW + kh * a.KW + kw) * LS + cl] : 0.f;
+            const float* sp = sh + (r * KHW + kh * a.KW + kw) * LS + c8;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (co < a.cout && c + q < a.cin) ? sp[q] : 0.f;
+            // cin_stride is a multiple of 8 (bf16) / 4 (fp32) and bke of 64 / 32: the 8 (4 + 4) channels stay inside one chunk
             const int k = a.korder == 1 ? ((c / a.bke) * nt + t) * a.bke + (c % a.bke) : t * a.cin_stride + c;
             const long long e = a.woff[cls] + (long long)co * wrow + k;
-            if (a.dtype == V2V_BF16) reinterpret_cast<unsigned short*>(a.dst)[e] = f32_to_bf16_bits(v);
-            else                     reinterpret_cast<float*>(a.dst)[e] = v;
+            if (a.dtype == V2V_BF16) {
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
+                pk.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.dst) + e) = pk;
+            } else {
+                float* d = reinterpret_cast<float*>(a.dst) + e;
+                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                if (c + 4 < a.cin_stride) *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
         }
         if (blockIdx.x == 0) {                               // the zero lines behind a row's taps (K padded to the tile depth)
             const int ktot = nt * a.cin_stride, npad = wrow - ktot;

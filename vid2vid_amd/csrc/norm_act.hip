@@ -308,13 +308,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdRedArgs a
     double* shd = reinterpret_cast<double*>(&sh[0][0][0]);       // [4][64][2] doubles = 4 KiB of the 8 KiB
     const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cx;
+    // the rows were written through to memory by their producers; one agent-scope acquire (invalidate) lets this workgroup
+    // read them with ordinary, pipelined loads (128 serial agent-scope atomic loads per thread cost 13 us per launch)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double d1 = 0.0, d2 = 0.0;
     if (c < a.C) {
+        const float2* rows2 = reinterpret_cast<const float2*>(a.partials);
+#pragma unroll 8
         for (int r = ph; r < (int)gridDim.x; r += 4) {
-            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.partials + ((long long)r * a.C + c) * 2),
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            d1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
-            d2 += (double)__uint_as_float((unsigned)(bits >> 32));
+            const float2 v = rows2[(long long)r * a.C + c];
+            d1 += (double)v.x;
+            d2 += (double)v.y;
         }
     }
     shd[(ph * 64 + cx) * 2] = d1; shd[(ph * 64 + cx) * 2 + 1] = d2;
@@ -615,7 +619,12 @@ extern "C" int v2v_bn_backward(const void* dy, const float* raw, int32_t c_strid
     if ((uintptr_t)draw & 15) { set_error("bn_backward: draw must be 16-byte aligned"); return V2V_EINVAL; }
     if (act != V2V_ACT_NONE && act != V2V_ACT_RELU && act != V2V_ACT_LEAKY) { set_error("bn_backward: activation"); return V2V_EINVAL; }
     auto op = std::make_unique<BnBwdOp>();
-    long long ppb; const int nblk = bwd_blocks(P, &ppb);
+    long long ppb; int nblk = bwd_blocks(P, &ppb);     // (the workspace bound the caller sized)
+    const int slabs = (int)ceil_div(C, 64);
+    if ((long long)nblk * slabs > 2048 && nblk > 64) {  // enough workgroups already: fewer, longer pixel blocks = fewer partial rows
+        long long want = ceil_div(2048, slabs); if (want < 64) want = 64;
+        if (want < nblk) { ppb = ceil_div(P, want); nblk = (int)ceil_div(P, ppb); }
+    }
     op->dtype = dtype; op->nblk = nblk; op->do_apply = true;
     float* partials = workspace;                      // [nblk][C][2]
     float* coef = workspace + (long long)nblk * C * 2; // [2][C]
