@@ -215,3 +215,10 @@ if has headsab; then
   done
   lap headsab
 fi
+if has w4; then
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -x -k "patch_kernel or conv2d_pair or fused_norm" > gpurun_out/${TAG}_w4test.log 2>&1; echo "4-wave tile tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_w4test.log | cut -c1-300 | tail -8
+  timeout 600 python scripts/pp2_bench.py bf16 > gpurun_out/${TAG}_pp3_bench.txt 2>&1; echo "pp3 bench rc=$?"
+  grep -v amdgpu gpurun_out/${TAG}_pp3_bench.txt | head -60 | cut -c1-120
+  lap w4
+fi

@@ -72,13 +72,13 @@ for cin, cout, H, W in ((1024, 1024, 32, 64), (512, 512, 32, 64), (1024, 1024, 6
         return fn
 
     ncc = xs[0].Cs // (64 if prec == "bf16" else 32)
-    for tile, S in ((54, 1), (54, 2), (53, 1), (53, 2), (70, 1), (71, 1), (75, 1),
-                    (80, 1), (80, 2), (81, 1), (81, 2), (81, 4), (82, 1), (83, 1), (84, 1), (84, 2), (85, 1), (85, 2)):
+    for tile, S in ((54, 1), (54, 2), (70, 1),
+                    (80, 1), (80, 2), (82, 1), (83, 1), (84, 1), (84, 2), (85, 1), (86, 1), (86, 2), (87, 1)):
         if W % 64 and tile in (51, 57, 73, 74):
             pass
         if 2 * S <= ncc:
             singles["t%d S%d" % (tile, S)] = single(tile, S)
-    for tile, S in ((70, 1), (71, 1), (75, 1), (80, 1), (82, 1), (83, 1), (81, 1), (81, 2), (84, 1), (85, 1), (85, 2), (80, 2)):
+    for tile, S in ((80, 1), (82, 1), (83, 1), (84, 1), (85, 1), (86, 1), (87, 1), (86, 2)):
         if 2 * S <= ncc:
             pairs["pair t%d S%d" % (tile, S)] = pair(tile, S)
     for cold in (True, False):

@@ -43,14 +43,17 @@ constexpr int pending_at(int tap, int GP, int LB, int D) {
 
 // ABL = 1: ablation instance (scripts/pp2_ablate.py): 1 / 2 hot operands, 4 no stores, 32 no fragment ds_reads,
 // 64 no MFMAs, 128 no LDS-DMA in the main loop, 256 no vmcnt wait in the main loop.  Results are wrong when set.
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0>
-__global__ __launch_bounds__(512) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
+// WGM x WGN waves: 4 x 2 (512 threads, wave tile BM/4 x BN/2) or 2 x 2 (256 threads, one wave per SIMD, wave tile BM/2 x BN/2).
+// The 4-wave form with 128 px x 128 channels has 64 x 64 wave tiles: 16 MFMAs per 16 fragment reads instead of 8 per 12 --
+// 64 KB of LDS reads per step and CU instead of 96 KB, below the ~200 B/clk the LDS delivers beside the 512 MFMA cycles.
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2>
+__global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
     const ConvKArgs p = select_group(p_in);
     const int ab = ABL ? p.ablate : 0;
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PR = (TH + 2) * PW;
-    constexpr int NW = 8, WGM = 4, WGN = 2;
+    constexpr int WGM = WGM_, WGN = WGN_, NW = WGM * WGN;
     constexpr int NG = (PR + 7) / 8;
     constexpr int GP = (NG + NW - 1) / NW;                    // patch pieces per wave per chunk
     constexpr int PATCH = GP * NW * 1024;
@@ -304,24 +307,26 @@ __global__ __launch_bounds__(512) void conv3x3_pp3_kernel(const ConvKArgs p_in) 
         });
 }
 
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0>
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2>
 static int launch_pp3_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
-    constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + 7) / 8;
-    const size_t lds = (size_t)2 * GP * 8 * 1024 + (size_t)D * BN * 128;
-    auto kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL>;
+    constexpr int NW = WGM * WGN;
+    constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW;
+    const size_t lds = (size_t)2 * GP * NW * 1024 + (size_t)D * BN * 128;
+    auto kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid((unsigned)(k.m_tiles * k.n_tiles * k.splitk), 1u, (unsigned)groups);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, k);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, k);
     return check_launch();
 }
 
 // single-phase tile configurations (ids 80..89)
 static const PatchCfg kPp3Cfgs[] = {
     {80, 8, 32, 64}, {81, 8, 32, 128}, {82, 8, 32, 64}, {83, 4, 64, 64}, {84, 4, 32, 128}, {85, 4, 64, 128},
+    {86, 4, 32, 128}, {87, 2, 64, 128},     // 4 waves (2 x 2), 64 x 64 wave tiles
     {88, 8, 32, 128}, {89, 8, 32, 64},     // ablation instances of 81 / 80
 };
 static inline const PatchCfg* find_pp3_cfg(int id) {
@@ -339,6 +344,8 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 83: return launch_pp3_cfg<T, 4, 64, 64, 4>(k, groups, s);    // 256 px x  64 for 64-wide tiles, 144 KiB
         case 84: return launch_pp3_cfg<T, 4, 32, 128, 4>(k, groups, s);   // 128 px x 128, wave tile 32x64
         case 85: return launch_pp3_cfg<T, 4, 64, 128, 3>(k, groups, s);   // 256 px x 128 for 64-wide tiles, 3 slices, 160 KiB
+        case 86: return launch_pp3_cfg<T, 4, 32, 128, 4, 0, 2, 2>(k, groups, s);   // 128 px x 128, FOUR waves, wave tile 64x64, 120 KiB
+        case 87: return launch_pp3_cfg<T, 2, 64, 128, 4, 0, 2, 2>(k, groups, s);   // same for 64-wide tile rows
         case 88: return launch_pp3_cfg<T, 8, 32, 128, 4, 1>(k, groups, s);
         case 89: return launch_pp3_cfg<T, 8, 32, 64, 4, 1>(k, groups, s);
     }

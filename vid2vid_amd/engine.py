@@ -286,9 +286,10 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               # (csrc/conv3x3_pp2_kernel.h)
               70: (8, 32, 64), 71: (8, 32, 128), 72: (8, 32, 64), 73: (4, 64, 64), 74: (4, 64, 64), 75: (4, 32, 128),
               # single-phase software-pipelined schedule (csrc/conv3x3_pp3_kernel.h): two fragment register sets, ONE barrier per step
-              80: (8, 32, 64), 81: (8, 32, 128), 82: (8, 32, 64), 83: (4, 64, 64), 84: (4, 32, 128), 85: (4, 64, 128)}
+              80: (8, 32, 64), 81: (8, 32, 128), 82: (8, 32, 64), 83: (4, 64, 64), 84: (4, 32, 128), 85: (4, 64, 128),
+              86: (4, 32, 128), 87: (2, 64, 128)}      # 86 / 87: four waves, 64 x 64 wave tiles
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
-PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85)
+PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87)
 
 
 def is_patch_tile(t):
