@@ -222,3 +222,12 @@ if has w4; then
   grep -v amdgpu gpurun_out/${TAG}_pp3_bench.txt | head -60 | cut -c1-120
   lap w4
 fi
+if has deferab; then
+  timeout 900 python -m pytest tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 600 -k "not full_size" > gpurun_out/${TAG}_golden.log 2>&1; echo "golden rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_golden.log | cut -c1-300 | tail -8
+  for v in 1 0 1 0; do
+    V2V_DEFER_ENCODE=$v timeout 500 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_de$v.json 2> gpurun_out/${TAG}_bench_de$v.err; echo "bench defer_encode=$v rc=$?"
+    cut -c1-200 gpurun_out/${TAG}_bench_de$v.json
+  done
+  lap deferab
+fi
