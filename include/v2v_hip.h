@@ -432,6 +432,13 @@ int       v2v_plan_instantiate_graph(v2v_plan* p, void* stream);/* capture into 
 int       v2v_plan_launch_graph(v2v_plan* p, void* stream);
 /* per-op HIP-event timing of one eager replay: ms[i] for op i, names via v2v_plan_op_name */
 int       v2v_plan_profile(v2v_plan* p, void* stream, float* ms, int32_t n);
+/* concurrent timeline of one eager replay with every lane on its own stream: start / end of op i in ms since the replay began,
+ * and the lane it ran on (lanes may be NULL); the schedule the lanes produce, which a serialising kernel trace cannot show.
+ * Time comes from a one-thread kernel storing the device wall clock before / after every op (timing events of different streams
+ * gave inconsistent intervals), which costs a few us per op. */
+int       v2v_plan_timeline(v2v_plan* p, void* stream, float* t0_ms, float* t1_ms, int32_t* lanes, int32_t n);
+/* the same measurement with the ops and the stamps captured into a hipGraph (the schedule of the real graph replay) */
+int       v2v_plan_timeline_graph(v2v_plan* p, void* stream, float* t0_ms, float* t1_ms, int32_t* lanes, int32_t n);
 const char* v2v_plan_op_name(const v2v_plan* p, int32_t i);
 int       v2v_plan_set_label(v2v_plan* p, const char* label);   /* labels the last recorded op */
 const char* v2v_plan_op_label(const v2v_plan* p, int32_t i);

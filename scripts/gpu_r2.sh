@@ -231,3 +231,52 @@ if has deferab; then
   done
   lap deferab
 fi
+if has lanetl; then
+  timeout 300 python scripts/lane_timeline.py > gpurun_out/${TAG}_lane_timeline.txt 2> gpurun_out/${TAG}_lane_timeline.err; echo "lane timeline rc=$?"
+  head -3 gpurun_out/${TAG}_lane_timeline.txt; tail -2 gpurun_out/${TAG}_lane_timeline.err
+  lap lanetl
+fi
+if has graphq; then
+  for q in default 1 2 3 4 8; do
+    if [ $q = default ]; then unset DEBUG_HIP_FORCE_GRAPH_QUEUES; else export DEBUG_HIP_FORCE_GRAPH_QUEUES=$q; fi
+    timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_q$q.json 2> gpurun_out/${TAG}_bench_q$q.err; echo "bench DEBUG_HIP_FORCE_GRAPH_QUEUES=$q rc=$?"
+    cut -c1-160 gpurun_out/${TAG}_bench_q$q.json
+    timeout 300 python scripts/lane_timeline.py > gpurun_out/${TAG}_lane_timeline_q$q.txt 2>/dev/null; head -2 gpurun_out/${TAG}_lane_timeline_q$q.txt | cut -c1-200; grep "down_img.4 *$" gpurun_out/${TAG}_lane_timeline_q$q.txt | head -1
+  done
+  unset DEBUG_HIP_FORCE_GRAPH_QUEUES
+  lap graphq
+fi
+if has imglane; then
+  for v in 1 0 1 0; do
+    V2V_IMG_LANE=$v timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_il$v.json 2> gpurun_out/${TAG}_bench_il$v.err; echo "bench img_lane=$v rc=$?"
+    cut -c1-160 gpurun_out/${TAG}_bench_il$v.json
+  done
+  V2V_IMG_LANE=1 timeout 300 python scripts/lane_timeline.py > gpurun_out/${TAG}_lane_timeline.txt 2>/dev/null; head -2 gpurun_out/${TAG}_lane_timeline.txt | cut -c1-200; grep "down_img.4 *$\|down_seg.13.c1" gpurun_out/${TAG}_lane_timeline.txt | head -2
+  lap imglane
+fi
+if has hwq; then
+  for q in default 2 8 16; do
+    if [ $q = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
+    for il in 1 0; do
+      V2V_IMG_LANE=$il timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_hwq${q}_il$il.json 2> gpurun_out/${TAG}_bench_hwq${q}_il$il.err; echo "bench GPU_MAX_HW_QUEUES=$q img_lane=$il rc=$?"
+      cut -c1-160 gpurun_out/${TAG}_bench_hwq${q}_il$il.json
+    done
+    V2V_IMG_LANE=1 timeout 300 python scripts/lane_timeline.py > gpurun_out/${TAG}_lane_timeline_hwq$q.txt 2>/dev/null; head -1 gpurun_out/${TAG}_lane_timeline_hwq$q.txt | cut -c1-200; grep "down_img.4 *$\|down_seg.13.c1" gpurun_out/${TAG}_lane_timeline_hwq$q.txt | head -2
+  done
+  unset GPU_MAX_HW_QUEUES
+  lap hwq
+fi
+if has graphlog; then
+  AMD_LOG_LEVEL=4 timeout 300 python scripts/lane_timeline.py 2>&1 >/dev/null | grep -i "max_streams\|parallel streams\|max streams" | sort | uniq -c | head -10
+  lap graphlog
+fi
+if has segab; then
+  timeout 900 python -m pytest tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 600 -k "not full_size" > gpurun_out/${TAG}_golden.log 2>&1; echo "golden rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_golden.log | cut -c1-300 | tail -8
+  for v in segments single segments single; do
+    V2V_GRAPH_MODE=$v timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_gm$v.json 2> gpurun_out/${TAG}_bench_gm$v.err; echo "bench graph_mode=$v rc=$?"
+    cut -c1-160 gpurun_out/${TAG}_bench_gm$v.json
+  done
+  timeout 300 python scripts/lane_timeline.py > gpurun_out/${TAG}_lane_timeline.txt 2>/dev/null; head -2 gpurun_out/${TAG}_lane_timeline.txt | cut -c1-200; grep "down_img.4 *$\|down_seg.13.c1\|warp_blend" gpurun_out/${TAG}_lane_timeline.txt | head -3
+  lap segab
+fi

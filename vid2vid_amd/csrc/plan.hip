@@ -6,6 +6,7 @@
 #include "v2v_internal.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace v2v {
 
@@ -27,6 +28,15 @@ struct v2v_plan {
     std::vector<std::unique_ptr<v2v::Op>> ops;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // segmented form (v2v_plan_instantiate_graph, mode 1): one LINEAR graph per run of ops of a lane between cross-lane
+    // edges, launched on one persistent stream per lane with events for the edges
+    struct Step { int kind; int a, b; };                  // kind 0: launch segment a on lane b; 1: lane a waits for lane b
+    std::vector<hipGraph_t> seg_graph;
+    std::vector<hipGraphExec_t> seg_exec;
+    std::vector<Step> program;
+    hipStream_t lane_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> edge_events;                   // one per kind-1 step, in program order
+    bool segmented = false;
 };
 
 namespace v2v {
@@ -81,6 +91,10 @@ extern "C" void v2v_plan_destroy(v2v_plan* p) {
     if (g_recording == p) g_recording = nullptr;
     if (p->exec) hipGraphExecDestroy(p->exec);
     if (p->graph) hipGraphDestroy(p->graph);
+    for (auto e : p->seg_exec) if (e) hipGraphExecDestroy(e);
+    for (auto g : p->seg_graph) if (g) hipGraphDestroy(g);
+    for (auto ev : p->edge_events) hipEventDestroy(ev);
+    for (int k = 1; k < 8; ++k) if (p->lane_stream[k]) hipStreamDestroy(p->lane_stream[k]);
     delete p;
 }
 
@@ -109,11 +123,123 @@ extern "C" int v2v_plan_run(v2v_plan* p, void* stream) {
     return 0;
 }
 
+// Segmented instantiation.  Measured with v2v_plan_timeline_graph (profiles/r02_a44_lane_timeline.txt): a single hipGraph
+// with three parallel branches never ran more than TWO of them at a time -- the image tower's head, ready at 60 us, started
+// at 700 us when the label tower's chain had finished (queue-count knobs of the runtime change nothing).  Here every lane is
+// a real HIP stream, every run of ops of a lane between two cross-lane edges is a linear graph launched on it, and the edges
+// are events: the same dependencies, scheduled by the hardware queues.
+__global__ void stamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
+
+static void plan_drop_segments(v2v_plan* p) {
+    for (auto e : p->seg_exec) if (e) hipGraphExecDestroy(e);
+    for (auto g : p->seg_graph) if (g) hipGraphDestroy(g);
+    for (auto ev : p->edge_events) hipEventDestroy(ev);
+    p->seg_exec.clear(); p->seg_graph.clear(); p->edge_events.clear(); p->program.clear();
+    p->segmented = false;
+}
+
+static int plan_instantiate_segments(v2v_plan* p, unsigned long long* stamps = nullptr) {
+    plan_drop_segments(p);
+    hipStream_t cs = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_error("plan: capture stream: %s", hipGetErrorString(e)); return (int)e; }
+    bool joined[8] = {true, false, false, false, false, false, false, false};
+    std::vector<size_t> open[8];                           // ops of the lane's current segment, in recording order
+    int rc = 0;
+    // closes the lane's open segment: one linear graph, one launch step
+    auto close = [&](int lane) -> int {
+        if (open[lane].empty()) return 0;
+        hipError_t q = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (q != hipSuccess) { set_error("plan: begin capture: %s", hipGetErrorString(q)); return (int)q; }
+        int r = 0;
+        for (size_t m : open[lane]) {
+            if (stamps) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, cs, stamps + 2 * m);
+            r = p->ops[m]->launch(cs);
+            if (stamps) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, cs, stamps + 2 * m + 1);
+            if (r != 0) break;
+        }
+        hipGraph_t g = nullptr;
+        hipError_t q2 = hipStreamEndCapture(cs, &g);
+        if (r != 0) { if (g) hipGraphDestroy(g); return r; }
+        if (q2 != hipSuccess) { set_error("plan: end capture: %s", hipGetErrorString(q2)); return (int)q2; }
+        hipGraphExec_t ex = nullptr;
+        q = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        if (q != hipSuccess) { hipGraphDestroy(g); set_error("plan: instantiate: %s", hipGetErrorString(q)); return (int)q; }
+        p->seg_graph.push_back(g); p->seg_exec.push_back(ex);
+        p->program.push_back({0, (int)p->seg_exec.size() - 1, lane});
+        open[lane].clear();
+        return 0;
+    };
+    for (size_t i = 0; i < p->ops.size() && rc == 0; ++i) {
+        Op* op = p->ops[i].get();
+        if (WaitOp* w = dynamic_cast<WaitOp*>(op)) {
+            if (!joined[w->signal]) { set_error("plan: lane %d waits for lane %d, which has no work yet", w->waiter, w->signal); rc = V2V_EINVAL; break; }
+            rc = close(w->signal);                           // the event is recorded behind everything the signalling lane has so far
+            if (rc == 0) rc = close(w->waiter);              // and the waiter's later ops start a new segment behind the wait
+            joined[w->waiter] = true;
+            p->program.push_back({1, w->waiter, w->signal});
+        } else if (!joined[op->lane]) { set_error("plan: op '%s' recorded on lane %d before the lane was forked", op->name(), op->lane); rc = V2V_EINVAL; }
+        else open[op->lane].push_back(i);
+    }
+    for (int k = 1; k < 8 && rc == 0; ++k) rc = close(k);
+    if (rc == 0) rc = close(0);
+    hipStreamDestroy(cs);
+    if (rc != 0) { plan_drop_segments(p); return rc; }
+    for (int k = 1; k < 8; ++k)
+        if (joined[k]) {
+            p->program.push_back({1, 0, k});                 // every lane joins lane 0 at the end
+            if (!p->lane_stream[k] && hipStreamCreateWithFlags(&p->lane_stream[k], hipStreamNonBlocking) != hipSuccess) { set_error("plan: lane stream"); plan_drop_segments(p); return V2V_EINVAL; }
+        }
+    for (auto& st : p->program)
+        if (st.kind == 1) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("plan: lane event"); plan_drop_segments(p); return V2V_EINVAL; }
+            p->edge_events.push_back(ev);
+        }
+    p->segmented = true;
+    return 0;
+}
+
+static int plan_launch_segments(v2v_plan* p, hipStream_t s) {
+    size_t ev = 0;
+    for (const auto& st : p->program) {
+        if (st.kind == 0) {
+            hipStream_t ls = st.b == 0 ? s : p->lane_stream[st.b];
+            hipError_t e = hipGraphLaunch(p->seg_exec[st.a], ls);
+            if (e != hipSuccess) { set_error("plan: segment launch: %s", hipGetErrorString(e)); return (int)e; }
+        } else {
+            hipStream_t sw = st.a == 0 ? s : p->lane_stream[st.a], sg = st.b == 0 ? s : p->lane_stream[st.b];
+            hipEvent_t e_ = p->edge_events[ev++];
+            hipError_t e = hipEventRecord(e_, sg);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sw, e_, 0);
+            if (e != hipSuccess) { set_error("plan: lane edge: %s", hipGetErrorString(e)); return (int)e; }
+        }
+    }
+    return 0;
+}
+
+static int graph_mode() {        // V2V_GRAPH_MODE: "single" = one hipGraph with parallel branches, default = one linear graph per lane segment
+    static const int m = [] { const char* e = getenv("V2V_GRAPH_MODE"); return (e && e[0] == 's' && e[1] == 'i') ? 0 : 1; }();
+    return m;
+}
+
 extern "C" int v2v_plan_instantiate_graph(v2v_plan* p, void* stream) {
     if (!p) return V2V_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
     if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+    plan_drop_segments(p);
+    {
+        bool lanes_used = false;
+        for (auto& op : p->ops) if (op->lane != 0) { lanes_used = true; break; }
+        if (lanes_used && graph_mode() == 1) {
+            int rc0 = v2v_plan_run(p, stream);               // one eager pass first (kernel attributes, code objects)
+            if (rc0 != 0) return rc0;
+            hipError_t e0 = hipStreamSynchronize(s);
+            if (e0 != hipSuccess) { set_error("plan: warm-up failed: %s", hipGetErrorString(e0)); return (int)e0; }
+            return plan_instantiate_segments(p);
+        }
+    }
     // one eager pass first: sets per-kernel attributes and faults in code objects outside capture
     int rc = v2v_plan_run(p, stream);
     if (rc != 0) return rc;
@@ -163,6 +289,7 @@ extern "C" int v2v_plan_instantiate_graph(v2v_plan* p, void* stream) {
 }
 
 extern "C" int v2v_plan_launch_graph(v2v_plan* p, void* stream) {
+    if (p && p->segmented) return plan_launch_segments(p, reinterpret_cast<hipStream_t>(stream));
     if (!p || !p->exec) { set_error("plan: graph not instantiated"); return V2V_EINVAL; }
     hipError_t e = hipGraphLaunch(p->exec, reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) { set_error("plan: graph launch: %s", hipGetErrorString(e)); return (int)e; }
@@ -185,6 +312,166 @@ extern "C" int v2v_plan_profile(v2v_plan* p, void* stream, float* ms, int32_t n)
     if (rc == 0)
         for (size_t i = 0; i < nops; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
     for (auto& e : ev) hipEventDestroy(e);
+    return rc;
+}
+
+// Concurrent timeline: the plan replayed eagerly with every lane on its own stream (the edges the graph capture uses) and a
+// one-thread kernel that stores the device's constant-rate wall clock before and after every op on ITS stream (HIP timing
+// events of different streams gave inconsistent, even negative, intervals); t0 / t1 = start / end of op i in ms since the
+// replay began.  The stamps cost a few us per op, so the replay is slower than the graph, but it shows which lane waits for
+// which -- rocprofv3's kernel trace serialises kernels and shows every kernel alone.
+
+extern "C" int v2v_plan_timeline(v2v_plan* p, void* stream, float* t0, float* t1, int32_t* lanes, int32_t n) {
+    if (!p || !t0 || !t1 || n < (int)p->ops.size()) { set_error("plan: timeline buffers too small"); return V2V_EINVAL; }
+    if (g_dry_run) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t nops = p->ops.size();
+    hipStream_t ls[8] = {s, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool joined[8] = {true, false, false, false, false, false, false, false};
+    std::vector<hipEvent_t> edges;
+    unsigned long long* dclk = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dclk), (2 * nops + 1) * sizeof(unsigned long long)) != hipSuccess) { set_error("plan: timeline buffer"); return V2V_EINVAL; }
+    hipMemsetAsync(dclk, 0, (2 * nops + 1) * sizeof(unsigned long long), s);
+    auto edge = [&](int waiter, int signal) -> int {
+        if (!joined[signal]) { set_error("plan: lane %d waits for lane %d, which has no work yet", waiter, signal); return V2V_EINVAL; }
+        if (!ls[waiter] && hipStreamCreateWithFlags(&ls[waiter], hipStreamNonBlocking) != hipSuccess) { set_error("plan: lane stream"); return V2V_EINVAL; }
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("plan: lane event"); return V2V_EINVAL; }
+        edges.push_back(ev);
+        hipEventRecord(ev, ls[signal]);
+        hipStreamWaitEvent(ls[waiter], ev, 0);
+        joined[waiter] = true;
+        return 0;
+    };
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, dclk + 2 * nops);
+    int rc = 0;
+    for (size_t i = 0; i < nops && rc == 0; ++i) {
+        Op* op = p->ops[i].get();
+        if (lanes) lanes[i] = op->lane;
+        if (WaitOp* w = dynamic_cast<WaitOp*>(op)) {
+            rc = edge(w->waiter, w->signal);
+            if (rc == 0) { hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ls[w->waiter], dclk + 2 * i); hipMemcpyAsync(dclk + 2 * i + 1, dclk + 2 * i, 8, hipMemcpyDeviceToDevice, ls[w->waiter]); }
+        } else if (!joined[op->lane]) { set_error("plan: op on lane %d before the lane was forked", op->lane); rc = V2V_EINVAL; }
+        else {
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ls[op->lane], dclk + 2 * i);
+            rc = op->launch(ls[op->lane]);
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ls[op->lane], dclk + 2 * i + 1);
+        }
+    }
+    for (int k = 1; k < 8 && rc == 0; ++k)
+        if (joined[k]) rc = edge(0, k);
+    hipStreamSynchronize(s);
+    for (int k = 1; k < 8; ++k) if (ls[k]) { hipStreamSynchronize(ls[k]); hipStreamDestroy(ls[k]); }
+    if (rc == 0) {
+        std::vector<unsigned long long> h(2 * nops + 1);
+        hipMemcpy(h.data(), dclk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        int khz = 100000, dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+        const unsigned long long base = h[2 * nops];
+        for (size_t i = 0; i < nops; ++i) {
+            t0[i] = (float)((double)(long long)(h[2 * i] - base) / (double)khz);
+            t1[i] = (float)((double)(long long)(h[2 * i + 1] - base) / (double)khz);
+        }
+    }
+    for (auto ev : edges) hipEventDestroy(ev);
+    hipFree(dclk);
+    return rc;
+}
+
+// The same stamps captured INTO a hipGraph (one stream per lane, as v2v_plan_instantiate_graph) and launched as a graph: the
+// schedule of the real frame replay, without the host's issue order of an eager replay.  The graph is launched twice, the
+// second launch is reported.
+extern "C" int v2v_plan_timeline_graph(v2v_plan* p, void* stream, float* t0, float* t1, int32_t* lanes, int32_t n) {
+    if (!p || !t0 || !t1 || n < (int)p->ops.size()) { set_error("plan: timeline buffers too small"); return V2V_EINVAL; }
+    if (g_dry_run) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t nops = p->ops.size();
+    unsigned long long* dclk = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dclk), (2 * nops + 1) * sizeof(unsigned long long)) != hipSuccess) { set_error("plan: timeline buffer"); return V2V_EINVAL; }
+    hipMemset(dclk, 0, (2 * nops + 1) * sizeof(unsigned long long));
+    if (p->segmented) {                                        // the plan as it is replayed: per-lane segment graphs on real streams
+        int rc = plan_instantiate_segments(p, dclk);
+        for (int rep = 0; rep < 2 && rc == 0; ++rep) {
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, dclk + 2 * nops);
+            rc = plan_launch_segments(p, s);
+        }
+        hipStreamSynchronize(s);
+        if (rc == 0) {
+            std::vector<unsigned long long> h(2 * nops + 1);
+            hipMemcpy(h.data(), dclk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            int khz = 100000, dev = 0;
+            hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+            const unsigned long long base = h[2 * nops];
+            for (size_t i = 0; i < nops; ++i) {
+                if (lanes) lanes[i] = p->ops[i]->lane;
+                t0[i] = (float)((double)(long long)(h[2 * i] - base) / (double)khz);
+                t1[i] = (float)((double)(long long)(h[2 * i + 1] - base) / (double)khz);
+            }
+        }
+        const int rc2 = plan_instantiate_segments(p);           // back to the stamp-free program
+        hipFree(dclk);
+        return rc != 0 ? rc : rc2;
+    }
+    hipStream_t cs = nullptr;
+    hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { set_error("plan: begin capture: %s", hipGetErrorString(e)); hipStreamDestroy(cs); hipFree(dclk); return (int)e; }
+    hipStream_t ls[8] = {cs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool joined[8] = {true, false, false, false, false, false, false, false};
+    std::vector<hipEvent_t> evs;
+    auto edge = [&](int waiter, int signal) -> int {
+        if (!joined[signal]) { set_error("plan: lane %d waits for lane %d, which has no work yet", waiter, signal); return V2V_EINVAL; }
+        if (!ls[waiter] && hipStreamCreateWithFlags(&ls[waiter], hipStreamNonBlocking) != hipSuccess) { set_error("plan: lane stream"); return V2V_EINVAL; }
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("plan: lane event"); return V2V_EINVAL; }
+        evs.push_back(ev);
+        hipError_t q = hipEventRecord(ev, ls[signal]);
+        if (q == hipSuccess) q = hipStreamWaitEvent(ls[waiter], ev, 0);
+        if (q != hipSuccess) { set_error("plan: lane edge: %s", hipGetErrorString(q)); return (int)q; }
+        joined[waiter] = true;
+        return 0;
+    };
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, cs, dclk + 2 * nops);
+    int rc = 0;
+    for (size_t i = 0; i < nops && rc == 0; ++i) {
+        Op* op = p->ops[i].get();
+        if (lanes) lanes[i] = op->lane;
+        if (WaitOp* w = dynamic_cast<WaitOp*>(op)) rc = edge(w->waiter, w->signal);
+        else if (!joined[op->lane]) { set_error("plan: op on lane %d before the lane was forked", op->lane); rc = V2V_EINVAL; }
+        else {
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ls[op->lane], dclk + 2 * i);
+            rc = op->launch(ls[op->lane]);
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ls[op->lane], dclk + 2 * i + 1);
+        }
+    }
+    for (int k = 1; k < 8 && rc == 0; ++k)
+        if (joined[k]) rc = edge(0, k);
+    hipGraph_t g = nullptr;
+    hipError_t e2 = hipStreamEndCapture(cs, &g);
+    for (int k = 0; k < 8; ++k) if (ls[k]) hipStreamDestroy(ls[k]);
+    for (auto ev : evs) hipEventDestroy(ev);
+    hipGraphExec_t ex = nullptr;
+    if (rc == 0 && e2 != hipSuccess) { set_error("plan: end capture: %s", hipGetErrorString(e2)); rc = (int)e2; }
+    if (rc == 0 && (e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0)) != hipSuccess) { set_error("plan: instantiate: %s", hipGetErrorString(e)); rc = (int)e; }
+    if (rc == 0) {
+        hipGraphLaunch(ex, s); hipGraphLaunch(ex, s);
+        hipStreamSynchronize(s);
+        std::vector<unsigned long long> h(2 * nops + 1);
+        hipMemcpy(h.data(), dclk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        int khz = 100000, dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+        const unsigned long long base = h[2 * nops];
+        for (size_t i = 0; i < nops; ++i) {
+            t0[i] = (float)((double)(long long)(h[2 * i] - base) / (double)khz);
+            t1[i] = (float)((double)(long long)(h[2 * i + 1] - base) / (double)khz);
+        }
+    }
+    if (ex) hipGraphExecDestroy(ex);
+    if (g) hipGraphDestroy(g);
+    hipFree(dclk);
     return rc;
 }
 

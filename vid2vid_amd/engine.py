@@ -261,6 +261,16 @@ class Plan:
             out.append((lib.v2v_plan_op_name(self.h, i).decode(), lib.v2v_plan_op_label(self.h, i).decode(), ms[i]))
         return out
 
+    def timeline(self, graph=True):
+        """[(op, label, lane, start_ms, end_ms)] of one replay with every lane on its own stream: captured as a hipGraph
+        (the real schedule) or issued eagerly (shows the host's issue order as well)."""
+        n = self.num_ops
+        t0, t1, ln = (C.c_float * n)(), (C.c_float * n)(), (C.c_int32 * n)()
+        fn = lib.v2v_plan_timeline_graph if graph else lib.v2v_plan_timeline
+        check(fn(self.h, _stream(), t0, t1, ln, n), "plan_timeline")
+        return [(lib.v2v_plan_op_name(self.h, i).decode(), lib.v2v_plan_op_label(self.h, i).decode(), int(ln[i]), t0[i], t1[i])
+                for i in range(n)]
+
     def __del__(self):
         try:
             lib.v2v_plan_destroy(self.h)
