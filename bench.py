@@ -339,6 +339,58 @@ def main():
     torch.cuda.synchronize(dev)
     release_tuning()                             # N > 1, rank 0: the other ranks may now build with its selections
 
+    # ---------------- host-fed rate (SURVEY 8f-2): uint8 labels + int32 instance ids from pinned host memory every frame ----
+    # (a side figure, measured before the CPU oracle runs: after 128 oracle threads have been busy the launching thread of this
+    # loop is measurably slower -- 258 instead of 300 frames/s -- although the GPU-resident `value` below is not affected)
+    host_fed = None
+    if rank == 0 and world == 1 and not face:
+        try:
+            lab8, inst32 = lab.to(torch.uint8).cpu().pin_memory(), inst.to(torch.int32).cpu().pin_memory()
+            # double-buffered staging: frame t+1's maps are uploaded on a copy stream while frame t's graph runs
+            dA = [torch.empty(1, tG, 1, H, W, dtype=torch.uint8, device=dev) for _ in range(2)]
+            dI = [torch.empty(1, tG, 1, H, W, dtype=torch.int32, device=dev) for _ in range(2)]
+            copy_stream = torch.cuda.Stream(device=dev)
+            ready = [torch.cuda.Event(), torch.cuda.Event()]
+            consumed = [torch.cuda.Event(), torch.cuda.Event()]
+
+            def upload(t):
+                b, k = t & 1, t % L
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(consumed[b])          # the frame that last read this buffer has taken its copy
+                    dA[b].view(tG, H, W).copy_(lab8[k:k + tG], non_blocking=True)
+                    dI[b].view(tG, H, W).copy_(inst32[k:k + tG], non_blocking=True)
+                    ready[b].record(copy_stream)
+
+            def host_step(t):
+                b = t & 1
+                torch.cuda.current_stream(dev).wait_event(ready[b])
+                out_ = model.inference(dA[b], frames[:, :tG - 1] if t == 0 else None, dI[b])
+                consumed[b].record(torch.cuda.current_stream(dev))
+                upload(t + 1)
+                return out_
+
+            for b_ in range(2):
+                consumed[b_].record(torch.cuda.current_stream(dev))
+            upload(0)
+            model.fake_B_prev = None
+            for t in range(3):
+                host_step(t)                       # builds the uint8 frame plan
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for t in range(3, 3 + args.steps):
+                host_step(t)
+            torch.cuda.synchronize(dev)
+            el_h = time.perf_counter() - t0
+            host_fed = {"value": round(args.steps / el_h, 3), "unit": "frames/s", "ms_per_step": round(el_h / args.steps * 1e3, 4),
+                        "h2d_bytes_per_frame": tG * H * W * 5,
+                        "note": "every frame uploads its %d label maps (uint8) and instance maps (int32) from pinned host memory, double-buffered "
+                                "on a copy stream (the reference's loader hands over host tensors, test.py:37-45); PCIe-inclusive, never `value`" % tG}
+            model.fake_B_prev = None
+            run_step(model, 0)                      # back on the resident fp32-encoded plan for the profile below
+            torch.cuda.synchronize(dev)
+        except Exception as ex:
+            host_fed = {"error": repr(ex)[:300]}
+
     # ---------------- parity BEFORE timing: oracle vs the fp32 path and vs the benchmarked bf16 path ----------
     # rank 0 at N=1 only: the CPU oracle (also the cpu_baseline) generates PAR_FRAMES frames of the same seeded workload;
     # an fp32 model holding the same weights and the benchmarked model replay them.  Every output of the finest scale is
@@ -452,56 +504,6 @@ def main():
     fp = model._active_plan
     finite = bool(torch.isfinite(fp.out["fake_B"]).all().item())
 
-    # ---------------- host-fed rate (SURVEY 8f-2): uint8 labels + int32 instance ids from pinned host memory every frame ----
-    host_fed = None
-    if rank == 0 and world == 1 and not face:
-        try:
-            lab8, inst32 = lab.to(torch.uint8).cpu().pin_memory(), inst.to(torch.int32).cpu().pin_memory()
-            # double-buffered staging: frame t+1's maps are uploaded on a copy stream while frame t's graph runs
-            dA = [torch.empty(1, tG, 1, H, W, dtype=torch.uint8, device=dev) for _ in range(2)]
-            dI = [torch.empty(1, tG, 1, H, W, dtype=torch.int32, device=dev) for _ in range(2)]
-            copy_stream = torch.cuda.Stream(device=dev)
-            ready = [torch.cuda.Event(), torch.cuda.Event()]
-            consumed = [torch.cuda.Event(), torch.cuda.Event()]
-
-            def upload(t):
-                b, k = t & 1, t % L
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(consumed[b])          # the frame that last read this buffer has taken its copy
-                    dA[b].view(tG, H, W).copy_(lab8[k:k + tG], non_blocking=True)
-                    dI[b].view(tG, H, W).copy_(inst32[k:k + tG], non_blocking=True)
-                    ready[b].record(copy_stream)
-
-            def host_step(t):
-                b = t & 1
-                torch.cuda.current_stream(dev).wait_event(ready[b])
-                out_ = model.inference(dA[b], frames[:, :tG - 1] if t == 0 else None, dI[b])
-                consumed[b].record(torch.cuda.current_stream(dev))
-                upload(t + 1)
-                return out_
-
-            for b_ in range(2):
-                consumed[b_].record(torch.cuda.current_stream(dev))
-            upload(0)
-            model.fake_B_prev = None
-            for t in range(3):
-                host_step(t)                       # builds the uint8 frame plan
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for t in range(3, 3 + args.steps):
-                host_step(t)
-            torch.cuda.synchronize(dev)
-            el_h = time.perf_counter() - t0
-            host_fed = {"value": round(args.steps / el_h, 3), "unit": "frames/s", "ms_per_step": round(el_h / args.steps * 1e3, 4),
-                        "h2d_bytes_per_frame": tG * H * W * 5,
-                        "note": "every frame uploads its %d label maps (uint8) and instance maps (int32) from pinned host memory, double-buffered "
-                                "on a copy stream (the reference's loader hands over host tensors, test.py:37-45); PCIe-inclusive, never `value`" % tG}
-            model.fake_B_prev = None
-            run_step(model, 0)                      # back on the resident fp32-encoded plan for the profile below
-            torch.cuda.synchronize(dev)
-        except Exception as ex:
-            host_fed = {"error": repr(ex)[:300]}
-
     # ---------------- roofline of the dominant kernel (HIP events, same plan, same stream) ----
     roofline = None
     if rank == 0:
@@ -559,7 +561,9 @@ def main():
             fused_ = bool(c0 and c0.get("fused_norm"))
             alg = None if c0 is None else c0["members"] * (c0["N"] * c0["H"] * c0["W"] * c0["cin"] * esz + c0["cout"] * c0["cin"] * 9 * esz
                                                             + c0["N"] * c0["OH"] * c0["OW"] * c0["cout"] * (2 * esz if fused_ else 4))
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+            import re
+            natural = lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))]      # r02_a51 after r02_a7
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=natural, reverse=True):
                 tj = json.load(open(fn))
                 if list(tj.get("cfg", [])) == [dom[0], dom[1], dom[2]] and tj.get("hbm_bytes_per_launch"):
                     traffic = tj["hbm_bytes_per_launch"]
@@ -567,7 +571,7 @@ def main():
                                       "source": "profiles/" + os.path.basename(fn) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                       "passes, FETCH_SIZE x2 per the gfx950 correction; the 1024->1024 3x3 layer)"}
                     break
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_in_graph.json")), reverse=True):
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_in_graph.json")), key=natural, reverse=True):
                 gj = json.load(open(fn))
                 if list(gj.get("cfg", [])) == [dom[0], dom[1], dom[2]] and gj.get("avg_us"):
                     in_graph = {"avg_launch_us": gj["avg_us"], "achieved": round(a["flops"] / a["launches"] / gj["avg_us"] / 1e6, 2),

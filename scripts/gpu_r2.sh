@@ -280,3 +280,10 @@ if has segab; then
   timeout 300 python scripts/lane_timeline.py > gpurun_out/${TAG}_lane_timeline.txt 2>/dev/null; head -2 gpurun_out/${TAG}_lane_timeline.txt | cut -c1-200; grep "down_img.4 *$\|down_seg.13.c1\|warp_blend" gpurun_out/${TAG}_lane_timeline.txt | head -3
   lap segab
 fi
+if has hostfed; then
+  for v in segments single segments single; do
+    V2V_GRAPH_MODE=$v timeout 300 python bench.py --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_hf$v.json 2> gpurun_out/${TAG}_bench_hf$v.err; echo "bench graph_mode=$v rc=$?"
+    python -c "import json; j=json.load(open('gpurun_out/${TAG}_bench_hf$v.json')); print(j['value'], j['host_fed']['value'])"
+  done
+  lap hostfed
+fi
