@@ -287,3 +287,9 @@ if has hostfed; then
   done
   lap hostfed
 fi
+if has overhead2; then
+  for v in segments single; do
+    echo "== V2V_GRAPH_MODE=$v"; V2V_GRAPH_MODE=$v timeout 300 python scripts/frame_overhead.py 2>/dev/null
+  done | tee gpurun_out/${TAG}_frame_overhead.txt
+  lap overhead2
+fi

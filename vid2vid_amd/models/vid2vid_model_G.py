@@ -114,8 +114,9 @@ class _FramePlan:
         if use_graph and not eng.record_only:
             self.plan.instantiate_graph()
 
-    def _time_frames(self, n=8, reps=5):
-        """Median ms per replay of the current graph (buffers hold whatever they hold: the timing is data independent)."""
+    def _time_frames(self, n=16, reps=3):
+        """Median ms per replay of the current graph (buffers hold whatever they hold: the timing is data independent).
+        16 replays per sample: the lane streams start every sample from idle, which costs the first replay ~0.5 ms extra."""
         ts = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
