@@ -293,3 +293,10 @@ if has overhead2; then
   done | tee gpurun_out/${TAG}_frame_overhead.txt
   lap overhead2
 fi
+if has fgfork; then
+  for v in late early late early; do
+    V2V_FG_FORK=$v timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_fg$v.json 2> gpurun_out/${TAG}_bench_fg$v.err; echo "bench fg_fork=$v rc=$?"
+    cut -c1-160 gpurun_out/${TAG}_bench_fg$v.json
+  done
+  lap fgfork
+fi
