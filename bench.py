@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1]): label2city 512x256, n_scales_spatial=1, --f
 ngf=128 / 9 blocks (411 M parameters, 2115 GFLOP per frame), batch 1 per sequence, one sequence
 per GPU, bf16 storage + fp32 MFMA accumulate, random-init weights, seeded synthetic label /
 instance / image sequences already resident in HBM.  A "step" is one generated frame: refresh
-the plan's input buffers (device-to-device) + one hipGraph launch of the whole frame.
+the plan's input buffers (device-to-device) + one replay of the frame plan (per-lane segment hipGraphs on three streams).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \

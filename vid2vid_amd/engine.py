@@ -13,7 +13,7 @@ emits the fused HIP launches:
 
 All tensors handed to the library are NHWC with a channel stride padded to 16 bytes.  The
 emitted launches either run immediately (eager) or are recorded into a `Plan` that is then
-replayed per frame as one native call / one hipGraph.  No torch compute op is on this path.
+replayed per frame as one native call (hipGraphs, one per lane segment).  No torch compute op is on this path.
 """
 import contextlib
 import ctypes as C
