@@ -430,6 +430,10 @@ int       v2v_plan_num_ops(const v2v_plan* p);
 int       v2v_plan_run(v2v_plan* p, void* stream);              /* eager replay                   */
 int       v2v_plan_instantiate_graph(v2v_plan* p, void* stream);/* capture into a hipGraphExec    */
 int       v2v_plan_launch_graph(v2v_plan* p, void* stream);
+/* The launch program v2v_plan_instantiate_graph builds for a plan with lanes (no device needed): steps[3*i..] = {0, segment,
+ * lane} launch a linear graph of consecutive ops of one lane, or {1, waiter, signal} an event edge; seg_of_op[i] = segment of
+ * recorded op i (-1 for lane_wait ops; may be NULL).  Returns the number of steps. */
+int       v2v_plan_segment_program(const v2v_plan* p, int32_t* steps, int32_t max_steps, int32_t* seg_of_op, int32_t n_ops);
 /* per-op HIP-event timing of one eager replay: ms[i] for op i, names via v2v_plan_op_name */
 int       v2v_plan_profile(v2v_plan* p, void* stream, float* ms, int32_t n);
 /* concurrent timeline of one eager replay with every lane on its own stream: start / end of op i in ms since the replay began,
@@ -440,6 +444,7 @@ int       v2v_plan_timeline(v2v_plan* p, void* stream, float* t0_ms, float* t1_m
 /* the same measurement with the ops and the stamps captured into a hipGraph (the schedule of the real graph replay) */
 int       v2v_plan_timeline_graph(v2v_plan* p, void* stream, float* t0_ms, float* t1_ms, int32_t* lanes, int32_t n);
 const char* v2v_plan_op_name(const v2v_plan* p, int32_t i);
+int       v2v_plan_op_lane(const v2v_plan* p, int32_t i);       /* lane of op i; for a lane_wait op: waiter | signal << 8 */
 int       v2v_plan_set_label(v2v_plan* p, const char* label);   /* labels the last recorded op */
 const char* v2v_plan_op_label(const v2v_plan* p, int32_t i);
 /* Lanes = parallel branches of a recorded plan (0..7, thread-local; default 0).  Ops recorded after v2v_plan_set_lane(k)

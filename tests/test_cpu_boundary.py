@@ -310,6 +310,72 @@ def test_twin_chains_record_paired_launches():
         N._ENGINES.clear()
 
 
+def test_segment_program_of_the_frame_plan_respects_every_edge():
+    """The plan executor replays a plan with lanes as one linear hipGraph per lane segment on per-lane streams with event edges
+    (csrc/plan.hip, plan_segment_program).  For the recorded 512x256 frame (three lanes) the launch program must keep every lane's
+    ops in recording order, put an op into exactly one segment of its own lane, and place every edge behind all earlier ops of
+    the signalling lane and in front of all later ops of the waiting lane -- checked without a device."""
+    import ctypes as C
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models import create_model
+    if torch.cuda.is_available():
+        pytest.skip("dry-run census is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        opt = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True, precision="bf16", gpu_ids=[])
+        m = create_model(opt)
+        H, W = 256, 512
+        m.inference(torch.randint(0, 35, (1, 3, 1, H, W)).float(), torch.zeros(1, 2, 3, H, W), torch.randint(0, 20, (1, 3, 1, H, W)).float())
+        plan = m._active_plan.plan
+        n = plan.num_ops
+        names = [lib.v2v_plan_op_name(plan.h, i).decode() for i in range(n)]
+        lanes = [lib.v2v_plan_op_lane(plan.h, i) for i in range(n)]
+        steps = (C.c_int32 * (3 * 4 * n))()
+        seg_of = (C.c_int32 * n)()
+        ns = lib.v2v_plan_segment_program(plan.h, steps, 4 * n, seg_of, n)
+        assert ns > 0
+        prog = [(steps[3 * i], steps[3 * i + 1], steps[3 * i + 2]) for i in range(ns)]
+        waits = [i for i in range(n) if names[i] == "lane_wait"]
+        used = sorted({l for i, l in enumerate(lanes) if names[i] != "lane_wait"})
+        assert used == [0, 1, 2]
+        # every op in exactly one segment of its own lane; lane_wait ops in none
+        seg_lane, seg_pos = {}, {}
+        for pos, (kind, a, b) in enumerate(prog):
+            if kind == 0:
+                assert a not in seg_lane
+                seg_lane[a], seg_pos[a] = b, pos
+        for i in range(n):
+            if names[i] == "lane_wait":
+                assert seg_of[i] == -1
+            else:
+                assert seg_lane[seg_of[i]] == lanes[i]
+        # per lane: segments are launched in the recording order of their ops
+        for l in used:
+            ops = [i for i in range(n) if names[i] != "lane_wait" and lanes[i] == l]
+            pos = [seg_pos[seg_of[i]] for i in ops]
+            assert pos == sorted(pos)
+        # edges: the recorded ones in order, then one join of every forked lane into lane 0
+        edges = [(pos, a, b) for pos, (kind, a, b) in enumerate(prog) if kind == 1]
+        assert len(edges) == len(waits) + len(used) - 1
+        assert sorted((a, b) for _, a, b in edges[len(waits):]) == [(0, l) for l in used if l != 0]
+        for (pos, a, b), i in zip(edges, waits):
+            waiter, signal = lanes[i] & 0xff, lanes[i] >> 8
+            assert (a, b) == (waiter, signal)
+            for j in range(n):
+                if names[j] == "lane_wait":
+                    continue
+                if lanes[j] == signal and j < i:
+                    assert seg_pos[seg_of[j]] < pos          # recorded (hence launched) before the event is recorded
+                if lanes[j] == waiter and j > i:
+                    assert seg_pos[seg_of[j]] > pos          # launched behind the wait
+        assert sum(1 for k, _, _ in prog if k == 0) <= 12       # 9 segment graphs for this frame: a handful of launches, not 120
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_three_scale_narrow_towers_lowering_records(precision):
     """n_scales_spatial = 3 at the widths of tests/golden/inference_label2city_s3_64x128.npz (ngf 8 -> 4 -> 2: towers with

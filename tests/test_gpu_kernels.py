@@ -621,6 +621,13 @@ def test_onehot_stem_equals_dense_conv_on_the_encoding(case, prec):
         if u8:
             assert torch.equal(got, first)
         first = got
+    # the 1-byte label | edge map (v2v_label_codes) the frame plan stages the stems from: same result bit for bit
+    assert x.onehot.codes is None
+    assert eng.label_codes(x.onehot, H, W) is not None
+    raw_c, _, _ = eng.onehot_conv(x, conv, label="stem")
+    got_c = raw_c[:H * W * cs].view(H, W, cs)[..., :cout].permute(2, 0, 1).cpu()
+    assert torch.equal(got_c, first)
+    x.onehot.codes = None
     # whole group (norm + ReLU) vs this library's dense convolution on the materialised encoding
     y1 = eng.unpack(eng.conv_group(x, conv, L.PAD_REFLECT, 3, norm, L.ACT_RELU, 0.0, label="stem")).cpu()
     assert eng.conv_log[-1].get("onehot")

@@ -138,64 +138,77 @@ static void plan_drop_segments(v2v_plan* p) {
     p->segmented = false;
 }
 
+// The launch program of the segmented form, without touching the device: `segments[k]` = indices of the ops of segment k in
+// recording order, `program` = the steps {0, segment, lane} / {1, waiter, signal} in issue order.  Per lane the ops keep their
+// recording order; an edge closes the open segment of both lanes it touches; every lane that was forked joins lane 0 at the end.
+static int plan_segment_program(const v2v_plan* p, std::vector<std::vector<size_t>>* segments, std::vector<v2v_plan::Step>* program) {
+    bool joined[8] = {true, false, false, false, false, false, false, false};
+    std::vector<size_t> open[8];
+    auto close = [&](int lane) {
+        if (open[lane].empty()) return;
+        segments->push_back(open[lane]);
+        program->push_back({0, (int)segments->size() - 1, lane});
+        open[lane].clear();
+    };
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        Op* op = p->ops[i].get();
+        if (WaitOp* w = dynamic_cast<WaitOp*>(op)) {
+            if (!joined[w->signal]) { set_error("plan: lane %d waits for lane %d, which has no work yet", w->waiter, w->signal); return V2V_EINVAL; }
+            close(w->signal);                                // the event is recorded behind everything the signalling lane has so far
+            close(w->waiter);                                // and the waiter's later ops start a new segment behind the wait
+            joined[w->waiter] = true;
+            program->push_back({1, w->waiter, w->signal});
+        } else if (op->lane < 0 || op->lane >= 8 || !joined[op->lane]) {
+            set_error("plan: op '%s' recorded on lane %d before the lane was forked", op->name(), op->lane); return V2V_EINVAL;
+        } else open[op->lane].push_back(i);
+    }
+    for (int k = 1; k < 8; ++k) close(k);
+    close(0);
+    for (int k = 1; k < 8; ++k)
+        if (joined[k]) program->push_back({1, 0, k});       // every lane joins lane 0 at the end
+    return 0;
+}
+
 static int plan_instantiate_segments(v2v_plan* p, unsigned long long* stamps = nullptr) {
     plan_drop_segments(p);
+    std::vector<std::vector<size_t>> segments;
+    int rc = plan_segment_program(p, &segments, &p->program);
+    if (rc != 0) { p->program.clear(); return rc; }
     hipStream_t cs = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-    if (e != hipSuccess) { set_error("plan: capture stream: %s", hipGetErrorString(e)); return (int)e; }
-    bool joined[8] = {true, false, false, false, false, false, false, false};
-    std::vector<size_t> open[8];                           // ops of the lane's current segment, in recording order
-    int rc = 0;
-    // closes the lane's open segment: one linear graph, one launch step
-    auto close = [&](int lane) -> int {
-        if (open[lane].empty()) return 0;
+    if (e != hipSuccess) { set_error("plan: capture stream: %s", hipGetErrorString(e)); p->program.clear(); return (int)e; }
+    for (const auto& seg : segments) {                       // one linear graph per segment
         hipError_t q = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-        if (q != hipSuccess) { set_error("plan: begin capture: %s", hipGetErrorString(q)); return (int)q; }
-        int r = 0;
-        for (size_t m : open[lane]) {
+        if (q != hipSuccess) { set_error("plan: begin capture: %s", hipGetErrorString(q)); rc = (int)q; break; }
+        for (size_t m : seg) {
             if (stamps) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, cs, stamps + 2 * m);
-            r = p->ops[m]->launch(cs);
+            rc = p->ops[m]->launch(cs);
             if (stamps) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, cs, stamps + 2 * m + 1);
-            if (r != 0) break;
+            if (rc != 0) break;
         }
         hipGraph_t g = nullptr;
         hipError_t q2 = hipStreamEndCapture(cs, &g);
-        if (r != 0) { if (g) hipGraphDestroy(g); return r; }
-        if (q2 != hipSuccess) { set_error("plan: end capture: %s", hipGetErrorString(q2)); return (int)q2; }
+        if (rc != 0) { if (g) hipGraphDestroy(g); break; }
+        if (q2 != hipSuccess) { set_error("plan: end capture: %s", hipGetErrorString(q2)); rc = (int)q2; break; }
         hipGraphExec_t ex = nullptr;
         q = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-        if (q != hipSuccess) { hipGraphDestroy(g); set_error("plan: instantiate: %s", hipGetErrorString(q)); return (int)q; }
+        if (q != hipSuccess) { hipGraphDestroy(g); set_error("plan: instantiate: %s", hipGetErrorString(q)); rc = (int)q; break; }
         p->seg_graph.push_back(g); p->seg_exec.push_back(ex);
-        p->program.push_back({0, (int)p->seg_exec.size() - 1, lane});
-        open[lane].clear();
-        return 0;
-    };
-    for (size_t i = 0; i < p->ops.size() && rc == 0; ++i) {
-        Op* op = p->ops[i].get();
-        if (WaitOp* w = dynamic_cast<WaitOp*>(op)) {
-            if (!joined[w->signal]) { set_error("plan: lane %d waits for lane %d, which has no work yet", w->waiter, w->signal); rc = V2V_EINVAL; break; }
-            rc = close(w->signal);                           // the event is recorded behind everything the signalling lane has so far
-            if (rc == 0) rc = close(w->waiter);              // and the waiter's later ops start a new segment behind the wait
-            joined[w->waiter] = true;
-            p->program.push_back({1, w->waiter, w->signal});
-        } else if (!joined[op->lane]) { set_error("plan: op '%s' recorded on lane %d before the lane was forked", op->name(), op->lane); rc = V2V_EINVAL; }
-        else open[op->lane].push_back(i);
     }
-    for (int k = 1; k < 8 && rc == 0; ++k) rc = close(k);
-    if (rc == 0) rc = close(0);
     hipStreamDestroy(cs);
     if (rc != 0) { plan_drop_segments(p); return rc; }
-    for (int k = 1; k < 8; ++k)
-        if (joined[k]) {
-            p->program.push_back({1, 0, k});                 // every lane joins lane 0 at the end
-            if (!p->lane_stream[k] && hipStreamCreateWithFlags(&p->lane_stream[k], hipStreamNonBlocking) != hipSuccess) { set_error("plan: lane stream"); plan_drop_segments(p); return V2V_EINVAL; }
-        }
-    for (auto& st : p->program)
+    for (auto& st : p->program) {
         if (st.kind == 1) {
             hipEvent_t ev;
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("plan: lane event"); plan_drop_segments(p); return V2V_EINVAL; }
             p->edge_events.push_back(ev);
         }
+        const int lanes_of_step[2] = {st.kind == 0 ? st.b : st.a, st.kind == 0 ? st.b : st.b};
+        for (int k : lanes_of_step)
+            if (k != 0 && !p->lane_stream[k] && hipStreamCreateWithFlags(&p->lane_stream[k], hipStreamNonBlocking) != hipSuccess) {
+                set_error("plan: lane stream"); plan_drop_segments(p); return V2V_EINVAL;
+            }
+    }
     p->segmented = true;
     return 0;
 }
@@ -286,6 +299,21 @@ extern "C" int v2v_plan_instantiate_graph(v2v_plan* p, void* stream) {
     e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { set_error("plan: instantiate: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
+}
+
+extern "C" int v2v_plan_segment_program(const v2v_plan* p, int32_t* steps, int32_t max_steps, int32_t* seg_of_op, int32_t n_ops) {
+    if (!p || !steps || max_steps < 0) { set_error("plan: segment_program arguments"); return V2V_EINVAL; }
+    std::vector<std::vector<size_t>> segments;
+    std::vector<v2v_plan::Step> program;
+    const int rc = plan_segment_program(p, &segments, &program);
+    if (rc != 0) return rc;
+    if ((int)program.size() > max_steps || (seg_of_op && n_ops < (int)p->ops.size())) { set_error("plan: segment_program buffers too small"); return V2V_EINVAL; }
+    for (size_t i = 0; i < program.size(); ++i) { steps[3 * i] = program[i].kind; steps[3 * i + 1] = program[i].a; steps[3 * i + 2] = program[i].b; }
+    if (seg_of_op) {
+        for (size_t i = 0; i < p->ops.size(); ++i) seg_of_op[i] = -1;       // lane_wait ops belong to no segment
+        for (size_t k = 0; k < segments.size(); ++k) for (size_t m : segments[k]) seg_of_op[m] = (int32_t)k;
+    }
+    return (int)program.size();
 }
 
 extern "C" int v2v_plan_launch_graph(v2v_plan* p, void* stream) {
@@ -478,6 +506,12 @@ extern "C" int v2v_plan_timeline_graph(v2v_plan* p, void* stream, float* t0, flo
 extern "C" const char* v2v_plan_op_name(const v2v_plan* p, int32_t i) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return "";
     return p->ops[i]->name();
+}
+
+extern "C" int v2v_plan_op_lane(const v2v_plan* p, int32_t i) {
+    if (!p || i < 0 || i >= (int)p->ops.size()) return V2V_EINVAL;
+    if (const WaitOp* w = dynamic_cast<const WaitOp*>(p->ops[i].get())) return w->waiter | (w->signal << 8);     // lane_wait: waiter | signal << 8
+    return p->ops[i]->lane;
 }
 
 extern "C" int v2v_plan_set_label(v2v_plan* p, const char* label) {

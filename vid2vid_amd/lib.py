@@ -140,10 +140,12 @@ PROTOTYPES = {
     "v2v_plan_run": (C.c_int, [_P, _P]),
     "v2v_plan_instantiate_graph": (C.c_int, [_P, _P]),
     "v2v_plan_launch_graph": (C.c_int, [_P, _P]),
+    "v2v_plan_segment_program": (C.c_int, [_P, C.POINTER(_I), _I, C.POINTER(_I), _I]),
     "v2v_plan_profile": (C.c_int, [_P, _P, C.POINTER(C.c_float), _I]),
     "v2v_plan_timeline": (C.c_int, [_P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_I), _I]),
     "v2v_plan_timeline_graph": (C.c_int, [_P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_I), _I]),
     "v2v_plan_op_name": (C.c_char_p, [_P, _I]),
+    "v2v_plan_op_lane": (C.c_int, [_P, _I]),
     "v2v_plan_set_label": (C.c_int, [_P, C.c_char_p]),
     "v2v_plan_op_label": (C.c_char_p, [_P, _I]),
     "v2v_plan_set_lane": (C.c_int, [_I]),
