@@ -300,3 +300,9 @@ if has fgfork; then
   done
   lap fgfork
 fi
+if has heads2; then
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -x -k "head or merged" > gpurun_out/${TAG}_headstest.log 2>&1; echo "heads tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_headstest.log | cut -c1-300 | tail -6
+  timeout 200 python scripts/head_bench.py 2>/dev/null | tee gpurun_out/${TAG}_head_bench.txt
+  lap heads2
+fi
