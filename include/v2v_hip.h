@@ -147,7 +147,9 @@ int64_t v2v_conv_packed_elems(int32_t cin, int32_t cin_stride, int32_t cout, int
 int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t cin_stride, int32_t cout,
                               int32_t KH, int32_t KW, int32_t transposed, int32_t stride, int32_t pad,
                               int32_t dtype, int32_t korder, void* stream);
-/* korder 0 (tap-major, above) is what the implicit-GEMM tile configurations (ids 1..23) read.  korder 1 is
+/* korder + 256: the fp32 source tensor is channels-last -- [cout][KH][KW][cin] for a Conv2d weight, [cin][KH][KW][cout] for a
+ * ConvTranspose2d weight (the fused optimizer's flat buffers hold 4-D weights that way; same packed result).
+ * korder 0 (tap-major, above) is what the implicit-GEMM tile configurations (ids 1..23) read.  korder 1 is
  * k = (chunk * KH*KW + tap) * E + c_in_chunk with E = elements per 128 bytes and channel c = chunk*E + c_in_chunk
  * (channel-chunk outer, tap inner; Conv2d with cin_stride % E == 0 only; same element count): the layout of the
  * LDS-resident-patch 3x3 kernel (tile ids 32..37, csrc/conv3x3_patch_kernel.h), which fetches the input patch of
@@ -193,7 +195,10 @@ typedef struct v2v_wgrad_desc {
     int32_t p_stride, q_stride;
     int32_t KH, KW, stride, pad, pad_mode;
     int32_t dtype;
-    int32_t accumulate;      /* 1: add into grad (optimizer .grad buffer), 0: overwrite        */
+    int32_t accumulate;      /* bit 0: add into grad (optimizer .grad buffer) instead of overwriting; bit 1 (+2): grad is
+                              * CHANNELS-LAST, [rows][KH][KW][cols] (optim.FlatBuffers keeps 4-D weights that way): the
+                              * column order the kernel computes in, so no transpose pass -- and with one K split and
+                              * q_stride == cols the tiles are written straight into grad                                 */
 } v2v_wgrad_desc;
 int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d);
 int     v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream);

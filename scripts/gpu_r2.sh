@@ -306,3 +306,14 @@ if has heads2; then
   timeout 200 python scripts/head_bench.py 2>/dev/null | tee gpurun_out/${TAG}_head_bench.txt
   lap heads2
 fi
+if has cltest; then
+  timeout 900 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short --timeout 300 -x -k "conv2d_backward or conv_transpose2d_backward or norm_act_residual or fused_adam" > gpurun_out/${TAG}_cltest.log 2>&1; echo "channels-last tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_cltest.log | cut -c1-300 | tail -8
+  timeout 900 python -m pytest tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 600 -k "training or model_D" > gpurun_out/${TAG}_traingolden.log 2>&1; echo "training golden rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E " gpurun_out/${TAG}_traingolden.log | cut -c1-300 | tail -6
+  for v in 1 0; do
+    V2V_WEIGHTS_CL=$v timeout 600 python bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_train_cl$v.json 2> gpurun_out/${TAG}_train_cl$v.err; echo "train bench weights_cl=$v rc=$?"
+    cut -c1-200 gpurun_out/${TAG}_train_cl$v.json
+  done
+  lap cltest
+fi

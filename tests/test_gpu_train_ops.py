@@ -52,9 +52,14 @@ def _ref_conv(x, conv, k, stride, pad, mode):
     return F.conv2d(xp, conv.weight, conv.bias, stride=stride, padding=0 if mode == "reflect" else pad)
 
 
+@pytest.mark.parametrize("layout", ["std", "channels_last"])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CONV_BWD_CASES)
-def test_conv2d_backward(case, prec):
+def test_conv2d_backward(case, prec, layout, monkeypatch):
+    """layout channels_last: the parameters live in optim.FlatBuffers (weights and their gradients stored [cout][KH][KW][cin]):
+    the forward / backward-data packings read that layout (v2v_conv_pack_weights korder + 256) and the weight gradient is
+    written in it (accumulate + 2: straight into .grad when the input's channel stride equals cin, else by the no-transpose
+    reduce)."""
     from vid2vid_amd import lib as L
     from vid2vid_amd import autograd as AG
     cin, cout, k, stride, pad, mode, H, W, N = case
@@ -76,6 +81,11 @@ def test_conv2d_backward(case, prec):
     (yr * r).sum().backward()
     # ---- HIP ----
     conv = conv.to(DEV)
+    if layout == "channels_last":
+        from vid2vid_amd.optim import FlatBuffers
+        monkeypatch.setenv("V2V_WEIGHTS_CL", "1")
+        fb = FlatBuffers([conv.weight, conv.bias])
+        assert fb.channels_last and (k == 1 or (AG.is_channels_last(conv.weight) and AG.is_channels_last(conv.weight.grad)))
     xg = x.to(DEV).requires_grad_(True)
     xa = eng.pack(xg)
     assert xa.t.requires_grad
@@ -103,9 +113,10 @@ CONVT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("layout", ["std", "channels_last"])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CONVT_CASES)
-def test_conv_transpose2d_backward(case, prec):
+def test_conv_transpose2d_backward(case, prec, layout, monkeypatch):
     from vid2vid_amd import lib as L
     from vid2vid_amd import autograd as AG
     cin, cout, k, pad, op, H, W, N = case
@@ -125,6 +136,11 @@ def test_conv_transpose2d_backward(case, prec):
     r = rnd(torch.randn_like(yr))
     (yr * r).sum().backward()
     conv = conv.to(DEV)
+    if layout == "channels_last":                          # weight [cin][cout][k][k] stored [cin][k][k][cout] in the flat buffers
+        from vid2vid_amd.optim import FlatBuffers
+        monkeypatch.setenv("V2V_WEIGHTS_CL", "1")
+        fb = FlatBuffers([conv.weight, conv.bias])
+        assert fb.channels_last and AG.is_channels_last(conv.weight.grad)
     xg = x.to(DEV).requires_grad_(True)
     ya = AG.conv_group(eng, eng.pack(xg), conv, L.PAD_ZERO, None, None, L.ACT_RELU, 0.0, None, None, False, 1.0, "t")
     y = eng.unpack(ya)

@@ -30,9 +30,14 @@ def _grad_ptr(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
     g = p.grad
-    if g.dtype != torch.float32 or not g.is_contiguous():
-        raise RuntimeError("parameter gradients must be contiguous fp32")
+    if g.dtype != torch.float32 or not (g.is_contiguous() or is_channels_last(g)):
+        raise RuntimeError("parameter gradients must be fp32, contiguous or channels-last (optim.FlatBuffers)")
     return C.c_void_p(g.data_ptr())
+
+
+def is_channels_last(t):
+    """A 4-D tensor stored [d0][KH][KW][d1] (optim.FlatBuffers keeps conv weights and their gradients that way)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.permute(0, 2, 3, 1).is_contiguous()
 
 
 class _Cfg:
@@ -153,8 +158,8 @@ class ConvFn(torch.autograd.Function):
                 d.rows, d.cols, d.p_stride, d.q_stride = cout, cfg.cin, cs_gs, x.Cs
                 d.stride, d.pad, d.pad_mode = conv.stride[0], cfg.pad, cfg.pad_mode
             d.KH, d.KW = conv.kernel_size
-            d.dtype, d.accumulate = dt, 1
             d.grad = _grad_ptr(weight).value
+            d.dtype, d.accumulate = dt, 1 + (2 if is_channels_last(weight.grad) else 0)
             d.zero_page = eng.zero_page().data_ptr()
             nbytes = lib.v2v_conv_wgrad_workspace(C.byref(d))
             if nbytes <= 0:

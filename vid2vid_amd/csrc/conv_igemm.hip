@@ -146,6 +146,7 @@ struct PackArgs {
     long long total;
     int dtype;
     int korder, bke;     // korder 1: k = (chunk*ntaps + tap)*bke + c_in_chunk  (channel-chunk outer, tap inner)
+    int src_cl;          // the fp32 source is channels-last: [dim0][KH][KW][dim1] (optim.FlatBuffers master weights)
 };
 
 __global__ void pack_weights_kernel(const PackArgs a) {
@@ -177,8 +178,10 @@ __global__ void pack_weights_kernel(const PackArgs a) {
             if (a.transposed) { kh = a.kh0[cls] + a.kstep * th; kw = a.kw0[cls] + a.kstep * tw; }
             else              { kh = th; kw = tw; }
             long long src;
-            if (a.transposed) src = (((long long)c * a.cout + co) * a.KH + kh) * a.KW + kw;   // [cin][cout][kh][kw]
-            else              src = (((long long)co * a.cin + c) * a.KH + kh) * a.KW + kw;    // [cout][cin][kh][kw]
+            if (a.src_cl) src = a.transposed ? (((long long)c * a.KH + kh) * a.KW + kw) * a.cout + co       // [cin][kh][kw][cout]
+                                             : (((long long)co * a.KH + kh) * a.KW + kw) * a.cin + c;      // [cout][kh][kw][cin]
+            else if (a.transposed) src = (((long long)c * a.cout + co) * a.KH + kh) * a.KW + kw;   // [cin][cout][kh][kw]
+            else                   src = (((long long)co * a.cin + c) * a.KH + kh) * a.KW + kw;    // [cout][cin][kh][kw]
             v = a.w[src];
         }
         if (a.dtype == V2V_BF16) reinterpret_cast<unsigned short*>(a.dst)[e] = f32_to_bf16_bits(v);
@@ -192,16 +195,37 @@ __global__ void pack_weights_kernel(const PackArgs a) {
 // step re-packs every layer for its forward and backward-data operators.  Here a workgroup owns 8 rows x 64 channels
 // x all taps: the source runs are contiguous ([c0..c0+63][KH][KW] of a row for a Conv2d weight, [co0..co0+7][KH][KW] of
 // a channel for a ConvTranspose2d-layout read), go through LDS, and leave as 64-element contiguous runs per (row, tap).
-constexpr int PK_TCO = 8, PK_TC = 64, PK_MAXT = 16;
+constexpr int PK_MAXT = 16;
 
+// PK_TCO x PK_TC: 8 rows x 64 channels (sources whose channel / tap run is the contiguous one), or 32 x 32 for the transposed
+// read of a channels-last source, whose contiguous run is along the ROWS
+template <int PK_TCO, int PK_TC>
 __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const PackArgs a) {
-    __shared__ float sh[PK_TCO * PK_MAXT * (PK_TC + PK_MAXT)];
+    extern __shared__ float sh[];                            // [PK_TCO * KHW][PK_TC + KHW]
     const int c0 = blockIdx.x * PK_TC, co0 = blockIdx.y * PK_TCO;
     const int KHW = a.KH * a.KW;
     const int LS = PK_TC + KHW;                              // LDS row stride: bank = tap * KHW + channel, distinct over a wave's run
     const int tid = threadIdx.x;
     // ---- read: contiguous source runs (16-byte loads) -> sh[(row * KHW + full tap) * LS + channel]
-    if (!a.transposed) {
+    if (a.src_cl && !a.transposed) {
+        // channels-last master weight [co][tap][c]: per (row, tap) the tile's 64 channels are one contiguous run
+        const int nc = min(PK_TC, a.cin - c0);
+        for (int i = tid; i < PK_TCO * KHW * PK_TC; i += 256) {
+            const int cl = i % PK_TC, rf = i / PK_TC;
+            const int r = rf / KHW, f = rf - r * KHW;
+            const int co = co0 + r;
+            if (co < a.cout && cl < nc) sh[(r * KHW + f) * LS + cl] = a.w[((long long)co * KHW + f) * a.cin + c0 + cl];
+        }
+    } else if (a.src_cl) {
+        // transposed read of a channels-last weight [c][tap][co]: per (channel, tap) the tile's rows are one contiguous run
+        const int nr = min(PK_TCO, a.cout - co0);
+        for (int i = tid; i < PK_TC * KHW * PK_TCO; i += 256) {
+            const int r = i % PK_TCO, cf = i / PK_TCO;
+            const int cl = cf / KHW, f = cf - cl * KHW;
+            const int c = c0 + cl;
+            if (c < a.cin && r < nr) sh[(r * KHW + f) * LS + cl] = a.w[((long long)c * KHW + f) * a.cout + co0 + r];
+        }
+    } else if (!a.transposed) {
         const int nc = min(PK_TC, a.cin - c0);
         const int run = nc > 0 ? nc * KHW : 0;
         for (int r = 0; r < PK_TCO; ++r) {
@@ -243,8 +267,8 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const PackArgs 
         const int wrow = a.wrow[cls];
         const int n = PK_TCO * nt * (PK_TC / 8);
         for (int j = tid; j < n; j += 256) {
-            const int c8 = (j & 7) * 8;
-            const int rt = j >> 3;
+            const int c8 = (j % (PK_TC / 8)) * 8;
+            const int rt = j / (PK_TC / 8);
             const int r = rt / nt, t = rt - r * nt;
             const int co = co0 + r, c = c0 + c8;
             if (co >= a.cout_p || c >= a.cin_stride) continue;
@@ -288,8 +312,19 @@ struct PackOp : Op {
     PackArgs a;
     int launch(hipStream_t s) override {
         if (a.KH * a.KW <= PK_MAXT) {
-            const dim3 grid((unsigned)ceil_div(a.cin_stride, PK_TC), (unsigned)ceil_div(a.cout_p, PK_TCO));
-            hipLaunchKernelGGL(pack_weights_tiled_kernel, grid, dim3(256), 0, s, a);
+            const int khw = a.KH * a.KW;
+            if (a.src_cl && a.transposed) {
+                const size_t lds = (size_t)32 * khw * (32 + khw) * sizeof(float);
+                auto kern = pack_weights_tiled_kernel<32, 32>;
+                static bool attr_done = false;
+                if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_done = true; }
+                const dim3 grid((unsigned)ceil_div(a.cin_stride, 32), (unsigned)ceil_div(a.cout_p, 32));
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+            } else {
+                const size_t lds = (size_t)8 * khw * (64 + khw) * sizeof(float);
+                const dim3 grid((unsigned)ceil_div(a.cin_stride, 64), (unsigned)ceil_div(a.cout_p, 8));
+                hipLaunchKernelGGL((pack_weights_tiled_kernel<8, 64>), grid, dim3(256), lds, s, a);
+            }
             return check_launch();
         }
         const int threads = 256;
@@ -508,6 +543,8 @@ extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int
                                      int32_t KH, int32_t KW, int32_t transposed, int32_t stride, int32_t pad,
                                      int32_t dtype, int32_t korder, void* stream) {
     if (!w || !dst) { set_error("pack: null pointer"); return V2V_EINVAL; }
+    const int src_cl = (korder >> 8) & 1;                      // + 256: the source tensor is channels-last (see the header)
+    korder &= 255;
     if (korder != 0 && (korder != 1 || transposed || cin_stride % bke_of(dtype) != 0)) {
         set_error("pack: korder 1 needs a Conv2d whose channel stride is a multiple of the 128-byte chunk"); return V2V_EINVAL;
     }
@@ -517,7 +554,7 @@ extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int
     PackArgs& a = op->a;
     a.w = w; a.dst = dst; a.cin = cin; a.cin_stride = cin_stride; a.cout = cout; a.cout_p = g.cout_p;
     a.KH = KH; a.KW = KW; a.transposed = transposed; a.kstep = stride; a.ncls = g.ncls; a.total = g.total; a.dtype = dtype;
-    a.korder = korder; a.bke = bke_of(dtype);
+    a.korder = korder; a.bke = bke_of(dtype); a.src_cl = src_cl;
     for (int c = 0; c < 4; ++c) {
         a.nkh[c] = g.nkh[c]; a.nkw[c] = g.nkw[c]; a.kh0[c] = g.kh0[c]; a.kw0[c] = g.kw0[c];
         a.kpad[c] = g.kpad[c]; a.wrow[c] = g.wrow[c]; a.woff[c] = g.woff[c];

@@ -37,6 +37,9 @@ struct WgradKArgs {
     int Kpix, kper;         // total pixels, pixels per split (multiple of BK)
     int m_tiles, n_tiles;
     int Rp, Cp;             // slab rows / columns (tile multiples)
+    // channels-last gradient [rows][tap][cols] (optim.FlatBuffers): with one K split and q_stride == cols the slab layout IS the
+    // gradient layout and the tile goes straight to .grad (no slab, no transpose pass)
+    float* grad_direct; int grad_rows, grad_ld, accumulate;
 };
 
 __device__ __forceinline__ void wg_glds16(const char* g, char* lds) {
@@ -176,7 +179,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * BM + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                slab[(long long)row * p.Cp + col] = acc[i][j][r];
+                if (p.grad_direct) {
+                    if (row < p.grad_rows && col < p.grad_ld) {
+                        float* g = p.grad_direct + (long long)row * p.grad_ld + col;
+                        *g = p.accumulate ? *g + acc[i][j][r] : acc[i][j][r];
+                    }
+                } else slab[(long long)row * p.Cp + col] = acc[i][j][r];
             }
         }
 }
@@ -388,7 +396,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(const WgradKAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * BM + wm * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                slab[(long long)row * p.Cp + col] = acc[i][j][r];
+                if (p.grad_direct) {
+                    if (row < p.grad_rows && col < p.grad_ld) {
+                        float* g = p.grad_direct + (long long)row * p.grad_ld + col;
+                        *g = p.accumulate ? *g + acc[i][j][r] : acc[i][j][r];
+                    }
+                } else slab[(long long)row * p.Cp + col] = acc[i][j][r];
             }
         }
 }
@@ -438,6 +451,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs
     }
 }
 
+// channels-last gradient [rows][tap][cols]: the slab columns are (tap, c over the Q stride) already -- no transpose, one coalesced
+// pass: grad[r][tap*C + c] (+)= sum_k slab[k][r][tap*QCs + c]
+__global__ __launch_bounds__(256) void wgrad_reduce_cl_kernel(const WgradReduceArgs a) {
+    const int r = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;            // tap * C + c
+    if (e >= a.KHW * a.C) return;
+    const int tap = e / a.C, c = e - tap * a.C;
+    const float* src = a.slab + (long long)r * a.Cp + (long long)tap * a.QCs + c;
+    const long long slab_sz = (long long)a.Rp * a.Cp;
+    float s = 0.f;
+    for (int k = 0; k < a.splits; ++k) s += src[(long long)k * slab_sz];
+    float* dst = a.grad + (long long)r * a.KHW * a.C + e;
+    *dst = a.accumulate ? *dst + s : s;
+}
+
 // V2V_WGRAD_BF16=legacy: bf16 operands widened on the LDS read and multiplied on the exact-fp32 MFMA (the round-1 v1
 // kernel), kept for A/B measurements
 static bool legacy_bf16() {
@@ -466,7 +494,7 @@ static int wgrad_cfg() {
 }
 
 struct WgradOp : Op {
-    WgradKArgs k; WgradReduceArgs r; int dtype, splits, bm;
+    WgradKArgs k; WgradReduceArgs r; int dtype, splits, bm; int grad_cl = 0;
     void launch_bf16(dim3 grid, hipStream_t s) {
         if (bm == 64) { launch_wgrad_bf16<64, 128, 32, 3, 4, true>(grid, s, k); return; }
         switch (wgrad_cfg()) {
@@ -502,6 +530,7 @@ struct WgradOp : Op {
         }
         int rc = check_launch();
         if (rc != 0) return rc;
+        if (k.grad_direct) return 0;                          // the tiles went straight into the channels-last gradient
         WgradReduceArgs rr = r;
         if (r.splits > 16) {          // many K splits (few tiles, many pixels): fold them 8-fold in place, in parallel
             const long long n = (long long)r.Rp * r.Cp;
@@ -510,7 +539,8 @@ struct WgradOp : Op {
             if (rc != 0) return rc;
             rr.splits = 8;
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)r.R, (unsigned)ceil_div(r.C, 64)), dim3(256), 0, s, rr);
+        if (grad_cl) hipLaunchKernelGGL(wgrad_reduce_cl_kernel, dim3((unsigned)ceil_div((long long)r.KHW * r.C, 256), (unsigned)r.R), dim3(256), 0, s, rr);
+        else         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)r.R, (unsigned)ceil_div(r.C, 64)), dim3(256), 0, s, rr);
         return check_launch();
     }
     const char* name() const override { return "conv_wgrad"; }
@@ -521,6 +551,12 @@ static const int WG_BN = 128, WG_BK = 32;
 // row-tile height: 128 on the bf16 matrix pipe when the layer has more than 64 gradient rows, else 64
 static int wgrad_bm(const v2v_wgrad_desc* d) {
     if (!(d->dtype == V2V_BF16 && d->rows > 64 && !legacy_bf16())) return 64;
+    {   // channels-last gradient that can be written directly: 64-row tiles when they give an unsplit launch of >= 1024 workgroups
+        // where 128-row tiles would need a K split (and with it slabs and the reduce pass)
+        static const int on = [] { const char* e = getenv("V2V_WGRAD_CL64"); return (e && e[0] == '0') ? 0 : 1; }();
+        const long long t128 = ceil_div(d->rows, 128) * ceil_div((long long)d->KH * d->KW * d->q_stride, 128);
+        if (on && ((d->accumulate >> 1) & 1) && d->q_stride == d->cols && t128 < 1024 && 2 * t128 >= 1024) return 64;
+    }
     return (wgrad_cfg() == 3 || wgrad_cfg() == 5 || wgrad_cfg() == 7 || wgrad_cfg() == 9) ? 256 : 128;
 }
 
@@ -533,6 +569,9 @@ static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* 
     const long long tiles = (long long)*m_tiles * *n_tiles;
     static const int target = [] { const char* e = getenv("V2V_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     long long s = ceil_div(target, tiles);               // ~4 workgroups per CU (512 measured slower: profiles/r01 q1 vs q2)
+    // channels-last gradient with q_stride == cols: an unsplit launch writes its tiles straight into .grad (no slab, no
+    // reduce pass) -- worth more than the extra workgroups of a split once the tiles alone cover the chip twice
+    if (((d->accumulate >> 1) & 1) && d->q_stride == d->cols && tiles >= 1024) s = 1;
     const long long smax = ceil_div(kpix, 8 * WG_BK);     // at least 8 chunks per split
     if (s > smax) s = smax;
     if (s < 1) s = 1;
@@ -590,5 +629,10 @@ extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
     r.slab = k.slab; r.grad = d->grad; r.splits = sp; r.R = d->rows; r.C = d->cols; r.KHW = d->KH * d->KW;
     r.QCs = d->q_stride; r.Rp = k.Rp; r.Cp = k.Cp; r.accumulate = d->accumulate;
     op->dtype = d->dtype; op->splits = sp; op->bm = wgrad_bm(d);
+    op->grad_cl = (d->accumulate >> 1) & 1;                    // accumulate + 2: `grad` is channels-last [rows][KH][KW][cols]
+    r.accumulate = d->accumulate & 1;
+    if (op->grad_cl && sp == 1 && d->q_stride == d->cols) {    // slab layout == gradient layout: write the tiles directly
+        k.grad_direct = d->grad; k.grad_rows = d->rows; k.grad_ld = d->KH * d->KW * d->cols; k.accumulate = d->accumulate & 1;
+    }
     return submit(std::move(op), stream);
 }

@@ -147,11 +147,13 @@ class PackedConv:
         if not force and ver == self.version:
             return
         w32 = w.detach()
-        if w32.dtype != torch.float32 or not w32.is_contiguous():
+        src_cl = (w32.dtype == torch.float32 and w32.dim() == 4 and not w32.is_contiguous()
+                  and w32.permute(0, 2, 3, 1).is_contiguous())          # optim.FlatBuffers: channels-last master weights
+        if not src_cl and (w32.dtype != torch.float32 or not w32.is_contiguous()):
             w32 = w32.float().contiguous()
         check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), self.cin, self.cin_stride, self.cout,
                                         self.KH, self.KW, int(self.transposed), self.stride, self.pad, self.dtype,
-                                        self.korder, _stream()),
+                                        self.korder + (256 if src_cl else 0), _stream()),
               "conv_pack_weights")
         if self.role == "fwd":
             self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()

@@ -65,7 +65,7 @@ class BaseModel(torch.nn.Module):
             if nb and getattr(m, "num_batches_tracked", None) is not None:
                 m.num_batches_tracked.add_(nb)
                 m._v2v_batches = 0
-        state = {k: v.detach().cpu() for k, v in network.state_dict().items()}
+        state = {k: v.detach().cpu().contiguous() for k, v in network.state_dict().items()}     # (flat-buffer weights are channels-last views)
         torch.save(state, self._ckpt_path(network_label, epoch_label))
 
     def load_network(self, network, network_label, epoch_label, save_dir=""):

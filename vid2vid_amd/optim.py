@@ -14,6 +14,7 @@ torch.optim.Adam (no amsgrad); `param_groups[0]['lr']` is honoured so the refere
 update_learning_rate (models/base_model.py:154-160) keeps working.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -40,19 +41,34 @@ class FlatBuffers:
         # update counter of THIS buffer: the fused optimizer writes flat_param from a HIP kernel (invisible to torch's
         # tensor version counters), so packed weight copies (engine.PackedConv) watch this box through the parameter
         self.epoch = [0]
+        # V2V_WEIGHTS_CL=1: 4-D (convolution) weights live CHANNELS-LAST in the flat buffers: physically [d0][KH][KW][d1],
+        # logically still [d0][d1][KH][KW] (a permuted view, as torch.channels_last tensors are).  That is the column order the
+        # weight-gradient kernel computes in -- an unsplit launch writes its tiles straight into .grad and a split one needs no
+        # transpose in its reduce pass -- and the order the forward re-pack reads in contiguous runs.  Measured on the 512x256
+        # training chunk it is a wash (+0.9 %: the unsplit weight-gradient launch and the transposed re-pack of the backward-data
+        # operator give back what the transpose-free reduce saves; profiles/r02_a64_weights_cl_ab.txt), so it is OFF by default;
+        # both layouts are covered by tests/test_gpu_train_ops.py.
+        self.channels_last = os.environ.get("V2V_WEIGHTS_CL", "0") == "1"
         with torch.no_grad():
             for p, o in zip(self.params, offs):
-                view = self.flat_param[o:o + p.numel()].view(p.shape)
+                view = self._view(self.flat_param, p, o)
                 view.copy_(p.data)
                 p.data = view
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+                p.grad = self._view(self.flat_grad, p, o)
                 p._v2v_epoch = self.epoch
+
+    def _view(self, flat, p, o):
+        seg = flat[o:o + p.numel()]
+        if self.channels_last and p.dim() == 4:
+            d0, d1, kh, kw = p.shape
+            return seg.view(d0, kh, kw, d1).permute(0, 3, 1, 2)
+        return seg.view(p.shape)
 
     def rebind_grads(self):
         """Re-attach `.grad` views (e.g. after a foreign zero_grad(set_to_none=True))."""
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+                p.grad = self._view(self.flat_grad, p, o)
 
 
 class FusedAdam(torch.optim.Optimizer):
