@@ -317,3 +317,8 @@ if has cltest; then
   done
   lap cltest
 fi
+if has benchdef1; then
+  timeout 400 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench (defaults) rc=$?"
+  cut -c1-600 gpurun_out/${TAG}_bench_default.json; tail -3 gpurun_out/${TAG}_bench_default.err
+  lap benchdef1
+fi
