@@ -603,9 +603,9 @@ class LocalEnhancer(nn.Module):
 
 # --------------------------------------------------------------------------------------
 # first-frame generators with instance-wise feature encoding (models/networks.py:421-632)
-# Parameter containers + lowering are composed from the validated primitives (concat, avgpool, conv groups); the lowering
-# has NOT been run on a GPU yet (round 1 ran out of GPU time): tests/test_gpu_golden.py gates its parity test behind
-# V2V_RUN_UNVALIDATED=1.  The oracle side is pinned (tests/golden/face_first_frame_nets_32x32.npz).
+# Parameter containers + lowering are composed from the validated primitives (concat, avgpool, conv groups); parity on the
+# GPU: tests/test_gpu_golden.py::test_feature_encoding_first_frame_nets_vs_reference against the reference's own classes
+# (tests/golden/face_first_frame_nets_32x32.npz).
 # --------------------------------------------------------------------------------------
 class Global_with_z(nn.Module):
     """models/networks.py:421-467: GlobalGenerator whose stem, residual trunk, up-sampling trunk and head each see the
