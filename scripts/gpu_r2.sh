@@ -322,3 +322,30 @@ if has benchdef1; then
   cut -c1-600 gpurun_out/${TAG}_bench_default.json; tail -3 gpurun_out/${TAG}_bench_default.err
   lap benchdef1
 fi
+if has s2abl; then
+  timeout 200 python scripts/s2_ablate.py > gpurun_out/${TAG}_s2_ablate.txt 2> gpurun_out/${TAG}_s2_ablate.err; echo "s2 ablate rc=$?"
+  cat gpurun_out/${TAG}_s2_ablate.txt; tail -3 gpurun_out/${TAG}_s2_ablate.err
+  lap s2abl
+fi
+if has s2trace; then
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_s2_$TAG -o s2 -- python $R/scripts/s2_ablate.py > $R/gpurun_out/${TAG}_s2_ablate_host.txt 2> $R/gpurun_out/${TAG}_s2_trace.err; echo "rocprof rc=$?"
+  python $R/scripts/s2_ablate_trace.py $(find /tmp/prof_s2_$TAG -name "*.db" | head -1) > $R/gpurun_out/${TAG}_s2_ablate_trace.txt 2>> $R/gpurun_out/${TAG}_s2_trace.err
+  cat $R/gpurun_out/${TAG}_s2_ablate_trace.txt; tail -3 $R/gpurun_out/${TAG}_s2_trace.err
+  cd $R
+  lap s2trace
+fi
+if has s2fin; then
+  for v in "1 1" "0 1" "0 0"; do set -- $v
+    FIN=$1 STATS=$2 timeout 100 python scripts/s2_ablate.py 2>/dev/null | grep -v cold | cut -c1-150
+  done > gpurun_out/${TAG}_s2_fin_ab.txt; cat gpurun_out/${TAG}_s2_fin_ab.txt
+  lap s2fin
+fi
+if has fintest; then
+  timeout 400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 300 \
+      -k "finalize or onehot or fused_norm or batchnorm or running_stats or conv_transpose or inference_api or composite_generator or graph_replay" > gpurun_out/${TAG}_fintest.log 2>&1; echo "fin tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_fintest.log | cut -c1-300 | tail -20
+  lap fintest
+  FIN=1 STATS=1 timeout 100 python scripts/s2_ablate.py 2>/dev/null | grep -v cold | cut -c1-150 > gpurun_out/${TAG}_s2_fin_after.txt; cat gpurun_out/${TAG}_s2_fin_after.txt
+  lap s2after
+fi

@@ -519,15 +519,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                 const int c = tid % BN, ph = tid / BN;
                 const int ncol = nt * BN + c;
                 double s1 = 0.0, s2 = 0.0;
-                if (ncol < p.cout && ph < PH) {
-                    for (int r = ph; r < total; r += PH) {
-                        const unsigned long long bits = __hip_atomic_load(
-                            reinterpret_cast<const unsigned long long*>(p.stats + ((long long)r * p.cout + ncol) * 2),
-                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
-                        s2 += (double)__uint_as_float((unsigned)(bits >> 32));
-                    }
-                }
+                if (ncol < p.cout && ph < PH) sum_stat_rows<16>(p.stats, (long long)ncol * 2, (long long)p.cout * 2, ph, PH, total, s1, s2);
                 if (ph < PH) {
                     acc2[(ph * BN + c) * 2 + 0] = s1;
                     acc2[(ph * BN + c) * 2 + 1] = s2;

@@ -342,14 +342,7 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
         const int c = tid % CS, ph = tid / CS;
         const int ncol = c0 + c;
         double s1 = 0.0, s2 = 0.0;
-        if (ncol < a.cout) {
-            for (int r = ph; r < (int)gridDim.x; r += PH) {
-                const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.stats + ((long long)r * a.cout + ncol) * 2),
-                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
-                s2 += (double)__uint_as_float((unsigned)(bits >> 32));
-            }
-        }
+        if (ncol < a.cout) sum_stat_rows<16>(a.stats, (long long)ncol * 2, (long long)a.cout * 2, ph, PH, (int)gridDim.x, s1, s2);
         acc2[(ph * CS + c) * 2 + 0] = s1;
         acc2[(ph * CS + c) * 2 + 1] = s2;
         __syncthreads();

@@ -56,6 +56,35 @@ __device__ __forceinline__ float apply_act(float v, int act, float param) {
     }
 }
 
+// In-kernel norm finalize, shared by the conv and gather-sum stem kernels: thread (channel, phase ph of PH) adds the (sum, sum^2)
+// rows ph, ph + PH, ph + 2 PH, ... (< total) of its channel IN THAT ORDER, in double.  The rows were published by other workgroups
+// with 8-byte agent-scope (write-through) stores and are read with agent-scope loads, U of them in flight at a time: one load per
+// loop trip (the first version) serialised 32-64 memory round trips in the last workgroup of a 128-512 row layer -- 3-19 us of
+// tail per launch (profiles/r02_a68_s2_fin_ab.txt).  The summation order, hence every bit of the result, is unchanged.
+template <int U>
+__device__ __forceinline__ void sum_stat_rows(const float* stats, long long col2, long long row_stride, int ph, int PH, int total,
+                                              double& s1, double& s2) {
+    const unsigned long long* const base = reinterpret_cast<const unsigned long long*>(stats + col2);   // 8-byte granules
+    const long long rs = row_stride / 2;
+    int r = ph;
+    for (; r + (U - 1) * PH < total; r += U * PH) {
+        unsigned long long b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            b[u] = __hip_atomic_load(base + (long long)(r + u * PH) * rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s1 += (double)__uint_as_float((unsigned)(b[u] & 0xffffffffull));
+            s2 += (double)__uint_as_float((unsigned)(b[u] >> 32));
+        }
+    }
+    for (; r < total; r += PH) {
+        const unsigned long long b = __hip_atomic_load(base + (long long)r * rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s1 += (double)__uint_as_float((unsigned)(b & 0xffffffffull));
+        s2 += (double)__uint_as_float((unsigned)(b >> 32));
+    }
+}
+
 // ---- host side: op recording ---------------------------------------------------------
 struct Op {
     virtual ~Op() {}
