@@ -99,7 +99,7 @@ typedef struct v2v_conv_desc {
     void*   slabs;          /* splitk > 1: v2v_conv_splitk_workspace() bytes of scratch              */
     int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
     int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major */
-    int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA) */
+    int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA), 512 = return at once (launch floor), 1024 = no main loop (prologue + epilogue) */
     const void* res0;       /* V2V_OUT_NORM_ACT_NHWC: NULL or a residual [N][OH][OW][cout_stride] (activation dtype) added after the activation */
     const void* res1;       /* second residual, NULL or as res0                                                   */
     int32_t act_split;      /* 0, or first output channel of a SECOND head merged into this launch (see "merged heads")  */

@@ -349,3 +349,27 @@ if has fintest; then
   FIN=1 STATS=1 timeout 100 python scripts/s2_ablate.py 2>/dev/null | grep -v cold | cut -c1-150 > gpurun_out/${TAG}_s2_fin_after.txt; cat gpurun_out/${TAG}_s2_fin_after.txt
   lap s2after
 fi
+if has fixedcost; then
+  timeout 150 python scripts/fixed_cost.py > gpurun_out/${TAG}_fixed_cost.txt 2> gpurun_out/${TAG}_fixed_cost.err; echo "fixed cost rc=$?"
+  cat gpurun_out/${TAG}_fixed_cost.txt; tail -3 gpurun_out/${TAG}_fixed_cost.err
+  lap fixedcost
+fi
+if has fixedtrace; then
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_fc_$TAG -o fc -- python $R/scripts/fixed_cost.py > $R/gpurun_out/${TAG}_fixed_cost_host.txt 2> $R/gpurun_out/${TAG}_fc_trace.err; echo "rocprof rc=$?"
+  python $R/scripts/fixed_cost_trace.py $(find /tmp/prof_fc_$TAG -name "*.db" | head -1) > $R/gpurun_out/${TAG}_fixed_cost_trace.txt 2>> $R/gpurun_out/${TAG}_fc_trace.err
+  cat $R/gpurun_out/${TAG}_fixed_cost_trace.txt
+  cd $R
+  lap fixedtrace
+fi
+if has fixedtrace3; then
+  cd /tmp
+  for v in "0 0" "0 1"; do set -- $v
+    FIN=$1 STATS=$2 timeout 100 rocprofv3 --kernel-trace -d /tmp/prof_fc_${TAG}_$1$2 -o fc -- python $R/scripts/fixed_cost.py > /dev/null 2>> $R/gpurun_out/${TAG}_fc_trace.err
+    echo "FIN=$1 STATS=$2" >> $R/gpurun_out/${TAG}_fixed_cost_trace3.txt
+    python $R/scripts/fixed_cost_trace.py $(find /tmp/prof_fc_${TAG}_$1$2 -name "*.db" | head -1) | grep -v "^#" >> $R/gpurun_out/${TAG}_fixed_cost_trace3.txt 2>> $R/gpurun_out/${TAG}_fc_trace.err
+  done
+  cat $R/gpurun_out/${TAG}_fixed_cost_trace3.txt
+  cd $R
+  lap fixedtrace3
+fi

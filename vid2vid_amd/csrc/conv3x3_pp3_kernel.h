@@ -42,7 +42,7 @@ constexpr int pending_at(int tap, int GP, int LB, int D) {
 }  // namespace pp3
 
 // ABL = 1: ablation instance (scripts/pp2_ablate.py): 1 / 2 hot operands, 4 no stores, 32 no fragment ds_reads,
-// 64 no MFMAs, 128 no LDS-DMA in the main loop, 256 no vmcnt wait in the main loop.  Results are wrong when set.
+// 64 no MFMAs, 128 no LDS-DMA in the main loop, 256 no vmcnt wait in the main loop, 512 return at once, 1024 no main loop.  Results are wrong when set.
 // WGM x WGN waves: 4 x 2 (512 threads, wave tile BM/4 x BN/2) or 2 x 2 (256 threads, one wave per SIMD, wave tile BM/2 x BN/2).
 // The 4-wave form with 128 px x 128 channels has 64 x 64 wave tiles: 16 MFMAs per 16 fragment reads instead of 8 per 12 --
 // 64 KB of LDS reads per step and CU instead of 96 KB, below the ~200 B/clk the LDS delivers beside the 512 MFMA cycles.
@@ -50,6 +50,7 @@ template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, 
 __global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
     const ConvKArgs p = select_group(p_in);
     const int ab = ABL ? p.ablate : 0;
+    if (ab & 512) return;                                     // ablation: the launch itself
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PR = (TH + 2) * PW;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const Con
         iteration(std::integral_constant<int, 8>{}, std::integral_constant<int, P0>{});
     };
     // 9 taps per chunk: the register-set parity flips from chunk to chunk
-    int c = 0;
+    int c = (ab & 1024) ? ncc : 0;                            // ablation 1024: prologue + epilogue only
     for (; c + 1 < ncc; c += 2) {
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});

@@ -567,6 +567,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
     typedef typename Mma<T>::Frag Frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.ablate & 512) return;               // ablation: the launch itself (dispatch of the grid with this LDS / wave footprint)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -590,7 +591,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
     const int kpad = p.kpad[cls];
     const int nk_all = kpad / BKE;
     const int kb = (int)(((long long)nk_all * slice) / S);            // this slice's first K chunk
-    const int nk = (int)(((long long)nk_all * (slice + 1)) / S) - kb; // and its chunk count
+    const int nk = (p.ablate & 1024) ? 0 : (int)(((long long)nk_all * (slice + 1)) / S) - kb; // and its chunk count (ablation 1024: no main loop)
     const int H = p.H, W = p.W, cs = p.cin_stride;
     const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
     const char* const zp = p.zero_page;
