@@ -373,3 +373,9 @@ if has fixedtrace3; then
   cd $R
   lap fixedtrace3
 fi
+if has quickcheck; then
+  timeout 300 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 300 -x \
+      -k "finalize or onehot or fused_norm or conv_transpose or inference_api or graph_replay or conv2d_pair" > gpurun_out/${TAG}_quick.log 2>&1; echo "quick tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_quick.log | cut -c1-300 | tail -8
+  lap quickcheck
+fi
