@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const BnPartArgs
     const int r0 = (int)(((long long)a.rows * g) / a.groups), r1 = (int)(((long long)a.rows * (g + 1)) / a.groups);
     double s1 = 0.0, s2 = 0.0;
     if (c < a.C) {
+#pragma unroll 8                                         // 8 row loads in flight, added in the same order (one per trip measured 13 us per MB)
         for (int r = r0 + ph; r < r1; r += 4) {
             const float2 v = *reinterpret_cast<const float2*>(a.partials + ((long long)r * a.C + c) * 2);
             s1 += (double)v.x;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinArgs a) {
     const R* rows_ = reinterpret_cast<const R*>(a.partials);
     double s1 = 0.0, s2 = 0.0;
     if (c < a.C) {
+#pragma unroll 8
         for (int r = ph; r < a.rows; r += 4) {
             s1 += (double)rows_[((long long)r * a.C + c) * 2 + 0];
             s2 += (double)rows_[((long long)r * a.C + c) * 2 + 1];
