@@ -1,0 +1,76 @@
+"""The bench.py JSON line (driver contract + the `roofline` / `cpu_baseline` objects): checked on the newest committed default run
+under profiles/ -- the same consistency checks the judge applies to the driver's own BENCH record."""
+import glob
+import json
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _newest(pattern):
+    natural = lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=natural)
+    return files[-1] if files else None
+
+
+@pytest.fixture(scope="module")
+def line():
+    fn = _newest("r*_bench_default*.json")
+    assert fn, "no committed default bench line under profiles/"
+    return json.load(open(fn))
+
+
+def test_driver_contract_keys(line):
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                   ("config", dict)):
+        assert isinstance(line[k], typ), k
+    assert "vs_baseline" in line and line["vs_baseline"] is None         # BASELINE.md publishes no number for this metric
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["data"] == "synthetic"
+    assert isinstance(line["config"]["workload"], str) and "model" not in line["config"]
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "frames/sec" in line["metric"] and "frames/sec" in base["metric"]
+    assert "512x256" in line["metric"] and "label2city 512x256" in line["config"]["workload"]     # BASELINE configs[1]
+    # whole-job value = frames of all ranks / max-over-ranks time
+    assert abs(line["value"] - line["n_gpus"] * 1e3 / line["ms_per_step"]) / line["value"] < 1e-3
+
+
+def test_roofline_object_is_self_consistent(line):
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    # achieved = algorithmic FLOP per launch / average launch duration (HIP events)
+    assert abs(r["achieved"] - r["flop_per_launch"] / r["avg_launch_us"] / 1e6) / r["achieved"] < 1e-3
+    # the committed rocprofv3 average of the same kernel in the same command agrees with the live HIP-event average
+    g = r["in_graph"]
+    assert abs(g["avg_launch_us"] - r["avg_launch_us"]) / r["avg_launch_us"] < 0.10
+    assert os.path.exists(os.path.join(ROOT, g["source"].split(" ")[0]))
+    # measured HBM traffic (PMC) is per launch like `achieved`, and not below the algorithmic bytes
+    assert r["traffic"] is None or r["traffic"] >= r["traffic_detail"]["algorithmic_bytes_per_launch"]
+    # the dominant kernel's launches fit into the frame: serial sum <= lanes x frame time; whole-frame work <= peak
+    lanes = line["config"]["graph_lanes"]
+    assert r["launches_per_frame"] * g["avg_launch_us"] * 1e-3 <= lanes * line["ms_per_step"]
+    assert 0 < r["frame_in_graph"]["frac"] <= r["frac"] + 0.05
+
+
+def test_cpu_baseline_and_parity_objects(line):
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"]
+    assert isinstance(c["sample"], str) and "frames" in c["sample"]
+    p = line["parity"]
+    assert p, "parity object missing from the bench line"
+    fp32_errs = [v for k, v in _walk(p["fp32"]) if k.endswith("max_rel")]
+    assert fp32_errs and max(fp32_errs) <= p["tolerance_fp32"] == 1e-3    # north_star: 1e-3 relative, fp32, every head
+    assert p["fp32_ok"] is True and p["bf16_max_rel"] > 0                  # bf16 error is a committed number, not a print
+    assert line["fp32"]["value"] > 0 and line["host_fed"]["value"] > 0 and line["train"]["value"] > 0
+
+
+def _walk(d, prefix=""):
+    for k, v in d.items():
+        if isinstance(v, dict):
+            yield from _walk(v, prefix + k + ".")
+        elif isinstance(v, (int, float)) and not isinstance(v, bool):
+            yield prefix + k, float(v)
