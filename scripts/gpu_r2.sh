@@ -379,3 +379,9 @@ if has quickcheck; then
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_quick.log | cut -c1-300 | tail -8
   lap quickcheck
 fi
+if has pixcheck; then
+  timeout 60 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x --tb=short -p no:cacheprovider \
+      -k "conv_transpose2d or convtranspose_splitk or (conv2d_all_output_modes and bf16)" > gpurun_out/${TAG}_pixcheck.log 2>&1; echo "pix tests rc=$?"
+  tail -3 gpurun_out/${TAG}_pixcheck.log | cut -c1-200
+  lap pixcheck
+fi

@@ -803,17 +803,23 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
     }
     __syncthreads();                      // LDS ring is free: reused for the statistics reduction
 
+    // row -> output pixel.  The uniform operands are pinned in SGPRs: left to itself the compiler re-fetches them from the kernel
+    // argument segment for EVERY row of the unrolled epilogue (s_load + s_waitcnt lgkmcnt(0), 1-4 per row, 133 in a 128 x 128 tile)
+    // and rebuilds the division reciprocals each time -- 7-13 us of every launch with neither main loop nor stores
+    // (profiles/r02_a72_fixed_cost_trace_nofin.txt)
+    int e_os = p.os, e_mcls = p.Mc[cls], e_owc = p.OWc[cls], e_hwc = p.OHc[cls] * p.OWc[cls], e_oh = p.OH, e_ow = p.OW;
+    int e_m0 = mt * BM;
+    asm volatile("" : "+s"(e_os), "+s"(e_mcls), "+s"(e_owc), "+s"(e_hwc), "+s"(e_oh), "+s"(e_ow), "+s"(e_m0));
     conv_epilogue<T, BM, BN, WGM, WGN>(p, acc, smem, tid, wm, wn, helper, cls, tiles, lin, slice, S, nt, cls * p.m_tiles + mt,
         [&](int row) -> int {                  // N*OH*OW < 2^31 (host check)
-            const int m = mt * BM + row;
-            if (m >= p.Mc[cls]) return -1;
-            if (p.os == 1) return m;
-            const int owc_e = p.OWc[cls], hwc = p.OHc[cls] * owc_e;
-            const int n = m / hwc;
-            const int rem = m - n * hwc;
-            const int oi = rem / owc_e;
-            const int oj = rem - oi * owc_e;
-            return (n * p.OH + (oi * 2 + (cls >> 1))) * p.OW + (oj * 2 + (cls & 1));
+            const int m = e_m0 + row;
+            if (m >= e_mcls) return -1;
+            if (e_os == 1) return m;
+            const int n = m / e_hwc;
+            const int rem = m - n * e_hwc;
+            const int oi = rem / e_owc;
+            const int oj = rem - oi * e_owc;
+            return (n * e_oh + (oi * 2 + (cls >> 1))) * e_ow + (oj * 2 + (cls & 1));
         });
 }
 
