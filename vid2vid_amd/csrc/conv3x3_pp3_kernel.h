@@ -46,15 +46,23 @@ constexpr int pending_at(int tap, int GP, int LB, int D) {
 // WGM x WGN waves: 4 x 2 (512 threads, wave tile BM/4 x BN/2) or 2 x 2 (256 threads, one wave per SIMD, wave tile BM/2 x BN/2).
 // The 4-wave form with 128 px x 128 channels has 64 x 64 wave tiles: 16 MFMAs per 16 fragment reads instead of 8 per 12 --
 // 64 KB of LDS reads per step and CU instead of 96 KB, below the ~200 B/clk the LDS delivers beside the 512 MFMA cycles.
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2>
-__global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
+// KS_ = 2 ("K pairs"): the 8 waves are WGM x WGN wave tiles x 2 K halves -- wave (tile, half h) multiplies K sub-steps 2h, 2h+1 of every
+// step on a wave tile twice as wide (4 x 1 wave tiles of 64 x 64 in the 256 px x 64 workgroup tile instead of 4 x 2 of 64 x 32): 8 MFMAs
+// per step as before, but 8 fragment reads instead of 12 (the B fragments of a 64-wide wave tile are shared by its two row tiles), i.e.
+// 64 KB of LDS reads per step and CU instead of 96 KB -- the main loop of the 4 x 2 form is co-limited by the LDS read rate
+// (12 ds_read_b128 x 8 waves = 96 KB per step against 512 MFMA cycles; profiles/r02_a5_pp3_ablate.txt: removing the reads saves as much
+// as removing the MFMAs).  After the loop the two halves of a pair exchange one half of their accumulators through LDS (64 KB, once per
+// launch): each wave ends up with the complete sums of a 64 x 32 tile, exactly the 4 x 2 layout the shared epilogue expects.
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1>
+__global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
     const ConvKArgs p = select_group(p_in);
     const int ab = ABL ? p.ablate : 0;
     if (ab & 512) return;                                     // ablation: the launch itself
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PR = (TH + 2) * PW;
-    constexpr int WGM = WGM_, WGN = WGN_, NW = WGM * WGN;
+    constexpr int WGM = WGM_, WGN = WGN_, KS = KS_, NW = WGM * WGN * KS;
+    constexpr int SS = 4 / KS;                                // K sub-steps (16 elements each) of a step that one wave multiplies
     constexpr int NG = (PR + 7) / 8;
     constexpr int GP = (NG + NW - 1) / NW;                    // patch pieces per wave per chunk
     constexpr int PATCH = GP * NW * 1024;
@@ -65,8 +73,9 @@ __global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const Con
     constexpr int PPT = (GP + NPT - 1) / NPT;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int NMMA = 4 * TM * TN;                         // MFMAs of one step
-    constexpr int NRD = 4 * (TM + TN);                        // fragment reads of one step
+    constexpr int NMMA = SS * TM * TN;                        // MFMAs of one step (per wave)
+    constexpr int NRD = SS * (TM + TN);                       // fragment reads of one step (per wave)
+    static_assert(KS == 1 || (KS == 2 && TN == 2 && WGN == 1), "K pairs: 64-wide wave tiles that split into the two 32-wide epilogue tiles");
     static_assert(TW % 32 == 0 && (TW & (TW - 1)) == 0, "a 32-row fragment must lie inside one tile row");
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile");
     static_assert(BN % (8 * NW) == 0 && LB >= 1, "weight loader rounds");
@@ -81,7 +90,8 @@ __global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const Con
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WGN, wn = wid % WGN;
+    const int wk = wid % KS;                                  // K half of this wave (0 when KS == 1)
+    const int wm = (wid / KS) / WGN, wn = (wid / KS) % WGN;
     const int cls = 0;
 
     const int tiles = p.m_tiles * p.n_tiles;
@@ -154,9 +164,9 @@ __global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const Con
         const int m0 = wm * WM + i * 32;
         qb[i] = (m0 / TW) * PW + (m0 % TW) + lr;
     }
-    int foff[4];
+    int foff[SS];                                             // B fragments: 16-byte slot of sub-step wk * SS + s, swizzled by the weight row
 #pragma unroll
-    for (int s = 0; s < 4; ++s) foff[s] = ((s * 2 + hi) ^ ((lr >> 1) & 7)) << 4;
+    for (int s = 0; s < SS; ++s) foff[s] = (((wk * SS + s) * 2 + hi) ^ ((lr >> 1) & 7)) << 4;
     const int b_row_off = (wn * WN + lr) * 128;
 
     f32x16 acc[TM][TN];
@@ -166,18 +176,18 @@ __global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const Con
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    Frag fa[2][4][TM], fb[2][4][TN];                         // two register sets: multiply one, fill the other
+    Frag fa[2][SS][TM], fb[2][SS][TN];                       // two register sets: multiply one, fill the other
 
     // fragment read q of a step (0 .. NRD-1: the A reads i-major, then the B reads) into set `PARN`
     // aaddr[i]: byte address of patch row (qb[i] + tap offset) with its swizzle term ax[i]; pb: weight stage + row
     auto read_frag = [&](auto qc, auto parc, const char* (&arow)[TM], int (&ax)[TM], const char* pb) {
         constexpr int q = decltype(qc)::value;
         constexpr int PARN = decltype(parc)::value;
-        if constexpr (q < 4 * TM) {
-            constexpr int i = q / 4, s = q % 4;
-            fa[PARN][s][i] = *reinterpret_cast<const Frag*>(arow[i] + (((s * 2 + hi) ^ ax[i]) << 4));
+        if constexpr (q < SS * TM) {
+            constexpr int i = q / SS, s = q % SS;
+            fa[PARN][s][i] = *reinterpret_cast<const Frag*>(arow[i] + ((((wk * SS + s) * 2 + hi) ^ ax[i]) << 4));
         } else {
-            constexpr int s = (q - 4 * TM) / TN, j = (q - 4 * TM) % TN;
+            constexpr int s = (q - SS * TM) / TN, j = (q - SS * TM) % TN;
             fb[PARN][s][j] = *reinterpret_cast<const Frag*>(pb + j * 32 * 128 + foff[s]);
         }
     };
@@ -300,20 +310,47 @@ __global__ __launch_bounds__(WGM_ * WGN_ * 64) void conv3x3_pp3_kernel(const Con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail duplicates must land before the LDS is reused
     __syncthreads();
 
-    conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt,
-        [&](int row) -> int {                  // TW is a power of two; N*OH*OW < 2^31 (host check)
-            const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
-            if (oh >= H || ow >= W) return -1;
-            return (n_img * H + oh) * W + ow;
-        });
+    auto pix_of = [&](int row) -> int {        // TW is a power of two; N*OH*OW < 2^31 (host check)
+        const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
+        if (oh >= H || ow >= W) return -1;
+        return (n_img * H + oh) * W + ow;
+    };
+    if constexpr (KS == 1) {
+        conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of);
+    } else {
+        // K pairs: wave (tile, half h) keeps column tile j = h of its 64-wide wave tile and hands column tile 1 - h to its partner
+        // (wave id ^ 1), which holds the other half of the K sum for it.  Same lane <-> element map on both sides (same MFMA
+        // layout), so the exchange is lane-linear: [wave][i][reg][lane] floats, conflict-free 4-byte accesses.
+        static_assert(2 * PATCH >= NW * TM * 16 * 64 * 4, "K pairs: the accumulator exchange lives in the patch buffers");
+        float* const xch = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float give = wk == 0 ? acc[i][1][r] : acc[i][0][r];
+                xch[((wid * TM + i) * 16 + r) * 64 + lane] = give;
+            }
+        __syncthreads();
+        f32x16 acc2[TM][1];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float own = wk == 0 ? acc[i][0][r] : acc[i][1][r];
+                acc2[i][0][r] = own + xch[(((wid ^ 1) * TM + i) * 16 + r) * 64 + lane];
+            }
+        __syncthreads();                                      // the exchange area becomes the epilogue's scratch
+        // 4 x 2 layout of 64 x 32 tiles: this wave's tile is (wm, 2 * wn + wk)
+        conv_epilogue<T, BM, BN, WGM, 2 * WGN, ABL == 0>(p, acc2, smem, tid, wm, 2 * wn + wk, false, cls, tiles, lin, slice, S, nt, mt, pix_of);
+    }
 }
 
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2>
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2, int KS = 1>
 static int launch_pp3_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
-    constexpr int NW = WGM * WGN;
+    constexpr int NW = WGM * WGN * KS;
     constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW;
     const size_t lds = (size_t)2 * GP * NW * 1024 + (size_t)D * BN * 128;
-    auto kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN>;
+    auto kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN, KS>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -324,11 +361,12 @@ static int launch_pp3_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
     return check_launch();
 }
 
-// single-phase tile configurations (ids 80..89)
+// single-phase tile configurations (ids 80..91)
 static const PatchCfg kPp3Cfgs[] = {
     {80, 8, 32, 64}, {81, 8, 32, 128}, {82, 8, 32, 64}, {83, 4, 64, 64}, {84, 4, 32, 128}, {85, 4, 64, 128},
     {86, 4, 32, 128}, {87, 2, 64, 128},     // 4 waves (2 x 2), 64 x 64 wave tiles
     {88, 8, 32, 128}, {89, 8, 32, 64},     // ablation instances of 81 / 80
+    {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
 };
 static inline const PatchCfg* find_pp3_cfg(int id) {
     for (const PatchCfg& c : kPp3Cfgs)
@@ -347,6 +385,8 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 85: return launch_pp3_cfg<T, 4, 64, 128, 3>(k, groups, s);   // 256 px x 128 for 64-wide tiles, 3 slices, 160 KiB
         case 86: return launch_pp3_cfg<T, 4, 32, 128, 4, 0, 2, 2>(k, groups, s);   // 128 px x 128, FOUR waves, wave tile 64x64, 120 KiB
         case 87: return launch_pp3_cfg<T, 2, 64, 128, 4, 0, 2, 2>(k, groups, s);   // same for 64-wide tile rows
+        case 90: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 4, 1, 2>(k, groups, s);   // as 82 (256 px x 64, 5 slices), K pairs: 8 reads per 8 MFMAs
+        case 91: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 4, 1, 2>(k, groups, s);   // as 83 for 64-wide tile rows
         case 88: return launch_pp3_cfg<T, 8, 32, 128, 4, 1>(k, groups, s);
         case 89: return launch_pp3_cfg<T, 8, 32, 64, 4, 1>(k, groups, s);
     }
