@@ -161,6 +161,8 @@ int     v2v_conv_stats_rows(const v2v_conv_desc* d);
 int64_t v2v_conv_splitk_workspace(const v2v_conv_desc* d, int32_t* tickets);
 /* Largest m_tiles * n_tiles (* 2 for a pair) a V2V_OUT_NORM_ACT_NHWC launch may have on this device (= its CU count). */
 int     v2v_conv_fused_norm_max_workgroups(void);
+/* Constants of the exact division q = (umulhi(M, n) + n) >> l of 0 <= n < 2^31 by 1 <= d < 2^31 (conv epilogue: row -> pixel map of the transposed layers; no reference counterpart, host-side helper exported for its test). */
+int     v2v_fastdiv_magic(uint32_t d, uint32_t* m_out, int32_t* l_out);
 /* Tile configuration id the launch would use (after auto selection). */
 int     v2v_conv_tile_config(const v2v_conv_desc* d);
 /* Launch.  nn.Conv2d / nn.ConvTranspose2d forward (models/networks.py:132-183 etc.), and -- with the

@@ -164,3 +164,26 @@ def test_label_colormaps_match_reference(golden):
     g = golden("visual_util")
     for n in (35, 20, 12):
         assert np.array_equal(visual.labelcolormap(n), g["lab%d.cmap" % n]), n
+
+
+def test_fastdiv_magic_divides_exactly():
+    """Conv epilogue row -> pixel map: q = (umulhi(M, n) + n) >> l with the library's (M, l) equals n // d for every 0 <= n < 2^31."""
+    import ctypes as C
+    import random
+    from vid2vid_amd import lib as L
+    rnd = random.Random(7)
+    ds = list(range(1, 600)) + [1 << k for k in range(31)] + [(1 << k) - 1 for k in range(2, 32)] + [(1 << k) + 1 for k in range(1, 31)] \
+        + [rnd.randrange(1, 1 << 31) for _ in range(500)] + [32 * 64, 64 * 128, 128 * 256, 256 * 512, 511 * 1023, 2048 * 1024 // 4]
+    for d in ds:
+        if not 1 <= d < (1 << 31):
+            continue
+        m, l = C.c_uint32(0), C.c_int32(0)
+        assert L.lib.v2v_fastdiv_magic(d, C.byref(m), C.byref(l)) == 0
+        M, sh = m.value, l.value
+        for n in [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, (1 << 31) - 2] + [rnd.randrange(0, 1 << 31) for _ in range(40)]:
+            if 0 <= n < (1 << 31):
+                t = (M * n) >> 32
+                assert t + n < (1 << 32)
+                assert (t + n) >> sh == n // d, (n, d, M, sh)
+    m, l = C.c_uint32(0), C.c_int32(0)
+    assert L.lib.v2v_fastdiv_magic(0, C.byref(m), C.byref(l)) != 0

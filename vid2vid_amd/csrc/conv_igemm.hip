@@ -429,6 +429,11 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.sm = d->stride; k.os = 1; k.dstep = 1;
         k.OHc[0] = d->OH; k.OWc[0] = d->OW; k.Mc[0] = d->N * d->OH * d->OW;
     }
+    for (int c = 0; c < 4; ++c) {                              // reciprocals of the class grid sizes (epilogue row -> pixel map)
+        uint32_t m; int32_t l;
+        v2v_fastdiv_magic((uint32_t)(k.OHc[c] * k.OWc[c] > 0 ? k.OHc[c] * k.OWc[c] : 1), &m, &l); k.div_m[c][0] = m; k.div_l[c][0] = l;
+        v2v_fastdiv_magic((uint32_t)(k.OWc[c] > 0 ? k.OWc[c] : 1), &m, &l);                       k.div_m[c][1] = m; k.div_l[c][1] = l;
+    }
     const long long Mc = k.Mc[0];   // class 0 is the largest
     for (int c = 0; c < 4; ++c) {
         k.nkh[c] = g.nkh[c]; k.nkw[c] = g.nkw[c]; k.dh0[c] = g.dh0[c]; k.dw0[c] = g.dw0[c];
@@ -591,6 +596,18 @@ static int device_cus() {
         else { (void)hipGetLastError(); cus = 256; }
     }
     return cus;
+}
+
+// Division of 0 <= n < 2^31 by a constant 1 <= d < 2^31 as q = (umulhi(M, n) + n) >> l  (Granlund & Montgomery, "Division by invariant
+// integers using multiplication", the round-up form): l = ceil(log2 d), M = floor(2^32 (2^l - d) / d) + 1 < 2^32; umulhi(M, n) < n, so
+// the sum stays below 2^32.  Used by the conv epilogue for the per-row divisions by the (uniform) class grid sizes.
+extern "C" int v2v_fastdiv_magic(uint32_t d, uint32_t* m_out, int32_t* l_out) {
+    if (d == 0 || d >= (1u << 31) || !m_out || !l_out) { set_error("fastdiv: divisor out of range"); return V2V_EINVAL; }
+    int l = 0;
+    while ((1ull << l) < d) ++l;
+    *m_out = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    *l_out = l;
+    return 0;
 }
 
 static int fused_norm_resident(const ConvOp* op) {

@@ -52,6 +52,8 @@ struct ConvKArgs {
     int cls_rev;         // dispatch the parity classes of a transposed convolution in descending order of their tap count
     int act_split, act_b; float act_param_b, out_scale_b;   // conv7x7_head_kernel: channels >= act_split (> 0) use this activation / scale
     const char* res0; const char* res1;   // V2V_OUT_NORM_ACT_NHWC: residuals added after the activation (or NULL)
+    // exact division of 0 <= n < 2^31 by the class grid sizes: q = (umulhi(M, n) + n) >> l (v2v_fastdiv_magic), [class][0: OHc*OWc, 1: OWc]
+    unsigned div_m[4][2]; int div_l[4][2];
     ConvGroupPtrs g1;    // grouped launch (conv3x3_pp2_kernel): operands of block z == 1
 };
 
@@ -414,24 +416,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
         }
     } else if (p.out_mode == V2V_OUT_ACT_NHWC) {
         T* const out = reinterpret_cast<T*>(p.out);
+        // uniform epilogue operands pinned in SGPRs: the unrolled store loops otherwise re-fetch them from the kernel-argument
+        // segment per element (profiles/r02_isa_sload_report.txt: 32-128 s_load_dword + s_waitcnt per launch)
+        int e_act = p.act; float e_act_param = p.act_param, e_out_scale = p.out_scale;
+        asm volatile("" : "+s"(e_act), "+s"(e_act_param), "+s"(e_out_scale));
         // NONE / RELU / LEAKY (every norm-less hidden layer) as one select with hoisted conditions: bit for bit apply_act()
-        const bool simple = p.act == V2V_ACT_NONE || p.act == V2V_ACT_RELU || p.act == V2V_ACT_LEAKY;
+        const bool simple = e_act == V2V_ACT_NONE || e_act == V2V_ACT_RELU || e_act == V2V_ACT_LEAKY;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int ncol = nt * BN + wn * WN + j * 32 + lr;
             const bool nvalid = ncol < p.cout && !helper;
             const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
             if (simple) {
-                const bool is_none = p.act == V2V_ACT_NONE, is_relu = p.act == V2V_ACT_RELU;
+                const bool is_none = e_act == V2V_ACT_NONE, is_relu = e_act == V2V_ACT_RELU;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (opx[i][r] >= 0 && nvalid) {
                             float v = acc[i][j][r] + bv;
-                            const float neg = is_relu ? 0.f : v * p.act_param;
+                            const float neg = is_relu ? 0.f : v * e_act_param;
                             v = (is_none || v > 0.f) ? v : neg;
-                            store_act(out, (unsigned)opx[i][r] * cs_out + (unsigned)ncol, v * p.out_scale);
+                            store_act(out, (unsigned)opx[i][r] * cs_out + (unsigned)ncol, v * e_out_scale);
                         }
             } else {
 #pragma unroll
@@ -440,11 +446,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                     for (int r = 0; r < 16; ++r)
                         if (opx[i][r] >= 0 && nvalid)
                             store_act(out, (unsigned)opx[i][r] * cs_out + (unsigned)ncol,
-                                      apply_act(acc[i][j][r] + bv, p.act, p.act_param) * p.out_scale);
+                                      apply_act(acc[i][j][r] + bv, e_act, e_act_param) * e_out_scale);
             }
         }
     } else {                                       // planar fp32 NCHW (API-facing heads)
         float* const out = reinterpret_cast<float*>(p.out);
+        int e_act = p.act; float e_act_param = p.act_param, e_out_scale = p.out_scale;
+        asm volatile("" : "+s"(e_act), "+s"(e_act_param), "+s"(e_out_scale));
         const unsigned ohow = (unsigned)(p.OH * p.OW);
         if (p.N > 1) {                             // pixel index -> n * cout * OH*OW + pixel-in-image
 #pragma unroll
@@ -466,7 +474,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (opx[i][r] >= 0 && nvalid)
-                        out[(unsigned)opx[i][r] + (unsigned)ncol * ohow] = apply_act(acc[i][j][r] + bv, p.act, p.act_param) * p.out_scale;
+                        out[(unsigned)opx[i][r] + (unsigned)ncol * ohow] = apply_act(acc[i][j][r] + bv, e_act, e_act_param) * e_out_scale;
         }
     }
     if (want_stats) {
@@ -809,15 +817,17 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
     // (profiles/r02_a72_fixed_cost_trace_nofin.txt)
     int e_os = p.os, e_mcls = p.Mc[cls], e_owc = p.OWc[cls], e_hwc = p.OHc[cls] * p.OWc[cls], e_oh = p.OH, e_ow = p.OW;
     int e_m0 = mt * BM;
+    unsigned e_mh = p.div_m[cls][0], e_mw = p.div_m[cls][1]; int e_lh = p.div_l[cls][0], e_lw = p.div_l[cls][1];
     asm volatile("" : "+s"(e_os), "+s"(e_mcls), "+s"(e_owc), "+s"(e_hwc), "+s"(e_oh), "+s"(e_ow), "+s"(e_m0));
+    asm volatile("" : "+s"(e_mh), "+s"(e_mw), "+s"(e_lh), "+s"(e_lw));
     conv_epilogue<T, BM, BN, WGM, WGN>(p, acc, smem, tid, wm, wn, helper, cls, tiles, lin, slice, S, nt, cls * p.m_tiles + mt,
         [&](int row) -> int {                  // N*OH*OW < 2^31 (host check)
             const int m = e_m0 + row;
             if (m >= e_mcls) return -1;
             if (e_os == 1) return m;
-            const int n = m / e_hwc;
+            const int n = (int)((__umulhi(e_mh, (unsigned)m) + (unsigned)m) >> e_lh);       // m / e_hwc, exact for 0 <= m < 2^31
             const int rem = m - n * e_hwc;
-            const int oi = rem / e_owc;
+            const int oi = (int)((__umulhi(e_mw, (unsigned)rem) + (unsigned)rem) >> e_lw);  // rem / e_owc
             const int oj = rem - oi * e_owc;
             return (n * e_oh + (oi * 2 + (cls >> 1))) * e_ow + (oj * 2 + (cls & 1));
         });

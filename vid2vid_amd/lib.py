@@ -73,6 +73,7 @@ PROTOTYPES = {
     "v2v_conv_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_tile_config": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_fused_norm_max_workgroups": (C.c_int, []),
+    "v2v_fastdiv_magic": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(_I)]),
     "v2v_conv_splitk_workspace": (_L, [C.POINTER(ConvDesc), C.POINTER(_I)]),
     "v2v_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "v2v_conv2d_pair": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _P]),
