@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-3 GPU visits (branch r3-prep: first validation of what was staged at the end of round 2).  scripts/gpu_r3.sh <tag> [parts...]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=${1:-r3}; shift
+WHAT=${*:-kpairs}
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+T0=$(date +%s)
+lap() { echo "[$(( $(date +%s) - T0 )) s] $1"; }
+if has kpairs; then      # tiles 90 / 91 (K pairs): parity of the single, paired and fused-norm forms, then the kernel time beside tile 82
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x --tb=short -k "conv3x3_patch_kernel or conv2d_pair or fused_norm_pair" > gpurun_out/${TAG}_kpairs_tests.log 2>&1; echo "kpairs tests rc=$?"
+  tail -5 gpurun_out/${TAG}_kpairs_tests.log | cut -c1-300
+  lap kpairs_tests
+  cd /tmp
+  for cfg in 82,1 90,1; do
+    timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/kp_${TAG}_${cfg/,/_} -o kp -- python $R/scripts/conv_layer_run.py --pair --fused --cfg $cfg,0 --reps 40 > /dev/null 2>&1
+    python $R/scripts/rocprof_summary.py $(find /tmp/kp_${TAG}_${cfg/,/_} -name "*.db" | head -1) "# paired fused 1024->1024 3x3 @64x32, tile $cfg, cold cache" | grep -E "conv3x3_pp3|^#" | cut -c1-200
+  done | tee $R/gpurun_out/${TAG}_kpairs_kernel.txt
+  cd $R
+  lap kpairs_kernel
+fi
+if has epilogue; then    # SGPR pins + reciprocal division: parity of every generic tile / output mode, then the fixed cost again
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train_ops.py -m gpu -q -x --tb=short -k "conv2d_all_output_modes or conv2d_every_tile_config or conv_transpose or convtranspose or backward" > gpurun_out/${TAG}_epilogue_tests.log 2>&1; echo "epilogue tests rc=$?"
+  tail -5 gpurun_out/${TAG}_epilogue_tests.log | cut -c1-300
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_fc_$TAG -o fc -- python $R/scripts/fixed_cost.py > /dev/null 2>&1
+  python $R/scripts/fixed_cost_trace.py $(find /tmp/prof_fc_$TAG -name "*.db" | head -1) | tee $R/gpurun_out/${TAG}_fixed_cost_trace.txt
+  cd $R
+  lap epilogue
+fi
+if has benchab; then     # the frame with the committed cache (pairs on tile 82) against pairs forced to tile 90, one box
+  for pt in "" "90,1"; do
+    V2V_PAIR_TILE=$pt timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line 2>/dev/null | python -c "import sys, json; j = json.loads(sys.stdin.read()); print('pair tile ${pt:-cache}:', j['value'], 'frames/s', j['ms_per_step'], 'ms', j['roofline']['kernel'][:70], j['roofline']['avg_launch_us'], 'us')"
+  done | tee gpurun_out/${TAG}_kpairs_bench_ab.txt
+  lap benchab
+fi
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short --timeout 900 --durations=10 > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300 | tail -30
+  lap tests
+fi
