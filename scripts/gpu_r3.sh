@@ -9,11 +9,11 @@ has() { [[ " $WHAT " == *" $1 "* ]]; }
 T0=$(date +%s)
 lap() { echo "[$(( $(date +%s) - T0 )) s] $1"; }
 if has kpairs; then      # tiles 90 / 91 (K pairs): parity of the single, paired and fused-norm forms, then the kernel time beside tile 82
-  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x --tb=short -k "conv3x3_patch_kernel or conv2d_pair or fused_norm_pair" > gpurun_out/${TAG}_kpairs_tests.log 2>&1; echo "kpairs tests rc=$?"
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "conv3x3_patch_kernel or conv2d_pair or fused_norm_pair" > gpurun_out/${TAG}_kpairs_tests.log 2>&1; echo "kpairs tests rc=$?"
   tail -5 gpurun_out/${TAG}_kpairs_tests.log | cut -c1-300
   lap kpairs_tests
   cd /tmp
-  for cfg in 82,1 90,1; do
+  for cfg in 82,1 90,1 92,1; do
     timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/kp_${TAG}_${cfg/,/_} -o kp -- python $R/scripts/conv_layer_run.py --pair --fused --cfg $cfg,0 --reps 40 > /dev/null 2>&1
     python $R/scripts/rocprof_summary.py $(find /tmp/kp_${TAG}_${cfg/,/_} -name "*.db" | head -1) "# paired fused 1024->1024 3x3 @64x32, tile $cfg, cold cache" | grep -E "conv3x3_pp3|^#" | cut -c1-200
   done | tee $R/gpurun_out/${TAG}_kpairs_kernel.txt
@@ -30,7 +30,7 @@ if has epilogue; then    # SGPR pins + reciprocal division: parity of every gene
   lap epilogue
 fi
 if has benchab; then     # the frame with the committed cache (pairs on tile 82) against pairs forced to tile 90, one box
-  for pt in "" "90,1"; do
+  for pt in "" "90,1" "92,1"; do
     V2V_PAIR_TILE=$pt timeout 400 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-line 2>/dev/null | python -c "import sys, json; j = json.loads(sys.stdin.read()); print('pair tile ${pt:-cache}:', j['value'], 'frames/s', j['ms_per_step'], 'ms', j['roofline']['kernel'][:70], j['roofline']['avg_launch_us'], 'us')"
   done | tee gpurun_out/${TAG}_kpairs_bench_ab.txt
   lap benchab

@@ -211,7 +211,9 @@ PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33
               (80, 1), (81, 1), (82, 1), (83, 1), (84, 1), (85, 1), (80, 2), (81, 2), (83, 3), (84, 2), (85, 2), (82, 4),
               (86, 1), (87, 1), (86, 2), (87, 2),
               # K pairs (two K halves per wave tile, accumulators exchanged through LDS)
-              (90, 1), (91, 1), (90, 2), (91, 3)]
+              (90, 1), (91, 1), (90, 2), (91, 3),
+              # K quads
+              (92, 1), (93, 1), (92, 2), (93, 2)]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -297,7 +299,7 @@ def test_conv2d_pair_equals_two_launches(case, prec):
     assert eng.pair_eligible(xa[0], convs[0], xa[1], convs[1])
     for tile, S in [(70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2),
                     (80, 1), (81, 1), (82, 1), (83, 1), (84, 1), (85, 1), (80, 2), (81, 2), (86, 1), (87, 1), (86, 2),
-                    (90, 1), (91, 1), (90, 2)]:
+                    (90, 1), (91, 1), (90, 2), (92, 1), (93, 1), (92, 2)]:
         if 2 * S > ncc:
             continue
         eng.pair_override = (tile, S)
@@ -349,7 +351,7 @@ def test_fused_norm_pair_equals_conv_plus_bn_apply(case, prec):
     xa = [eng.pack((torch.randn(N, cin, H, W) * (1.0 + i)).to(DEV)) for i in range(2)]
     ra = [eng.pack(torch.randn(N, cout, H, W).to(DEV)) for _ in range(2)]
     pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
-    for tile in (80, 81, 82, 83, 84, 85, 86, 87, 90, 91):
+    for tile in (80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93):
         eng.pair_override = (tile, 1)
         if not eng.fused_norm_fits((tile, 1, 0), N, H, W, cout):
             continue

@@ -53,6 +53,8 @@ constexpr int pending_at(int tap, int GP, int LB, int D) {
 // (12 ds_read_b128 x 8 waves = 96 KB per step against 512 MFMA cycles; profiles/r02_a5_pp3_ablate.txt: removing the reads saves as much
 // as removing the MFMAs).  After the loop the two halves of a pair exchange one half of their accumulators through LDS (64 KB, once per
 // launch): each wave ends up with the complete sums of a 64 x 32 tile, exactly the 4 x 2 layout the shared epilogue expects.
+// KS_ = 4 ("K quads"): 2 x 1 wave tiles of 128 x 64, four K quarters -- one sub-step per wave and step, 8 MFMAs per 6 fragment reads
+// (48 KB of LDS reads per step and CU), 128 accumulator registers per lane, a three-round reduce-scatter at the end.
 template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1>
 __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
     const ConvKArgs p = select_group(p_in);
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NMMA = SS * TM * TN;                        // MFMAs of one step (per wave)
     constexpr int NRD = SS * (TM + TN);                       // fragment reads of one step (per wave)
-    static_assert(KS == 1 || (KS == 2 && TN == 2 && WGN == 1), "K pairs: 64-wide wave tiles that split into the two 32-wide epilogue tiles");
+    static_assert(KS == 1 || (KS == 2 && TN == 2 && WGN == 1) || (KS == 4 && TM == 4 && WGN == 1),
+                  "K pairs: 64-wide wave tiles that split into two 32-wide epilogue tiles; K quads: 128-row wave tiles that split into four 32-row ones");
     static_assert(TW % 32 == 0 && (TW & (TW - 1)) == 0, "a 32-row fragment must lie inside one tile row");
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile");
     static_assert(BN % (8 * NW) == 0 && LB >= 1, "weight loader rounds");
@@ -317,6 +320,38 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     };
     if constexpr (KS == 1) {
         conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of);
+    } else if constexpr (KS == 4) {
+        // K quads: the four waves of a 128-row wave tile each hold one K quarter of all of it.  Reduce-scatter in three rounds: in
+        // round d wave h hands row tile (h + d) % 4 to wave (h + d) % 4 of its quad and collects its own row tile h from wave
+        // (h - d) % 4 -- 64 KB per round through the patch buffers ([wave][j][reg][lane], lane-linear).  The sum order
+        // own + (h-1) + (h-2) + (h-3) is fixed, so the result does not depend on timing.  Then the 8 x 1 layout of 32 x BN tiles.
+        static_assert(2 * PATCH >= NW * TN * 16 * 64 * 4, "K quads: the accumulator exchange lives in the patch buffers");
+        float* const xch = reinterpret_cast<float*>(smem);
+        f32x16 acc4[1][TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc4[0][j][r] = wk == 0 ? acc[0][j][r] : wk == 1 ? acc[1][j][r] : wk == 2 ? acc[2][j][r] : acc[3][j][r];
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+            const int to = (wk + d) & 3;                       // row tile (and quad member) that receives this round
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float give = to == 0 ? acc[0][j][r] : to == 1 ? acc[1][j][r] : to == 2 ? acc[2][j][r] : acc[3][j][r];
+                    xch[((wid * TN + j) * 16 + r) * 64 + lane] = give;
+                }
+            __syncthreads();
+            const int from = (wid & ~3) | ((wk - d) & 3);     // the quad member that wrote row tile wk this round
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc4[0][j][r] += xch[((from * TN + j) * 16 + r) * 64 + lane];
+            __syncthreads();
+        }
+        conv_epilogue<T, BM, BN, WGM * 4, WGN, ABL == 0>(p, acc4, smem, tid, wm * 4 + wk, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of);
     } else {
         // K pairs: wave (tile, half h) keeps column tile j = h of its 64-wide wave tile and hands column tile 1 - h to its partner
         // (wave id ^ 1), which holds the other half of the K sum for it.  Same lane <-> element map on both sides (same MFMA
@@ -361,12 +396,13 @@ static int launch_pp3_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
     return check_launch();
 }
 
-// single-phase tile configurations (ids 80..91)
+// single-phase tile configurations (ids 80..93)
 static const PatchCfg kPp3Cfgs[] = {
     {80, 8, 32, 64}, {81, 8, 32, 128}, {82, 8, 32, 64}, {83, 4, 64, 64}, {84, 4, 32, 128}, {85, 4, 64, 128},
     {86, 4, 32, 128}, {87, 2, 64, 128},     // 4 waves (2 x 2), 64 x 64 wave tiles
     {88, 8, 32, 128}, {89, 8, 32, 64},     // ablation instances of 81 / 80
     {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
+    {92, 8, 32, 64}, {93, 4, 64, 64},      // K quads: 2 x 1 wave tiles of 128 x 64, four K quarters: 6 reads per 8 MFMAs
 };
 static inline const PatchCfg* find_pp3_cfg(int id) {
     for (const PatchCfg& c : kPp3Cfgs)
@@ -387,6 +423,8 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 87: return launch_pp3_cfg<T, 2, 64, 128, 4, 0, 2, 2>(k, groups, s);   // same for 64-wide tile rows
         case 90: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 4, 1, 2>(k, groups, s);   // as 82 (256 px x 64, 5 slices), K pairs: 8 reads per 8 MFMAs
         case 91: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 4, 1, 2>(k, groups, s);   // as 83 for 64-wide tile rows
+        case 92: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 2, 1, 4>(k, groups, s);   // as 82, K quads
+        case 93: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 2, 1, 4>(k, groups, s);   // as 83, K quads
         case 88: return launch_pp3_cfg<T, 8, 32, 128, 4, 1>(k, groups, s);
         case 89: return launch_pp3_cfg<T, 8, 32, 64, 4, 1>(k, groups, s);
     }

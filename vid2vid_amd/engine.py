@@ -300,14 +300,15 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               # single-phase software-pipelined schedule (csrc/conv3x3_pp3_kernel.h): two fragment register sets, ONE barrier per step
               80: (8, 32, 64), 81: (8, 32, 128), 82: (8, 32, 64), 83: (4, 64, 64), 84: (4, 32, 128), 85: (4, 64, 128),
               86: (4, 32, 128), 87: (2, 64, 128),      # 86 / 87: four waves, 64 x 64 wave tiles
-              90: (8, 32, 64), 91: (4, 64, 64)}        # 90 / 91: 82 / 83 with K pairs (8 fragment reads per 8 MFMAs)
+              90: (8, 32, 64), 91: (4, 64, 64),        # 90 / 91: 82 / 83 with K pairs (8 fragment reads per 8 MFMAs)
+              92: (8, 32, 64), 93: (4, 64, 64)}        # 92 / 93: K quads (6 reads per 8 MFMAs)
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
-PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91)
+PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
 
 
 def is_patch_tile(t):
     """Tile ids of the LDS-patch 3x3 kernels (weights in K order 1): patch 32-48, ping-pong 50-57, ping-pong 2 70-79."""
-    return 32 <= t < 60 or 70 <= t < 92
+    return 32 <= t < 60 or 70 <= t < 94
 FUSE_FINALIZE_MAX_PIXELS = 32768   # larger layers leave thousands of statistics rows: parallel two-stage finalize instead
 PREFETCH_DIST = 12          # K chunks (128 B of every weight row each) the helper wave runs ahead
 
@@ -787,7 +788,7 @@ class Engine:
         """V2V_OUT_NORM_ACT_NHWC (include/v2v_hip.h, "fused norm"): single-phase tiles, no split-K, every workgroup of the
         launch resident at once."""
         t, S = tile3[0], max(int(tile3[1]), 1)
-        if not (self.fused_norm and self.fused_finalize and (80 <= t < 88 or t in (90, 91)) and S == 1 and cout % vec_of(self.dtype) == 0):
+        if not (self.fused_norm and self.fused_finalize and (80 <= t < 88 or 90 <= t < 94) and S == 1 and cout % vec_of(self.dtype) == 0):
             return False
         th, tw, bn = PATCH_CFGS[t]
         if self._fused_norm_wgs is None:
