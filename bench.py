@@ -60,7 +60,77 @@ def parse():
     ap.add_argument("--profile-frames", type=int, default=3)
     ap.add_argument("--no-train-line", action="store_true", help="infer: skip the short --mode train run reported under \"train\"")
     ap.add_argument("--dump-ops", default="", help="write the per-op timing table (json) here")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps frames each; `value` is the MEDIAN window")
+    ap.add_argument("--min-warmup-s", type=float, default=0.5, help="warm up for at least this long (and at least --warmup frames) before the first window")
+    ap.add_argument("--no-hires", action="store_true", help="infer: skip the 2048x1024 / 3-scale companion run reported under \"hires\"")
+    ap.add_argument("--no-train-parity", action="store_true", help="train: skip the fp32 chunk-vs-oracle parity leg (outputs, losses, gradient norms)")
     return ap.parse_args()
+
+
+def train_parity(args, dev, local_rank, opt, modelG, modelD, flowNet):
+    """Parity BEFORE timing ("losses and a gradient norm for train configs"): ONE chunk of train.py's inner loop
+    at the benchmarked geometry in fp32 against the CPU oracle holding the same weights -- outputs, every loss of
+    Vid2VidModelD.forward, and the gradients of G, D and D_T0 (norm and relative L2 distance of the whole flattened
+    gradient); the same chunk through the bf16 kernels is reported beside it.  The chunk holds 3 frames so that temporal
+    scale 0 is active (tD = 3); flow_ref / conf_ref come from this run's FlowNet2 and are inputs of both sides."""
+    import torch
+    from oracle import train_parity as TP
+    from vid2vid_amd import synthetic
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models.vid2vid_model_G import Vid2VidModelG
+    from vid2vid_amd.models.vid2vid_model_D import Vid2VidModelD
+    H, W, S = args.height, args.width, args.scales
+    nfl = 3 if S == 1 else 1                         # the CPU side costs ~20 s per frame at 512x256, ~55 s at 1024x512 / 2 scales
+    tG = opt.n_frames_G
+    nT = nfl + tG - 1
+    lab, inst, frames = synthetic.label2city_sequence(nT, H, W, seed=4321, device=dev)
+    A, I, B = lab.view(1, nT, 1, H, W), inst.view(1, nT, 1, H, W), frames
+    with torch.no_grad():
+        flow_ref, conf_ref = flowNet(B[:, tG - 1:], B[:, tG - 2:-1])
+    flow_ref, conf_ref = flow_ref.detach().float(), conf_ref.detach().float()
+    srcG, srcD = modelG.module, modelD.module
+    has_T = nfl >= opt.n_frames_D
+
+    def pair(precision):
+        o = make_opt(isTrain=True, label_nc=35, use_instance=True, fg=True, random_init_ok=True, loadSize=W, precision=precision,
+                     gpu_ids=[local_rank], n_scales_spatial=S, num_D=args.num_D, n_frames_total=2 * max(nfl, 2),
+                     max_frames_per_gpu=nfl, n_scales_temporal=1, no_vgg=args.no_vgg, niter_fix_global=0)
+        G = Vid2VidModelG(); G.initialize(o)
+        D = Vid2VidModelD(); D.initialize(o)
+        for si in range(S):
+            getattr(G, "netG%d" % si).load_state_dict(getattr(srcG, "netG%d" % si).state_dict())
+        D.netD.load_state_dict(srcD.netD.state_dict())
+        D.netD_T0.load_state_dict(srcD.netD_T0.state_dict())
+        if not args.no_vgg:
+            D.criterionVGG.vgg.load_state_dict(srcD.criterionVGG.vgg.state_dict())
+        G.engine.refresh_weights()
+        return o, G, D
+
+    cpu = lambda m: {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    o32, G32, D32 = pair("fp32")
+    got32 = TP.hip_chunk(G32, D32, A, I, B, flow_ref, conf_ref)
+    ref = TP.oracle_chunk([cpu(getattr(G32, "netG%d" % si)) for si in range(S)], cpu(D32.netD), cpu(D32.netD_T0) if has_T else None,
+                          A.cpu(), I.cpu(), B.cpu(), flow_ref.cpu(), conf_ref.cpu(),
+                          n_down=o32.n_downsample_G, n_blocks=o32.n_blocks, n_blocks_local=o32.n_blocks_local, n_frames_load=nfl,
+                          num_D=args.num_D, sd_vgg=None if args.no_vgg else cpu(D32.criterionVGG.vgg),
+                          param_names=TP.param_names_of(G32, D32))
+    c32 = TP.compare(got32, ref)
+    del G32, D32, got32
+    torch.cuda.empty_cache()
+    _, G16, D16 = pair("bf16")
+    c16 = TP.compare(TP.hip_chunk(G16, D16, A, I, B, flow_ref, conf_ref), ref)
+    del G16, D16
+    torch.cuda.empty_cache()
+    ok = bool(c32["max_forward"] <= 1e-3 and c32["max_loss"] <= 1e-3 and c32["max_grad_norm"] <= 2e-3
+              and all(v["finite"] for v in c32["grads"].values()))
+    return {"chunk": "label2city %dx%d, n_scales_spatial=%d, num_D=%d, %d frames (first chunk of a sequence), VGG %s, temporal scale 0 %s"
+                     % (W, H, S, args.num_D, nfl, "off" if args.no_vgg else "on (this run's random-init VGG19)", "active" if has_T else "inactive"),
+            "reference": "oracle/train_parity.py: CPU autograd of oracle/vid2vid_oracle.py, pinned to the reference's own chunk "
+                         "(outputs, losses, complete gradients) by tests/golden/training_label2city_s2_32x64.npz",
+            "measure": "forward: per pixel |got-ref| / (|ref| + rms(ref)); losses: |got-ref| / max(|ref|, 1e-3); gradients: "
+                       "relative error of the norm and relative L2 distance of the whole flattened gradient per optimizer",
+            "tolerance_fp32": {"forward": 1e-3, "losses": 1e-3, "grad_norm": 2e-3},
+            "fp32": c32, "fp32_ok": ok, "bf16": c16, "oracle_seconds": round(ref["seconds"], 1)}
 
 
 def run_train(args, dev, rank, world, local_rank, emit=True):
@@ -147,6 +217,15 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    parity = None
+    if rank == 0 and world == 1 and not args.no_train_parity:
+        try:
+            parity = train_parity(args, dev, local_rank, opt, modelG, modelD, flowNet)
+        except Exception as ex:                                     # reported, never silently dropped
+            import traceback
+            traceback.print_exc()
+            parity = {"error": repr(ex)[:400]}
+
     # tile search on the first sequence (every conv shape of the step: forward, backward-data), then plain warm-up
     eng.autotune = not args.no_autotune
     t_tune = time.perf_counter()
@@ -230,7 +309,7 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
                        "autotune_s": round(t_tune, 1),
                        "parallelism": "dp%d over sequences (RCCL all-reduce of flat gradients per optimizer)" % args.gpus,
                        "loss_G": round(float(loss_G), 4), "loss_D": round(float(loss_D), 4), "output_finite": finite},
-            "roofline": roofline, "flownet2": flownet_line, "cpu_baseline": None,
+            "parity": parity, "roofline": roofline, "flownet2": flownet_line, "cpu_baseline": None,
         }
         if emit:
             print(json.dumps(out))
@@ -318,21 +397,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed_fps(m, steps, warmup):
+    def timed_fps(m, steps, warmup, windows=1, min_warm_s=0.0):
+        """Warm up for >= `warmup` frames AND >= min_warm_s seconds (clocks ramp after the idle CPU legs), then time
+        `windows` windows of EXACTLY `steps` frames, each bracketed by barrier + synchronize on both sides and reduced
+        with MAX over the ranks.  Returns (median window, all windows, warm-up frames)."""
         m.fake_B_prev = None
-        for t in range(warmup):
+        t, tw = 0, time.perf_counter()
+        while t < warmup or (time.perf_counter() - tw) < min_warm_s:
             run_step(m, t)
-        barrier()
-        t0 = time.perf_counter()
-        for t in range(warmup, warmup + steps):
-            run_step(m, t)
-        barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = tt.item()
-        return el
+            t += 1
+            if t % 8 == 0:
+                torch.cuda.synchronize(dev)          # the host must not run ahead: the warm-up time is GPU time
+        els = []
+        for _ in range(max(windows, 1)):
+            barrier()
+            t0 = time.perf_counter()
+            for _k in range(steps):
+                run_step(m, t)
+                t += 1
+            barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = tt.item()
+            els.append(el)
+        return sorted(els)[len(els) // 2], els, t - steps * len(els)
 
     model.fake_B_prev = None
     run_step(model, 0)                           # builds the frame plan (tile searches, graph): never inside the timed region
@@ -490,8 +580,8 @@ def main():
                   "note": "bf16 storage is a throughput mode: its error is reported, not gated at 1e-3 (the reference's own "
                           "bf16-autocast differs from its fp32 by 2e-2, BASELINE.md section 2)"}
         if model32 is not model:                   # companion figure: the path that carries the 1e-3 parity, same workload
-            el32 = timed_fps(model32, max(args.steps // 2, 5), 2)
             n32 = max(args.steps // 2, 5)
+            el32, _, _ = timed_fps(model32, n32, 2, windows=3, min_warm_s=0.3)
             fp32_line = {"value": round(n32 / el32, 3), "unit": "frames/s", "ms_per_step": round(el32 / n32 * 1e3, 4),
                          "steps": n32, "dtype": "fp32 (v_mfma_f32_32x32x2_f32, exact)",
                          "frac_of_fp32_mfma_peak": round(sum(c["flops"] for c in model32._active_plan.conv_log if not c.get("onehot")) / (el32 / n32) / 1e12 / PEAK_TFLOPS["fp32"], 4)}
@@ -499,17 +589,18 @@ def main():
             torch.cuda.empty_cache()
 
     # ---------------- the timed region ----------------
-    elapsed = timed_fps(model, args.steps, args.warmup)
+    elapsed, window_s, warm_frames = timed_fps(model, args.steps, args.warmup, args.windows, args.min_warmup_s)
     fps = args.gpus * args.steps / elapsed
     fp = model._active_plan
     finite = bool(torch.isfinite(fp.out["fake_B"]).all().item())
 
     # ---------------- roofline of the dominant kernel (HIP events, same plan, same stream) ----
-    roofline = None
-    if rank == 0:
+    def kernel_table(fp_, nprof):
+        """HIP-event durations of every launch of an eager single-stream replay of the frame plan, joined with the plan's
+        conv census: per (tile, split-K, members) configuration the summed time and algorithmic FLOP."""
         # one entry per LAUNCH: the two members of a paired launch (v2v_conv2d_pair) are one kernel
         launches, i = [], 0
-        mfma_log = [c for c in fp.conv_log if not c.get("onehot")]       # one-hot stems are gather-sums, not conv2d launches
+        mfma_log = [c for c in fp_.conv_log if not c.get("onehot")]       # one-hot stems are gather-sums, not conv2d launches
         while i < len(mfma_log):
             c = mfma_log[i]
             if c.get("pair"):
@@ -520,9 +611,8 @@ def main():
                 launches.append(dict(c, members=1))
                 i += 1
         acc = {}
-        nprof = max(args.profile_frames, 1)
         for _ in range(nprof):
-            rows = fp.plan.profile()
+            rows = fp_.plan.profile()
             convs = [r for r in rows if r[0] == KERNEL_FAMILY]
             assert len(convs) == len(launches), (len(convs), len(launches))
             for (name, label, ms), c in zip(convs, launches):
@@ -532,6 +622,24 @@ def main():
         total_ms = {}
         for name, label, ms in rows:
             total_ms[name] = total_ms.get(name, 0.0) + ms
+        return acc, rows, convs, launches, mfma_log, total_ms
+
+    def tile_label(dom, fused=False):
+        from vid2vid_amd.engine import TILE_CFGS, PATCH_CFGS
+        if dom[0] in PATCH_CFGS:
+            th_, tw_, bn = PATCH_CFGS[dom[0]]
+            fam = "conv3x3_pp3_kernel" if dom[0] >= 80 else "conv3x3_pp2_kernel" if dom[0] >= 70 else "conv3x3_pp_kernel" if dom[0] >= 50 else "conv3x3_patch_kernel"
+            return fam, "%dx%d px x %d,splitK=%d%s%s" % (th_, tw_, bn, dom[1], ",paired launch (2 convolutions)" if dom[2] == 2 else "",
+                                                           ",norm+act+residual fused" if fused else "")
+        if dom[0] == 60:
+            return "conv7x7_head_kernel", "halo patch,splitK=%d" % dom[1]
+        bm, bn, _ = TILE_CFGS.get(dom[0], (0, 0, False))
+        return "conv_igemm_kernel", "%dx%d,splitK=%d" % (bm, bn, dom[1])
+
+    roofline = None
+    if rank == 0:
+        nprof = max(args.profile_frames, 1)
+        acc, rows, convs, launches, mfma_log, total_ms = kernel_table(fp, nprof)
         dom = max(acc, key=lambda k: acc[k]["flops"])
         a = acc[dom]
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
@@ -539,16 +647,7 @@ def main():
         rb = [(ms, c) for (n_, l_, ms), c in zip(convs, launches) if c["cin"] == 1024 and c["cout"] == 1024 and c["KH"] == 3]
         rb_tf = (sum(c["flops"] for _, c in rb) / (sum(ms for ms, _ in rb) * 1e-3) / 1e12) if rb else None
         peak = PEAK_TFLOPS[args.precision]
-        from vid2vid_amd.engine import TILE_CFGS, PATCH_CFGS
-        if dom[0] in PATCH_CFGS:
-            th_, tw_, bn = PATCH_CFGS[dom[0]]
-            fam = "conv3x3_pp3_kernel" if dom[0] >= 80 else "conv3x3_pp2_kernel" if dom[0] >= 70 else "conv3x3_pp_kernel" if dom[0] >= 50 else "conv3x3_patch_kernel"
-            tile_name = "%dx%d px x %d,splitK=%d%s%s" % (th_, tw_, bn, dom[1], ",paired launch (2 convolutions)" if dom[2] == 2 else "",
-                                                           ",norm+act+residual fused" if (rb and rb[0][1].get("fused_norm")) else "")
-        else:
-            bm, bn, _ = TILE_CFGS.get(dom[0], (0, 0, False))
-            fam = "conv_igemm_kernel"
-            tile_name = "%dx%d,splitK=%d" % (bm, bn, dom[1])
+        fam, tile_name = tile_label(dom, bool(rb and rb[0][1].get("fused_norm")))
         # committed measurements of the same kernel configuration (separate rocprofv3 runs, scripts/gpu_r2.sh): HBM traffic
         # per launch (PMC passes) and the kernel's average duration INSIDE the graph (kernel trace of this bench command)
         traffic = traffic_detail = in_graph = None
@@ -605,6 +704,113 @@ def main():
                 json.dump([dict(op=n_, label=l_, ms=ms, tile=(lambda c: [c["tile"], c.get("splitk", 1), c["members"]])(next(it)) if n_ == KERNEL_FAMILY else None)
                            for n_, l_, ms in rows], f, indent=1)
 
+    def hires_companion():
+        """2048x1024, n_scales_spatial=3 (three generators, 415 M parameters, 5064 GFLOP per frame as dense convolutions):
+        frames/s of inference() in the benchmarked dtype (median of 3 windows), the dominant kernel's fraction of the
+        MFMA peak from HIP events, and fp32 parity of ONE frame against the CPU oracle (every head of the finest scale)."""
+        nonlocal A, I, frames, lab, inst
+        Hh, Wh, Sh, Lh = 1024, 2048, 3, 4
+        A = I = frames = lab = inst = None               # release the 512x256 sequence
+
+        def build_h(precision):
+            o = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True, loadSize=Wh,
+                         precision=precision, gpu_ids=[local_rank], n_scales_spatial=Sh)
+            o.use_graph = not args.no_graph
+            torch.manual_seed(0)
+            m = create_model(o)
+            with torch.no_grad():
+                for si in range(Sh):
+                    getattr(m, "netG%d" % si).model_final_flow[1].weight.mul_(0.1)
+            return o, m
+        oh, mh = build_h(args.precision)
+        lab_h, inst_h, fr_h = synthetic.label2city_sequence(Lh + tG, Hh, Wh, seed=1234 + rank, device=dev)
+        Ah, Ih = lab_h.view(1, Lh + tG, 1, Hh, Wh), inst_h.view(1, Lh + tG, 1, Hh, Wh)
+
+        def step_h(m, t):
+            k = t % Lh
+            return m.inference(Ah[:, k:k + tG], fr_h[:, :tG - 1] if t == 0 else None, Ih[:, k:k + tG])
+        mh.fake_B_prev = None
+        tb = time.perf_counter()
+        step_h(mh, 0)                                    # plan build (tile selections replayed from the cache when present)
+        torch.cuda.synchronize(dev)
+        build_s = time.perf_counter() - tb
+        n_h = max(args.steps // 2, 10)
+        t, tw = 1, time.perf_counter()
+        while t < 3 or time.perf_counter() - tw < args.min_warmup_s:
+            step_h(mh, t); t += 1
+            torch.cuda.synchronize(dev)
+        els = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _k in range(n_h):
+                step_h(mh, t); t += 1
+            torch.cuda.synchronize(dev)
+            els.append(time.perf_counter() - t0)
+        el = sorted(els)[1]
+        fph = mh._active_plan
+        acc, rows, convs, launches, mfma_log, total_ms = kernel_table(fph, 1)
+        peak = PEAK_TFLOPS[args.precision]
+        dom = max(acc, key=lambda k: acc[k]["flops"])
+        a = acc[dom]
+        fam, tname = tile_label(dom)
+        by_time = sorted(acc.items(), key=lambda kv: -kv[1]["ms"])[:4]
+        line = {"metric": "synthesized frames/sec (Vid2VidModelG.inference, %dx%d)" % (Wh, Hh),
+                "value": round(n_h / el, 3), "unit": "frames/s", "ms_per_step": round(el / n_h * 1e3, 3), "steps": n_h,
+                "windows_ms_per_step": [round(e / n_h * 1e3, 3) for e in els], "dtype": args.precision,
+                "workload": "label2city %dx%d inference, n_scales_spatial=%d, --fg --use_instance, ngf=128 (%.1fM params random-init, %.0f GFLOP/frame "
+                            "as dense convolutions), batch 1, sequence resident in HBM" % (Wh, Hh, Sh, sum(q.numel() for q in mh.parameters()) / 1e6,
+                                                                                        sum(c["flops"] for c in fph.conv_log) / 1e9),
+                "launches_per_frame": fph.plan.num_ops, "plan_build_s": round(build_s, 1),
+                "roofline": {"bound": "mfma", "kernel": "%s<%s,%s> (tile config %d)" % (fam, args.precision, tname, dom[0]),
+                             "achieved": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                             "frac": round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / peak, 4), "launches_per_frame": a["launches"],
+                             "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
+                             "frame_in_graph": {"achieved": round(sum(c["flops"] for c in mfma_log) / (el / n_h) / 1e12, 2), "unit": "TFLOP/s",
+                                                "frac": round(sum(c["flops"] for c in mfma_log) / (el / n_h) / 1e12 / peak, 4)},
+                             "frame_ms_eager_events": round(sum(ms for _, _, ms in rows), 3),
+                             "slowest_configs_ms": {"tile %d/S%d/x%d" % k: round(v["ms"], 3) for k, v in by_time},
+                             "per_kernel_ms": {k: round(v, 3) for k, v in sorted(total_ms.items(), key=lambda kv: -kv[1])}}}
+        if do_cpu:
+            from oracle import vid2vid_oracle as O
+            sds = [{k: v.detach().float().cpu() for k, v in getattr(mh, "netG%d" % s_).state_dict().items()} for s_ in range(Sh)]
+            orc = O.InferenceOracle(sds, 35, True, True, [26], oh.n_downsample_G, oh.n_blocks, oh.n_blocks_local)
+            c0 = time.perf_counter()
+            ref_f, _ = orc.step(lab_h[:tG].cpu().view(1, tG, 1, Hh, Wh), fr_h[:, :tG - 1].cpu(), inst_h[:tG].cpu().view(1, tG, 1, Hh, Wh))
+            cpu_s = time.perf_counter() - c0
+            refs_h = dict(fake_B=ref_f, raw=orc.last["raw0"], flow=orc.last["flow0"], weight=orc.last["weight0"])
+
+            def errs(m):
+                m.fake_B_prev = None
+                fake, _ = step_h(m, 0)
+                fpm = m._active_plan
+                got = dict(fake_B=fake, raw=fpm.out["raw0"], flow=fpm.out["flow0"], weight=fpm.out["weight0"])
+                res = {}
+                for k, r in refs_h.items():
+                    g = got[k].detach().float().cpu()
+                    e = (g - r).abs() / (r.abs() + r.pow(2).mean().sqrt().item() + 1e-12)
+                    res[k] = {"max_rel": float("%.3e" % e.max().item()), "mean_rel": float("%.3e" % e.mean().item()),
+                              "finite": bool(torch.isfinite(g).all().item())}
+                return res
+            e16 = errs(mh) if args.precision == "bf16" else None
+            sd_keep = [getattr(mh, "netG%d" % s_).state_dict() for s_ in range(Sh)]
+            del mh
+            torch.cuda.empty_cache()
+            _, m32 = build_h("fp32")
+            for s_ in range(Sh):
+                getattr(m32, "netG%d" % s_).load_state_dict(sd_keep[s_])
+            m32.engine.refresh_weights()
+            e32 = errs(m32)
+            line["parity"] = {"frames": 1, "reference": "oracle/vid2vid_oracle.py, first generated frame from the given real frames, all 3 scales",
+                              "tolerance_fp32": 1e-3, "fp32": e32, "fp32_max_rel": max(v["max_rel"] for v in e32.values()),
+                              "fp32_ok": bool(max(v["max_rel"] for v in e32.values()) <= 1e-3 and all(v["finite"] for v in e32.values())),
+                              "bf16": e16}
+            line["cpu_baseline"] = {"value": round(1.0 / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                    "sample": "1 frame of the same %dx%d / 3-scale workload (no warm-up), fp32, oracle/vid2vid_oracle.py" % (Wh, Hh)}
+            del m32
+            torch.cuda.empty_cache()
+        return line
+
     sys.stdout = _stdout
     if rank == 0:
         out = {
@@ -613,6 +819,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
+            "timing": {"windows_ms_per_step": [round(e / args.steps * 1e3, 4) for e in window_s], "statistic": "median window",
+                       "warmup_frames_run": warm_frames, "min_warmup_s": args.min_warmup_s,
+                       "note": "%d windows of exactly --steps frames, each bracketed by barrier + synchronize and MAX-reduced over ranks; "
+                               "`value` / `ms_per_step` are the median window" % len(window_s)},
             "config": {"workload": "%s %dx%d inference, n_scales_spatial=%d, %s, ngf=128 n_blocks=9 "
                                    "(%.1fM params random-init, %.0f GFLOP/frame as dense convolutions%s), batch 1 per sequence, 1 sequence per GPU"
                                    % (args.dataset, W, H, args.scales, "input_nc=15, no fg tower" if face else "--fg --use_instance", sum(q.numel() for q in model.parameters()) / 1e6,
@@ -634,11 +844,24 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        # ---- companion figure: the OTHER resolution of BASELINE's metric, 2048x1024 with n_scales_spatial=3 (configs[4] geometry) ----
+        if world == 1 and not args.no_hires and not face and args.scales == 1 and (W, H) == (512, 256):
+            sys.stdout = sys.stderr
+            try:
+                model = fp = None
+                torch.cuda.empty_cache()
+                out["hires"] = hires_companion()
+            except Exception as ex:
+                import traceback
+                traceback.print_exc()
+                out["hires"] = {"error": repr(ex)[:400]}
+            finally:
+                sys.stdout = _stdout
         # ---- companion figure: the training step (train.py inner loop) on the same geometry, a short run ----
         if world == 1 and not args.no_train_line and not face and args.scales == 1:
             import argparse
             try:
-                del model
+                model = None
                 torch.cuda.empty_cache()
                 targs = argparse.Namespace(**vars(args))
                 targs.mode, targs.steps, targs.warmup, targs.no_vgg = "train", 6, 2, False
@@ -647,6 +870,7 @@ def main():
                                 "steps": tr["steps"], "warmup": tr["warmup"], "dtype": tr["dtype"],
                                 "frac_of_mfma_peak": tr["roofline"]["frac"], "tflops": tr["roofline"]["achieved"],
                                 "workload": tr["config"]["workload"], "output_finite": tr["config"]["output_finite"],
+                                "parity": tr["parity"], "flownet2": tr["flownet2"],
                                 "note": "python bench.py --mode train: the full line (per-kind FLOP, launches per step)"}
             except Exception as ex:             # the headline line must not depend on the companion run
                 out["train"] = {"error": repr(ex)[:300]}

@@ -99,7 +99,7 @@ typedef struct v2v_conv_desc {
     void*   slabs;          /* splitk > 1: v2v_conv_splitk_workspace() bytes of scratch              */
     int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
     int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major */
-    int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA), 512 = return at once (launch floor), 1024 = no main loop (prologue + epilogue) */
+    int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA), 512 = return at once (launch floor), 1024 = no main loop (prologue + epilogue), 2048 = one workgroup per channel tile stays away from the fused-norm barrier (exercises its give-up path: NaN outputs + v2v_device_status bit 0) */
     const void* res0;       /* V2V_OUT_NORM_ACT_NHWC: NULL or a residual [N][OH][OW][cout_stride] (activation dtype) added after the activation */
     const void* res1;       /* second residual, NULL or as res0                                                   */
     int32_t act_split;      /* 0, or first output channel of a SECOND head merged into this launch (see "merged heads")  */
@@ -122,7 +122,9 @@ typedef struct v2v_conv_desc {
  * (>= 256 zero ints, re-armed in-kernel) and `fin_scale_shift` given, and ALL workgroups of the launch co-resident:
  * m_tiles * n_tiles (* 2 for v2v_conv2d_pair) <= the number of compute units.  Two such launches must never run
  * concurrently on one device (each could hold half of the CUs and wait for the rest): issue them from one stream / one
- * plan lane only.  A barrier that does not complete within ~30 ms gives up and the outputs are NaN. */
+ * plan lane only, and keep the device to ONE process while they run (a co-tenant holding compute units can keep part of the
+ * workgroups off the chip).  A barrier that does not complete within ~1 s gives up: the outputs of that launch are NaN AND bit 0
+ * of the library's host-visible status word is set -- poll it with v2v_device_status() (no synchronisation needed). */
 
 /* splitk = S > 1: the S workgroups of a tile each reduce 1/S of the K chunks and publish an fp32 partial tile; the
  * last to arrive sums the S partial tiles in slice order (deterministic, independent of arrival order) and runs the
@@ -526,6 +528,10 @@ int         v2v_get_dry_run(void);
 /* library / device info */
 int         v2v_version(void);
 const char* v2v_last_error(void);
+/* Asynchronous device-side failures (kernels cannot return an error): a host-mapped status word the kernels OR bits into.
+ * bit 0: a fused-norm spin barrier timed out (see "Fused norm"), the outputs of that launch are NaN.  Reading it needs no
+ * stream synchronisation; the value reflects the launches that have executed so far.  clear != 0 resets it. */
+int         v2v_device_status(int32_t clear);
 int         v2v_device_info(int32_t* cus, int32_t* lds_per_cu, int64_t* hbm_bytes, char* arch, int32_t arch_len);
 
 #ifdef __cplusplus

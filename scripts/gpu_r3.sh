@@ -40,3 +40,24 @@ if has tests; then
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300 | tail -30
   lap tests
 fi
+if has r3new; then      # round-3 additions: ADVICE fixes, barrier give-up report, full-width training parity
+  timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short --timeout 900 -s --durations=8 \
+      -k "few_classes or follow_a_fused_optimizer or barrier_timeout or two_optimizers or full_width_training or fused_norm_pair" > gpurun_out/${TAG}_r3new.log 2>&1; echo "r3new rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|training chunk|forward|losses|grads|^E  " gpurun_out/${TAG}_r3new.log | cut -c1-1200 | tail -60
+  lap r3new
+fi
+if has benchdefault; then    # the driver's command, timed
+  /usr/bin/time -v timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$?"
+  grep -E "Elapsed|Maximum resident" gpurun_out/${TAG}_bench_default.err
+  python - <<PY
+import json
+j = json.load(open("gpurun_out/${TAG}_bench_default.json"))
+print("value", j["value"], "ms", j["ms_per_step"], "windows", j["timing"]["windows_ms_per_step"])
+print("parity fp32", j["parity"]["fp32_max_rel"], "bf16", j["parity"]["bf16_max_rel"], j["parity"]["bf16_mean_rel"])
+print("roofline", j["roofline"]["kernel"], j["roofline"]["frac"], j["roofline"]["avg_launch_us"])
+print("hires", json.dumps(j.get("hires"))[:1500])
+print("train", json.dumps(j.get("train"))[:3000])
+PY
+  tail -5 gpurun_out/${TAG}_bench_default.err | cut -c1-300
+  lap benchdefault
+fi

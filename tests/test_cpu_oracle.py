@@ -266,3 +266,47 @@ def test_feature_encoding_first_frame_nets_match_reference(golden):
     ids = inst[0, 0].long()
     for i in torch.unique(ids):                                  # every instance is constant per channel
         assert out[0, :, ids == i].std(dim=1, unbiased=False).max().item() < 1e-6
+
+
+def test_train_parity_harness_vs_reference(golden):
+    """oracle/train_parity.py::oracle_chunk (the CPU side of the full-width training parity checks in tests/test_gpu_golden.py
+    and bench.py) reproduces the reference's own chunk: every loss, the three loss totals and the COMPLETE parameter
+    gradients of G0, G1, D and D_T0 as the reference's autograd produced them (fixture made by tests/golden/make_golden.py)."""
+    from oracle import train_parity as TP
+    from util import sd_from_npz
+    g = golden("training_label2city_s2_32x64")
+    sds = {k: sd_from_npz(g, "sd%s." % k) for k in ("G0", "G1", "D", "DT0")}
+    names = {"G": [[], []], "D": [], "DT": []}
+    ref_flat = {"G": [], "D": [], "DT": []}
+    for key in g.keys():
+        if key.startswith("gradG.G0."):
+            names["G"][0].append(key[len("gradG.G0."):])
+        elif key.startswith("gradG.G1."):
+            names["G"][1].append(key[len("gradG.G1."):])
+        elif key.startswith("gradD.D."):
+            names["D"].append(key[len("gradD.D."):])
+        elif key.startswith("gradDT.DT0."):
+            names["DT"].append(key[len("gradDT.DT0."):])
+    assert len(names["G"][0]) > 10 and len(names["G"][1]) > 10 and len(names["D"]) > 5 and len(names["DT"]) > 5
+    for si in (0, 1):
+        ref_flat["G"] += [T(g["gradG.G%d.%s" % (si, n)]).reshape(-1).double() for n in names["G"][si]]
+    ref_flat["D"] = [T(g["gradD.D." + n]).reshape(-1).double() for n in names["D"]]
+    ref_flat["DT"] = [T(g["gradDT.DT0." + n]).reshape(-1).double() for n in names["DT"]]
+    lab, inst, B = [T(g["in." + k]) for k in ("labels", "inst", "B")]
+    r = TP.oracle_chunk([sds["G0"], sds["G1"]], sds["D"], sds["DT0"], lab, inst, B, T(g["in.flow_ref"]), T(g["in.conf_ref"]),
+                        n_down=2, n_blocks=2, n_blocks_local=1, n_frames_load=3, param_names=names)
+    for k in ("fake_B", "fake_B_raw", "flow", "weight"):
+        assert_close(r["outs"][k], g["out." + k], 1e-4, k)
+    for k, v in r["losses"].items():
+        ref = float(g["loss." + k])
+        assert abs(v - ref) <= 2e-4 * max(abs(ref), 1e-3), (k, v, ref)
+    for k, name in (("G", "total_G"), ("D", "total_D"), ("DT", "total_D_T0")):
+        ref = float(g["loss." + name])
+        assert abs(r["totals"][k] - ref) <= 2e-4 * abs(ref), (name, r["totals"][k], ref)
+    for k in ("G", "D", "DT"):
+        ref = torch.cat(ref_flat[k])
+        got = r["grads"][k]
+        assert got.numel() == ref.numel()
+        l2 = (got - ref).norm().item() / ref.norm().item()
+        print("gradient of %s: %d values, |ref| %.4e, relative L2 distance %.2e" % (k, ref.numel(), ref.norm().item(), l2))
+        assert l2 < 1e-3, (k, l2)

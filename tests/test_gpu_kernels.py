@@ -379,6 +379,45 @@ def test_fused_norm_pair_equals_conv_plus_bn_apply(case, prec):
         assert int(t.abs().sum().item()) == 0, "tickets of %s must be re-armed" % (key,)
 
 
+def test_fused_norm_barrier_timeout_is_reported():
+    """A fused-norm barrier that cannot complete (here: one workgroup per channel tile stays away, ablate bit 2048; in
+    the field: a co-tenant process holding compute units) gives up after ~1 s, poisons the launch's outputs with NaN AND
+    sets bit 0 of the host-visible status word (v2v_device_status) -- the host learns about it without a sync on the
+    data; the tickets re-arm and the next launch is fine."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib
+    torch.manual_seed(9)
+    eng = _engine("bf16")
+    cin = cout = 128
+    H, W = 16, 32
+    convs = [nn.Conv2d(cin, cout, 3, padding=0).to(DEV) for _ in range(2)]
+    norms = [nn.BatchNorm2d(cout).to(DEV) for _ in range(2)]
+    xa = [eng.pack(torch.randn(1, cin, H, W).to(DEV)) for _ in range(2)]
+    eng.pair_override = (82, 1)
+    eng.fused_norm = True
+    assert eng.fused_norm_fits((82, 1, 0), 1, H, W, cout)
+    lib.v2v_device_status(1)
+
+    def run():
+        y = eng.conv_group_pair(xa[0], convs[0], norms[0], xa[1], convs[1], norms[1], L.PAD_REFLECT, 1, L.ACT_RELU, 0.0,
+                                labels=("a", "b"))
+        assert eng.conv_log[-1]["fused_norm"]
+        torch.cuda.synchronize()
+        return y
+    y = run()
+    assert torch.isfinite(y[0].t.float()).all() and lib.v2v_device_status(0) == 0
+    eng.ablate = 2048
+    try:
+        y = run()
+    finally:
+        eng.ablate = 0
+    assert not torch.isfinite(y[0].t.float()).all(), "the barrier should have given up"
+    assert lib.v2v_device_status(0) & 1
+    assert lib.v2v_device_status(1) & 1 and lib.v2v_device_status(0) == 0          # read-and-clear
+    y = run()                                                                       # tickets re-armed
+    assert torch.isfinite(y[0].t.float()).all() and torch.isfinite(y[1].t.float()).all() and lib.v2v_device_status(0) == 0
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(128, 3, 24, 64, "reflect", 1, "tanh"), (64, 2, 19, 45, "reflect", 2, "none"),
                                   (128, 1, 33, 70, "zero", 1, "sigmoid"), (192, 4, 9, 32, "reflect", 1, "none"),
@@ -437,6 +476,52 @@ def test_merged_heads_equal_separate_heads(case, prec):
     ref_w = torch.sigmoid(F.conv2d(xr, _round(seq_w[1].weight.detach().cpu(), prec), seq_w[1].bias.detach().cpu()))
     assert_close(both[0].cpu(), ref_f, 1e-4, "merged heads: flow")
     assert_close(both[1].cpu(), ref_w, 1e-4, "merged heads: weight")
+
+
+def test_merged_heads_follow_a_fused_optimizer_step():
+    """The merged flow + weight head re-packs when its SOURCE layers change.  FusedAdam writes the parameters from a
+    HIP kernel (no torch version bump) and MergedConv.weight is a fresh torch.cat on every read, so the pack's version key
+    must come from the two source layers (it compared equal and the merged pack stayed stale)."""
+    from vid2vid_amd.optim import FusedAdam
+    C_, H, W = 64, 24, 40
+    torch.manual_seed(77)
+    eng = _engine("fp32")
+    x = eng.pack(torch.randn(1, C_, H, W).to(DEV))
+    seq_flow = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(C_, 2, 7)).to(DEV)
+    seq_w = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(C_, 1, 7), nn.Sigmoid()).to(DEV)
+    eng.merge_heads = True
+
+    def heads():
+        with torch.no_grad():
+            f, w = eng.head_pair(x, seq_flow, 20.0, seq_w, 1.0, label="heads")
+        return f.clone(), w.clone()
+
+    def ref():
+        xr = F.pad(eng.unpack(x).cpu(), (3,) * 4, mode="reflect")
+        return (20.0 * F.conv2d(xr, seq_flow[1].weight.detach().cpu(), seq_flow[1].bias.detach().cpu()),
+                torch.sigmoid(F.conv2d(xr, seq_w[1].weight.detach().cpu(), seq_w[1].bias.detach().cpu())))
+
+    f0, w0 = heads()
+    opt = FusedAdam(list(seq_flow.parameters()) + list(seq_w.parameters()), lr=0.05)   # re-homes the parameters
+    f1, w1 = heads()
+    assert torch.equal(f0, f1) and torch.equal(w0, w1)
+    for step in range(2):
+        opt.zero_grad()
+        for p in opt.flat.params:
+            p.grad.add_(torch.randn_like(p))
+        opt.step()
+        eng.refresh_weights()
+        f2, w2 = heads()
+        rf, rw = ref()
+        assert (f2 - f1).abs().max().item() > 1e-2, "the merged pack did not follow the optimizer step"
+        assert_close(f2.cpu(), rf, 1e-4, "merged flow head after step %d" % step)
+        assert_close(w2.cpu(), rw, 1e-4, "merged weight head after step %d" % step)
+        f1 = f2
+    with torch.no_grad():                                   # and an in-place write of one source layer (load_state_dict)
+        seq_w[1].weight.mul_(-1.0)
+    f3, w3 = heads()
+    rf, rw = ref()
+    assert_close(w3.cpu(), rw, 1e-4, "merged weight head after an in-place write")
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -582,6 +667,24 @@ def test_encode_labels_and_mask(prec):
     m2 = eng.fg_mask(pooled, (T - 1) * (nc + 1), [26, 3]).cpu()
     ref_m = O.compute_mask(_round(ref_p, prec).view(1, T, nc + 1, ref_p.shape[-2], ref_p.shape[-1]), T - 1, [26, 3])
     assert_close(m2, ref_m.reshape(m2.shape), 1e-6 if prec == "fp32" else 2e-2, "coarse fg mask")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("nc,use_inst", [(1, True), (2, False), (2, True), (3, True), (5, False), (6, True), (7, False)])
+def test_encode_labels_few_classes(nc, use_inst, prec):
+    """Datasets with few label classes: one 16-byte output vector then spans three or more of the T frames
+    (per_frame <= 6 channels in bf16, <= 2 in fp32) -- every frame's one-hot / edge channel must still be written."""
+    from oracle import vid2vid_oracle as O
+    torch.manual_seed(50 + nc)
+    eng = _engine(prec)
+    T, H, W = 3, 21, 35
+    lab = torch.randint(0, nc, (T, H, W)).float()
+    inst = torch.randint(0, 4, (T, H // 4 + 1, W // 4 + 1)).repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :H, :W].float()
+    enc = O.encode_input(lab.view(1, T, 1, H, W), inst.view(1, T, 1, H, W) if use_inst else None, nc)
+    x, mask = eng.encode_labels(lab.to(DEV), inst.to(DEV) if use_inst else None, T, H, W, nc, [0], use_inst)
+    got = eng.unpack(x).cpu()
+    assert torch.equal(got, enc.reshape(1, -1, H, W))
+    assert torch.equal(mask.cpu(), O.compute_mask(enc, T - 1, [0]).reshape(1, 1, H, W))
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

@@ -448,11 +448,54 @@ def test_single_rank_rccl_overlapped_optimizer_step():
                 g = torch.randn_like(p)
                 p.grad.add_(g); q.grad.add_(g)
             oa.step(); ob.step()
-            assert len(gs._pending) == 1                  # enqueued, not waited for
+            assert gs.pending(oa)                        # enqueued, not waited for
         parallel.wait_pending()
         torch.cuda.synchronize()
         for p, q in zip(a, b):
             assert torch.equal(p.detach(), q.detach()), "world 1: the all-reduce is the identity"
+    finally:
+        parallel._ACTIVE_SYNCS.clear()
+        dist.destroy_process_group()
+
+
+def test_two_optimizers_wait_only_for_their_own_overlapped_step():
+    """train.py:86-93 order: optimizer_G.step() then optimizer_D.zero_grad().  Both optimizers share ONE GradSync; D's
+    zero_grad must leave G's (all-reduce + Adam) pair pending on the side stream (it used to wait for all of
+    them, which serialised G's 1.66 GB all-reduce in front of D's backward), G's own zero_grad must wait for it, and
+    parallel.wait_pending() clears whatever is left."""
+    import os, socket
+    import torch.distributed as dist
+    from vid2vid_amd import parallel
+    from vid2vid_amd.optim import FusedAdam
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(4)
+        pg = [nn.Parameter(torch.randn(256, 64, 3, 3, device=DEV))]
+        pd = [nn.Parameter(torch.randn(64, 16, 4, 4, device=DEV))]
+        rg, rd = [nn.Parameter(p.detach().clone()) for p in pg], [nn.Parameter(p.detach().clone()) for p in pd]
+        og, od = FusedAdam(pg, lr=1e-3), FusedAdam(pd, lr=1e-3)
+        ref_g, ref_d = FusedAdam(rg, lr=1e-3), FusedAdam(rd, lr=1e-3)
+        gs = parallel.sync_optimizers([og, od], bucket_bytes=64 << 10, force_collective=True)
+        assert og.grad_sync is od.grad_sync is gs
+        for it in range(3):
+            og.zero_grad(); ref_g.zero_grad()
+            assert not gs.pending(og)
+            g = torch.randn_like(pg[0]); pg[0].grad.add_(g); rg[0].grad.add_(g)
+            og.step(); ref_g.step()
+            assert gs.pending(og)
+            od.zero_grad(); ref_d.zero_grad()                 # D's zero_grad: G's pair stays in flight
+            assert gs.pending(og) and not gs.pending(od)
+            g = torch.randn_like(pd[0]); pd[0].grad.add_(g); rd[0].grad.add_(g)
+            od.step(); ref_d.step()
+            assert gs.pending(og) and gs.pending(od)
+        og.zero_grad()                                        # its own event only
+        assert not gs.pending(og) and gs.pending(od)
+        parallel.wait_pending()
+        assert not gs.pending()
+        torch.cuda.synchronize()
+        assert torch.equal(pg[0].detach(), rg[0].detach()) and torch.equal(pd[0].detach(), rd[0].detach())
     finally:
         parallel._ACTIVE_SYNCS.clear()
         dist.destroy_process_group()

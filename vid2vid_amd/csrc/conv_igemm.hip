@@ -380,6 +380,25 @@ struct ConvOp : Op {
     const char* name() const override { return "conv_igemm"; }
 };
 
+// One host-mapped (pinned, device-visible) status word per process: kernels OR bits into it at system scope, the host reads it
+// without any synchronisation (v2v_device_status).  Bit 0: a fused-norm spin barrier gave up (its outputs are NaN).  Allocated on
+// the first fused-norm launch; no device or a failed allocation -> NULL, the kernels then only poison their outputs.
+static int* status_word() {
+    static int* dev = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        if (v2v_get_dry_run()) return nullptr;                       // CPU host: nothing is launched, nothing to report
+        tried = true;
+        int* host = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *host = 0;
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess || d != (void*)host) { (void)hipGetLastError(); (void)hipHostFree(host); return nullptr; }
+        dev = host;
+    }
+    return dev;
+}
+
 static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true) {
     if (!d || !d->in || !d->w || !d->out || !d->zero_page) { set_error("conv: null pointer"); return V2V_EINVAL; }
     if (d->dtype != V2V_F32 && d->dtype != V2V_BF16) { set_error("conv: bad dtype"); return V2V_EINVAL; }
@@ -453,6 +472,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
             return V2V_EINVAL;
         }
         k.res0 = (const char*)d->res0; k.res1 = (const char*)d->res1;
+        k.status = launching ? status_word() : nullptr;
     }
     if (d->fin_counter) {
         if (!d->stats || !d->fin_scale_shift || d->fin_count <= 0 ||
@@ -608,6 +628,14 @@ extern "C" int v2v_fastdiv_magic(uint32_t d, uint32_t* m_out, int32_t* l_out) {
     *m_out = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
     *l_out = l;
     return 0;
+}
+
+extern "C" int v2v_device_status(int32_t clear) {
+    int* w = status_word();
+    if (w == nullptr) return 0;
+    const int v = __atomic_load_n(w, __ATOMIC_RELAXED);
+    if (clear && v) __atomic_fetch_and(w, 0, __ATOMIC_RELAXED);
+    return v;
 }
 
 static int fused_norm_resident(const ConvOp* op) {

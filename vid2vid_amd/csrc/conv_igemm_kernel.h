@@ -54,6 +54,7 @@ struct ConvKArgs {
     const char* res0; const char* res1;   // V2V_OUT_NORM_ACT_NHWC: residuals added after the activation (or NULL)
     // exact division of 0 <= n < 2^31 by the class grid sizes: q = (umulhi(M, n) + n) >> l (v2v_fastdiv_magic), [class][0: OHc*OWc, 1: OWc]
     unsigned div_m[4][2]; int div_l[4][2];
+    int* status;         // host-mapped status word of the library (v2v_device_status) or NULL: bit 0 = a fused-norm barrier gave up
     ConvGroupPtrs g1;    // grouped launch (conv3x3_pp2_kernel): operands of block z == 1
 };
 
@@ -288,11 +289,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             int* const flag = reinterpret_cast<int*>(smem + 16384);
             if (tid == 0) {
                 int* const arrive = p.fin_counter + nt;
-                int ok = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1 ? 1 : 0;
+                // ablate 2048 (test of the give-up path): the first workgroup of the channel tile never arrives
+                const int inc = ((p.ablate & 2048) && stat_row == 0) ? 0 : 1;
+                int ok = __hip_atomic_fetch_add(arrive, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1 ? 1 : 0;
                 for (int it = 0; !ok && it < (1 << 20); ++it) {    // bounded (~1 s): a barrier that cannot complete gives up
                     __builtin_amdgcn_s_sleep(1);
                     ok = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total ? 1 : 0;
                 }
+                if (!ok && p.status) __hip_atomic_fetch_or(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 *flag = ok;
             }
             __syncthreads();

@@ -21,8 +21,8 @@ struct EncodeArgs {
     int T, H, W, label_nc, c_stride; const int* fg; int n_fg;
 };
 
-// One thread per (pixel, 16-byte vector of output channels).  A vector spans at most two label frames (36 channels per
-// frame, 4 or 8 channels per vector): their labels are loaded ONCE per thread, the instance-edge test runs only for a
+// One thread per (pixel, 16-byte vector of output channels).  A vector usually spans at most two label frames (36 channels
+// per frame, 4 or 8 channels per vector): their labels are loaded ONCE per thread, the instance-edge test runs only for a
 // vector that holds an edge channel, and the vector leaves as ONE 16-byte store (round 1 issued 8 two-byte stores per
 // thread and re-read the label per channel: 45 us for the 33 MB output at 512x256, 7x off the HBM rate).
 // LT / IT: element types of the label / instance maps -- float (the reference's loader hands integers encoded as
@@ -48,12 +48,16 @@ __global__ __launch_bounds__(256) void encode_labels_kernel(const EncodeArgs a) 
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             const int ch = c0 + q;
-            const int t = ch >= (t0 + 1) * per_frame ? t1 : t0;
+            // a vector spans two frames at most when per_frame >= VEC - 1 (every label2city / face recipe); with fewer
+            // channels per frame (label_nc <= 6 in bf16) it can span three or more: those middle frames' labels are
+            // loaded on demand (they used to be attributed to t1 and silently encoded as 0)
+            const int t = ch >= (t0 + 1) * per_frame ? (ch >= t1 * per_frame ? t1 : ch / per_frame) : t0;
             const int c = ch - t * per_frame;
             float val = 0.f;
             if (t < a.T) {
                 if (c < a.label_nc) {
-                    val = ((t == t0 ? lab0 : lab1) == c) ? 1.f : 0.f;
+                    const int lab = t == t0 ? lab0 : (t == t1 ? lab1 : (int)labels[t * hw + pix]);
+                    val = (lab == c) ? 1.f : 0.f;
                 } else {
                     // instance-boundary edge: 4-neighbour inequality (models/base_model.py:146-152)
                     const int y = (int)(pix / a.W), x = (int)(pix - (long long)y * a.W);

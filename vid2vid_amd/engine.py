@@ -140,12 +140,16 @@ class PackedConv:
 
     def refresh(self, force=False):
         """(Re)pack if the parameter changed (optimizer step / load_state_dict)."""
-        w = self.mod.weight
-        box = getattr(w, "_v2v_epoch", None)       # optim.FlatBuffers: bumped by the fused optimizer that owns `w`
-        ver = (w._version, w.data_ptr(), None if self.mod.bias is None else self.mod.bias._version, _PARAM_EPOCH[0],
-               0 if box is None else box[0])
-        if not force and ver == self.version:
-            return
+        if hasattr(self.mod, "version_key"):       # MergedConv: `weight` is a fresh torch.cat on every read (version 0, recycled
+            ver = self.mod.version_key()           # address) -- the key comes from the two source layers (ADVICE r2)
+            if not force and ver == self.version:
+                return
+            w = self.mod.weight
+        else:
+            w = self.mod.weight
+            ver = _param_version(self.mod)
+            if not force and ver == self.version:
+                return
         w32 = w.detach()
         src_cl = (w32.dtype == torch.float32 and w32.dim() == 4 and not w32.is_contiguous()
                   and w32.permute(0, 2, 3, 1).is_contiguous())          # optim.FlatBuffers: channels-last master weights
@@ -158,6 +162,16 @@ class PackedConv:
         if self.role == "fwd":
             self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()
         self.version = ver
+
+
+def _param_version(mod):
+    """What changes when a layer's weight / bias changes: torch's version counters (in-place writes, load_state_dict),
+    the storage address (re-homing into flat buffers), and the update counter of the fused optimizer that owns the
+    parameter (optim.FlatBuffers.epoch: its HIP kernel writes are invisible to torch)."""
+    w = mod.weight
+    box = getattr(w, "_v2v_epoch", None)
+    return (w._version, w.data_ptr(), None if mod.bias is None else mod.bias._version, _PARAM_EPOCH[0],
+            0 if box is None else box[0])
 
 
 class MergedConv:
@@ -173,6 +187,9 @@ class MergedConv:
         self.kernel_size, self.stride, self.padding, self.groups = a.kernel_size, a.stride, a.padding, a.groups
         self.in_channels, self.out_channels = a.in_channels, a.out_channels + b.out_channels
         self.output_padding = (0, 0)
+
+    def version_key(self):
+        return _param_version(self.a) + _param_version(self.b)
 
     @property
     def weight(self):
@@ -334,6 +351,11 @@ class Engine:
             # dry run: every v2v_* call still validates its arguments, nothing is ever launched (include/v2v_hip.h,
             # v2v_set_dry_run) -- lets the CPU test-suite drive whole training / inference control flows
             lib.v2v_set_dry_run(1)
+        elif lib.v2v_get_dry_run():
+            # the dry-run switch is process-wide: with it set, every launch, plan run and optimizer step of THIS engine
+            # would return success without executing anything -- refuse instead of computing nothing
+            raise RuntimeError("v2v dry-run mode is on (a record-only Engine was created in this process): call "
+                               "vid2vid_amd.networks.set_record_only(False) before creating a GPU engine")
         self.dtype = dtype
         self.tdtype = _TORCH_DTYPE[dtype]
         self.align_corners = align_corners

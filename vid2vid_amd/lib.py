@@ -156,6 +156,7 @@ PROTOTYPES = {
     "v2v_get_dry_run": (C.c_int, []),
     "v2v_version": (C.c_int, []),
     "v2v_last_error": (C.c_char_p, []),
+    "v2v_device_status": (C.c_int, [_I]),
     "v2v_device_info": (C.c_int, [C.POINTER(_I), C.POINTER(_I), C.POINTER(_L), C.c_char_p, _I]),
 }
 

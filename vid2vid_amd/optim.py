@@ -124,7 +124,7 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         from .lib import lib, check
         if self.grad_sync is not None:
-            self.grad_sync.wait_pending()            # an overlapped step of the previous chunk still reads the gradients
+            self.grad_sync.wait_pending(owner=self)  # only THIS optimizer's overlapped step still reads these gradients
         self.flat.rebind_grads()
         g = self.flat.flat_grad
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if g.is_cuda else None
@@ -157,7 +157,7 @@ class FusedAdam(torch.optim.Optimizer):
 
         gs = self.grad_sync
         if gs is not None and f.flat_param.is_cuda and (gs.world > 1 or gs.force_collective):
-            gs.run_overlapped(f.flat_grad, adam)     # RCCL all-reduce + Adam on the side stream, behind this backward pass
+            gs.run_overlapped(f.flat_grad, adam, owner=self)     # RCCL all-reduce + Adam on the side stream, behind this backward pass
         else:
             adam(gs.all_reduce(f.flat_grad) if gs is not None else 1.0, None)
         f.epoch[0] += 1                                      # packed copies of THESE parameters are now stale

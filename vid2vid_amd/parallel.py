@@ -58,7 +58,7 @@ class GradSync:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.force_collective = force_collective     # run the collective even for a world of 1 (single-GPU RCCL test)
         self._stream = None
-        self._pending = []                           # events of enqueued (all-reduce + Adam) pairs
+        self._pending = {}                           # owner (an optimizer) -> event of its enqueued (all-reduce + Adam) pair
 
     @property
     def world(self):
@@ -86,9 +86,11 @@ class GradSync:
             self._stream = torch.cuda.Stream(device=device)
         return self._stream
 
-    def run_overlapped(self, flat, fn):
+    def run_overlapped(self, flat, fn, owner=None):
         """Enqueue all_reduce(flat) followed by fn(grad_scale, stream) on the side stream, ordered after everything already
-        on the current stream; returns immediately.  fn launches the optimizer kernel on the stream it is handed."""
+        on the current stream; returns immediately.  fn launches the optimizer kernel on the stream it is handed.  The
+        completion event is filed under `owner` (the optimizer): that optimizer's next zero_grad waits for ITS event only,
+        so optimizer_D.zero_grad() / backward (train.py:89-90) really run beside G's all-reduce."""
         cur = torch.cuda.current_stream(flat.device)
         side = self.side_stream(flat.device)
         side.wait_stream(cur)
@@ -97,17 +99,31 @@ class GradSync:
             fn(scale, side)
             ev = torch.cuda.Event()
             ev.record(side)
-        self._pending.append(ev)
+        key = id(owner) if owner is not None else None
+        old = self._pending.pop(key, None)
+        if old is not None:                          # same owner stepped twice without a wait in between: side-stream order
+            pass                                     # already serialises the two pairs, the newer event covers the older
+        self._pending[key] = ev
 
-    def wait_pending(self, device=None):
-        """The current stream waits for every enqueued (all-reduce + optimizer) pair: call before parameters or gradient
-        buffers are read or written again."""
+    def pending(self, owner=None):
+        """True while an enqueued pair of `owner` (any owner if None) has not been waited for (test hook)."""
+        return bool(self._pending) if owner is None else id(owner) in self._pending
+
+    def wait_pending(self, device=None, owner=None):
+        """The current stream waits for the enqueued (all-reduce + optimizer) pairs: all of them (before ANY parameter is
+        read again: RankModel.forward, checkpoint saving) or, with `owner`, only that optimizer's (before its gradient
+        buffer is zeroed / written again)."""
         if not self._pending:
             return
         cur = torch.cuda.current_stream(device)
-        for ev in self._pending:
+        if owner is not None:
+            ev = self._pending.pop(id(owner), None)
+            if ev is not None:
+                cur.wait_event(ev)
+            return
+        for ev in self._pending.values():
             cur.wait_event(ev)
-        self._pending = []
+        self._pending = {}
 
     def broadcast(self, flat, src=0):
         if self.world > 1:
