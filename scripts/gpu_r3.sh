@@ -47,8 +47,8 @@ if has r3new; then      # round-3 additions: ADVICE fixes, barrier give-up repor
   lap r3new
 fi
 if has benchdefault; then    # the driver's command, timed
-  /usr/bin/time -v timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$?"
-  grep -E "Elapsed|Maximum resident" gpurun_out/${TAG}_bench_default.err
+  TB=$(date +%s)
+  timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$? wall $(( $(date +%s) - TB )) s"
   python - <<PY
 import json
 j = json.load(open("gpurun_out/${TAG}_bench_default.json"))

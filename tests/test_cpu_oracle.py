@@ -1,6 +1,7 @@
 """The oracle (oracle/vid2vid_oracle.py) pinned against outputs of the REFERENCE itself
 (tests/golden/*.npz, produced by tests/golden/make_golden.py).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import vid2vid_oracle as O
@@ -166,6 +167,69 @@ def test_native_ops_two_independent_restatements_agree():
     assert np.abs(O.channelnorm(T(x)).numpy() - S2.channelnorm_forward(x)).max() <= 1e-6
     x2 = rs.randn(1, 2, 4, 4).astype(np.float32)                      # the 2-channel (flow) use, models.py:137,150
     assert np.abs(O.channelnorm(T(x2)).numpy() - S2.channelnorm_forward(x2)).max() <= 1e-6
+
+
+def _ref_ops():
+    from oracle import ref_ops as R
+    if not R.available():
+        pytest.skip("oracle/_ref/libref_ops.so not built and /root/reference absent")
+    return R
+
+
+def test_native_op_oracles_vs_executed_reference_kernels():
+    """The PIN of the three CUDA-only ops: the reference's own kernel bodies (correlation_cuda_kernel.cu:16-147,
+    resample2d_kernel.cu:15-190, channelnorm_kernel.cu:18-96), compiled unmodified from /root/reference by
+    oracle/ref_ops/build.sh and executed on host cores with 32-lane warp semantics (oracle/ref_ops/cuda_emu.h), against
+    both restatements -- FlowNetC's geometry (pad 20, displacement 20, stride2 2, FlowNetC.py:31), > 32 channels (second trip
+    of the per-lane channel walk), a 3x3 kernel with stride1 2, flows that leave the image, backward kernels against the
+    autograd of the restatement.  Only the fp32 summation order may differ: 1e-6."""
+    import numpy as np
+    from oracle import native_ops_scalar as S2
+    R = _ref_ops()
+    rs = np.random.RandomState(17)
+    for (n, c, h, w, pad, k, disp, s1, s2) in [(1, 40, 4, 6, 20, 1, 20, 1, 2), (2, 5, 5, 7, 4, 1, 4, 1, 2), (1, 3, 9, 10, 3, 3, 2, 2, 1),
+                                               (1, 7, 6, 6, 2, 1, 2, 1, 1)]:
+        a, b = T(rs.randn(n, c, h, w).astype(np.float32)), T(rs.randn(n, c, h, w).astype(np.float32))
+        ref = R.correlation(a, b, pad, k, disp, s1, s2)
+        got = O.correlation(a, b, pad, k, disp, s1, s2)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        scale = max(1.0, ref.abs().max().item())
+        assert (got - ref).abs().max().item() <= 1e-6 * scale, ("vectorised oracle", c, h, w, pad, k, disp, s1, s2)
+        got2 = T(S2.correlation_forward(a.numpy(), b.numpy(), pad, k, disp, s1, s2))
+        assert (got2 - ref).abs().max().item() <= 1e-6 * scale, ("scalar transliteration", c, h, w, pad, k, disp, s1, s2)
+    img = T(rs.randn(2, 3, 7, 9).astype(np.float32))
+    flow = T((rs.randn(2, 2, 7, 9) * 3.0).astype(np.float32))
+    flow[0, :, 0, 0] = T(np.array([-0.25, -0.75], np.float32)); flow[0, :, 6, 8] = 0.5; flow[1, :, 3, 4] = T(np.array([2.0, -1.0], np.float32))
+    for ks in (1, 2):
+        ref = R.resample2d(img, flow, ks)
+        if ks == 1:
+            assert (O.resample2d(img, flow) - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+            assert (T(S2.resample2d_forward(img.numpy(), flow.numpy())) - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    # output at the flow's resolution (resample2d.py:14-17: the output takes the flow's spatial size)
+    flow_s = T((rs.randn(2, 2, 5, 6) * 2.0).astype(np.float32))
+    assert R.resample2d(img, flow_s).shape == (2, 3, 5, 6)
+    # backward kernels: d img (atomic scatter of the bilinear weights), d flow -- against autograd of the restatement,
+    # away from integer sample positions and borders where the kernel's one-sided differences and autograd's subgradients differ
+    imgb = T(rs.randn(1, 3, 12, 14).astype(np.float32))
+    fl = T((rs.rand(1, 2, 12, 14).astype(np.float32) * 0.8 + 0.1))
+    fl[:, :, :3] *= -1.0                                              # negative flows too (floor vs truncation in the alpha of :93-94)
+    fl[:, :, :, :2] = 0.5; fl[:, :, :2] = 0.5; fl[:, :, -2:] = -0.5; fl[:, :, :, -2:] = -0.5          # keep every sample inside the image
+    gout = T(rs.randn(1, 3, 12, 14).astype(np.float32))
+    ia, fa = imgb.clone().requires_grad_(True), fl.clone().requires_grad_(True)
+    O.resample2d(ia, fa).backward(gout)
+    g_img, g_flow = R.resample2d_backward(imgb, fl, gout)
+    # the backward kernel's alpha = xf - int(xf) (:93-94) is the forward's xf - floor(xf) only for xf >= 0: rows >= 3 here
+    assert (g_flow - fa.grad).abs().max().item() <= 1e-5 * fa.grad.abs().max().item(), "d flow"
+    assert (g_img[:, :, 4:-3] - ia.grad[:, :, 4:-3]).abs().max().item() <= 1e-5 * ia.grad.abs().max().item(), "d img (non-negative positions)"
+    x = T(rs.randn(2, 3, 5, 6).astype(np.float32))
+    ref = R.channelnorm(x)
+    assert (O.channelnorm(x) - ref).abs().max().item() <= 1e-6 and (T(S2.channelnorm_forward(x.numpy())) - ref).abs().max().item() <= 1e-6
+    x2 = T(rs.randn(1, 2, 4, 4).astype(np.float32))                   # the 2-channel (flow) use, models.py:137,150
+    assert (O.channelnorm(x2) - R.channelnorm(x2)).abs().max().item() <= 1e-6
+    xa = x.clone().requires_grad_(True)
+    go = T(rs.randn(2, 1, 5, 6).astype(np.float32))
+    O.channelnorm(xa).backward(go)
+    assert (R.channelnorm_backward(x, ref, go) - xa.grad).abs().max().item() <= 1e-5
 
 
 def test_flownet2_oracle_vs_reference_composition(golden):

@@ -399,7 +399,8 @@ def test_fused_norm_barrier_timeout_is_reported():
     lib.v2v_device_status(1)
 
     def run():
-        y = eng.conv_group_pair(xa[0], convs[0], norms[0], xa[1], convs[1], norms[1], L.PAD_REFLECT, 1, L.ACT_RELU, 0.0,
+        # no activation: fmaxf(NaN, 0) = 0, a ReLU would hide the poison (the status word does not depend on it)
+        y = eng.conv_group_pair(xa[0], convs[0], norms[0], xa[1], convs[1], norms[1], L.PAD_REFLECT, 1, L.ACT_NONE, 0.0,
                                 labels=("a", "b"))
         assert eng.conv_log[-1]["fused_norm"]
         torch.cuda.synchronize()
@@ -681,7 +682,7 @@ def test_encode_labels_few_classes(nc, use_inst, prec):
     lab = torch.randint(0, nc, (T, H, W)).float()
     inst = torch.randint(0, 4, (T, H // 4 + 1, W // 4 + 1)).repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :H, :W].float()
     enc = O.encode_input(lab.view(1, T, 1, H, W), inst.view(1, T, 1, H, W) if use_inst else None, nc)
-    x, mask = eng.encode_labels(lab.to(DEV), inst.to(DEV) if use_inst else None, T, H, W, nc, [0], use_inst)
+    x, mask = eng.encode_labels(lab.to(DEV), inst.to(DEV) if use_inst else None, T, H, W, nc, [0], True)
     got = eng.unpack(x).cpu()
     assert torch.equal(got, enc.reshape(1, -1, H, W))
     assert torch.equal(mask.cpu(), O.compute_mask(enc, T - 1, [0]).reshape(1, 1, H, W))
@@ -827,6 +828,38 @@ def test_flownet2_native_ops():
     lib.check(lib.lib.v2v_channelnorm_forward(P(xd), P(out), 2, 3, 21, 33, 2, s), "channelnorm")
     assert_close(out.cpu(), O.channelnorm(x), 1e-6, "channelnorm")
     assert_close(out.cpu(), torch.from_numpy(S2.channelnorm_forward(x.numpy())), 1e-6, "channelnorm vs scalar transliteration")
+
+
+def test_flownet2_native_ops_vs_executed_reference_kernels():
+    """The HIP kernels against the reference's OWN CUDA kernel bodies executed on host cores (oracle/ref_ops.py: compiled
+    from /root/reference by oracle/ref_ops/build.sh, 32-lane warp semantics; the library travels with the snapshot):
+    correlation on FlowNetC's geometry (the LDS-staged fast path, > 1 channel chunk, ragged width) and on the generic
+    path, Resample2d incl. flows that leave the image and an output at the flow's resolution, ChannelNorm."""
+    import ctypes as C
+    from oracle import ref_ops as R
+    from vid2vid_amd import lib
+    if not R.available():
+        pytest.skip("oracle/_ref/libref_ops.so was not shipped")
+    torch.manual_seed(19)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (n, c, h, w, pad, k, md, s1, s2) in [(1, 72, 5, 9, 20, 1, 20, 1, 2), (2, 9, 6, 5, 4, 1, 4, 1, 2), (1, 6, 9, 11, 4, 3, 4, 2, 1)]:
+        a, b = torch.randn(n, c, h, w), torch.randn(n, c, h, w)
+        ref = R.correlation(a, b, pad, k, md, s1, s2)
+        out = torch.full(ref.shape, float("nan"), device=DEV)
+        ad, bd = a.to(DEV), b.to(DEV)
+        lib.check(lib.lib.v2v_correlation_forward(P(ad), P(bd), P(out), n, c, h, w, pad, k, md, s1, s2, 1, s), "corr")
+        assert_close(out.cpu(), ref, 1e-5, "correlation vs the reference kernel %s" % ((n, c, h, w, pad, k, md, s1, s2),))
+    img, fl = torch.randn(2, 3, 13, 17), torch.randn(2, 2, 13, 17) * 5
+    out = torch.empty(2, 3, 13, 17, device=DEV)
+    imd, fld = img.to(DEV), fl.to(DEV)
+    lib.check(lib.lib.v2v_resample2d_forward(P(imd), P(fld), P(out), 2, 3, 13, 17, 13, 17, 1, s), "resample2d")
+    assert_close(out.cpu(), R.resample2d(img, fl), 1e-5, "resample2d vs the reference kernel")
+    x = torch.randn(2, 3, 13, 17)
+    out = torch.empty(2, 1, 13, 17, device=DEV)
+    xd = x.to(DEV)
+    lib.check(lib.lib.v2v_channelnorm_forward(P(xd), P(out), 2, 3, 13, 17, 2, s), "channelnorm")
+    assert_close(out.cpu(), R.channelnorm(x), 1e-6, "channelnorm vs the reference kernel")
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
