@@ -469,6 +469,9 @@ int       v2v_plan_lane_wait(int32_t waiter, int32_t signal);
  * x*255, clipped, truncated) or uint8 [H][W][3] (tensor2label: argmax over C > 1 planes or the stored id for C == 1,
  * coloured through cmap[n_label][3]).  Integer-exact against the reference's numpy arithmetic. */
 int v2v_tensor2im(const float* x, uint8_t* out, int32_t C, int32_t H, int32_t W, int32_t normalize, void* stream);
+/* tensor2flow (util/util.py:89-107): flow planar fp32 [2][H][W] -> uint8 [H][W][3], hue = direction / 2 degrees, value = magnitude
+ * min-max normalised over the image, full saturation, HSV -> RGB as OpenCV's 8-bit conversion.  range_ws: 2 uint32 of scratch. */
+int v2v_tensor2flow(const float* flow, uint8_t* out, uint32_t* range_ws, int32_t H, int32_t W, void* stream);
 int v2v_tensor2label(const float* x, uint8_t* out, const uint8_t* cmap, int32_t n_label, int32_t C, int32_t H, int32_t W,
                      void* stream);
 

@@ -782,3 +782,47 @@ def generate_frames_train(sds, real_A_all, real_B_all, fg, fg_labels, n_down, n_
             if s == S - 1:
                 raws.append(raw.unsqueeze(1)); flows.append(flow.unsqueeze(1)); weights.append(weight.unsqueeze(1))
     return fakes[0][:, tG - 1:], torch.cat(raws, 1), torch.cat(flows, 1), torch.cat(weights, 1)
+
+
+# --------------------------------------------------------------------------------------
+# visualisation: tensor2flow (util/util.py:89-107)
+# --------------------------------------------------------------------------------------
+def tensor2flow(output):
+    """util/util.py:89-107 restated in numpy.  The reference calls OpenCV (opencv-python, unpinned in docker/Dockerfile and
+    absent from /root/reference and from this image: PARITY UNPINNED for this helper), so its three calls are restated
+    from OpenCV's published definitions:
+      cv2.cartToPolar(x, y)            -> mag = sqrt(x^2 + y^2), ang = atan2(y, x) in [0, 2 pi)  (OpenCV's fastAtan2 is a
+                                          polynomial with ~0.3 degree error; the exact angle is used here, so a hue level may
+                                          differ by one from a run of the reference with a given OpenCV build)
+      cv2.normalize(mag, None, 0, 255, NORM_MINMAX) -> (mag - min) * 255 / (max - min)   (0 for a constant image)
+      cv2.cvtColor(hsv, COLOR_HSV2RGB) for uint8    -> H in half degrees, S = V = x / 255, the six-sector (v, p, q, t)
+                                          table, * 255 rounded to nearest
+    numpy stores of floats into the uint8 `hsv` array truncate.  Returns uint8 (H, W, 3)."""
+    import numpy as np
+    t = output
+    if t.dim() == 5:
+        t = t[0, -1]
+    if t.dim() == 4:
+        t = t[0]
+    f = np.transpose(t.detach().cpu().float().numpy(), (1, 2, 0))
+    fx, fy = f[..., 0], f[..., 1]
+    mag = np.sqrt(fx * fx + fy * fy).astype(np.float32)
+    ang = np.arctan2(fy, fx).astype(np.float32)
+    ang = np.where(ang < 0, ang + np.float32(2 * np.pi), ang).astype(np.float32)
+    H8 = (ang * np.float32(180.0) / np.float32(np.pi) / np.float32(2.0)).astype(np.int32) & 255
+    mn, mx = mag.min(), mag.max()
+    scale = np.float32(255.0) / (mx - mn) if (mx - mn) > 1.1920929e-07 else np.float32(0.0)
+    V8 = ((mag - mn) * scale).astype(np.int32) & 255
+    v = V8.astype(np.float32) * np.float32(1.0 / 255.0)
+    h = H8.astype(np.float32) * np.float32(6.0 / 180.0)
+    sector = np.floor(h).astype(np.int32)
+    fr = h - sector.astype(np.float32)
+    sector = sector % 6
+    tab = np.stack([v, np.zeros_like(v), v * (np.float32(1.0) - fr), v * fr], -1)
+    sd = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])          # (b, g, r)
+    idx = sd[sector]
+    b = np.take_along_axis(tab, idx[..., 0:1], -1)[..., 0]
+    g = np.take_along_axis(tab, idx[..., 1:2], -1)[..., 0]
+    r = np.take_along_axis(tab, idx[..., 2:3], -1)[..., 0]
+    rgb = np.stack([r, g, b], -1) * np.float32(255.0)
+    return np.rint(np.clip(rgb, 0, 255)).astype(np.uint8)

@@ -61,3 +61,20 @@ PY
   tail -5 gpurun_out/${TAG}_bench_default.err | cut -c1-300
   lap benchdefault
 fi
+if has retune; then     # new tile selections (K-pair tiles eligible) for 512x256 AND the 2048x1024 / 3-scale companion, one cache
+  rm -f gpurun_out/${TAG}_tune.json
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune.json timeout 1500 python bench.py --retune --no-cpu-baseline --no-train-line --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_bench_retune.json 2> gpurun_out/${TAG}_bench_retune.err; echo "retune rc=$?"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_bench_retune.json'))
+print('value', j['value'], j['ms_per_step'], j['timing']['windows_ms_per_step']); print(j['roofline']['kernel'], j['roofline']['frac'], j['roofline']['avg_launch_us'])
+print('hires', j['hires']['value'], j['hires']['ms_per_step'], j['hires']['plan_build_s'], j['hires']['roofline']['slowest_configs_ms'])"
+  tail -3 gpurun_out/${TAG}_bench_retune.err | cut -c1-300
+  lap retune
+  cp gpurun_out/${TAG}_tune.json /tmp/tune_new.json
+  V2V_TUNE_CACHE=/tmp/tune_new.json timeout 900 python bench.py --no-cpu-baseline --no-train-line > gpurun_out/${TAG}_bench_replay.json 2> gpurun_out/${TAG}_bench_replay.err; echo "replay rc=$?"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_bench_replay.json'))
+print('replay value', j['value'], j['ms_per_step'], j['timing']['windows_ms_per_step']); print(j['roofline']['kernel'], j['roofline']['frac'], j['roofline']['avg_launch_us'])
+print('hires', j['hires']['value'], j['hires']['ms_per_step'], j['hires']['plan_build_s'])"
+  lap replay
+fi

@@ -925,3 +925,27 @@ def test_visualisation_kernels_equal_reference_numpy(golden):
         w.save(visual.tensor2label(d("lab35.x"), 35), os.path.join(tmp, "l%d.png" % i))
     w.close()
     assert np.array_equal(np.asarray(Image.open(os.path.join(tmp, "l3.png"))), g["lab35.rgb"])
+
+
+def test_tensor2flow_equals_numpy_restatement():
+    """visual.tensor2flow (util/util.py:89-107; OpenCV is absent, oracle.tensor2flow restates its three calls -- parity
+    unpinned for this helper, stated there): hue / value levels are integers derived from float32 atan2 / sqrt, so the device
+    and numpy results may differ by one level where a value sits on a truncation boundary; everything else is exact.
+    Known answers: +x red, +y (down) chartreuse, -x cyan, zero flow black."""
+    import numpy as np
+    from oracle import vid2vid_oracle as O
+    from vid2vid_amd import visual
+    torch.manual_seed(3)
+    for shape in [(1, 2, 37, 53), (2, 64, 96), (1, 3, 2, 16, 24)]:
+        f = torch.randn(*shape) * 4.0
+        got = visual.to_numpy(visual.tensor2flow(f.to(DEV)))
+        ref = O.tensor2flow(f)
+        assert got.shape == ref.shape and got.dtype == np.uint8
+        diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        assert (diff > 0).mean() < 2e-2 and diff.max() <= 9, (float((diff > 0).mean()), int(diff.max()))    # one hue level = up to 8.5 in a channel
+    f = torch.zeros(2, 2, 2); f[0, 0, 0] = 1; f[1, 0, 1] = 1; f[0, 1, 0] = -1
+    got = visual.to_numpy(visual.tensor2flow(f.to(DEV)))
+    assert got[0, 0].tolist() == [255, 0, 0] and got[1, 0].tolist() == [0, 255, 255] and got[1, 1].tolist() == [0, 0, 0]
+    assert abs(int(got[0, 1, 0]) - 127) <= 1 and got[0, 1, 1] == 255 and got[0, 1, 2] == 0
+    const = torch.ones(2, 8, 8)                                   # constant magnitude: cv2.normalize maps it to 0
+    assert visual.to_numpy(visual.tensor2flow(const.to(DEV))).max() == 0 and O.tensor2flow(const).max() == 0

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "v2v_instance_mean_planar": (C.c_int, [_P, _P, _P, _P, _I, _L, _P]),
     "v2v_tensor2im": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "v2v_tensor2label": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "v2v_tensor2flow": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "v2v_onehot_conv_table_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "v2v_onehot_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_onehot_conv_stats_rows": (C.c_int, [_I, _I]),

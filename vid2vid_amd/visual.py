@@ -7,6 +7,7 @@ does not stall a generator that runs at hundreds of frames per second.
 
     tensor2im(t, normalize=True)  -> uint8 device tensor (H, W, C) or (H, W) for one plane      (util/util.py:48-71)
     tensor2label(t, n_label)      -> uint8 device tensor (H, W, 3)                              (util/util.py:73-87)
+    tensor2flow(t)                -> uint8 device tensor (H, W, 3), HSV-coded flow picture      (util/util.py:89-107)
     to_numpy(img)                 -> what the reference's function returns (numpy uint8)
 """
 import ctypes as C
@@ -84,6 +85,20 @@ def tensor2label(output, n_label):
     out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
     check(lib.v2v_tensor2label(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(_CMAPS[key].data_ptr()),
                                n_label, Cc, H, W, _stream(x)), "tensor2label")
+    return out
+
+
+def tensor2flow(output):
+    """util/util.py:89-107 (used by save_all_tensors :38-41 for `flow_ref` and `flow`): direction -> hue, magnitude (min-max
+    normalised over the image) -> value.  The reference computes it with OpenCV on the host after a D2H copy of the flow."""
+    x = _planes(output)
+    if x.shape[0] != 2:
+        raise ValueError("tensor2flow expects 2 flow planes, got %d" % x.shape[0])
+    _, H, W = x.shape
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(2, dtype=torch.int32, device=x.device)
+    check(lib.v2v_tensor2flow(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), H, W, _stream(x)),
+          "tensor2flow")
     return out
 
 
