@@ -26,8 +26,28 @@ class RankModel(nn.Module):
         return self.module(*inputs, **kwargs)
 
 
-def wrap_model(opt, modelG, modelD, flowNet):
+def wrap_model(opt, modelG, modelD, flowNet, layout=None):
+    """reference models/models.py:10-23.  `--n_gpus_gen` smaller than the number of GPUs of a sequence group selects the
+    generator / discriminator rank roles (vid2vid_amd/roles.py); otherwise every rank trains G and D on its own sequence."""
+    if layout is not None:
+        from ..roles import wrap_roles
+        return wrap_roles(opt, modelG, modelD, flowNet, layout)
     return RankModel(opt, modelG), RankModel(opt, modelD), RankModel(opt, flowNet)
+
+
+def _role_layout(opt):
+    """One process per GPU: `--gpu_ids` (the reference's list of the GPUs that share ONE sequence) becomes the size of a
+    sequence group and this process keeps its own device only."""
+    import os
+    from .. import roles
+    layout = roles.layout_from_opt(opt) if opt.isTrain else None
+    if layout is not None:
+        opt.role_group_size = layout.group_size
+        local = int(os.environ.get("LOCAL_RANK", layout.rank))
+        opt.gpu_ids = [opt.gpu_ids[local % len(opt.gpu_ids)]]
+        print("vid2vid_amd: rank %d = %s-rank %d of sequence group %d (%d generator + %d discriminator ranks per sequence)"
+              % (layout.rank, layout.role, layout.g if layout.role == "G" else layout.d, layout.seq, layout.n_gen, layout.n_disc))
+    return layout
 
 
 def create_model(opt):
@@ -35,6 +55,7 @@ def create_model(opt):
     if opt.model != "vid2vid":
         raise ValueError("Model [%s] not recognized." % opt.model)
     from .vid2vid_model_G import Vid2VidModelG
+    layout = _role_layout(opt)
     modelG = Vid2VidModelG()
     if opt.isTrain:
         from .vid2vid_model_D import Vid2VidModelD
@@ -45,7 +66,7 @@ def create_model(opt):
     if opt.isTrain:
         modelD.initialize(opt)
         flowNet.initialize(opt)
-        modelG, modelD, flowNet = wrap_model(opt, modelG, modelD, flowNet)
+        modelG, modelD, flowNet = wrap_model(opt, modelG, modelD, flowNet, layout)
         return [modelG, modelD, flowNet]
     return modelG
 

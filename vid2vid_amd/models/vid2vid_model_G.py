@@ -272,12 +272,13 @@ class Vid2VidModelG(BaseModel):
         BaseModel.initialize(self, opt)
         self.n_scales = opt.n_scales_spatial
         self.use_single_G = opt.use_single_G
-        self.split_gpus = (opt.n_gpus_gen < len(opt.gpu_ids)) and (opt.batchSize == 1)
-        if self.split_gpus:
-            # reference :37-45 moves D / FlowNet2 to the GPUs behind n_gpus_gen because a chunk does not fit a 32 GB device; a rank
-            # here owns one 288 GB GPU and holds G, D and FlowNet2 itself: the option is accepted, not acted on
-            print("vid2vid_amd: n_gpus_gen < len(gpu_ids) (generator / discriminator device split) is not needed on 288 GB GPUs "
-                  "and is ignored: every rank trains G and D on its own GPU")
+        # reference :37-45: n_gpus_gen < len(gpu_ids) puts G on n_gpus_gen GPUs and D / FlowNet2 on the rest.  With one process per
+        # GPU that is a rank-role layout (vid2vid_amd/roles.py, set up by create_model before this runs: opt.gpu_ids is then this
+        # rank's own device and opt.role_group_size the reference's GPU count); a single process cannot drive several GPUs here
+        self.split_gpus = bool(getattr(opt, "role_group_size", 0))
+        if (opt.n_gpus_gen < len(opt.gpu_ids)) and (opt.batchSize == 1) and opt.isTrain:
+            raise RuntimeError("n_gpus_gen=%d < %d GPUs selects the generator / discriminator rank roles: launch one process per GPU "
+                               "(python -m torch.distributed.run --nproc-per-node %d train.py ...)" % (opt.n_gpus_gen, len(opt.gpu_ids), len(opt.gpu_ids)))
 
         input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
         netG_input_nc = input_nc * opt.n_frames_G
@@ -491,8 +492,10 @@ class Vid2VidModelG(BaseModel):
         real_B = None if real_image is None else real_image.to(dev, torch.float32)
         return real_A, real_B, None
 
-    def forward(self, input_A, input_B, inst_A, fake_B_prev, dummy_bs=0):
-        """n_frames_load frames with autograd (reference :114-137).  Returns the reference's 7-tuple."""
+    def forward(self, input_A, input_B, inst_A, fake_B_prev, dummy_bs=0, frame_range=None):
+        """n_frames_load frames with autograd (reference :114-137).  Returns the reference's 7-tuple.
+        frame_range=(t0, t1) (roles.py, a generator rank of a sequence group): only frames t0..t1-1 of the chunk, `fake_B_prev`
+        being the tG-1 frames just before t0; fake_B / fake_B_raw / flow / weight then hold t1-t0 frames."""
         tG = self.opt.n_frames_G
         if dummy_bs:
             input_A, input_B, inst_A, fake_B_prev = [None if t is None else t[dummy_bs:] for t in
@@ -504,7 +507,7 @@ class Vid2VidModelG(BaseModel):
         if is_first_frame:
             with torch.no_grad():
                 fake_B_prev = self._first_frames_train(real_A_all, real_B_all)
-        fake_B, fake_B_raw, flow, weight = self.generate_frame_train(real_A_all, list(fake_B_prev), is_first_frame)
+        fake_B, fake_B_raw, flow, weight = self.generate_frame_train(real_A_all, list(fake_B_prev), is_first_frame, frame_range)
         fake_B_prev = [B[:, -tG + 1:].detach() for B in fake_B]
         fake_B = [B[:, tG - 1:] for B in fake_B]
         return fake_B[0], fake_B_raw, flow, weight, real_A_all[:, tG - 1:], real_B_all[:, tG - 2:], fake_B_prev
@@ -519,7 +522,7 @@ class Vid2VidModelG(BaseModel):
             first = real_B_all[:, :tG - 1].contiguous()
         return self.build_pyr(first)
 
-    def generate_frame_train(self, real_A_all, fake_B_pyr, is_first_frame):
+    def generate_frame_train(self, real_A_all, fake_B_pyr, is_first_frame, frame_range=None):
         """Frame-sequential, coarse-to-fine generation with the reference's detach rules (:139-196)."""
         opt, eng = self.opt, self.engine
         tG, S = opt.n_frames_G, self.n_scales
@@ -527,14 +530,16 @@ class Vid2VidModelG(BaseModel):
             real_A_pyr = self.build_pyr(real_A_all.contiguous())
         per = real_A_all.shape[2]
         fake_Bs_raw = flows = weights = None
-        for t in range(self.n_frames_load):
+        t0, t1 = (0, self.n_frames_load) if frame_range is None else frame_range
+        for t in range(t0, t1):
             feat = flow_feat = fg_feat = None
+            lt = t - t0                                # index into fake_B_pyr, which starts tG-1 frames before frame t0
             for s in range(S):
                 si = S - 1 - s
                 real_As = real_A_pyr[si]
                 _, _, _, h, w = real_As.shape
                 x = eng.pack(real_As[:, t:t + tG].reshape(self.bs, -1, h, w).contiguous())
-                prevs = fake_B_pyr[si][:, t:t + tG - 1]
+                prevs = fake_B_pyr[si][:, lt:lt + tG - 1]
                 if (t % self.n_frames_bp) == 0:
                     prevs = prevs.detach()
                 prev_nchw = prevs.reshape(self.bs, -1, h, w).contiguous()

@@ -53,8 +53,9 @@ class GradSync:
     several frames and scales, so a bucket is only complete when its backward pass ends.
     On CPU tensors (gloo tests) everything runs in order on the host."""
 
-    def __init__(self, group=None, bucket_bytes=64 << 20, force_collective=False):
+    def __init__(self, group=None, bucket_bytes=64 << 20, force_collective=False, scale=None):
         self.group = group
+        self.scale = scale                           # None: 1 / world (mean over data-parallel ranks); roles.py passes 1 / n_sequence_groups
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.force_collective = force_collective     # run the collective even for a world of 1 (single-GPU RCCL test)
         self._stream = None
@@ -62,6 +63,8 @@ class GradSync:
 
     @property
     def world(self):
+        if self.group is None and self.scale is not None:
+            return 1                                 # a role that exists once (roles.py, one sequence group): nothing to reduce
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def buckets(self, flat):
@@ -74,11 +77,11 @@ class GradSync:
         applied inside the fused optimizer kernel (v2v_adam_step grad_scale): no extra pass over the buffer."""
         world = self.world
         if world == 1 and not (self.force_collective and dist.is_initialized()):
-            return 1.0
+            return 1.0 if self.scale is None else self.scale
         works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets(flat)]
         for w in works:
             w.wait()
-        return 1.0 / world
+        return 1.0 / world if self.scale is None else self.scale
 
     # ---- overlap with the following backward pass (GPU only) ----
     def side_stream(self, device):
