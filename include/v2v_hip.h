@@ -377,6 +377,14 @@ int v2v_correlation_forward(const float* in1, const float* in2, float* out,
                             int32_t N, int32_t C, int32_t H, int32_t W,
                             int32_t pad_size, int32_t kernel_size, int32_t max_displacement,
                             int32_t stride1, int32_t stride2, int32_t corr_type_multiply, void* stream);
+/* The same correlation for FlowNetC's geometry class (kernel_size 1, stride1 1, stride2 2, pad = max_displacement: FlowNetC.py:31)
+ * on the matrix pipe, between two NHWC activation tensors [N][H][W][cs_in] (C real channels, dtype = activation dtype), fused with
+ * what surrounds it in FlowNetC.forward (FlowNetC.py:86-93): the result / C passes LeakyReLU(leaky_slope) and lands as
+ * (2 max_disp / stride2 + 1)^2 consecutive channels at channel c_off of the NHWC tensor `out` [N][H][W][cs_out] -- the concat buffer
+ * of conv3_1.  C must be a multiple of 16 (bf16) / 8 (fp32). */
+int v2v_correlation_nhwc(const void* f1, const void* f2, void* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                         int32_t cs_in, int32_t cs_out, int32_t c_off, int32_t max_displacement, int32_t stride2,
+                         float leaky_slope, int32_t dtype, void* stream);
 /* resample2d_cuda.forward (resample2d_kernel.cu:15-64): out[b,c,y,x] = bilinear(img, x+fx, y+fy) */
 int v2v_resample2d_forward(const float* img, const float* flow, float* out,
                            int32_t N, int32_t C, int32_t H, int32_t W, int32_t OH, int32_t OW,

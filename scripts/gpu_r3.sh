@@ -78,3 +78,16 @@ print('replay value', j['value'], j['ms_per_step'], j['timing']['windows_ms_per_
 print('hires', j['hires']['value'], j['hires']['ms_per_step'], j['hires']['plan_build_s'])"
   lap replay
 fi
+if has corr; then       # matrix-pipe correlation: parity, then the kernel and FlowNet2 under rocprofv3, then the train line
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 600 -k "correlation or flownet2 or tensor2flow or grad_scale_is_the_mean" > gpurun_out/${TAG}_corr_tests.log 2>&1; echo "corr tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_corr_tests.log | cut -c1-400 | tail -20
+  lap corr_tests
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_tr_$TAG -o tr -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-train-parity > $R/gpurun_out/${TAG}_train.json 2> $R/gpurun_out/${TAG}_train.err; echo "train rc=$?"
+  python $R/scripts/rocprof_summary.py $(find /tmp/prof_tr_$TAG -name "*.db" | head -1) "# round 3, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --mode train --steps 6 --warmup 2 --no-train-parity (bf16, 512x256, VGG on; autotune launches of the first chunks included)" > $R/gpurun_out/${TAG}_train_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_train.err
+  head -30 $R/gpurun_out/${TAG}_train_kernel_stats.txt | cut -c1-220
+  python -c "
+import json; j = json.load(open('$R/gpurun_out/${TAG}_train.json')); print('train', j['value'], j['ms_per_step'], j['roofline']['frac']); print(j['flownet2'])"
+  cd $R
+  lap corr_train
+fi

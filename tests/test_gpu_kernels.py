@@ -843,7 +843,7 @@ def test_flownet2_native_ops_vs_executed_reference_kernels():
     torch.manual_seed(19)
     P = lambda t: C.c_void_p(t.data_ptr())
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for (n, c, h, w, pad, k, md, s1, s2) in [(1, 72, 5, 9, 20, 1, 20, 1, 2), (2, 9, 6, 5, 4, 1, 4, 1, 2), (1, 6, 9, 11, 4, 3, 4, 2, 1)]:
+    for (n, c, h, w, pad, k, md, s1, s2) in [(1, 72, 5, 9, 20, 1, 20, 1, 2), (2, 9, 6, 5, 4, 1, 4, 1, 2), (1, 6, 9, 11, 5, 3, 4, 2, 1)]:       # (pad >= max_disp + kernel radius: the reference kernel reads out of bounds otherwise)
         a, b = torch.randn(n, c, h, w), torch.randn(n, c, h, w)
         ref = R.correlation(a, b, pad, k, md, s1, s2)
         out = torch.full(ref.shape, float("nan"), device=DEV)
@@ -949,3 +949,36 @@ def test_tensor2flow_equals_numpy_restatement():
     assert abs(int(got[0, 1, 0]) - 127) <= 1 and got[0, 1, 1] == 255 and got[0, 1, 2] == 0
     const = torch.ones(2, 8, 8)                                   # constant magnitude: cv2.normalize maps it to 0
     assert visual.to_numpy(visual.tensor2flow(const.to(DEV))).max() == 0 and O.tensor2flow(const).max() == 0
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(1, 256, 32, 64), (2, 64, 9, 37), (1, 32, 5, 70), (2, 16, 3, 8)])
+def test_correlation_nhwc_matrix_pipe(case, prec):
+    """v2v_correlation_nhwc (FlowNetC's correlation on the matrix pipe, NHWC in, LeakyReLU + concat offset fused) against
+    the oracle's restatement of correlation_cuda_kernel.cu:73-147 followed by LeakyReLU(0.1) (FlowNetC.py:86-89), and -- for
+    the small cases -- against the reference kernel itself executed on the host (oracle/ref_ops.py).  Ragged widths (tiles of
+    32 px), rows whose displaced partner row leaves the image, channels = 1..16 K steps; the untouched channels of the
+    concat buffer stay as they were.  bf16: operands are rounded to bf16 first, products are then exact, sums in fp32."""
+    import ctypes as C
+    from oracle import vid2vid_oracle as O, ref_ops as R
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, check
+    from vid2vid_amd.engine import _ptr, _stream
+    B, Cc, H, W = case
+    torch.manual_seed(Cc + W)
+    eng = _engine(prec)
+    a, b = _round(torch.randn(B, Cc, H, W), prec), _round(torch.randn(B, Cc, H, W), prec)
+    ref = F.leaky_relu(O.correlation(a, b, 20, 1, 20, 1, 2), 0.1)
+    if B * H * W <= 80 and R.available():
+        assert_close(ref, F.leaky_relu(R.correlation(a, b, 20, 1, 20, 1, 2), 0.1), 1e-6, "oracle vs the executed reference kernel")
+    xa, xb = eng.pack(a.to(DEV)), eng.pack(b.to(DEV))
+    off, total = 32, 32 + 441
+    cs_out = (total + 7) // 8 * 8
+    out = torch.full((B, H, W, cs_out), 7.0, dtype=eng.tdtype, device=DEV)
+    check(lib.v2v_correlation_nhwc(_ptr(xa.t), _ptr(xb.t), _ptr(out), B, Cc, H, W, xa.Cs, cs_out, off, 20, 2, 0.1, eng.dtype, _stream()),
+          "correlation_nhwc")
+    got = out[..., off:off + 441].permute(0, 3, 1, 2).float().cpu()
+    assert_close(got, _round(ref, prec) if prec == "bf16" else ref, 1e-5 if prec == "fp32" else 8e-3, "correlation_nhwc %s" % (case,))
+    assert (out[..., :off] == 7.0).all() and (out[..., off + 441:] == 7.0).all()
+    bad = lib.v2v_correlation_nhwc(_ptr(xa.t), _ptr(xb.t), _ptr(out), B, Cc, H, W, xa.Cs, cs_out, off, 20, 1, 0.1, eng.dtype, _stream())
+    assert bad == L.EINVAL if hasattr(L, "EINVAL") else bad != 0

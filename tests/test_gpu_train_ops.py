@@ -409,7 +409,7 @@ def test_fused_adam_grad_scale_is_the_mean_of_summed_gradients():
 
     class FakeSync:                       # what GradSync.all_reduce returns after summing `world` ranks
         world, force_collective = 1, False
-        def wait_pending(self): pass
+        def wait_pending(self, device=None, owner=None): pass
         def all_reduce(self, flat): return 1.0 / world
 
     opt.grad_sync = FakeSync()

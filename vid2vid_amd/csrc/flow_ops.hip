@@ -83,24 +83,30 @@ __global__ __launch_bounds__(256) void correlation_kernel(const CorrArgs a) {
 //   * compute: thread (row r, tj, strip) owns 4 same-parity pixels (x, x+2, x+4, x+6) x all D values of ti = 84
 //     accumulators; per channel it reads ONE 16-byte-aligned window of 24 floats (6 ds_read_b128) that serves all
 //     4 x 21 products -- 3.5 FMAs per LDS float instead of 1 global load per FMA.
-constexpr int CL_CC = 8, CL_TX = 32, CL_ROWS = 2, CL_DMAX = 21, CL_HALF = 36, CL_NR = CL_DMAX + CL_ROWS - 1;
+// Round 3: the displacement rows are split into groups of CL_TJ = 7 over blockIdx.y (3x the workgroups, 128 threads, 18 KB of
+// LDS each, the same staged bytes in total: a group stages its own 7 + 1 f2 rows) -- this planar kernel stays the C-ABI form of
+// the op (v2v_correlation_forward); FlowNet2's plan uses correlation_mma_kernel below.
+constexpr int CL_CC = 8, CL_TX = 32, CL_ROWS = 2, CL_DMAX = 21, CL_HALF = 36, CL_TJ = 7, CL_NR = CL_TJ + CL_ROWS - 1, CL_THREADS = 128;
 
-__global__ __launch_bounds__(384) void correlation_lds_kernel(const CorrArgs a) {
+__global__ __launch_bounds__(CL_THREADS) void correlation_lds_kernel(const CorrArgs a) {
     __shared__ __attribute__((aligned(16))) float f2s[CL_CC][CL_NR][2 * CL_HALF];
     __shared__ float f1s[CL_CC][CL_ROWS][CL_TX];
     const int tid = threadIdx.x;
     const int n = blockIdx.z;
     const int ox0 = blockIdx.x * CL_TX;
-    const int oy0 = (blockIdx.y >> 1) * 4 + (blockIdx.y & 1);          // rows oy0 and oy0 + 2
+    const int ngroups = (a.D + CL_TJ - 1) / CL_TJ;
+    const int by = blockIdx.y / ngroups, tj0 = (blockIdx.y - by * ngroups) * CL_TJ;
+    const int oy0 = (by >> 1) * 4 + (by & 1);                          // rows oy0 and oy0 + 2
     const int D = a.D, drad = a.drad;
-    const int ncols = CL_TX + 4 * drad, nrows = D + CL_ROWS - 1;
+    const int ncols = CL_TX + 4 * drad, nrows = CL_NR;
     const long long hw = (long long)a.H * a.W;
     const float* f1 = a.in1 + (long long)n * a.C * hw;
     const float* f2 = a.in2 + (long long)n * a.C * hw;
     // compute role
-    const bool worker = tid < CL_ROWS * CL_DMAX * 8;
-    const int r = tid / (CL_DMAX * 8), u = tid - r * (CL_DMAX * 8);
-    const int tj = u >> 3, strip = u & 7;
+    const bool worker = tid < CL_ROWS * CL_TJ * 8;
+    const int r = tid / (CL_TJ * 8), u = tid - r * (CL_TJ * 8);
+    const int tjl = u >> 3, strip = u & 7;
+    const int tj = tj0 + tjl;
     const int par = strip & 1, s4 = strip >> 1;
     const bool active = worker && tj < D;
     float acc[4][CL_DMAX];
@@ -111,16 +117,16 @@ __global__ __launch_bounds__(384) void correlation_lds_kernel(const CorrArgs a) 
 
     for (int c0 = 0; c0 < a.C; c0 += CL_CC) {
         __syncthreads();                                             // previous chunk fully consumed
-        for (int e = tid; e < CL_CC * nrows * ncols; e += 384) {
+        for (int e = tid; e < CL_CC * nrows * ncols; e += CL_THREADS) {
             const int c = e / (nrows * ncols);
             const int rem = e - c * nrows * ncols;
             const int q = rem / ncols, xx = rem - q * ncols;
-            const int y = oy0 - 2 * drad + 2 * q, x = ox0 - 2 * drad + xx;
+            const int y = oy0 - 2 * drad + 2 * (tj0 + q), x = ox0 - 2 * drad + xx;
             float v = 0.f;
             if (c0 + c < a.C && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) v = f2[(c0 + c) * hw + (long long)y * a.W + x];
             f2s[c][q][(xx & 1) * CL_HALF + (xx >> 1)] = v;
         }
-        for (int e = tid; e < CL_CC * CL_ROWS * CL_TX; e += 384) {
+        for (int e = tid; e < CL_CC * CL_ROWS * CL_TX; e += CL_THREADS) {
             const int c = e / (CL_ROWS * CL_TX);
             const int rem = e - c * CL_ROWS * CL_TX;
             const int rr = rem / CL_TX, px = rem - rr * CL_TX;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(384) void correlation_lds_kernel(const CorrArgs a) 
 #pragma unroll 2
             for (int c = 0; c < CL_CC; ++c) {
                 // pixels px_k = par + 8*s4 + 2k; their taps live at parity `par`, index 4*s4 + k + t  (t = 0 .. D-1)
-                const float4* wv = reinterpret_cast<const float4*>(&f2s[c][r + tj][par * CL_HALF + 4 * s4]);
+                const float4* wv = reinterpret_cast<const float4*>(&f2s[c][r + tjl][par * CL_HALF + 4 * s4]);
                 float w[24];
 #pragma unroll
                 for (int v = 0; v < 6; ++v) { const float4 t4 = wv[v]; w[4 * v] = t4.x; w[4 * v + 1] = t4.y; w[4 * v + 2] = t4.z; w[4 * v + 3] = t4.w; }
@@ -162,11 +168,142 @@ __global__ __launch_bounds__(384) void correlation_lds_kernel(const CorrArgs a) 
     }
 }
 
+// ---- correlation on the matrix pipe, NHWC in / NHWC out (FlowNetC's geometry class: kernel_size 1, stride1 1, stride2 2,
+// pad == max_disp; round 3) ----
+// The LDS kernel above needs 401 us for the 512x256 frame pair (N = 2, C = 256, 32 x 64 -> 441 x 32 x 64): 32-64 workgroups on
+// 256 CUs, each walking 32 channel chunks behind two barriers, in front of an unpack (NHWC -> planar fp32) and behind a pack
+// (planar -> NHWC + LeakyReLU) launch.  The work is a banded matrix product: for one output row y, one displacement row tj and
+// 32 consecutive pixels x0 .. x0+31 the outputs are
+//     out[x][ti] = sum_c f1[y][x][c] * f2[y + 2(tj - drad)][x + 2(ti - drad)][c]
+// i.e. the (m, n = m + 2 ti) entries of the 32 x 96 product of the f1 row segment [32 px][C] with the f2 row segment
+// [x0 - 2 drad .. x0 - 2 drad + 95][C]: three 32 x 32 MFMA tiles per K step with K = channels, which are CONTIGUOUS in the NHWC
+// activations -- every fragment is one 16-byte load per lane straight from global memory / L2 (both feature maps together are
+// 2-4 MB), no LDS staging, no barrier.  22-44 % of the products are wanted (2 drad + 1 = 21 of 96 columns per pixel, one
+// parity), which the matrix pipe's rate pays for many times over in bf16 and about evens out in fp32
+// (v_mfma_f32_32x32x2_f32, exact products).  One wave = (n, y, x tile, tj): N * OH * ceil(OW / 32) * D waves (2688 for the
+// frame pair above) instead of 32-64 workgroups.  The epilogue gathers the wanted diagonal band through a 32 x D LDS tile, applies
+// 1 / C and the LeakyReLU that follows the correlation in FlowNetC (FlowNetC.py:88-89) and writes D consecutive channels per
+// pixel into the NHWC concat buffer of conv3_1 at its channel offset -- the planar 441-channel tensor never exists.
+struct CorrMmaArgs {
+    const void* f1; const void* f2; void* out;
+    int N, C, H, W, cs_in, cs_out, c_off, D, drad;
+    float inv_c, leaky;
+};
+
+template <typename T> struct CorrFrag;
+template <> struct CorrFrag<bf16_t> {
+    typedef bf16x8 V;
+    static constexpr int KS = 16;                    // channels per MFMA step
+    __device__ static __forceinline__ V zero() { V z; for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.f; return z; }
+    __device__ static __forceinline__ void mma(const V& a, const V& b, f32x16& c) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct CorrFrag<float> {
+    typedef f32x4 V;
+    static constexpr int KS = 8;                     // lane half h holds channels 4h .. 4h+3 of the step; MFMA j contracts {j, 4 + j}
+    __device__ static __forceinline__ V zero() { V z = {0.f, 0.f, 0.f, 0.f}; return z; }
+    __device__ static __forceinline__ void mma(const V& a, const V& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+
+constexpr int CM_DMAX = 21;
+
+// grid (ceil(OW / 32), OH, N * ceil(D / 4)), block 256: wave w of the block takes tj = 4 * (blockIdx.z % groups) + w
+template <typename T>
+__global__ __launch_bounds__(256) void correlation_mma_kernel(const CorrMmaArgs a) {
+    typedef CorrFrag<T> F;
+    typedef typename F::V V;
+    __shared__ float tile[4][32 * CM_DMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = (a.D + 3) >> 2;
+    const int n = blockIdx.z / groups, tj = (blockIdx.z - n * groups) * 4 + wave;
+    if (tj >= a.D) return;
+    const int y = blockIdx.y, x0 = blockIdx.x * 32;
+    const int lr = lane & 31, hi = lane >> 5;
+    const int y2 = y + 2 * (tj - a.drad);
+    const T* f1 = reinterpret_cast<const T*>(a.f1) + (long long)n * a.H * a.W * a.cs_in;
+    const T* f2 = reinterpret_cast<const T*>(a.f2) + (long long)n * a.H * a.W * a.cs_in;
+    float* const my = tile[wave];
+    const bool row_ok = (unsigned)y2 < (unsigned)a.H;
+    if (row_ok) {
+        f32x16 acc[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        constexpr int KE = F::KS / 2;                       // elements per lane and step (16 bytes)
+        const int xa = x0 + lr;
+        const bool a_ok = xa < a.W;
+        const T* pa = f1 + ((long long)y * a.W + (a_ok ? xa : 0)) * a.cs_in + hi * KE;
+        const T* pb[3]; bool b_ok[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int xb = x0 - 2 * a.drad + 32 * b + lr;
+            b_ok[b] = (unsigned)xb < (unsigned)a.W;
+            pb[b] = f2 + ((long long)y2 * a.W + (b_ok[b] ? xb : 0)) * a.cs_in + hi * KE;
+        }
+        const int steps = a.C / F::KS;
+        V fa = a_ok ? *reinterpret_cast<const V*>(pa) : F::zero(), fb[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) fb[b] = b_ok[b] ? *reinterpret_cast<const V*>(pb[b]) : F::zero();
+        for (int ks = 0; ks < steps; ++ks) {
+            V na = F::zero(), nb[3] = {F::zero(), F::zero(), F::zero()};
+            if (ks + 1 < steps) {                            // next step's fragments are in flight under this step's MFMAs
+                const int o = (ks + 1) * F::KS;
+                if (a_ok) na = *reinterpret_cast<const V*>(pa + o);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) if (b_ok[b]) nb[b] = *reinterpret_cast<const V*>(pb[b] + o);
+            }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) F::mma(fa, fb[b], acc[b]);
+            fa = na;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) fb[b] = nb[b];
+        }
+        // the wanted band: output (m, ti) is the product entry (m, n') with n' = m + 2 ti (n' counts f2 columns from x0 - 2 drad)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = (i >> 2) * 8 + hi * 4 + (i & 3);
+                const int d = 32 * b + lr - m;
+                if (d >= 0 && !(d & 1) && (d >> 1) < a.D) my[m * CM_DMAX + (d >> 1)] = acc[b][i];
+            }
+    }
+    // (wave-private LDS tile: the wave's own writes are visible to its own reads after the LDS counter drains)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    T* out = reinterpret_cast<T*>(a.out);
+    const int total = 32 * a.D;
+    for (int e = lane; e < total; e += 64) {
+        const int m = e / a.D, ti = e - m * a.D;
+        const int x = x0 + m;
+        if (x >= a.W) continue;
+        float v = row_ok ? my[m * CM_DMAX + ti] * a.inv_c : 0.f;
+        v = v > 0.f ? v : v * a.leaky;
+        store_act(out, (((long long)n * a.H + y) * a.W + x) * a.cs_out + a.c_off + tj * a.D + ti, v);
+    }
+}
+
+struct CorrMmaOp : Op {
+    CorrMmaArgs a; int dtype;
+    int launch(hipStream_t s) override {
+        dim3 grid((unsigned)ceil_div(a.W, 32), (unsigned)a.H, (unsigned)(a.N * ((a.D + 3) / 4)));
+        if (dtype == V2V_BF16) hipLaunchKernelGGL(correlation_mma_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+        else                   hipLaunchKernelGGL(correlation_mma_kernel<float>, grid, dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "correlation"; }
+};
+
 struct CorrLdsOp : Op {
     CorrArgs a;
     int launch(hipStream_t s) override {
-        dim3 grid((unsigned)ceil_div(a.OW, CL_TX), (unsigned)(ceil_div(a.OH, 4) * 2), (unsigned)a.N);
-        hipLaunchKernelGGL(correlation_lds_kernel, grid, dim3(384), 0, s, a);
+        dim3 grid((unsigned)ceil_div(a.OW, CL_TX), (unsigned)(ceil_div(a.OH, 4) * 2 * ceil_div(a.D, CL_TJ)), (unsigned)a.N);
+        hipLaunchKernelGGL(correlation_lds_kernel, grid, dim3(CL_THREADS), 0, s, a);
         return check_launch();
     }
     const char* name() const override { return "correlation"; }
@@ -490,6 +627,24 @@ extern "C" int v2v_correlation_forward(const float* in1, const float* in2, float
     }
     auto op = std::make_unique<CorrOp>();
     op->a = a;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_correlation_nhwc(const void* f1, const void* f2, void* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                                    int32_t cs_in, int32_t cs_out, int32_t c_off, int32_t max_displacement, int32_t stride2,
+                                    float leaky_slope, int32_t dtype, void* stream) {
+    if (!f1 || !f2 || !out || N < 1 || H < 1 || W < 1 || (dtype != V2V_F32 && dtype != V2V_BF16)) { set_error("correlation_nhwc: bad argument"); return V2V_EINVAL; }
+    const int ks = dtype == V2V_BF16 ? 16 : 8, vec = dtype == V2V_BF16 ? 8 : 4;
+    const int drad = stride2 > 0 ? max_displacement / stride2 : -1;
+    if (stride2 != 2 || (max_displacement & 1) || drad < 1 || 2 * drad + 1 > CM_DMAX || C < ks || C % ks != 0 || cs_in % vec != 0 || cs_in < C ||
+        c_off < 0 || cs_out < c_off + (2 * drad + 1) * (2 * drad + 1)) {
+        set_error("correlation_nhwc: FlowNetC's geometry class only (kernel 1, stride1 1, stride2 2, pad = max_displacement even, <= 21 x 21 displacements), "
+                  "channels a multiple of %d, got C=%d cs_in=%d max_disp=%d stride2=%d", ks, C, cs_in, max_displacement, stride2);
+        return V2V_EINVAL;
+    }
+    auto op = std::make_unique<CorrMmaOp>();
+    op->a = CorrMmaArgs{f1, f2, out, N, C, H, W, cs_in, cs_out, c_off, 2 * drad + 1, drad, 1.f / (float)C, leaky_slope};
+    op->dtype = dtype;
     return submit(std::move(op), stream);
 }
 

@@ -184,9 +184,13 @@ class FlowNet2(nn.Module):
         c2 = R.cv(m.conv2, c1)
         c3 = R.cv(m.conv3, c2)
         c2a, c3a = Act(c2.t[:B], c2.C), Act(c3.t[:B], c3.C)
-        corr = R.correlation(c3)                                   # planar [B,441,h,w]
         redir = R.cv(m.conv_redir, c3a)
-        in31 = R.cat([redir, None], extra=(corr, 441, 0.1))        # cat(conv_redir, leaky_relu(corr, 0.1))
+        if R.corr_mma_ok(c3):                                      # matrix-pipe correlation straight into the concat buffer (round 3)
+            in31, off = R.cat([redir, None], reserve=441)
+            R.correlation_into(c3, in31, off, 0.1)                 # cat(conv_redir, leaky_relu(corr, 0.1)), FlowNetC.py:86-93
+        else:
+            corr = R.correlation(c3)                               # planar [B,441,h,w]
+            in31 = R.cat([redir, None], extra=(corr, 441, 0.1))
         c3_1 = R.cv(m.conv3_1, in31)
         c4 = R.cv(m.conv4_1, R.cv(m.conv4, c3_1))
         c5 = R.cv(m.conv5_1, R.cv(m.conv5, c4))
@@ -283,13 +287,14 @@ class _Runner:
             self._pack_into(p, out.t, i * B, 0)
         return out
 
-    def cat(self, acts, extra=None):
+    def cat(self, acts, extra=None, reserve=0):
         """torch.cat along channels of NHWC Acts; `extra` = (planar tensor, C, leaky slope) appended last
-        (replaces a None placeholder)."""
+        (replaces a None placeholder); `reserve` = channels left for a producer that writes into the buffer itself
+        (returns (Act, channel offset of the reserved range))."""
         eng = self.eng
         parts = [a for a in acts if a is not None]
         N, H, W = parts[0].N, parts[0].H, parts[0].W
-        total = sum(a.C for a in parts) + (extra[1] if extra else 0)
+        total = sum(a.C for a in parts) + (extra[1] if extra else 0) + reserve
         out = self._zeros_act(N, H, W, total)
         off = 0
         for a in parts:
@@ -299,6 +304,8 @@ class _Runner:
             off += a.C
         if extra:
             self._pack_into(extra[0], out.t, 0, off, 1.0, extra[2])
+        if reserve:
+            return out, off
         return out
 
     def unpack(self, a):
@@ -328,6 +335,21 @@ class _Runner:
         check(lib.v2v_channelnorm_forward(_ptr(x), _ptr(out), B, Cc, H, W, 2, _stream()), "channelnorm")
         self.eng.label("channelnorm")
         return out
+
+    def corr_mma_ok(self, c3):
+        """v2v_correlation_nhwc: channels a whole number of MFMA K steps (FlowNetC: 256).  V2V_CORR_MMA=0: the planar C-ABI op."""
+        import os
+        ks = 16 if self.eng.dtype == L.BF16 else 8
+        return os.environ.get("V2V_CORR_MMA", "1") != "0" and c3.C % ks == 0 and c3.N % 2 == 0
+
+    def correlation_into(self, c3, out, c_off, slope):
+        """Correlation(pad 20, k 1, max_disp 20, stride1 1, stride2 2) of the two halves of the stacked conv3 output + LeakyReLU
+        (FlowNetC.py:31,86-89), written as 441 channels at `c_off` of the NHWC concat buffer `out`."""
+        eng = self.eng
+        B = c3.N // 2
+        check(lib.v2v_correlation_nhwc(_ptr(c3.t[:B]), _ptr(c3.t[B:]), _ptr(out.t), B, c3.C, c3.H, c3.W, c3.Cs, out.Cs, c_off,
+                                       20, 2, float(slope), eng.dtype, _stream()), "correlation_nhwc")
+        eng.label("correlation")
 
     def correlation(self, c3):
         """Correlation(pad 20, k 1, max_disp 20, stride1 1, stride2 2) between the two halves of the

@@ -132,6 +132,7 @@ PROTOTYPES = {
     "v2v_resample_flow": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "v2v_correlation_out_size": (C.c_int, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "v2v_correlation_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "v2v_correlation_nhwc": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "v2v_resample2d_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_channelnorm_forward": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "v2v_plan_create": (_P, []),
