@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "x3": 2500.0 / 3}   # dense MFMA peaks, MI355X_MICROARCH.md (x3: three bf16 products per product)
 KERNEL_FAMILY = "conv_igemm"
 
 
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "x3"])
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--scales", type=int, default=1, help="n_scales_spatial (3 with --width 2048 --height 1024 = BASELINE configs[4] geometry, inference)")
@@ -494,6 +494,7 @@ def main():
     cpu = None
     parity = None
     fp32_line = None
+    x3_line = None
     do_cpu = rank == 0 and args.gpus == 1 and not args.no_cpu_baseline
     if do_cpu:
         from oracle import vid2vid_oracle as O
@@ -593,6 +594,31 @@ def main():
                          "frac_of_fp32_mfma_peak": round(sum(c["flops"] for c in model32._active_plan.conv_log if not c.get("onehot")) / (el32 / n32) / 1e12 / PEAK_TFLOPS["fp32"], 4)}
             del model32
             torch.cuda.empty_cache()
+        # companion figure: the "x3" precision -- fp32 storage, statistics and norms, the 3x3 convolutions (ResnetBlocks,
+        # stride-2 stages: 80 % of the frame's FLOP) on the bf16 matrix pipe over bf16x3 operands (engine.X3Conv): the parity bar
+        # of the fp32 path at a multiple of its speed
+        if args.precision == "bf16" and not face:
+            try:
+                _, model_x3 = build_model("x3")
+                for s in range(S):
+                    getattr(model_x3, "netG%d" % s).load_state_dict(getattr(model, "netG%d" % s).state_dict())
+                model_x3.engine.refresh_weights()
+                ex3 = errors_of(model_x3)
+                nx3 = max(args.steps // 2, 5)
+                elx3, _, _ = timed_fps(model_x3, nx3, 2, windows=3, min_warm_s=0.3)
+                logx3 = model_x3._active_plan.conv_log
+                x3_line = {"value": round(nx3 / elx3, 3), "unit": "frames/s", "ms_per_step": round(elx3 / nx3 * 1e3, 4), "steps": nx3,
+                           "dtype": "fp32 storage / statistics / norms; 3x3 convolutions as bf16x3 (hi + lo operands, 3 bf16 MFMA products, fp32 accumulate)",
+                           "parity": ex3, "max_rel": max(v["max_rel"] for v in ex3.values()),
+                           "ok_1e-3": bool(max(v["max_rel"] for v in ex3.values()) <= 1e-3 and all(v["finite"] for v in ex3.values())),
+                           "x3_convs_per_frame": sum(1 for c in logx3 if c.get("x3")), "convs_per_frame": len(logx3),
+                           "x3_flop_share": round(sum(c["flops"] for c in logx3 if c.get("x3")) / max(sum(c["flops"] for c in logx3), 1.0), 3)}
+                del model_x3
+                torch.cuda.empty_cache()
+            except Exception as ex:
+                import traceback
+                traceback.print_exc()
+                x3_line = {"error": repr(ex)[:400]}
 
     # ---------------- the timed region ----------------
     elapsed, window_s, warm_frames = timed_fps(model, args.steps, args.warmup, args.windows, args.min_warmup_s)
@@ -757,6 +783,12 @@ def main():
         fph = mh._active_plan
         acc, rows, convs, launches, mfma_log, total_ms = kernel_table(fph, 1)
         peak = PEAK_TFLOPS[args.precision]
+        if args.dump_ops:                                # per-op table of the 2048x1024 frame (scripts/per_layer_roofline.py reads it)
+            it = iter(launches)
+            with open(args.dump_ops + ".hires.json", "w") as f:
+                json.dump([dict(op=n_, label=l_, ms=ms, **({k: c_[k] for k in ("tile", "splitk", "members", "flops", "cin", "cout", "KH", "H", "W", "OH", "OW", "stride") if k in c_}
+                                                           if n_ == KERNEL_FAMILY and (c_ := next(it)) is not None else {}))
+                           for n_, l_, ms in rows], f, indent=1)
         dom = max(acc, key=lambda k: acc[k]["flops"])
         a = acc[dom]
         fam, tname = tile_label(dom)
@@ -846,6 +878,7 @@ def main():
                        "output_finite": finite},
             "parity": parity,
             "fp32": fp32_line,
+            "x3": x3_line,
             "host_fed": host_fed,
             "roofline": roofline,
             "cpu_baseline": cpu,

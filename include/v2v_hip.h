@@ -317,6 +317,10 @@ int v2v_fg_mask_nhwc(const void* x, float* mask, int64_t P, int32_t c_stride, in
                      const int32_t* fg_labels_dev, int32_t n_fg, int32_t dtype, void* stream);
 
 /* planar fp32 NCHW [C][H][W] -> NHWC activation dtype [H][W][c_stride] (zero channel padding) */
+/* bf16x3 operand of the fp32 engine's "x3" mode: x fp32 NHWC [pixels][cs_in] (C real channels, C % 4 == 0) -> bf16 NHWC
+ * [pixels][cs_out], channels [hi | lo | hi] with hi = bf16(x), lo = bf16(x - hi).  Convolved with weights laid out [hi(W) | hi(W) |
+ * lo(W)] along the input channels (any conv kernel of this library, dtype V2V_BF16, cin = 3 C) this gives x * W to ~2^-17 relative. */
+int v2v_split_x3(const float* x, void* y, int64_t pixels, int32_t C, int32_t cs_in, int32_t cs_out, void* stream);
 int v2v_pack_nchw_to_nhwc(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
                           int32_t c_stride, int32_t dtype, void* stream);
 /* NHWC activation dtype -> planar fp32 NCHW */

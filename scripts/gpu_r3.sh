@@ -91,3 +91,25 @@ import json; j = json.load(open('$R/gpurun_out/${TAG}_train.json')); print('trai
   cd $R
   lap corr_train
 fi
+if has hiresops; then    # per-op tables of both resolutions with a given tune cache (TUNE=path inside the repo)
+  cp ${TUNE:-profiles/tune_cache.json} /tmp/tune_ops.json
+  V2V_TUNE_CACHE=/tmp/tune_ops.json timeout 900 python bench.py --no-cpu-baseline --no-train-line --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_bench_ops.json 2> gpurun_out/${TAG}_bench_ops.err; echo "ops rc=$?"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_bench_ops.json'))
+print('value', j['value'], j['ms_per_step']); print('hires', j['hires']['value'], j['hires']['ms_per_step'], j['hires']['plan_build_s'])"
+  cp /tmp/tune_ops.json gpurun_out/${TAG}_tune_after.json
+  lap hiresops
+fi
+if has x3; then
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 600 -s -k "x3_conv_groups or full_size_512x256" > gpurun_out/${TAG}_x3_tests.log 2>&1; echo "x3 tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  |rel err" gpurun_out/${TAG}_x3_tests.log | cut -c1-400 | tail -20
+  lap x3_tests
+  cp ${TUNE:-profiles/tune_cache.json} /tmp/tune_x3.json
+  V2V_TUNE_CACHE=/tmp/tune_x3.json timeout 900 python bench.py --no-hires --no-train-line > gpurun_out/${TAG}_bench_x3.json 2> gpurun_out/${TAG}_bench_x3.err; echo "bench rc=$?"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_bench_x3.json'))
+print('value', j['value'], j['ms_per_step']); print('fp32', j['fp32']); print('x3', json.dumps(j['x3'])[:1200])"
+  tail -3 gpurun_out/${TAG}_bench_x3.err | cut -c1-300
+  cp /tmp/tune_x3.json gpurun_out/${TAG}_tune_after.json
+  lap x3_bench
+fi

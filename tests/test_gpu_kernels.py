@@ -982,3 +982,48 @@ def test_correlation_nhwc_matrix_pipe(case, prec):
     assert (out[..., :off] == 7.0).all() and (out[..., off + 441:] == 7.0).all()
     bad = lib.v2v_correlation_nhwc(_ptr(xa.t), _ptr(xb.t), _ptr(out), B, Cc, H, W, xa.Cs, cs_out, off, 20, 1, 0.1, eng.dtype, _stream())
     assert bad == L.EINVAL if hasattr(L, "EINVAL") else bad != 0
+
+
+@torch.no_grad()
+def test_x3_conv_groups_match_the_fp32_path():
+    """The fp32 engine's "x3" mode (engine.X3Conv + csrc split_x3): 3x3 convolutions with whole-chunk input channels run on
+    the bf16 matrix pipe over [hi | lo | hi] operands and [hi(W) | hi(W) | lo(W)] weights.  Against the exact-fp32 MFMA path on
+    the same fp32 inputs: a ResnetBlock pair (reflect padding, norm, ReLU, residual), a stride-2 down-sampling group and a
+    512 -> 512 single group -- 2e-4 per pixel (the dropped lo x lo term and the 2^-17 residues), bit-identical packed inputs."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.engine import Engine
+    torch.manual_seed(21)
+    e32 = Engine(DEV, L.F32)
+    e3 = Engine(DEV, L.F32, x3=True)
+    for e in (e32, e3):
+        e.autotune = False
+    # split_x3 itself: hi + lo reproduces x to 2^-16, hi is the bf16 rounding
+    x = torch.randn(1, 64, 9, 13)
+    xa = e3.pack(x.to(DEV))
+    sp = e3.split_x3(xa).t.float().cpu()
+    hi, lo = sp[..., :64], sp[..., 64:128]
+    xr = xa.t.float().cpu()
+    assert torch.equal(hi, xr.bfloat16().float()) and torch.equal(sp[..., 128:], hi)
+    assert ((hi + lo) - xr).abs().max().item() <= 2.0 ** -16 * xr.abs().max().item()
+    for (cin, cout, H, W, stride) in [(128, 128, 16, 32, 1), (64, 128, 20, 36, 2), (512, 512, 8, 16, 1)]:
+        convs = [nn.Conv2d(cin, cout, 3, stride=stride, padding=0 if stride == 1 else 1).to(DEV) for _ in range(2)]
+        norms = [nn.BatchNorm2d(cout).to(DEV) for _ in range(2)]
+        for n in norms:
+            n.weight.normal_(1.0, 0.1); n.bias.normal_(0.0, 0.1)
+        xs = [torch.randn(1, cin, H, W).to(DEV) for _ in range(2)]
+        outs = {}
+        for name, e in (("fp32", e32), ("x3", e3)):
+            pk = [e.pack(t) for t in xs]
+            pm, po = (L.PAD_REFLECT, 1) if stride == 1 else (L.PAD_ZERO, None)
+            n0 = len(e.conv_log)
+            if stride == 1 and cin == cout:
+                res = [e.pack(torch.randn(1, cout, H, W, generator=torch.Generator().manual_seed(5 + i)).to(DEV)) for i in range(2)]
+                ya, yb = e.conv_group_pair(pk[0], convs[0], norms[0], pk[1], convs[1], norms[1], pm, po, L.ACT_RELU, 0.0,
+                                           adds_a=(res[0], None), adds_b=(res[1], None), labels=("a", "b"))
+                outs[name] = [e.unpack(ya).cpu(), e.unpack(yb).cpu()]
+            y = e.conv_group(pk[0], convs[0], pm, po, norms[0], L.ACT_RELU, 0.0, label="single")
+            outs.setdefault(name, []).append(e.unpack(y).cpu())
+            took = [bool(c.get("x3")) for c in e.conv_log[n0:]]
+            assert all(took) if name == "x3" else not any(took), (name, took)
+        for a, b in zip(outs["x3"], outs["fp32"]):
+            assert_close(a, b, 2e-4, "x3 vs fp32 MFMA, %d -> %d stride %d" % (cin, cout, stride))

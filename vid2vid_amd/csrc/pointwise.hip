@@ -766,6 +766,58 @@ extern "C" int v2v_encode_labels_u8(const uint8_t* labels, const int32_t* inst, 
     return submit(std::move(op), stream);
 }
 
+// ---------------------------------------------------------------------------------------
+// bf16x3: an fp32 activation as three bf16 channel groups [hi | lo | hi], hi = bf16(x), lo = bf16(x - hi)   (round 3)
+// ---------------------------------------------------------------------------------------
+// A convolution of this tensor with the weights laid out [hi(W) | hi(W) | lo(W)] along the input channels is
+//     hi(x) hi(W) + lo(x) hi(W) + hi(x) lo(W)  =  x W  up to the dropped lo(x) lo(W) term (2^-18 relative) and the 2^-17 residues
+// -- near-fp32 products on the bf16 matrix pipe (16x the fp32-input MFMA rate at 3x the K extent) with NO change to any
+// convolution kernel: the K extent simply triples.  fp32 accumulation as everywhere.  Used by the fp32 engine's "x3" mode for
+// the 3x3 ResnetBlock convolutions (74 % of the frame's FLOP); the statistics, the norm and the activations stay fp32.
+struct SplitX3Args { const float* x; unsigned short* y; long long P; int C, cs_in, cs_out; };
+
+__global__ __launch_bounds__(256) void split_x3_kernel(const SplitX3Args a) {
+    const int vpr = a.C >> 2;                                   // float4 per pixel
+    const long long total = a.P * vpr;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long p = e / vpr;
+        const int c = (int)(e - p * vpr) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(a.x + p * a.cs_in + c);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        unsigned short hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            hi[q] = f32_to_bf16_bits(f[q]);
+            lo[q] = f32_to_bf16_bits(f[q] - bf16_bits_to_f32(hi[q]));       // exact difference, then rounded: |residue| <= 2^-17 |x|
+        }
+        const uint2 vh = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+        const uint2 vl = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+        unsigned short* o = a.y + p * a.cs_out + c;
+        *reinterpret_cast<uint2*>(o) = vh;
+        *reinterpret_cast<uint2*>(o + a.C) = vl;
+        *reinterpret_cast<uint2*>(o + 2 * a.C) = vh;
+    }
+}
+
+struct SplitX3Op : Op {
+    SplitX3Args a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(split_x3_kernel, dim3(grid_for(a.P * (a.C >> 2))), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "split_x3"; }
+};
+
+extern "C" int v2v_split_x3(const float* x, void* y, int64_t pixels, int32_t C, int32_t cs_in, int32_t cs_out, void* stream) {
+    if (!x || !y || pixels < 1 || C < 4 || C % 4 != 0 || cs_in < C || cs_in % 4 != 0 || cs_out < 3 * C || cs_out % 4 != 0) {
+        set_error("split_x3: C must be a multiple of 4, cs_in >= C, cs_out >= 3 C"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<SplitX3Op>();
+    op->a = SplitX3Args{x, reinterpret_cast<unsigned short*>(y), pixels, C, cs_in, cs_out};
+    return submit(std::move(op), stream);
+}
+
 extern "C" int v2v_pack_nchw_to_nhwc(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
                                      int32_t c_stride, int32_t dtype, void* stream) {
     const int vec = dtype == V2V_BF16 ? 8 : 4;

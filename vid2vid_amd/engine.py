@@ -203,6 +203,32 @@ class MergedConv:
         return torch.cat([z(self.a), z(self.b)], 0)
 
 
+class X3Conv:
+    """An nn.Conv2d seen by the bf16 kernels as a convolution over the bf16x3 operand (csrc/pointwise.hip, split_x3): the
+    input channels are [hi(x) | lo(x) | hi(x)], the weights [hi(W) | hi(W) | lo(W)] -- the product is x * W to ~2^-17
+    relative on the bf16 matrix pipe.  What PackedConv / Engine.conv need of an nn.Conv2d, assembled on read."""
+
+    def __init__(self, conv):
+        self.src = conv
+        self.kernel_size, self.stride, self.padding, self.groups = conv.kernel_size, conv.stride, conv.padding, conv.groups
+        self.in_channels, self.out_channels = 3 * conv.in_channels, conv.out_channels
+        self.output_padding = (0, 0)
+
+    def version_key(self):
+        return _param_version(self.src)
+
+    @property
+    def weight(self):
+        w = self.src.weight.detach().float()
+        hi = w.bfloat16().float()
+        lo = (w - hi).bfloat16().float()
+        return torch.cat([hi, hi, lo], 1).contiguous()
+
+    @property
+    def bias(self):
+        return None if self.src.bias is None else self.src.bias.detach()
+
+
 class PackedOneHot:
     """Gather table [49][cin][64 | 128] of a 7x7 stem Conv2d (csrc/onehot_stem.hip), refreshed like PackedConv."""
 
@@ -340,8 +366,14 @@ def _cfg3(v):
 class Engine:
     """Emits v2v_* launches for one device / one activation dtype."""
 
-    def __init__(self, device, dtype=L.F32, align_corners=False, record_only=False):
+    def __init__(self, device, dtype=L.F32, align_corners=False, record_only=False, x3=False):
         self.device = torch.device(device)
+        # x3 (fp32 engine only): 3x3 convolutions whose input channels are whole 128-byte chunks run on the bf16 matrix pipe
+        # over bf16x3 operands (X3Conv / split_x3): fp32-grade products at 3x the bf16 cost instead of the fp32-input MFMA
+        # rate; statistics, norms, activations and everything else stay fp32
+        self.x3 = bool(x3) and dtype == L.F32
+        self._x3_engine = None
+        self._x3_convs = {}
         # record_only: launches may only be RECORDED into a Plan (never executed).  Used by the CPU
         # test-suite to check the lowering (layer census, argument validation) without a GPU.
         self.record_only = record_only
@@ -817,6 +849,46 @@ class Engine:
             self._fused_norm_wgs = int(lib.v2v_conv_fused_norm_max_workgroups())
         return members * N * -(-H // th) * -(-W // tw) * -(-cout // bn) <= self._fused_norm_wgs
 
+    # ---------------- bf16x3 ("x3") operands for the fp32 engine ----------------
+    def _x3_ok(self, x, conv, pad_override=None):
+        if not (self.x3 and isinstance(conv, nn.Conv2d) and conv.groups == 1 and conv.kernel_size == (3, 3)
+                and x.C == conv.in_channels and x.C % 64 == 0 and x.Cs == x.C and self.fused_finalize
+                and not self._training() and not self.record_only):
+            return False
+        pad = conv.padding[0] if pad_override is None else pad_override
+        st = conv.stride[0]
+        OH, OW = (x.H + 2 * pad - 3) // st + 1, (x.W + 2 * pad - 3) // st + 1
+        return x.N * OH * OW <= FUSE_FINALIZE_MAX_PIXELS          # the statistics are finalized inside the conv launch
+
+    def _x3_enter(self):
+        sub = self._x3_engine
+        if sub is None:
+            sub = self._x3_engine = Engine(self.device, L.BF16, self.align_corners)
+            sub.fused_norm = False                                # the norm runs in fp32 on the raw output (bn_apply of THIS engine)
+        sub.plan, sub._lane, sub._sset = self.plan, self._lane, self._sset
+        sub.autotune, sub.update_running_stats, sub.lanes_enabled = self.autotune, self.update_running_stats, self.lanes_enabled
+        sub.fused_finalize = self.fused_finalize
+        return sub
+
+    def _x3_wrap(self, conv):
+        w = self._x3_convs.get(id(conv))
+        if w is None:
+            w = self._x3_convs[id(conv)] = X3Conv(conv)
+        return w
+
+    def split_x3(self, x):
+        """fp32 Act (C channels, C % 64 == 0, dense stride) -> bf16 Act of 3 C channels [hi | lo | hi]."""
+        out = torch.empty((x.N, x.H, x.W, 3 * x.C), dtype=torch.bfloat16, device=self.device)
+        self._keep(out)
+        check(lib.v2v_split_x3(_ptr(x.t), _ptr(out), x.N * x.H * x.W, x.C, x.Cs, 3 * x.C, _stream()), "split_x3")
+        self.label("split_x3")
+        return Act(out, 3 * x.C)
+
+    def _x3_log(self, sub, n0):
+        for c in sub.conv_log[n0:]:                               # algorithmic work in this engine's census (K was tripled)
+            self.conv_log.append(dict(c, cin=c["cin"] // 3, flops=c["flops"] / 3.0, x3=True))
+        del sub.conv_log[n0:]
+
     def conv_pair(self, xa, ma, xb, mb, pad_mode, pad, fins, labels, fuse=None):
         """Two convolutions of identical geometry as ONE launch (include/v2v_hip.h, v2v_conv2d_pair).  Member b works on
         scratch sub-set 1 of the current lane.  Returns ((raw, rows, finalized), (raw, rows, finalized)), shape.
@@ -910,8 +982,17 @@ class Engine:
         fins = ((norma, ssa), (normb, ssb)) if self.fused_finalize else (None, None)
         N, OH, OW = xa.N, xa.H, xa.W
         ya, yb = self.empty_act(N, OH, OW, cout), self.empty_act(N, OH, OW, cout)
-        (ra, rb), shp = self.conv_pair(xa, conva, xb, convb, pad_mode, pad, fins, labels,
-                                       fuse=(act, act_param, adds_a, adds_b, ya, yb))
+        if self._x3_ok(xa, conva, pad) and self._x3_ok(xb, convb, pad):
+            sub = self._x3_enter()
+            n0 = len(sub.conv_log)
+            xa3 = self.split_x3(xa)
+            with self.scratch_set(1):
+                xb3 = self.split_x3(xb)
+            (ra, rb), shp = sub.conv_pair(xa3, self._x3_wrap(conva), xb3, self._x3_wrap(convb), pad_mode, pad, fins, labels, fuse=None)
+            self._x3_log(sub, n0)
+        else:
+            (ra, rb), shp = self.conv_pair(xa, conva, xb, convb, pad_mode, pad, fins, labels,
+                                           fuse=(act, act_param, adds_a, adds_b, ya, yb))
         if ra[0] is None:                 # norm + activation + residuals ran inside the conv launch
             return ya, yb
         cs_raw = (cout + 3) // 4 * 4
@@ -1199,8 +1280,16 @@ class Engine:
                                    ss=ss, finalized=fin is not None)
         if norm is not None:
             ss = self.scratch("scale_shift", 4 * conv.out_channels)
-            raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC, want_stats=True, label=label,
-                                       fin=(norm, ss) if self.fused_finalize else None)
+            if self._x3_ok(x, conv, pad_override):
+                sub = self._x3_enter()
+                n0 = len(sub.conv_log)
+                raw, rows, shp = sub.conv(self.split_x3(x), self._x3_wrap(conv), pad_mode, pad_override, L.OUT_RAW_F32_NHWC,
+                                          want_stats=True, label=label, fin=(norm, ss))
+                self.last_finalized = sub.last_finalized
+                self._x3_log(sub, n0)
+            else:
+                raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC, want_stats=True, label=label,
+                                           fin=(norm, ss) if self.fused_finalize else None)
             return self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param, add0=add0, add1=add1,
                                    label=label, ss=ss, finalized=self.fused_finalize and self.last_finalized)
         if add0 is not None or add1 is not None:

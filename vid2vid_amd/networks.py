@@ -31,13 +31,17 @@ _ALIGN_CORNERS = {"value": False}   # oracle in this container: torch>=1.3 defau
 _ENGINES = {}
 
 
+X3 = L.F32 + 16          # precision code of the fp32 engine with bf16x3 operands for its 3x3 convolutions (engine.X3Conv)
+
+
 def set_precision(p):
-    """'fp32' (exact fp32 MFMA, parity path) or 'bf16' (throughput path)."""
-    _PRECISION["value"] = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16}[p]
+    """'fp32' (exact fp32 MFMA, parity path), 'bf16' (throughput path) or 'x3' (fp32 storage / norms, the 3x3 convolutions on
+    the bf16 matrix pipe over bf16x3 operands: fp32-grade results at a multiple of the fp32 path's speed)."""
+    _PRECISION["value"] = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16, "x3": X3}[p]
 
 
 def get_precision():
-    return "bf16" if _PRECISION["value"] == L.BF16 else "fp32"
+    return {L.BF16: "bf16", X3: "x3"}.get(_PRECISION["value"], "fp32")
 
 
 def set_align_corners(flag):
@@ -65,12 +69,12 @@ def get_engine(device=None, precision=None):
     prec = _PRECISION["value"] if precision is None else precision
     key = (str(device), prec, _ALIGN_CORNERS["value"])
     if key not in _ENGINES:
-        _ENGINES[key] = Engine(device, prec, _ALIGN_CORNERS["value"],
-                               record_only=_RECORD_ONLY["value"] and device.type == "cpu")
+        _ENGINES[key] = Engine(device, prec & 15, _ALIGN_CORNERS["value"],
+                               record_only=_RECORD_ONLY["value"] and device.type == "cpu", x3=bool(prec & 16))
     return _ENGINES[key]
 
 
-_PREC_CODE = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16}
+_PREC_CODE = {"fp32": L.F32, "f32": L.F32, "bf16": L.BF16, "x3": X3}
 
 
 def bind_precision(root, precision):
