@@ -110,7 +110,7 @@ class PackedConv:
         self.mod = mod
         self.role = role
         self.korder = korder      # 0: tap-major K (implicit-GEMM tiles), 1: channel-chunk-major (patch kernel)
-        mod_t = isinstance(mod, nn.ConvTranspose2d)
+        mod_t = getattr(mod, "is_transposed", isinstance(mod, nn.ConvTranspose2d))
         w = mod.weight
         self.KH, self.KW = mod.kernel_size
         self.stride = mod.stride[0]
@@ -210,9 +210,10 @@ class X3Conv:
 
     def __init__(self, conv):
         self.src = conv
+        self.is_transposed = isinstance(conv, nn.ConvTranspose2d)      # weight [cin][cout][kh][kw]: the input channels are dim 0
         self.kernel_size, self.stride, self.padding, self.groups = conv.kernel_size, conv.stride, conv.padding, conv.groups
         self.in_channels, self.out_channels = 3 * conv.in_channels, conv.out_channels
-        self.output_padding = (0, 0)
+        self.output_padding = tuple(conv.output_padding) if self.is_transposed else (0, 0)
 
     def version_key(self):
         return _param_version(self.src)
@@ -222,7 +223,7 @@ class X3Conv:
         w = self.src.weight.detach().float()
         hi = w.bfloat16().float()
         lo = (w - hi).bfloat16().float()
-        return torch.cat([hi, hi, lo], 1).contiguous()
+        return torch.cat([hi, hi, lo], 0 if self.is_transposed else 1).contiguous()
 
     @property
     def bias(self):
@@ -850,14 +851,20 @@ class Engine:
         return members * N * -(-H // th) * -(-W // tw) * -(-cout // bn) <= self._fused_norm_wgs
 
     # ---------------- bf16x3 ("x3") operands for the fp32 engine ----------------
-    def _x3_ok(self, x, conv, pad_override=None):
-        if not (self.x3 and isinstance(conv, nn.Conv2d) and conv.groups == 1 and conv.kernel_size == (3, 3)
-                and x.C == conv.in_channels and x.C % 64 == 0 and x.Cs == x.C and self.fused_finalize
-                and not self._training() and not self.record_only):
+    def _x3_ok(self, x, conv, pad_override=None, with_norm=True):
+        tr = isinstance(conv, nn.ConvTranspose2d)
+        if not (self.x3 and (isinstance(conv, nn.Conv2d) or (tr and tuple(conv.stride) == (2, 2))) and conv.groups == 1
+                and conv.kernel_size in ((3, 3), (7, 7)) and x.C == conv.in_channels and x.C % 64 == 0 and x.Cs == x.C
+                and self.fused_finalize and not self._training() and not self.record_only):
             return False
+        if not with_norm:
+            return True
         pad = conv.padding[0] if pad_override is None else pad_override
-        st = conv.stride[0]
-        OH, OW = (x.H + 2 * pad - 3) // st + 1, (x.W + 2 * pad - 3) // st + 1
+        st, k = conv.stride[0], conv.kernel_size[0]
+        if tr:
+            OH, OW = (x.H - 1) * st - 2 * pad + k + conv.output_padding[0], (x.W - 1) * st - 2 * pad + k + conv.output_padding[0]
+        else:
+            OH, OW = (x.H + 2 * pad - k) // st + 1, (x.W + 2 * pad - k) // st + 1
         return x.N * OH * OW <= FUSE_FINALIZE_MAX_PIXELS          # the statistics are finalized inside the conv launch
 
     def _x3_enter(self):
@@ -1298,6 +1305,12 @@ class Engine:
         if (head_nchw and isinstance(conv, nn.Conv2d) and conv.kernel_size == (7, 7) and conv.out_channels <= 32
                 and x.Cs % bke != 0 and x.H * x.W >= 65536):
             x = self.widen(x, (x.Cs + bke - 1) // bke * bke)      # e.g. the 32-channel scale-2 towers: 64-byte rows
+        if head_nchw and self._x3_ok(x, conv, pad_override, with_norm=False):     # API-facing 7x7 heads: planar fp32 straight from the bf16x3 product
+            sub = self._x3_enter()
+            n0 = len(sub.conv_log)
+            out, _, _ = sub.conv(self.split_x3(x), self._x3_wrap(conv), pad_mode, pad_override, L.OUT_F32_NCHW, act, act_param, out_scale, label=label)
+            self._x3_log(sub, n0)
+            return out
         out, _, _ = self.conv(x, conv, pad_mode, pad_override, L.OUT_F32_NCHW if head_nchw else L.OUT_ACT_NHWC,
                               act, act_param, out_scale if head_nchw else 1.0, label=label)
         return out
@@ -1313,7 +1326,7 @@ class Engine:
             act = (L.ACT_NONE, 0.0) if len(mods) == 2 else self._act_code(mods[2])
             return None if act is None else (int(mods[0].padding[0]), mods[1], act)
         pa, pb = parse(seq_a), parse(seq_b)
-        if (not self.merge_heads or pa is None or pb is None or self._training() or pa[0] != pb[0]
+        if (not self.merge_heads or self.x3 or pa is None or pb is None or self._training() or pa[0] != pb[0]
                 or pa[1].kernel_size != (7, 7) or pa[1].out_channels + pb[1].out_channels > 16):
             return None
         key = (id(pa[1]), id(pb[1]))
