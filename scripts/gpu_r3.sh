@@ -113,3 +113,13 @@ print('value', j['value'], j['ms_per_step']); print('fp32', j['fp32']); print('x
   cp /tmp/tune_x3.json gpurun_out/${TAG}_tune_after.json
   lap x3_bench
 fi
+if has hirestune; then   # the isolated tile search is noisy at 2048x1024: search it NRUN times on top of the base cache (only NEW keys are measured), keep every result
+  for i in 1 2 3; do
+    cp ${TUNE:-profiles/tune_cache.json} /tmp/tune_h$i.json
+    V2V_TUNE_CACHE=/tmp/tune_h$i.json timeout 600 python bench.py --width 2048 --height 1024 --scales 3 --no-cpu-baseline --no-train-line --steps 20 > gpurun_out/${TAG}_hires_$i.json 2> gpurun_out/${TAG}_hires_$i.err; echo "hires run $i rc=$?"
+    python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_hires_$i.json')); print('run $i:', j['value'], 'frames/s', j['ms_per_step'], 'ms', j['config'].get('frame_tune'))"
+    cp /tmp/tune_h$i.json gpurun_out/${TAG}_tune_h$i.json
+  done
+  lap hirestune
+fi
