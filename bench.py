@@ -277,7 +277,7 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
                         "gflop_per_pair": round(fl / (nrep * n_frames_load) / 1e9, 1),
                         "tflops": round(fl / tf / 1e12, 2), "frac_of_mfma_peak": round(fl / tf / 1e12 / PEAK_TFLOPS[args.precision], 4),
                         "convs_per_pair": (flowNet.module.convs_launched - c0) // (nrep * n_frames_load),
-                        "note": "FlowNet2 (C + S + S + SD + fusion) on %dx%d pairs, hipGraph replay, correlation on the LDS-staged kernel" % (W, H)}
+                        "note": "FlowNet2 (C + S + S + SD + fusion) on %dx%d pairs, hipGraph replay, correlation on the matrix pipe (v2v_correlation_nhwc)" % (W, H)}
 
     sys.stdout = _stdout
     if rank == 0:

@@ -76,7 +76,7 @@ if has prof2; then
   DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
   python $R/scripts/rocprof_summary.py $DB "# round 2, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline (bf16, 512x256; tile selections replayed from profiles/tune_cache.json, no autotune launches in this trace; kernels run inside the 3-lane frame graph)" > $R/gpurun_out/${TAG}_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_bench_prof.err
   head -14 $R/gpurun_out/${TAG}_kernel_stats.txt | cut -c1-200
-  python $R/scripts/in_graph_json.py $DB $NEEDLE $DOM $R/gpurun_out/${TAG}_in_graph.json
+  python $R/scripts/in_graph_json.py $DB $NEEDLE $DOM $R/gpurun_out/${TAG}_in_graph.json ${WGS:-0}
   cut -c1-300 $R/gpurun_out/${TAG}_bench_prof.json
   CFG2=$(echo $DOM | cut -d, -f1,2)
   timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/tr_f -o pmc -- python $R/scripts/conv_layer_run.py --pair --fused --cfg $CFG2,0 > $R/gpurun_out/${TAG}_traffic_fetch.log 2>&1; echo "traffic fetch rc=$?"

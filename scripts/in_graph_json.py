@@ -7,13 +7,21 @@ import sqlite3
 import sys
 
 db, needle, cfg, out = sys.argv[1:5]
+wgs = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # only launches of this many workgroups (a template instance serves several layer shapes)
 c = sqlite3.connect(db)
-rows = c.execute("select name, count(*), avg(end-start), min(end-start), max(end-start) from kernels where name like ? "
-                 "group by name order by 2 desc", ("%" + needle + "%",)).fetchall()
+cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
+where = ""
+if wgs and "grid_size" in cols and "workgroup_size" in cols:
+    where = " and grid_size / workgroup_size = %d" % wgs
+elif wgs and "grid_size_x" in cols and "workgroup_size_x" in cols:
+    where = " and (grid_size_x / workgroup_size_x) * (grid_size_y / workgroup_size_y) * (grid_size_z / workgroup_size_z) = %d" % wgs
+rows = c.execute("select name, count(*), avg(end-start), min(end-start), max(end-start) from kernels where name like ?" + where +
+                 " group by name order by 2 desc", ("%" + needle + "%",)).fetchall()
 res = {"cfg": [int(v) for v in cfg.split(",")], "kernel": rows[0][0] if rows else None,
        "launches": rows[0][1] if rows else 0, "avg_us": round(rows[0][2] / 1e3, 2) if rows else None,
        "min_us": round(rows[0][3] / 1e3, 2) if rows else None, "max_us": round(rows[0][4] / 1e3, 2) if rows else None,
        "note": "rocprofv3 --kernel-trace of `python bench.py` replaying profiles/tune_cache.json: every launch of this kernel "
-               "inside the frame hipGraph (3 lanes sharing the chip), warm-up and timed frames alike"}
+               "inside the frame hipGraph (3 lanes sharing the chip), warm-up and timed frames alike"
+               + (("; launches of %d workgroups only (filter: %s)" % (wgs, where.strip() or "none: grid columns not found")) if wgs else "")}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))

@@ -1027,3 +1027,32 @@ def test_x3_conv_groups_match_the_fp32_path():
             assert all(took) if name == "x3" else not any(took), (name, took)
         for a, b in zip(outs["x3"], outs["fp32"]):
             assert_close(a, b, 2e-4, "x3 vs fp32 MFMA, %d -> %d stride %d" % (cin, cout, stride))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("u8", [False, True])
+@pytest.mark.parametrize("size", [(37, 53), (64, 96), (2, 3)])
+def test_encode_labels_pooled_equals_pooling_the_encoding(size, u8, prec):
+    """v2v_encode_labels_pooled (one build_pyr level straight from the label / instance maps) is bit-identical to
+    v2v_avgpool3s2_nhwc of v2v_encode_labels' output, and its full-resolution foreground mask to encode_labels' mask; the
+    vectorised pooling kernel itself against torch's AvgPool2d(3, 2, 1, count_include_pad=False) on the oracle's encoding."""
+    from oracle import vid2vid_oracle as O
+    H, W = size
+    torch.manual_seed(H * 7 + W)
+    eng = _engine(prec)
+    T, nc = 3, 35
+    lab = torch.randint(0, nc, (T, H, W))
+    inst = torch.randint(0, 5, (T, H // 3 + 1, W // 3 + 1)).repeat_interleave(3, 1).repeat_interleave(3, 2)[:, :H, :W].contiguous()
+    if u8:
+        labd, instd = lab.to(torch.uint8).to(DEV), inst.to(torch.int32).to(DEV)
+    else:
+        labd, instd = lab.float().to(DEV), inst.float().to(DEV)
+    x, mask = eng.encode_labels(labd, instd, T, H, W, nc, [26, 3], True, chunk_stride=True)
+    pooled = eng.avgpool_nhwc(x)
+    x0, p2, mask2 = eng.encode_labels_pooled(labd, instd, T, H, W, nc, [26, 3], True, chunk_stride=True)
+    assert p2.t.shape == pooled.t.shape and p2.C == pooled.C and x0.onehot is not None and x0.t.shape == x.t.shape
+    assert torch.equal(p2.t, pooled.t), "pooled encoding differs from pooling the encoding"
+    assert torch.equal(mask2, mask)
+    enc = O.encode_input(lab.float().view(1, T, 1, H, W), inst.float().view(1, T, 1, H, W), nc).reshape(1, -1, H, W)
+    ref = F.avg_pool2d(enc, 3, 2, 1, count_include_pad=False)
+    assert_close(eng.unpack(p2).cpu(), ref, 1e-6 if prec == "fp32" else 4e-3, "pooled encoding vs torch")

@@ -94,8 +94,23 @@ extern "C" void v2v_plan_destroy(v2v_plan* p) {
     for (auto e : p->seg_exec) if (e) hipGraphExecDestroy(e);
     for (auto g : p->seg_graph) if (g) hipGraphDestroy(g);
     for (auto ev : p->edge_events) hipEventDestroy(ev);
-    for (int k = 1; k < 8; ++k) if (p->lane_stream[k]) hipStreamDestroy(p->lane_stream[k]);
-    delete p;
+    delete p;                                       // (lane streams belong to the process-wide pool below)
+}
+
+// Lane streams are a PROCESS-WIDE pool (round 3): the runtime maps streams onto a small number of hardware queues round-robin in
+// creation order, so a plan that created its own lane streams late in a process (after other plans, copy streams, capture streams)
+// could find two of its lanes -- or a lane and the caller's stream -- on ONE hardware queue and lose their overlap: the 2048x1024
+// frame measured 17.2 ms as the fourth plan of a process and 15.1 ms alone (profiles/r03_c1 vs r03_b9).  Created once, on first use,
+// the lanes keep distinct queues for every plan of the process.  Plans of one process run one after the other on the caller's
+// stream, so sharing the lane streams only adds the ordering they already had.
+static hipStream_t pool_lane_stream(int k) {
+    static hipStream_t pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (k <= 0 || k >= 8) return nullptr;
+    if (!pool[k]) {
+        for (int j = 1; j <= k; ++j)                 // in lane order: the mapping does not depend on which lane a plan touches first
+            if (!pool[j] && hipStreamCreateWithFlags(&pool[j], hipStreamNonBlocking) != hipSuccess) { pool[j] = nullptr; return nullptr; }
+    }
+    return pool[k];
 }
 
 extern "C" int v2v_plan_begin_record(v2v_plan* p) {
@@ -205,7 +220,7 @@ static int plan_instantiate_segments(v2v_plan* p, unsigned long long* stamps = n
         }
         const int lanes_of_step[2] = {st.kind == 0 ? st.b : st.a, st.kind == 0 ? st.b : st.b};
         for (int k : lanes_of_step)
-            if (k != 0 && !p->lane_stream[k] && hipStreamCreateWithFlags(&p->lane_stream[k], hipStreamNonBlocking) != hipSuccess) {
+            if (k != 0 && !p->lane_stream[k] && !(p->lane_stream[k] = pool_lane_stream(k))) {
                 set_error("plan: lane stream"); plan_drop_segments(p); return V2V_EINVAL;
             }
     }

@@ -94,6 +94,113 @@ __global__ __launch_bounds__(256) void encode_labels_kernel(const EncodeArgs a) 
     }
 }
 
+// encode_input + get_edges followed by ONE level of build_pyr (AvgPool2d(3, 2, 1, count_include_pad=False), base_model.py:122-134),
+// straight from the label / instance maps (round 3): out[oy][ox][t * per + c] = (number of in-bounds window pixels whose label is c) /
+// (number of in-bounds window pixels), the edge channel likewise with the 4-neighbour instance-boundary test -- bit for bit what
+// avgpool_nhwc_kernel computes on the materialised encoding (window sums of 0 / 1 are exact integers, the same division), without
+// the full-resolution one-hot tensor: at 2048 x 1024 that tensor is 537 MB written by encode_labels (0.45 ms) and read back by the
+// pooling kernel (0.73 ms), and nothing else needs it once the finest scale's stems read the label maps themselves
+// (csrc/onehot_stem.hip).  The full-resolution foreground mask (compute_mask) is written by the threads of channel vector 0.
+template <typename T, typename LT, typename IT>
+__global__ __launch_bounds__(256) void encode_labels_pooled_kernel(const EncodeArgs a) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int OH = (a.H - 1) / 2 + 1, OW = (a.W - 1) / 2 + 1;
+    const int vpr = a.c_stride / VEC;
+    const long long hw = (long long)a.H * a.W;
+    const long long nvec = (long long)OH * OW * vpr;
+    const int per_frame = a.label_nc + (a.inst ? 1 : 0);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const LT* labels = reinterpret_cast<const LT*>(a.labels);
+    const IT* inst = reinterpret_cast<const IT*>(a.inst);
+    T* out = reinterpret_cast<T*>(a.out);
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        const long long opix = v / vpr;
+        const int c0 = (int)(v - opix * vpr) * VEC;
+        const int oy = (int)(opix / OW), ox = (int)(opix - (long long)oy * OW);
+        int tq[VEC], cq[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) { tq[q] = (c0 + q) / per_frame; cq[q] = (c0 + q) - tq[q] * per_frame; }
+        const int t_first = tq[0], t_last = min(tq[VEC - 1], a.T - 1);
+        float s[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s[q] = 0.f;
+        int cnt = 0;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = 2 * oy + dy;
+            if (y < 0 || y >= a.H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = 2 * ox + dx;
+                if (x < 0 || x >= a.W) continue;
+                ++cnt;
+                const long long pix = (long long)y * a.W + x;
+                for (int t = t_first; t <= t_last; ++t) {
+                    const int lab = (int)labels[t * hw + pix];
+                    int edge = -1;                      // computed on demand: only a vector that holds frame t's edge channel needs it
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        if (tq[q] != t) continue;
+                        if (cq[q] < a.label_nc) {
+                            s[q] += (lab == cq[q]) ? 1.f : 0.f;
+                        } else {
+                            if (edge < 0) {
+                                const IT* ip = inst + t * hw;
+                                const IT ctr = ip[pix];
+                                bool e = false;
+                                if (x > 0)       e = e || (ip[pix - 1] != ctr);
+                                if (x < a.W - 1) e = e || (ip[pix + 1] != ctr);
+                                if (y > 0)       e = e || (ip[pix - a.W] != ctr);
+                                if (y < a.H - 1) e = e || (ip[pix + a.W] != ctr);
+                                edge = e ? 1 : 0;
+                            }
+                            s[q] += (float)edge;
+                        }
+                    }
+                }
+            }
+        }
+        const float fc = (float)cnt;
+        const long long e0 = opix * a.c_stride + c0;
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(out + e0) = make_float4(s[0] / fc, s[1] / fc, s[2] / fc, s[3] / fc);
+        } else {
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16_bits(s[0] / fc) | ((unsigned)f32_to_bf16_bits(s[1] / fc) << 16);
+            pk.y = (unsigned)f32_to_bf16_bits(s[2] / fc) | ((unsigned)f32_to_bf16_bits(s[3] / fc) << 16);
+            pk.z = (unsigned)f32_to_bf16_bits(s[4] / fc) | ((unsigned)f32_to_bf16_bits(s[5] / fc) << 16);
+            pk.w = (unsigned)f32_to_bf16_bits(s[6] / fc) | ((unsigned)f32_to_bf16_bits(s[7] / fc) << 16);
+            *reinterpret_cast<uint4*>(out + e0) = pk;
+        }
+        if (a.mask && c0 == 0) {
+            // compute_mask (models/vid2vid_model_G.py:322-330) on the last frame, FULL resolution: the 2 x 2 pixels this output pixel owns
+            for (int yy = 2 * oy; yy < min(2 * oy + 2, a.H); ++yy)
+                for (int xx = 2 * ox; xx < min(2 * ox + 2, a.W); ++xx) {
+                    const int lab = (int)labels[(long long)(a.T - 1) * hw + (long long)yy * a.W + xx];
+                    float m = 0.f;
+                    for (int i = 0; i < a.n_fg; ++i) m += (a.fg[i] == lab) ? 1.f : 0.f;
+                    a.mask[(long long)yy * a.W + xx] = fminf(fmaxf(m, 0.f), 1.f);
+                }
+        }
+    }
+}
+
+struct EncodePooledOp : Op {
+    EncodeArgs a; int dtype; int in_u8 = 0;
+    int launch(hipStream_t s) override {
+        const int vec = dtype == V2V_BF16 ? 8 : 4;
+        const long long nvec = (long long)((a.H - 1) / 2 + 1) * ((a.W - 1) / 2 + 1) * (a.c_stride / vec);
+        const dim3 g(grid_for(nvec, 256, 16384)), b(256);
+        if (in_u8) {
+            if (dtype == V2V_BF16) hipLaunchKernelGGL((encode_labels_pooled_kernel<bf16_t, unsigned char, int>), g, b, 0, s, a);
+            else                   hipLaunchKernelGGL((encode_labels_pooled_kernel<float, unsigned char, int>), g, b, 0, s, a);
+        } else {
+            if (dtype == V2V_BF16) hipLaunchKernelGGL((encode_labels_pooled_kernel<bf16_t, float, float>), g, b, 0, s, a);
+            else                   hipLaunchKernelGGL((encode_labels_pooled_kernel<float, float, float>), g, b, 0, s, a);
+        }
+        return check_launch();
+    }
+    const char* name() const override { return "encode_labels_pooled"; }
+};
+
 struct EncodeOp : Op {
     EncodeArgs a; int dtype; int in_u8 = 0;
     int launch(hipStream_t s) override {
@@ -205,19 +312,27 @@ __global__ __launch_bounds__(256) void avgpool_planar_kernel(const PoolArgs a) {
     }
 }
 
+// One thread per (output pixel, 16-byte channel vector): 9 vector loads, one vector store (round 3: the element-per-thread form
+// above it replaced needed 0.73 ms for the 1024 x 2048 x 128 label encoding, 0.9 TB/s).  Same arithmetic per element: window
+// values summed in row-major order in fp32, divided by the number of in-bounds taps.
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const PoolArgs a) {
+    constexpr int VEC = ElemTraits<T>::VEC;
     const T* x = reinterpret_cast<const T*>(a.x);
     T* y = reinterpret_cast<T*>(a.y);
-    const long long total = (long long)a.N * a.OH * a.OW * a.c_stride;
+    const int vpr = a.c_stride / VEC;
+    const long long total = (long long)a.N * a.OH * a.OW * vpr;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int c = (int)(e % a.c_stride);
-        long long t = e / a.c_stride;
+        const int c = (int)(e % vpr) * VEC;
+        long long t = e / vpr;
         const int ox = (int)(t % a.OW); t /= a.OW;
         const int oy = (int)(t % a.OH);
         const long long n = t / a.OH;
-        float s = 0.f; int cnt = 0;
+        float s[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s[q] = 0.f;
+        int cnt = 0;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
             const int iy = 2 * oy + dy;
@@ -226,11 +341,29 @@ __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const PoolArgs a) {
             for (int dx = -1; dx <= 1; ++dx) {
                 const int ix = 2 * ox + dx;
                 if (ix < 0 || ix >= a.W) continue;
-                s += load_act(x, ((n * a.H + iy) * a.W + ix) * a.c_stride + c);
+                const uint4 v = *reinterpret_cast<const uint4*>(x + ((n * a.H + iy) * a.W + ix) * a.c_stride + c);
+                if constexpr (VEC == 4) {
+                    s[0] += __uint_as_float(v.x); s[1] += __uint_as_float(v.y); s[2] += __uint_as_float(v.z); s[3] += __uint_as_float(v.w);
+                } else {
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s[2 * k] += __uint_as_float(w[k] << 16); s[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+                }
                 ++cnt;
             }
         }
-        store_act(y, e, s / (float)cnt);
+        const float fc = (float)cnt;
+        T* o = y + (((n * a.OH + oy) * a.OW + ox) * (long long)a.c_stride + c);
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(s[0] / fc, s[1] / fc, s[2] / fc, s[3] / fc);
+        } else {
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16_bits(s[0] / fc) | ((unsigned)f32_to_bf16_bits(s[1] / fc) << 16);
+            pk.y = (unsigned)f32_to_bf16_bits(s[2] / fc) | ((unsigned)f32_to_bf16_bits(s[3] / fc) << 16);
+            pk.z = (unsigned)f32_to_bf16_bits(s[4] / fc) | ((unsigned)f32_to_bf16_bits(s[5] / fc) << 16);
+            pk.w = (unsigned)f32_to_bf16_bits(s[6] / fc) | ((unsigned)f32_to_bf16_bits(s[7] / fc) << 16);
+            *reinterpret_cast<uint4*>(o) = pk;
+        }
     }
 }
 
@@ -240,7 +373,7 @@ struct PoolOp : Op {
         if (planar) {
             hipLaunchKernelGGL(avgpool_planar_kernel, dim3(grid_for(a.planes * a.OH * a.OW)), dim3(256), 0, s, a);
         } else {
-            const long long n = (long long)a.N * a.OH * a.OW * a.c_stride;
+            const long long n = (long long)a.N * a.OH * a.OW * (a.c_stride / (dtype == V2V_BF16 ? 8 : 4));
             if (dtype == V2V_BF16) hipLaunchKernelGGL(avgpool_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
             else                   hipLaunchKernelGGL(avgpool_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
         }
@@ -766,6 +899,21 @@ extern "C" int v2v_encode_labels_u8(const uint8_t* labels, const int32_t* inst, 
     return submit(std::move(op), stream);
 }
 
+extern "C" int v2v_encode_labels_pooled(const void* labels, const void* inst, void* out, float* mask,
+                                        int32_t T, int32_t H, int32_t W, int32_t label_nc, int32_t c_stride,
+                                        const int32_t* fg_labels_dev, int32_t n_fg, int32_t dtype, int32_t maps_u8, void* stream) {
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    const int need = T * (label_nc + (inst ? 1 : 0));
+    if (!labels || !out || T < 1 || H < 1 || W < 1 || label_nc < 1 || c_stride % vec != 0 || need > c_stride || (maps_u8 && label_nc > 256) ||
+        (mask && n_fg > 0 && !fg_labels_dev) || ((uintptr_t)out & 15) != 0 || ((uintptr_t)inst & 3) != 0) {
+        set_error("encode_labels_pooled: bad argument"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<EncodePooledOp>();
+    op->a = EncodeArgs{labels, inst, out, mask, T, H, W, label_nc, c_stride, fg_labels_dev, n_fg};
+    op->dtype = dtype; op->in_u8 = maps_u8 ? 1 : 0;
+    return submit(std::move(op), stream);
+}
+
 // ---------------------------------------------------------------------------------------
 // bf16x3: an fp32 activation as three bf16 channel groups [hi | lo | hi], hi = bf16(x), lo = bf16(x - hi)   (round 3)
 // ---------------------------------------------------------------------------------------
@@ -844,7 +992,7 @@ extern "C" int v2v_avgpool3s2_planar(const float* x, float* y, int64_t planes, i
 
 extern "C" int v2v_avgpool3s2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t c_stride,
                                    int32_t dtype, void* stream) {
-    if (!x || !y) { set_error("avgpool: null"); return V2V_EINVAL; }
+    if (!x || !y || c_stride % (dtype == V2V_BF16 ? 8 : 4) != 0) { set_error("avgpool: null pointer or a channel stride that is not whole 16-byte vectors"); return V2V_EINVAL; }
     auto op = std::make_unique<PoolOp>();
     op->a = PoolArgs{x, y, 0, N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, c_stride}; op->planar = false; op->dtype = dtype;
     return submit(std::move(op), stream);

@@ -1461,6 +1461,36 @@ class Engine:
         check(lib.v2v_memcpy_d2d(_ptr(dst), _ptr(src), nbytes, _stream()), "memcpy_d2d")
         self.label("memcpy_d2d")
 
+    def encode_labels_pooled(self, labels, inst, T, H, W, label_nc, fg_labels, want_mask, chunk_stride=False, source=None):
+        """(lazy full-resolution Act, pooled Act, full-resolution mask): the encoded label maps one pyramid level down, straight
+        from the maps (v2v_encode_labels_pooled).  The full-resolution Act carries only its LabelSource -- its tensor is allocated
+        (shape / stride bookkeeping) but NEVER WRITTEN: legal only when every consumer reads the maps (gather-sum stems)."""
+        per = label_nc + (1 if inst is not None else 0)
+        bke = 64 if self.dtype == L.BF16 else 32
+        cs = pad_channels(T * per, self.dtype)
+        if chunk_stride:
+            cs = (T * per + bke - 1) // bke * bke
+        lazy = torch.empty((1, H, W, cs), dtype=self.tdtype, device=self.device)
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        pooled = torch.empty((1, OH, OW, cs), dtype=self.tdtype, device=self.device)
+        self._keep(pooled)
+        mask = self.empty_f32(1, 1, H, W) if want_mask else None
+        fg = None
+        if want_mask:
+            fg = torch.tensor(list(fg_labels), dtype=torch.int32, device=self.device)
+            self._keep(fg)
+        u8 = labels.dtype == torch.uint8
+        if u8 and inst is not None and inst.dtype != torch.int32:
+            raise TypeError("uint8 label maps go with int32 instance maps")
+        if not u8 and (labels.dtype != torch.float32 or (inst is not None and inst.dtype != torch.float32)):
+            raise TypeError("label / instance maps must be fp32-encoded integers, or uint8 + int32")
+        check(lib.v2v_encode_labels_pooled(_ptr(labels), _ptr(inst), _ptr(pooled), _ptr(mask), T, H, W, label_nc, cs, _ptr(fg),
+                                           0 if fg is None else fg.numel(), self.dtype, int(u8), _stream()), "encode_labels_pooled")
+        self.label("encode_labels_pooled")
+        x0 = Act(lazy, T * per)
+        x0.onehot = source if source is not None else LabelSource(labels, inst, T, label_nc)
+        return x0, Act(pooled, T * per), mask
+
     def encode_labels(self, labels, inst, T, H, W, label_nc, fg_labels, want_mask, chunk_stride=False, source=None):
         """chunk_stride: pad the channel stride to a whole 128-byte K chunk (108 -> 128 channels) so that the
         narrow fine-scale 7x7 stems (cout <= 32) can run on the LDS-patch kernel (tile 60)."""

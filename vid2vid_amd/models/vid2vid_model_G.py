@@ -212,13 +212,20 @@ class _FramePlan:
                 eng.label_codes(src, H, W)                   # one byte per pixel: what the gather-sum stems stage from
             # (writing the one-hot tensor on the foreground tower's lane instead of in front of the towers was measured: -1.5 %,
             # it delays that tower and competes with the label stem; profiles/r02_a29_label_codes_ab.txt)
-            x0, mask0 = eng.encode_labels(self.labels, self.inst, tG, H, W, opt.label_nc, opt.fg_labels, opt.fg,
-                                          chunk_stride=S > 1, source=src)   # fine-scale stems (cout <= 32): LDS-patch 7x7 kernel
+            x1 = None
+            if S > 1 and gather and os.environ.get("V2V_POOLED_ENCODE", "1") != "0":
+                # every consumer of the full-resolution encoding reads the label maps itself: it is never written; the first
+                # pyramid level comes straight from the maps (537 MB less written and read back per frame at 2048x1024)
+                x0, x1, mask0 = eng.encode_labels_pooled(self.labels, self.inst, tG, H, W, opt.label_nc, opt.fg_labels, opt.fg,
+                                                         chunk_stride=True, source=src)
+            else:
+                x0, mask0 = eng.encode_labels(self.labels, self.inst, tG, H, W, opt.label_nc, opt.fg_labels, opt.fg,
+                                              chunk_stride=S > 1, source=src)   # fine-scale stems (cout <= 32): LDS-patch 7x7 kernel
         else:
-            x0, mask0 = eng.pack(self.raw_in), None
+            x0, mask0, x1 = eng.pack(self.raw_in), None, None
         xs, masks = [x0], [mask0]
         for si in range(1, S):                      # build_pyr of the encoded labels (:205)
-            xs.append(eng.avgpool_nhwc(xs[-1]))
+            xs.append(x1 if (si == 1 and x1 is not None) else eng.avgpool_nhwc(xs[-1]))
             masks.append(None)
         per = x0.C // tG
         feat = flow_feat = fg_feat = None
