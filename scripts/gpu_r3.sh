@@ -123,3 +123,18 @@ import json; j = json.load(open('gpurun_out/${TAG}_hires_$i.json')); print('run 
   done
   lap hirestune
 fi
+if has pooltest; then
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 600 -k "pooled or encode_labels or three_scales or full_size_2048 or avgpool or pyr" > gpurun_out/${TAG}_pool_tests.log 2>&1; echo "pool tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_pool_tests.log | cut -c1-400 | tail -20
+  lap pooltest
+fi
+if has headhc; then
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 600 -k "conv7x7 or merged_heads or three_scales or onehot_stem" > gpurun_out/${TAG}_head_tests.log 2>&1; echo "head tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_head_tests.log | cut -c1-400 | tail -20
+  lap headtests
+  python - <<'PY'
+import sqlite3, glob
+for db in glob.glob('/tmp/prof_*/**/*.db', recursive=True)[:1]:
+    c = sqlite3.connect(db); print(db, [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()])
+PY
+fi

@@ -422,7 +422,10 @@ def test_fused_norm_barrier_timeout_is_reported():
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(128, 3, 24, 64, "reflect", 1, "tanh"), (64, 2, 19, 45, "reflect", 2, "none"),
                                   (128, 1, 33, 70, "zero", 1, "sigmoid"), (192, 4, 9, 32, "reflect", 1, "none"),
-                                  (64, 13, 17, 40, "reflect", 1, "none")])
+                                  (64, 13, 17, 40, "reflect", 1, "none"),
+                                  # channel strides of whole HALF chunks (64-byte patch rows, round 3): 1 and 3 half chunks in bf16, 3 in fp32
+                                  (32, 3, 20, 45, "reflect", 1, "tanh"), (96, 2, 17, 40, "reflect", 1, "none"), (48, 16, 12, 33, "zero", 2, "none"),
+                                  (16, 3, 9, 70, "reflect", 1, "sigmoid")])
 def test_conv7x7_head_kernel(case, prec):
     """7x7 head kernel (tile id 60: LDS-resident halo patch + 16-wide MFMA) against torch and
     against the implicit-GEMM kernel on the same packed weights."""
@@ -440,6 +443,8 @@ def test_conv7x7_head_kernel(case, prec):
     ref = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "none": lambda t: t}[actn](ref) * 20.0
     conv = conv.to(DEV)
     xa = eng.pack(x.to(DEV))
+    if (xa.Cs * (2 if prec == "bf16" else 4)) % 64 != 0:      # e.g. 16 bf16 channels = 32-byte rows: widened to a whole half chunk
+        xa = eng.widen(xa, 32 if prec == "bf16" else 16)
     pm, po = (L.PAD_REFLECT, 3) if mode == "reflect" else (L.PAD_ZERO, None)
     outs = {}
     for tile in (60, 3):

@@ -41,15 +41,23 @@ template <> struct Mma16<float> {
     }
 };
 
-template <typename T, int NT>
+// HC = 1 (round 3): 64-byte patch rows -- channel strides that are whole HALF chunks (the 32- and 16-channel towers of the 1024x512 and
+// 2048x1024 scales, which used to be widened to 64 channels in front of their heads: twice / four times the patch bytes, LDS reads and
+// MFMAs for zeros).  One 16 x 16 x 32 MFMA step per tap, 16 patch rows per 1-KiB LDS-DMA piece, 36 KiB of LDS (four workgroups per CU).
+// The 16-byte slot of row q is XOR-ed with (q >> 2) & 3: 16 consecutive rows x one slot index hit 16 distinct 16-byte bank groups.
+template <typename T, int NT, int HC = 0>
 __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, const T* __restrict__ w_ro) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BKE = ElemTraits<T>::BKE;
     constexpr int TH = 8, TW = 32, HALO = 3, KS = 7;
     constexpr int PW = TW + 2 * HALO, PR = (TH + 2 * HALO) * PW;     // 38 x 14 = 532 patch rows
     constexpr int NW = 4;
-    constexpr int NG = (PR + 7) / 8, GP = (NG + NW - 1) / NW;         // 67 pieces, 17 per wave
+    constexpr int ROWB = HC ? 64 : 128;                               // bytes per patch row = per channel chunk of a pixel
+    constexpr int SLOTS = ROWB / 16, RPP = 1024 / ROWB, NH = ROWB / 64;
+    constexpr int NG = (PR + RPP - 1) / RPP, GP = (NG + NW - 1) / NW; // 128-byte rows: 67 pieces, 17 per wave; 64-byte rows: 34 / 9
+    constexpr int CKE = ROWB / (int)sizeof(T);                        // elements per row
     typedef typename Mma16<T>::Frag Frag;
+#define V2V_HEAD_SWZ(q) (HC ? (((q) >> 2) & 3) : (((q) >> 1) & 7))
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
     const int th = trem / p.tiles_w;
     const int oh0 = th * TH, ow0 = (trem - th * p.tiles_w) * TW;
     const int H = p.H, W = p.W, cs = p.cin_stride;
-    const int ncc = cs / BKE;
+    const int ncc = cs / CKE;
     const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
 
     // patch loader geometry: piece g = k*NW + wid covers patch rows 8g..8g+7 (see conv3x3_patch_kernel.h)
@@ -71,8 +79,8 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
     unsigned pok = 0;
 #pragma unroll
     for (int k = 0; k < GP; ++k) {
-        const int q = (k * NW + wid) * 8 + (lane >> 3);
-        const int ls = (lane & 7) ^ ((q >> 1) & 7);
+        const int q = (k * NW + wid) * RPP + lane / SLOTS;
+        const int ls = (lane % SLOTS) ^ V2V_HEAD_SWZ(q);
         const int pr = q / PW, pc = q - pr * PW;
         int ih = oh0 + pr - HALO, iw = ow0 + pc - HALO;
         bool ok = q < PR;
@@ -105,18 +113,18 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
         if (cc > 0) __syncthreads();                                  // every wave is done with the previous chunk's patch
 #pragma unroll
         for (int k = 0; k < GP; ++k) {
-            const char* src = ((pok >> k) & 1u) ? p.in + pp[k] + cc * 128 : p.zero_page;
+            const char* src = ((pok >> k) & 1u) ? p.in + pp[k] + cc * ROWB : p.zero_page;
             glds16(src, smem + (k * NW + wid) * 1024);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const T* const wcc = wlane + cc * BKE;
+        const T* const wcc = wlane + cc * CKE;
         for (int dy = 0; dy < KS; ++dy) {
-            Frag bf[KS][2][NT];                                       // one kernel row of weight fragments in flight
+            Frag bf[KS][NH][NT];                                      // one kernel row of weight fragments in flight
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         bf[dx][h][n] = *reinterpret_cast<const Frag*>(wcc + n * wnt + (long long)(dy * KS + dx) * cs + h * 4 * VEC);
@@ -125,10 +133,10 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int q = qg[g] + dy * PW + dx;
-                    const char* const arow = smem + q * 128;
-                    const int ax = (q >> 1) & 7;
+                    const char* const arow = smem + q * ROWB;
+                    const int ax = V2V_HEAD_SWZ(q);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NH; ++h) {
                         const Frag a = *reinterpret_cast<const Frag*>(arow + (((h * 4 + kg) ^ ax) << 4));
 #pragma unroll
                         for (int n = 0; n < NT; ++n) Mma16<T>::run(a, bf[dx][h][n], acc[g][n]);
@@ -198,6 +206,8 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
     }
 }
 
+#undef V2V_HEAD_SWZ
+
 template <typename T>
 static inline int launch_head_typed(const ConvKArgs& k, hipStream_t s) {
     constexpr int PR = (8 + 6) * (32 + 6);
@@ -208,6 +218,15 @@ static inline int launch_head_typed(const ConvKArgs& k, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv7x7_head_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv7x7_head_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
+    }
+    if ((k.cin_stride * (int)sizeof(T)) % 128 != 0) {                 // whole half chunks only: 64-byte patch rows
+        constexpr int GPH = ((PR + 15) / 16 + 3) / 4;
+        const size_t ldsh = (size_t)GPH * 4 * 1024;                   // 36 KiB
+        if (k.cout <= 16)
+            hipLaunchKernelGGL((conv7x7_head_kernel<T, 1, 1>), dim3((unsigned)k.m_tiles), dim3(256), ldsh, s, k, reinterpret_cast<const T*>(k.w));
+        else
+            hipLaunchKernelGGL((conv7x7_head_kernel<T, 2, 1>), dim3((unsigned)k.m_tiles), dim3(256), ldsh, s, k, reinterpret_cast<const T*>(k.w));
+        return check_launch();
     }
     if (k.cout <= 16)
         hipLaunchKernelGGL((conv7x7_head_kernel<T, 1>), dim3((unsigned)k.m_tiles), dim3(256), lds, s, k, reinterpret_cast<const T*>(k.w));

@@ -492,12 +492,12 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     if (op->cfg == 60) {
         // conv7x7_head_kernel: 7x7 / stride 1 / pad 3 Conv2d with <= 16 output channels written planar fp32
         if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->cout > 32 ||
-            d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 0 || d->splitk > 1 || d->fin_counter ||
+            d->cin_stride % (bke_of(d->dtype) / 2) != 0 || d->w_korder != 0 || d->splitk > 1 || d->fin_counter ||
             !(d->out_mode == V2V_OUT_F32_NCHW || d->out_mode == V2V_OUT_RAW_F32_NHWC) ||
             (d->stats && d->out_mode != V2V_OUT_RAW_F32_NHWC) ||
             (long long)d->N * d->H * d->W * d->cin_stride * (d->dtype == V2V_BF16 ? 2 : 4) >= (1ll << 32)) {
-            set_error("conv: tile config 60 (7x7, cout <= 32) needs a 7x7/s1/p3 Conv2d, cin_stride %% %d == 0, planar fp32 or raw "
-                      "NHWC output without in-kernel norm finalize", bke_of(d->dtype)); return V2V_EINVAL;
+            set_error("conv: tile config 60 (7x7, cout <= 32) needs a 7x7/s1/p3 Conv2d, cin_stride %% %d == 0 (whole 64-byte half chunks), planar fp32 or raw "
+                      "NHWC output without in-kernel norm finalize", bke_of(d->dtype) / 2); return V2V_EINVAL;
         }
         k.tiles_h = (int)ceil_div(d->OH, 8);
         k.tiles_w = (int)ceil_div(d->OW, 32);

@@ -1149,7 +1149,7 @@ class Engine:
                 if S == 1 and t >= 18 and tiles < 96:
                     continue            # large tiles that cannot fill the chip without split-K
                 cands.append((t, S, 0))      # (prefetch-helper variants never won a sweep: not searched)
-        bke_ = 64 if self.dtype == L.BF16 else 32
+        bke_ = 32 if self.dtype == L.BF16 else 16         # whole 64-byte half chunks (conv7x7_head_kernel, HC = 1)
         if (not d.transposed and d.KH == 7 and d.KW == 7 and d.stride == 1 and d.pad == 3 and cout <= 32
                 and d.cin_stride % bke_ == 0 and not d.fin_counter
                 and (d.out_mode == L.OUT_F32_NCHW or d.out_mode == L.OUT_RAW_F32_NHWC)):
@@ -1301,10 +1301,10 @@ class Engine:
                                    label=label, ss=ss, finalized=self.fused_finalize and self.last_finalized)
         if add0 is not None or add1 is not None:
             raise NotImplementedError("residual adds need a norm layer in the group")
-        bke = 64 if self.dtype == L.BF16 else 32
+        bke = 32 if self.dtype == L.BF16 else 16              # the 7x7 head kernel reads whole 64-byte half chunks
         if (head_nchw and isinstance(conv, nn.Conv2d) and conv.kernel_size == (7, 7) and conv.out_channels <= 32
                 and x.Cs % bke != 0 and x.H * x.W >= 65536):
-            x = self.widen(x, (x.Cs + bke - 1) // bke * bke)      # e.g. the 32-channel scale-2 towers: 64-byte rows
+            x = self.widen(x, (x.Cs + bke - 1) // bke * bke)      # e.g. the 16-channel foreground tower of scale 2: 32-byte rows
         if head_nchw and self._x3_ok(x, conv, pad_override, with_norm=False):     # API-facing 7x7 heads: planar fp32 straight from the bf16x3 product
             sub = self._x3_enter()
             n0 = len(sub.conv_log)
@@ -1336,8 +1336,8 @@ class Engine:
                 merged = self._merged_heads[key] = MergedConv(pa[1], pb[1])
             except ValueError:
                 return None
-        bke = 64 if self.dtype == L.BF16 else 32
-        if x.Cs % bke != 0:                       # the 7x7 head kernel reads whole 128-byte channel chunks
+        bke = 32 if self.dtype == L.BF16 else 16
+        if x.Cs % bke != 0:                       # the 7x7 head kernel reads whole 64-byte half chunks
             if x.H * x.W < 65536:
                 return None
             x = self.widen(x, (x.Cs + bke - 1) // bke * bke)
