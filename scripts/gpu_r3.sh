@@ -138,3 +138,8 @@ for db in glob.glob('/tmp/prof_*/**/*.db', recursive=True)[:1]:
     c = sqlite3.connect(db); print(db, [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()])
 PY
 fi
+if has lazytest; then
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 600 -k "conv7x7_head or three_scales or full_size_2048 or training_chunk_vs_reference or inference" > gpurun_out/${TAG}_lazy_tests.log 2>&1; echo "lazy tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_lazy_tests.log | cut -c1-400 | tail -20
+  lap lazytest
+fi

@@ -444,7 +444,8 @@ def test_conv7x7_head_kernel(case, prec):
     conv = conv.to(DEV)
     xa = eng.pack(x.to(DEV))
     if (xa.Cs * (2 if prec == "bf16" else 4)) % 64 != 0:      # e.g. 16 bf16 channels = 32-byte rows: widened to a whole half chunk
-        xa = eng.widen(xa, 32 if prec == "bf16" else 16)
+        hc = 32 if prec == "bf16" else 16
+        xa = eng.widen(xa, (xa.Cs + hc - 1) // hc * hc)
     pm, po = (L.PAD_REFLECT, 3) if mode == "reflect" else (L.PAD_ZERO, None)
     outs = {}
     for tile in (60, 3):

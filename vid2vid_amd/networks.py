@@ -474,6 +474,14 @@ class CompositeLocalGenerator(BaseNetwork):
     def flow_multiplier(self):
         return 20.0 * (2 ** self.scale)
 
+    def label_stems(self):
+        """The convolutions that read the encoded label maps directly (7x7 stems of the label and foreground towers): when all
+        of them run as gather-sums on the maps, the full-resolution encoding is never written (Engine.encode_labels_pooled)."""
+        convs = [next(mm for mm in self.model_down_seg if isinstance(mm, nn.Conv2d))]
+        if self.use_fg_model:
+            convs.append(next(mm for mm in self.indv_down if isinstance(mm, nn.Conv2d)))
+        return convs
+
     def emit(self, eng, x, prev, img_prev_nchw, mask, img_feat_coarse, flow_feat_coarse, img_fg_feat_coarse,
              use_raw_only, tag="G1"):
         """Same lane structure as CompositeGenerator.emit: label stem | image stem | foreground branch in parallel, then
