@@ -143,3 +143,7 @@ if has lazytest; then
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_lazy_tests.log | cut -c1-400 | tail -20
   lap lazytest
 fi
+if has pooledonly; then
+  timeout 600 python -m pytest tests -m gpu -q --tb=short -k "encode_labels_pooled" 2>&1 | tail -3
+  lap pooledonly
+fi

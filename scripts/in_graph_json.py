@@ -11,10 +11,21 @@ wgs = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # only launches of this 
 c = sqlite3.connect(db)
 cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
 where = ""
-if wgs and "grid_size" in cols and "workgroup_size" in cols:
-    where = " and grid_size / workgroup_size = %d" % wgs
-elif wgs and "grid_size_x" in cols and "workgroup_size_x" in cols:
-    where = " and (grid_size_x / workgroup_size_x) * (grid_size_y / workgroup_size_y) * (grid_size_z / workgroup_size_z) = %d" % wgs
+if wgs:
+    import re
+    def col(kind, ax):
+        pats = {"g": ("grid_size_%s", "grid_%s", "grid%s", "grid_size%s"), "w": ("workgroup_size_%s", "workgroup_%s", "wg_%s", "block_%s", "workgroup_size%s")}[kind]
+        for p in pats:
+            if p % ax in cols:
+                return p % ax
+        return None
+    gx, gy, gz, wx, wy, wz = [col(k, a) for k in "gw" for a in "xyz"]
+    if "grid_size" in cols and "workgroup_size" in cols:
+        where = " and grid_size / workgroup_size = %d" % wgs
+    elif all((gx, gy, gz, wx, wy, wz)):
+        where = " and (%s / %s) * (%s / %s) * (%s / %s) = %d" % (gx, wx, gy, wy, gz, wz, wgs)
+    else:
+        print("in_graph_json: no grid / workgroup columns among", cols, file=sys.stderr)
 rows = c.execute("select name, count(*), avg(end-start), min(end-start), max(end-start) from kernels where name like ?" + where +
                  " group by name order by 2 desc", ("%" + needle + "%",)).fetchall()
 res = {"cfg": [int(v) for v in cfg.split(",")], "kernel": rows[0][0] if rows else None,

@@ -105,79 +105,91 @@ template <typename T, typename LT, typename IT>
 __global__ __launch_bounds__(256) void encode_labels_pooled_kernel(const EncodeArgs a) {
     constexpr int VEC = ElemTraits<T>::VEC;
     const int OH = (a.H - 1) / 2 + 1, OW = (a.W - 1) / 2 + 1;
-    const int vpr = a.c_stride / VEC;
-    const long long hw = (long long)a.H * a.W;
-    const long long nvec = (long long)OH * OW * vpr;
+    const unsigned vpr = (unsigned)(a.c_stride / VEC);
+    const unsigned hw = (unsigned)a.H * (unsigned)a.W;                // < 2^31 (host check): 32-bit index arithmetic throughout
+    const unsigned nvec = (unsigned)OH * (unsigned)OW * vpr;
     const int per_frame = a.label_nc + (a.inst ? 1 : 0);
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    const unsigned stride = gridDim.x * blockDim.x;
     const LT* labels = reinterpret_cast<const LT*>(a.labels);
     const IT* inst = reinterpret_cast<const IT*>(a.inst);
     T* out = reinterpret_cast<T*>(a.out);
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-        const long long opix = v / vpr;
+    for (unsigned v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        const unsigned opix = v / vpr;
         const int c0 = (int)(v - opix * vpr) * VEC;
-        const int oy = (int)(opix / OW), ox = (int)(opix - (long long)oy * OW);
+        const int oy = (int)(opix / (unsigned)OW), ox = (int)(opix - (unsigned)oy * (unsigned)OW);
+        // frame / channel of each of the vector's channels: one division, then carries (a vector can span several frames when
+        // a frame has fewer channels than the vector)
         int tq[VEC], cq[VEC];
+        {
+            int t = c0 / per_frame, c = c0 - t * per_frame;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) { tq[q] = (c0 + q) / per_frame; cq[q] = (c0 + q) - tq[q] * per_frame; }
+            for (int q = 0; q < VEC; ++q) {
+                tq[q] = t; cq[q] = c;
+                if (++c == per_frame) { c = 0; ++t; }
+            }
+        }
         const int t_first = tq[0], t_last = min(tq[VEC - 1], a.T - 1);
-        float s[VEC];
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) s[q] = 0.f;
+        // window counts as 8-bit fields of one 64-bit word (a window holds <= 9 pixels): per window pixel and frame ONE range test
+        // and one shifted add instead of VEC compare-and-adds.  For frame t the vector's label channels are a contiguous run:
+        // channel c sits at field qs[t] + (c - cs[t]) while cs[t] <= c < ce[t]; the frame's edge channel (if in the vector) at qe[t].
+        unsigned long long acc = 0ull;
         int cnt = 0;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int y = 2 * oy + dy;
-            if (y < 0 || y >= a.H) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int x = 2 * ox + dx;
-                if (x < 0 || x >= a.W) continue;
-                ++cnt;
-                const long long pix = (long long)y * a.W + x;
-                for (int t = t_first; t <= t_last; ++t) {
-                    const int lab = (int)labels[t * hw + pix];
-                    int edge = -1;                      // computed on demand: only a vector that holds frame t's edge channel needs it
+        const int y0 = max(2 * oy - 1, 0), y1 = min(2 * oy + 1, a.H - 1), x0 = max(2 * ox - 1, 0), x1 = min(2 * ox + 1, a.W - 1);
+        for (int t = t_first; t <= t_last; ++t) {
+            int qs = -1, cs = 0, ce = 0, qe = -1;
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        if (tq[q] != t) continue;
-                        if (cq[q] < a.label_nc) {
-                            s[q] += (lab == cq[q]) ? 1.f : 0.f;
-                        } else {
-                            if (edge < 0) {
-                                const IT* ip = inst + t * hw;
-                                const IT ctr = ip[pix];
-                                bool e = false;
-                                if (x > 0)       e = e || (ip[pix - 1] != ctr);
-                                if (x < a.W - 1) e = e || (ip[pix + 1] != ctr);
-                                if (y > 0)       e = e || (ip[pix - a.W] != ctr);
-                                if (y < a.H - 1) e = e || (ip[pix + a.W] != ctr);
-                                edge = e ? 1 : 0;
-                            }
-                            s[q] += (float)edge;
-                        }
+            for (int q = 0; q < VEC; ++q) {
+                if (tq[q] != t) continue;
+                if (cq[q] < a.label_nc) { if (qs < 0) { qs = q; cs = cq[q]; } ce = cq[q] + 1; }
+                else qe = q;
+            }
+            const LT* lp = labels + (unsigned)t * hw;
+            const IT* ip = inst + (unsigned)t * hw;
+            cnt = 0;
+            for (int y = y0; y <= y1; ++y) {
+                for (int x = x0; x <= x1; ++x) {
+                    ++cnt;
+                    const unsigned pix = (unsigned)y * (unsigned)a.W + (unsigned)x;
+                    if (qs >= 0) {
+                        const int lab = (int)lp[pix];
+                        if (lab >= cs && lab < ce) acc += 1ull << (8 * (qs + lab - cs));
+                    }
+                    if (qe >= 0) {
+                        const IT ctr = ip[pix];
+                        bool e = false;
+                        if (x > 0)       e = e || (ip[pix - 1] != ctr);
+                        if (x < a.W - 1) e = e || (ip[pix + 1] != ctr);
+                        if (y > 0)       e = e || (ip[pix - a.W] != ctr);
+                        if (y < a.H - 1) e = e || (ip[pix + a.W] != ctr);
+                        if (e) acc += 1ull << (8 * qe);
                     }
                 }
             }
         }
+        if (cnt == 0) cnt = (y1 - y0 + 1) * (x1 - x0 + 1);           // padding-only vectors: no frame visited
+        float s[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s[q] = (float)((acc >> (8 * q)) & 0xffull);
         const float fc = (float)cnt;
-        const long long e0 = opix * a.c_stride + c0;
+        T* const o = out + (size_t)opix * a.c_stride + c0;
         if constexpr (VEC == 4) {
-            *reinterpret_cast<float4*>(out + e0) = make_float4(s[0] / fc, s[1] / fc, s[2] / fc, s[3] / fc);
+            *reinterpret_cast<float4*>(o) = make_float4(s[0] / fc, s[1] / fc, s[2] / fc, s[3] / fc);
         } else {
             uint4 pk;
             pk.x = (unsigned)f32_to_bf16_bits(s[0] / fc) | ((unsigned)f32_to_bf16_bits(s[1] / fc) << 16);
             pk.y = (unsigned)f32_to_bf16_bits(s[2] / fc) | ((unsigned)f32_to_bf16_bits(s[3] / fc) << 16);
             pk.z = (unsigned)f32_to_bf16_bits(s[4] / fc) | ((unsigned)f32_to_bf16_bits(s[5] / fc) << 16);
             pk.w = (unsigned)f32_to_bf16_bits(s[6] / fc) | ((unsigned)f32_to_bf16_bits(s[7] / fc) << 16);
-            *reinterpret_cast<uint4*>(out + e0) = pk;
+            *reinterpret_cast<uint4*>(o) = pk;
         }
         if (a.mask && c0 == 0) {
             // compute_mask (models/vid2vid_model_G.py:322-330) on the last frame, FULL resolution: the 2 x 2 pixels this output pixel owns
             for (int yy = 2 * oy; yy < min(2 * oy + 2, a.H); ++yy)
                 for (int xx = 2 * ox; xx < min(2 * ox + 2, a.W); ++xx) {
-                    const int lab = (int)labels[(long long)(a.T - 1) * hw + (long long)yy * a.W + xx];
+                    const int lab = (int)labels[(unsigned)(a.T - 1) * hw + (unsigned)yy * (unsigned)a.W + (unsigned)xx];
                     float m = 0.f;
                     for (int i = 0; i < a.n_fg; ++i) m += (a.fg[i] == lab) ? 1.f : 0.f;
-                    a.mask[(long long)yy * a.W + xx] = fminf(fmaxf(m, 0.f), 1.f);
+                    a.mask[(unsigned)yy * (unsigned)a.W + (unsigned)xx] = fminf(fmaxf(m, 0.f), 1.f);
                 }
         }
     }
@@ -905,7 +917,8 @@ extern "C" int v2v_encode_labels_pooled(const void* labels, const void* inst, vo
     const int vec = dtype == V2V_BF16 ? 8 : 4;
     const int need = T * (label_nc + (inst ? 1 : 0));
     if (!labels || !out || T < 1 || H < 1 || W < 1 || label_nc < 1 || c_stride % vec != 0 || need > c_stride || (maps_u8 && label_nc > 256) ||
-        (mask && n_fg > 0 && !fg_labels_dev) || ((uintptr_t)out & 15) != 0 || ((uintptr_t)inst & 3) != 0) {
+        (mask && n_fg > 0 && !fg_labels_dev) || ((uintptr_t)out & 15) != 0 || ((uintptr_t)inst & 3) != 0 ||
+        (long long)T * H * W >= (1ll << 31) || (long long)((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (c_stride / vec) >= (1ll << 31)) {
         set_error("encode_labels_pooled: bad argument"); return V2V_EINVAL;
     }
     auto op = std::make_unique<EncodePooledOp>();
