@@ -147,3 +147,29 @@ if has pooledonly; then
   timeout 600 python -m pytest tests -m gpu -q --tb=short -k "encode_labels_pooled" 2>&1 | tail -3
   lap pooledonly
 fi
+if has corrpmc; then     # the correlation kernel: duration (kernel trace) and fabric traffic (separate PMC passes), bf16 and fp32
+  cd /tmp
+  for pr in bf16 fp32; do
+    timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/cr_$pr -o cr -- python $R/scripts/corr_run.py --precision $pr > /tmp/cr_$pr.log 2>&1
+    python $R/scripts/rocprof_summary.py $(find /tmp/cr_$pr -name "*.db" | head -1) "# v2v_correlation_nhwc, $pr, N=2 C=256 32x64 -> 441 channels, cold cache" | grep -E "correlation|^#"
+    tail -1 /tmp/cr_$pr.log
+  done > $R/gpurun_out/${TAG}_correlation_profile.txt 2>&1
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout 200 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/cp_$ctr -o cp -- python $R/scripts/corr_run.py > /dev/null 2>&1
+    python $R/scripts/pmc_kernel.py $(find /tmp/cp_$ctr -name "*.db" | head -1) $ctr correlation_mma
+  done >> $R/gpurun_out/${TAG}_correlation_profile.txt 2>&1
+  cat $R/gpurun_out/${TAG}_correlation_profile.txt | cut -c1-220
+  cd $R
+  lap corrpmc
+fi
+if has final; then       # evidence for the committed line: in-graph duration + PMC traffic of the dominant tile, copied where bench.py looks, then the driver's command
+  DOM=${DOM:-91,1,2} WGS=256 NEEDLE=${NEEDLE:-conv3x3_pp3_kernelIDF16bLi4ELi64ELi64ELi4ELi0ELi4ELi1ELi2} bash scripts/gpu_r2.sh ${TAG} prof2
+  cp gpurun_out/${TAG}_in_graph.json profiles/${TAG}_in_graph.json; cp gpurun_out/${TAG}_traffic.json profiles/${TAG}_traffic.json
+  TB=$(date +%s)
+  timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$? wall $(( $(date +%s) - TB )) s"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_bench_default.json'))
+print('value', j['value'], j['ms_per_step'], j['timing']['windows_ms_per_step']); r = j['roofline']; print(r['kernel'], r['frac'], r['avg_launch_us'], r['in_graph'], r['traffic'])
+print('x3', j['x3']['value'], j['x3']['max_rel'], 'fp32', j['fp32']['value'], 'hires', j['hires']['value'], j['hires']['parity']['fp32_max_rel'], 'train', j['train']['value'], j['train']['parity']['fp32_ok'])"
+  lap final
+fi
