@@ -558,6 +558,8 @@ class Engine:
             pc.refresh(force)
         for pc in self._packed_onehot.values():
             pc.refresh(force)
+        if self._x3_engine is not None:                 # the bf16x3 weight views live in the sub-engine (X3Conv.version_key follows the source layer)
+            self._x3_engine.refresh_weights(force)
 
     # ---------------- one-hot stem (label-map input) ----------------
     def onehot_conv_ok(self, conv, cin, H, W, pad_mode=L.PAD_REFLECT, pad=3):
