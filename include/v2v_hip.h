@@ -328,6 +328,11 @@ int v2v_fg_mask_nhwc(const void* x, float* mask, int64_t P, int32_t c_stride, in
  * [pixels][cs_out], channels [hi | lo | hi] with hi = bf16(x), lo = bf16(x - hi).  Convolved with weights laid out [hi(W) | hi(W) |
  * lo(W)] along the input channels (any conv kernel of this library, dtype V2V_BF16, cin = 3 C) this gives x * W to ~2^-17 relative. */
 int v2v_split_x3(const float* x, void* y, int64_t pixels, int32_t C, int32_t cs_in, int32_t cs_out, void* stream);
+/* v2v_bn_apply / v2v_bn_apply_pair in fp32 (raw_b == NULL: one member) that also write the result as the bf16x3 operand
+ * [pixels][3 C] of the consumer convolution: no separate v2v_split_x3 pass.  Dense channel stride (c_stride == C), C % 4 == 0. */
+int v2v_bn_apply_x3(const float* raw_a, const float* scale_shift_a, const void* add0_a, const void* add1_a, void* y_a, void* x3_a,
+                    const float* raw_b, const float* scale_shift_b, const void* add0_b, const void* add1_b, void* y_b, void* x3_b,
+                    int32_t c_stride_raw, int64_t P, int32_t C, int32_t act, float act_param, void* stream);
 int v2v_pack_nchw_to_nhwc(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
                           int32_t c_stride, int32_t dtype, void* stream);
 /* NHWC activation dtype -> planar fp32 NCHW */

@@ -112,12 +112,14 @@ struct BnApplyArgs {
     long long P; int C; int c_stride; int act; float act_param;
     // second member of a paired launch (v2v_bn_apply_pair, gridDim.y == 2): same geometry, its own tensors
     const float* raw1; const float* scale_shift1; const void* add0_1; const void* add1_1; void* y1;
+    // fp32 only (v2v_bn_apply_x3): the result also as the bf16x3 operand [hi | lo | hi] of the consumer convolution, channel stride 3 C
+    unsigned short* x3 = nullptr; unsigned short* x3_1 = nullptr;
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a_in) {
     BnApplyArgs a = a_in;
-    if (blockIdx.y != 0) { a.raw = a_in.raw1; a.scale_shift = a_in.scale_shift1; a.add0 = a_in.add0_1; a.add1 = a_in.add1_1; a.y = a_in.y1; }
+    if (blockIdx.y != 0) { a.raw = a_in.raw1; a.scale_shift = a_in.scale_shift1; a.add0 = a_in.add0_1; a.add1 = a_in.add1_1; a.y = a_in.y1; a.x3 = a_in.x3_1; }
     constexpr int VEC = ElemTraits<T>::VEC;
     const int vpr = a.c_stride / VEC;                       // vectors per pixel row
     const long long nvec = a.P * vpr;
@@ -165,6 +167,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a_in) {
         }
         if constexpr (VEC == 4) {
             *reinterpret_cast<float4*>(y + e) = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.x3) {                                      // the arithmetic of split_x3_kernel (csrc/pointwise.hip), no second pass
+                unsigned short hi[4], lo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    hi[q] = f32_to_bf16_bits(o[q]);
+                    lo[q] = f32_to_bf16_bits(o[q] - bf16_bits_to_f32(hi[q]));
+                }
+                const uint2 vh = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+                const uint2 vl = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+                unsigned short* o3 = a.x3 + pix * 3ll * a.C + c0;
+                *reinterpret_cast<uint2*>(o3) = vh;
+                *reinterpret_cast<uint2*>(o3 + a.C) = vl;
+                *reinterpret_cast<uint2*>(o3 + 2 * a.C) = vh;
+            }
         } else {
             uint4 pk;
             pk.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
@@ -605,6 +621,28 @@ extern "C" int v2v_bn_apply_pair(const float* raw_a, const float* scale_shift_a,
     a.act = act; a.act_param = act_param;
     a.raw1 = raw_b; a.scale_shift1 = scale_shift_b; a.add0_1 = add0_b; a.add1_1 = add1_b; a.y1 = y_b;
     op->dtype = dtype; op->members = 2;
+    return submit(std::move(op), stream);
+}
+
+// fp32 bn_apply (one or two members) that ALSO writes the bf16x3 operand of the result (include/v2v_hip.h, v2v_split_x3): the consumer
+// convolution of the fp32 engine's x3 mode reads it directly, the separate split pass disappears.
+extern "C" int v2v_bn_apply_x3(const float* raw_a, const float* scale_shift_a, const void* add0_a, const void* add1_a, void* y_a, void* x3_a,
+                               const float* raw_b, const float* scale_shift_b, const void* add0_b, const void* add1_b, void* y_b, void* x3_b,
+                               int32_t c_stride_raw, int64_t P, int32_t C, int32_t act, float act_param, void* stream) {
+    const bool two = raw_b != nullptr;
+    if (!raw_a || !scale_shift_a || !y_a || !x3_a || P <= 0 || C < 4 || C % 4 != 0 || c_stride_raw % 4 != 0 || C > c_stride_raw ||
+        (two && (!scale_shift_b || !y_b || !x3_b || y_a == y_b || x3_a == x3_b || (add0_a != nullptr) != (add0_b != nullptr) ||
+                 (add1_a != nullptr) != (add1_b != nullptr)))) {
+        set_error("bn_apply_x3: bad argument (fp32, dense channel stride C %% 4 == 0)"); return V2V_EINVAL;
+    }
+    auto op = std::make_unique<BnApplyOp>();
+    BnApplyArgs& a = op->a;
+    a.raw = raw_a; a.c_stride_raw = c_stride_raw; a.scale_shift = scale_shift_a;
+    a.add0 = add0_a; a.add1 = add1_a; a.y = y_a; a.P = P; a.C = C; a.c_stride = C;
+    a.act = act; a.act_param = act_param; a.x3 = reinterpret_cast<unsigned short*>(x3_a);
+    a.raw1 = raw_b; a.scale_shift1 = scale_shift_b; a.add0_1 = add0_b; a.add1_1 = add1_b; a.y1 = y_b;
+    a.x3_1 = reinterpret_cast<unsigned short*>(x3_b);
+    op->dtype = V2V_F32; op->members = two ? 2 : 1;
     return submit(std::move(op), stream);
 }
 

@@ -58,11 +58,12 @@ def pad_channels(c, dtype):
 
 class Act:
     """NHWC activation: tensor [N,H,W,Cs] (Cs = padded channel stride), C real channels."""
-    __slots__ = ("t", "C", "onehot")
+    __slots__ = ("t", "C", "onehot", "x3")
 
     def __init__(self, t, C, onehot=None):
         self.t, self.C = t, C
         self.onehot = onehot      # LabelSource when this Act is the one-hot encoding of label maps (encode_labels)
+        self.x3 = None            # x3 engines: the same values as a bf16x3 operand [hi | lo | hi], written by the producing bn_apply
 
     def detach(self):
         return Act(self.t.detach(), self.C)
@@ -885,8 +886,19 @@ class Engine:
             w = self._x3_convs[id(conv)] = X3Conv(conv)
         return w
 
+    def _x3_out(self, y):
+        """The bf16x3 side output of a bn_apply that produces `y`, or None when `y` cannot feed an x3 convolution."""
+        if not (self.x3 and y.C % 64 == 0 and y.Cs == y.C and not self._training() and not self.record_only):
+            return None
+        t = torch.empty((y.N, y.H, y.W, 3 * y.C), dtype=torch.bfloat16, device=self.device)
+        self._keep(t)
+        y.x3 = Act(t, 3 * y.C)
+        return t
+
     def split_x3(self, x):
         """fp32 Act (C channels, C % 64 == 0, dense stride) -> bf16 Act of 3 C channels [hi | lo | hi]."""
+        if x.x3 is not None:                                      # written by the producing bn_apply (v2v_bn_apply_x3)
+            return x.x3
         out = torch.empty((x.N, x.H, x.W, 3 * x.C), dtype=torch.bfloat16, device=self.device)
         self._keep(out)
         check(lib.v2v_split_x3(_ptr(x.t), _ptr(out), x.N * x.H * x.W, x.C, x.Cs, 3 * x.C, _stream()), "split_x3")
@@ -1020,10 +1032,16 @@ class Engine:
                     self.label(lbl + ".norm")
         a0, a1 = adds_a
         b0, b1 = adds_b
-        check(lib.v2v_bn_apply_pair(_ptr(ra[0]), _ptr(ssa), _ptr(None if a0 is None else a0.t), _ptr(None if a1 is None else a1.t), _ptr(ya.t),
-                                    _ptr(rb[0]), _ptr(ssb), _ptr(None if b0 is None else b0.t), _ptr(None if b1 is None else b1.t), _ptr(yb.t),
-                                    cs_raw, N * OH * OW, cout, ya.Cs, act, act_param, self.dtype, _stream()),
-              "bn_apply_pair " + labels[0])
+        xa3, xb3 = self._x3_out(ya), self._x3_out(yb)
+        if xa3 is not None and xb3 is not None:
+            check(lib.v2v_bn_apply_x3(_ptr(ra[0]), _ptr(ssa), _ptr(None if a0 is None else a0.t), _ptr(None if a1 is None else a1.t), _ptr(ya.t), _ptr(xa3),
+                                      _ptr(rb[0]), _ptr(ssb), _ptr(None if b0 is None else b0.t), _ptr(None if b1 is None else b1.t), _ptr(yb.t), _ptr(xb3),
+                                      cs_raw, N * OH * OW, cout, act, act_param, _stream()), "bn_apply_x3 (pair) " + labels[0])
+        else:
+            check(lib.v2v_bn_apply_pair(_ptr(ra[0]), _ptr(ssa), _ptr(None if a0 is None else a0.t), _ptr(None if a1 is None else a1.t), _ptr(ya.t),
+                                        _ptr(rb[0]), _ptr(ssb), _ptr(None if b0 is None else b0.t), _ptr(None if b1 is None else b1.t), _ptr(yb.t),
+                                        cs_raw, N * OH * OW, cout, ya.Cs, act, act_param, self.dtype, _stream()),
+                  "bn_apply_pair " + labels[0])
         self.label(labels[0] + ".apply + " + labels[1] + ".apply")
         return ya, yb
 
@@ -1265,10 +1283,16 @@ class Engine:
                                       _ptr(ss), _ptr(rm), _ptr(rv), mom, _ptr(ws), _stream()), "bn_finalize " + label)
             self.label(label + ".norm")
         y = self.empty_act(N, OH, OW, cout)
-        check(lib.v2v_bn_apply(_ptr(raw), cs_raw, _ptr(ss),
-                               _ptr(None if add0 is None else add0.t), _ptr(None if add1 is None else add1.t),
-                               _ptr(y.t), N * OH * OW, cout, y.Cs, act, act_param, self.dtype, _stream()),
-              "bn_apply " + label)
+        y3 = self._x3_out(y)
+        if y3 is not None:
+            check(lib.v2v_bn_apply_x3(_ptr(raw), _ptr(ss), _ptr(None if add0 is None else add0.t), _ptr(None if add1 is None else add1.t),
+                                      _ptr(y.t), _ptr(y3), None, None, None, None, None, None,
+                                      cs_raw, N * OH * OW, cout, act, act_param, _stream()), "bn_apply_x3 " + label)
+        else:
+            check(lib.v2v_bn_apply(_ptr(raw), cs_raw, _ptr(ss),
+                                   _ptr(None if add0 is None else add0.t), _ptr(None if add1 is None else add1.t),
+                                   _ptr(y.t), N * OH * OW, cout, y.Cs, act, act_param, self.dtype, _stream()),
+                  "bn_apply " + label)
         self.label(label + ".apply")
         return y
 

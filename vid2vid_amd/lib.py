@@ -156,6 +156,7 @@ PROTOTYPES = {
     "v2v_plan_lane_wait": (C.c_int, [_I, _I]),
     "v2v_memcpy_d2d": (C.c_int, [_P, _P, _L, _P]),
     "v2v_split_x3": (C.c_int, [_P, _P, _L, _I, _I, _I, _P]),
+    "v2v_bn_apply_x3": (C.c_int, [_P] * 12 + [_I, _L, _I, _I, _F, _P]),
     "v2v_set_dry_run": (C.c_int, [_I]),
     "v2v_get_dry_run": (C.c_int, []),
     "v2v_version": (C.c_int, []),
