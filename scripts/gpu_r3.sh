@@ -173,3 +173,15 @@ print('value', j['value'], j['ms_per_step'], j['timing']['windows_ms_per_step'])
 print('x3', j['x3']['value'], j['x3']['max_rel'], 'fp32', j['fp32']['value'], 'hires', j['hires']['value'], j['hires']['parity']['fp32_max_rel'], 'train', j['train']['value'], j['train']['parity']['fp32_ok'])"
   lap final
 fi
+if has headab; then      # 7x7 heads: 128-byte patch rows (two workgroups per CU) against 64-byte rows for every stride (four per CU)
+  for hc in 0 1; do
+    echo "V2V_HEAD_HC=$hc"; V2V_HEAD_HC=$hc timeout 200 python scripts/head_bench.py 2>/dev/null
+  done | tee gpurun_out/${TAG}_head_hc_ab.txt
+  V2V_HEAD_HC=1 timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "conv7x7 or merged_heads" 2>&1 | tail -2
+  for hc in 0 1; do
+    cp profiles/tune_cache.json /tmp/tune_hc$hc.json
+    V2V_HEAD_HC=$hc V2V_TUNE_CACHE=/tmp/tune_hc$hc.json timeout 600 python bench.py --no-cpu-baseline --no-train-line 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); print('V2V_HEAD_HC=$hc: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms;  2048x1024', j['hires']['value'], 'fps', j['hires']['ms_per_step'], 'ms')"
+  done | tee -a gpurun_out/${TAG}_head_hc_ab.txt
+  lap headab
+fi

@@ -74,3 +74,23 @@ def _walk(d, prefix=""):
             yield from _walk(v, prefix + k + ".")
         elif isinstance(v, (int, float)) and not isinstance(v, bool):
             yield prefix + k, float(v)
+
+
+def test_round3_companion_objects(line):
+    """The default line carries BOTH resolutions of BASELINE's metric, the parity-carrying precisions beside the bf16
+    throughput mode, a stable timer, and the training chunk's parity against the oracle."""
+    t = line["timing"]
+    w = sorted(t["windows_ms_per_step"])
+    assert len(w) >= 5 and abs(w[len(w) // 2] - line["ms_per_step"]) < 1e-3 and (w[-1] - w[0]) / w[0] < 0.05
+    h = line["hires"]
+    assert "2048x1024" in h["metric"] and h["value"] > 0 and abs(h["value"] - 1e3 / h["ms_per_step"]) / h["value"] < 1e-3
+    assert h["parity"]["fp32_ok"] is True and h["parity"]["fp32_max_rel"] <= 1e-3 and h["cpu_baseline"]["value"] > 0
+    assert 0 < h["roofline"]["frac"] < 1 and h["roofline"]["frame_in_graph"]["frac"] <= h["roofline"]["frac"]
+    x = line["x3"]
+    assert x["ok_1e-3"] is True and x["max_rel"] <= 1e-3 and x["value"] > line["fp32"]["value"] * 1.5      # the point of the mode
+    assert x["x3_flop_share"] > 0.7
+    p = line["train"]["parity"]
+    assert p["fp32_ok"] is True and p["fp32"]["max_forward_frame0"] <= 1e-3 and p["fp32"]["max_loss"] <= 1e-3
+    assert set(p["fp32"]["grads"]) == {"G", "D", "DT"} and all(g["finite"] for g in p["fp32"]["grads"].values())
+    assert p["fp32"]["max_grad_norm"] <= p["tolerance_fp32"]["grad_norm"] and p["bf16"]["max_grad_l2"] < 0.5
+    assert line["train"]["flownet2"]["pairs_per_s"] > 0

@@ -219,7 +219,10 @@ static inline int launch_head_typed(const ConvKArgs& k, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv7x7_head_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if ((k.cin_stride * (int)sizeof(T)) % 128 != 0) {                 // whole half chunks only: 64-byte patch rows
+    // V2V_HEAD_HC=1: 64-byte patch rows for every channel stride (a 128-byte chunk = two half chunks: twice the patch loads and
+    // barriers, half the LDS -> four workgroups per CU instead of two); default: only where the stride requires it
+    static const int force_hc = [] { const char* e = getenv("V2V_HEAD_HC"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (force_hc || (k.cin_stride * (int)sizeof(T)) % 128 != 0) {     // whole half chunks only: 64-byte patch rows
         constexpr int GPH = ((PR + 15) / 16 + 3) / 4;
         const size_t ldsh = (size_t)GPH * 4 * 1024;                   // 36 KiB
         if (k.cout <= 16)
