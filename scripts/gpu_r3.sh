@@ -185,3 +185,8 @@ import sys, json; j = json.loads(sys.stdin.read()); print('V2V_HEAD_HC=$hc: 512x
   done | tee -a gpurun_out/${TAG}_head_hc_ab.txt
   lap headab
 fi
+if has smoke; then
+  timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"
+  tail -1 gpurun_out/${TAG}_smoke.log
+  lap smoke
+fi
