@@ -190,3 +190,14 @@ if has smoke; then
   tail -1 gpurun_out/${TAG}_smoke.log
   lap smoke
 fi
+if has configs; then     # the other BASELINE configurations on one GPU: configs[2] geometry (1024x512 train, 2 scales, num_D=3) and configs[3] (edge2face 512x512)
+  cp profiles/tune_cache.json /tmp/tune_cfg.json
+  V2V_TUNE_CACHE=/tmp/tune_cfg.json timeout 900 python bench.py --mode train --width 1024 --height 512 --scales 2 --num-D 3 --frames-per-gpu 1 --steps 6 --warmup 2 > gpurun_out/${TAG}_train_1024_s2.json 2> gpurun_out/${TAG}_train_1024_s2.err; echo "train 1024 rc=$?"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_train_1024_s2.json')); print('train 1024x512 S=2 num_D=3:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', j['roofline']['frac']); p = j['parity']; print('parity fp32_ok', p.get('fp32_ok'), p['fp32']['max_forward'], p['fp32']['max_loss'], p['fp32']['max_grad_norm'], 'oracle', p['oracle_seconds'], 's')"
+  lap train1024
+  V2V_TUNE_CACHE=/tmp/tune_cfg.json timeout 600 python bench.py --dataset edge2face --width 512 --height 512 --cpu-frames 1 > gpurun_out/${TAG}_bench_edge2face.json 2> gpurun_out/${TAG}_bench_edge2face.err; echo "edge2face rc=$?"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_bench_edge2face.json')); print('edge2face 512x512:', j['value'], 'frames/s', j['ms_per_step'], 'ms', j['roofline']['kernel'][:60], j['roofline']['frac']); print('parity fp32', j['parity']['fp32_max_rel'], 'bf16', j['parity']['bf16_max_rel'], 'fp32 line', j['fp32'])"
+  lap edge2face
+fi
