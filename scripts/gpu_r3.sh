@@ -201,3 +201,7 @@ import json; j = json.load(open('gpurun_out/${TAG}_train_1024_s2.json')); print(
 import json; j = json.load(open('gpurun_out/${TAG}_bench_edge2face.json')); print('edge2face 512x512:', j['value'], 'frames/s', j['ms_per_step'], 'ms', j['roofline']['kernel'][:60], j['roofline']['frac']); print('parity fp32', j['parity']['fp32_max_rel'], 'bf16', j['parity']['bf16_max_rel'], 'fp32 line', j['fp32'])"
   lap edge2face
 fi
+if has c8; then
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "conv7x7" 2>&1 | grep -E "passed|failed|^E  |FAILED" | cut -c1-300 | tail -12
+  lap c8test
+fi

@@ -1062,3 +1062,50 @@ def test_encode_labels_pooled_equals_pooling_the_encoding(size, u8, prec):
     enc = O.encode_input(lab.float().view(1, T, 1, H, W), inst.float().view(1, T, 1, H, W), nc).reshape(1, -1, H, W)
     ref = F.avg_pool2d(enc, 3, 2, 1, count_include_pad=False)
     assert_close(eng.unpack(p2).cpu(), ref, 1e-6 if prec == "fp32" else 4e-3, "pooled encoding vs torch")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(6, 32, 19, 45), (6, 128, 16, 70), (3, 64, 9, 33), (6, 16, 40, 64), (2, 100, 8, 32)])
+def test_conv7x7_c8_kernel(case, prec):
+    """Tile 61 (conv7x7_c8_kernel: pixels of exactly 16 bytes, four taps per 16 x 16 x 32 MFMA step -- the 6-channel previous-frame
+    stems): raw fp32 NHWC + per-tile statistics and planar fp32 + activation, against torch and the implicit-GEMM kernel; ragged
+    tiles, 1 / 2 / 4 / 8 output-channel tiles, reflection and zero padding.  Not eligible (more than 16 bytes per pixel): refused."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W = case
+    if prec == "fp32" and cin > 4:
+        eng = _engine(prec)
+        conv = nn.Conv2d(cin, cout, 7).to(DEV)
+        eng.tile_override[(cin, cout, 7, 1, 0)] = 61
+        with pytest.raises(RuntimeError):
+            eng.conv(eng.pack(torch.randn(1, cin, H, W).to(DEV)), conv, L.PAD_REFLECT, 3, L.OUT_RAW_F32_NHWC, want_stats=True)
+        return
+    torch.manual_seed(cin * 7 + cout)
+    eng = _engine(prec)
+    conv = nn.Conv2d(cin, cout, 7, padding=0)
+    x = torch.randn(2, cin, H, W)
+    xr, wr = _round(x, prec), _round(conv.weight.detach(), prec)
+    ref = F.conv2d(F.pad(xr, (3,) * 4, mode="reflect"), wr, conv.bias.detach())
+    ref0 = torch.tanh(F.conv2d(xr, wr, conv.bias.detach(), padding=3)) * 2.0
+    conv = conv.to(DEV)
+    xa = eng.pack(x.to(DEV))
+    assert xa.Cs * (2 if prec == "bf16" else 4) == 16
+    res = {}
+    for tile in (61, 3):
+        eng.tile_override[(cin, cout, 7, 1, 0)] = tile
+        raw, rows, (N, OH, OW) = eng.conv(xa, conv, L.PAD_REFLECT, 3, L.OUT_RAW_F32_NHWC, want_stats=True)
+        assert eng.conv_log[-1]["tile"] == tile
+        cs = (cout + 3) // 4 * 4
+        got = raw[:N * OH * OW * cs].view(N, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2).clone()
+        assert_close(got.cpu(), ref, 1e-4, "raw tile %d" % tile)
+        st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+        assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "sum tile %d" % tile)
+        assert_close(st[:, 1], ref.pow(2).sum((0, 2, 3)), 1e-3, "sum^2 tile %d" % tile)
+        res[tile] = got
+        o, _, _ = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_F32_NCHW, L.ACT_TANH, 0.0, 2.0) if False else (None, None, None)
+    assert_close(res[61].cpu(), res[3].cpu(), 1e-4, "c8 kernel vs implicit GEMM")
+    conv0 = nn.Conv2d(cin, cout, 7, padding=3).to(DEV)
+    conv0.load_state_dict(conv.state_dict())
+    eng.tile_override[(cin, cout, 7, 1, 0)] = 61
+    o, _, _ = eng.conv(xa, conv0, L.PAD_ZERO, None, L.OUT_F32_NCHW, L.ACT_TANH, 0.0, 2.0)
+    assert eng.conv_log[-1]["tile"] == 61
+    assert_close(o.cpu(), ref0, 1e-4 if prec == "fp32" else 3e-3, "planar + tanh, zero padding")

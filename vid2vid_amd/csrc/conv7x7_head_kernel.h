@@ -41,6 +41,72 @@ template <> struct Mma16<float> {
     }
 };
 
+// Shared tail of the 7x7 kernels of this file: planar fp32 (+ activation, per-channel for merged heads) or raw fp32 NHWC + per-tile
+// statistics.  Accumulator layout of the 16-wide MFMA: acc[g][n][r] = pixel (g >> 1 -> tile row 2 wid + that, (g & 1) * 16 + kg * 4 + r)
+// x output channel n * 16 + lp.
+template <typename T, int NT>
+__device__ __forceinline__ void head_epilogue(const ConvKArgs& p, f32x4 (&acc)[4][NT], char* smem, const int tid, const int wid, const int lp,
+                                              const int kg, const int mt, const int n_img, const int oh0, const int ow0) {
+    const int H = p.H, W = p.W;
+    const bool raw_mode = p.out_mode == V2V_OUT_RAW_F32_NHWC;
+    const long long hw = (long long)H * W;
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        s1[n] = 0.f; s2[n] = 0.f;
+        const int co = n * 16 + lp;
+        const bool cvalid = co < p.cout;
+        const float bv = (p.bias && cvalid) ? p.bias[co] : 0.f;
+        // two heads merged into one launch (model_final_flow + model_final_w): the second head's channels have their own epilogue
+        const bool second = p.act_split > 0 && co >= p.act_split;
+        const int act = second ? p.act_b : p.act;
+        const float act_param = second ? p.act_param_b : p.act_param, out_scale = second ? p.out_scale_b : p.out_scale;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int oh = oh0 + 2 * wid + (g >> 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ow = ow0 + (g & 1) * 16 + kg * 4 + r;
+                if (cvalid && oh < H && ow < W && !(p.ablate & 4)) {
+                    float v = acc[g][n][r] + bv;
+                    if (raw_mode) {
+                        s1[n] += v;
+                        s2[n] += v * v;
+                        reinterpret_cast<float*>(p.out)[(((long long)n_img * H + oh) * W + ow) * p.cout_stride + co] = v;
+                    } else {
+                        v = apply_act(v, act, act_param) * out_scale;
+                        reinterpret_cast<float*>(p.out)[((long long)n_img * p.cout + co) * hw + (long long)oh * W + ow] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats != nullptr) {
+        // lanes lp, lp+16, lp+32, lp+48 hold the same channel: fold the 4 k-groups, then the 4 waves through LDS
+        __syncthreads();                                              // the patch is dead: LDS becomes scratch
+        float* red = reinterpret_cast<float*>(smem);                  // [4 waves][16*NT][2]
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float a1 = s1[n], a2 = s2[n];
+            a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+            if (kg == 0) {
+                red[(wid * 16 * NT + n * 16 + lp) * 2 + 0] = a1;
+                red[(wid * 16 * NT + n * 16 + lp) * 2 + 1] = a2;
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * NT && tid < p.cout) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a1 += red[(w * 16 * NT + tid) * 2 + 0]; a2 += red[(w * 16 * NT + tid) * 2 + 1]; }
+            float* dst = p.stats + ((long long)mt * p.cout + tid) * 2;
+            dst[0] = a1;
+            dst[1] = a2;
+        }
+    }
+}
+
 // HC = 1 (round 3): 64-byte patch rows -- channel strides that are whole HALF chunks (the 32- and 16-channel towers of the 1024x512 and
 // 2048x1024 scales, which used to be widened to 64 channels in front of their heads: twice / four times the patch bytes, LDS reads and
 // MFMAs for zeros).  One 16 x 16 x 32 MFMA step per tap, 16 patch rows per 1-KiB LDS-DMA piece, 36 KiB of LDS (four workgroups per CU).
@@ -146,67 +212,111 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
         }
     }
 
-    // ---------------- epilogue: planar fp32 (+ activation) or raw fp32 NHWC + per-tile statistics ----------------
-    const bool raw_mode = p.out_mode == V2V_OUT_RAW_F32_NHWC;
-    const long long hw = (long long)H * W;
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        s1[n] = 0.f; s2[n] = 0.f;
-        const int co = n * 16 + lp;
-        const bool cvalid = co < p.cout;
-        const float bv = (p.bias && cvalid) ? p.bias[co] : 0.f;
-        // two heads merged into one launch (model_final_flow + model_final_w): the second head's channels have their own epilogue
-        const bool second = p.act_split > 0 && co >= p.act_split;
-        const int act = second ? p.act_b : p.act;
-        const float act_param = second ? p.act_param_b : p.act_param, out_scale = second ? p.out_scale_b : p.out_scale;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int oh = oh0 + 2 * wid + (g >> 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ow = ow0 + (g & 1) * 16 + kg * 4 + r;
-                if (cvalid && oh < H && ow < W && !(p.ablate & 4)) {
-                    float v = acc[g][n][r] + bv;
-                    if (raw_mode) {
-                        s1[n] += v;
-                        s2[n] += v * v;
-                        reinterpret_cast<float*>(p.out)[(((long long)n_img * H + oh) * W + ow) * p.cout_stride + co] = v;
-                    } else {
-                        v = apply_act(v, act, act_param) * out_scale;
-                        reinterpret_cast<float*>(p.out)[((long long)n_img * p.cout + co) * hw + (long long)oh * W + ow] = v;
-                    }
-                }
-            }
-        }
-    }
-    if (p.stats != nullptr) {
-        // lanes lp, lp+16, lp+32, lp+48 hold the same channel: fold the 4 k-groups, then the 4 waves through LDS
-        __syncthreads();                                              // the patch is dead: LDS becomes scratch
-        float* red = reinterpret_cast<float*>(smem);                  // [4 waves][16*NT][2]
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            float a1 = s1[n], a2 = s2[n];
-            a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
-            a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
-            if (kg == 0) {
-                red[(wid * 16 * NT + n * 16 + lp) * 2 + 0] = a1;
-                red[(wid * 16 * NT + n * 16 + lp) * 2 + 1] = a2;
-            }
-        }
-        __syncthreads();
-        if (tid < 16 * NT && tid < p.cout) {
-            float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { a1 += red[(w * 16 * NT + tid) * 2 + 0]; a2 += red[(w * 16 * NT + tid) * 2 + 1]; }
-            float* dst = p.stats + ((long long)mt * p.cout + tid) * 2;
-            dst[0] = a1;
-            dst[1] = a2;
-        }
-    }
+    head_epilogue<T, NT>(p, acc, smem, tid, wid, lp, kg, mt, n_img, oh0, ow0);
 }
 
 #undef V2V_HEAD_SWZ
+
+// ---- 7x7 stems over 16-byte pixels (tile id 61; round 3) ----
+// The previous-frame stems (Conv2d(6, ngf_s, 7) behind ReflectionPad2d(3): models/networks.py:134-135,262) read 6 channels = ONE
+// 16-byte vector per pixel (bf16, stride 8).  As an implicit GEMM over 128-byte K chunks every tap fetches a chunk that is 7/8
+// padding: 446 us for 6 -> 32 at 2048x1024 against 47 us of HBM time for its 33 MB in / 268 MB out (profiles/r03_c4_per_layer_
+// roofline_hires.txt).  Here K = tap * 8 + c is walked in steps of FOUR TAPS: one 16 x 16 x 32 MFMA step takes, per lane, the
+// 16 bytes of pixel (p + tap offset) from a 8.5-KB LDS halo patch (A) and the 16 bytes W[cout][tap][8] from the tap-major packed
+// weights (B; 13 steps cover the 49 taps, the padding taps hit zero weights).  The pixel tile, the wave / accumulator layout and
+// the epilogue (raw fp32 NHWC + per-tile statistics, or planar fp32 + activation) are those of conv7x7_head_kernel.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv7x7_c8_kernel(const ConvKArgs p, const T* __restrict__ w_ro) {
+    constexpr int VEC = ElemTraits<T>::VEC;                           // 8 bf16 / 4 fp32 = the whole channel stride
+    constexpr int TH = 8, TW = 32, HALO = 3, KS = 7;
+    constexpr int PW = TW + 2 * HALO, PR = (TH + 2 * HALO) * PW;     // 38 x 14 = 532 patch pixels, 16 bytes each
+    constexpr int NW = 4, NG = (PR + 63) / 64, GP = (NG + NW - 1) / NW;  // 9 LDS-DMA pieces of 64 pixels, 3 per wave
+    constexpr int STEPS = (KS * KS + 3) / 4;                          // 13 steps of 4 taps
+    typedef typename Mma16<T>::Frag Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x;
+    const int tpi = p.tiles_h * p.tiles_w;
+    const int n_img = mt / tpi;
+    const int trem = mt - n_img * tpi;
+    const int th = trem / p.tiles_w;
+    const int oh0 = th * TH, ow0 = (trem - th * p.tiles_w) * TW;
+    const int H = p.H, W = p.W;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+
+    // the patch: lane l of piece g brings pixel q = 64 g + l
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+        const int g = k * NW + wid;
+        if (g < NG) {
+            const int q = g * 64 + lane;
+            const int pr = q / PW, pc = q - pr * PW;
+            int ih = oh0 + pr - HALO, iw = ow0 + pc - HALO;
+            int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+            int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+            ih = reflect ? rh : ih;
+            iw = reflect ? rw : iw;
+            const bool ok = q < PR && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            const char* src = ok ? p.in + ((long long)(n_img * H + ih) * W + iw) * 16 : p.zero_page;
+            glds16(src, smem + g * 1024);
+        }
+    }
+    const int lp = lane & 15, kg = lane >> 4;
+    // lane's tap of step s: t = 4 s + kg (taps >= 49 read a valid patch pixel against zero weights)
+    int qg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qg[g] = (2 * wid + (g >> 1)) * PW + (g & 1) * 16 + lp;
+    const T* const wlane = w_ro + p.woff[0] + (long long)lp * p.wrow[0] + kg * VEC;
+    const long long wnt = 16ll * p.wrow[0];
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { acc[g][n][0] = 0.f; acc[g][n][1] = 0.f; acc[g][n][2] = 0.f; acc[g][n][3] = 0.f; }
+    Frag bf[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const Frag*>(wlane + n * wnt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        Frag nb[NT];
+        if (s + 1 < STEPS) {                                          // next step's weight fragments under this step's MFMAs
+#pragma unroll
+            for (int n = 0; n < NT; ++n) nb[n] = *reinterpret_cast<const Frag*>(wlane + n * wnt + (s + 1) * 4 * VEC);
+        }
+        int t = 4 * s + kg;
+        t = t < KS * KS ? t : KS * KS - 1;
+        const int toff = (t / KS) * PW + (t % KS);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const Frag a = *reinterpret_cast<const Frag*>(smem + (qg[g] + toff) * 16);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) Mma16<T>::run(a, bf[n], acc[g][n]);
+        }
+        if (s + 1 < STEPS) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = nb[n];
+        }
+    }
+    head_epilogue<T, NT>(p, acc, smem, tid, wid, lp, kg, mt, n_img, oh0, ow0);
+}
+
+template <typename T>
+static inline int launch_c8_typed(const ConvKArgs& k, hipStream_t s) {
+    constexpr int PR = (8 + 6) * (32 + 6);
+    const size_t lds = (size_t)((PR + 63) / 64) * 1024;               // 9 KiB (the statistics scratch of the epilogue needs 4 x 16 NT x 8 B <= 4 KiB)
+    const dim3 g((unsigned)k.m_tiles), b(256);
+    const T* w = reinterpret_cast<const T*>(k.w);
+    if (k.cout <= 16)      hipLaunchKernelGGL((conv7x7_c8_kernel<T, 1>), g, b, lds, s, k, w);
+    else if (k.cout <= 32) hipLaunchKernelGGL((conv7x7_c8_kernel<T, 2>), g, b, lds, s, k, w);
+    else if (k.cout <= 64) hipLaunchKernelGGL((conv7x7_c8_kernel<T, 4>), g, b, lds, s, k, w);
+    else                   hipLaunchKernelGGL((conv7x7_c8_kernel<T, 8>), g, b, lds, s, k, w);
+    return check_launch();
+}
 
 template <typename T>
 static inline int launch_head_typed(const ConvKArgs& k, hipStream_t s) {

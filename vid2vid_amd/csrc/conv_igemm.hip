@@ -351,6 +351,8 @@ int launch_pp3_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp3_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s);
 int launch_head_f32(const ConvKArgs& k, hipStream_t s);
+int launch_c8_bf16(const ConvKArgs& k, hipStream_t s);
+int launch_c8_f32(const ConvKArgs& k, hipStream_t s);
 
 static int choose_cfg(long long Mc, int cout, int ncls) {
     if (cout <= 32) return 4;
@@ -372,6 +374,7 @@ struct ConvOp : Op {
     int launch(hipStream_t s) override {
         if (cfg >= 80) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, groups, s) : launch_pp3_f32(cfg, k, groups, s);
         if (cfg >= 70) return dtype == V2V_BF16 ? launch_pp2_bf16(cfg, k, groups, s) : launch_pp2_f32(cfg, k, groups, s);
+        if (cfg == 61) return dtype == V2V_BF16 ? launch_c8_bf16(k, s) : launch_c8_f32(k, s);
         if (cfg == 60) return dtype == V2V_BF16 ? launch_head_bf16(k, s) : launch_head_f32(k, s);
         if (cfg >= 50) return dtype == V2V_BF16 ? launch_pp_bf16(cfg, k, s) : launch_pp_f32(cfg, k, s);
         if (cfg >= 32) return dtype == V2V_BF16 ? launch_patch_bf16(cfg, k, s) : launch_patch_f32(cfg, k, s);
@@ -489,7 +492,22 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     op->dtype = d->dtype;
     op->cfg = d->tile ? d->tile : choose_cfg(Mc, d->cout, g.ncls);
     int tile_bm, tile_bn;
-    if (op->cfg == 60) {
+    if (op->cfg == 61) {
+        // conv7x7_c8_kernel: 7x7 / stride 1 / pad 3 Conv2d over pixels of exactly 16 bytes (8 bf16 / 4 fp32 channels), <= 128 output channels
+        if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->cout > 128 ||
+            d->cin_stride * (d->dtype == V2V_BF16 ? 2 : 4) != 16 || d->w_korder != 0 || d->splitk > 1 || d->fin_counter || d->act_split != 0 ||
+            !(d->out_mode == V2V_OUT_F32_NCHW || d->out_mode == V2V_OUT_RAW_F32_NHWC) ||
+            (d->stats && d->out_mode != V2V_OUT_RAW_F32_NHWC) ||
+            (long long)d->N * d->H * d->W * 16 >= (1ll << 32)) {
+            set_error("conv: tile config 61 (7x7 over 16-byte pixels) needs a 7x7/s1/p3 Conv2d, a channel stride of 16 bytes, cout <= 128, planar fp32 "
+                      "or raw NHWC output without in-kernel norm finalize"); return V2V_EINVAL;
+        }
+        k.tiles_h = (int)ceil_div(d->OH, 8);
+        k.tiles_w = (int)ceil_div(d->OW, 32);
+        k.m_tiles = d->N * k.tiles_h * k.tiles_w;
+        k.n_tiles = 1;
+        tile_bm = 256; tile_bn = 4;
+    } else if (op->cfg == 60) {
         // conv7x7_head_kernel: 7x7 / stride 1 / pad 3 Conv2d with <= 16 output channels written planar fp32
         if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->cout > 32 ||
             d->cin_stride % (bke_of(d->dtype) / 2) != 0 || d->w_korder != 0 || d->splitk > 1 || d->fin_counter ||

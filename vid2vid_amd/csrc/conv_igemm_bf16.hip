@@ -11,4 +11,5 @@ int launch_pp_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_p
 int launch_pp2_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s) { return launch_pp2_typed<bf16_t>(cfg, k, groups, s); }
 int launch_pp3_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s) { return launch_pp3_typed<bf16_t>(cfg, k, groups, s); }
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s) { return launch_head_typed<bf16_t>(k, s); }
+int launch_c8_bf16(const ConvKArgs& k, hipStream_t s) { return launch_c8_typed<bf16_t>(k, s); }
 }

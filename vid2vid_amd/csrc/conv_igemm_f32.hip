@@ -10,4 +10,5 @@ int launch_pp_f32(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_pp
 int launch_pp2_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s) { return launch_pp2_typed<float>(cfg, k, groups, s); }
 int launch_pp3_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s) { return launch_pp3_typed<float>(cfg, k, groups, s); }
 int launch_head_f32(const ConvKArgs& k, hipStream_t s) { return launch_head_typed<float>(k, s); }
+int launch_c8_f32(const ConvKArgs& k, hipStream_t s) { return launch_c8_typed<float>(k, s); }
 }

@@ -1174,6 +1174,10 @@ class Engine:
                 and d.cin_stride % bke_ == 0 and not d.fin_counter
                 and (d.out_mode == L.OUT_F32_NCHW or d.out_mode == L.OUT_RAW_F32_NHWC)):
             cands.append((60, 1, 0))          # conv7x7_head_kernel (LDS patch + 16-wide MFMA)
+        if (not d.transposed and d.KH == 7 and d.KW == 7 and d.stride == 1 and d.pad == 3 and cout <= 128
+                and d.cin_stride * (2 if self.dtype == L.BF16 else 4) == 16 and not d.fin_counter
+                and (d.out_mode == L.OUT_F32_NCHW or d.out_mode == L.OUT_RAW_F32_NHWC)):
+            cands.append((61, 1, 0))          # conv7x7_c8_kernel: 16-byte pixels (the 6-channel previous-frame stems), four taps per MFMA step
         if mod is not None and self.patch_eligible(d):
             ncc = d.cin_stride // (64 if self.dtype == L.BF16 else 32)
             for t, (th, tw, bn) in sorted(PATCH_CFGS.items()):
