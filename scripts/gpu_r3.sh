@@ -205,3 +205,7 @@ if has c8; then
   timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "conv7x7" 2>&1 | grep -E "passed|failed|^E  |FAILED" | cut -c1-300 | tail -12
   lap c8test
 fi
+if has subset; then
+  timeout 600 python -m pytest tests/test_gpu_golden.py -m gpu -q --tb=short -k "three_scales or inference or composite or first_frame or local" 2>&1 | grep -E "passed|failed|^E  |FAILED" | cut -c1-300 | tail -8
+  lap subset
+fi
