@@ -64,7 +64,7 @@ class TinyG(nn.Module):
     def encode_input(self, A, B, inst):
         return A.float(), B.float(), None
 
-    def forward(self, A, B, inst, prev, frame_range=None):
+    def forward(self, A, B, inst, prev, frame_range=None, first_chunk=None):
         real_A, real_B, _ = self.encode_input(A, B, inst)
         pyr = [real_B[:, :TG - 1]] if prev is None else [p for p in prev]
         t0, t1 = (0, self.n_frames_load) if frame_range is None else frame_range

@@ -499,10 +499,12 @@ class Vid2VidModelG(BaseModel):
         real_B = None if real_image is None else real_image.to(dev, torch.float32)
         return real_A, real_B, None
 
-    def forward(self, input_A, input_B, inst_A, fake_B_prev, dummy_bs=0, frame_range=None):
+    def forward(self, input_A, input_B, inst_A, fake_B_prev, dummy_bs=0, frame_range=None, first_chunk=None):
         """n_frames_load frames with autograd (reference :114-137).  Returns the reference's 7-tuple.
         frame_range=(t0, t1) (roles.py, a generator rank of a sequence group): only frames t0..t1-1 of the chunk, `fake_B_prev`
-        being the tG-1 frames just before t0; fake_B / fake_B_raw / flow / weight then hold t1-t0 frames."""
+        being the tG-1 frames just before t0; fake_B / fake_B_raw / flow / weight then hold t1-t0 frames.  first_chunk: whether the
+        chunk opens a sequence (`--no_first_img` makes ALL its frames raw-only, reference :160); a generator rank behind the first
+        one receives its previous frames and cannot tell from `fake_B_prev is None`."""
         tG = self.opt.n_frames_G
         if dummy_bs:
             input_A, input_B, inst_A, fake_B_prev = [None if t is None else t[dummy_bs:] for t in
@@ -514,6 +516,8 @@ class Vid2VidModelG(BaseModel):
         if is_first_frame:
             with torch.no_grad():
                 fake_B_prev = self._first_frames_train(real_A_all, real_B_all)
+        if first_chunk is not None:
+            is_first_frame = bool(first_chunk)
         fake_B, fake_B_raw, flow, weight = self.generate_frame_train(real_A_all, list(fake_B_prev), is_first_frame, frame_range)
         fake_B_prev = [B[:, -tG + 1:].detach() for B in fake_B]
         fake_B = [B[:, tG - 1:] for B in fake_B]

@@ -223,7 +223,7 @@ class RoleModelG(nn.Module):
                 prev = [_recv(s, L.g_ranks[g - 1], dev) for s in pyr_shapes]
             else:
                 prev = fake_B_prev_last
-            outs = m(input_A, input_B, inst_A, prev, frame_range=(g * k, (g + 1) * k))
+            outs = m(input_A, input_B, inst_A, prev, frame_range=(g * k, (g + 1) * k), first_chunk=fake_B_prev_last is None)
             fake_B, fake_B_raw, flow, weight, real_A, real_Bp, tail = outs
             sends = _Sends()
             if L.n_gen > 1:
