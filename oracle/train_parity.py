@@ -48,8 +48,8 @@ def oracle_chunk(sds_G, sd_D, sd_DT, lab, inst, B, flow_ref, conf_ref, *, label_
     sd_D = _trainable(sd_D)
     sd_DT = None if sd_DT is None else _trainable(sd_DT)
     real_A = O.encode_input(lab, inst, label_nc)
-    fake_B, fake_B_raw, flow, weight = O.generate_frames_train(sds_G, real_A, B, fg, list(fg_labels), n_down, n_blocks,
-                                                               n_blocks_local, n_frames_load, tG)
+    fake_B, fake_B_raw, flow, weight, fake_pyr = O.generate_frames_train(sds_G, real_A, B, fg, list(fg_labels), n_down, n_blocks,
+                                                                         n_blocks_local, n_frames_load, tG, return_pyramid=True)
     real_Bp = B[:, tG - 2:]
     real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
     fake_B_prev = torch.cat([real_B_prev[:, 0:1], fake_B[:, :-1].detach()], 1)          # compute_fake_B_prev (:332-336)
@@ -93,20 +93,42 @@ def oracle_chunk(sds_G, sd_D, sd_DT, lab, inst, B, flow_ref, conf_ref, *, label_
         losses={k: float(v.detach()) for k, v in list(losses.items()) + list(lt.items())},
         totals=dict(G=float(loss_G.detach()), D=float(loss_D.detach()), DT=None if loss_DT is None else float(loss_DT.detach())),
         grads=dict(G=_flat(gG), D=_flat(gD), DT=_flat(gDT)),
+        # fake_B_pyr of the chunk (finest scale first; the tG-1 given frames, then the generated ones): what a teacher-forced
+        # product run starts every frame t > 0 from (hip_chunk(teacher=...))
+        fake_pyr=fake_pyr,
         seconds=time.perf_counter() - t0)
     return out
 
 
-def hip_chunk(G, D, lab, inst, B, flow_ref, conf_ref):
+def hip_chunk(G, D, lab, inst, B, flow_ref, conf_ref, teacher=None):
     """The product side: the same chunk through Vid2VidModelG.forward / Vid2VidModelD.forward (train.py:50-82) and the three
-    backward passes (train.py:86-93).  G, D: initialised Vid2VidModelG / Vid2VidModelD on the GPU; tensors on the GPU."""
+    backward passes (train.py:86-93).  G, D: initialised Vid2VidModelG / Vid2VidModelD on the GPU; tensors on the GPU.
+
+    teacher = the oracle's `fake_pyr`: TEACHER-FORCED run.  north_star's bar is "the same inputs" on both sides; in a
+    chunk of several frames the inputs of frame t > 0 include the previous fake frames, so every frame t > 0 starts from the
+    REFERENCE's previous frames at every scale instead of the product's own (which differ by ~1e-4 and would propagate).
+    With n_frames_bp = 1 those frames are detached on both sides (models/vid2vid_model_G.py:167-168), so the autograd graph
+    is the chunk's own: the frames are generated by one Vid2VidModelG.forward call each (`frame_range`, the entry point the
+    generator ranks of roles.py use), concatenated, and everything behind G -- the discriminators' batch over all frames,
+    the losses, the three backward passes -- is the single chunk of train.py.  teacher=None: free-running chunk."""
     opt = G.opt
     tD = opt.n_frames_D
+    tG = opt.n_frames_G
 
     def reshape(ts):
         return [None if t is None else t.contiguous().view(-1, t.size(2), t.size(3), t.size(4)) for t in ts]
 
-    fake_B, fake_B_raw, flow, weight, real_A, real_Bp, _ = G(lab, B, inst, None)
+    if teacher is None or G.n_frames_load == 1:
+        fake_B, fake_B_raw, flow, weight, real_A, real_Bp, _ = G(lab, B, inst, None)
+    else:
+        dev = B.device
+        parts = []
+        for t in range(G.n_frames_load):
+            prev = None if t == 0 else [p[:, t:t + tG - 1].to(dev, torch.float32).contiguous() for p in teacher]
+            o = G(lab, B, inst, prev, frame_range=(t, t + 1), first_chunk=True)
+            parts.append(o[:4])
+            real_A, real_Bp = o[4], o[5]
+        fake_B, fake_B_raw, flow, weight = [torch.cat([p[i] for p in parts], 1) for i in range(4)]
     real_B_prev, real_B = real_Bp[:, :-1], real_Bp[:, 1:]
     fake_B_prev = G.compute_fake_B_prev(real_B_prev, None, fake_B)
     losses = D(0, reshape([real_B, fake_B, fake_B_raw, real_A, real_B_prev, fake_B_prev, flow, weight, flow_ref, conf_ref]))

@@ -755,10 +755,12 @@ def model_D_temporal_losses(sdDT, real_B, fake_B, flow_ref, tD=3, n_layers_D=3, 
     return {"G_T_GAN": l_gan, "G_T_GAN_Feat": l_fm, "D_T_real": l_real, "D_T_fake": l_fake, "G_T_Warp": torch.zeros(())}
 
 
-def generate_frames_train(sds, real_A_all, real_B_all, fg, fg_labels, n_down, n_blocks, n_blocks_local, n_frames_load, tG=3):
+def generate_frames_train(sds, real_A_all, real_B_all, fg, fg_labels, n_down, n_blocks, n_blocks_local, n_frames_load, tG=3,
+                          return_pyramid=False):
     """Vid2VidModelG.forward / generate_frame_train (models/vid2vid_model_G.py:114-196) for batch 1, first chunk
     (real first frames), n_frames_bp = 1, finetune_all.  real_A_all (1,T,C,H,W) encoded labels, real_B_all (1,T,3,H,W).
-    Returns fake_B, fake_B_raw, flow, weight: (1, n_frames_load, ., H, W)."""
+    Returns fake_B, fake_B_raw, flow, weight: (1, n_frames_load, ., H, W); with return_pyramid additionally the
+    fake_B_pyr of :139-196 -- per scale (finest first) the tG-1 given frames followed by the generated ones, detached."""
     S = len(sds)
     A_pyr = build_pyr(real_A_all, S)
     B_pyr = build_pyr(real_B_all[:, :tG - 1], S)
@@ -781,7 +783,10 @@ def generate_frames_train(sds, real_A_all, real_B_all, fg, fg_labels, n_down, n_
             fakes[si] = torch.cat([fakes[si], fake_B.unsqueeze(1)], 1)
             if s == S - 1:
                 raws.append(raw.unsqueeze(1)); flows.append(flow.unsqueeze(1)); weights.append(weight.unsqueeze(1))
-    return fakes[0][:, tG - 1:], torch.cat(raws, 1), torch.cat(flows, 1), torch.cat(weights, 1)
+    res = fakes[0][:, tG - 1:], torch.cat(raws, 1), torch.cat(flows, 1), torch.cat(weights, 1)
+    if return_pyramid:
+        return res + ([f.detach() for f in fakes],)
+    return res
 
 
 # --------------------------------------------------------------------------------------

@@ -146,8 +146,47 @@ def test_shared_tuning_cache_world2(tmp_path):
     assert res == [(0, "ok"), (1, "ok")]
 
 
+def test_update_fixed_params_default_is_the_reference_behaviour():
+    """the reference's update_fixed_params stores a NEW Adam in self.optimizer_G (base_model.py:161-168)
+    while train.py keeps stepping the one it captured (train.py:29) -- the finest scale trains on with its old moments, the
+    coarse scales never move, update_learning_rate decays only the new object.  That is the default here."""
+    import torch
+    from vid2vid_amd import networks as N
+    from vid2vid_amd.options import make_opt
+    from vid2vid_amd.models.vid2vid_model_G import Vid2VidModelG
+    from vid2vid_amd.models.base_model import _UnsteppedAdam
+    if torch.cuda.is_available():
+        pytest.skip("record-only construction is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        opt = make_opt(isTrain=True, label_nc=35, use_instance=True, fg=True, ngf=8, n_blocks=2, n_blocks_local=1,
+                       n_scales_spatial=2, n_downsample_G=2, loadSize=64, niter_fix_global=3, no_vgg=True, random_init_ok=True,
+                       precision="fp32", gpu_ids=[], n_gpus_gen=1, niter=10, niter_decay=10)
+        G = Vid2VidModelG(); G.initialize(opt)
+        captured = G.optimizer_G
+        flat_ptr, n_fine = captured.flat.flat_param.data_ptr(), sum(p.numel() for p in G.netG1.parameters())
+        captured.exp_avg.fill_(1.0); captured.step_count = 7
+        lr0 = captured.param_groups[0]["lr"]
+        G.update_fixed_params()
+        # the captured optimizer is untouched: same flat buffer over the finest scale only, moments and step count kept
+        assert G._optimizer_G_live is captured and captured.flat.flat_param.data_ptr() == flat_ptr
+        assert sum(p.numel() for p in captured.flat.params) == n_fine and captured.step_count == 7 and float(captured.exp_avg.min()) == 1.0
+        # self.optimizer_G is a fresh, never-stepped stand-in; finetune_all is set as in the reference
+        assert isinstance(G.optimizer_G, _UnsteppedAdam) and G.optimizer_G is not captured and G.finetune_all
+        assert not G._train_coarse                       # the unobservable coarse-scale gradients are not computed
+        # update_learning_rate reaches the stand-in only (base_model.py:154-159 looks the attribute up again)
+        G.update_learning_rate(15, "G")
+        assert G.optimizer_G.param_groups[0]["lr"] == pytest.approx(opt.lr * 0.5) and captured.param_groups[0]["lr"] == lr0
+        G.update_fixed_params()                          # idempotent (init_params and update_models may both call it)
+        assert G._optimizer_G_live is captured
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()
+
+
 def test_update_fixed_params_rebuilds_the_captured_optimizer_in_place():
-    """train.py captures optimizer_G once (train.py:29); update_fixed_params (base_model.py:162-168) must
+    """opt.fix_update_fixed_params: train.py captures optimizer_G once (train.py:29); with the fix selected
+    update_fixed_params (base_model.py:162-168) must
     not leave that object stepping a flat buffer no parameter views.  After the call the SAME optimizer object owns every
     scale: each parameter's storage and gradient live inside its (new) flat buffers, values are preserved, moments are
     fresh, and the gradient synchroniser attached by parallel.sync_optimizers is still attached."""
@@ -161,7 +200,7 @@ def test_update_fixed_params_rebuilds_the_captured_optimizer_in_place():
     try:
         opt = make_opt(isTrain=True, label_nc=35, use_instance=True, fg=True, ngf=8, n_blocks=2, n_blocks_local=1,
                        n_scales_spatial=2, n_downsample_G=2, loadSize=64, niter_fix_global=3, no_vgg=True, random_init_ok=True,
-                       precision="fp32", gpu_ids=[], n_gpus_gen=1)
+                       precision="fp32", gpu_ids=[], n_gpus_gen=1, fix_update_fixed_params=True)
         G = Vid2VidModelG(); G.initialize(opt)
         captured = G.optimizer_G                         # what create_optimizer() hands to train.py
         marker = object()

@@ -14,6 +14,26 @@ from .. import networks
 from ..networks import get_engine
 
 
+class _UnsteppedAdam:
+    """What `self.optimizer_G` is after the reference's update_fixed_params (base_model.py:165): an Adam over all scales that
+    nobody steps (train.py holds the optimizer it captured before).  Only its learning rate is ever touched again
+    (update_learning_rate); step / zero_grad exist so that code written against the attribute does not break."""
+
+    def __init__(self, lr, betas, n_params=0):
+        self.param_groups = [{"lr": lr, "betas": tuple(betas), "params": []}]
+        self.n_params = n_params
+        self.grad_sync = None
+
+    def zero_grad(self, set_to_none=False): pass
+    def step(self, closure=None): return None
+    def state_dict(self): return {}
+    def load_state_dict(self, state): pass
+
+    def rebuild(self, params, lr=None, betas=None):
+        if lr is not None:
+            self.param_groups[0]["lr"] = lr
+
+
 class BaseModel(torch.nn.Module):
     def name(self):
         return "BaseModel"
@@ -149,15 +169,32 @@ class BaseModel(torch.nn.Module):
         self.old_lr = lr
 
     def update_fixed_params(self):
+        """reference models/base_model.py:161-168, called by update_models / init_params once epoch > niter_fix_global.
+
+        What the reference's call DOES, observably: it builds a NEW torch.optim.Adam over all scales and stores it in
+        `self.optimizer_G` -- but train.py stepped, and keeps stepping, the optimizer object it captured at start-up
+        (train.py:29: create_optimizer runs before init_params).  So after this call (a) the finest scale goes on training with
+        its old moments, (b) the coarse scales receive gradients (`finetune_all` stops the detach of :181-186) that no
+        optimizer ever applies -- their weights never move -- and (c) update_learning_rate (:154-159) from now on decays the
+        learning rate of the new, never-stepped object while the captured one keeps the rate it had.
+
+        Default here = exactly that behaviour, so that a run switched over from the reference produces the reference's
+        parameters: the captured FusedAdam is left alone (`self._optimizer_G_live` keeps a handle for checkpoints / gradient
+        sync), `self.optimizer_G` becomes an unstepped stand-in that takes (c), and the coarse-scale gradients of (b), which
+        nothing can observe, are not computed (`_train_coarse` stays False: the finest scale's gradient is identical with or
+        without the detach).  `opt.fix_update_fixed_params` (or V2V_FIX_UPDATE_FIXED_PARAMS=1) selects what the reference's
+        authors evidently meant instead: the captured optimizer is rebuilt IN PLACE over all scales (fresh moments, lr /
+        betas of the reference's new Adam), so train.py's handle trains every scale.  INTEGRATION.md section A documents both."""
         params = []
         for s in range(self.n_scales):
             params += list(getattr(self, "netG" + str(s)).parameters())
-        # The reference builds a NEW torch.optim.Adam here (base_model.py:162-168) while train.py keeps stepping the
-        # optimizer it captured at start-up (train.py:29), so its coarse scales receive gradients that nobody applies.
-        # Here the captured optimizer object is rebuilt IN PLACE over all scales (fresh moments, same lr / betas as the
-        # reference's new Adam): whoever holds a reference to it -- train.py, parallel.GradSync -- now trains every scale,
-        # and no second flat buffer ever aliases live parameters.
-        self.optimizer_G.rebuild(params, lr=self.old_lr, betas=(self.opt.beta1, 0.999))
+        fix = bool(getattr(self.opt, "fix_update_fixed_params", False)) or os.environ.get("V2V_FIX_UPDATE_FIXED_PARAMS", "0") == "1"
+        if fix:
+            self.optimizer_G.rebuild(params, lr=self.old_lr, betas=(self.opt.beta1, 0.999))
+            self._train_coarse = True
+        elif not isinstance(self.optimizer_G, _UnsteppedAdam):
+            self._optimizer_G_live = self.optimizer_G
+            self.optimizer_G = _UnsteppedAdam(lr=self.old_lr, betas=(self.opt.beta1, 0.999), n_params=sum(p.numel() for p in params))
         self.finetune_all = True
         print("------------ Now finetuning all scales -----------")
 

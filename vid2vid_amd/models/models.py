@@ -43,8 +43,16 @@ def _role_layout(opt):
     layout = roles.layout_from_opt(opt) if opt.isTrain else None
     if layout is not None:
         opt.role_group_size = layout.group_size
+        # one process per GPU: this process's device is the launcher's LOCAL_RANK (what parallel.init_distributed / bench.py
+        # selected with torch.cuda.set_device), NOT an index into --gpu_ids -- two sequence groups on one node (8 processes,
+        # --gpu_ids 0,1,2,3) would otherwise put ranks 4-7 on the GPUs of ranks 0-3
         local = int(os.environ.get("LOCAL_RANK", layout.rank))
-        opt.gpu_ids = [opt.gpu_ids[local % len(opt.gpu_ids)]]
+        if torch.cuda.is_available():
+            ndev = torch.cuda.device_count()
+            if local >= ndev:
+                raise RuntimeError("role split: LOCAL_RANK %d but only %d GPUs are visible (one process per GPU)" % (local, ndev))
+            torch.cuda.set_device(local)
+        opt.gpu_ids = [local]
         print("vid2vid_amd: rank %d = %s-rank %d of sequence group %d (%d generator + %d discriminator ranks per sequence)"
               % (layout.rank, layout.role, layout.g if layout.role == "G" else layout.d, layout.seq, layout.n_gen, layout.n_disc))
     return layout

@@ -318,6 +318,7 @@ class Vid2VidModelG(BaseModel):
             self.n_frames_load = self.n_gpus * self.n_frames_per_gpu
             self.old_lr = opt.lr
             self.finetune_all = opt.niter_fix_global == 0
+            self._train_coarse = self.finetune_all      # whether gradients reach the coarse scales (base_model.update_fixed_params)
             params = list(getattr(self, "netG" + str(self.n_scales - 1)).parameters())
             if self.finetune_all:
                 for s in range(self.n_scales - 1):
@@ -559,7 +560,7 @@ class Vid2VidModelG(BaseModel):
                 netG = getattr(self, "netG" + str(s))
                 fake_B, flow, weight, fake_B_raw, feat, flow_feat, fg_feat = netG.emit(
                     eng, x, eng.pack(prev_nchw), prev_nchw, mask, feat, flow_feat, fg_feat, use_raw_only, tag="G%d" % s)
-                if s != S - 1 and not self.finetune_all:       # train the finest scale only (:181-186)
+                if s != S - 1 and not getattr(self, "_train_coarse", self.finetune_all):       # train the finest scale only (:181-186)
                     fake_B, feat = fake_B.detach(), feat.detach()
                     if flow is not None:
                         flow, flow_feat = flow.detach(), flow_feat.detach()

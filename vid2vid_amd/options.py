@@ -27,6 +27,8 @@ _DEFAULTS = dict(
     precision=None,           # 'fp32' | 'bf16' | None (None: bf16 iff opt.fp16)
     random_init_ok=False,     # allow create_model() without a G0 checkpoint (benchmarks / smoke)
     vgg19_checkpoint="checkpoints/vgg19-dcbb9e9d.pth",   # torchvision's vgg19 state_dict (the reference downloads it)
+    fix_update_fixed_params=False,   # True: update_fixed_params rebuilds the captured optimizer over all scales (the reference's
+                                     # evident intent); False: the reference's observable behaviour (models/base_model.py docstring)
 )
 
 

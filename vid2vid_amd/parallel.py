@@ -39,6 +39,13 @@ def init_distributed(backend=None):
     return rank, world, local_rank
 
 
+def host_staged(t, group=None):
+    """True when a collective / point-to-point transfer of the device tensor `t` must go through host memory: the process
+    group's backend is gloo (CPU transport).  RCCL ("nccl") moves device memory directly over xGMI; gloo with device tensors is
+    the debugging / single-GPU-several-ranks configuration (tests/test_gpu_roles.py), never the production path."""
+    return bool(t.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo")
+
+
 class GradSync:
     """Bucketed in-place all-reduce (sum) of a flat gradient buffer, overlapped with the NEXT backward pass.
 
@@ -84,6 +91,11 @@ class GradSync:
         world = self.world
         if world == 1 and not (self.force_collective and dist.is_initialized()):
             return 1.0 if self.scale is None else self.scale
+        if host_staged(flat, self.group):
+            host = flat.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            flat.copy_(host)
+            return 1.0 / world if self.scale is None else self.scale
         if self.wire_dtype is not None and self.wire_dtype != flat.dtype:
             pairs = [(b, b.to(self.wire_dtype)) for b in self.buckets(flat)]             # bucket by bucket: conversion of k+1 beside the ring of k
             works = [dist.all_reduce(w_, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for _, w_ in pairs]
@@ -143,7 +155,12 @@ class GradSync:
 
     def broadcast(self, flat, src=0):
         if self.world > 1:
-            dist.broadcast(flat, src=src, group=self.group)
+            if host_staged(flat, self.group):
+                host = flat.detach().cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                flat.copy_(host)
+            else:
+                dist.broadcast(flat, src=src, group=self.group)
 
 
 _ACTIVE_SYNCS = []

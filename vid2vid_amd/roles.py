@@ -96,6 +96,12 @@ def layout_from_opt(opt, rank=None, world=None):
     n_gen = opt.n_gpus_gen
     if group_size <= 1 or n_gen < 0 or n_gen >= group_size or opt.batchSize != 1 or not opt.isTrain:
         return None
+    if int(getattr(opt, "max_frames_backpropagate", 1)) > 1:
+        # the reference lets gradients cross the generator GPUs when n_frames_bp > 1 (`.cuda(gpu_id)` keeps the autograd edge,
+        # models/vid2vid_model_G.py:152-168); here the previous frames arrive detached from the generator rank before, so a
+        # larger n_frames_bp would silently train something else
+        raise ValueError("the generator / discriminator rank roles support --max_frames_backpropagate 1 only (previous frames cross "
+                         "generator ranks detached); got %d" % opt.max_frames_backpropagate)
     return RoleLayout(rank, world, group_size, n_gen)
 
 
@@ -110,6 +116,8 @@ class _Sends:
 
     def send(self, t, dst):
         t = t.detach().contiguous()
+        if _staged(t):
+            t = t.cpu()                              # gloo: CPU transport (see parallel.host_staged); RCCL sends device memory
         self.work.append((dist.isend(t, dst), t))
 
     def wait(self):
@@ -118,7 +126,16 @@ class _Sends:
         self.work = []
 
 
+def _staged(t_or_device):
+    dev = t_or_device.device if torch.is_tensor(t_or_device) else t_or_device
+    return bool(dev is not None and torch.device(dev).type == "cuda" and dist.get_backend() == "gloo")
+
+
 def _recv(shape, src, device, dtype=torch.float32):
+    if _staged(device):
+        t = torch.empty(shape, dtype=dtype)
+        dist.recv(t, src)
+        return t.to(device)
     t = torch.empty(shape, dtype=dtype, device=device)
     dist.recv(t, src)
     return t
@@ -184,6 +201,12 @@ class NullOptimizer:
     def state_dict(self): return {}
     def load_state_dict(self, state): pass
 
+    def rebuild(self, params, lr=None, betas=None):
+        """FusedAdam.rebuild's signature (BaseModel.update_fixed_params runs on EVERY rank, also on the ranks that do not own
+        the generator): nothing to re-home here, only the learning rate is kept for update_learning_rate's print-out."""
+        if lr is not None:
+            self.param_groups[0]["lr"] = lr
+
 
 # ---------------------------------------------------------------------------------------------------------------
 # the three wrappers (drop-in for models.RankModel)
@@ -197,6 +220,25 @@ class _RoleState:
         self.anchor = None           # D-rank: tensors whose zero-weighted sum keeps a loss attached to _Remote
         self.sink = None             # G-rank: ditto for _GradSink
         self.fake_tail = None        # D-rank: last tG-1 fake frames (finest scale) of the previous chunk
+
+
+def _broadcast_state(nets, group, src):
+    """Every tensor of the networks' state_dicts (parameters outside the optimizer's flat buffer -- the coarse scales while
+    `niter_fix_global` holds them fixed -- and the norm layers' running statistics) from `src` to the ranks of `group`:
+    replicas of one network must start identical whatever each process's RNG did."""
+    if group is None:
+        return
+    with torch.no_grad():
+        for net in nets:
+            for t in net.state_dict().values():
+                if not torch.is_tensor(t) or t.numel() == 0:
+                    continue
+                buf = t.detach().contiguous()
+                if _staged(buf):
+                    buf = buf.cpu()
+                dist.broadcast(buf, src=src, group=group)
+                if buf.data_ptr() != t.data_ptr():
+                    t.copy_(buf)
 
 
 class RoleModelG(nn.Module):
@@ -217,6 +259,9 @@ class RoleModelG(nn.Module):
         has_flow = not getattr(self.opt, "no_flow", False)
         shapes = [(1, k, self.opt.output_nc, H, W), (1, k, self.opt.output_nc, H, W)] + ([(1, k, 2, H, W), (1, k, 1, H, W)] if has_flow else [])
         pyr_shapes = [(1, tG - 1, self.opt.output_nc, H >> s, W >> s) for s in range(S)]
+        if getattr(m, "n_frames_bp", 1) > 1:
+            raise RuntimeError("role split: n_frames_bp = %d > 1 (update_training_batch with --max_frames_backpropagate > 1) would need "
+                               "gradients to cross the generator ranks; not supported" % m.n_frames_bp)
         if L.role == "G":
             g = L.g
             if g > 0:                                   # the frames just before mine were generated by G-rank g-1
@@ -336,6 +381,10 @@ def wrap_roles(opt, modelG, modelD, flowNet, layout):
         modelG.optimizer_G.grad_sync = gs
         if L.pg_G is not None:
             gs.broadcast(modelG.optimizer_G.flat.flat_param, src=0)
+            # ... and everything the flat buffer does not hold: the coarse scales while niter_fix_global keeps them out of the
+            # optimizer, and every norm layer's running statistics
+            _broadcast_state([getattr(modelG, "netG%d" % s_) for s_ in range(getattr(modelG, "n_scales", 1)) if hasattr(modelG, "netG%d" % s_)],
+                             L.pg_G, 0)
         parallel._ACTIVE_SYNCS.append(gs)
     else:
         modelG.optimizer_G = NullOptimizer(lr)
@@ -347,6 +396,8 @@ def wrap_roles(opt, modelG, modelD, flowNet, layout):
         modelD.optimizer_D.grad_sync = gsd
         if L.pg_D is not None:
             gsd.broadcast(modelD.optimizer_D.flat.flat_param, src=L.n_gen + 0)
+            if hasattr(modelD, "netD"):
+                _broadcast_state([modelD.netD], L.pg_D, L.n_gen + 0)
     else:
         modelD.optimizer_D = NullOptimizer(lr)
     for s in range(t_scales):
@@ -355,6 +406,8 @@ def wrap_roles(opt, modelG, modelD, flowNet, layout):
             getattr(modelD, name).grad_sync = gsd
             if L.pg_D is not None:
                 gsd.broadcast(getattr(modelD, name).flat.flat_param, src=L.n_gen + L.n_disc - 1)
+                if hasattr(modelD, "netD_T%d" % s):
+                    _broadcast_state([getattr(modelD, "netD_T%d" % s)], L.pg_D, L.n_gen + L.n_disc - 1)
         else:
             setattr(modelD, name, NullOptimizer(lr))
     # checkpoints: each network is written by its owner in sequence group 0 (the other replicas are never updated)
