@@ -42,17 +42,26 @@ def test_roofline_object_is_self_consistent(line):
     r = line["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
-    # achieved = algorithmic FLOP per launch / average launch duration (HIP events)
+    # achieved = algorithmic FLOP per launch / average launch duration of the kernel IN the frame graph
     assert abs(r["achieved"] - r["flop_per_launch"] / r["avg_launch_us"] / 1e6) / r["achieved"] < 1e-3
-    # the committed rocprofv3 average of the same kernel in the same command agrees with the live HIP-event average
-    g = r["in_graph"]
-    assert abs(g["avg_launch_us"] - r["avg_launch_us"]) / r["avg_launch_us"] < 0.10
-    assert os.path.exists(os.path.join(ROOT, g["source"].split(" ")[0]))
+    # `frac` is the in-graph figure: the committed rocprofv3 kernel-trace average of the bench command for the
+    # selected configuration when one exists, else this run's timeline stamps; the eager (alone-on-chip) figure is the companion
+    g, e = r.get("in_graph_rocprof"), r["eager"]
+    assert e["avg_launch_us"] > 0 and 0 < e["frac"] < 1
+    if g is not None:
+        # (a line measured before the matching rocprof file was committed carries the timeline figure instead: an upper bound)
+        assert abs(g["avg_launch_us"] - r["avg_launch_us"]) / r["avg_launch_us"] < 1e-6 or \
+            (r["measured"].startswith("in the frame graph") and r["avg_launch_us"] >= g["avg_launch_us"])
+        assert os.path.exists(os.path.join(ROOT, g["source"].split(" ")[0]))
+        assert abs(g["avg_launch_us"] - e["avg_launch_us"]) / e["avg_launch_us"] < 0.15      # in the graph vs alone: same kernel
+    live = r.get("in_graph_live")
+    if live is not None:                                     # stamps are an upper bound of the rocprof duration
+        assert live["avg_launch_us"] >= 0.95 * r["avg_launch_us"]
     # measured HBM traffic (PMC) is per launch like `achieved`, and not below the algorithmic bytes
     assert r["traffic"] is None or r["traffic"] >= r["traffic_detail"]["algorithmic_bytes_per_launch"]
     # the dominant kernel's launches fit into the frame: serial sum <= lanes x frame time; whole-frame work <= peak
     lanes = line["config"]["graph_lanes"]
-    assert r["launches_per_frame"] * g["avg_launch_us"] * 1e-3 <= lanes * line["ms_per_step"]
+    assert r["launches_per_frame"] * r["avg_launch_us"] * 1e-3 <= lanes * line["ms_per_step"]
     assert 0 < r["frame_in_graph"]["frac"] <= r["frac"] + 0.05
 
 
@@ -85,12 +94,36 @@ def test_round3_companion_objects(line):
     h = line["hires"]
     assert "2048x1024" in h["metric"] and h["value"] > 0 and abs(h["value"] - 1e3 / h["ms_per_step"]) / h["value"] < 1e-3
     assert h["parity"]["fp32_ok"] is True and h["parity"]["fp32_max_rel"] <= 1e-3 and h["cpu_baseline"]["value"] > 0
-    assert 0 < h["roofline"]["frac"] < 1 and h["roofline"]["frame_in_graph"]["frac"] <= h["roofline"]["frac"]
+    hr = h["roofline"]                                       # the configuration holding the most TIME of the 2048x1024 frame
+    assert hr["bound"] in ("hbm", "mfma") and 0 < hr["frac"] < 1 and abs(hr["frac"] - hr["achieved"] / hr["peak"]) < 1e-3
+    assert hr["ms_per_frame"] >= hr["flop_heaviest"]["ms_per_frame"] and 0 < hr["frame_vs_per_layer_bounds"]["frac"] < 1
     x = line["x3"]
     assert x["ok_1e-3"] is True and x["max_rel"] <= 1e-3 and x["value"] > line["fp32"]["value"] * 1.5      # the point of the mode
     assert x["x3_flop_share"] > 0.7
     p = line["train"]["parity"]
-    assert p["fp32_ok"] is True and p["fp32"]["max_forward_frame0"] <= 1e-3 and p["fp32"]["max_loss"] <= 1e-3
+    assert p["fp32_ok"] is True and p["fp32"]["max_forward"] <= 1e-3 and p["fp32"]["max_loss"] <= 1e-3        # EVERY frame (teacher-forced)
     assert set(p["fp32"]["grads"]) == {"G", "D", "DT"} and all(g["finite"] for g in p["fp32"]["grads"].values())
-    assert p["fp32"]["max_grad_norm"] <= p["tolerance_fp32"]["grad_norm"] and p["bf16"]["max_grad_l2"] < 0.5
+    assert p["fp32"]["max_grad_norm"] <= p["tolerance_fp32"]["grad_norm"] == 1e-3 and p["bf16"]["max_grad_l2"] < 0.5
+    assert p["free_running_fp32"]["max_forward"] < 1e-2
     assert line["train"]["flownet2"]["pairs_per_s"] > 0
+
+
+def test_round4_objects(line):
+    """the parity-carrying throughput as flat top-level keys, BASELINE configs[0] literally (256x128
+    2-frame clip, GPU vs the CPU oracle timed on the same clip), and configs[4]'s geometry as a TRAINING chunk on one GPU
+    with its fp32 parity against the oracle, frames trained/s and peak memory."""
+    assert line["parity_ok"] is True and line["parity_max_rel"] <= 1e-3 and line["parity_value"] == line["x3"]["value"]
+    assert line["hires_value"] == line["hires"]["value"] and line["train_hires_value"] == line["train_hires"]["value"]
+    # the flat keys sit ahead of the nested objects (the driver's record keeps top-level scalars)
+    keys = list(line.keys())
+    assert keys.index("parity_value") < keys.index("config") and keys.index("train_hires_value") < keys.index("roofline")
+    c1 = line["c1"]
+    assert "256x128" in c1["workload"] and "2-frame clip" in c1["workload"] and c1["value"] > 0
+    assert c1["parity"]["fp32_ok"] is True and c1["parity"]["x3_ok"] is True and c1["parity"]["frames"] == 2
+    assert c1["cpu_baseline"]["value"] > 0 and c1["cpu_baseline"]["cores"] >= 1 and c1["value"] > 100 * c1["cpu_baseline"]["value"]
+    th = line["train_hires"]
+    assert "2048x1024" in th["metric"] and "n_scales_spatial=3 num_D=4" in th["workload"] and th["value"] > 0
+    assert 0 < th["peak_memory_gb"] < 288
+    p = th["parity"]
+    assert p["fp32_ok"] is True and p["fp32"]["max_forward"] <= 1e-3 and p["fp32"]["max_loss"] <= 1e-3 and p["fp32"]["max_grad_norm"] <= 1e-3
+    assert set(p["fp32"]["grads"]) == {"G", "D"} and p["fp32"]["grads"]["G"]["numel"] > 4e8          # all three scales' parameters

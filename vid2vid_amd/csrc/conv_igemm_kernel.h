@@ -390,24 +390,67 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             return;
         }
     }
+    // ---- 16-byte stores through a wave-private LDS transposition (round 4) ----
+    // The MFMA C layout gives a lane ONE channel of 16 rows: stored as it lies that is one 4-byte (fp32) or 2-byte (bf16) store
+    // per element -- 32 store instructions per 32x32 block, and the stride-2 / transposed / fine-scale layers spent ~10 us of
+    // every launch issuing them (profiles/r02_a67_s2_ablate_trace.txt; guide T21: an epilogue's store tail is ISSUE-bound).
+    // Each wave now parks a 32x32 block (after bias / activation, fp32) in its own 4 KB of LDS -- lane (col, half) writes
+    // row-major, conflict-free -- and reads it back 16 bytes of consecutive channels per lane (fp32: linear in the lane id,
+    // conflict-free; bf16: 8 floats per lane), i.e. 4 (fp32) / 2 (bf16) vector stores per block instead of 32.  Wave-private: no
+    // workgroup barrier, only the in-order LDS queue.  Same values, same statistics arithmetic as before (the statistics still
+    // come from the registers in the old order); a vector is used only when it lies wholly inside the layer's own channels and
+    // the output is 16-byte aligned -- otherwise (partial channel vectors, outputs written at an odd channel offset of a wider
+    // tensor) the scalar stores remain.
+    constexpr int RED_BYTES = ((WGM * BN * 8 + 1023) / 1024) * 1024;
+    float* const tw = reinterpret_cast<float*>(smem + RED_BYTES) + (wm * WGN + wn) * 1024;
+    const bool vec_ok = !helper && ((reinterpret_cast<unsigned long long>(p.out) & 15ull) == 0ull);
     if (p.out_mode == V2V_OUT_RAW_F32_NHWC) {
         float* const out = reinterpret_cast<float*>(p.out);
+        const bool vec4 = vec_ok && (cs_out & 3u) == 0u;
+        int spx[TM][4];                                // output pixel of the rows this lane STORES: (lane >> 3) + 8 k
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = pix_of(wm * WM + i * 32 + (lane >> 3) + 8 * k);
+                spx[i][k] = (helper || (p.ablate & 4)) ? -1 : o;
+            }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int ncol = nt * BN + wn * WN + j * 32 + lr;
             const bool nvalid = ncol < p.cout && !helper;
             const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
+            const int vcol = nt * BN + wn * WN + j * 32 + 4 * (lane & 7);     // first channel of this lane's vectors
+            const bool vfull = vec4 && vcol + 4 <= p.cout;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] + bv;
                     if (opx[i][r] >= 0 && nvalid) {
-                        const float v = acc[i][j][r] + bv;
                         s1 += v;
                         s2 = __builtin_fmaf(v, v, s2);          // explicit: the raw and the fused-norm paths must round alike
-                        out[(unsigned)opx[i][r] * cs_out + (unsigned)ncol] = v;
                     }
+                    tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lr] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + ((lane >> 3) + 8 * k) * 32 + 4 * (lane & 7));
+                    if (spx[i][k] < 0) continue;
+                    float* const dst = out + (unsigned)spx[i][k] * cs_out + (unsigned)vcol;
+                    if (vfull) *reinterpret_cast<f32x4*>(dst) = v4;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (vcol + e < p.cout && !helper) dst[e] = v4[e];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the block is in registers before the next one overwrites it
+            }
             if (want_stats) {
                 s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 32);
@@ -426,31 +469,71 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
         asm volatile("" : "+s"(e_act), "+s"(e_act_param), "+s"(e_out_scale));
         // NONE / RELU / LEAKY (every norm-less hidden layer) as one select with hoisted conditions: bit for bit apply_act()
         const bool simple = e_act == V2V_ACT_NONE || e_act == V2V_ACT_RELU || e_act == V2V_ACT_LEAKY;
+        const bool is_none = e_act == V2V_ACT_NONE, is_relu = e_act == V2V_ACT_RELU;
+        constexpr int VEC = ElemTraits<T>::VEC;               // channels per 16-byte vector
+        constexpr int LPR = 32 / VEC;                        // lanes per 32-channel row: 8 (fp32) / 4 (bf16)
+        constexpr int RPP = 64 / LPR;                        // rows per pass of the wave: 8 / 16
+        constexpr int NPASS = 32 / RPP;                      // 4 / 2
+        const bool vecT = vec_ok && (cs_out % (unsigned)VEC) == 0u;
+        int spx[TM][NPASS];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const int o = pix_of(wm * WM + i * 32 + lane / LPR + RPP * k);
+                spx[i][k] = (helper || (p.ablate & 4)) ? -1 : o;
+            }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int ncol = nt * BN + wn * WN + j * 32 + lr;
             const bool nvalid = ncol < p.cout && !helper;
             const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
-            if (simple) {
-                const bool is_none = e_act == V2V_ACT_NONE, is_relu = e_act == V2V_ACT_RELU;
+            const int vcol = nt * BN + wn * WN + j * 32 + VEC * (lane % LPR);
+            const bool vfull = vecT && vcol + VEC <= p.cout;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (opx[i][r] >= 0 && nvalid) {
-                            float v = acc[i][j][r] + bv;
-                            const float neg = is_relu ? 0.f : v * e_act_param;
-                            v = (is_none || v > 0.f) ? v : neg;
-                            store_act(out, (unsigned)opx[i][r] * cs_out + (unsigned)ncol, v * e_out_scale);
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bv;
+                    if (simple) {
+                        const float neg = is_relu ? 0.f : v * e_act_param;
+                        v = (is_none || v > 0.f) ? v : neg;
+                    } else {
+                        v = apply_act(v, e_act, e_act_param);
+                    }
+                    tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lr] = v * e_out_scale;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < NPASS; ++k) {
+                    const float* const src = tw + (lane / LPR + RPP * k) * 32 + VEC * (lane % LPR);
+                    float o[VEC];
+#pragma unroll
+                    for (int q = 0; q < VEC / 4; ++q) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(src + 4 * q);
+                        o[4 * q + 0] = v4[0]; o[4 * q + 1] = v4[1]; o[4 * q + 2] = v4[2]; o[4 * q + 3] = v4[3];
+                    }
+                    if (spx[i][k] < 0) continue;
+                    const unsigned eo = (unsigned)spx[i][k] * cs_out + (unsigned)vcol;
+                    if (vfull) {
+                        if constexpr (VEC == 4) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + eo) = f32x4{o[0], o[1], o[2], o[3]};
+                        } else {
+                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+                            u32x4s pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pk[e] = (unsigned)f32_to_bf16_bits(o[2 * e]) | ((unsigned)f32_to_bf16_bits(o[2 * e + 1]) << 16);
+                            *reinterpret_cast<u32x4s*>(reinterpret_cast<unsigned short*>(out) + eo) = pk;
                         }
-            } else {
+                    } else {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (opx[i][r] >= 0 && nvalid)
-                            store_act(out, (unsigned)opx[i][r] * cs_out + (unsigned)ncol,
-                                      apply_act(acc[i][j][r] + bv, e_act, e_act_param) * e_out_scale);
+                        for (int e = 0; e < VEC; ++e)
+                            if (vcol + e < p.cout && !helper) store_act(out, eo + e, o[e]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
     } else {                                       // planar fp32 NCHW (API-facing heads)
