@@ -58,6 +58,10 @@ extern "C" {
 #define V2V_OUT_F32_NCHW     2  /* fp32 planar NCHW (API-facing heads)                */
 #define V2V_OUT_NORM_ACT_NHWC 3 /* activation dtype NHWC after the training-mode norm (batch statistics of THIS launch),
                                  * activation and residual adds -- see "fused norm" below                            */
+#define V2V_OUT_RAW_ACT_NHWC 4  /* pre-norm like mode 0, but STORED in the activation dtype (bf16 storage: half the bytes of the
+                                 * raw tensor the following v2v_bn_apply_raw reads back); the per-tile statistics and the in-kernel
+                                 * finalize still come from the fp32 accumulators, bit for bit those of mode 0.  Generic, patch
+                                 * and single-phase tiles (not tiles 60 / 61).  With V2V_F32 storage identical to mode 0.           */
 
 /* Descriptor of one convolution / transposed convolution launch.  POD, passed by pointer,
  * copied by the callee before it returns. */
@@ -232,6 +236,11 @@ int v2v_bn_finalize_groups(int32_t rows);
 int v2v_bn_apply(const float* raw, int32_t c_stride_raw, const float* scale_shift,
                  const void* add0, const void* add1, void* y, int64_t P, int32_t C, int32_t c_stride,
                  int32_t act, float act_param, int32_t dtype, void* stream);
+/* v2v_bn_apply whose raw operand is stored in `raw_dtype` (V2V_F32: exactly v2v_bn_apply; V2V_BF16: the V2V_OUT_RAW_ACT_NHWC
+ * output of a bf16 convolution, [P][c_stride_raw] bf16 with c_stride_raw % 8 == 0).  Same arithmetic on the widened values. */
+int v2v_bn_apply_raw(const void* raw, int32_t raw_dtype, int32_t c_stride_raw, const float* scale_shift,
+                     const void* add0, const void* add1, void* y, int64_t P, int32_t C, int32_t c_stride,
+                     int32_t act, float act_param, int32_t dtype, void* stream);
 /* Two bn_apply passes of identical geometry as ONE launch (block y picks its member): the norm + activation
  * (+ residual) passes behind a v2v_conv2d_pair.  Bitwise the result of two v2v_bn_apply calls. */
 int v2v_bn_apply_pair(const float* raw_a, const float* scale_shift_a, const void* add0_a, const void* add1_a, void* y_a,

@@ -31,8 +31,104 @@ PY
   tail -5 gpurun_out/${TAG}_bench_default.err | cut -c1-300
   lap benchdefault
 fi
+if has epi; then        # the vectorised conv epilogue (every RAW / ACT output of every tile): the whole suite minus the CPU-oracle-heavy tests
+  timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short --timeout 900 -k "not full_width_training and not full_size" > gpurun_out/${TAG}_epi_tests.log 2>&1; echo "epi tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_epi_tests.log | cut -c1-400 | tail -30
+  lap epi
+fi
+if has benchq; then     # quick A/B figure: both resolutions, no CPU legs, no training line
+  timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_benchq.json 2> gpurun_out/${TAG}_benchq.err; echo "benchq rc=$?"
+  python - <<PY
+import json
+j = json.load(open("gpurun_out/${TAG}_benchq.json"))
+print("512x256", j["value"], "fps", j["ms_per_step"], "ms", j["timing"]["windows_ms_per_step"])
+print(" per_kernel_ms", j["roofline"]["per_kernel_ms"], "eager sum", j["roofline"]["frame_ms_eager_events"])
+h = j["hires"]; print("2048x1024", h["value"], "fps", h["ms_per_step"], "ms; eager sum", h["roofline"]["frame_ms_eager_events"], h["roofline"]["slowest_configs_ms"])
+print(" per_kernel_ms", h["roofline"]["per_kernel_ms"])
+print(" hires roofline", h["roofline"]["kernel"], h["roofline"]["bound"], h["roofline"]["frac"], h["roofline"]["frame_vs_per_layer_bounds"])
+PY
+  tail -3 gpurun_out/${TAG}_benchq.err | cut -c1-300
+  lap benchq
+fi
+if has phases; then     # per-workgroup phase stamps of the stride-2 / transposed / ResnetBlock launches
+  timeout 600 python scripts/kernel_phases.py > gpurun_out/${TAG}_kernel_phases.txt 2> gpurun_out/${TAG}_kernel_phases.err; echo "phases rc=$?"
+  cut -c1-330 gpurun_out/${TAG}_kernel_phases.txt; tail -3 gpurun_out/${TAG}_kernel_phases.err
+  lap phases
+fi
+if has benchpar; then   # 512x256 with the CPU-oracle parity legs only (bf16 error of the benchmarked path), no companions
+  timeout 900 python bench.py --no-train-line --no-train-hires --no-c1 --no-hires > gpurun_out/${TAG}_benchpar.json 2> gpurun_out/${TAG}_benchpar.err; echo "benchpar rc=$?"
+  python - <<PY
+import json
+j = json.load(open("gpurun_out/${TAG}_benchpar.json"))
+print("512x256", j["value"], "fps", j["ms_per_step"], "ms")
+p = j["parity"]; print(" fp32", p["fp32_max_rel"], "bf16", p["bf16"], "drift", p["free_running_drift"])
+print(" x3", j["x3"]["value"], j["x3"]["max_rel"], "fp32", j["fp32"]["value"])
+PY
+  lap benchpar
+fi
+if has sqpmc; then      # SQ counters of the dominant tile (paired 1024->1024 3x3 + fused norm, tile 91): MFMA busy cycles, LDS bank conflicts, wave / wait cycles (separate passes)
+  cd /tmp
+  NEEDLE=${NEEDLE:-conv3x3_pp3_kernel}
+  P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
+  P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS"
+  P3="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM"
+  : > $R/gpurun_out/${TAG}_sq_counters.txt
+  i=0
+  for P in "$P1" "$P2" "$P3"; do
+    i=$((i+1))
+    timeout 200 rocprofv3 --kernel-trace --pmc $P -d /tmp/sq_${TAG}_$i -o pmc -- python $R/scripts/conv_layer_run.py --pair --fused --cfg ${CFG:-91,1},0 --reps 20 > /tmp/sq_${TAG}_$i.log 2>&1; echo "sq pass $i rc=$?"
+    python $R/scripts/pmc_all.py $(find /tmp/sq_${TAG}_$i -name "*.db" | head -1) $NEEDLE "pass $i: rocprofv3 --kernel-trace --pmc $P -- python scripts/conv_layer_run.py --pair --fused --cfg ${CFG:-91,1},0 --reps 20 (paired 1024->1024 3x3 @64x32 + fused norm, bf16, cold cache)" >> $R/gpurun_out/${TAG}_sq_counters.txt 2>&1
+  done
+  cat $R/gpurun_out/${TAG}_sq_counters.txt | cut -c1-200
+  cd $R
+  lap sqpmc
+fi
+if has trainprof; then  # rocprofv3 table of the training step (bf16, 512x256, VGG on)
+  cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_tr_$TAG -o tr -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-train-parity > $R/gpurun_out/${TAG}_train.json 2> $R/gpurun_out/${TAG}_train.err; echo "train rc=$?"
+  python $R/scripts/rocprof_summary.py $(find /tmp/prof_tr_$TAG -name "*.db" | head -1) "# round 4, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --mode train --steps 6 --warmup 2 --no-train-parity (bf16, 512x256, VGG on; autotune launches of the first chunks included)" > $R/gpurun_out/${TAG}_train_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_train.err
+  head -40 $R/gpurun_out/${TAG}_train_kernel_stats.txt | cut -c1-220
+  python -c "
+import json; j = json.load(open('$R/gpurun_out/${TAG}_train.json')); print('train', j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['gflop_per_step_by_kind']); print(j['flownet2'])"
+  cd $R
+  lap trainprof
+fi
+if has rawab; then      # bf16 raw tensors on / off on ONE box: both resolutions + the bf16 error of the 512x256 frame
+  for rb in 1 0 1 0; do
+    V2V_RAW_BF16=$rb timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
+print('V2V_RAW_BF16=$rb: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms bn_apply', j['roofline']['per_kernel_ms'].get('bn_apply'), 'conv', j['roofline']['per_kernel_ms'].get('conv_igemm'), '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms bn_apply', h['roofline']['per_kernel_ms'].get('bn_apply'), 'conv', h['roofline']['per_kernel_ms'].get('conv_igemm'))"
+  done | tee gpurun_out/${TAG}_raw_bf16_ab.txt
+  lap rawab
+fi
+if has trainprof2; then # steady-state table of the training step: a first run fills the tile cache, the profiled second run replays it (no autotune launches in the trace)
+  rm -f /tmp/tune_train.json
+  V2V_TUNE_CACHE=/tmp/tune_train.json timeout 600 python bench.py --mode train --steps 4 --warmup 1 --no-train-parity > gpurun_out/${TAG}_train_first.json 2> gpurun_out/${TAG}_train_first.err; echo "train(first) rc=$?"
+  cd /tmp
+  V2V_TUNE_CACHE=/tmp/tune_train.json timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_tr2_$TAG -o tr -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-train-parity > $R/gpurun_out/${TAG}_train.json 2> $R/gpurun_out/${TAG}_train.err; echo "train(profiled) rc=$?"
+  python $R/scripts/rocprof_summary.py $(find /tmp/prof_tr2_$TAG -name "*.db" | head -1) "# round 4, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --mode train --steps 6 --warmup 2 --no-train-parity (bf16, 512x256, VGG on, 2 frames per chunk; tile selections replayed from a cache filled by a previous run; 3 tuning-sequence chunks + 2 warm-up + 6 timed chunks in the trace)" > $R/gpurun_out/${TAG}_train_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_train.err
+  head -60 $R/gpurun_out/${TAG}_train_kernel_stats.txt | cut -c1-200
+  python -c "
+import json
+for f in ('first', ''):
+    j = json.load(open('$R/gpurun_out/${TAG}_train' + ('_first' if f else '') + '.json')); print('train', f or 'profiled', j['value'], j['ms_per_step'], j['roofline']['frac'], j['config']['autotune_s'], j['roofline']['conv_launches_per_step'])"
+  cd $R
+  lap trainprof2
+fi
+if has roles; then
+  timeout 600 python -m pytest tests/test_gpu_roles.py -m gpu -q -rf --tb=short -s > gpurun_out/${TAG}_roles.log 2>&1; echo "roles rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|max \|d\||^E  " gpurun_out/${TAG}_roles.log | cut -c1-300 | tail -40
+  lap roles
+fi
 if has tests; then
   timeout 2400 python -m pytest tests -m gpu -q -rf --tb=short --timeout 1500 --durations=15 > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300 | tail -30
   lap tests
+fi
+if has dbg1; then
+  for envs in ${DBGENVS:-"X=1" "V2V_FUSED_NORM=0" "V2V_TWIN=0" "V2V_LANES=0" "V2V_RAW_BF16=0"}; do
+    echo "== $envs"
+    env $envs timeout 300 python -m pytest tests/test_gpu_golden.py -m gpu -q --tb=line -k "inference_api_vs_reference or flownet2_vs_reference" 2>&1 | grep -E "passed|failed|Error|error" | cut -c1-250
+  done
+  lap dbg1
 fi

@@ -7,7 +7,7 @@ src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include")
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + inc,
-                    "-c", src, "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_kr.o"], capture_output=True, text=True)
+                    "-c", src] + sys.argv[3:] + ["-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_kr.o"], capture_output=True, text=True)
 for b in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
     name = b.split("\n")[0].strip()
     if flt not in name:

@@ -123,6 +123,52 @@ def test_conv2d_every_tile_config(tile, prec):
     assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "stats")
 
 
+@pytest.mark.parametrize("shape", [(72, 96, 3, 1, 1, 21, 37, 0), (128, 256, 3, 2, 1, 32, 48, 0), (64, 40, 3, 2, 1, 16, 24, 1), (256, 128, 3, 1, 1, 16, 32, 0)])
+def test_conv_raw_output_in_activation_dtype(shape):
+    """V2V_OUT_RAW_ACT_NHWC (round 4): the pre-norm output of a bf16 convolution stored as bf16.  Against the fp32-raw launch of the
+    same layer and tile: the statistics rows (and the in-kernel finalize record) are IDENTICAL bit for bit -- they come from the fp32
+    accumulators -- the stored tensor is the fp32 raw rounded to bf16 exactly, and v2v_bn_apply_raw on it equals v2v_bn_apply on the
+    widened values exactly.  Stride 1 / stride 2 / transposed, ragged channel counts (40: partial vectors take the scalar stores),
+    generic and single-phase tiles; Engine.conv_group then runs the whole group and is compared with the fp32-raw engine."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, check
+    from vid2vid_amd.engine import _ptr, _stream
+    cin, cout, k, stride, pad, H, W, tr = shape
+    torch.manual_seed(cin + cout)
+    eng = _engine("bf16")
+    conv = (nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1) if tr else nn.Conv2d(cin, cout, k, stride=stride, padding=pad)).to(DEV)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    x = eng.pack(torch.randn(1, cin, H, W, device=DEV))
+    ss32, ss16 = torch.zeros(4 * cout, device=DEV), torch.zeros(4 * cout, device=DEV)
+    with torch.no_grad():
+        eng.raw_bf16 = True
+        raw32, rows, (N, OH, OW) = eng.conv(x, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss32))
+        tile = eng.conv_log[-1]["tile"]
+        cs4, cs8 = (cout + 3) // 4 * 4, (cout + 7) // 8 * 8
+        r32 = raw32[:N * OH * OW * cs4].view(-1, cs4)[:, :cout].clone()
+        st32 = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].clone()
+        raw16, rows2, _ = eng.conv(x, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss16), raw_act_ok=True)
+        assert raw16.dtype == torch.bfloat16 and rows2 == rows and eng.conv_log[-1]["tile"] == tile
+        r16 = raw16[:N * OH * OW * cs8].view(-1, cs8)[:, :cout].clone()
+        st16 = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].clone()
+        assert torch.equal(st16, st32), "statistics rows differ between fp32 and bf16 raw storage"
+        assert torch.equal(ss16, ss32), "in-kernel finalize record differs"
+        assert torch.equal(r16, r32.bfloat16()), "stored raw is not the fp32 raw rounded to bf16 (max diff %g)" % (r16.float() - r32).abs().max().item()
+        # bn_apply_raw == bn_apply on the widened tensor
+        wide = torch.zeros(N * OH * OW, cs4, device=DEV)
+        wide[:, :cout] = r16.float()
+        ya, yb = eng.empty_act(N, OH, OW, cout), eng.empty_act(N, OH, OW, cout)
+        check(lib.v2v_bn_apply_raw(_ptr(raw16), L.BF16, cs8, _ptr(ss16), None, None, _ptr(ya.t), N * OH * OW, cout, ya.Cs, L.ACT_RELU, 0.0, L.BF16, _stream()), "bn_apply_raw")
+        check(lib.v2v_bn_apply(_ptr(wide), cs4, _ptr(ss16), None, None, _ptr(yb.t), N * OH * OW, cout, yb.Cs, L.ACT_RELU, 0.0, L.BF16, _stream()), "bn_apply")
+        assert torch.equal(ya.t, yb.t)
+        # the whole group through the engine: bf16 raw against fp32 raw, one more bf16 rounding of the pre-norm value
+        y16 = eng.unpack(eng.conv_group(x, conv, L.PAD_ZERO, None, norm, L.ACT_RELU, 0.0)).float()
+        eng.raw_bf16 = False
+        y32 = eng.unpack(eng.conv_group(x, conv, L.PAD_ZERO, None, norm, L.ACT_RELU, 0.0)).float()
+        eng.raw_bf16 = True
+        assert (y16 - y32).abs().max().item() <= 0.04 * max(y32.abs().max().item(), 1.0)
+
+
 # (tile, splitk, prefetch): split-K slices that start mid-tap, the prefetch helper wave on 4- and 8-wave tiles,
 # large wave tiles; cin chosen so that both the uniform tap walk (cs % chunk == 0) and the per-lane walk run
 SPLITK_CFGS = [(2, 2, 0), (2, 3, 12), (3, 4, 12), (13, 2, 12), (13, 1, 12), (17, 3, 12), (1, 2, 0), (5, 4, 12), (7, 1, 4),
@@ -277,6 +323,7 @@ def test_conv2d_pair_equals_two_launches(case, prec):
     torch.manual_seed(cin * 3 + W)
     eng = _engine(prec)
     eng.fused_norm = False            # this test reads the raw fp32 outputs; the fused variant has its own test below
+    eng.raw_bf16 = False              # (and the bf16-raw storage of single launches: test_conv_raw_output_in_activation_dtype)
     pad = 0 if mode == "reflect" else 1
     convs = [nn.Conv2d(cin, cout, 3, padding=pad) for _ in range(2)]
     norms = [nn.BatchNorm2d(cout).to(DEV) for _ in range(2)]

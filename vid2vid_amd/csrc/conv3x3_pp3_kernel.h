@@ -60,6 +60,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     const ConvKArgs p = select_group(p_in);
     const int ab = ABL ? p.ablate : 0;
     if (ab & 512) return;                                     // ablation: the launch itself
+    V2V_STAMP(p, 0);
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PR = (TH + 2) * PW;
@@ -202,8 +203,10 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     for (int t = 0; t < D; ++t)
 #pragma unroll
         for (int i = 0; i < LB; ++i) issue_w_piece(i, t, t);
+    V2V_STAMP(p, 1);
     wait_vmcnt<(D - 1) * LB>();                              // the patch and slice 0 have landed (this wave's share)
     __builtin_amdgcn_s_barrier();
+    V2V_STAMP(p, 2);
     {
         const char* arow[TM]; int ax[TM];
 #pragma unroll
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail duplicates must land before the LDS is reused
     __syncthreads();
+    V2V_STAMP(p, 3);
 
     auto pix_of = [&](int row) -> int {        // TW is a power of two; N*OH*OW < 2^31 (host check)
         const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));

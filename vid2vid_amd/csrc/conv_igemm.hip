@@ -366,6 +366,8 @@ static int choose_cfg(long long Mc, int cout, int ncls) {
     return 3;
 }
 
+static unsigned long long* g_conv_dbg_clocks = nullptr;    // v2v_conv_debug_clocks
+
 struct ConvOp : Op {
     ConvKArgs k;
     int ncls, cfg, dtype;
@@ -479,7 +481,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     }
     if (d->fin_counter) {
         if (!d->stats || !d->fin_scale_shift || d->fin_count <= 0 ||
-            (d->out_mode != V2V_OUT_RAW_F32_NHWC && d->out_mode != V2V_OUT_NORM_ACT_NHWC)) {
+            (d->out_mode != V2V_OUT_RAW_F32_NHWC && d->out_mode != V2V_OUT_NORM_ACT_NHWC && d->out_mode != V2V_OUT_RAW_ACT_NHWC)) {
             set_error("conv: in-kernel norm finalize needs stats, fin_scale_shift, fin_count and RAW output"); return V2V_EINVAL;
         }
         k.fin_counter = d->fin_counter; k.fin_gamma = d->fin_gamma; k.fin_beta = d->fin_beta; k.fin_out = d->fin_scale_shift;
@@ -488,9 +490,17 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.fin_inv_count = 1.0 / (double)d->fin_count;
         k.fin_unbias = d->fin_count > 1 ? (double)d->fin_count / (double)(d->fin_count - 1) : 1.0;
     }
+    if (d->out_mode == V2V_OUT_RAW_ACT_NHWC && d->dtype == V2V_F32) k.out_mode = V2V_OUT_RAW_F32_NHWC;     // fp32 storage: the same tensor
+    if (d->out_mode < 0 || d->out_mode > V2V_OUT_RAW_ACT_NHWC) { set_error("conv: bad out_mode %d", d->out_mode); return V2V_EINVAL; }
+    if (d->stats && d->out_mode == V2V_OUT_RAW_ACT_NHWC && d->cout_stride % (d->dtype == V2V_BF16 ? 8 : 4) != 0) {
+        set_error("conv: RAW_ACT output needs a channel stride of whole 16-byte vectors"); return V2V_EINVAL;
+    }
     op->ncls = g.ncls;
     op->dtype = d->dtype;
     op->cfg = d->tile ? d->tile : choose_cfg(Mc, d->cout, g.ncls);
+    if (d->out_mode == V2V_OUT_RAW_ACT_NHWC && (op->cfg == 60 || op->cfg == 61)) {
+        set_error("conv: tile config %d writes fp32 raw only (V2V_OUT_RAW_F32_NHWC)", op->cfg); return V2V_EINVAL;
+    }
     int tile_bm, tile_bn;
     if (op->cfg == 61) {
         // conv7x7_c8_kernel: 7x7 / stride 1 / pad 3 Conv2d over pixels of exactly 16 bytes (8 bf16 / 4 fp32 channels), <= 128 output channels
@@ -561,6 +571,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.slabs = (float*)d->slabs; k.sk_counter = d->sk_counter;
     }
     k.ablate = d->ablate;
+    k.dbg = g_conv_dbg_clocks;
     {
         static const int rev = [] { const char* e = getenv("V2V_CLS_ORDER"); return (e && e[0] == '0') ? 0 : 1; }();
         k.cls_rev = rev;
@@ -603,6 +614,11 @@ extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int
         a.kpad[c] = g.kpad[c]; a.wrow[c] = g.wrow[c]; a.woff[c] = g.woff[c];
     }
     return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_conv_debug_clocks(void* device_buffer) {
+    g_conv_dbg_clocks = reinterpret_cast<unsigned long long*>(device_buffer);
+    return 0;
 }
 
 extern "C" int v2v_conv_stats_rows(const v2v_conv_desc* d) {

@@ -56,7 +56,23 @@ struct ConvKArgs {
     unsigned div_m[4][2]; int div_l[4][2];
     int* status;         // host-mapped status word of the library (v2v_device_status) or NULL: bit 0 = a fused-norm barrier gave up
     ConvGroupPtrs g1;    // grouped launch (conv3x3_pp2_kernel): operands of block z == 1
+    unsigned long long* dbg;   // v2v_conv_debug_clocks: [workgroup][8] constant-rate (100 MHz) wall-clock stamps of the kernel's phases, or NULL
 };
+
+// phase stamp k of this workgroup (thread 0): 0 entry, 1 prologue set up (first loads issued), 2 first tile landed, 3 main loop done,
+// 4 outputs stored, 5 statistics row published, 6 exit.  COMPILED OUT of the product build (V2V_STAMP_MASK = 0): with the stamps
+// compiled in -- even with a NULL buffer, i.e. never executed -- most kernels sit at the 106-SGPR ceiling and the fp32 golden tests
+// turn flaky (profiles/r04_a4_stamps_flaky.txt: 1-2 of 3 tests fail per run with the stamps in, 0 of 18 without), so the
+// instrumented library is a PROFILING build only:  touch conv_igemm_kernel.h && make -C vid2vid_amd/csrc EXTRA=-DV2V_STAMP_MASK=0x7f,
+// run scripts/kernel_phases.py, rebuild without EXTRA.  Its timings are what it is for; its results are not to be trusted.
+#ifndef V2V_STAMP_MASK
+#define V2V_STAMP_MASK 0
+#endif
+#define V2V_STAMP(p_, k_)                                                                                                   \
+    do {                                                                                                                   \
+        if (((V2V_STAMP_MASK >> (k_)) & 1) && (p_).dbg != nullptr && threadIdx.x == 0)                                                                       \
+            (p_).dbg[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k_)] = wall_clock64(); \
+    } while (0)
 
 __device__ __forceinline__ int xcd_remap(int bid, int ntot) {
     const int q = ntot >> 3, r = ntot & 7, xcd = bid & 7, idx = bid >> 3;
@@ -461,12 +477,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                 }
             }
         }
-    } else if (p.out_mode == V2V_OUT_ACT_NHWC) {
+    } else if (p.out_mode == V2V_OUT_ACT_NHWC || p.out_mode == V2V_OUT_RAW_ACT_NHWC) {
         T* const out = reinterpret_cast<T*>(p.out);
+        // V2V_OUT_RAW_ACT_NHWC: the pre-norm value (bias added, no activation) stored in T; the statistics below come from the fp32
+        // accumulators in the order of the RAW_F32 branch, so the (sum, sum^2) rows are bit for bit those of mode 0
+        const bool raw_t = p.out_mode == V2V_OUT_RAW_ACT_NHWC;
         // uniform epilogue operands pinned in SGPRs: the unrolled store loops otherwise re-fetch them from the kernel-argument
         // segment per element (profiles/r02_isa_sload_report.txt: 32-128 s_load_dword + s_waitcnt per launch)
-        int e_act = p.act; float e_act_param = p.act_param, e_out_scale = p.out_scale;
-        asm volatile("" : "+s"(e_act), "+s"(e_act_param), "+s"(e_out_scale));
+        int e_act = raw_t ? V2V_ACT_NONE : p.act; float e_act_param = p.act_param;
+        int e_scale_bits = raw_t ? 0x3f800000 : __float_as_int(p.out_scale);     // (an integer select: a float one would be a VALU op)
+        asm volatile("" : "+s"(e_act), "+s"(e_act_param), "+s"(e_scale_bits));
+        const float e_out_scale = __int_as_float(e_scale_bits);
         // NONE / RELU / LEAKY (every norm-less hidden layer) as one select with hoisted conditions: bit for bit apply_act()
         const bool simple = e_act == V2V_ACT_NONE || e_act == V2V_ACT_RELU || e_act == V2V_ACT_LEAKY;
         const bool is_none = e_act == V2V_ACT_NONE, is_relu = e_act == V2V_ACT_RELU;
@@ -490,11 +511,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
             const int vcol = nt * BN + wn * WN + j * 32 + VEC * (lane % LPR);
             const bool vfull = vecT && vcol + VEC <= p.cout;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r] + bv;
+                    if (raw_t && want_stats && opx[i][r] >= 0 && nvalid) {
+                        s1 += v;
+                        s2 = __builtin_fmaf(v, v, s2);
+                    }
                     if (simple) {
                         const float neg = is_relu ? 0.f : v * e_act_param;
                         v = (is_none || v > 0.f) ? v : neg;
@@ -535,6 +561,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            if (raw_t && want_stats) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (hi == 0 && !helper) {
+                    const int c = wn * WN + j * 32 + lr;
+                    red[(wm * BN + c) * 2 + 0] = s1;
+                    red[(wm * BN + c) * 2 + 1] = s2;
+                }
+            }
         }
     } else {                                       // planar fp32 NCHW (API-facing heads)
         float* const out = reinterpret_cast<float*>(p.out);
@@ -564,6 +599,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                         out[(unsigned)opx[i][r] + (unsigned)ncol * ohow] = apply_act(acc[i][j][r] + bv, e_act, e_act_param) * e_out_scale;
         }
     }
+    V2V_STAMP(p, 4);
     if (want_stats) {
         __syncthreads();
         if (tid < BN) {
@@ -599,6 +635,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             // No release/acquire fence: a release would write back the XCD L2's dirty conv output (+30 us measured).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            V2V_STAMP(p, 5);
             int* flag = reinterpret_cast<int*>(smem + 16384);
             const int total = (int)gridDim.y * p.m_tiles;
             if (tid == 0) {
@@ -641,6 +678,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             }
         }
     }
+    V2V_STAMP(p, 6);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int NS, bool HELPER>
@@ -663,6 +701,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.ablate & 512) return;               // ablation: the launch itself (dispatch of the grid with this LDS / wave footprint)
+    V2V_STAMP(p, 0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -871,12 +910,14 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
         }
     } else {
         for (int t = 0; t < D && t < nk; ++t) issue();
+        V2V_STAMP(p, 1);
         for (int ks = 0; ks < nk; ++ks) {
             // tile ks must have landed; in steady state tiles ks+1 .. ks+D-1 stay in flight
             if (ks + D <= nk) wait_vmcnt<LPT * (D - 1)>();
             else              wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();     // every wave's part of tile ks is in LDS, and every wave
                                               // is done reading stage (ks-1)%NS, which is refilled now
+            if (ks == 0) V2V_STAMP(p, 2);
             if (ks + D < nk) issue();
             const char* sb = smem + (ks % NS) * STAGE;
             if (p.ablate & 16) continue;      // loader-only ablation
@@ -897,6 +938,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
         }
     }
     __syncthreads();                      // LDS ring is free: reused for the statistics reduction
+    V2V_STAMP(p, 3);
 
     // row -> output pixel.  The uniform operands are pinned in SGPRs: left to itself the compiler re-fetches them from the kernel
     // argument segment for EVERY row of the unrolled epilogue (s_load + s_waitcnt lgkmcnt(0), 1-4 per row, 133 in a 128 x 128 tile)

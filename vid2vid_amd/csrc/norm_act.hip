@@ -114,6 +114,7 @@ struct BnApplyArgs {
     const float* raw1; const float* scale_shift1; const void* add0_1; const void* add1_1; void* y1;
     // fp32 only (v2v_bn_apply_x3): the result also as the bf16x3 operand [hi | lo | hi] of the consumer convolution, channel stride 3 C
     unsigned short* x3 = nullptr; unsigned short* x3_1 = nullptr;
+    int raw_bf16 = 0;       // v2v_bn_apply_raw: `raw` holds bf16 (V2V_OUT_RAW_ACT_NHWC of a bf16 convolution), stride in bf16 elements
 };
 
 template <typename T>
@@ -136,6 +137,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a_in) {
             const int c = c0 + q * 4;
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f), sc = r, sh = r;
             if (c < a.C) {   // c_stride_raw is a multiple of 4 and >= C: the 4-wide raw load stays inside the pixel's row
+                if (a.raw_bf16) {
+                    const uint2 rb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.raw) + pix * a.c_stride_raw + c);
+                    r = make_float4(__uint_as_float(rb.x << 16), __uint_as_float(rb.x & 0xffff0000u),
+                                    __uint_as_float(rb.y << 16), __uint_as_float(rb.y & 0xffff0000u));
+                } else
                 r = *reinterpret_cast<const float4*>(a.raw + pix * a.c_stride_raw + c);
                 if ((a.C & 3) == 0) {
                     sc = *reinterpret_cast<const float4*>(a.scale_shift + c);
@@ -597,6 +603,28 @@ extern "C" int v2v_bn_apply(const float* raw, int32_t c_stride_raw, const float*
     a.add0 = add0; a.add1 = add1; a.y = y; a.P = P; a.C = C; a.c_stride = c_stride;
     a.act = act; a.act_param = act_param;
     a.raw1 = nullptr; a.scale_shift1 = nullptr; a.add0_1 = nullptr; a.add1_1 = nullptr; a.y1 = nullptr;
+    op->dtype = dtype;
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_bn_apply_raw(const void* raw, int32_t raw_dtype, int32_t c_stride_raw, const float* scale_shift,
+                                const void* add0, const void* add1, void* y, int64_t P, int32_t C, int32_t c_stride,
+                                int32_t act, float act_param, int32_t dtype, void* stream) {
+    if (raw_dtype == V2V_F32)
+        return v2v_bn_apply(reinterpret_cast<const float*>(raw), c_stride_raw, scale_shift, add0, add1, y, P, C, c_stride, act, act_param, dtype, stream);
+    const int vec = dtype == V2V_BF16 ? 8 : 4;
+    if (raw_dtype != V2V_BF16 || !raw || !scale_shift || !y || P <= 0) { set_error("bn_apply_raw: bad argument"); return V2V_EINVAL; }
+    if (c_stride % vec != 0 || c_stride_raw % 8 != 0 || C < 1 || C > c_stride || C > c_stride_raw || (((uintptr_t)raw) & 15)) {
+        set_error("bn_apply_raw: bf16 raw needs a 16-byte aligned tensor and channel strides that are multiples of 8 (C=%d stride=%d raw=%d)", C, c_stride, c_stride_raw);
+        return V2V_EINVAL;
+    }
+    auto op = std::make_unique<BnApplyOp>();
+    BnApplyArgs& a = op->a;
+    a.raw = reinterpret_cast<const float*>(raw); a.c_stride_raw = c_stride_raw; a.scale_shift = scale_shift;
+    a.add0 = add0; a.add1 = add1; a.y = y; a.P = P; a.C = C; a.c_stride = c_stride;
+    a.act = act; a.act_param = act_param;
+    a.raw1 = nullptr; a.scale_shift1 = nullptr; a.add0_1 = nullptr; a.add1_1 = nullptr; a.y1 = nullptr;
+    a.raw_bf16 = 1;
     op->dtype = dtype;
     return submit(std::move(op), stream);
 }

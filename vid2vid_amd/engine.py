@@ -401,6 +401,13 @@ class Engine:
         # conv + norm + activation + residuals in one launch (spin barrier between the workgroups of a channel tile) for
         # the paired ResnetBlock convolutions; V2V_FUSED_NORM=0: raw fp32 output + bn_apply launch
         self.fused_norm = bool(int(os.environ.get("V2V_FUSED_NORM", "1")))
+        # V2V_RAW_BF16=1 (bf16 storage, inference plans): the pre-norm output of an UNPAIRED convolution (stride-2 / transposed stages,
+        # the foreground tower, fine-scale ResnetBlocks) is stored as bf16 instead of fp32 (V2V_OUT_RAW_ACT_NHWC) -- the conv writes and
+        # the bn_apply reads half the bytes; the statistics still come from the fp32 accumulators.  Built, tested
+        # (test_conv_raw_output_in_activation_dtype) and measured on one box (profiles/r04_a6_raw_bf16_ab.txt): bn_apply -7 % / -10 %,
+        # but the convolutions' epilogues pay more for the bf16 packing than the stores save (+3 % / +7 % conv time) -- the frame is
+        # 1.7 % SLOWER at both resolutions and the bf16 error grows (fake_B mean 1.44e-2 -> 1.64e-2).  OFF by default.
+        self.raw_bf16 = bool(int(os.environ.get("V2V_RAW_BF16", "0")))
         self._fused_norm_wgs = None
         # model_final_flow + model_final_w (same input) as one 7x7 head launch; V2V_MERGE_HEADS=0: one launch each
         self.merge_heads = bool(int(os.environ.get("V2V_MERGE_HEADS", "1")))
@@ -645,7 +652,7 @@ class Engine:
 
     # ---------------- primitive emitters ----------------
     def conv(self, x, mod, pad_mode=L.PAD_ZERO, pad_override=None, out_mode=L.OUT_RAW_F32_NHWC,
-             act=L.ACT_NONE, act_param=0.0, out_scale=1.0, want_stats=False, out=None, label="", fin=None, act_b=None):
+             act=L.ACT_NONE, act_param=0.0, out_scale=1.0, want_stats=False, out=None, label="", fin=None, act_b=None, raw_act_ok=False):
         """Emit one convolution.  Returns (out, stats_rows, (N,OH,OW)).
         fin = (norm module, ss tensor [4*cout]): finalize the training-mode norm statistics inside the conv
         kernel (last-arriving workgroup), so no separate bn_finalize launch is needed."""
@@ -668,7 +675,11 @@ class Engine:
         d.KH, d.KW, d.stride, d.pad, d.pad_mode = pc.KH, pc.KW, pc.stride, pad, pad_mode
         d.transposed = int(pc.transposed)
         d.OH, d.OW = OH, OW
-        d.dtype, d.out_mode, d.act = self.dtype, out_mode, act
+        # raw_act_ok (conv_group -> norm_apply only): the raw tensor may be stored in the activation dtype.  Never on the autograd
+        # path (the backward kernels read fp32 raw), never for the 7x7 layers (tiles 60 / 61 and the gather-sum stems write fp32)
+        raw_t = bool(raw_act_ok and out_mode == L.OUT_RAW_F32_NHWC and self.raw_bf16 and self.dtype == L.BF16 and out is None
+                     and pc.KH != 7 and not torch.is_grad_enabled())
+        d.dtype, d.out_mode, d.act = self.dtype, (L.OUT_RAW_ACT_NHWC if raw_t else out_mode), act
         d.act_param, d.out_scale = act_param, out_scale
         if act_b is not None:          # (first channel, activation, parameter, scale) of the second head of a merged pair
             d.act_split, d.act_b, d.act_param_b, d.out_scale_b = act_b
@@ -686,7 +697,12 @@ class Engine:
         d.bias = None if pc.bias is None else pc.bias.data_ptr()      # of the packing in use (aliases the parameter)
         if pc.cin != x.C:
             raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
-        if out_mode == L.OUT_RAW_F32_NHWC:
+        if raw_t:
+            cs = (pc.cout + 7) // 8 * 8
+            d.cout_stride = cs
+            out = self.scratch("raw", (N * OH * OW * cs + 1) // 2)[:N * OH * OW * cs // 2].view(torch.bfloat16)     # the same scratch, half the bytes
+            d.out = out.data_ptr()
+        elif out_mode == L.OUT_RAW_F32_NHWC:
             cs = (pc.cout + 3) // 4 * 4
             d.cout_stride = cs
             if out is None:
@@ -1272,7 +1288,8 @@ class Engine:
         """[bn_finalize +] bn_apply on the shared raw/statistics scratch (ss: caller-owned [4][C] statistics
         buffer, kept for the backward pass on the training path; finalized: the conv kernel already wrote it)."""
         N, OH, OW = shape
-        cs_raw = (cout + 3) // 4 * 4
+        raw_bf16 = raw.dtype == torch.bfloat16                 # Engine.conv(raw_act_ok=True): V2V_OUT_RAW_ACT_NHWC
+        cs_raw = (cout + 7) // 8 * 8 if raw_bf16 else (cout + 3) // 4 * 4
         if ss is None:
             ss = self.scratch("scale_shift", 4 * cout)
         if not finalized:
@@ -1292,6 +1309,11 @@ class Engine:
             check(lib.v2v_bn_apply_x3(_ptr(raw), _ptr(ss), _ptr(None if add0 is None else add0.t), _ptr(None if add1 is None else add1.t),
                                       _ptr(y.t), _ptr(y3), None, None, None, None, None, None,
                                       cs_raw, N * OH * OW, cout, act, act_param, _stream()), "bn_apply_x3 " + label)
+        elif raw_bf16:
+            check(lib.v2v_bn_apply_raw(_ptr(raw), L.BF16, cs_raw, _ptr(ss),
+                                       _ptr(None if add0 is None else add0.t), _ptr(None if add1 is None else add1.t),
+                                       _ptr(y.t), N * OH * OW, cout, y.Cs, act, act_param, self.dtype, _stream()),
+                  "bn_apply_raw " + label)
         else:
             check(lib.v2v_bn_apply(_ptr(raw), cs_raw, _ptr(ss),
                                    _ptr(None if add0 is None else add0.t), _ptr(None if add1 is None else add1.t),
@@ -1326,7 +1348,7 @@ class Engine:
                 self._x3_log(sub, n0)
             else:
                 raw, rows, shp = self.conv(x, conv, pad_mode, pad_override, L.OUT_RAW_F32_NHWC, want_stats=True, label=label,
-                                           fin=(norm, ss) if self.fused_finalize else None)
+                                           fin=(norm, ss) if self.fused_finalize else None, raw_act_ok=True)
             return self.norm_apply(raw, rows, shp, conv.out_channels, norm, act, act_param, add0=add0, add1=add1,
                                    label=label, ss=ss, finalized=self.fused_finalize and self.last_finalized)
         if add0 is not None or add1 is not None:

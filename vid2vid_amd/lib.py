@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libv2v_hip.so")
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-OUT_RAW_F32_NHWC, OUT_ACT_NHWC, OUT_F32_NCHW, OUT_NORM_ACT_NHWC = 0, 1, 2, 3
+OUT_RAW_F32_NHWC, OUT_ACT_NHWC, OUT_F32_NCHW, OUT_NORM_ACT_NHWC, OUT_RAW_ACT_NHWC = 0, 1, 2, 3, 4
 
 
 class ConvDesc(C.Structure):
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "v2v_conv_packed_elems": (_L, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "v2v_conv_pack_weights": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "v2v_conv_stats_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "v2v_conv_debug_clocks": (C.c_int, [_P]),
     "v2v_conv_tile_config": (C.c_int, [C.POINTER(ConvDesc)]),
     "v2v_conv_fused_norm_max_workgroups": (C.c_int, []),
     "v2v_fastdiv_magic": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(_I)]),
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "v2v_bn_finalize_groups": (C.c_int, [_I]),
     "v2v_bn_apply": (C.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
     "v2v_bn_apply_pair": (C.c_int, [_P] * 10 + [_I, _L, _I, _I, _I, _F, _I, _P]),
+    "v2v_bn_apply_raw": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
     "v2v_avgpool3s2_planar": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "v2v_avgpool3s2_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "v2v_maxpool2_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
