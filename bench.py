@@ -707,7 +707,13 @@ def main():
         return acc, rows, convs, launches, mfma_log, total_ms
 
     def tile_label(dom, fused=False):
-        from vid2vid_amd.engine import TILE_CFGS, PATCH_CFGS
+        from vid2vid_amd.engine import TILE_CFGS, PATCH_CFGS, S2_CFGS, T2_CFGS
+        if dom[0] in T2_CFGS:
+            th_, tw_, bn = T2_CFGS[dom[0]]
+            return "conv3x3_t2_kernel", "%dx%d positions x %d x 4 classes (transposed stride 2),splitK=1" % (th_, tw_, bn)
+        if dom[0] in S2_CFGS:
+            th_, tw_, bn = S2_CFGS[dom[0]]
+            return "conv3x3_s2_kernel", "%dx%d px x %d (stride 2, plane-resident patch),splitK=1" % (th_, tw_, bn)
         if dom[0] in PATCH_CFGS:
             th_, tw_, bn = PATCH_CFGS[dom[0]]
             fam = "conv3x3_pp3_kernel" if dom[0] >= 80 else "conv3x3_pp2_kernel" if dom[0] >= 70 else "conv3x3_pp_kernel" if dom[0] >= 50 else "conv3x3_patch_kernel"

@@ -93,6 +93,35 @@ import json; j = json.load(open('$R/gpurun_out/${TAG}_train.json')); print('trai
   cd $R
   lap trainprof
 fi
+if has s2test; then     # stride-2 patch kernel: parity, then the kernel beside the generic tiles on the three main-tower shapes
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "stride2_patch or transpose_stride2_patch" > gpurun_out/${TAG}_s2_tests.log 2>&1; echo "s2 tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_s2_tests.log | cut -c1-300 | tail -20
+  lap s2test
+fi
+if has s2bench; then
+  timeout 600 python scripts/s2_bench.py 2>&1 | tee gpurun_out/${TAG}_s2_bench.txt | cut -c1-250
+  lap s2bench
+fi
+if has retune; then     # new tile selections (stride-2 / transposed patch tiles eligible) for 512x256 AND the 2048x1024 companion, one cache; then a replay
+  rm -f gpurun_out/${TAG}_tune.json
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune.json timeout 1700 python bench.py --retune --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_bench_retune.json 2> gpurun_out/${TAG}_bench_retune.err; echo "retune rc=$?"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_bench_retune.json'))
+print('retune value', j['value'], j['ms_per_step'], j['timing']['windows_ms_per_step'], 'eager sum', j['roofline']['frame_ms_eager_events']); print(j['roofline']['kernel'], j['roofline']['frac'], j['roofline']['avg_launch_us'])
+print('frame tune', j['config'].get('frame_tune'))
+print('hires', j['hires']['value'], j['hires']['ms_per_step'], j['hires']['plan_build_s'], j['hires']['roofline']['slowest_configs_ms'])"
+  tail -3 gpurun_out/${TAG}_bench_retune.err | cut -c1-300
+  cp gpurun_out/${TAG}_tune.json /tmp/tune_new.json
+  for i in 1 2; do
+  V2V_TUNE_CACHE=/tmp/tune_new.json timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
+print('replay(new cache): 512x256', j['value'], 'fps', j['ms_per_step'], 'ms eager', j['roofline']['frame_ms_eager_events'], '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms eager', h['roofline']['frame_ms_eager_events'])"
+  timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
+print('replay(committed cache): 512x256', j['value'], 'fps', j['ms_per_step'], 'ms eager', j['roofline']['frame_ms_eager_events'], '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms eager', h['roofline']['frame_ms_eager_events'])"
+  done
+  lap retune
+fi
 if has rawab; then      # bf16 raw tensors on / off on ONE box: both resolutions + the bf16 error of the 512x256 frame
   for rb in 1 0 1 0; do
     V2V_RAW_BF16=$rb timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
@@ -131,4 +160,12 @@ if has dbg1; then
     env $envs timeout 300 python -m pytest tests/test_gpu_golden.py -m gpu -q --tb=line -k "inference_api_vs_reference or flownet2_vs_reference" 2>&1 | grep -E "passed|failed|Error|error" | cut -c1-250
   done
   lap dbg1
+fi
+if has kernarg; then    # where kernel arguments live: HIP_FORCE_DEV_KERNARG (device memory) on / off, same box
+  for ka in 1 0 1 0; do
+    HIP_FORCE_DEV_KERNARG=$ka timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
+print('HIP_FORCE_DEV_KERNARG=$ka: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms eager sum', j['roofline']['frame_ms_eager_events'], '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms')"
+  done | tee gpurun_out/${TAG}_kernarg_ab.txt
+  lap kernarg
 fi

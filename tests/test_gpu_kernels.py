@@ -169,6 +169,98 @@ def test_conv_raw_output_in_activation_dtype(shape):
         assert (y16 - y32).abs().max().item() <= 0.04 * max(y32.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("tile", [100, 101, 102, 103])
+@pytest.mark.parametrize("geom", [(64, 72, 37, 45, 2), (128, 200, 16, 64, 1), (192, 64, 9, 33, 1), (320, 136, 32, 32, 1)])
+def test_conv3x3_stride2_patch_kernel(geom, tile, prec):
+    """conv3x3_s2_kernel (round 4; tile ids 100-103): the 3x3 / stride 2 / zero-pad 1 Conv2d of the generators' down-sampling stages
+    (models/networks.py:136,147,156,176,248) on the plane-resident LDS patch.  Odd and even input sizes (every parity of the last
+    input row / column against the zero border), output tiles that overhang the image in both directions, 1 / 2 / 3 / 5 channel
+    chunks (even and odd counts: both register-set parities of the chunk loop, the single-chunk tail reloads), batch 2, cout ragged
+    against 64 and 128; raw fp32 output + statistics rows against torch, the activation-dtype epilogue, and bitwise equality with
+    itself on a second launch (no race in the single-buffered plane refill)."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, N = geom
+    bke = 64 if prec == "bf16" else 32
+    if cin % bke != 0:
+        pytest.skip("channel stride must be whole 128-byte chunks")
+    torch.manual_seed(tile + cin)
+    eng = _engine(prec)
+    conv = nn.Conv2d(cin, cout, 3, stride=2, padding=1)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.1); conv.bias.normal_(0, 0.5)
+    x = torch.randn(N, cin, H, W)
+    ref = F.conv2d(_round(x, prec), _round(conv.weight.detach(), prec), conv.bias.detach(), stride=2, padding=1)
+    eng.tile_override[(cin, cout, 3, 2, 0)] = (tile, 1, 0)
+    conv = conv.to(DEV)
+    xa = eng.pack(x.to(DEV))
+    with torch.no_grad():
+        raw, rows, (n_, OH, OW) = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+        assert eng.conv_log[-1]["tile"] == tile and (OH, OW) == tuple(ref.shape[2:])
+        cs = (cout + 3) // 4 * 4
+        got = raw[:n_ * OH * OW * cs].view(n_, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2).clone()
+        assert_close(got.cpu(), ref, 1e-4, "s2 tile %d %s" % (tile, str(geom)))
+        st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+        assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "stats sum")
+        assert_close(st[:, 1], (ref * ref).sum((0, 2, 3)), 1e-3, "stats sumsq")
+        raw2, _, _ = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+        assert torch.equal(raw2[:n_ * OH * OW * cs].view(n_, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2), got), "not reproducible"
+        out, _, _ = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_ACT_NHWC, L.ACT_LEAKY, 0.2)
+        assert_close(eng.unpack(out).cpu(), F.leaky_relu(ref, 0.2), 1e-4 if prec == "fp32" else 1e-2, "act")
+        # against the generic implicit-GEMM tile on the same operands: same products, fp32 accumulation in another order
+        eng.tile_override[(cin, cout, 3, 2, 0)] = (14, 1, 0)
+        raw3, _, _ = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+        assert_close(raw3[:n_ * OH * OW * cs].view(n_, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2).cpu(), got.cpu(), 2e-5, "vs generic tile")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("tile", [110, 111, 112, 113])
+@pytest.mark.parametrize("geom", [(64, 72, 19, 23, 2, 1), (128, 200, 16, 32, 1, 1), (192, 64, 9, 33, 1, 0), (320, 136, 16, 16, 1, 1)])
+def test_conv_transpose_stride2_patch_kernel(geom, tile, prec):
+    """conv3x3_t2_kernel (round 4; tile ids 110-113): ConvTranspose2d(3x3, stride 2, padding 1, output_padding 1 | 0) of the generators'
+    up-sampling stages (models/networks.py:170-176,254-260) with all four output-parity classes per workgroup on one LDS patch.
+    Output padding 0 (odd output size: the classes' grids differ) and 1, tiles that overhang the input in both directions, 1 / 2 / 3 /
+    5 channel chunks, batch 2, cout ragged against 64 and 128: raw fp32 output + the 4 x m_tiles statistics rows (and the in-kernel
+    finalize behind them) against torch, the activation-dtype epilogue, bitwise reproducibility, and the generic class-grid launch."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, N, op = geom
+    bke = 64 if prec == "bf16" else 32
+    if cin % bke != 0:
+        pytest.skip("channel stride must be whole 128-byte chunks")
+    torch.manual_seed(tile + cin)
+    eng = _engine(prec)
+    conv = nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=op)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.1); conv.bias.normal_(0, 0.5)
+    x = torch.randn(N, cin, H, W)
+    ref = F.conv_transpose2d(_round(x, prec), _round(conv.weight.detach(), prec), conv.bias.detach(), stride=2, padding=1, output_padding=op)
+    eng.tile_override[(cin, cout, 3, 2, 1)] = (tile, 1, 0)
+    conv = conv.to(DEV)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    ss = torch.zeros(4 * cout, device=DEV)
+    xa = eng.pack(x.to(DEV))
+    with torch.no_grad():
+        raw, rows, (n_, OH, OW) = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+        assert eng.conv_log[-1]["tile"] == tile and (OH, OW) == tuple(ref.shape[2:])
+        cs = (cout + 3) // 4 * 4
+        got = raw[:n_ * OH * OW * cs].view(n_, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2).clone()
+        assert_close(got.cpu(), ref, 1e-4, "t2 tile %d %s" % (tile, str(geom)))
+        st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+        assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "stats sum")
+        assert_close(st[:, 1], (ref * ref).sum((0, 2, 3)), 1e-3, "stats sumsq")
+        if eng.last_finalized:                                    # scale / shift / mean / invstd written by the last of the 4 m_tiles arrivals
+            mean = ref.mean((0, 2, 3)); var = ref.var((0, 2, 3), unbiased=False)
+            assert_close(ss[2 * cout:3 * cout].cpu(), mean, 1e-3, "finalize mean")
+            assert_close(ss[3 * cout:].cpu(), 1.0 / torch.sqrt(var + norm.eps), 1e-3, "finalize invstd")
+        raw2, _, _ = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+        assert torch.equal(raw2[:n_ * OH * OW * cs].view(n_, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2), got), "not reproducible"
+        out, _, _ = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_ACT_NHWC, L.ACT_LEAKY, 0.2)
+        assert_close(eng.unpack(out).cpu(), F.leaky_relu(ref, 0.2), 1e-4 if prec == "fp32" else 1e-2, "act")
+        eng.tile_override[(cin, cout, 3, 2, 1)] = (14, 1, 0)
+        raw3, _, _ = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+        assert_close(raw3[:n_ * OH * OW * cs].view(n_, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2).cpu(), got.cpu(), 2e-5, "vs generic tile")
+
+
 # (tile, splitk, prefetch): split-K slices that start mid-tap, the prefetch helper wave on 4- and 8-wave tiles,
 # large wave tiles; cin chosen so that both the uniform tap walk (cs % chunk == 0) and the per-lane walk run
 SPLITK_CFGS = [(2, 2, 0), (2, 3, 12), (3, 4, 12), (13, 2, 12), (13, 1, 12), (17, 3, 12), (1, 2, 0), (5, 4, 12), (7, 1, 4),

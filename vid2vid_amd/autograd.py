@@ -197,7 +197,7 @@ def _conv_backward_data(eng, cfg, conv, transposed, g, cout, x, N, OH, OW):
     d.transposed = int(pc.transposed)
     d.OH, d.OW = HO, WO
     d.dtype, d.out_mode, d.act, d.act_param, d.out_scale, d.tile = eng.dtype, L.OUT_ACT_NHWC, L.ACT_NONE, 0.0, 1.0, 0
-    eng.tune_backward_data(d, cfg.cin)
+    eng.tune_backward_data(d, cfg.cin, conv=conv, reflect=reflect)     # (also points d.w at the packing the selected tile reads)
     check(lib.v2v_conv2d(C.byref(d), _stream()), "conv backward-data " + cfg.label)
     eng.log_backward("bwd_data", cfg.label, conv, cfg.cin, cout, N, H * W if transposed else OH * OW)
     if not reflect:

@@ -44,6 +44,8 @@
 #include "conv3x3_pp_kernel.h"
 #include "conv3x3_pp2_kernel.h"
 #include "conv3x3_pp3_kernel.h"
+#include "conv3x3_s2_kernel.h"
+#include "conv3x3_t2_kernel.h"
 #include "conv7x7_head_kernel.h"
 #include <cstdarg>
 #include <cstring>
@@ -349,6 +351,10 @@ int launch_pp2_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp2_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp3_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp3_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
+int launch_s2_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
+int launch_s2_f32(int cfg, const ConvKArgs& k, hipStream_t s);
+int launch_t2_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
+int launch_t2_f32(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s);
 int launch_head_f32(const ConvKArgs& k, hipStream_t s);
 int launch_c8_bf16(const ConvKArgs& k, hipStream_t s);
@@ -374,6 +380,8 @@ struct ConvOp : Op {
     long long slab_bytes; int sk_tickets;
     int groups = 1;      // 2: grouped launch (v2v_conv2d_pair), second member's tensors in k.g1
     int launch(hipStream_t s) override {
+        if (cfg >= 110) return dtype == V2V_BF16 ? launch_t2_bf16(cfg, k, s) : launch_t2_f32(cfg, k, s);
+        if (cfg >= 100) return dtype == V2V_BF16 ? launch_s2_bf16(cfg, k, s) : launch_s2_f32(cfg, k, s);
         if (cfg >= 80) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, groups, s) : launch_pp3_f32(cfg, k, groups, s);
         if (cfg >= 70) return dtype == V2V_BF16 ? launch_pp2_bf16(cfg, k, groups, s) : launch_pp2_f32(cfg, k, groups, s);
         if (cfg == 61) return dtype == V2V_BF16 ? launch_c8_bf16(k, s) : launch_c8_f32(k, s);
@@ -532,6 +540,38 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.m_tiles = d->N * k.tiles_h * k.tiles_w;
         k.n_tiles = 1;
         tile_bm = 256; tile_bn = 4;
+    } else if (op->cfg >= 110) {
+        // conv3x3_t2_kernel: ConvTranspose2d(3x3, stride 2, padding 1), all four output-parity classes per workgroup, full-tap (korder 2) weights
+        const PatchCfg* pc = find_t2_cfg(op->cfg);
+        if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
+        if (!d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 ||
+            d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 2 || d->splitk > 1 || d->out_mode == V2V_OUT_NORM_ACT_NHWC ||
+            (long long)d->N * d->H * d->W * d->cin_stride * (d->dtype == V2V_BF16 ? 2 : 4) >= (1ll << 32)) {
+            set_error("conv: transposed stride-2 patch tile config %d needs a ConvTranspose2d(3x3, s2, p1), cin_stride %% %d == 0, korder-2 weights, no split-K",
+                      op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
+        }
+        k.tiles_h = (int)ceil_div((d->OH + 1) / 2, pc->TH);    // tiles of input positions (a, b): output pixels (2a + py, 2b + px)
+        k.tiles_w = (int)ceil_div((d->OW + 1) / 2, pc->TW);
+        k.m_tiles = d->N * k.tiles_h * k.tiles_w;
+        k.n_tiles = (int)ceil_div(d->cout, pc->BN);
+        k.woff[0] = 0; k.wrow[0] = 9 * d->cin_stride;          // the single full-tap matrix
+        k.fin_rows = 4 * k.m_tiles;                            // every workgroup publishes one statistics row per class
+        tile_bm = pc->TH * pc->TW; tile_bn = pc->BN;
+    } else if (op->cfg >= 100) {
+        // conv3x3_s2_kernel: 3x3 / stride 2 / pad 1 (zero) Conv2d, channel stride a multiple of the 128-byte chunk, korder-1 weights
+        const PatchCfg* pc = find_s2_cfg(op->cfg);
+        if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
+        if (d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->pad_mode != V2V_PAD_ZERO ||
+            d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 1 || d->splitk > 1 || d->out_mode == V2V_OUT_NORM_ACT_NHWC ||
+            (long long)d->N * d->H * d->W * d->cin_stride * (d->dtype == V2V_BF16 ? 2 : 4) >= (1ll << 32)) {
+            set_error("conv: stride-2 patch tile config %d needs a 3x3/s2/p1 zero-padded Conv2d, cin_stride %% %d == 0, korder-1 weights, no split-K",
+                      op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
+        }
+        k.tiles_h = (int)ceil_div(d->OH, pc->TH);
+        k.tiles_w = (int)ceil_div(d->OW, pc->TW);
+        k.m_tiles = d->N * k.tiles_h * k.tiles_w;
+        k.n_tiles = (int)ceil_div(d->cout, pc->BN);
+        tile_bm = pc->TH * pc->TW; tile_bn = pc->BN;
     } else if (op->cfg >= 32) {
         // conv3x3_patch_kernel: 3x3 / stride 1 / pad 1 Conv2d, channel stride a multiple of the 128-byte chunk,
         // weights packed channel-chunk outer (korder 1)
@@ -599,11 +639,25 @@ extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int
     if (!w || !dst) { set_error("pack: null pointer"); return V2V_EINVAL; }
     const int src_cl = (korder >> 8) & 1;                      // + 256: the source tensor is channels-last (see the header)
     korder &= 255;
-    if (korder != 0 && (korder != 1 || transposed || cin_stride % bke_of(dtype) != 0)) {
+    if (korder == 2) {
+        // full-tap packing of a ConvTranspose2d(3x3, stride 2) for conv3x3_t2_kernel: ONE matrix [cout_p][9 * cin_stride], channel-chunk
+        // outer, kernel tap ky * 3 + kx inner -- the korder-1 layout of a Conv2d, read from the [cin][cout][kh][kw] parameter.  Same
+        // element count as the four class matrices of korder 0 (1 + 2 + 2 + 4 = 9 taps).
+        if (!transposed || stride != 2 || KH != 3 || KW != 3 || cin_stride % bke_of(dtype) != 0) {
+            set_error("pack: korder 2 needs a ConvTranspose2d(3x3, stride 2) whose channel stride is a multiple of the 128-byte chunk"); return V2V_EINVAL;
+        }
+    } else if (korder != 0 && (korder != 1 || transposed || cin_stride % bke_of(dtype) != 0)) {
         set_error("pack: korder 1 needs a Conv2d whose channel stride is a multiple of the 128-byte chunk"); return V2V_EINVAL;
     }
     ConvGeom g;
     conv_geom(cin_stride, cout, KH, KW, transposed, stride, pad, dtype, &g);
+    if (korder == 2) {
+        g.ncls = 1; g.nkh[0] = 3; g.nkw[0] = 3; g.kh0[0] = 0; g.kw0[0] = 0;
+        g.ktot[0] = g.kpad[0] = g.wrow[0] = 9 * cin_stride; g.woff[0] = 0;
+        g.total = (long long)g.cout_p * g.wrow[0];
+        stride = 1;                                            // kstep: consecutive taps
+        korder = 1;                                            // destination order
+    }
     auto op = std::make_unique<PackOp>();
     PackArgs& a = op->a;
     a.w = w; a.dst = dst; a.cin = cin; a.cin_stride = cin_stride; a.cout = cout; a.cout_p = g.cout_p;

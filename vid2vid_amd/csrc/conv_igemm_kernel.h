@@ -56,6 +56,7 @@ struct ConvKArgs {
     unsigned div_m[4][2]; int div_l[4][2];
     int* status;         // host-mapped status word of the library (v2v_device_status) or NULL: bit 0 = a fused-norm barrier gave up
     ConvGroupPtrs g1;    // grouped launch (conv3x3_pp2_kernel): operands of block z == 1
+    int fin_rows;        // statistics rows (= finalize tickets) per channel tile when it is not gridDim.y * m_tiles (conv3x3_t2_kernel: 4 m_tiles), else 0
     unsigned long long* dbg;   // v2v_conv_debug_clocks: [workgroup][8] constant-rate (100 MHz) wall-clock stamps of the kernel's phases, or NULL
 };
 
@@ -301,7 +302,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             // 3. spin barrier of the workgroups that share this output-channel tile (all resident: host check)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const int total = (int)gridDim.y * p.m_tiles;
+            const int total = p.fin_rows > 0 ? p.fin_rows : (int)gridDim.y * p.m_tiles;
             int* const flag = reinterpret_cast<int*>(smem + 16384);
             if (tid == 0) {
                 int* const arrive = p.fin_counter + nt;
@@ -637,7 +638,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             __syncthreads();
             V2V_STAMP(p, 5);
             int* flag = reinterpret_cast<int*>(smem + 16384);
-            const int total = (int)gridDim.y * p.m_tiles;
+            const int total = p.fin_rows > 0 ? p.fin_rows : (int)gridDim.y * p.m_tiles;
             if (tid == 0) {
                 const int tk = __hip_atomic_fetch_add(p.fin_counter + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int last = tk == total - 1 ? 1 : 0;

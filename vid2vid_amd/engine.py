@@ -347,13 +347,23 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               86: (4, 32, 128), 87: (2, 64, 128),      # 86 / 87: four waves, 64 x 64 wave tiles
               90: (8, 32, 64), 91: (4, 64, 64),        # 90 / 91: 82 / 83 with K pairs (8 fragment reads per 8 MFMAs)
               92: (8, 32, 64), 93: (4, 64, 64)}        # 92 / 93: K quads (6 reads per 8 MFMAs)
+# stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
+S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
+# ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
+T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 64)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
 
 
 def is_patch_tile(t):
     """Tile ids of the LDS-patch 3x3 kernels (weights in K order 1): patch 32-48, ping-pong 50-57, ping-pong 2 70-79."""
-    return 32 <= t < 60 or 70 <= t < 94
+    return 32 <= t < 60 or 70 <= t < 94 or 100 <= t < 110
+
+
+def tile_korder(t):
+    """Weight packing a tile id reads: 0 tap-major class matrices (implicit-GEMM tiles, 7x7 kernels), 1 channel-chunk-major (patch
+    kernels, stride-2 patch kernel), 2 the full-tap chunk-major matrix of a transposed layer (conv3x3_t2_kernel, ids 110-119)."""
+    return 2 if 110 <= t < 120 else 1 if is_patch_tile(t) else 0
 FUSE_FINALIZE_MAX_PIXELS = 32768   # larger layers leave thousands of statistics rows: parallel two-stage finalize instead
 PREFETCH_DIST = 12          # K chunks (128 B of every weight row each) the helper wave runs ahead
 
@@ -690,8 +700,8 @@ class Engine:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
         if act_b is not None:
             d.tile, d.splitk, d.prefetch = 60, 1, 0          # per-channel epilogues exist in the 7x7 head kernel only
-        if is_patch_tile(d.tile):
-            pc = self._use_korder1(d, mod, x.Cs)
+        if tile_korder(d.tile):
+            pc = self._use_korder(d, mod, x.Cs, tile_korder(d.tile))
         elif self.plan is None:
             pc.refresh()               # eager use: follow optimizer updates (only the packing this launch reads)
         d.bias = None if pc.bias is None else pc.bias.data_ptr()      # of the packing in use (aliases the parameter)
@@ -756,7 +766,7 @@ class Engine:
             self._tune_wide[tune_key] = list(getattr(self, "_last_wide", []))
             self._save_tune_cache()
             d.tile, d.splitk, d.prefetch = self._tuned[tune_key]
-            pc = self._use_korder1(d, mod, x.Cs) if is_patch_tile(d.tile) else self._use_korder0(d, mod, x.Cs)
+            pc = self._use_korder(d, mod, x.Cs, tile_korder(d.tile))
             d.bias = None if pc.bias is None else pc.bias.data_ptr()
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
@@ -1089,7 +1099,7 @@ class Engine:
                                           adds_a=(xa, None), adds_b=(xb, None), labels=(na + ".c2", nb + ".c2"))
         return xa, xb
 
-    def tune_backward_data(self, d, dx_channels):
+    def tune_backward_data(self, d, dx_channels, conv=None, reflect=False):
         """Tile selection for a backward-data launch (autograd._conv_backward_data): same measured search as the
         forward convs (implicit-GEMM tiles x split-K; the operator is the forward kernel with role-swapped weights),
         keyed separately (leading -1) in the same tuning table.  Measured only while `autotune` is on (the first
@@ -1100,11 +1110,17 @@ class Engine:
                 d.tile, d.splitk, d.prefetch = 0, 0, 0
                 self._splitk_workspace(d)
                 return
-            self._tuned[key] = self._autotune(d, False, dx_channels)
+            # conv given: the patch kernels are candidates too -- backward-data of a stride-2 Conv2d is a transposed stride-2 convolution
+            # (conv3x3_t2_kernel), that of a ConvTranspose2d a stride-2 convolution (conv3x3_s2_kernel), on the role-swapped packings
+            self._tuned[key] = self._autotune(d, False, dx_channels, mod=conv, cin_stride=d.cin_stride, role="bwd", reflect=reflect)
             self._save_tune_cache()
         d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[key])
+        if conv is not None:
+            self._use_korder(d, conv, d.cin_stride, tile_korder(d.tile), role="bwd", reflect=reflect)
         if not self._splitk_workspace(d):
             d.tile, d.splitk, d.prefetch = 0, 0, 0
+            if conv is not None:
+                self._use_korder(d, conv, d.cin_stride, 0, role="bwd", reflect=reflect)
             self._splitk_workspace(d)
 
     def log_backward(self, kind, label, conv, cin, cout, N, pixels):
@@ -1134,6 +1150,11 @@ class Engine:
         d.w, d.w_korder = pc.buf.data_ptr(), 1
         return pc
 
+    def _use_korder(self, d, mod, cin_stride, korder, role="fwd", reflect=False):
+        pc = self.packed(mod, cin_stride, role=role, reflect=reflect, korder=korder)
+        d.w, d.w_korder = pc.buf.data_ptr(), korder
+        return pc
+
     def _use_korder0(self, d, mod, cin_stride):
         pc = self.packed(mod, cin_stride, korder=0)
         d.w, d.w_korder = pc.buf.data_ptr(), 0
@@ -1143,6 +1164,18 @@ class Engine:
         bke = 64 if self.dtype == L.BF16 else 32
         return (not d.transposed and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1
                 and d.cin_stride % bke == 0)
+
+    def s2_eligible(self, d):
+        """conv3x3_s2_kernel: 3x3 / stride 2 / zero pad 1 Conv2d whose channel stride is a whole 128-byte chunk."""
+        bke = 64 if self.dtype == L.BF16 else 32
+        return (not d.transposed and d.KH == 3 and d.KW == 3 and d.stride == 2 and d.pad == 1 and d.pad_mode == L.PAD_ZERO
+                and d.cin_stride % bke == 0 and d.out_mode != L.OUT_NORM_ACT_NHWC and os.environ.get("V2V_S2_PATCH", "1") != "0")
+
+    def t2_eligible(self, d):
+        """conv3x3_t2_kernel: ConvTranspose2d(3x3, stride 2, padding 1) whose channel stride is a whole 128-byte chunk."""
+        bke = 64 if self.dtype == L.BF16 else 32
+        return (bool(d.transposed) and d.KH == 3 and d.KW == 3 and d.stride == 2 and d.pad == 1
+                and d.cin_stride % bke == 0 and d.out_mode != L.OUT_NORM_ACT_NHWC and os.environ.get("V2V_T2_PATCH", "1") != "0")
 
     def _splitk_workspace(self, d):
         """Attach the split-K slab scratch and ticket words to a descriptor (no-op for splitk <= 1)."""
@@ -1165,7 +1198,7 @@ class Engine:
         self._keep(skc)
         return True
 
-    def _autotune(self, d, want_stats, cout, mod=None, cin_stride=0, reps=5):
+    def _autotune(self, d, want_stats, cout, mod=None, cin_stride=0, reps=5, role="fwd", reflect=False):
         """Time every (tile, split-K, weight-prefetch) configuration that fits this launch; returns the fastest
         triple.  Runs once per conv shape while a frame plan is being built, never inside a timed region.  Each
         timed launch is preceded by a 384 MB memset: at batch 1 a frame streams ~0.8 GB of weights, so every layer
@@ -1194,7 +1227,7 @@ class Engine:
                 and d.cin_stride * (2 if self.dtype == L.BF16 else 4) == 16 and not d.fin_counter
                 and (d.out_mode == L.OUT_F32_NCHW or d.out_mode == L.OUT_RAW_F32_NHWC)):
             cands.append((61, 1, 0))          # conv7x7_c8_kernel: 16-byte pixels (the 6-channel previous-frame stems), four taps per MFMA step
-        if mod is not None and self.patch_eligible(d):
+        if mod is not None and role == "fwd" and self.patch_eligible(d):
             ncc = d.cin_stride // (64 if self.dtype == L.BF16 else 32)
             for t, (th, tw, bn) in sorted(PATCH_CFGS.items()):
                 if tw == 64 and d.OW % 64 != 0 and d.OW > 32:
@@ -1206,13 +1239,23 @@ class Engine:
                     if S == 1 and tiles < 64:
                         continue
                     cands.append((t, S, 0))
+        if mod is not None and self.s2_eligible(d):
+            for t, (th, tw, bn) in sorted(S2_CFGS.items()):
+                tiles = d.N * -(-d.OH // th) * -(-d.OW // tw) * -(-cout // bn)
+                if tiles >= 64:
+                    cands.append((t, 1, 0))
+        if mod is not None and self.t2_eligible(d):
+            for t, (th, tw, bn) in sorted(T2_CFGS.items()):
+                tiles = d.N * -(-((d.OH + 1) // 2) // th) * -(-((d.OW + 1) // 2) // tw) * -(-cout // bn)
+                if tiles >= 48:
+                    cands.append((t, 1, 0))
         st = _stream()
         if self._thrash is None:
             self._thrash = torch.empty(96 << 20, dtype=torch.float32, device=self.device)
         def time_cfg(t, S, pf, reps):
             d.tile, d.splitk, d.prefetch = t, S, pf
             if mod is not None:
-                (self._use_korder1 if is_patch_tile(t) else self._use_korder0)(d, mod, cin_stride)
+                self._use_korder(d, mod, cin_stride, tile_korder(t), role=role, reflect=reflect)
             if want_stats:
                 rows = lib.v2v_conv_stats_rows(C.byref(d))
                 if rows <= 0:
