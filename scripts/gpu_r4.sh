@@ -122,6 +122,29 @@ print('replay(committed cache): 512x256', j['value'], 'fps', j['ms_per_step'], '
   done
   lap retune
 fi
+if has x3tune; then     # tile selections of the x3 plan (bf16 sub-engine, K tripled) measured on top of the committed cache, whole-frame search included
+  cp profiles/tune_cache.json /tmp/tune_x3.json
+  V2V_TUNE_CACHE=/tmp/tune_x3.json timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 > gpurun_out/${TAG}_bench_x3_tune.json 2> gpurun_out/${TAG}_bench_x3_tune.err; echo "x3 tune rc=$?"
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_bench_x3_tune.json')); print('x3 (tuning run)', j['value'], 'fps', j['ms_per_step'], 'ms', j['config'].get('frame_tune'))"
+  cp /tmp/tune_x3.json gpurun_out/${TAG}_tune_x3.json
+  for i in 1 2; do
+    V2V_TUNE_CACHE=/tmp/tune_x3.json timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); print('x3 replay(new cache)', j['value'], 'fps', j['ms_per_step'], 'ms launches', j['config']['launches_per_frame'])"
+  done
+  timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); print('x3 replay(committed cache + in-run search of the missing shapes)', j['value'], 'fps', j['ms_per_step'], 'ms')"
+  lap x3tune
+fi
+if has bwdpatch; then   # backward-data on the patch kernels: parity, then the training step with / without them (tile search of the first sequence each time)
+  timeout 900 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short -k "backward_data_on_the_patch or conv2d_backward or conv_transpose2d_backward" > gpurun_out/${TAG}_bwd_tests.log 2>&1; echo "bwd tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_bwd_tests.log | cut -c1-300 | tail -20
+  for pt in 1 0 1 0; do
+    V2V_S2_PATCH=$pt V2V_T2_PATCH=$pt timeout 600 python bench.py --mode train --steps 8 --warmup 2 --no-train-parity 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); print('patch kernels in the tile search = $pt: train', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', j['roofline']['frac'], 'autotune', j['config']['autotune_s'], 's')"
+  done | tee gpurun_out/${TAG}_train_patch_ab.txt
+  lap bwdpatch
+fi
 if has rawab; then      # bf16 raw tensors on / off on ONE box: both resolutions + the bf16 error of the 512x256 frame
   for rb in 1 0 1 0; do
     V2V_RAW_BF16=$rb timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "

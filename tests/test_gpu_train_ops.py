@@ -153,6 +153,52 @@ def test_conv_transpose2d_backward(case, prec, layout, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [("conv", 64, 128, 17, 29, 110), ("conv", 128, 64, 16, 32, 111), ("conv", 64, 192, 32, 32, 113),
+                                  ("convT", 128, 64, 9, 13, 100), ("convT", 64, 128, 16, 16, 101), ("convT", 192, 64, 8, 32, 103)])
+def test_backward_data_on_the_patch_kernels(case, prec):
+    """Round 4: backward-data of a stride-2 3x3 Conv2d IS a transposed stride-2 convolution of dY with the role-swapped weights ->
+    conv3x3_t2_kernel (korder-2 packing of role 'bwd'); backward-data of a ConvTranspose2d(3x3, s2) IS a stride-2 convolution of dY ->
+    conv3x3_s2_kernel (korder 1, role 'bwd').  The tile search of the training step may select them (Engine.tune_backward_data);
+    here they are forced and dX / dW / db are checked against CPU autograd, odd sizes included."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd import autograd as AG
+    kind, cin, cout, H, W, tile = case
+    bke = 64 if prec == "bf16" else 32
+    torch.manual_seed(cin + cout + tile)
+    eng = _engine(prec)
+    if kind == "conv":
+        conv = nn.Conv2d(cin, cout, 3, stride=2, padding=1)
+        cref = nn.Conv2d(cin, cout, 3, stride=2, padding=1)
+        eng.bwd_tile_override[(cout, cin, 3, 2, 1)] = (tile, 1, 0)          # dY (cout channels) -> dX (cin channels), transposed
+    else:
+        conv = nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1)
+        cref = nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1)
+        eng.bwd_tile_override[(cout, cin, 3, 2, 0)] = (tile, 1, 0)          # a stride-2 Conv2d of dY
+    if cout % bke != 0:
+        pytest.skip("dY channel stride must be whole 128-byte chunks")
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.2); conv.bias.normal_(0, 0.5)
+    rnd = (lambda t: t.bfloat16().float()) if prec == "bf16" else (lambda t: t.clone())
+    x = torch.randn(2, cin, H, W)
+    xr = rnd(x).requires_grad_(True)
+    with torch.no_grad():
+        cref.weight.copy_(rnd(conv.weight)); cref.bias.copy_(conv.bias)
+    yr = cref(xr)
+    r = rnd(torch.randn_like(yr))
+    (yr * r).sum().backward()
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    ya = AG.conv_group(eng, eng.pack(xg), conv, L.PAD_ZERO, None, None, L.ACT_NONE, 0.0, None, None, False, 1.0, "t")
+    y = eng.unpack(ya)
+    assert_close(y.detach().cpu(), yr.detach(), 1e-4 if prec == "fp32" else 1e-2, "forward " + str(case))
+    (y * r.to(DEV)).sum().backward()
+    assert any(c.get("kind") == "bwd_data" for c in eng.conv_log)
+    tol = 2e-4 if prec == "fp32" else 3e-2
+    assert_close(xg.grad.cpu(), xr.grad, tol, "dX " + str(case))
+    assert_close(conv.weight.grad.cpu(), cref.weight.grad, tol, "dW " + str(case))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("norm_kind", ["batch", "instance"])
 @pytest.mark.parametrize("act", ["relu", "leaky", "none"])
 def test_conv_norm_act_residual_backward(norm_kind, act, prec):

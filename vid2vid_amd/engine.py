@@ -445,6 +445,7 @@ class Engine:
                 self.tile_override[tuple(int(x) for x in k.split(","))] = tuple(int(x) for x in v.split(","))
         self.autotune = False    # measure the tile configurations once per conv shape (plan build time)
         self._tuned = {}         # (cin,cout,KH,stride,transposed,N,H,W,out_mode,Cs) -> (tile, splitk, prefetch)
+        self.bwd_tile_override = {}   # (dY channels, dX channels, KH, stride, transposed) of a backward-data operator -> tile (tests)
         self._tune_alts = {}     # same key -> runner-up configurations of the isolated search (this process only)
         self._tune_wide = {}     # same key -> the wider candidate list used for the heaviest shapes of a frame
         # optional persistent tuning cache (V2V_TUNE_CACHE=<json>): a profiling run can replay exactly the
@@ -1105,6 +1106,14 @@ class Engine:
         keyed separately (leading -1) in the same tuning table.  Measured only while `autotune` is on (the first
         training steps of bench.py --mode train); later steps replay the selection."""
         key = (-1, d.cin, d.cout, d.KH, d.stride, d.transposed, d.N, d.H, d.W, d.cin_stride, d.cout_stride, d.pad)
+        forced = self.bwd_tile_override.get((d.cin, d.cout, d.KH, d.stride, int(d.transposed)))
+        if forced is not None:                       # tests: a given tile for the backward-data operator (dY channels, dX channels, k, stride, transposed)
+            d.tile, d.splitk, d.prefetch = _cfg3(forced)
+            if conv is not None:
+                self._use_korder(d, conv, d.cin_stride, tile_korder(d.tile), role="bwd", reflect=reflect)
+            if not self._splitk_workspace(d):
+                raise RuntimeError("bwd_tile_override: split-K workspace")
+            return
         if key not in self._tuned:
             if not (self.autotune and self.plan is None and not self.record_only):
                 d.tile, d.splitk, d.prefetch = 0, 0, 0
