@@ -123,6 +123,25 @@ def test_conv2d_every_tile_config(tile, prec):
     assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "stats")
 
 
+def test_bf16_hardware_conversion_is_rne():
+    """Round 4: every fp32 -> bf16 store of the library goes through v_cvt_pk_bf16_f32 (csrc/v2v_internal.h, pack_bf16x2).  Checked
+    bit for bit against torch's round-to-nearest-even conversion on 2 M random BIT PATTERNS (every exponent, denormals, ties, values
+    that round up to infinity, +-0, +-inf); NaNs must stay NaNs."""
+    eng = _engine("bf16")
+    g = torch.Generator().manual_seed(5)
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, 8, 512, 512), generator=g, dtype=torch.int64).to(torch.int32)
+    ties = (torch.randint(0, 2 ** 16, (4096,), generator=g, dtype=torch.int64) << 16 | 0x8000).to(torch.int32)      # exactly half-way cases
+    bits.view(-1)[:4096] = ties
+    special = torch.tensor([0, -2 ** 31, 0x7f800000, -8388608, 0x7f7fffff, 0x7f7f8000, 0x00000001, 0x00008000, 0x00018000, 0x7f7f7fff], dtype=torch.int64).to(torch.int32)
+    bits.view(-1)[4096:4096 + special.numel()] = special
+    x = bits.view(torch.float32)
+    got = eng.pack(x.to(DEV)).t.permute(0, 3, 1, 2).contiguous().cpu()              # NHWC bf16 -> NCHW
+    want = x.bfloat16()
+    nan = torch.isnan(x)
+    assert torch.isnan(got.float()[nan]).all()
+    assert torch.equal(got.view(torch.int16)[~nan], want.view(torch.int16)[~nan]), "hardware bf16 conversion differs from round-to-nearest-even"
+
+
 @pytest.mark.parametrize("shape", [(72, 96, 3, 1, 1, 21, 37, 0), (128, 256, 3, 2, 1, 32, 48, 0), (64, 40, 3, 2, 1, 16, 24, 1), (256, 128, 3, 1, 1, 16, 32, 0)])
 def test_conv_raw_output_in_activation_dtype(shape):
     """V2V_OUT_RAW_ACT_NHWC (round 4): the pre-norm output of a bf16 convolution stored as bf16.  Against the fp32-raw launch of the

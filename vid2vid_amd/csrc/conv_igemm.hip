@@ -286,10 +286,10 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const PackArgs 
             const long long e = a.woff[cls] + (long long)co * wrow + k;
             if (a.dtype == V2V_BF16) {
                 uint4 pk;
-                pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-                pk.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
-                pk.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                pk.z = pack_bf16x2(v[4], v[5]);
+                pk.w = pack_bf16x2(v[6], v[7]);
                 *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.dst) + e) = pk;
             } else {
                 float* d = reinterpret_cast<float*>(a.dst) + e;

@@ -400,7 +400,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                     }
                     u32x4 pk;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (unsigned)f32_to_bf16_bits(o[2 * e]) | ((unsigned)f32_to_bf16_bits(o[2 * e + 1]) << 16);
+                    for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
                     *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + eo) = pk;
                 }
             }
@@ -550,7 +550,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                             typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
                             u32x4s pk;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) pk[e] = (unsigned)f32_to_bf16_bits(o[2 * e]) | ((unsigned)f32_to_bf16_bits(o[2 * e + 1]) << 16);
+                            for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
                             *reinterpret_cast<u32x4s*>(reinterpret_cast<unsigned short*>(out) + eo) = pk;
                         }
                     } else {

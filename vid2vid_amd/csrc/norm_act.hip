@@ -189,10 +189,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a_in) {
             }
         } else {
             uint4 pk;
-            pk.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
-            pk.z = (unsigned)f32_to_bf16_bits(o[4]) | ((unsigned)f32_to_bf16_bits(o[5]) << 16);
-            pk.w = (unsigned)f32_to_bf16_bits(o[6]) | ((unsigned)f32_to_bf16_bits(o[7]) << 16);
+            pk.x = pack_bf16x2(o[0], o[1]);
+            pk.y = pack_bf16x2(o[2], o[3]);
+            pk.z = pack_bf16x2(o[4], o[5]);
+            pk.w = pack_bf16x2(o[6], o[7]);
             *reinterpret_cast<uint4*>(y + e) = pk;
         }
     }
@@ -395,8 +395,8 @@ __device__ __forceinline__ void store4(float* p, const float v[4]) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
     uint2 t;
-    t.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-    t.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+    t.x = pack_bf16x2(v[0], v[1]);
+    t.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = t;
 }
 

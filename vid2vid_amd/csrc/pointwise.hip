@@ -78,10 +78,10 @@ __global__ __launch_bounds__(256) void encode_labels_kernel(const EncodeArgs a) 
             *reinterpret_cast<float4*>(out + e0) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
             uint4 pk;                                  // 0.0 / 1.0 are exact in bf16
-            pk.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
-            pk.z = (unsigned)f32_to_bf16_bits(o[4]) | ((unsigned)f32_to_bf16_bits(o[5]) << 16);
-            pk.w = (unsigned)f32_to_bf16_bits(o[6]) | ((unsigned)f32_to_bf16_bits(o[7]) << 16);
+            pk.x = pack_bf16x2(o[0], o[1]);
+            pk.y = pack_bf16x2(o[2], o[3]);
+            pk.z = pack_bf16x2(o[4], o[5]);
+            pk.w = pack_bf16x2(o[6], o[7]);
             *reinterpret_cast<uint4*>(out + e0) = pk;
         }
         if (a.mask && c0 == 0) {
@@ -176,10 +176,10 @@ __global__ __launch_bounds__(256) void encode_labels_pooled_kernel(const EncodeA
             *reinterpret_cast<float4*>(o) = make_float4(s[0] / fc, s[1] / fc, s[2] / fc, s[3] / fc);
         } else {
             uint4 pk;
-            pk.x = (unsigned)f32_to_bf16_bits(s[0] / fc) | ((unsigned)f32_to_bf16_bits(s[1] / fc) << 16);
-            pk.y = (unsigned)f32_to_bf16_bits(s[2] / fc) | ((unsigned)f32_to_bf16_bits(s[3] / fc) << 16);
-            pk.z = (unsigned)f32_to_bf16_bits(s[4] / fc) | ((unsigned)f32_to_bf16_bits(s[5] / fc) << 16);
-            pk.w = (unsigned)f32_to_bf16_bits(s[6] / fc) | ((unsigned)f32_to_bf16_bits(s[7] / fc) << 16);
+            pk.x = pack_bf16x2(s[0] / fc, s[1] / fc);
+            pk.y = pack_bf16x2(s[2] / fc, s[3] / fc);
+            pk.z = pack_bf16x2(s[4] / fc, s[5] / fc);
+            pk.w = pack_bf16x2(s[6] / fc, s[7] / fc);
             *reinterpret_cast<uint4*>(o) = pk;
         }
         if (a.mask && c0 == 0) {
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const PoolArgs a) {
             *reinterpret_cast<float4*>(o) = make_float4(s[0] / fc, s[1] / fc, s[2] / fc, s[3] / fc);
         } else {
             uint4 pk;
-            pk.x = (unsigned)f32_to_bf16_bits(s[0] / fc) | ((unsigned)f32_to_bf16_bits(s[1] / fc) << 16);
-            pk.y = (unsigned)f32_to_bf16_bits(s[2] / fc) | ((unsigned)f32_to_bf16_bits(s[3] / fc) << 16);
-            pk.z = (unsigned)f32_to_bf16_bits(s[4] / fc) | ((unsigned)f32_to_bf16_bits(s[5] / fc) << 16);
-            pk.w = (unsigned)f32_to_bf16_bits(s[6] / fc) | ((unsigned)f32_to_bf16_bits(s[7] / fc) << 16);
+            pk.x = pack_bf16x2(s[0] / fc, s[1] / fc);
+            pk.y = pack_bf16x2(s[2] / fc, s[3] / fc);
+            pk.z = pack_bf16x2(s[4] / fc, s[5] / fc);
+            pk.w = pack_bf16x2(s[6] / fc, s[7] / fc);
             *reinterpret_cast<uint4*>(o) = pk;
         }
     }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void add_kernel(const AddArgs p) {
             auto add2 = [](unsigned x, unsigned z) {
                 const float lo = bf16_bits_to_f32((unsigned short)(x & 0xffffu)) + bf16_bits_to_f32((unsigned short)(z & 0xffffu));
                 const float hi = bf16_bits_to_f32((unsigned short)(x >> 16)) + bf16_bits_to_f32((unsigned short)(z >> 16));
-                return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+                return pack_bf16x2(lo, hi);
             };
             uo.x = add2(ua.x, ub.x); uo.y = add2(ua.y, ub.y); uo.z = add2(ua.z, ub.z); uo.w = add2(ua.w, ub.w);
         }
