@@ -110,6 +110,12 @@ typedef struct v2v_conv_desc {
     int32_t act_b;          /* activation of channels >= act_split                                                */
     float   act_param_b;
     float   out_scale_b;
+    double* fin_workspace;  /* round 4, with fin_counter: NULL, or v2v_bn_finalize_groups(rows) * cout * 2 doubles.  Given, a layer with more than
+                             * 512 statistics rows is finalized IN the conv launch in two levels -- the last workgroup of each row group reduces
+                             * the group (the arithmetic of bn_partial_reduce), the last group finalizes (that of bn_finalize on the group
+                             * rows): bit for bit the v2v_bn_finalize result, two launches fewer.  fin_counter must then hold
+                             * 256 + groups * ceil(cout / 64) ints (zero before the first launch, re-armed in-kernel).  NULL: rows > 512 are
+                             * rejected for the in-kernel finalize as before (call v2v_bn_finalize).                                          */
 } v2v_conv_desc;
 
 /* Merged heads (tile 60, V2V_OUT_F32_NCHW, act_split > 0): model_final_flow (2 channels, no activation, x 20) and

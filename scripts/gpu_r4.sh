@@ -145,6 +145,16 @@ import sys, json; j = json.loads(sys.stdin.read()); print('patch kernels in the 
   done | tee gpurun_out/${TAG}_train_patch_ab.txt
   lap bwdpatch
 fi
+if has fin2; then       # two-level in-kernel finalize: parity, then both resolutions with / without it on one box
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "two_level_in_kernel" > gpurun_out/${TAG}_fin2_tests.log 2>&1; echo "fin2 tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_fin2_tests.log | cut -c1-300 | tail -20
+  for f2 in 1 0 1 0; do
+    V2V_FIN2=$f2 timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>gpurun_out/${TAG}_fin2_$f2.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']; k = h['roofline']['per_kernel_ms']
+print('V2V_FIN2=$f2: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms launches', j['config']['launches_per_frame'], '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms launches', h['launches_per_frame'], 'bn_finalize', k.get('bn_finalize'), 'bn_partial_reduce', k.get('bn_partial_reduce'), 'conv', k.get('conv_igemm'))"
+  done | tee gpurun_out/${TAG}_fin2_ab.txt
+  lap fin2
+fi
 if has rawab; then      # bf16 raw tensors on / off on ONE box: both resolutions + the bf16 error of the 512x256 frame
   for rb in 1 0 1 0; do
     V2V_RAW_BF16=$rb timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "

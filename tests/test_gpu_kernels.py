@@ -123,6 +123,46 @@ def test_conv2d_every_tile_config(tile, prec):
     assert_close(st[:, 0], ref.sum((0, 2, 3)), 1e-3, "stats")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [("conv", 32, 64, 3, 1, 256, 320, (10, 1, 0)), ("conv", 64, 32, 3, 1, 384, 512, (84, 1, 0)),
+                                  ("conv", 64, 64, 3, 2, 1024, 768, (100, 1, 0)), ("convT", 64, 32, 3, 2, 192, 256, (110, 1, 0)),
+                                  ("conv", 32, 24, 3, 1, 400, 300, (14, 2, 0))])
+def test_two_level_in_kernel_finalize_equals_bn_finalize(case, prec):
+    """Round 4: layers with more than 512 statistics rows finalize inside the conv launch in two levels (v2v_conv_desc.fin_workspace):
+    the last workgroup of each row group reduces its group, the last group writes the scale / shift record.  The record, the running
+    statistics and the normalised output must be BIT FOR BIT what conv + v2v_bn_finalize (bn_partial_reduce + bn_finalize) produce,
+    whichever workgroup happens to be last -- generic, single-phase 3x3, stride-2 and transposed patch tiles, a split-K launch."""
+    from vid2vid_amd import lib as L
+    kind, cin, cout, k, stride, H, W, cfg = case
+    bke = 64 if prec == "bf16" else 32
+    if cfg[0] >= 32 and cin % bke != 0:
+        pytest.skip("patch tiles need whole 128-byte chunks")
+    torch.manual_seed(cin * 7 + H)
+    eng = _engine(prec)
+    conv = (nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1) if kind == "convT"
+            else nn.Conv2d(cin, cout, k, stride=stride, padding=1)).to(DEV)
+    x = eng.pack(torch.randn(1, cin, H, W, device=DEV))
+    eng.tile_override[(cin, cout, k, stride, int(kind == "convT"))] = cfg
+    outs = []
+    with torch.no_grad():
+        for two in (True, False):
+            eng.fused_finalize2 = two
+            norm = nn.BatchNorm2d(cout).to(DEV)
+            with torch.no_grad():
+                norm.weight.copy_(torch.linspace(0.5, 1.5, cout)); norm.bias.copy_(torch.linspace(-0.2, 0.2, cout))
+            eng.update_running_stats = True
+            ss = torch.zeros(4 * cout, device=DEV)
+            for rep in range(2):                          # twice: the tickets re-arm themselves
+                raw, rows, shp = eng.conv(x, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+                assert rows > 512 and eng.conv_log[-1]["tile"] == cfg[0]
+                assert eng.last_finalized == two
+                y = eng.norm_apply(raw, rows, shp, cout, norm, L.ACT_RELU, 0.0, ss=ss, finalized=eng.last_finalized)
+            outs.append((ss.clone(), norm.running_mean.clone(), norm.running_var.clone(), y.t.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("scale/shift/mean/invstd", "running_mean", "running_var", "normalised output")):
+        assert torch.equal(a, b), "two-level in-kernel finalize differs from v2v_bn_finalize: " + what
+    assert float(outs[0][0][3 * cout:].min()) > 0                 # invstd finite and positive
+
+
 def test_bf16_hardware_conversion_is_rne():
     """Round 4: every fp32 -> bf16 store of the library goes through v_cvt_pk_bf16_f32 (csrc/v2v_internal.h, pack_bf16x2).  Checked
     bit for bit against torch's round-to-nearest-even conversion on 2 M random BIT PATTERNS (every exponent, denormals, ties, values

@@ -610,6 +610,15 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         if (launching && (!d->slabs || !d->sk_counter)) { set_error("conv: splitk needs slabs and sk_counter"); return V2V_EINVAL; }
         k.slabs = (float*)d->slabs; k.sk_counter = d->sk_counter;
     }
+    if (d->fin_counter && d->fin_workspace && d->out_mode != V2V_OUT_NORM_ACT_NHWC) {
+        // two-level in-kernel finalize for layers with more than 512 statistics rows (the arithmetic of v2v_bn_finalize's two stages)
+        const int rows = k.fin_rows > 0 ? k.fin_rows : g.ncls * k.m_tiles;
+        const int groups = rows > 512 ? (rows >= 64 * 128 ? 64 : (rows + 127) / 128) : 0;      // = v2v_bn_finalize_groups(rows)
+        if (groups > 0) {
+            if (k.n_tiles > 128) { set_error("conv: two-level finalize supports up to 128 channel tiles"); return V2V_EINVAL; }
+            k.fin_groups = groups; k.fin_ws = d->fin_workspace;
+        }
+    }
     k.ablate = d->ablate;
     k.dbg = g_conv_dbg_clocks;
     {

@@ -56,6 +56,7 @@ struct ConvKArgs {
     unsigned div_m[4][2]; int div_l[4][2];
     int* status;         // host-mapped status word of the library (v2v_device_status) or NULL: bit 0 = a fused-norm barrier gave up
     ConvGroupPtrs g1;    // grouped launch (conv3x3_pp2_kernel): operands of block z == 1
+    int fin_groups; double* fin_ws;   // two-level in-kernel finalize (rows > 512): row groups and their fp64 (sum, sum^2) rows [groups][cout][2], or 0 / NULL
     int fin_rows;        // statistics rows (= finalize tickets) per channel tile when it is not gridDim.y * m_tiles (conv3x3_t2_kernel: 4 m_tiles), else 0
     unsigned long long* dbg;   // v2v_conv_debug_clocks: [workgroup][8] constant-rate (100 MHz) wall-clock stamps of the kernel's phases, or NULL
 };
@@ -639,6 +640,110 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             V2V_STAMP(p, 5);
             int* flag = reinterpret_cast<int*>(smem + 16384);
             const int total = p.fin_rows > 0 ? p.fin_rows : (int)gridDim.y * p.m_tiles;
+            constexpr int NT = NW * 64;
+            if (p.fin_groups > 0) {
+                // ---- two levels (round 4): layers with more than 512 rows (the fine scales of 2048x1024: 2048-16384 rows) ----
+                // Level 1: the rows are cut into G groups exactly as v2v_bn_finalize cuts them (group g = rows [total g / G,
+                // total (g+1) / G)); the LAST workgroup of a group to publish its row reduces the group with the arithmetic of
+                // bn_partial_reduce_kernel (4 row phases per channel in fp64, combined ((p0+p1)+p2)+p3) into an fp64 row of fin_ws.
+                // Level 2: the last group to finish reduces the G group rows with the arithmetic of bn_finalize_kernel<double> and
+                // writes the scale / shift record.  Same bits as the two launches it replaces, whichever workgroup happens to be last.
+                const int G = p.fin_groups;
+                int g = (int)(((long long)stat_row * G) / total);
+                while ((int)(((long long)total * (g + 1)) / G) <= stat_row) ++g;
+                while ((int)(((long long)total * g) / G) > stat_row) --g;
+                const int r0 = (int)(((long long)total * g) / G), r1 = (int)(((long long)total * (g + 1)) / G);
+                if (tid == 0) {
+                    int* cnt = p.fin_counter + 256 + g * p.n_tiles + nt;
+                    const int tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = tk == (r1 - r0) - 1 ? 1 : 0;
+                    if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *flag = last;
+                }
+                __syncthreads();
+                if (!*flag) { V2V_STAMP(p, 6); return; }
+                __syncthreads();
+                double* const sh = reinterpret_cast<double*>(smem);          // [4][BN][2] fp64, <= 8 KiB
+                constexpr int CP = NT / 4 < BN ? NT / 4 : BN;                // channels per pass (4 row phases each)
+                for (int cb = 0; cb < BN; cb += CP) {
+                    const int cl = cb + tid % CP, ph = tid / CP;
+                    const int ncol = nt * BN + cl;
+                    if (tid < 4 * CP) {
+                        double s1 = 0.0, s2 = 0.0;
+                        if (ncol < p.cout) {
+                            const unsigned long long* const base = reinterpret_cast<const unsigned long long*>(p.stats) + ncol;
+#pragma unroll 8
+                            for (int r = r0 + ph; r < r1; r += 4) {
+                                const unsigned long long b = __hip_atomic_load(base + (long long)r * p.cout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                s1 += (double)__uint_as_float((unsigned)(b & 0xffffffffull));
+                                s2 += (double)__uint_as_float((unsigned)(b >> 32));
+                            }
+                        }
+                        sh[(ph * BN + cl) * 2 + 0] = s1;
+                        sh[(ph * BN + cl) * 2 + 1] = s2;
+                    }
+                    __syncthreads();
+                    if (tid < CP && ncol < p.cout) {
+                        const double t1 = ((sh[(0 * BN + cl) * 2] + sh[(1 * BN + cl) * 2]) + sh[(2 * BN + cl) * 2]) + sh[(3 * BN + cl) * 2];
+                        const double t2 = ((sh[(0 * BN + cl) * 2 + 1] + sh[(1 * BN + cl) * 2 + 1]) + sh[(2 * BN + cl) * 2 + 1]) + sh[(3 * BN + cl) * 2 + 1];
+                        unsigned long long* const dst = reinterpret_cast<unsigned long long*>(p.fin_ws + ((long long)g * p.cout + ncol) * 2);
+                        __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 1, (unsigned long long)__double_as_longlong(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __syncthreads();
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    const int tk = __hip_atomic_fetch_add(p.fin_counter + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = tk == G - 1 ? 1 : 0;
+                    if (last) __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *flag = last;
+                }
+                __syncthreads();
+                if (!*flag) { V2V_STAMP(p, 6); return; }
+                __syncthreads();
+                for (int cb = 0; cb < BN; cb += CP) {
+                    const int cl = cb + tid % CP, ph = tid / CP;
+                    const int ncol = nt * BN + cl;
+                    if (tid < 4 * CP) {
+                        double s1 = 0.0, s2 = 0.0;
+                        if (ncol < p.cout) {
+                            const unsigned long long* const base = reinterpret_cast<const unsigned long long*>(p.fin_ws) + (long long)ncol * 2;
+#pragma unroll 8
+                            for (int r = ph; r < G; r += 4) {
+                                const unsigned long long b1 = __hip_atomic_load(base + (long long)r * p.cout * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long b2 = __hip_atomic_load(base + (long long)r * p.cout * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                s1 += __longlong_as_double((long long)b1);
+                                s2 += __longlong_as_double((long long)b2);
+                            }
+                        }
+                        sh[(ph * BN + cl) * 2 + 0] = s1;
+                        sh[(ph * BN + cl) * 2 + 1] = s2;
+                    }
+                    __syncthreads();
+                    if (tid < CP && ncol < p.cout) {
+                        const double s1 = ((sh[(0 * BN + cl) * 2] + sh[(1 * BN + cl) * 2]) + sh[(2 * BN + cl) * 2]) + sh[(3 * BN + cl) * 2];
+                        const double s2 = ((sh[(0 * BN + cl) * 2 + 1] + sh[(1 * BN + cl) * 2 + 1]) + sh[(2 * BN + cl) * 2 + 1]) + sh[(3 * BN + cl) * 2 + 1];
+                        const double mean = s1 * p.fin_inv_count;
+                        double var = s2 * p.fin_inv_count - mean * mean;
+                        if (var < 0.0) var = 0.0;
+                        const double invstd = 1.0 / sqrt(var + (double)p.fin_eps);
+                        const double gm = p.fin_gamma ? (double)p.fin_gamma[ncol] : 1.0;
+                        const double bt = p.fin_beta ? (double)p.fin_beta[ncol] : 0.0;
+                        const double sc = gm * invstd;
+                        p.fin_out[ncol] = (float)sc;
+                        p.fin_out[p.cout + ncol] = (float)(bt - mean * sc);
+                        p.fin_out[2 * p.cout + ncol] = (float)mean;
+                        p.fin_out[3 * p.cout + ncol] = (float)invstd;
+                        if (p.fin_rmean) p.fin_rmean[ncol] = (1.f - p.fin_momentum) * p.fin_rmean[ncol] + p.fin_momentum * (float)mean;
+                        if (p.fin_rvar)  p.fin_rvar[ncol]  = (1.f - p.fin_momentum) * p.fin_rvar[ncol] + p.fin_momentum * (float)(var * p.fin_unbias);
+                    }
+                    __syncthreads();
+                }
+                V2V_STAMP(p, 6);
+                return;
+            }
             if (tid == 0) {
                 const int tk = __hip_atomic_fetch_add(p.fin_counter + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int last = tk == total - 1 ? 1 : 0;
@@ -647,7 +752,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             }
             __syncthreads();
             if (*flag) {
-                constexpr int NT = NW * 64, PH = NT / BN;
+                constexpr int PH = NT / BN;
                 double* acc2 = reinterpret_cast<double*>(smem);      // [PH][BN][2], <= 8 KiB
                 const int c = tid % BN, ph = tid / BN;
                 const int ncol = nt * BN + c;

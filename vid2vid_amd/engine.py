@@ -460,6 +460,12 @@ class Engine:
                 pass
         self.update_running_stats = False
         self.fused_finalize = True   # norm statistics finalized by the conv kernel's last workgroup (small layers)
+        # round 4, V2V_FIN2=1: layers with more than 512 statistics rows (> 32768 output pixels) finalize in the conv launch too, in
+        # two levels (v2v_conv_desc.fin_workspace; bit for bit v2v_bn_finalize: test_two_level_in_kernel_finalize_equals_bn_finalize).
+        # Built, tested, measured on one box (profiles/r04_b7_fin2_ab.txt): 66 launches fewer per 2048x1024 frame (355 -> 289), the
+        # two finalize kernels -0.45 ms, but every workgroup of those thousand-tile launches now drains its stores and takes a ticket
+        # before it exits: conv +1.0 ms -- 83.1 -> 80.3 frames/s (512x256: 372 -> 367).  OFF by default.
+        self.fused_finalize2 = bool(int(os.environ.get("V2V_FIN2", "0")))
         self.last_finalized = False  # did the last conv() finalize its statistics in-kernel?
         self.ablate = 0              # profiling ablations (scripts/conv_ablate.py); results are wrong when set
 
@@ -633,7 +639,7 @@ class Engine:
             key = (self._lane, self._sset)
             fin_counter = self._fin_counters.get(key)
             if fin_counter is None:
-                fin_counter = self._fin_counters[key] = torch.zeros(512, dtype=torch.int32, device=self.device)
+                fin_counter = self._fin_counters[key] = torch.zeros(256 + 64 * 128, dtype=torch.int32, device=self.device)
             fn = L.OneHotNorm()
             fn.counter = fin_counter.data_ptr() + 4 * 256              # words 256..: clear of the conv kernels' per-tile tickets (0..255)
             fn.gamma = None if gamma is None else gamma.data_ptr()
@@ -739,7 +745,10 @@ class Engine:
                 check(rows or -1, "conv_stats_rows")
             st = self.scratch("stats", rows * pc.cout * 2)
             d.stats = st.data_ptr()
-            if fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS:
+            # (not for the 7x7 layers: their halo-patch tiles 60 / 61 have no in-kernel finalize and must stay eligible)
+            two_level = bool(fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS and self.fused_finalize2 and rows > 512
+                             and pc.KH != 7 and d.tile not in (60, 61))
+            if fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS and not two_level:
                 fin = None             # one workgroup walking >1000 rows costs 0.1-1 ms (profiles/r01_v15_finalize_tail.txt)
             self.last_finalized = fin is not None
             if fin is not None:
@@ -747,7 +756,8 @@ class Engine:
                 gamma, beta, eps, mom, rm, rv = self._norm_params(norm, N)
                 fin_counter = self._fin_counters.get((self._lane, self._sset))
                 if fin_counter is None:
-                    fin_counter = self._fin_counters[(self._lane, self._sset)] = torch.zeros(512, dtype=torch.int32, device=self.device)
+                    # [0,128) finalize tickets per channel tile, [128,256) fused-norm departures, [256, 256 + 64 * 128) row-group tickets
+                    fin_counter = self._fin_counters[(self._lane, self._sset)] = torch.zeros(256 + 64 * 128, dtype=torch.int32, device=self.device)
                 d.fin_counter = fin_counter.data_ptr()
                 d.fin_gamma = None if gamma is None else gamma.data_ptr()
                 d.fin_beta = None if beta is None else beta.data_ptr()
@@ -755,6 +765,9 @@ class Engine:
                 d.fin_running_mean = None if rm is None else rm.data_ptr()
                 d.fin_running_var = None if rv is None else rv.data_ptr()
                 d.fin_eps, d.fin_momentum, d.fin_count = eps, mom, N * OH * OW
+                if two_level:          # round 4: large layers finalize inside the conv launch in two levels (no bn_partial_reduce / bn_finalize launches)
+                    ws = self.scratch("bn_ws", 64 * pc.cout * 2, torch.float64)
+                    d.fin_workspace = ws.data_ptr()
                 for t in (gamma, beta, ss, fin_counter):
                     if t is not None:
                         self._keep(t)
@@ -845,7 +858,7 @@ class Engine:
             key = (self._lane, self._sset)
             fin_counter = self._fin_counters.get(key)
             if fin_counter is None:
-                fin_counter = self._fin_counters[key] = torch.zeros(512, dtype=torch.int32, device=self.device)
+                fin_counter = self._fin_counters[key] = torch.zeros(256 + 64 * 128, dtype=torch.int32, device=self.device)
             d.fin_counter = fin_counter.data_ptr()
             d.fin_gamma = None if gamma is None else gamma.data_ptr()
             d.fin_beta = None if beta is None else beta.data_ptr()

@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("w_korder", C.c_int32), ("ablate", C.c_int32),
         ("res0", C.c_void_p), ("res1", C.c_void_p),
         ("act_split", C.c_int32), ("act_b", C.c_int32), ("act_param_b", C.c_float), ("out_scale_b", C.c_float),
+        ("fin_workspace", C.c_void_p),
     ]
 
 
