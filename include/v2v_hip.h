@@ -110,14 +110,14 @@ typedef struct v2v_conv_desc {
     int32_t act_b;          /* activation of channels >= act_split                                                */
     float   act_param_b;
     float   out_scale_b;
-    double* fin_workspace;  /* round 4, with fin_counter: NULL, or v2v_bn_finalize_groups(rows) * cout * 2 doubles.  Given, a layer with more than
-                             * 512 statistics rows is finalized IN the conv launch in two levels -- the last workgroup of each row group reduces
-                             * the group (the arithmetic of bn_partial_reduce), the last group finalizes (that of bn_finalize on the group
-                             * rows): bit for bit the v2v_bn_finalize result, two launches fewer.  fin_counter must then hold
-                             * 256 + groups * ceil(cout / 64) ints (zero before the first launch, re-armed in-kernel).  NULL: rows > 512 are
-                             * rejected for the in-kernel finalize as before (call v2v_bn_finalize).                                          */
+    double* fin_workspace;  /* round 4, with fin_counter: NULL, or v2v_bn_finalize_groups(rows) * cout * 2 doubles -> layers with more than 512 statistics rows finalize IN the launch in two levels (see "two-level finalize" below) */
 } v2v_conv_desc;
 
+/* Two-level finalize (fin_counter + fin_workspace, more than 512 statistics rows): the last workgroup of each row group reduces the
+ * group (the arithmetic of bn_partial_reduce), the last group finalizes (that of bn_finalize on the group rows): bit for bit the
+ * v2v_bn_finalize result, two launches fewer.  fin_counter must then hold 256 + groups * ceil(cout / 64) ints (zero before the first
+ * launch, re-armed in-kernel).  fin_workspace == NULL: such layers are not finalized in-kernel (call v2v_bn_finalize).  Measured
+ * slower than the two separate launches for thousand-tile layers: the Python engine leaves it off (V2V_FIN2=1 enables). */
 /* Merged heads (tile 60, V2V_OUT_F32_NCHW, act_split > 0): model_final_flow (2 channels, no activation, x 20) and
  * model_final_w (1 channel, sigmoid) read the same tensor (models/networks.py:181-183, 224-226); with their weights
  * concatenated along cout they are one launch whose channels >= act_split use act_b / act_param_b / out_scale_b. */
