@@ -202,3 +202,17 @@ print('HIP_FORCE_DEV_KERNARG=$ka: 512x256', j['value'], 'fps', j['ms_per_step'],
   done | tee gpurun_out/${TAG}_kernarg_ab.txt
   lap kernarg
 fi
+if has coresident; then  # can the foreground tower run UNDER the paired launches?  pairs on a 128 KiB tile, the tower's 512->512 convolutions on the 32 KiB generic tile
+  run() { env "$@" timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-hires 2>/dev/null | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); r = j['roofline']
+print('$*:', j['value'], 'fps', j['ms_per_step'], 'ms eager sum', r['frame_ms_eager_events'], '| dominant', r['kernel'][:60], 'in-graph live', (r.get('in_graph_live') or {}).get('avg_launch_us'), 'eager', r['eager']['avg_launch_us'])"; }
+  for rep in 1 2; do
+    run X=base
+    run V2V_PAIR_TILE=80,1
+    run V2V_PAIR_TILE=94,1
+    run V2V_PAIR_TILE=80,1 "V2V_TILE_OVERRIDE=512,512,3,1,0:10,1,0"
+    run V2V_PAIR_TILE=94,1 "V2V_TILE_OVERRIDE=512,512,3,1,0:10,1,0"
+    run "V2V_TILE_OVERRIDE=512,512,3,1,0:10,1,0"
+  done | tee gpurun_out/${TAG}_coresident_ab.txt
+  lap coresident
+fi

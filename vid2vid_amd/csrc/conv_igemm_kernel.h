@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
 // ---- conv launch ------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WGM, int WGN, int NS, bool HELPER>
 static int launch_cfg(const ConvKArgs& k, int ncls, hipStream_t s) {
-    const size_t lds = (size_t)NS * (BM + BN) * 128 + 256;    // + the prefetch wave's dummy LDS line
+    const size_t lds = (size_t)NS * (BM + BN) * 128 + (HELPER ? 256 : 0);    // + the prefetch wave's dummy LDS line (round 4: only where that wave exists -- tile 10 is then exactly 32 KiB and fits beside a 128 KiB single-phase workgroup on one CU)
     auto kern = conv_igemm_kernel<T, BM, BN, WGM, WGN, NS, HELPER>;
     static bool attr_done = false;
     if (!attr_done) {
