@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--min-warmup-s", type=float, default=0.5, help="warm up for at least this long (and at least --warmup frames) before the first window")
     ap.add_argument("--no-hires", action="store_true", help="infer: skip the 2048x1024 / 3-scale companion run reported under \"hires\"")
     ap.add_argument("--no-train-parity", action="store_true", help="train: skip the fp32 chunk-vs-oracle parity leg (outputs, losses, gradient norms)")
+    ap.add_argument("--no-c4", action="store_true", help="infer: skip the BASELINE configs[3] leg (edge2face 512x512) reported under \"c4\"")
+    ap.add_argument("--no-train-c3", action="store_true", help="infer: skip the BASELINE configs[2] geometry training leg (1024x512, 2 scales) reported under \"train_c3\"")
     ap.add_argument("--no-c1", action="store_true", help="infer: skip the literal BASELINE configs[0] leg (256x128 2-frame clip, GPU vs CPU oracle) reported under \"c1\"")
     ap.add_argument("--no-train-hires", action="store_true", help="infer: skip the 2048x1024 / 3-scale training chunk (configs[4] geometry on one GPU) reported under \"train_hires\"")
     ap.add_argument("--no-train-hires-parity", action="store_true", help="infer: time the 2048x1024 training chunk but skip its CPU-oracle parity (minutes of host time)")
@@ -970,18 +972,25 @@ def main():
             torch.cuda.empty_cache()
         return line
 
-    def c1_clip():
+    def c1_clip(c4=False):
         """BASELINE configs[0] literally: label2city 256x128, n_scales_spatial=1, a 2-frame clip (two generated frames behind
         the tG-1 given real frames; the reference's --use_single_G nets exist only for loadSize 512 / 1024 / 2048),
         full width (ngf 128, 9 blocks, --fg --use_instance).  The CPU oracle generates the clip (timed: the `cpu_baseline` of
         THIS config), the fp32 and x3 paths are gated against it per pixel at 1e-3 on every head, and the clip is timed on
-        the GPU in the benchmarked dtype (sequence reset + first-frame pyramid + 2 frames per clip)."""
+        the GPU in the benchmarked dtype (sequence reset + first-frame pyramid + 2 frames per clip).
+        c4=True: BASELINE configs[3] instead (edge2face 512x512: 15 raw input maps per frame, no instance map, no fg tower,
+        scripts/face/test_512.sh) -- the same two oracle-checked frames, and the throughput of a RUNNING sequence (steady
+        state, no reset per clip) since that config's metric is frames of inference()."""
         from oracle import vid2vid_oracle as O
-        Hc, Wc, nfc = 128, 256, 2
+        Hc, Wc, nfc = (512, 512, 2) if c4 else (128, 256, 2)
 
         def build_c(precision):
-            o = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True, loadSize=Wc,
-                         precision=precision, gpu_ids=[local_rank], n_scales_spatial=1)
+            if c4:
+                o = make_opt(label_nc=0, input_nc=15, use_instance=False, fg=False, use_real_img=True, random_init_ok=True,
+                             dataroot="datasets/face/", loadSize=Wc, precision=precision, gpu_ids=[local_rank], n_scales_spatial=1)
+            else:
+                o = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True, loadSize=Wc,
+                             precision=precision, gpu_ids=[local_rank], n_scales_spatial=1)
             o.use_graph = not args.no_graph
             o.frame_tune = 0                         # a side figure: per-shape tile search only
             torch.manual_seed(0)
@@ -990,27 +999,46 @@ def main():
                 m.netG0.model_final_flow[1].weight.mul_(0.1)
             return o, m
         oc, mc = build_c(args.precision)
-        lab_c, inst_c, fr_c = synthetic.label2city_sequence(nfc + tG - 1, Hc, Wc, seed=1234, device=dev)
-        Ac, Ic = lab_c.view(1, -1, 1, Hc, Wc), inst_c.view(1, -1, 1, Hc, Wc)
+        if c4:
+            Ac, fr_c = synthetic.edge2face_sequence(nfc + tG - 1 + 14, Hc, Wc, seed=1234, device=dev)
+            Ic = None
+        else:
+            lab_c, inst_c, fr_c = synthetic.label2city_sequence(nfc + tG - 1, Hc, Wc, seed=1234, device=dev)
+            Ac, Ic = lab_c.view(1, -1, 1, Hc, Wc), inst_c.view(1, -1, 1, Hc, Wc)
+
+        def step_c(m, t, k=None):
+            k = t if k is None else k
+            return m.inference(Ac[:, k:k + tG], fr_c[:, :tG - 1] if t == 0 else None, None if Ic is None else Ic[:, k:k + tG])
 
         def clip(m):
             m.fake_B_prev = None
-            outs = []
-            for t in range(nfc):
-                fake, _ = m.inference(Ac[:, t:t + tG], fr_c[:, :tG - 1] if t == 0 else None, Ic[:, t:t + tG])
-                outs.append(fake)
-            return outs
+            return [step_c(m, t)[0] for t in range(nfc)]
         clip(mc); clip(mc)
         torch.cuda.synchronize(dev)
-        ncl = 20
-        t0 = time.perf_counter()
-        for _ in range(ncl):
-            clip(mc)
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
+        if c4:                                        # a running sequence, the resident maps cycled: frames of inference() per second
+            ncl, nrun = 1, 40
+            for t in range(2, 10):
+                step_c(mc, t, t % 14)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for t in range(10, 10 + nrun):
+                step_c(mc, t, t % 14)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+        else:
+            ncl = 20
+            t0 = time.perf_counter()
+            for _ in range(ncl):
+                clip(mc)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
         sd = {k: v.detach().float().cpu() for k, v in mc.netG0.state_dict().items()}
-        orc = O.InferenceOracle([sd], 35, True, True, [26], oc.n_downsample_G, oc.n_blocks, oc.n_blocks_local)
-        lcc, icc, fcc = lab_c.cpu(), inst_c.cpu(), fr_c.cpu()
+        if c4:
+            orc = O.InferenceOracle([sd], 0, False, False, [], oc.n_downsample_G, oc.n_blocks, oc.n_blocks_local)
+            acc, fcc = Ac.cpu(), fr_c.cpu()
+        else:
+            orc = O.InferenceOracle([sd], 35, True, True, [26], oc.n_downsample_G, oc.n_blocks, oc.n_blocks_local)
+            lcc, icc, fcc = lab_c.cpu(), inst_c.cpu(), fr_c.cpu()
         refs_c, prevs_c, cpu_s = [], [], None
         for rep in range(2):                          # the clip twice: the second run is the timed one (warm allocator / threads)
             orc.fake_B_prev = None
@@ -1018,7 +1046,10 @@ def main():
             c0 = time.perf_counter()
             for t in range(nfc):
                 prevs_c.append(None if orc.fake_B_prev is None else [q.clone() for q in orc.fake_B_prev])
-                f_, _ = orc.step(lcc[t:t + tG].view(1, tG, 1, Hc, Wc), fcc[:, :tG - 1] if t == 0 else None, icc[t:t + tG].view(1, tG, 1, Hc, Wc))
+                if c4:
+                    f_, _ = orc.step(acc[:, t:t + tG], fcc[:, :tG - 1] if t == 0 else None, None)
+                else:
+                    f_, _ = orc.step(lcc[t:t + tG].view(1, tG, 1, Hc, Wc), fcc[:, :tG - 1] if t == 0 else None, icc[t:t + tG].view(1, tG, 1, Hc, Wc))
                 refs_c.append(dict(fake_B=f_.clone(), raw=orc.last["raw0"].clone(), flow=orc.last["flow0"].clone(), weight=orc.last["weight0"].clone()))
             cpu_s = time.perf_counter() - c0
 
@@ -1028,7 +1059,7 @@ def main():
             for t in range(nfc):
                 if t > 0:
                     m._active_plan.prev[0].copy_(prevs_c[t][0])
-                fake, _ = m.inference(Ac[:, t:t + tG], fr_c[:, :tG - 1] if t == 0 else None, Ic[:, t:t + tG])
+                fake, _ = step_c(m, t)
                 fpm = m._active_plan
                 got = dict(fake_B=fake, raw=fpm.out["raw0"], flow=fpm.out["flow0"], weight=fpm.out["weight0"])
                 for k, r in refs_c[t].items():
@@ -1054,13 +1085,21 @@ def main():
         par["x3_max_rel"] = max(v["max_rel"] for v in par["x3"].values())
         par["fp32_ok"] = bool(par["fp32_max_rel"] <= 1e-3 and all(v["finite"] for v in par["fp32"].values()))
         par["x3_ok"] = bool(par["x3_max_rel"] <= 1e-3 and all(v["finite"] for v in par["x3"].values()))
+        cpu_line = {"value": round(nfc / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": "the same %d-frame clip (second of two runs), fp32, oracle/vid2vid_oracle.py; clip %.2f s" % (nfc, cpu_s)}
+        if c4:
+            return {"workload": "BASELINE configs[3]: edge2face %dx%d, input_nc=15 (45 generator input channels), no instance map, no fg tower, "
+                                "n_scales_spatial=1, ngf=128 n_blocks=9 (%.1fM params random-init), batch 1, maps resident in HBM"
+                                % (Wc, Hc, sum(q.numel() for q in mc.parameters()) / 1e6),
+                    "metric": "synthesized frames/sec (Vid2VidModelG.inference, %dx%d edge2face)" % (Wc, Hc),
+                    "value": round(nrun / el, 3), "unit": "frames/s", "ms_per_step": round(el / nrun * 1e3, 4), "steps": nrun, "dtype": args.precision,
+                    "note": "running sequence (no reset), per-shape tile selection only; parity: the first %d frames vs the CPU oracle" % nfc,
+                    "parity": par, "cpu_baseline": cpu_line}
         return {"workload": "BASELINE configs[0]: label2city %dx%d, n_scales_spatial=1, %d-frame clip from %d given real frames (--use_real_img), "
                             "--fg --use_instance, ngf=128 n_blocks=9" % (Wc, Hc, nfc, tG - 1),
                 "value": round(ncl * nfc / el, 3), "unit": "frames/s", "ms_per_clip": round(el / ncl * 1e3, 3), "clips": ncl, "dtype": args.precision,
                 "note": "every clip resets the sequence (first-frame pyramid from the real frames) and generates %d frames" % nfc,
-                "parity": par,
-                "cpu_baseline": {"value": round(nfc / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                                 "sample": "the same %d-frame clip (second of two runs), fp32, oracle/vid2vid_oracle.py; clip %.2f s" % (nfc, cpu_s)}}
+                "parity": par, "cpu_baseline": cpu_line}
 
     sys.stdout = _stdout
     if rank == 0:
@@ -1122,6 +1161,19 @@ def main():
                 out["c1"] = {"error": repr(ex)[:400]}
             finally:
                 sys.stdout = _stdout
+        # ---- BASELINE configs[3]: edge2face 512x512 (two oracle-checked frames, steady-state frames/s) ----
+        if world == 1 and do_cpu and not args.no_c4 and not face and args.scales == 1 and (W, H) == (512, 256):
+            sys.stdout = sys.stderr
+            try:
+                model = fp = None
+                torch.cuda.empty_cache()
+                out["c4"] = c1_clip(c4=True)
+            except Exception as ex:
+                import traceback
+                traceback.print_exc()
+                out["c4"] = {"error": repr(ex)[:400]}
+            finally:
+                sys.stdout = _stdout
         # ---- companion figure: the training step (train.py inner loop) on the same geometry, a short run ----
         import argparse
 
@@ -1157,6 +1209,11 @@ def main():
             model = None
             train_companion("train_hires", width=2048, height=1024, scales=3, num_D=4, frames_total=6, frames_per_gpu=1,
                             no_train_parity=bool(args.no_train_hires_parity or args.no_cpu_baseline), no_bf16_train_parity=True)
+        # ---- BASELINE configs[2] geometry as a training chunk on one GPU (1024x512, n_scales_spatial=2, num_D=3): frames trained/s only --
+        # its fp32 chunk-vs-oracle parity is tests/test_gpu_golden.py::test_full_width_training_chunk_1024x512_s2_vs_oracle ----
+        if world == 1 and not args.no_train_c3 and not face and args.scales == 1 and (W, H) == (512, 256):
+            model = None
+            train_companion("train_c3", width=1024, height=512, scales=2, num_D=3, frames_total=6, frames_per_gpu=2, no_train_parity=True)
         # ---- flat scalars ahead of the nested objects: the figures that carry north_star's 1e-3 parity and the second resolution ----
         flat = {}
         if x3_line and "value" in x3_line:
@@ -1166,7 +1223,8 @@ def main():
             flat.update(fp32_value=fp32_line["value"], fp32_max_rel=None if parity is None else parity["fp32_max_rel"])
         if parity is not None:
             flat.update(value_max_rel=parity.get("bf16_max_rel"), value_mean_rel=parity.get("bf16_mean_rel"))
-        for key, name in (("hires", "hires_value"), ("train", "train_value"), ("train_hires", "train_hires_value"), ("c1", "c1_value")):
+        for key, name in (("hires", "hires_value"), ("train", "train_value"), ("train_hires", "train_hires_value"), ("train_c3", "train_c3_value"),
+                          ("c1", "c1_value"), ("c4", "c4_value")):
             if isinstance(out.get(key), dict) and "value" in out[key]:
                 flat[name] = out[key]["value"]
         if isinstance(out.get("train_hires"), dict) and isinstance(out["train_hires"].get("parity"), dict):

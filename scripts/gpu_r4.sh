@@ -31,13 +31,32 @@ PY
   tail -5 gpurun_out/${TAG}_bench_default.err | cut -c1-300
   lap benchdefault
 fi
+if has fillcache; then   # configs[2] / configs[3] legs of the default line: their shapes enter the tile cache (copied to profiles/tune_cache.json afterwards)
+  cp profiles/tune_cache.json gpurun_out/${TAG}_tune.json
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune.json timeout 1200 python bench.py --no-hires --no-train-line --no-train-hires --no-c1 > gpurun_out/${TAG}_bench_c3c4.json 2> gpurun_out/${TAG}_bench_c3c4.err; echo "fillcache rc=$?"
+  python - <<PY
+import json
+j = json.load(open("gpurun_out/${TAG}_bench_c3c4.json"))
+print({k: v for k, v in j.items() if not isinstance(v, (dict, list))})
+for k in ("c4", "train_c3"):
+    print(k, json.dumps(j.get(k))[:3000])
+PY
+  tail -5 gpurun_out/${TAG}_bench_c3c4.err | cut -c1-300
+  lap fillcache
+fi
+if has c3test; then     # the 3-frame C3 training chunk (teacher-forced) + the role split with real networks
+  timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short --timeout 1400 -s --durations=5 \
+      -k "training_chunk_1024x512 or role_split_with_real" > gpurun_out/${TAG}_c3test.log 2>&1; echo "c3test rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|training chunk|forward|grads|free-running|^E  " gpurun_out/${TAG}_c3test.log | cut -c1-1200 | tail -30
+  lap c3test
+fi
 if has epi; then        # the vectorised conv epilogue (every RAW / ACT output of every tile): the whole suite minus the CPU-oracle-heavy tests
   timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short --timeout 900 -k "not full_width_training and not full_size" > gpurun_out/${TAG}_epi_tests.log 2>&1; echo "epi tests rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_epi_tests.log | cut -c1-400 | tail -30
   lap epi
 fi
 if has benchq; then     # quick A/B figure: both resolutions, no CPU legs, no training line
-  timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_benchq.json 2> gpurun_out/${TAG}_benchq.err; echo "benchq rc=$?"
+  timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_benchq.json 2> gpurun_out/${TAG}_benchq.err; echo "benchq rc=$?"
   python - <<PY
 import json
 j = json.load(open("gpurun_out/${TAG}_benchq.json"))
@@ -56,7 +75,7 @@ if has phases; then     # per-workgroup phase stamps of the stride-2 / transpose
   lap phases
 fi
 if has benchpar; then   # 512x256 with the CPU-oracle parity legs only (bf16 error of the benchmarked path), no companions
-  timeout 900 python bench.py --no-train-line --no-train-hires --no-c1 --no-hires > gpurun_out/${TAG}_benchpar.json 2> gpurun_out/${TAG}_benchpar.err; echo "benchpar rc=$?"
+  timeout 900 python bench.py --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 --no-hires > gpurun_out/${TAG}_benchpar.json 2> gpurun_out/${TAG}_benchpar.err; echo "benchpar rc=$?"
   python - <<PY
 import json
 j = json.load(open("gpurun_out/${TAG}_benchpar.json"))
@@ -104,7 +123,7 @@ if has s2bench; then
 fi
 if has retune; then     # new tile selections (stride-2 / transposed patch tiles eligible) for 512x256 AND the 2048x1024 companion, one cache; then a replay
   rm -f gpurun_out/${TAG}_tune.json
-  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune.json timeout 1700 python bench.py --retune --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_bench_retune.json 2> gpurun_out/${TAG}_bench_retune.err; echo "retune rc=$?"
+  V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune.json timeout 1700 python bench.py --retune --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 --dump-ops gpurun_out/${TAG}_ops.json > gpurun_out/${TAG}_bench_retune.json 2> gpurun_out/${TAG}_bench_retune.err; echo "retune rc=$?"
   python -c "
 import json; j = json.load(open('gpurun_out/${TAG}_bench_retune.json'))
 print('retune value', j['value'], j['ms_per_step'], j['timing']['windows_ms_per_step'], 'eager sum', j['roofline']['frame_ms_eager_events']); print(j['roofline']['kernel'], j['roofline']['frac'], j['roofline']['avg_launch_us'])
@@ -113,10 +132,10 @@ print('hires', j['hires']['value'], j['hires']['ms_per_step'], j['hires']['plan_
   tail -3 gpurun_out/${TAG}_bench_retune.err | cut -c1-300
   cp gpurun_out/${TAG}_tune.json /tmp/tune_new.json
   for i in 1 2; do
-  V2V_TUNE_CACHE=/tmp/tune_new.json timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+  V2V_TUNE_CACHE=/tmp/tune_new.json timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>/dev/null | python -c "
 import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
 print('replay(new cache): 512x256', j['value'], 'fps', j['ms_per_step'], 'ms eager', j['roofline']['frame_ms_eager_events'], '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms eager', h['roofline']['frame_ms_eager_events'])"
-  timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+  timeout 900 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>/dev/null | python -c "
 import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
 print('replay(committed cache): 512x256', j['value'], 'fps', j['ms_per_step'], 'ms eager', j['roofline']['frame_ms_eager_events'], '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms eager', h['roofline']['frame_ms_eager_events'])"
   done
@@ -124,15 +143,15 @@ print('replay(committed cache): 512x256', j['value'], 'fps', j['ms_per_step'], '
 fi
 if has x3tune; then     # tile selections of the x3 plan (bf16 sub-engine, K tripled) measured on top of the committed cache, whole-frame search included
   cp profiles/tune_cache.json /tmp/tune_x3.json
-  V2V_TUNE_CACHE=/tmp/tune_x3.json timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 > gpurun_out/${TAG}_bench_x3_tune.json 2> gpurun_out/${TAG}_bench_x3_tune.err; echo "x3 tune rc=$?"
+  V2V_TUNE_CACHE=/tmp/tune_x3.json timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 > gpurun_out/${TAG}_bench_x3_tune.json 2> gpurun_out/${TAG}_bench_x3_tune.err; echo "x3 tune rc=$?"
   python -c "
 import json; j = json.load(open('gpurun_out/${TAG}_bench_x3_tune.json')); print('x3 (tuning run)', j['value'], 'fps', j['ms_per_step'], 'ms', j['config'].get('frame_tune'))"
   cp /tmp/tune_x3.json gpurun_out/${TAG}_tune_x3.json
   for i in 1 2; do
-    V2V_TUNE_CACHE=/tmp/tune_x3.json timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+    V2V_TUNE_CACHE=/tmp/tune_x3.json timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>/dev/null | python -c "
 import sys, json; j = json.loads(sys.stdin.read()); print('x3 replay(new cache)', j['value'], 'fps', j['ms_per_step'], 'ms launches', j['config']['launches_per_frame'])"
   done
-  timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+  timeout 900 python bench.py --precision x3 --no-cpu-baseline --no-hires --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>/dev/null | python -c "
 import sys, json; j = json.loads(sys.stdin.read()); print('x3 replay(committed cache + in-run search of the missing shapes)', j['value'], 'fps', j['ms_per_step'], 'ms')"
   lap x3tune
 fi
@@ -149,7 +168,7 @@ if has fin2; then       # two-level in-kernel finalize: parity, then both resolu
   timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "two_level_in_kernel" > gpurun_out/${TAG}_fin2_tests.log 2>&1; echo "fin2 tests rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_fin2_tests.log | cut -c1-300 | tail -20
   for f2 in 1 0 1 0; do
-    V2V_FIN2=$f2 timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>gpurun_out/${TAG}_fin2_$f2.err | python -c "
+    V2V_FIN2=$f2 timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>gpurun_out/${TAG}_fin2_$f2.err | python -c "
 import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']; k = h['roofline']['per_kernel_ms']
 print('V2V_FIN2=$f2: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms launches', j['config']['launches_per_frame'], '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms launches', h['launches_per_frame'], 'bn_finalize', k.get('bn_finalize'), 'bn_partial_reduce', k.get('bn_partial_reduce'), 'conv', k.get('conv_igemm'))"
   done | tee gpurun_out/${TAG}_fin2_ab.txt
@@ -157,7 +176,7 @@ print('V2V_FIN2=$f2: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms launches
 fi
 if has rawab; then      # bf16 raw tensors on / off on ONE box: both resolutions + the bf16 error of the 512x256 frame
   for rb in 1 0 1 0; do
-    V2V_RAW_BF16=$rb timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+    V2V_RAW_BF16=$rb timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>/dev/null | python -c "
 import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
 print('V2V_RAW_BF16=$rb: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms bn_apply', j['roofline']['per_kernel_ms'].get('bn_apply'), 'conv', j['roofline']['per_kernel_ms'].get('conv_igemm'), '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms bn_apply', h['roofline']['per_kernel_ms'].get('bn_apply'), 'conv', h['roofline']['per_kernel_ms'].get('conv_igemm'))"
   done | tee gpurun_out/${TAG}_raw_bf16_ab.txt
@@ -196,14 +215,14 @@ if has dbg1; then
 fi
 if has kernarg; then    # where kernel arguments live: HIP_FORCE_DEV_KERNARG (device memory) on / off, same box
   for ka in 1 0 1 0; do
-    HIP_FORCE_DEV_KERNARG=$ka timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 2>/dev/null | python -c "
+    HIP_FORCE_DEV_KERNARG=$ka timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>/dev/null | python -c "
 import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
 print('HIP_FORCE_DEV_KERNARG=$ka: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms eager sum', j['roofline']['frame_ms_eager_events'], '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms')"
   done | tee gpurun_out/${TAG}_kernarg_ab.txt
   lap kernarg
 fi
 if has coresident; then  # can the foreground tower run UNDER the paired launches?  pairs on a 128 KiB tile, the tower's 512->512 convolutions on the 32 KiB generic tile
-  run() { env "$@" timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-hires 2>/dev/null | python -c "
+  run() { env "$@" timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 --no-hires 2>/dev/null | python -c "
 import sys, json; j = json.loads(sys.stdin.read()); r = j['roofline']
 print('$*:', j['value'], 'fps', j['ms_per_step'], 'ms eager sum', r['frame_ms_eager_events'], '| dominant', r['kernel'][:60], 'in-graph live', (r.get('in_graph_live') or {}).get('avg_launch_us'), 'eager', r['eager']['avg_launch_us'])"; }
   for rep in 1 2; do
