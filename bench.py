@@ -721,8 +721,8 @@ def main():
             fam = "conv3x3_pp3_kernel" if dom[0] >= 80 else "conv3x3_pp2_kernel" if dom[0] >= 70 else "conv3x3_pp_kernel" if dom[0] >= 50 else "conv3x3_patch_kernel"
             return fam, "%dx%d px x %d,splitK=%d%s%s" % (th_, tw_, bn, dom[1], ",paired launch (2 convolutions)" if dom[2] == 2 else "",
                                                            ",norm+act+residual fused" if fused else "")
-        if dom[0] in (60, 61):
-            return ("conv7x7_head_kernel" if dom[0] == 60 else "conv7x7_c8_kernel"), "halo patch,splitK=%d" % dom[1]
+        if dom[0] in (60, 61, 62):
+            return {60: "conv7x7_head_kernel", 61: "conv7x7_c8_kernel", 62: "conv7x7_rowsum_kernel"}[dom[0]], "halo patch,splitK=%d" % dom[1]
         bm, bn, _ = TILE_CFGS.get(dom[0], (0, 0, False))
         return "conv_igemm_kernel", "%dx%d,splitK=%d" % (bm, bn, dom[1])
 

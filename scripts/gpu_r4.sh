@@ -50,6 +50,18 @@ if has c3test; then     # the 3-frame C3 training chunk (teacher-forced) + the r
   grep -E "^(FAILED|ERROR)|passed|failed|training chunk|forward|grads|free-running|^E  " gpurun_out/${TAG}_c3test.log | cut -c1-1200 | tail -30
   lap c3test
 fi
+if has heads; then      # conv7x7_rowsum_kernel (tile 62): parity, the kernel beside tile 60 on the head shapes, then both resolutions with / without it
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "rowsum or conv7x7_head_kernel or merged_heads" > gpurun_out/${TAG}_heads_tests.log 2>&1; echo "heads tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_heads_tests.log | cut -c1-300 | tail -20
+  timeout 600 python scripts/head_bench.py 2>&1 | tee gpurun_out/${TAG}_head_bench.txt | cut -c1-250
+  for hr in 1 0 1 0; do
+    V2V_HEAD_ROWSUM=$hr timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>gpurun_out/${TAG}_heads_$hr.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']
+print('V2V_HEAD_ROWSUM=$hr: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms conv', j['roofline']['per_kernel_ms'].get('conv_igemm'), '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms conv', h['roofline']['per_kernel_ms'].get('conv_igemm'), h['roofline']['slowest_configs_ms'])"
+  done | tee gpurun_out/${TAG}_heads_ab.txt
+  tail -3 gpurun_out/${TAG}_heads_1.err | cut -c1-300
+  lap heads
+fi
 if has epi; then        # the vectorised conv epilogue (every RAW / ACT output of every tile): the whole suite minus the CPU-oracle-heavy tests
   timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short --timeout 900 -k "not full_width_training and not full_size" > gpurun_out/${TAG}_epi_tests.log 2>&1; echo "epi tests rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_epi_tests.log | cut -c1-400 | tail -30

@@ -655,6 +655,48 @@ def test_conv7x7_head_kernel(case, prec):
     assert_close(outs[60].cpu(), outs[3].cpu(), 1e-4 if prec == "fp32" else 2e-3, "head vs implicit GEMM")
 
 
+@pytest.mark.parametrize("case", [(128, 3, 24, 64, "reflect", 1, "tanh"), (64, 2, 19, 45, "reflect", 2, "none"), (128, 1, 33, 70, "zero", 1, "sigmoid"),
+                                  (192, 4, 9, 32, "reflect", 1, "none"), (32, 3, 45, 100, "reflect", 2, "tanh"), (96, 2, 17, 40, "zero", 1, "none"),
+                                  (16, 3, 9, 70, "reflect", 1, "sigmoid"), (32, 3, 64, 128, "reflect", 1, "tanh")])
+def test_conv7x7_rowsum_kernel(case):
+    """Tile 62 (round 4): the bf16 generator heads (models/networks.py:180-183,151,279: Conv2d(C -> 3 | 2 | 1, 7) behind
+    ReflectionPad2d(3)) as a row GEMM over (kernel row, channel) with the kernel column folded into the MFMA's N index and a
+    shifted sum over the columns -- against torch on the bf16-rounded operands and against the 16-wide head kernel (tile 60),
+    ragged tiles (10 x 32 pixels), both paddings, 1-4 output channels, 1-6 half chunks of input channels, batch 2."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, mode, N, actn = case
+    torch.manual_seed(cin + cout + H)
+    eng = _engine("bf16")
+    conv = nn.Conv2d(cin, cout, 7, padding=0 if mode == "reflect" else 3)
+    x = torch.randn(N, cin, H, W)
+    xr = _round(x, "bf16")
+    if mode == "reflect":
+        xr = F.pad(xr, (3,) * 4, mode="reflect")
+    ref = F.conv2d(xr, _round(conv.weight.detach(), "bf16"), conv.bias.detach(), padding=0 if mode == "reflect" else 3)
+    act = {"tanh": L.ACT_TANH, "sigmoid": L.ACT_SIGMOID, "none": L.ACT_NONE}[actn]
+    ref = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "none": lambda t: t}[actn](ref) * 20.0
+    conv = conv.to(DEV)
+    xa = eng.pack(x.to(DEV))
+    if xa.Cs % 32 != 0:
+        xa = eng.widen(xa, (xa.Cs + 31) // 32 * 32)
+    pm, po = (L.PAD_REFLECT, 3) if mode == "reflect" else (L.PAD_ZERO, None)
+    outs = {}
+    for tile in (62, 60):
+        eng.tile_override[(cin, cout, 7, 1, 0)] = tile
+        o, _, _ = eng.conv(xa, conv, pm, po, L.OUT_F32_NCHW, act, 0.0, 20.0)
+        assert eng.conv_log[-1]["tile"] == tile
+        outs[tile] = o.clone()
+        assert torch.isfinite(o).all()
+        assert_close(o.cpu(), ref, 2e-3, "head tile %d" % tile)
+    # same bf16 operands, fp32 accumulation on both kernels: only the summation order differs
+    assert_close(outs[62].cpu(), outs[60].cpu(), 2e-4, "row-sum heads vs 16-wide head kernel")
+    # the engine's own choice for such a layer: a tuned / forced tile 60 becomes 62 on the bf16 path
+    del eng.tile_override[(cin, cout, 7, 1, 0)]
+    eng._tuned[(cin, cout, 7, 1, 0, N, H, W, L.OUT_F32_NCHW, xa.Cs)] = (60, 1, 0)
+    o, _, _ = eng.conv(xa, conv, pm, po, L.OUT_F32_NCHW, act, 0.0, 20.0)
+    assert eng.conv_log[-1]["tile"] == (62 if eng.rowsum_heads else 60) and torch.equal(o, outs[62 if eng.rowsum_heads else 60])
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(128, 40, 96), (64, 33, 70)])
 @torch.no_grad()
@@ -669,8 +711,8 @@ def test_merged_heads_equal_separate_heads(case, prec):
     seq_flow = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(C_, 2, 7)).to(DEV)
     seq_w = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(C_, 1, 7), nn.Sigmoid()).to(DEV)
     eng.merge_heads = True
-    for co in (1, 2):
-        eng.tile_override[(C_, co, 7, 1, 0)] = (60, 1, 0)          # the separate heads on the same kernel as the merged one
+    for co in (1, 2):         # the separate heads on the same kernel as the merged one (bf16: the row-sum heads, tile 62)
+        eng.tile_override[(C_, co, 7, 1, 0)] = (62 if prec == "bf16" and eng.rowsum_heads else 60, 1, 0)
     both = eng.head_pair(x, seq_flow, 20.0, seq_w, 1.0, label="heads")
     assert both is not None and both[0].shape == (1, 2, H, W) and both[1].shape == (1, 1, H, W)
     flow = eng.run_sequential(seq_flow, x, head_nchw=True, out_scale=20.0, name="flow")

@@ -318,6 +318,163 @@ static inline int launch_c8_typed(const ConvKArgs& k, hipStream_t s) {
     return check_launch();
 }
 
+// ---- generator heads as a ROW GEMM + shifted sum (tile id 62, bf16; round 4) ----
+// conv7x7_head_kernel spends one 16 x 16 x 32 MFMA per (tap, 16 pixels) with 3 of its 16 output columns alive: the 32 -> 3 heads of the
+// 2048x1024 scale took 250 us each for 134 MB of input (profiles/r03_e4_per_layer_roofline_hires.txt: 10 % of their HBM bound), the
+// 128 -> 3 heads at 512x256 63 us.  Here the kernel COLUMN joins the output channel in the GEMM's N index:
+//     V[oh][iw][(dx, co)] = sum_{dy, c} x[oh + dy - 3][iw][c] * w[co][dy][dx][c]        (M = patch pixels, K = 7 rows x C, N = 7 x 4 -> 32)
+//     out[oh][ow][co]     = sum_dx V[oh][ow + dx][(dx, co)]                              (iw in patch columns: ow + dx)
+// i.e. 7 C instead of 49 C of K and all 32 columns of the 32-wide MFMA in use: 3.5x fewer matrix cycles (2.9x with the 38 / 32 halo
+// columns).  With the patch rows flattened, m = oh * PW + iw, the A rows of V-tile row m at kernel row dy are patch rows m + dy * PW:
+// contiguous, so an M tile is any 32 consecutive m (it may straddle image rows).  A 10 x 32 pixel tile is 380 V rows = 12 M tiles, three
+// per wave.  The B rows (dy, n = dx * 4 + co) of a 32-channel chunk are brought from the tap-major packed matrix (korder 0: row co,
+// K = (dy * 7 + dx) * cs + c; rows >= cout are zero; n >= 28 reads the zero page) into LDS next to the patch by the same LDS-DMA
+// pieces, so no weight load sits in the MFMA loop.  V goes through LDS (fp32, row stride 33 words: the 7 shifted reads of 32
+// consecutive ow hit 32 different banks) and leaves as coalesced planar fp32 rows with bias + activation (per channel for the merged
+// flow + weight head).  53 KB of LDS: three workgroups per CU overlap one another's patch loads.
+template <typename T>          // bf16 storage only (the fp32 / x3 paths keep conv7x7_head_kernel's exact-fp32 MFMA)
+__global__ __launch_bounds__(256) void conv7x7_rowsum_kernel(const ConvKArgs p, const T* __restrict__ w_ro) {
+    static_assert(sizeof(T) == 2, "bf16");
+    constexpr int TH = 10, TW = 32, HALO = 3, KS = 7;
+    constexpr int PW = TW + 2 * HALO, PR = (TH + 2 * HALO) * PW;     // 38 x 16 = 608 patch rows of 64 bytes (32 channels)
+    constexpr int NW = 4, ROWB = 64, SLOTS = 4, RPP = 16;
+    constexpr int NGP = PR / RPP, GPP = (NGP + NW - 1) / NW;          // 38 patch pieces, <= 10 per wave
+    constexpr int NB = KS * 32, NGB = NB / RPP, GPB = (NGB + NW - 1) / NW;   // 224 weight rows = 14 pieces, <= 4 per wave
+    constexpr int B_OFF = NGP * 1024;                                 // 38912
+    constexpr int MT = 3;                                             // M tiles per wave (12 x 32 = 384 >= 380 V rows)
+    constexpr int VS = 33;                                            // V row stride in words
+    static_assert(PR % RPP == 0 && NB % RPP == 0 && 384 * VS * 4 <= B_OFF + NGB * 1024, "layout");
+#define V2V_RS_SWZ(q) (((q) >> 2) & 3)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x;
+    const int tpi = p.tiles_h * p.tiles_w;
+    const int n_img = mt / tpi;
+    const int trem = mt - n_img * tpi;
+    const int th = trem / p.tiles_w;
+    const int oh0 = th * TH, ow0 = (trem - th * p.tiles_w) * TW;
+    const int H = p.H, W = p.W, cs = p.cin_stride;
+    const int ncc = cs / 32;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+
+    // ---- loader geometry: patch piece g = k * NW + wid covers patch rows 16 g .. 16 g + 15, lane l row l / 4, 16-byte slot l % 4
+    unsigned pp[GPP];
+    unsigned pok = 0;
+#pragma unroll
+    for (int k = 0; k < GPP; ++k) {
+        const int q = (k * NW + wid) * RPP + lane / SLOTS;
+        const int ls = (lane % SLOTS) ^ V2V_RS_SWZ(q);
+        const int pr = q / PW, pc = q - pr * PW;
+        int ih = oh0 + pr - HALO, iw = ow0 + pc - HALO;
+        bool ok = q < PR;
+        int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+        int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+        ih = reflect ? rh : ih;
+        iw = reflect ? rw : iw;
+        ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+        iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        pp[k] = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * 8) * 2ll);
+        pok |= (ok ? 1u : 0u) << k;
+    }
+    // weight piece g covers B rows 16 g .. 16 g + 15: row rb = dy * 32 + n, n = dx * 4 + co
+    long long wp[GPB];
+    unsigned wok = 0;
+#pragma unroll
+    for (int k = 0; k < GPB; ++k) {
+        const int rb = (k * NW + wid) * RPP + lane / SLOTS;
+        const int ls = (lane % SLOTS) ^ V2V_RS_SWZ(rb);
+        const int dy = rb >> 5, n = rb & 31, dx = n >> 2, co = n & 3;
+        const bool ok = rb < NB && n < 4 * KS;
+        wp[k] = ok ? (p.woff[0] + (long long)co * p.wrow[0] + (long long)(dy * KS + dx) * cs + ls * 8) * 2ll : 0ll;
+        wok |= (ok ? 1u : 0u) << k;
+    }
+
+    // ---- fragments: lane l = (row l & 31, k half l >> 5) of the 32 x 32 x 16 MFMA, both operands
+    const int lr = lane & 31, hi = lane >> 5;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int cc = 0; cc < ncc; ++cc) {
+        if (cc > 0) __syncthreads();                                  // every wave is done with the previous chunk
+#pragma unroll
+        for (int k = 0; k < GPP; ++k) {
+            if (k * NW + wid < NGP) {
+                const char* src = ((pok >> k) & 1u) ? p.in + pp[k] + cc * ROWB : p.zero_page;
+                glds16(src, smem + (k * NW + wid) * 1024);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GPB; ++k) {
+            if (k * NW + wid < NGB) {
+                const char* src = ((wok >> k) & 1u) ? reinterpret_cast<const char*>(w_ro) + wp[k] + cc * ROWB : p.zero_page;
+                glds16(src, smem + B_OFF + (k * NW + wid) * 1024);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int rb = dy * 32 + lr;
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + B_OFF + rb * ROWB + (((2 * s + hi) ^ V2V_RS_SWZ(rb)) << 4));
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const int q = (wid * MT + t) * 32 + lr + dy * PW;     // rows >= PR (V rows >= 380 only) read the weight area: never used
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + q * ROWB + (((2 * s + hi) ^ V2V_RS_SWZ(q)) << 4));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- V -> LDS (C layout: column n = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), then the shifted sum
+    __syncthreads();                                                  // patch and weights are dead
+    float* const Vs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (wid * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            Vs[m * VS + lr] = acc[t][r];
+        }
+    __syncthreads();
+    const long long hw = (long long)H * W;
+    const int nout = p.cout * TH * TW;
+    for (int idx = tid; idx < nout; idx += 256) {
+        const int co = idx / (TH * TW);
+        const int px = idx - co * (TH * TW);
+        const int ohl = px >> 5, owl = px & 31;
+        const int oh = oh0 + ohl, ow = ow0 + owl;
+        const float* v0 = Vs + (ohl * PW + owl) * VS + co;
+        float v = 0.f;
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) v += v0[dx * (VS + 4)];
+        if (oh < H && ow < W) {
+            const bool second = p.act_split > 0 && co >= p.act_split;
+            const int act = second ? p.act_b : p.act;
+            const float act_param = second ? p.act_param_b : p.act_param, out_scale = second ? p.out_scale_b : p.out_scale;
+            v += p.bias ? p.bias[co] : 0.f;
+            reinterpret_cast<float*>(p.out)[((long long)n_img * p.cout + co) * hw + (long long)oh * W + ow] = apply_act(v, act, act_param) * out_scale;
+        }
+    }
+#undef V2V_RS_SWZ
+}
+
+static inline int launch_rowsum_bf16_impl(const ConvKArgs& k, hipStream_t s) {
+    const size_t lds = (size_t)(38 + 14) * 1024;                      // 52 KiB: three workgroups per CU
+    hipLaunchKernelGGL(conv7x7_rowsum_kernel<bf16_t>, dim3((unsigned)k.m_tiles), dim3(256), lds, s, k, reinterpret_cast<const bf16_t*>(k.w));
+    return check_launch();
+}
+
 template <typename T>
 static inline int launch_head_typed(const ConvKArgs& k, hipStream_t s) {
     constexpr int PR = (8 + 6) * (32 + 6);

@@ -358,6 +358,7 @@ int launch_t2_f32(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s);
 int launch_head_f32(const ConvKArgs& k, hipStream_t s);
 int launch_c8_bf16(const ConvKArgs& k, hipStream_t s);
+int launch_rowsum_bf16(const ConvKArgs& k, hipStream_t s);
 int launch_c8_f32(const ConvKArgs& k, hipStream_t s);
 
 static int choose_cfg(long long Mc, int cout, int ncls) {
@@ -384,6 +385,7 @@ struct ConvOp : Op {
         if (cfg >= 100) return dtype == V2V_BF16 ? launch_s2_bf16(cfg, k, s) : launch_s2_f32(cfg, k, s);
         if (cfg >= 80) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, groups, s) : launch_pp3_f32(cfg, k, groups, s);
         if (cfg >= 70) return dtype == V2V_BF16 ? launch_pp2_bf16(cfg, k, groups, s) : launch_pp2_f32(cfg, k, groups, s);
+        if (cfg == 62) return launch_rowsum_bf16(k, s);
         if (cfg == 61) return dtype == V2V_BF16 ? launch_c8_bf16(k, s) : launch_c8_f32(k, s);
         if (cfg == 60) return dtype == V2V_BF16 ? launch_head_bf16(k, s) : launch_head_f32(k, s);
         if (cfg >= 50) return dtype == V2V_BF16 ? launch_pp_bf16(cfg, k, s) : launch_pp_f32(cfg, k, s);
@@ -473,8 +475,8 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     }
     k.out_mode = d->out_mode; k.act = d->act; k.act_param = d->act_param; k.out_scale = d->out_scale;
     if (d->act_split != 0) {
-        if (d->act_split < 0 || d->act_split >= d->cout || d->tile != 60 || d->out_mode != V2V_OUT_F32_NCHW) {
-            set_error("conv: act_split (merged heads) needs tile 60, planar fp32 output and 0 < act_split < cout"); return V2V_EINVAL;
+        if (d->act_split < 0 || d->act_split >= d->cout || (d->tile != 60 && d->tile != 62) || d->out_mode != V2V_OUT_F32_NCHW) {
+            set_error("conv: act_split (merged heads) needs tile 60 / 62, planar fp32 output and 0 < act_split < cout"); return V2V_EINVAL;
         }
         k.act_split = d->act_split; k.act_b = d->act_b; k.act_param_b = d->act_param_b; k.out_scale_b = d->out_scale_b;
     }
@@ -525,6 +527,19 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.m_tiles = d->N * k.tiles_h * k.tiles_w;
         k.n_tiles = 1;
         tile_bm = 256; tile_bn = 4;
+    } else if (op->cfg == 62) {
+        // conv7x7_rowsum_kernel: the generator heads (7x7 / stride 1 / pad 3 Conv2d, <= 4 output channels, planar fp32 + activation), bf16
+        if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->cout > 4 || d->dtype != V2V_BF16 ||
+            d->cin_stride % 32 != 0 || d->w_korder != 0 || d->splitk > 1 || d->fin_counter || d->stats || d->out_mode != V2V_OUT_F32_NCHW ||
+            (long long)d->N * d->H * d->W * d->cin_stride * 2 >= (1ll << 32)) {
+            set_error("conv: tile config 62 (7x7 heads as row GEMM + shifted sum) needs a bf16 7x7/s1/p3 Conv2d with cout <= 4, cin_stride %% 32 == 0, "
+                      "planar fp32 output, no statistics"); return V2V_EINVAL;
+        }
+        k.tiles_h = (int)ceil_div(d->OH, 10);
+        k.tiles_w = (int)ceil_div(d->OW, 32);
+        k.m_tiles = d->N * k.tiles_h * k.tiles_w;
+        k.n_tiles = 1;
+        tile_bm = 320; tile_bn = 4;
     } else if (op->cfg == 60) {
         // conv7x7_head_kernel: 7x7 / stride 1 / pad 3 Conv2d with <= 16 output channels written planar fp32
         if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->cout > 32 ||

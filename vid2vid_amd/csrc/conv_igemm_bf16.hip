@@ -16,4 +16,5 @@ int launch_s2_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_s
 int launch_t2_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_t2_typed<bf16_t>(cfg, k, s); }
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s) { return launch_head_typed<bf16_t>(k, s); }
 int launch_c8_bf16(const ConvKArgs& k, hipStream_t s) { return launch_c8_typed<bf16_t>(k, s); }
+int launch_rowsum_bf16(const ConvKArgs& k, hipStream_t s) { return launch_rowsum_bf16_impl(k, s); }
 }

@@ -418,6 +418,9 @@ class Engine:
         # but the convolutions' epilogues pay more for the bf16 packing than the stores save (+3 % / +7 % conv time) -- the frame is
         # 1.7 % SLOWER at both resolutions and the bf16 error grows (fake_B mean 1.44e-2 -> 1.64e-2).  OFF by default.
         self.raw_bf16 = bool(int(os.environ.get("V2V_RAW_BF16", "0")))
+        # V2V_HEAD_ROWSUM=0: the bf16 generator heads (7x7, <= 4 output channels, planar fp32) stay on conv7x7_head_kernel (tile 60)
+        # instead of conv7x7_rowsum_kernel (tile 62: row GEMM over (kernel column, channel) + shifted sum) -- A/B switch
+        self.rowsum_heads = bool(int(os.environ.get("V2V_HEAD_ROWSUM", "1")))
         self._fused_norm_wgs = None
         # model_final_flow + model_final_w (same input) as one 7x7 head launch; V2V_MERGE_HEADS=0: one launch each
         self.merge_heads = bool(int(os.environ.get("V2V_MERGE_HEADS", "1")))
@@ -706,7 +709,11 @@ class Engine:
         if d.tile == 0 and tune_key in self._tuned:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
         if act_b is not None:
-            d.tile, d.splitk, d.prefetch = 60, 1, 0          # per-channel epilogues exist in the 7x7 head kernel only
+            d.tile, d.splitk, d.prefetch = 60, 1, 0          # per-channel epilogues exist in the 7x7 head kernels only
+        if d.tile == 60 and self.rowsum_heads and (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed)) not in self.tile_override \
+                and self.dtype == L.BF16 and pc.cout <= 4 and out_mode == L.OUT_F32_NCHW \
+                and x.Cs % 32 == 0 and not want_stats and fin is None:
+            d.tile = 62                                       # conv7x7_rowsum_kernel: the heads as row GEMM + shifted sum (bf16)
         if tile_korder(d.tile):
             pc = self._use_korder(d, mod, x.Cs, tile_korder(d.tile))
         elif self.plan is None:
@@ -1245,6 +1252,9 @@ class Engine:
                 and d.cin_stride % bke_ == 0 and not d.fin_counter
                 and (d.out_mode == L.OUT_F32_NCHW or d.out_mode == L.OUT_RAW_F32_NHWC)):
             cands.append((60, 1, 0))          # conv7x7_head_kernel (LDS patch + 16-wide MFMA)
+            if (self.rowsum_heads and self.dtype == L.BF16 and cout <= 4 and d.out_mode == L.OUT_F32_NCHW and d.cin_stride % 32 == 0
+                    and not d.stats):
+                cands.append((62, 1, 0))      # conv7x7_rowsum_kernel (row GEMM + shifted sum)
         if (not d.transposed and d.KH == 7 and d.KW == 7 and d.stride == 1 and d.pad == 3 and cout <= 128
                 and d.cin_stride * (2 if self.dtype == L.BF16 else 4) == 16 and not d.fin_counter
                 and (d.out_mode == L.OUT_F32_NCHW or d.out_mode == L.OUT_RAW_F32_NHWC)):
