@@ -247,3 +247,33 @@ print('$*:', j['value'], 'fps', j['ms_per_step'], 'ms eager sum', r['frame_ms_ea
   done | tee gpurun_out/${TAG}_coresident_ab.txt
   lap coresident
 fi
+if has xcdgrp; then     # paired launches with the members on disjoint XCD halves (grouped_xcd_map) + the row-GEMM heads (tile 62): parity, A/B on one box, fabric traffic
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "conv2d_pair or fused_norm_pair or rowsum or conv7x7_head_kernel or merged_heads" > gpurun_out/${TAG}_xcdgrp_tests.log 2>&1; echo "xcdgrp tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_xcdgrp_tests.log | cut -c1-300 | tail -20
+  lap xcdtests
+  timeout 300 python scripts/head_bench.py 2>&1 | tee gpurun_out/${TAG}_head_bench.txt | cut -c1-250
+  lap headbench
+  run() { env "$@" timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>gpurun_out/${TAG}_xcdgrp.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); r = j['roofline']; h = j['hires']
+print('$*: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms | dominant in-graph live', (r.get('in_graph_live') or {}).get('avg_launch_us'), 'eager', r['eager']['avg_launch_us'], 'conv', r['per_kernel_ms'].get('conv_igemm'), '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms conv', h['roofline']['per_kernel_ms'].get('conv_igemm'), h['roofline']['slowest_configs_ms'])"; }
+  for rep in 1 2; do
+    run V2V_GROUP_XCD=0 V2V_HEAD_ROWSUM=0
+    run V2V_GROUP_XCD=1 V2V_HEAD_ROWSUM=0
+    run V2V_GROUP_XCD=1 V2V_HEAD_ROWSUM=1
+  done | tee gpurun_out/${TAG}_xcdgrp_ab.txt
+  tail -3 gpurun_out/${TAG}_xcdgrp.err | cut -c1-300
+  lap xcdab
+  cd /tmp
+  for g in 1 0; do
+    V2V_GROUP_XCD=$g timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/trf_$g -o pmc -- python $R/scripts/conv_layer_run.py --pair --fused --cfg 91,1,0 > $R/gpurun_out/${TAG}_traffic_fetch_$g.log 2>&1; echo "traffic fetch (grp_xcd=$g) rc=$?"
+    V2V_GROUP_XCD=$g timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/trw_$g -o pmc -- python $R/scripts/conv_layer_run.py --pair --fused --cfg 91,1,0 > $R/gpurun_out/${TAG}_traffic_write_$g.log 2>&1; echo "traffic write (grp_xcd=$g) rc=$?"
+    python $R/scripts/pmc_traffic.py $(find /tmp/trf_$g -name "*.db" | head -1) $(find /tmp/trw_$g -name "*.db" | head -1) 91,1,2 $R/gpurun_out/${TAG}_traffic_grpxcd$g.json | cut -c1-500
+  done
+  cd $R
+  lap xcdtraffic
+fi
+if has traintests; then  # the kernels behind the training step that changed this visit: weight re-pack (every conv test packs), bn backward reduce / apply
+  timeout 900 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short > gpurun_out/${TAG}_traintests.log 2>&1; echo "traintests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_traintests.log | cut -c1-300 | tail -20
+  lap traintests
+fi

@@ -36,9 +36,10 @@
 namespace v2v {
 
 // second member of a grouped launch: blockIdx.z == 1 swaps in its own tensors (identical geometry by construction)
-__device__ __forceinline__ ConvKArgs select_group(const ConvKArgs& p) {
+__device__ __forceinline__ ConvKArgs select_group(const ConvKArgs& p, int member = -1) {
     ConvKArgs q = p;
-    if (blockIdx.z != 0) {
+    if (member < 0) member = (int)blockIdx.z;
+    if (member != 0) {
         q.in = p.g1.in; q.w = p.g1.w; q.bias = p.g1.bias; q.out = p.g1.out; q.stats = p.g1.stats;
         q.fin_counter = p.g1.fin_counter; q.fin_gamma = p.g1.fin_gamma; q.fin_beta = p.g1.fin_beta; q.fin_out = p.g1.fin_out;
         q.fin_rmean = p.g1.fin_rmean; q.fin_rvar = p.g1.fin_rvar; q.slabs = p.g1.slabs; q.sk_counter = p.g1.sk_counter;

@@ -57,7 +57,15 @@ constexpr int pending_at(int tap, int GP, int LB, int D) {
 // (48 KB of LDS reads per step and CU), 128 accumulator registers per lane, a three-round reduce-scatter at the end.
 template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1>
 __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
-    const ConvKArgs p = select_group(p_in);
+    // grouped launch: which member and which tile this workgroup works on (the members have identical geometry, so the
+    // tile count is known before the member is)
+    int member = (int)blockIdx.z, lin_all;
+    {
+        const int ntot = p_in.m_tiles * p_in.n_tiles * p_in.splitk;
+        if (p_in.grp_xcd && gridDim.z == 2 && (ntot & 7) == 0) lin_all = grouped_xcd_map(blockIdx.x, blockIdx.z, ntot, member);
+        else                                                  lin_all = xcd_remap(blockIdx.x, ntot);
+    }
+    const ConvKArgs p = select_group(p_in, member);
     const int ab = ABL ? p.ablate : 0;
     if (ab & 512) return;                                     // ablation: the launch itself
     V2V_STAMP(p, 0);
@@ -100,7 +108,6 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
 
     const int tiles = p.m_tiles * p.n_tiles;
     const int S = p.splitk;
-    const int lin_all = xcd_remap(blockIdx.x, tiles * S);
     const int lin = lin_all / S;
     const int slice = lin_all - lin * S;
     const int nt = lin / p.m_tiles;

@@ -228,37 +228,75 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const PackArgs 
             if (c < a.cin && r < nr) sh[(r * KHW + f) * LS + cl] = a.w[((long long)c * KHW + f) * a.cout + co0 + r];
         }
     } else if (!a.transposed) {
+        // All of a thread's 16-byte loads are issued BEFORE the first LDS store (round 4): the row-by-row loop of the first
+        // version waited for one global load per row -- 8 serialised memory latencies per workgroup, 43 us for a
+        // 1024 x 1024 x 3 x 3 layer that moves 56 MB (profiles/r04_a6_train_kernel_stats.txt: 6.6 % of the training step).
         const int nc = min(PK_TC, a.cin - c0);
         const int run = nc > 0 ? nc * KHW : 0;
-        for (int r = 0; r < PK_TCO; ++r) {
-            const int co = co0 + r;
-            if (co >= a.cout) break;
-            const float* src = a.w + ((long long)co * a.cin + c0) * KHW;
-            const bool al = (((unsigned long long)src) & 15) == 0;
-            for (int i4 = tid * 4; i4 < run; i4 += 1024) {
-                float v[4];
-                if (al && i4 + 4 <= run) { const float4 t = *reinterpret_cast<const float4*>(src + i4); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-                else { for (int q = 0; q < 4; ++q) v[q] = i4 + q < run ? src[i4 + q] : 0.f; }
+        const int nrow = min(PK_TCO, a.cout - co0);
+        const int Q = (run + 3) >> 2;                          // 16-byte pieces per row
+        const int totq = nrow > 0 ? nrow * Q : 0;
+        constexpr int MAXQ = PK_TCO * PK_MAXT * PK_TC / 4 / 256;
+        const float* const src0 = a.w + ((long long)co0 * a.cin + c0) * KHW;
+        const long long rstride = (long long)a.cin * KHW;
+        const bool al = ((((unsigned long long)src0) | ((unsigned long long)rstride * 4ull)) & 15) == 0;
+        float4 v[MAXQ];
+#pragma unroll
+        for (int u = 0; u < MAXQ; ++u) {
+            const int j = tid + u * 256;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < totq) {
+                const int r = j / Q, i4 = (j - r * Q) * 4;
+                const float* src = src0 + r * rstride + i4;
+                if (al && i4 + 4 <= run) v[u] = *reinterpret_cast<const float4*>(src);
+                else {
+                    v[u].x = src[0];
+                    if (i4 + 1 < run) v[u].y = src[1];
+                    if (i4 + 2 < run) v[u].z = src[2];
+                    if (i4 + 3 < run) v[u].w = src[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MAXQ; ++u) {
+            const int j = tid + u * 256;
+            if (j < totq) {
+                const int r = j / Q, i4 = (j - r * Q) * 4;
                 int cl = i4 / KHW, f = i4 - cl * KHW;
+                const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (i4 + q < run) sh[(r * KHW + f) * LS + cl] = v[q];
+                    if (i4 + q < run) sh[(r * KHW + f) * LS + cl] = vv[q];
                     if (++f == KHW) { f = 0; ++cl; }
                 }
             }
         }
     } else {
+        // transposed read ([c][co][kh][kw] source): per channel the tile's rows x taps are one contiguous run of nr * KHW floats;
+        // 8 independent loads per thread in flight per batch (the first version: one load per thread and pass, 8-32 passes)
         const int nr = min(PK_TCO, a.cout - co0);
         const int run = nr > 0 ? nr * KHW : 0;
-        // one channel per group of threads: 256 threads cover 256 / ceil(run) channels per pass
-        const int tpc = run <= 32 ? 32 : run <= 64 ? 64 : 128;           // threads per channel (run <= 8 * 16 = 128)
-        const int cpp = 256 / tpc;
-        for (int cb = 0; cb < PK_TC; cb += cpp) {
-            const int cl = cb + tid / tpc, i = tid % tpc;
-            const int c = c0 + cl;
-            if (cl < PK_TC && c < a.cin && i < run) {
-                const int r = i / KHW, f = i - r * KHW;
-                sh[(r * KHW + f) * LS + cl] = a.w[((long long)c * a.cout + co0) * KHW + i];
+        const int ncl = min(PK_TC, a.cin - c0);
+        const int tot = ncl > 0 ? ncl * run : 0;
+        for (int base = 0; base < tot; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = base + u * 256 + tid;
+                v[u] = 0.f;
+                if (j < tot) {
+                    const int cl = j / run, i = j - cl * run;
+                    v[u] = a.w[((long long)(c0 + cl) * a.cout + co0) * KHW + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = base + u * 256 + tid;
+                if (j < tot) {
+                    const int cl = j / run, i = j - cl * run;
+                    const int r = i / KHW, f = i - r * KHW;
+                    sh[(r * KHW + f) * LS + cl] = v[u];
+                }
             }
         }
     }
@@ -794,6 +832,10 @@ extern "C" int v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, v
     g.fin_rmean = ob.k.fin_rmean; g.fin_rvar = ob.k.fin_rvar; g.slabs = ob.k.slabs; g.sk_counter = ob.k.sk_counter;
     g.res0 = ob.k.res0; g.res1 = ob.k.res1;
     op->groups = 2;
+    {   // members on disjoint XCD halves (grouped_xcd_map; tiles 80-93 only -- conv3x3_pp2_kernel keeps the shared mapping); V2V_GROUP_XCD=0: off
+        static const int on = [] { const char* e = getenv("V2V_GROUP_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+        op->k.grp_xcd = on;
+    }
     if (a->out_mode == V2V_OUT_NORM_ACT_NHWC) {
         if ((a->res0 != nullptr) != (b->res0 != nullptr) || (a->res1 != nullptr) != (b->res1 != nullptr)) {
             set_error("conv pair: the members must have the same residual operands"); return V2V_EINVAL;

@@ -59,6 +59,7 @@ struct ConvKArgs {
     int fin_groups; double* fin_ws;   // two-level in-kernel finalize (rows > 512): row groups and their fp64 (sum, sum^2) rows [groups][cout][2], or 0 / NULL
     int fin_rows;        // statistics rows (= finalize tickets) per channel tile when it is not gridDim.y * m_tiles (conv3x3_t2_kernel: 4 m_tiles), else 0
     unsigned long long* dbg;   // v2v_conv_debug_clocks: [workgroup][8] constant-rate (100 MHz) wall-clock stamps of the kernel's phases, or NULL
+    int grp_xcd;         // grouped launch: member 0 on XCDs 0-3, member 1 on XCDs 4-7 (grouped_xcd_map) instead of both members on every XCD
 };
 
 // phase stamp k of this workgroup (thread 0): 0 entry, 1 prologue set up (first loads issued), 2 first tile landed, 3 main loop done,
@@ -79,6 +80,20 @@ struct ConvKArgs {
 __device__ __forceinline__ int xcd_remap(int bid, int ntot) {
     const int q = ntot >> 3, r = ntot & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Grouped launch (gridDim.z == 2, ntot = tiles * splitk workgroups per member, ntot % 8 == 0) with the members on DISJOINT XCD
+// halves.  The dispatcher deals workgroups to the 8 XCDs round-robin in launch order (x fastest, then z), i.e. XCD = blockIdx.x & 7
+// for either z.  xcd_remap gives every XCD ntot/8 consecutive tiles of BOTH members: with the 1024 -> 1024 pair (8 pixel tiles x 16
+// channel tiles per member) each XCD's L2 pulls the whole input of both members (2 x 4.2 MB) and 2 x 2 channel tiles of weights
+// (2 x 2.4 MB) = 13.1 MB, 105 MB over the fabric for 44 MB of distinct operands (profiles/r03_d1_traffic.json: 114 MB fetched with
+// the residuals).  Here XCD x works on member x >> 2 only: ntot/4 consecutive tiles = 4 channel tiles x all 8 pixel tiles, i.e. one
+// input (4.2 MB) + 4.7 MB of weights = 8.9 MB per XCD, 71 MB in total.  Returns the tile index, sets the member.
+__device__ __forceinline__ int grouped_xcd_map(int bx, int bz, int ntot, int& member) {
+    const int xcd = bx & 7;
+    const int idx = (bx >> 3) + bz * (ntot >> 3);          // 0 .. ntot/4 - 1: this XCD's workgroups of both z slices
+    member = xcd >> 2;
+    return (xcd & 3) * (ntot >> 2) + idx;
 }
 
 // 16 bytes per lane, global -> LDS, asynchronous (counted by vmcnt).  `lds` must be
