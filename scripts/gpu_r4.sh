@@ -277,3 +277,16 @@ if has traintests; then  # the kernels behind the training step that changed thi
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_traintests.log | cut -c1-300 | tail -20
   lap traintests
 fi
+if has trainab; then    # training step A/B by environment (one box): weight-gradient K split target, channels-last master weights
+  rm -f /tmp/tune_train.json
+  V2V_TUNE_CACHE=/tmp/tune_train.json timeout 600 python bench.py --mode train --steps 4 --warmup 1 --no-train-parity > /dev/null 2>&1
+  runt() { env "$@" V2V_TUNE_CACHE=/tmp/tune_train.json timeout 600 python bench.py --mode train --steps 8 --warmup 2 --no-train-parity 2>gpurun_out/${TAG}_trainab.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); print('$*: train', j['value'], 'frames/s', j['ms_per_step'], 'ms per chunk')"; }
+  for rep in 1 2; do
+    for envs in ${TRAINAB:-"X=base" "V2V_WGRAD_WGS=512" "V2V_WEIGHTS_CL=1" "V2V_WEIGHTS_CL=1,V2V_WGRAD_WGS=512"}; do
+      runt $(echo $envs | tr ',' ' ')
+    done
+  done | tee gpurun_out/${TAG}_trainab.txt
+  tail -3 gpurun_out/${TAG}_trainab.err | cut -c1-300
+  lap trainab
+fi

@@ -275,46 +275,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdRedArgs a
             sc[q] = 1.f; sf[q] = 0.f; mean[q] = 0.f; inv[q] = 1.f;
             if (a.mode == 0) { sc[q] = a.stats[c]; sf[q] = a.stats[a.C + c]; mean[q] = a.stats[2 * a.C + c]; inv[q] = a.stats[3 * a.C + c]; }
         }
-        // four pixels per trip, every load issued before the first use (round 4): with one pixel per trip a thread waited for
-        // one memory latency per pixel -- 4 in a row for the 64-pixel blocks of the 1024-channel layers, a third of a launch
-        // that is a latency chain (load -> LDS -> row store -> ticket -> row loads -> store), 434 launches per training chunk.
-        // The additions happen in the same order as before (p, p + 16, p + 32, ...): bit-identical sums.
-        for (long long pb = p0 + ty; pb < p1; pb += 64) {
-            float g[4][4], r[4][4];
-            bool ok[4];
+        for (long long p = p0 + ty; p < p1; p += 16) {
+            float g[4];
+            if (a.vec) load4(dy + p * a.c_stride + c0, g);
+            else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long long p = pb + 16 * u;
-                ok[u] = p < p1;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { g[u][q] = 0.f; r[u][q] = 0.f; }
-                if (!ok[u]) continue;
-                if (a.vec) load4(dy + p * a.c_stride + c0, g[u]);
+                for (int q = 0; q < 4; ++q) g[q] = c0 + q < a.C ? load_act(dy, p * a.c_stride + c0 + q) : 0.f;
+            }
+            if (a.mode == 0) {
+                float r[4];
+                if (a.vec) load4(a.raw + p * a.c_stride_raw + c0, r);
                 else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) g[u][q] = c0 + q < a.C ? load_act(dy, p * a.c_stride + c0 + q) : 0.f;
+                    for (int q = 0; q < 4; ++q) r[q] = c0 + q < a.C ? a.raw[p * a.c_stride_raw + c0 + q] : 0.f;
                 }
-                if (a.mode == 0) {
-                    if (a.vec) load4(a.raw + p * a.c_stride_raw + c0, r[u]);
-                    else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) r[u][q] = c0 + q < a.C ? a.raw[p * a.c_stride_raw + c0 + q] : 0.f;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    g[q] *= act_grad_pre(r[q] * sc[q] + sf[q], a.act, a.act_param);
+                    s2[q] += g[q] * ((r[q] - mean[q]) * inv[q]);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!ok[u]) continue;
-                if (a.mode == 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        g[u][q] *= act_grad_pre(r[u][q] * sc[q] + sf[q], a.act, a.act_param);
-                        s2[q] += g[u][q] * ((r[u][q] - mean[q]) * inv[q]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) s1[q] += g[u][q];
-            }
+            for (int q = 0; q < 4; ++q) s1[q] += g[q];
         }
     }
 #pragma unroll
@@ -439,32 +421,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
     }
     const long long p0 = (long long)blockIdx.x * 64;
     long long p1 = p0 + 64; if (p1 > a.P) p1 = a.P;
-    // the block's 64 pixels are 4 per thread: all 8 loads in flight before the first store (each thread reads and writes
-    // only its own elements, so an in-place dRaw == dY stays correct)
-    float g[4][4], r[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const long long p = p0 + ty + 16 * u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { g[u][q] = 0.f; r[u][q] = 0.f; }
-        if (p < p1 && c0 < a.C) {
-            if (a.vec) { load4(dy + p * a.c_stride + c0, g[u]); load4(a.raw + p * a.c_stride_raw + c0, r[u]); }
+    for (long long p = p0 + ty; p < p1; p += 16) {
+        float g[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        if (c0 < a.C) {
+            if (a.vec) { load4(dy + p * a.c_stride + c0, g); load4(a.raw + p * a.c_stride_raw + c0, r); }
             else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (okc[q]) { g[u][q] = load_act(dy, p * a.c_stride + c0 + q); r[u][q] = a.raw[p * a.c_stride_raw + c0 + q]; }
+                    if (okc[q]) { g[q] = load_act(dy, p * a.c_stride + c0 + q); r[q] = a.raw[p * a.c_stride_raw + c0 + q]; }
             }
         }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const long long p = p0 + ty + 16 * u;
-        if (p >= p1) continue;
-        float o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float gg = g[u][q] * act_grad_pre(r[u][q] * sc[q] + sf[q], a.act, a.act_param);
-            o[q] = okc[q] ? sc[q] * (gg - k1[q] - (r[u][q] - mean[q]) * inv[q] * k2[q]) : 0.f;
+            const float gg = g[q] * act_grad_pre(r[q] * sc[q] + sf[q], a.act, a.act_param);
+            o[q] = okc[q] ? sc[q] * (gg - k1[q] - (r[q] - mean[q]) * inv[q] * k2[q]) : 0.f;
         }
         store4(out + p * a.c_stride_out + c0, o);
     }
