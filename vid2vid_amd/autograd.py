@@ -14,6 +14,7 @@ graph.  Conventions:
   * nothing here falls back to torch compute.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -33,6 +34,9 @@ def _grad_ptr(p):
     if g.dtype != torch.float32 or not (g.is_contiguous() or is_channels_last(g)):
         raise RuntimeError("parameter gradients must be fp32, contiguous or channels-last (optim.FlatBuffers)")
     return C.c_void_p(g.data_ptr())
+
+
+_NORM_BIAS_GRAD = os.environ.get("V2V_NORM_BIAS_GRAD", "0") == "1"
 
 
 def is_channels_last(t):
@@ -139,7 +143,13 @@ class ConvFn(torch.autograd.Function):
                                            cfg.act_param, cfg.out_scale, dt, st), "act_backward " + cfg.label)
         cs_gs = g.stride(2)
         # ---- bias ----
-        if bias is not None and bias.requires_grad:
+        # A bias in front of a training-mode norm cancels in the norm's mean: its gradient, sum_p dRaw[p][c], is zero in exact
+        # arithmetic (dRaw is mean-free by construction) and rounding noise of ~1e-7 x |dRaw| in the reference's autograd.  The
+        # exact value is accumulated here (nothing is launched); V2V_NORM_BIAS_GRAD=1 restores the summed noise (one more
+        # reduction launch per layer: 197 of the 434 channel-sum / norm-backward reductions of a 512x256 training chunk).
+        if bias is not None and bias.requires_grad and norm is not None and not _NORM_BIAS_GRAD:
+            _grad_ptr(bias)                                   # += 0: only makes sure the (zeroed) buffer exists
+        elif bias is not None and bias.requires_grad:
             ws = eng.scratch("chsum_ws", lib.v2v_bn_backward_rows(P) * 2 * cout)
             check(lib.v2v_channel_sum(_ptr(g), _grad_ptr(bias), 1, _ptr(ws), P, cout, cs_gs, dt, st),
                   "channel_sum " + cfg.label)
