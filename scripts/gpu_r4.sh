@@ -290,3 +290,20 @@ import sys, json; j = json.loads(sys.stdin.read()); print('$*: train', j['value'
   tail -3 gpurun_out/${TAG}_trainab.err | cut -c1-300
   lap trainab
 fi
+if has onechunk; then   # single-chunk ping-pong tiles 58 / 59: parity, then beside the other tiles on the fine-scale shapes
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "conv3x3_patch_kernel" > gpurun_out/${TAG}_one_tests.log 2>&1; echo "onechunk tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_one_tests.log | cut -c1-300 | tail -20
+  timeout 300 python scripts/one_bench.py 2>&1 | tee gpurun_out/${TAG}_one_bench.txt | cut -c1-400
+  lap onechunk
+fi
+if has finfused; then   # second finalize stage inside bn_partial_reduce (one launch fewer per large layer): parity, then 2048x1024 with / without on one box
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "bn_finalize or in_kernel_finalize or two_level" > gpurun_out/${TAG}_finfused_tests.log 2>&1; echo "finfused tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_finfused_tests.log | cut -c1-300 | tail -20
+  for f in 1 0 1 0; do
+    V2V_BN_FIN_FUSED=$f timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>gpurun_out/${TAG}_finfused.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); h = j['hires']; pk = h['roofline']['per_kernel_ms']
+print('V2V_BN_FIN_FUSED=$f: 512x256', j['value'], 'fps | 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms | bn_partial_reduce', pk.get('bn_partial_reduce'), 'bn_finalize', pk.get('bn_finalize'), 'parity', (h.get('parity') or {}).get('fp32_max_rel'))"
+  done | tee gpurun_out/${TAG}_finfused_ab.txt
+  tail -3 gpurun_out/${TAG}_finfused.err | cut -c1-300
+  lap finfused
+fi

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Single-channel-chunk 3x3 layers (64 bf16 input channels: the fine-scale ResnetBlocks): the single-buffer ping-pong tiles 58 / 59
+(two workgroups per CU) beside the double-buffer tiles 56 / 57 and the generic / single-phase tiles, cold cache (384 MB memset
+between launches), bf16, raw fp32 output + statistics rows as the frame runs them.
+    python scripts/one_bench.py > gpurun_out/one_bench.txt"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn as nn
+from vid2vid_amd import lib as L
+from vid2vid_amd.engine import Engine
+
+eng = Engine("cuda:0", L.BF16)
+thrash = torch.empty(96 << 20, dtype=torch.float32, device="cuda:0")
+
+
+def timed(run, reps=9):
+    for _ in range(2):
+        run()
+    ts = []
+    for _ in range(reps):
+        thrash.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+SHAPES = [("G2 res 64->64 @1024x512", 64, 64, 512, 1024), ("G1 fg res 64->64 @512x256", 64, 64, 256, 512),
+          ("64->128 @512x256", 64, 128, 256, 512), ("64->64 @256x128", 64, 64, 128, 256)]
+TILES = [(10, 1, 0), (13, 1, 0), (36, 1, 0), (54, 1, 0), (56, 1, 0), (57, 1, 0), (80, 1, 0), (83, 1, 0), (94, 1, 0), (95, 1, 0)]   # (58 / 59: the experiment of profiles/r04_d4_*, not in the tree)
+with torch.no_grad():
+    for name, cin, cout, H, W in SHAPES:
+        mod = nn.Conv2d(cin, cout, 3).to("cuda:0")
+        x = eng.pack(torch.randn(1, cin, H, W, device="cuda:0"))
+        out, ref = [], None
+        for cfg in TILES:
+            eng.tile_override[(cin, cout, 3, 1, 0)] = cfg
+            try:
+                us = timed(lambda: eng.conv(x, mod, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True))
+            except Exception as e:
+                out.append("t%d: n/a" % cfg[0]); continue
+            raw = eng.conv(x, mod, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)[0][:H * W * cout].clone()
+            if ref is None:
+                ref = raw
+            d = (raw - ref).abs().max().item()
+            out.append("t%d: %6.1f us (d %.1e)" % (cfg[0], us, d))
+        gf = 2.0 * H * W * cin * cout * 9 / 1e9
+        print("%-28s %6.1f GF | %s" % (name, gf, "  ".join(out)), flush=True)

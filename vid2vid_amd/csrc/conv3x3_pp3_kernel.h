@@ -55,7 +55,12 @@ constexpr int pending_at(int tap, int GP, int LB, int D) {
 // launch): each wave ends up with the complete sums of a 64 x 32 tile, exactly the 4 x 2 layout the shared epilogue expects.
 // KS_ = 4 ("K quads"): 2 x 1 wave tiles of 128 x 64, four K quarters -- one sub-step per wave and step, 8 MFMAs per 6 fragment reads
 // (48 KB of LDS reads per step and CU), 128 accumulator registers per lane, a three-round reduce-scatter at the end.
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1>
+// ONE = true (tiles 94 / 95): layers with a SINGLE 128-byte channel chunk (64 bf16 input channels: the ResnetBlocks of the fine
+// scales).  Such a launch is thousands of tiles of 9 tap steps (~3 us) between a prologue and an epilogue that cost more than the
+// steps; the second patch buffer is never used, so it is dropped: PATCH + ring = 80 KiB and, at this kernel's 84 registers, TWO
+// workgroups share a CU -- each one's prologue / epilogue runs under the other's main loop.  (The same idea on the ping-pong
+// kernel needed a 128-register cap, spilled and was slower: profiles/r04_d4_single_chunk_two_wg_per_cu.txt.)
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false>
 __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
     // grouped launch: which member and which tile this workgroup works on (the members have identical geometry, so the
     // tile count is known before the member is)
@@ -92,12 +97,14 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile");
     static_assert(BN % (8 * NW) == 0 && LB >= 1, "weight loader rounds");
     static_assert(D >= 3 && D <= 5, "weight slices in flight");
-    static_assert(2 * PATCH + NSB * BST <= 160 * 1024, "LDS");
-    static_assert(2 * PATCH >= 32768, "epilogue scratch lives in the patch buffers");
+    constexpr int NPB = ONE ? 1 : 2;                          // patch buffers
+    static_assert(!ONE || KS == 1, "single-chunk tiles: no accumulator exchange (it would need 64 KiB of scratch)");
+    static_assert(NPB * PATCH + NSB * BST <= 160 * 1024 / (ONE ? 2 : 1), "LDS");
+    static_assert(NPB * PATCH >= 40960, "epilogue scratch (statistics rows + a 4 KiB transposition block per wave) lives in the patch buffers");
     typedef typename Mma<T>::Frag Frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const bring = smem + 2 * PATCH;
+    char* const bring = smem + NPB * PATCH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
 
     int step = 0, stage = 0, cc = 0;                          // step being multiplied, its weight stage, its chunk
     const char* pa = smem;                                    // patch buffer of chunk cc
-    char* pn = smem + PATCH;                                  // the other one (chunk cc+1 streams in)
+    char* pn = smem + (ONE ? 0 : PATCH);                      // the other one (chunk cc+1 streams in; ONE: there is none)
 
     // iteration: multiply step `step` (tap TAP) from set PAR, fill set 1-PAR with step+1, issue the DMA of step+D
     auto iteration = [&](auto tc, auto pc) {
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
         constexpr int NT = (TAP + 1) % 9;                    // tap of the step whose fragments are read now
         constexpr int tq = (NT / 3) * PW + (NT % 3);
         constexpr int k0 = pp3::cmin(TAP * PPT, GP);
-        constexpr int npz = pp3::np_at(TAP, GP, NPT);
+        constexpr int npz = ONE ? 0 : pp3::np_at(TAP, GP, NPT);   // ONE: no next chunk (host check), no next patch
         constexpr int NDMA = LB + npz;
         // issue slots: after MFMA m (m = 0 .. NMMA-2).  The reads go first (their latency then hides behind the remaining
         // MFMAs), RPS per slot; the DMA pieces follow, one per slot
@@ -291,11 +298,11 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
         // whatever found no slot (short MFMA sequences with many pieces)
         constexpr int DMA_IN_SLOTS = pp3::cmin(NDMA, NMMA - 1 - RUSED > 0 ? NMMA - 1 - RUSED : 0);
         static_for<NDMA - DMA_IN_SLOTS>([&](auto dc) { dma(std::integral_constant<int, DMA_IN_SLOTS + decltype(dc)::value>{}); });
-        if (!(ab & 256)) wait_vmcnt<pp3::pending_at(TAP, GP, LB, D)>();
+        if (!(ab & 256)) wait_vmcnt<(ONE ? (D - 2) * LB : pp3::pending_at(TAP, GP, LB, D))>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set 1-PAR is complete; the reads of slice step+1 are retired
         ++step;
         stage = nstage;
-        if constexpr (TAP == 8) {
+        if constexpr (TAP == 8 && !ONE) {
             ++cc;
             const char* t = pa; pa = pn; pn = const_cast<char*>(t);
         }
@@ -391,12 +398,12 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     }
 }
 
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2, int KS = 1>
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2, int KS = 1, bool ONE = false>
 static int launch_pp3_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
     constexpr int NW = WGM * WGN * KS;
     constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW;
-    const size_t lds = (size_t)2 * GP * NW * 1024 + (size_t)D * BN * 128;
-    auto kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN, KS>;
+    const size_t lds = (size_t)(ONE ? 1 : 2) * GP * NW * 1024 + (size_t)D * BN * 128;
+    auto kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN, KS, ONE>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -414,6 +421,7 @@ static const PatchCfg kPp3Cfgs[] = {
     {88, 8, 32, 128}, {89, 8, 32, 64},     // ablation instances of 81 / 80
     {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
     {92, 8, 32, 64}, {93, 4, 64, 64},      // K quads: 2 x 1 wave tiles of 128 x 64, four K quarters: 6 reads per 8 MFMAs
+    {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 80 KiB, two workgroups per CU
 };
 static inline const PatchCfg* find_pp3_cfg(int id) {
     for (const PatchCfg& c : kPp3Cfgs)
@@ -436,6 +444,12 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 91: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 4, 1, 2>(k, groups, s);   // as 83 for 64-wide tile rows
         case 92: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 2, 1, 4>(k, groups, s);   // as 82, K quads
         case 93: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 2, 1, 4>(k, groups, s);   // as 83, K quads
+        case 94: case 95:                  // single-chunk tiles: bf16 only (64 input channels = one 128-byte chunk), single launches only
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                if (cfg == 94) return launch_pp3_cfg<T, 8, 32, 64, 3, 0, 4, 2, 1, true>(k, 1, s);   // as 80 with 3 slices: 48 + 24 KiB
+                return launch_pp3_cfg<T, 4, 64, 64, 3, 0, 4, 2, 1, true>(k, 1, s);                  // as 83 with 3 slices: 56 + 24 KiB
+            }
+            break;
         case 88: return launch_pp3_cfg<T, 8, 32, 128, 4, 1>(k, groups, s);
         case 89: return launch_pp3_cfg<T, 8, 32, 64, 4, 1>(k, groups, s);
     }

@@ -23,7 +23,13 @@ struct BnFinArgs {
 // rows; one workgroup reducing them serially, whether the conv kernel's last arriver or a 1-block finalize, measured
 // 0.6-1.0 ms, profiles/r01_v15_finalize_tail.txt): grid (C/64, G) blocks each reduce rows [g*rows/G, (g+1)*rows/G)
 // of 64 channels in a fixed order into fp64 (sum, sum^2) -> ws[g][C][2].  Deterministic (fixed tree).
-struct BnPartArgs { const float* partials; int rows; int C; int groups; double* ws; };
+struct BnPartArgs {
+    const float* partials; int rows; int C; int groups; double* ws;
+    // stage 2 inside the same launch (round 4): the LAST group to finish a 64-channel slab (ticket word per slab, self re-arming)
+    // runs bn_finalize_kernel<double>'s arithmetic on the group rows -- bit for bit the two-launch result, one launch fewer per
+    // large layer (the 2048x1024 frame has ~50 of them, each a dependent ~6 us launch on the frame's critical path)
+    int* ticket; BnFinArgs fin;
+};
 
 __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const BnPartArgs a) {
     __shared__ double sh[4][64][2];
@@ -44,8 +50,56 @@ __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const BnPartArgs
     sh[ph][cx][1] = s2;
     __syncthreads();
     if (ph == 0 && c < a.C) {
-        a.ws[((long long)g * a.C + c) * 2 + 0] = ((sh[0][cx][0] + sh[1][cx][0]) + sh[2][cx][0]) + sh[3][cx][0];
-        a.ws[((long long)g * a.C + c) * 2 + 1] = ((sh[0][cx][1] + sh[1][cx][1]) + sh[2][cx][1]) + sh[3][cx][1];
+        const double t1 = ((sh[0][cx][0] + sh[1][cx][0]) + sh[2][cx][0]) + sh[3][cx][0];
+        const double t2 = ((sh[0][cx][1] + sh[1][cx][1]) + sh[2][cx][1]) + sh[3][cx][1];
+        double* dst = a.ws + ((long long)g * a.C + c) * 2;
+        if (a.ticket != nullptr) {       // write-through agent-scope stores: the finalizing workgroup may sit on another XCD (L2s are not coherent)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + 1, (unsigned long long)__double_as_longlong(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else { dst[0] = t1; dst[1] = t2; }
+    }
+    if (a.ticket == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int last_flag;
+    if (threadIdx.x == 0) {
+        const int tk = __hip_atomic_fetch_add(a.ticket + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == a.groups - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(a.ticket + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the group rows were written through by their producers
+    // ---- bn_finalize_kernel<double> on the group rows, same phases, same order ----
+    const BnFinArgs& f = a.fin;
+    s1 = 0.0; s2 = 0.0;
+    if (c < a.C) {
+#pragma unroll 8
+        for (int r = ph; r < a.groups; r += 4) {
+            s1 += a.ws[((long long)r * a.C + c) * 2 + 0];
+            s2 += a.ws[((long long)r * a.C + c) * 2 + 1];
+        }
+    }
+    sh[ph][cx][0] = s1;
+    sh[ph][cx][1] = s2;
+    __syncthreads();
+    if (ph == 0 && c < a.C) {
+        s1 = ((sh[0][cx][0] + sh[1][cx][0]) + sh[2][cx][0]) + sh[3][cx][0];
+        s2 = ((sh[0][cx][1] + sh[1][cx][1]) + sh[2][cx][1]) + sh[3][cx][1];
+        const double mean = s1 * f.inv_count;
+        double var = s2 * f.inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)f.eps);
+        const double gm = f.gamma ? (double)f.gamma[c] : 1.0;
+        const double bt = f.beta ? (double)f.beta[c] : 0.0;
+        const double sc = gm * invstd;
+        f.scale_shift[c] = (float)sc;
+        f.scale_shift[a.C + c] = (float)(bt - mean * sc);
+        f.scale_shift[2 * a.C + c] = (float)mean;
+        f.scale_shift[3 * a.C + c] = (float)invstd;
+        if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+        if (f.running_var)  f.running_var[c]  = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)(var * f.unbias);
     }
 }
 
@@ -570,12 +624,6 @@ extern "C" int v2v_bn_finalize(const float* partials, int32_t rows, int32_t C, i
                                double* workspace, void* stream) {
     if (!partials || !scale_shift || rows <= 0 || C <= 0 || count <= 0) { set_error("bn_finalize: bad argument"); return V2V_EINVAL; }
     const int groups = workspace ? v2v_bn_finalize_groups(rows) : 0;
-    if (groups > 0) {
-        auto p1 = std::make_unique<BnPartOp>();
-        p1->a.partials = partials; p1->a.rows = rows; p1->a.C = C; p1->a.groups = groups; p1->a.ws = workspace;
-        int rc = submit(std::move(p1), stream);
-        if (rc != 0) return rc;
-    }
     auto op = std::make_unique<BnFinOp>();
     BnFinArgs& a = op->a;
     a.partials = groups > 0 ? reinterpret_cast<const float*>(workspace) : partials;
@@ -585,6 +633,17 @@ extern "C" int v2v_bn_finalize(const float* partials, int32_t rows, int32_t C, i
     a.unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
     a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.scale_shift = scale_shift; a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum;
+    if (groups > 0) {
+        auto p1 = std::make_unique<BnPartOp>();
+        p1->a.partials = partials; p1->a.rows = rows; p1->a.C = C; p1->a.groups = groups; p1->a.ws = workspace;
+        p1->a.ticket = nullptr; p1->a.fin = a;
+        // stage 2 by the last group of every channel slab, inside the stage-1 launch (V2V_BN_FIN_FUSED=0: the two launches)
+        static const int fused = [] { const char* e = getenv("V2V_BN_FIN_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();
+        if (fused && !v2v_get_dry_run()) p1->a.ticket = take_tickets((int)ceil_div(C, 64));
+        const bool done = p1->a.ticket != nullptr;
+        int rc = submit(std::move(p1), stream);
+        if (rc != 0 || done) return rc;
+    }
     return submit(std::move(op), stream);
 }
 
