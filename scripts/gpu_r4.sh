@@ -307,3 +307,9 @@ print('V2V_BN_FIN_FUSED=$f: 512x256', j['value'], 'fps | 2048x1024', h['value'],
   tail -3 gpurun_out/${TAG}_finfused.err | cut -c1-300
   lap finfused
 fi
+if has stagger; then    # single-chunk tiles: start-up stagger of the second workgroup slot (V2V_ONE_STAGGER x ~4096 cycles)
+  for st in 0 1 2 3 4 6; do
+    echo "V2V_ONE_STAGGER=$st"; V2V_ONE_STAGGER=$st ONE_TILES=80,94,95 timeout 200 python scripts/one_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
+  done | tee gpurun_out/${TAG}_stagger.txt
+  lap stagger
+fi

@@ -58,8 +58,11 @@ constexpr int pending_at(int tap, int GP, int LB, int D) {
 // ONE = true (tiles 94 / 95): layers with a SINGLE 128-byte channel chunk (64 bf16 input channels: the ResnetBlocks of the fine
 // scales).  Such a launch is thousands of tiles of 9 tap steps (~3 us) between a prologue and an epilogue that cost more than the
 // steps; the second patch buffer is never used, so it is dropped: PATCH + ring = 80 KiB and, at this kernel's 84 registers, TWO
-// workgroups share a CU -- each one's prologue / epilogue runs under the other's main loop.  (The same idea on the ping-pong
-// kernel needed a 128-register cap, spilled and was slower: profiles/r04_d4_single_chunk_two_wg_per_cu.txt.)
+// workgroups share a CU.  Measured (profiles/r04_d6_*, r04_d8_*, r04_d10_*): bit-identical, 0-5 % faster than tiles 80 / 83 -- the
+// co-residency buys almost nothing and a start-up stagger of the second slot only adds its own delay, because what a tile costs
+// outside its 9 steps is instruction issue (geometry, statistics, store addressing: ~7 us per tile, profiles/r04_d7_*), which two
+// workgroups on the same SIMDs share rather than overlap.  (On the ping-pong kernel the same idea needed a 128-register cap,
+// spilled and was slower: profiles/r04_d4_single_chunk_two_wg_per_cu.txt.)
 template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false>
 __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
     // grouped launch: which member and which tile this workgroup works on (the members have identical geometry, so the
