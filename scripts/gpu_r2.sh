@@ -72,7 +72,7 @@ if has prof2; then
   # tile selections of profiles/tune_cache.json are replayed by default: the profile describes the benchmarked kernels
   DOM=${DOM:-82,1,2}; NEEDLE=${NEEDLE:-conv3x3_pp3_kernelIDF16bLi8ELi32ELi64ELi5}
   cd /tmp
-  timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train-line > $R/gpurun_out/${TAG}_bench_prof.json 2> $R/gpurun_out/${TAG}_bench_prof.err; echo "rocprof rc=$?"
+  timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train-line ${PROF_FLAGS:---no-train-hires --no-c1 --no-c4 --no-train-c3 --no-hires} > $R/gpurun_out/${TAG}_bench_prof.json 2> $R/gpurun_out/${TAG}_bench_prof.err; echo "rocprof rc=$?"
   DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
   python $R/scripts/rocprof_summary.py $DB "# round 2, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline (bf16, 512x256; tile selections replayed from profiles/tune_cache.json, no autotune launches in this trace; kernels run inside the 3-lane frame graph)" > $R/gpurun_out/${TAG}_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_bench_prof.err
   head -14 $R/gpurun_out/${TAG}_kernel_stats.txt | cut -c1-200

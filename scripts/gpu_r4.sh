@@ -313,3 +313,21 @@ if has stagger; then    # single-chunk tiles: start-up stagger of the second wor
   done | tee gpurun_out/${TAG}_stagger.txt
   lap stagger
 fi
+if has final; then      # evidence for the committed line: in-graph duration (rocprofv3 kernel trace of the bench command) + PMC traffic of the dominant paired tile, copied where bench.py looks, then the driver's command
+  DOM=${DOM:-90,1,2} WGS=256 NEEDLE=${NEEDLE:-conv3x3_pp3_kernelIDF16bLi8ELi32ELi64ELi5ELi0ELi4ELi1ELi2} bash scripts/gpu_r2.sh ${TAG} prof2
+  cp gpurun_out/${TAG}_in_graph.json profiles/${TAG}_in_graph.json; cp gpurun_out/${TAG}_traffic.json profiles/${TAG}_traffic.json
+  TB=$(date +%s)
+  timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$? wall $(( $(date +%s) - TB )) s"
+  python - <<PY
+import json
+j = json.load(open("gpurun_out/${TAG}_bench_default.json"))
+print({k: v for k, v in j.items() if not isinstance(v, (dict, list))})
+r = j["roofline"]
+print("roofline", r["kernel"], r["frac"], r["avg_launch_us"], "traffic", r["traffic"], "eager", r.get("eager"), "rocprof", r.get("in_graph_rocprof"))
+print("per_kernel_ms", r["per_kernel_ms"])
+for k in ("x3", "fp32", "c1", "hires", "train", "train_hires", "c4", "train_c3", "cpu_baseline"):
+    print(k, json.dumps(j.get(k))[:1200])
+PY
+  tail -3 gpurun_out/${TAG}_bench_default.err | cut -c1-300
+  lap final
+fi
