@@ -184,7 +184,7 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
     sys.stdout = sys.stderr
     # seeded initialisation (G, D / D_T, FlowNet2, the stand-in VGG19): the parity leg below compares THIS draw with the oracle, and an
     # unseeded one made its gradient-norm figure vary with the run (reference norms 321 ... 917 over four runs, i.e. 6.8e-5 ... 1.1e-3
-    # relative for the same ~1.0 of absolute error: profiles/r04_e2_bench_default_bf16.json)
+    # relative for the same ~1.0 of absolute error: profiles/r04_e2_default_line_bf16.json)
     torch.manual_seed(0)
     models = create_model(opt)            # role mode: roles.layout_from_opt -> the three role wrappers, per-role gradient groups
     modelG, modelD, flowNet, optimizer_G, optimizer_D, optimizer_D_T = create_optimizer(opt, models)
