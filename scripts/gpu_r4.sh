@@ -331,3 +331,15 @@ PY
   tail -3 gpurun_out/${TAG}_bench_default.err | cut -c1-300
   lap final
 fi
+if has fastep; then     # full-tile fast paths of the shared conv epilogue: bit-exactness tests, then the frame at both resolutions (compare with the previous visit's numbers of the same box class)
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "conv3x3_patch_kernel or conv2d_pair or fused_norm_pair or in_kernel_norm_finalize or two_level" > gpurun_out/${TAG}_fastep_tests.log 2>&1; echo "fastep tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_fastep_tests.log | cut -c1-300 | tail -20
+  timeout 600 python -m pytest tests/test_gpu_golden.py -m gpu -q --tb=short -k "inference_api_vs_reference or composite_generator" 2>&1 | tail -3
+  for f in 1 0 1 0; do
+  V2V_EPILOGUE_FAST=$f timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 2>gpurun_out/${TAG}_fastep.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read()); r = j['roofline']; h = j['hires']
+print('V2V_EPILOGUE_FAST=$f: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms | dominant in-graph live', (r.get('in_graph_live') or {}).get('avg_launch_us'), 'eager', r['eager']['avg_launch_us'], 'conv', r['per_kernel_ms'].get('conv_igemm'), '| 2048x1024', h['value'], 'fps', h['ms_per_step'], 'ms conv', h['roofline']['per_kernel_ms'].get('conv_igemm'))"
+  done | tee gpurun_out/${TAG}_fastep_ab.txt
+  timeout 200 python scripts/one_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-330 | tee gpurun_out/${TAG}_fastep_one_bench.txt
+  lap fastep
+fi

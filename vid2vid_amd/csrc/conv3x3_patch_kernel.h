@@ -271,7 +271,7 @@ __global__ __launch_bounds__((WGM * WGN + NL + NPF) * 64) void conv3x3_patch_ker
             const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
             if (oh >= H || ow >= W) return -1;
             return (n_img * H + oh) * W + ow;
-        });
+        }, oh0 + TH <= H && ow0 + TW <= W);
 }
 
 template <typename T, int TH, int TW, int BN, int WGM, int WGN, int NSB, int NL, int NPF>

@@ -334,13 +334,14 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     __syncthreads();
     V2V_STAMP(p, 3);
 
+    const bool tile_full = oh0 + TH <= H && ow0 + TW <= W;    // every row of the tile is a pixel of the layer (uniform: conv_epilogue's fast paths)
     auto pix_of = [&](int row) -> int {        // TW is a power of two; N*OH*OW < 2^31 (host check)
         const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
         if (oh >= H || ow >= W) return -1;
         return (n_img * H + oh) * W + ow;
     };
     if constexpr (KS == 1) {
-        conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of);
+        conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full);
     } else if constexpr (KS == 4) {
         // K quads: the four waves of a 128-row wave tile each hold one K quarter of all of it.  Reduce-scatter in three rounds: in
         // round d wave h hands row tile (h + d) % 4 to wave (h + d) % 4 of its quad and collects its own row tile h from wave
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
                 for (int r = 0; r < 16; ++r) acc4[0][j][r] += xch[((from * TN + j) * 16 + r) * 64 + lane];
             __syncthreads();
         }
-        conv_epilogue<T, BM, BN, WGM * 4, WGN, ABL == 0>(p, acc4, smem, tid, wm * 4 + wk, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of);
+        conv_epilogue<T, BM, BN, WGM * 4, WGN, ABL == 0>(p, acc4, smem, tid, wm * 4 + wk, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full);
     } else {
         // K pairs: wave (tile, half h) keeps column tile j = h of its 64-wide wave tile and hands column tile 1 - h to its partner
         // (wave id ^ 1), which holds the other half of the K sum for it.  Same lane <-> element map on both sides (same MFMA
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
             }
         __syncthreads();                                      // the exchange area becomes the epilogue's scratch
         // 4 x 2 layout of 64 x 32 tiles: this wave's tile is (wm, 2 * wn + wk)
-        conv_epilogue<T, BM, BN, WGM, 2 * WGN, ABL == 0>(p, acc2, smem, tid, wm, 2 * wn + wk, false, cls, tiles, lin, slice, S, nt, mt, pix_of);
+        conv_epilogue<T, BM, BN, WGM, 2 * WGN, ABL == 0>(p, acc2, smem, tid, wm, 2 * wn + wk, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full);
     }
 }
 

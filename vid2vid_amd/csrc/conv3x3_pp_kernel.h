@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvKArgs p) {
             const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
             if (oh >= H || ow >= W) return -1;
             return (n_img * H + oh) * W + ow;
-        });
+        }, oh0 + TH <= H && ow0 + TW <= W);
 }
 
 template <typename T, int TH, int TW, int BN, int NSB>

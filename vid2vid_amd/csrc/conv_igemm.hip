@@ -684,6 +684,10 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.cls_rev = rev;
     }
     k.pf_dist = (d->prefetch > 0 && (conv_cfg_has_helper(op->cfg) || (op->cfg >= 32 && op->cfg <= 37))) ? d->prefetch : 0;
+    {
+        static const int ep_fast = [] { const char* e = getenv("V2V_EPILOGUE_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
+        k.ep_slow = ep_fast ? 0 : 1;
+    }
     k.pf_mask = (k.pf_dist > 0 && k.m_tiles >= 8) ? 3 : 0;      // 1 prefetching workgroup per 4 M tiles of an N column
     return 0;
 }

@@ -60,6 +60,7 @@ struct ConvKArgs {
     int fin_rows;        // statistics rows (= finalize tickets) per channel tile when it is not gridDim.y * m_tiles (conv3x3_t2_kernel: 4 m_tiles), else 0
     unsigned long long* dbg;   // v2v_conv_debug_clocks: [workgroup][8] constant-rate (100 MHz) wall-clock stamps of the kernel's phases, or NULL
     int grp_xcd;         // grouped launch: member 0 on XCDs 0-3, member 1 on XCDs 4-7 (grouped_xcd_map) instead of both members on every XCD
+    int ep_slow;         // V2V_EPILOGUE_FAST=0: full tiles take the predicated epilogue paths too (A/B switch of conv_epilogue's fast paths)
 };
 
 // phase stamp k of this workgroup (thread 0): 0 entry, 1 prologue set up (first loads issued), 2 first tile landed, 3 main loop done,
@@ -134,7 +135,7 @@ template <typename T, int BM, int BN, int WGM, int WGN, bool FUSED_NORM = false,
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], char* smem,
                                               const int tid, const int wm, const int wn, const bool helper,
                                               const int cls, const int tiles, const int lin, const int slice, const int S,
-                                              const int nt, const int stat_row, PixOf pix_of) {
+                                              const int nt, const int stat_row, PixOf pix_of, const bool tile_full = false) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NW = WGM * WGN;
@@ -228,14 +229,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
     // arithmetic per element, bitwise identical results.
     float* red = reinterpret_cast<float*>(smem);   // [WGM][BN][2]
     const bool want_stats = p.stats != nullptr;
+    // FULL tiles (round 4): the caller knows (one scalar test) that every row of the tile is a pixel of the layer; with every
+    // channel of the tile inside the layer as well, no element needs a predicate -- the 32 per-lane row -> pixel evaluations
+    // below and the compare / select pair of every statistics update go away (~450 of the ~900 vector instructions a wave
+    // spends behind the main loop: profiles/r04_d7_fine_scale_conv_ablate.txt).  Wave-uniform branch, the same
+    // additions in the same order: bit-identical results; ragged tiles, ragged channel tiles and the helper wave take the old path.
+    const bool fast = tile_full && !p.ep_slow && !helper && !(p.ablate & 4) && (nt + 1) * BN <= p.cout &&
+                      (p.out_mode == V2V_OUT_RAW_F32_NHWC || (FUSED_NORM && p.out_mode == V2V_OUT_NORM_ACT_NHWC));   // the two paths with a fast form
     int opx[TM][16];                               // output pixel index of this lane's rows, < 0: outside the layer
+    if (!fast) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = pix_of(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
-            opx[i][r] = (helper || (p.ablate & 4)) ? -1 : o;
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int o = pix_of(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                opx[i][r] = (helper || (p.ablate & 4)) ? -1 : o;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) opx[i][r] = 0;         // never read on the fast paths; any valid value for the others
+    }
     const unsigned cs_out = (unsigned)p.cout_stride;
     if constexpr (FUSED_NORM) {
         if (p.out_mode == V2V_OUT_NORM_ACT_NHWC) {
@@ -247,6 +262,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                 const bool nvalid = ncol < p.cout;
                 const float bv = (p.bias != nullptr && nvalid) ? p.bias[ncol] : 0.f;
                 float s1 = 0.f, s2 = 0.f;
+                if (fast) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[i][j][r] + bv;
+                            s1 += v;
+                            s2 = __builtin_fmaf(v, v, s2);
+                        }
+                } else {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -256,6 +281,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                             s1 += v;
                             s2 = __builtin_fmaf(v, v, s2);          // explicit: the raw and the fused-norm paths must round alike
                         }
+                }
                 s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 32);
                 if (hi == 0) {
@@ -458,6 +484,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                if (fast) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r] + bv;
+                        s1 += v;
+                        s2 = __builtin_fmaf(v, v, s2);
+                        tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lr] = v;
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[i][j][r] + bv;
@@ -466,6 +501,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                         s2 = __builtin_fmaf(v, v, s2);          // explicit: the raw and the fused-norm paths must round alike
                     }
                     tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lr] = v;
+                }
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
