@@ -90,20 +90,14 @@ __global__ __launch_bounds__((WGM * WGN + NL + NPF) * 64) void conv3x3_patch_ker
     const int tiles = p.m_tiles * p.n_tiles;
     const int S = p.splitk;
     const int lin_all = xcd_remap(blockIdx.x, tiles * S);
-    const int lin = lin_all / S;
-    const int slice = lin_all - lin * S;
-    const int nt = lin / p.m_tiles;
-    const int mt = lin - nt * p.m_tiles;
-    const int tpi = p.tiles_h * p.tiles_w;                    // tiles per image
-    const int n_img = mt / tpi;
-    const int trem = mt - n_img * tpi;
-    const int th = trem / p.tiles_w;
-    const int oh0 = th * TH, ow0 = (trem - th * p.tiles_w) * TW;
+    int lin, slice, nt, mt, n_img, th, twi;
+    patch_tile_index(p, lin_all, lin, slice, nt, mt, n_img, th, twi);
+    const int oh0 = th * TH, ow0 = twi * TW;
 
     const int H = p.H, W = p.W, cs = p.cin_stride;
     const int ncc_all = cs * (int)sizeof(T) / 128;            // channel chunks (host guarantees cs*sizeof % 128 == 0)
-    const int ccb = (int)(((long long)ncc_all * slice) / S);
-    const int ncc = (int)(((long long)ncc_all * (slice + 1)) / S) - ccb;
+    int ccb, ncc;
+    patch_chunk_range(ncc_all, slice, S, ccb, ncc);
     const int nsteps = ncc * 9;
     const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
     const char* const zp = p.zero_page;

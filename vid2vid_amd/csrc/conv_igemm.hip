@@ -654,6 +654,14 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.n_tiles = (int)ceil_div(d->cout, c->BN);
         tile_bm = c->BM; tile_bn = c->BN;
     }
+    if (op->cfg >= 32 && k.tiles_h > 0 && k.tiles_w > 0 && k.m_tiles > 0) {   // patch kernels: tile-index divisions by multiplication (ConvKArgs.idx_m)
+        const uint32_t dv[3] = {(uint32_t)k.m_tiles, (uint32_t)(k.tiles_h * k.tiles_w), (uint32_t)k.tiles_w};
+        for (int i = 0; i < 3; ++i) {
+            uint32_t m = 0; int32_t l = 0;
+            if (v2v_fastdiv_magic(dv[i], &m, &l) != 0) return V2V_EINVAL;
+            k.idx_m[i] = m; k.idx_l[i] = l;
+        }
+    }
     // ---- split-K / weight prefetch ----
     k.splitk = d->splitk > 1 ? d->splitk : 1;
     int nk_min = k.kpad[0] / bke_of(d->dtype);

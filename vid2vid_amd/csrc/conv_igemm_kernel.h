@@ -61,6 +61,10 @@ struct ConvKArgs {
     unsigned long long* dbg;   // v2v_conv_debug_clocks: [workgroup][8] constant-rate (100 MHz) wall-clock stamps of the kernel's phases, or NULL
     int grp_xcd;         // grouped launch: member 0 on XCDs 0-3, member 1 on XCDs 4-7 (grouped_xcd_map) instead of both members on every XCD
     int ep_slow;         // V2V_EPILOGUE_FAST=0: full tiles take the predicated epilogue paths too (A/B switch of conv_epilogue's fast paths)
+    // patch kernels (tiles >= 32): exact division of the tile index by m_tiles, tiles_h * tiles_w and tiles_w as q = (umulhi(M, n) + n) >> l
+    // (v2v_fastdiv_magic) -- three scalar instructions each instead of the ~30 of a run-time division, which every wave of every
+    // workgroup executed four times before its first load (and two 64-bit divisions for the split-K chunk range, now behind S > 1)
+    unsigned idx_m[3]; int idx_l[3];
 };
 
 // phase stamp k of this workgroup (thread 0): 0 entry, 1 prologue set up (first loads issued), 2 first tile landed, 3 main loop done,
@@ -95,6 +99,30 @@ __device__ __forceinline__ int grouped_xcd_map(int bx, int bz, int ntot, int& me
     const int idx = (bx >> 3) + bz * (ntot >> 3);          // 0 .. ntot/4 - 1: this XCD's workgroups of both z slices
     member = xcd >> 2;
     return (xcd & 3) * (ntot >> 2) + idx;
+}
+
+__device__ __forceinline__ int fast_div(int n, unsigned M, int l) { return (int)((__umulhi(M, (unsigned)n) + (unsigned)n) >> l); }
+
+// tile index of a patch-kernel workgroup -> (K slice, channel tile, pixel tile, image, tile row, tile column); see ConvKArgs.idx_m
+__device__ __forceinline__ void patch_tile_index(const ConvKArgs& p, const int lin_all, int& lin, int& slice, int& nt, int& mt,
+                                                 int& n_img, int& th, int& tw) {
+    const int S = p.splitk;
+    lin = lin_all; slice = 0;
+    if (S > 1) { lin = lin_all / S; slice = lin_all - lin * S; }
+    nt = fast_div(lin, p.idx_m[0], p.idx_l[0]);
+    mt = lin - nt * p.m_tiles;
+    n_img = fast_div(mt, p.idx_m[1], p.idx_l[1]);
+    const int trem = mt - n_img * (p.tiles_h * p.tiles_w);
+    th = fast_div(trem, p.idx_m[2], p.idx_l[2]);
+    tw = trem - th * p.tiles_w;
+}
+// channel chunks [ccb, ccb + ncc) of K slice `slice` of S (whole 128-byte chunks; S == 1: all of them, no division)
+__device__ __forceinline__ void patch_chunk_range(const int ncc_all, const int slice, const int S, int& ccb, int& ncc) {
+    ccb = 0; ncc = ncc_all;
+    if (S > 1) {
+        ccb = (int)(((long long)ncc_all * slice) / S);
+        ncc = (int)(((long long)ncc_all * (slice + 1)) / S) - ccb;
+    }
 }
 
 // 16 bytes per lane, global -> LDS, asynchronous (counted by vmcnt).  `lds` must be
