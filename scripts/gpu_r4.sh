@@ -343,3 +343,11 @@ print('V2V_EPILOGUE_FAST=$f: 512x256', j['value'], 'fps', j['ms_per_step'], 'ms 
   timeout 200 python scripts/one_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-330 | tee gpurun_out/${TAG}_fastep_one_bench.txt
   lap fastep
 fi
+if has evidence2; then  # end-of-round evidence: per-op dumps of both resolutions (per-layer roofline tables) and the steady-state training table
+  timeout 600 python bench.py --no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3 --dump-ops gpurun_out/${TAG}_ops_bf16.json > gpurun_out/${TAG}_benchq.json 2> gpurun_out/${TAG}_benchq.err; echo "benchq rc=$?"
+  python scripts/per_layer_roofline.py gpurun_out/${TAG}_ops_bf16.json > gpurun_out/${TAG}_per_layer_roofline.txt 2>&1; tail -3 gpurun_out/${TAG}_per_layer_roofline.txt | cut -c1-300
+  python scripts/per_layer_roofline_hires.py gpurun_out/${TAG}_ops_bf16.json.hires.json > gpurun_out/${TAG}_per_layer_roofline_hires.txt 2>&1; tail -3 gpurun_out/${TAG}_per_layer_roofline_hires.txt | cut -c1-400
+  python -c "
+import json; j = json.load(open('gpurun_out/${TAG}_benchq.json')); print('512x256', j['value'], j['ms_per_step'], 'eager sum', j['roofline']['frame_ms_eager_events'], '| 2048x1024', j['hires']['value'], j['hires']['ms_per_step'], 'eager sum', j['hires']['roofline']['frame_ms_eager_events'])"
+  lap ops
+fi
