@@ -187,3 +187,67 @@ def test_fastdiv_magic_divides_exactly():
                 assert (t + n) >> sh == n // d, (n, d, M, sh)
     m, l = C.c_uint32(0), C.c_int32(0)
     assert L.lib.v2v_fastdiv_magic(0, C.byref(m), C.byref(l)) != 0
+
+
+def test_grouped_xcd_map_is_a_bijection_with_one_member_per_xcd():
+    """csrc/conv_igemm_kernel.h grouped_xcd_map (paired launches, round 4): restated on the host -- every (member, tile) pair is
+    worked on by exactly one workgroup, XCD x (= blockIdx.x & 7, whichever z) works on member x >> 2 only, and an XCD's tiles are
+    one contiguous run of ntot / 4 tiles (4 channel tiles x all pixel tiles for the 1024 -> 1024 pair: one input + a quarter of
+    the weights per XCD instead of both inputs + an eighth of each member's weights)."""
+    def grouped_xcd_map(bx, bz, ntot):
+        xcd = bx & 7
+        idx = (bx >> 3) + bz * (ntot >> 3)
+        return xcd >> 2, (xcd & 3) * (ntot >> 2) + idx
+    for ntot in (8, 16, 128, 256, 1024):
+        seen = {}
+        per_xcd = {}
+        for bz in (0, 1):
+            for bx in range(ntot):
+                member, tile = grouped_xcd_map(bx, bz, ntot)
+                assert 0 <= tile < ntot and member in (0, 1)
+                assert (member, tile) not in seen, (ntot, bx, bz)
+                seen[(member, tile)] = (bx, bz)
+                per_xcd.setdefault(bx & 7, []).append((member, tile))
+        assert len(seen) == 2 * ntot
+        for xcd, lst in per_xcd.items():
+            assert {m for m, _ in lst} == {xcd >> 2}
+            tiles = sorted(t for _, t in lst)
+            assert tiles == list(range(tiles[0], tiles[0] + ntot // 4)) and tiles[0] == (xcd & 3) * (ntot // 4)
+    # the 1024 -> 1024 pair: 8 pixel tiles x 16 channel tiles per member, channel tile = tile // 8
+    chan_tiles = {}
+    for bz in (0, 1):
+        for bx in range(128):
+            member, tile = grouped_xcd_map(bx, bz, 128)
+            chan_tiles.setdefault(bx & 7, set()).add((member, tile // 8))
+    assert all(len(v) == 4 for v in chan_tiles.values())          # 4 channel tiles of ONE member per XCD (was 2 + 2)
+
+
+def test_patch_tile_index_by_multiplication_equals_the_divisions():
+    """csrc/conv_igemm_kernel.h patch_tile_index: tile index -> (channel tile, pixel tile, image, tile row, tile column) with the
+    library's magic numbers (ConvKArgs.idx_m / idx_l) instead of run-time divisions -- same values for every tile of the BASELINE
+    geometries and a few ragged ones."""
+    import ctypes as C
+    from vid2vid_amd import lib as L
+
+    def magic(d):
+        m, l = C.c_uint32(0), C.c_int32(0)
+        assert L.lib.v2v_fastdiv_magic(d, C.byref(m), C.byref(l)) == 0
+        return m.value, l.value
+
+    def fdiv(n, ml):
+        return (((ml[0] * n) >> 32) + n) >> ml[1]
+
+    for N, OH, OW, TH, TW, cout, BN in [(1, 32, 64, 8, 32, 1024, 64), (1, 512, 1024, 8, 32, 64, 64), (1, 512, 1024, 4, 64, 64, 64),
+                                        (2, 37, 70, 4, 32, 200, 128), (3, 9, 33, 2, 64, 40, 64), (1, 1024, 2048, 8, 32, 32, 64)]:
+        tiles_h, tiles_w = -(-OH // TH), -(-OW // TW)
+        m_tiles, n_tiles = N * tiles_h * tiles_w, -(-cout // BN)
+        mm, mt_, mw = magic(m_tiles), magic(tiles_h * tiles_w), magic(tiles_w)
+        step = max(1, (m_tiles * n_tiles) // 5000)
+        for lin in list(range(0, m_tiles * n_tiles, step)) + [m_tiles * n_tiles - 1]:
+            nt = fdiv(lin, mm); mt = lin - nt * m_tiles
+            n_img = fdiv(mt, mt_); trem = mt - n_img * tiles_h * tiles_w
+            th = fdiv(trem, mw); tw = trem - th * tiles_w
+            assert (nt, mt) == divmod(lin, m_tiles)
+            assert (n_img, trem) == divmod(mt, tiles_h * tiles_w)
+            assert (th, tw) == divmod(trem, tiles_w)
+            assert 0 <= nt < n_tiles and 0 <= n_img < N and 0 <= th < tiles_h and 0 <= tw < tiles_w
