@@ -32,6 +32,132 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "x3": 2500.0 / 3}   # dense MFMA peaks, MI355X_MICROARCH.md (x3: three bf16 products per product)
 KERNEL_FAMILY = "conv_igemm"
 
+LINE_BUDGET = 6000          # bytes of the ONE stdout line (the driver keeps a 10 KB stdout tail and parses its last line)
+FULL_RECORD = "bench_full.json"
+
+
+def _clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(full):
+    """The ONE stdout line: contract keys, the flat scalars, `config`, `roofline`, `cpu_baseline`, `timing` -- nothing nested deeper
+    than that.  Every companion object (parity tables, hires / c1 / c4 / train legs, per-kernel tables) stays in the full record
+    (`bench_full.json`).  Strings are clipped until the serialised line fits LINE_BUDGET."""
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full.get(k) for k in contract}
+    for k, v in full.items():                                    # flat scalars (parity_value, hires_value, train_value, *_fp32_ok ...)
+        if k not in out and (v is None or isinstance(v, (bool, int, float, str))):
+            out[k] = v
+    # per-leg scalars the nested objects carry (value + parity verdicts), flattened
+    for leg in ("hires", "c1", "c4", "train", "train_hires", "train_c3", "fp32", "x3", "host_fed"):
+        o = full.get(leg)
+        if not isinstance(o, dict):
+            continue
+        if "error" in o:
+            out[leg + "_error"] = _clip(o["error"], 120)
+            continue
+        if "value" in o:
+            out.setdefault(leg + "_value", o["value"])
+        p = o.get("parity")
+        if isinstance(p, dict):
+            for pk in ("fp32_ok", "x3_ok", "fp32_max_rel", "x3_max_rel", "bf16_max_rel"):
+                if isinstance(p.get(pk), (bool, int, float)):
+                    out.setdefault("%s_%s" % (leg, pk), p[pk])
+            f32 = p.get("fp32")
+            if isinstance(f32, dict):
+                for pk in ("max_forward", "max_loss", "max_grad_norm", "max_grad_l2"):
+                    if isinstance(f32.get(pk), (int, float)):
+                        out.setdefault("%s_fp32_%s" % (leg, pk), f32[pk])
+        if isinstance(o.get("cpu_baseline"), dict) and "value" in o["cpu_baseline"]:
+            out.setdefault(leg + "_cpu_value", o["cpu_baseline"]["value"])
+        if isinstance(o.get("flownet2"), dict) and "pairs_per_s" in o["flownet2"]:
+            out.setdefault(leg + "_flownet2_pairs_per_s", o["flownet2"]["pairs_per_s"])
+        if "frac_of_mfma_peak" in o:
+            out.setdefault(leg + "_frac_of_mfma_peak", o["frac_of_mfma_peak"])
+        if "peak_memory_gb" in o:
+            out.setdefault(leg + "_peak_memory_gb", o["peak_memory_gb"])
+    par = full.get("parity")
+    if isinstance(par, dict):
+        for pk in ("fp32_ok", "fp32_max_rel", "bf16_max_rel", "bf16_mean_rel", "tolerance_fp32"):
+            if isinstance(par.get(pk), (bool, int, float)):
+                out.setdefault("parity_" + pk, par[pk])
+        if "error" in par:
+            out["parity_error"] = _clip(par["error"], 120)
+    t = full.get("timing")
+    if isinstance(t, dict):
+        out["timing"] = {k: t[k] for k in ("windows_ms_per_step", "statistic", "warmup_frames_run") if k in t}
+    c = full.get("config")
+    if isinstance(c, dict):
+        out["config"] = {k: v for k, v in c.items() if v is None or isinstance(v, (bool, int, float, str))}
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if k in r}
+        for k in ("avg_launch_us", "launches_per_frame", "flop_per_launch", "flop_per_step", "conv_launches_per_step", "measured", "resblock_1024_tflops"):
+            if k in r:
+                rr[k] = r[k]
+        td = r.get("traffic_detail")
+        if isinstance(td, dict):
+            rr["algorithmic_bytes_per_launch"] = td.get("algorithmic_bytes_per_launch")
+            rr["traffic_source"] = td.get("source")
+        for k in ("eager", "in_graph_live", "in_graph_rocprof"):
+            if isinstance(r.get(k), dict):
+                rr[k + "_us"] = r[k].get("avg_launch_us")
+                rr[k + "_frac"] = r[k].get("frac")
+        if isinstance(r.get("frame_in_graph"), dict):
+            rr["frame_frac"] = r["frame_in_graph"].get("frac")
+        out["roofline"] = rr
+    cb = full.get("cpu_baseline")
+    out["cpu_baseline"] = None if not isinstance(cb, dict) else {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+    if isinstance(full.get("leg_seconds"), dict):
+        out["leg_seconds"] = full["leg_seconds"]
+    out["full_record"] = FULL_RECORD
+    # clip strings until the line fits
+    for limit in (400, 240, 160, 100, 60):
+        if len(json.dumps(out, allow_nan=False, default=_nonfinite)) <= LINE_BUDGET:
+            break
+        for d in (out, out.get("config") or {}, out.get("roofline") or {}, out.get("cpu_baseline") or {}):
+            for k, v in list(d.items()):
+                if isinstance(v, str):
+                    d[k] = _clip(v, limit)
+    return _finite(out)
+
+
+def _nonfinite(o):
+    return repr(o)
+
+
+def _finite(o):
+    """NaN / +-Infinity are not JSON: a strict parser must read the line."""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def emit_record(full, stdout=None):
+    """Full record -> bench_full.json (repo root and gpurun_out/ when it exists); compact line -> stdout (exactly one line, written last)."""
+    stdout = stdout or sys.stdout
+    full = _finite(full)
+    text = json.dumps(full, allow_nan=False)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, FULL_RECORD), "w") as f:
+                    f.write(text + "\n")
+        except OSError as ex:
+            sys.stderr.write("bench: could not write %s in %s: %r\n" % (FULL_RECORD, d, ex))
+    # (the full record is NOT echoed to stderr: a driver that merges the two streams into one 10 KB tail must still end in the line)
+    sys.stderr.write("bench: full record (%d bytes) in %s\n" % (len(text), FULL_RECORD))
+    sys.stderr.flush()
+    line = json.dumps(compact_line(full), allow_nan=False)
+    assert len(line) <= LINE_BUDGET + 2000 and "\n" not in line, len(line)
+    stdout.write(line + "\n")
+    stdout.flush()
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -68,7 +194,8 @@ def parse():
     ap.add_argument("--no-train-c3", action="store_true", help="infer: skip the BASELINE configs[2] geometry training leg (1024x512, 2 scales) reported under \"train_c3\"")
     ap.add_argument("--no-c1", action="store_true", help="infer: skip the literal BASELINE configs[0] leg (256x128 2-frame clip, GPU vs CPU oracle) reported under \"c1\"")
     ap.add_argument("--no-train-hires", action="store_true", help="infer: skip the 2048x1024 / 3-scale training chunk (configs[4] geometry on one GPU) reported under \"train_hires\"")
-    ap.add_argument("--no-train-hires-parity", action="store_true", help="infer: time the 2048x1024 training chunk but skip its CPU-oracle parity (minutes of host time)")
+    ap.add_argument("--train-hires-parity", action="store_true", help="infer: also run the 2048x1024 training chunk's CPU-oracle parity inside the bench (minutes of host "
+                    "time; the same check is tests/test_gpu_golden.py::test_full_width_training_chunk_2048x1024_s3_vs_oracle)")
     ap.add_argument("--n-gpus-gen", type=int, default=-1, help="train: the reference's --n_gpus_gen; smaller than --group-size selects the generator / "
                     "discriminator rank roles (vid2vid_amd/roles.py), e.g. --gpus 8 --group-size 8 --n-gpus-gen 6 = configs[4]'s 6 G + 2 D layout")
     ap.add_argument("--group-size", type=int, default=0, help="train: GPUs that share ONE sequence (len of the reference's --gpu_ids); 0 = 1 (plain data parallelism)")
@@ -360,13 +487,13 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
             "parity": parity, "roofline": roofline, "flownet2": flownet_line, "cpu_baseline": None,
         }
         if emit:
-            print(json.dumps(out))
-            sys.stdout.flush()
+            emit_record(out, _stdout)
         return out
     return None
 
 
 def main():
+    t_main = time.perf_counter()
     args = parse()
     import torch
     import torch.distributed as dist
@@ -1106,6 +1233,7 @@ def main():
                 "parity": par, "cpu_baseline": cpu_line}
 
     sys.stdout = _stdout
+    leg_s = {"headline": round(time.perf_counter() - t_main, 1)}      # wall seconds per leg of the default command (full record)
     if rank == 0:
         out = {
             "metric": "synthesized frames/sec (Vid2VidModelG.inference, %dx%d)" % (W, H),
@@ -1145,7 +1273,9 @@ def main():
             try:
                 model = fp = None
                 torch.cuda.empty_cache()
+                _t = time.perf_counter()
                 out["hires"] = hires_companion()
+                leg_s["hires"] = round(time.perf_counter() - _t, 1)
             except Exception as ex:
                 import traceback
                 traceback.print_exc()
@@ -1158,7 +1288,9 @@ def main():
             try:
                 model = fp = None
                 torch.cuda.empty_cache()
+                _t = time.perf_counter()
                 out["c1"] = c1_clip()
+                leg_s["c1"] = round(time.perf_counter() - _t, 1)
             except Exception as ex:
                 import traceback
                 traceback.print_exc()
@@ -1171,7 +1303,9 @@ def main():
             try:
                 model = fp = None
                 torch.cuda.empty_cache()
+                _t = time.perf_counter()
                 out["c4"] = c1_clip(c4=True)
+                leg_s["c4"] = round(time.perf_counter() - _t, 1)
             except Exception as ex:
                 import traceback
                 traceback.print_exc()
@@ -1188,7 +1322,9 @@ def main():
                 targs.mode, targs.steps, targs.warmup, targs.no_vgg = "train", 6, 2, False
                 for k_, v_ in over.items():
                     setattr(targs, k_, v_)
+                _t = time.perf_counter()
                 tr = run_train(targs, dev, rank, 1, local_rank, emit=False)
+                leg_s[key] = round(time.perf_counter() - _t, 1)
                 out[key] = {"metric": tr["metric"], "value": tr["value"], "unit": tr["unit"], "ms_per_step": tr["ms_per_step"],
                             "steps": tr["steps"], "warmup": tr["warmup"], "dtype": tr["dtype"],
                             "frac_of_mfma_peak": tr["roofline"]["frac"], "tflops": tr["roofline"]["achieved"],
@@ -1212,7 +1348,7 @@ def main():
         if world == 1 and not args.no_train_hires and not face and args.scales == 1 and (W, H) == (512, 256):
             model = None
             train_companion("train_hires", width=2048, height=1024, scales=3, num_D=4, frames_total=6, frames_per_gpu=1,
-                            no_train_parity=bool(args.no_train_hires_parity or args.no_cpu_baseline), no_bf16_train_parity=True)
+                            no_train_parity=bool(not args.train_hires_parity or args.no_cpu_baseline), no_bf16_train_parity=True)
         # ---- BASELINE configs[2] geometry as a training chunk on one GPU (1024x512, n_scales_spatial=2, num_D=3): frames trained/s only --
         # its fp32 chunk-vs-oracle parity is tests/test_gpu_golden.py::test_full_width_training_chunk_1024x512_s2_vs_oracle ----
         if world == 1 and not args.no_train_c3 and not face and args.scales == 1 and (W, H) == (512, 256):
@@ -1235,12 +1371,13 @@ def main():
             flat["train_hires_fp32_ok"] = out["train_hires"]["parity"].get("fp32_ok")
         if isinstance(out.get("train"), dict) and isinstance(out["train"].get("parity"), dict):
             flat["train_fp32_ok"] = out["train"]["parity"].get("fp32_ok")
+        leg_s["total"] = round(time.perf_counter() - t_main, 1)
+        out["leg_seconds"] = leg_s
         head = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
         head.update(flat)
         head.update({k: v for k, v in out.items() if k not in head})
         out = head
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit_record(out, _stdout)
     if world > 1:
         dist.destroy_process_group()
 

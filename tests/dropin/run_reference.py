@@ -66,6 +66,12 @@ def rank_forward(self, *a, **k):
     name = type(self.module).__name__
     count(name + ".forward")
     report["shapes"].setdefault(name, shapes_of(out))
+    if name == "Vid2VidModelD":
+        # dry run: nothing executed, the loss tensors hold whatever the allocator returned.  The reference's printer skips losses
+        # that are exactly 0 (util/visualizer.py print_current_errors), so give them a defined non-zero value -- the test that
+        # every loss NAME reaches the log must not depend on heap garbage (it failed under MALLOC_PERTURB_=255, which zeroes mallocs)
+        for o in out:
+            o.data.fill_(1.0)
     return out
 
 

@@ -176,6 +176,7 @@ def _ref_ops():
     return R
 
 
+@pytest.mark.ref_checker
 def test_native_op_oracles_vs_executed_reference_kernels():
     """The PIN of the three CUDA-only ops: the reference's own kernel bodies (correlation_cuda_kernel.cu:16-147,
     resample2d_kernel.cu:15-190, channelnorm_kernel.cu:18-96), compiled unmodified from /root/reference by

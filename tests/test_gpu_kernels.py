@@ -1107,6 +1107,7 @@ def test_flownet2_native_ops():
     assert_close(out.cpu(), torch.from_numpy(S2.channelnorm_forward(x.numpy())), 1e-6, "channelnorm vs scalar transliteration")
 
 
+@pytest.mark.ref_checker
 def test_flownet2_native_ops_vs_executed_reference_kernels():
     """The HIP kernels against the reference's OWN CUDA kernel bodies executed on host cores (oracle/ref_ops.py: compiled
     from /root/reference by oracle/ref_ops/build.sh, 32-lane warp semantics; the library travels with the snapshot):
@@ -1120,7 +1121,9 @@ def test_flownet2_native_ops_vs_executed_reference_kernels():
     torch.manual_seed(19)
     P = lambda t: C.c_void_p(t.data_ptr())
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for (n, c, h, w, pad, k, md, s1, s2) in [(1, 72, 5, 9, 20, 1, 20, 1, 2), (2, 9, 6, 5, 4, 1, 4, 1, 2), (1, 6, 9, 11, 5, 3, 4, 2, 1)]:       # (pad >= max_disp + kernel radius: the reference kernel reads out of bounds otherwise)
+    for (n, c, h, w, pad, k, md, s1, s2) in [(1, 72, 5, 9, 20, 1, 20, 1, 2), (2, 9, 6, 5, 4, 1, 4, 1, 2), (1, 6, 9, 11, 5, 3, 4, 2, 1)]:
+        # (the kernel_size = 3 case: the reference kernel reads rows / columns -1 of its padded buffer for EVERY kernel_size > 1, whatever
+        # the pad (correlation_cuda_kernel.cu:90-91,111-123); oracle/ref_ops/ref_correlation.cpp gives those reads a zero guard band)
         a, b = torch.randn(n, c, h, w), torch.randn(n, c, h, w)
         ref = R.correlation(a, b, pad, k, md, s1, s2)
         out = torch.full(ref.shape, float("nan"), device=DEV)
