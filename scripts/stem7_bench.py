@@ -36,7 +36,7 @@ with torch.no_grad():
         if x.Cs % 64 != 0:
             x = eng.widen(x, (x.Cs + 63) // 64 * 64)
         out, ref = [], None
-        for t in tuple(others) + (120,):
+        for t in tuple(others) + (120, 121):
             eng.tile_override[(cin, cout, 7, 1, 0)] = (t, 1, 0)
             try:
                 us = timed(lambda: eng.conv(x, mod, L.PAD_REFLECT, 3, L.OUT_RAW_F32_NHWC, want_stats=True))

@@ -469,7 +469,7 @@ def test_conv3x3_patch_kernel(case, prec):
 @pytest.mark.parametrize("case", [(64, 64, 24, 64, "reflect", 1), (128, 64, 33, 70, "reflect", 2), (128, 128, 16, 96, "zero", 1),
                                   (192, 40, 9, 32, "reflect", 1), (64, 32, 64, 128, "reflect", 1)])
 def test_conv7x7_window_tiles(case):
-    """Tile 120 (STAGED in round 4 for round 5): the single-phase patch kernel with a 7x7 window -- the dense 7x7 stems on
+    """Tiles 120 / 121 (STAGED in round 4 for round 5; 120 ran green on a GPU at the end of round 4, 121 has not run yet): the single-phase patch kernel with a 7x7 window -- the dense 7x7 stems on
     the pooled label encodings.  bf16, 1-3 channel chunks, aligned and ragged images, reflection / zero padding, batch 2, with and
     without split-K over the chunks; raw output, per-tile statistics and the in-kernel norm finalize against torch and against the
     generic implicit-GEMM tile (same products, different summation order: 2e-5 of the output scale); reproducible bit for bit."""
@@ -496,7 +496,7 @@ def test_conv7x7_window_tiles(case):
     for k in range(2):
         raw, _, (n_, OH, OW) = eng.conv(xa[k], conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
         base.append(raw[:n_ * OH * OW * cout].view(n_, OH, OW, cout).permute(0, 3, 1, 2).clone())
-    for it, (tile, S) in enumerate([(120, 1), (120, 2), (120, 3)]):
+    for it, (tile, S) in enumerate([(120, 1), (121, 1), (120, 2), (121, 3)]):
         if S > ncc:
             continue
         k = it % 2

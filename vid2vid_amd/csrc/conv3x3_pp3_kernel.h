@@ -69,7 +69,7 @@ __device__ __forceinline__ void pp3_run_chunk(F& it, std::integer_sequence<int, 
 // outside its 9 steps is instruction issue (geometry, statistics, store addressing: ~7 us per tile, profiles/r04_d7_*), which two
 // workgroups on the same SIMDs share rather than overlap.  (On the ping-pong kernel the same idea needed a 128-register cap,
 // spilled and was slower: profiles/r04_d4_single_chunk_two_wg_per_cu.txt.)
-// KK = 7 (tile 120, STAGED FOR ROUND 5 -- built, not yet run on a GPU): the same schedule for a KK x KK window, pad KK / 2 --
+// KK = 7 (tiles 120 / 121, STAGED FOR ROUND 5 -- built, not yet run on a GPU): the same schedule for a KK x KK window, pad KK / 2 --
 // the dense 7x7 stems on the pooled label encodings (108 -> 64 / 32 at 1024x512, 108 -> 128 / 64 at 512x256 and edge2face's
 // 45 -> 128), which the 2048x1024 per-layer table puts first (1.47 ms on generic tiles that re-fetch their activations for each
 // of the 49 taps: profiles/r04_f3_per_layer_roofline_hires.txt).  NT = KK^2 tap steps per channel chunk over a (TH + KK - 1) x
@@ -163,7 +163,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         pp[k] = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
         pok |= (ok ? 1u : 0u) << k;
     }
-    auto issue_patch = [&](int k, int cc_local, char* buf) {
+    auto issue_patch = [&](int k, int cc_local, char* buf) __attribute__((always_inline)) {
         const int cg = cc_local < ncc ? cc_local : ncc - 1;    // tail: a harmless reload keeps the DMA counts uniform
         const char* src = (((pok >> k) & 1u) && !(ab & 1)) ? p.in + pp[k] + (ccb + cg) * 128 : zp;
         glds16(src, buf + (k * NW + wid) * 1024);
@@ -179,7 +179,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         r = r < p.cout_p ? r : p.cout_p - 1;
         wp[i] = p.w + ((long long)p.woff[0] + r * p.wrow[0] + lslot * VEC) * (long long)sizeof(T) + (long long)ccb * NT * 128;
     }
-    auto issue_w_piece = [&](int i, int step, int stage) {
+    auto issue_w_piece = [&](int i, int step, int stage) __attribute__((always_inline)) {
         const int sg = step < nsteps ? step : nsteps - 1;      // tail duplicate into a free stage
         glds16(wp[i] + ((ab & 2) ? 0ll : (long long)sg * 128), bring + stage * BST + wid * 1024 + i * NW * 1024);
     };
@@ -247,7 +247,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     char* pn = smem + (ONE ? 0 : PATCH);                      // the other one (chunk cc+1 streams in; ONE: there is none)
 
     // iteration: multiply step `step` (tap TAP) from set PAR, fill set 1-PAR with step+1, issue the DMA of step+D
-    auto iteration = [&](auto tc, auto pc) {
+    auto iteration = [&](auto tc, auto pc) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tc)::value;
         constexpr int PAR = decltype(pc)::value;
         constexpr int NTAP = (TAP + 1) % NT;                 // tap of the step whose fragments are read now
@@ -277,13 +277,13 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         }
         const int nstage = stage + 1 == NSB ? 0 : stage + 1;
         const char* const pb = bring + nstage * BST + b_row_off;
-        auto dma = [&](auto dc) {
+        auto dma = [&](auto dc) __attribute__((always_inline)) {
             constexpr int d = decltype(dc)::value;
             if (ab & 128) return;
             if constexpr (d < LB) issue_w_piece(d, step + D, stage);       // slice step+D refills the stage of slice `step`
             else                  issue_patch(k0 + d - LB, cc + 1, pn);
         };
-        auto reads_of_slot = [&](auto mc) {
+        auto reads_of_slot = [&](auto mc) __attribute__((always_inline)) {
             constexpr int m = decltype(mc)::value;
             if (ab & 32) return;
             static_for<RPS>([&](auto rc) {
@@ -318,7 +318,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         }
     };
     static_assert(NT % 2 == 1, "an odd number of taps per chunk: the register-set parity flips from chunk to chunk");
-    auto chunk = [&](auto par0c) {
+    auto chunk = [&](auto par0c) __attribute__((always_inline)) {
         constexpr int P0 = decltype(par0c)::value;
         if constexpr (NT == 9) {                             // the 3x3 kernels exactly as they shipped in round 4
             iteration(std::integral_constant<int, 0>{}, std::integral_constant<int, P0>{});
@@ -347,7 +347,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     V2V_STAMP(p, 3);
 
     const bool tile_full = oh0 + TH <= H && ow0 + TW <= W;    // every row of the tile is a pixel of the layer (uniform: conv_epilogue's fast paths)
-    auto pix_of = [&](int row) -> int {        // TW is a power of two; N*OH*OW < 2^31 (host check)
+    auto pix_of = [&](int row) __attribute__((always_inline)) -> int {        // TW is a power of two; N*OH*OW < 2^31 (host check)
         const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
         if (oh >= H || ow >= W) return -1;
         return (n_img * H + oh) * W + ow;
@@ -419,8 +419,10 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     conv3x3_pp3_body<T, TH, TW, BN, D, ABL, WGM_, WGN_, KS_, ONE, 3>(p_in);
 }
 
-// 7x7 window: its own entry point, pinned to two waves per SIMD -- left to its occupancy heuristics the compiler allocates 82
-// registers for the 98 unrolled tap steps and spills 1.7 KB per lane (-Rpass-analysis=kernel-resource-usage)
+// 7x7 window: its own entry point, pinned to two waves per SIMD.  The lambdas of the body are always_inline: with 98 unrolled tap
+// steps the inliner otherwise leaves some of them as calls, their by-reference captures pin the argument block (a 700-byte struct)
+// and the pipeline state to scratch memory -- 85 registers + 1.8 KB of scratch per lane for the 128-channel tile, and a back end that
+// cannot honour the epilogue's SGPR pins ("illegal VGPR to SGPR copy") -- -Rpass-analysis=kernel-resource-usage before / after
 template <typename T, int TH, int TW, int BN, int D, int WGM_ = 4, int WGN_ = 2>
 __global__ __launch_bounds__(WGM_ * WGN_ * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv7x7_pp3_kernel(const ConvKArgs p_in) {
     conv3x3_pp3_body<T, TH, TW, BN, D, 0, WGM_, WGN_, 1, false, 7>(p_in);
@@ -452,8 +454,7 @@ static const PatchCfg kPp3Cfgs[] = {
     {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
     {92, 8, 32, 64}, {93, 4, 64, 64},      // K quads: 2 x 1 wave tiles of 128 x 64, four K quarters: 6 reads per 8 MFMAs
     {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 80 KiB, two workgroups per CU
-    {120, 4, 32, 64},                      // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk
-                                           // (a 128-channel tile, <4, 32, 128, D 3>, compiles to 85 registers + 1.8 KB of scratch per lane: not offered)
+    {120, 4, 32, 64}, {121, 4, 32, 128},   // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk
 };
 static inline const PatchCfg* find_pp3_cfg(int id) {
     for (const PatchCfg& c : kPp3Cfgs)
@@ -476,9 +477,11 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 91: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 4, 1, 2>(k, groups, s);   // as 83 for 64-wide tile rows
         case 92: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 2, 1, 4>(k, groups, s);   // as 82, K quads
         case 93: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 2, 1, 4>(k, groups, s);   // as 83, K quads
-        case 120:                          // 7x7 window: bf16 only for now (the fp32 instantiation doubles an 8-minute translation unit)
-            if constexpr (std::is_same<T, bf16_t>::value)
-                return launch_pp3_cfg<T, 4, 32, 64, 4, 0, 4, 2, 1, false, 7>(k, 1, s);    // 128 px x 64, 2 x 48 + 32 = 128 KiB, 103 registers
+        case 120: case 121:                // 7x7 window: bf16 only for now (the fp32 instantiations double an 8-minute translation unit)
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                if (cfg == 120) return launch_pp3_cfg<T, 4, 32, 64, 4, 0, 4, 2, 1, false, 7>(k, 1, s);    // 128 px x  64, 2 x 48 + 32 = 128 KiB, 109 registers
+                return launch_pp3_cfg<T, 4, 32, 128, 3, 0, 4, 2, 1, false, 7>(k, 1, s);                   // 128 px x 128, 2 x 48 + 48 = 144 KiB, 163 registers
+            }
             break;
         case 94: case 95:                  // single-chunk tiles: bf16 only (64 input channels = one 128-byte chunk), single launches only
             if constexpr (std::is_same<T, bf16_t>::value) {

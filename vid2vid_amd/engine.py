@@ -354,7 +354,7 @@ S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 1
 T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 64)}
 # dense 7x7 / stride 1 / pad 3 convolutions on the single-phase kernel with a 7x7 window (csrc/conv3x3_pp3_kernel.h, KK = 7): id -> (TH, TW, BN).
 # STAGED FOR ROUND 5: built and dry-run tested, not yet run on a GPU -- offered to the tile search only with V2V_S7_PATCH=1
-S7_CFGS = {120: (4, 32, 64)}
+S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
 
@@ -1199,7 +1199,7 @@ class Engine:
                 and d.cin_stride % bke == 0)
 
     def s7_eligible(self, d):
-        """7x7-window tile 120: dense bf16 7x7 / stride 1 / pad 3 Conv2d whose channel stride is a whole number of 128-byte chunks
+        """7x7-window tiles 120 / 121: dense bf16 7x7 / stride 1 / pad 3 Conv2d whose channel stride is a whole number of 128-byte chunks
         (the stems on the pooled label encodings, edge2face's 45 -> 128 stem); opt-in until validated on a GPU."""
         return (self.dtype == L.BF16 and not d.transposed and d.KH == 7 and d.KW == 7 and d.stride == 1 and d.pad == 3
                 and d.cin_stride % 64 == 0 and d.out_mode != L.OUT_NORM_ACT_NHWC and os.environ.get("V2V_S7_PATCH", "0") == "1")
