@@ -427,6 +427,8 @@ def test_conv7x7_window_tile_is_validated_by_the_library():
             return d
         assert lib.v2v_conv2d(C.byref(desc(7, 128, 1, 120)), None) == 0, lib.v2v_last_error()
         assert lib.v2v_conv_stats_rows(C.byref(desc(7, 128, 1, 120))) == 16 * 4        # 4 x 32 pixel tiles of the 64 x 128 image
+        d121 = desc(7, 128, 1, 121); d121.cout = d121.cout_stride = 128
+        assert lib.v2v_conv2d(C.byref(d121), None) == 0, lib.v2v_last_error()          # the 128-channel tile
         assert lib.v2v_conv2d(C.byref(desc(3, 128, 1, 120)), None) != 0                # a 3x3 layer
         assert lib.v2v_conv2d(C.byref(desc(7, 128, 0, 120)), None) != 0                # tap-major weights
         assert lib.v2v_conv2d(C.byref(desc(7, 112, 1, 120)), None) != 0                # 112 channels: not whole 128-byte chunks
