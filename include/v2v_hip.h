@@ -232,7 +232,9 @@ int v2v_bn_finalize(const float* partials, int32_t rows, int32_t C, int64_t coun
                     double* workspace, void* stream);
 /* workspace: NULL, or v2v_bn_finalize_groups(rows) * C * 2 doubles.  With a workspace, layers that leave more than 512
  * statistics rows (large M) are reduced by a parallel two-stage tree (groups x C/64 workgroups, then one per 64
- * channels) instead of one workgroup walking every row; the result is deterministic either way.  Returns 0 groups
+ * channels) instead of one workgroup walking every row; the result is deterministic either way.  Round 4: the second stage
+ * runs inside the first stage's launch (the last group of a 64-channel slab finalizes; ticket words from the library's own
+ * device pool, self re-arming) -- same bits, one launch fewer; V2V_BN_FIN_FUSED=0 keeps the two launches.  Returns 0 groups
  * for rows <= 512 (single stage, the summation order the in-kernel finalize of v2v_conv2d reproduces). */
 int v2v_bn_finalize_groups(int32_t rows);
 

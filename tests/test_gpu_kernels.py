@@ -411,7 +411,7 @@ PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33
               (90, 1), (91, 1), (90, 2), (91, 3),
               # K quads
               (92, 1), (93, 1), (92, 2), (93, 2),
-              # single-chunk tiles (one patch buffer, two workgroups per CU): bf16 layers with exactly 64 input channels
+              # single-chunk tiles (one patch buffer, three weight stages): bf16 layers with exactly 64 input channels
               (94, 1), (95, 1)]
 
 

@@ -63,12 +63,13 @@ __device__ __forceinline__ void pp3_run_chunk(F& it, std::integer_sequence<int, 
 // (48 KB of LDS reads per step and CU), 128 accumulator registers per lane, a three-round reduce-scatter at the end.
 // ONE = true (tiles 94 / 95): layers with a SINGLE 128-byte channel chunk (64 bf16 input channels: the ResnetBlocks of the fine
 // scales).  Such a launch is thousands of tiles of 9 tap steps (~3 us) between a prologue and an epilogue that cost more than the
-// steps; the second patch buffer is never used, so it is dropped: PATCH + ring = 80 KiB and, at this kernel's 84 registers, TWO
-// workgroups share a CU.  Measured (profiles/r04_d6_*, r04_d8_*, r04_d10_*): bit-identical, 0-5 % faster than tiles 80 / 83 -- the
-// co-residency buys almost nothing and a start-up stagger of the second slot only adds its own delay, because what a tile costs
-// outside its 9 steps is instruction issue (geometry, statistics, store addressing: ~7 us per tile, profiles/r04_d7_*), which two
-// workgroups on the same SIMDs share rather than overlap.  (On the ping-pong kernel the same idea needed a 128-register cap,
-// spilled and was slower: profiles/r04_d4_single_chunk_two_wg_per_cu.txt.)
+// steps; the second patch buffer is never used, so it is dropped: PATCH + ring = 72 / 80 KiB.  Bit-identical to tiles 80 / 83 and
+// 0-5 % faster (profiles/r04_d6_*, r04_d8_*).  NOTE: the intent was two workgroups per CU, but LDS is not what decides that here --
+// the kernel descriptor says 167 VGPRs (llvm-readelf --notes; rocprofv3's kernel-trace column prints half of that, 84), i.e. three
+// waves per SIMD, so an 8-wave workgroup stays alone on its CU whatever its LDS footprint.  Whether a second resident workgroup
+// would hide a tile's ~7 us of prologue / epilogue (mostly instruction issue: profiles/r04_d7_*) is therefore still untested for
+// this kernel; on the ping-pong kernel a 128-register cap did give two workgroups per CU, spilled 39 registers and was slower
+// (profiles/r04_d4_single_chunk_two_wg_per_cu.txt).
 // KK = 7 (tiles 120 / 121, STAGED FOR ROUND 5 -- built, not yet run on a GPU): the same schedule for a KK x KK window, pad KK / 2 --
 // the dense 7x7 stems on the pooled label encodings (108 -> 64 / 32 at 1024x512, 108 -> 128 / 64 at 512x256 and edge2face's
 // 45 -> 128), which the 2048x1024 per-layer table puts first (1.47 ms on generic tiles that re-fetch their activations for each
@@ -453,7 +454,7 @@ static const PatchCfg kPp3Cfgs[] = {
     {88, 8, 32, 128}, {89, 8, 32, 64},     // ablation instances of 81 / 80
     {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
     {92, 8, 32, 64}, {93, 4, 64, 64},      // K quads: 2 x 1 wave tiles of 128 x 64, four K quarters: 6 reads per 8 MFMAs
-    {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 80 KiB, two workgroups per CU
+    {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 72 / 80 KiB
     {120, 4, 32, 64}, {121, 4, 32, 128},   // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk
 };
 static inline const PatchCfg* find_pp3_cfg(int id) {
