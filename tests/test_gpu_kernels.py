@@ -412,7 +412,7 @@ PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33
               # K quads
               (92, 1), (93, 1), (92, 2), (93, 2),
               # single-chunk tiles (one patch buffer, three weight stages): bf16 layers with exactly 64 input channels
-              (94, 1), (95, 1)]
+              (94, 1), (95, 1), (96, 1)]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -443,7 +443,7 @@ def test_conv3x3_patch_kernel(case, prec):
     for it, (tile, S) in enumerate(PATCH_CFGS):
         if S > ncc:
             continue
-        if tile in (94, 95) and (ncc != 1 or prec != "bf16"):
+        if tile in (94, 95, 96) and (ncc != 1 or prec != "bf16"):
             continue
         k = it % 2
         eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, S, 12 if (tile <= 37 and it % 3 == 0) else 0)

@@ -117,7 +117,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     constexpr int NPB = ONE ? 1 : 2;                          // patch buffers
     static_assert(!ONE || KS == 1, "single-chunk tiles: no accumulator exchange (it would need 64 KiB of scratch)");
     static_assert(NPB * PATCH + NSB * BST <= 160 * 1024 / (ONE ? 2 : 1), "LDS");
-    static_assert(NPB * PATCH >= 40960, "epilogue scratch (statistics rows + a 4 KiB transposition block per wave) lives in the patch buffers");
+    static_assert(NPB * PATCH >= 20480 + (NW > 4 ? 20480 : 0), "epilogue scratch (statistics rows + a 4 KiB transposition block per wave; the finalize flag at 16 KiB) lives in the patch buffers");
     typedef typename Mma<T>::Frag Frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -455,6 +455,8 @@ static const PatchCfg kPp3Cfgs[] = {
     {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
     {92, 8, 32, 64}, {93, 4, 64, 64},      // K quads: 2 x 1 wave tiles of 128 x 64, four K quarters: 6 reads per 8 MFMAs
     {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 72 / 80 KiB
+    {96, 4, 32, 64},                       // single-chunk layers, FOUR waves (2 x 2, 64 x 32 wave tiles), 28 + 24 = 52 KiB, 167 + 32 registers: the
+                                           // tile that really puts two workgroups on a CU (staged for round 5; 94 / 95 never did: DESIGN 3.6 item 15)
     {120, 4, 32, 64}, {121, 4, 32, 128},   // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk
 };
 static inline const PatchCfg* find_pp3_cfg(int id) {
@@ -483,6 +485,9 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
                 if (cfg == 120) return launch_pp3_cfg<T, 4, 32, 64, 4, 0, 4, 2, 1, false, 7>(k, 1, s);    // 128 px x  64, 2 x 48 + 32 = 128 KiB, 109 registers
                 return launch_pp3_cfg<T, 4, 32, 128, 3, 0, 4, 2, 1, false, 7>(k, 1, s);                   // 128 px x 128, 2 x 48 + 48 = 144 KiB, 163 registers
             }
+            break;
+        case 96:                           // single-chunk, four waves: two co-resident workgroups per CU by registers (2 waves / SIMD) and LDS (52 KiB)
+            if constexpr (std::is_same<T, bf16_t>::value) return launch_pp3_cfg<T, 4, 32, 64, 3, 0, 2, 2, 1, true>(k, 1, s);
             break;
         case 94: case 95:                  // single-chunk tiles: bf16 only (64 input channels = one 128-byte chunk), single launches only
             if constexpr (std::is_same<T, bf16_t>::value) {

@@ -654,7 +654,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
             set_error("conv: patch tile config %d needs a 3x3/s1/p1 Conv2d, cin_stride %% %d == 0 and korder-1 weights",
                       op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
         }
-        if ((op->cfg == 94 || op->cfg == 95) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
+        if ((op->cfg == 94 || op->cfg == 95 || op->cfg == 96) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
                                                  d->out_mode == V2V_OUT_NORM_ACT_NHWC)) {
             set_error("conv: tile config %d is a single-chunk tile: bf16, cin_stride exactly %d, no split-K, no fused norm", op->cfg, bke_of(d->dtype));
             return V2V_EINVAL;

@@ -347,7 +347,7 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               86: (4, 32, 128), 87: (2, 64, 128),      # 86 / 87: four waves, 64 x 64 wave tiles
               90: (8, 32, 64), 91: (4, 64, 64),        # 90 / 91: 82 / 83 with K pairs (8 fragment reads per 8 MFMAs)
               92: (8, 32, 64), 93: (4, 64, 64),        # 92 / 93: K quads (6 reads per 8 MFMAs)
-              94: (8, 32, 64), 95: (4, 64, 64)}        # 94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
+              94: (8, 32, 64), 95: (4, 64, 64), 96: (4, 32, 64)}        # 94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
 # stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
 S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
 # ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
@@ -361,7 +361,7 @@ PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92
 
 def is_patch_tile(t):
     """Tile ids of the LDS-patch 3x3 kernels (weights in K order 1): patch 32-48, ping-pong 50-57, ping-pong 2 70-79."""
-    return 32 <= t < 60 or 70 <= t < 96 or 100 <= t < 110 or 120 <= t < 130
+    return 32 <= t < 60 or 70 <= t < 97 or 100 <= t < 110 or 120 <= t < 130
 
 
 def tile_korder(t):
