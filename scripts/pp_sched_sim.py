@@ -94,18 +94,18 @@ if _RUN_PP:
     sys.exit(0 if ok else 1)
 
 
-def simulate_pp3(GP, LB, D, ncc, wait_fn=None):
+def simulate_pp3(GP, LB, D, ncc, wait_fn=None, NT=9):
     """Single-phase schedule of conv3x3_pp3_kernel: every wave runs  B_j | MFMA(j) || ds_read(j+1) || DMA issue W(j+D), P |
     vmcnt wait  per iteration j, ONE barrier per step, weight ring of D stages (slice j+D refills the stage of slice j)."""
-    NPT = 9 - D
+    NPT = NT - D                       # NT = taps per channel chunk: 9 (3x3) or 49 (the 7x7 window of tiles 120 / 121)
     PPT = (GP + NPT - 1) // NPT
-    nsteps = ncc * 9
+    nsteps = ncc * NT
     def npieces(tap):
         if tap >= NPT: return 0
         return cmin((tap + 1) * PPT, GP) - cmin(tap * PPT, GP)
-    assert sum(npieces(t) for t in range(9)) == GP
+    assert sum(npieces(t) for t in range(NT)) == GP
     def pending(tap):
-        return (D - 2) * LB + sum(npieces((tap - u + 18) % 9) for u in range(0, D - 1))
+        return (D - 2) * LB + sum(npieces((tap - u + 2 * NT) % NT) for u in range(0, D - 1))
     if wait_fn is None:
         wait_fn = pending
     errors, outstanding, cnt = [], [], {}
@@ -131,7 +131,7 @@ def simulate_pp3(GP, LB, D, ncc, wait_fn=None):
     read(('W', 0), LB, -0.5); read(('P', 0), GP, -0.5)
     wait((D - 2) * LB, -0.5)
     for j in range(nsteps):
-        tap, c = j % 9, j // 9
+        tap, c = j % NT, j // NT
         for item, old in ((('W', j + D), ('W', j)),):
             if old in last_read and last_read[old] >= j:
                 errors.append("WAR: %s issued at phase %d, %s last read at %s" % (item, j, old, last_read[old]))
@@ -143,7 +143,7 @@ def simulate_pp3(GP, LB, D, ncc, wait_fn=None):
             issue(('P', c + 1), npieces(tap), j)
         if j + 1 < nsteps:
             read(('W', j + 1), LB, j)
-            read(('P', (j + 1) // 9), GP, j)
+            read(('P', (j + 1) // NT), GP, j)
         wait(wait_fn(tap), j)
     return errors
 
@@ -156,4 +156,8 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pp3":
                 e = simulate_pp3(GP, LB, D, 3)
                 print("pp3 D=%d GP=%d LB=%d: %s" % (D, GP, LB, "OK" if not e else "%d errors, e.g. %s" % (len(e), e[0])))
                 ok &= not e
+    for D, GP, LB in ((4, 6, 1), (3, 6, 2), (4, 12, 2), (5, 6, 1)):        # 7x7 window: tile 120 (D 4, GP 6, LB 1) and variants
+        e = simulate_pp3(GP, LB, D, 3, NT=49)
+        print("pp3 7x7 D=%d GP=%d LB=%d: %s" % (D, GP, LB, "OK" if not e else "%d errors, e.g. %s" % (len(e), e[0])))
+        ok &= not e
     sys.exit(0 if ok else 1)

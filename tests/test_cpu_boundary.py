@@ -399,3 +399,39 @@ def test_three_scale_narrow_towers_lowering_records(precision):
     finally:
         N.set_record_only(False)
         N._ENGINES.clear()
+
+
+def test_conv7x7_window_tile_is_validated_by_the_library():
+    """Tile 120 (the single-phase patch kernel with a 7x7 window; STAGED for round 5, never run on a GPU yet): in dry-run mode the
+    C ABI accepts it for a dense bf16 7x7 / stride 1 / pad 3 Conv2d whose channel stride is a whole number of 128-byte chunks with
+    channel-chunk-major weights -- and rejects it for a 3x3 layer, for tap-major weights and for a ragged channel stride."""
+    import ctypes as C
+    from vid2vid_amd import networks as N
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, ConvDesc
+    if torch.cuda.is_available():
+        pytest.skip("dry-run validation is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        buf = torch.zeros(1 << 20)
+        def desc(K, cin_stride, korder, tile):
+            d = ConvDesc()
+            d.in_, d.w, d.out, d.zero_page = buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr()
+            d.bias, d.stats = None, None
+            d.N, d.H, d.W, d.OH, d.OW = 1, 64, 128, 64, 128
+            d.cin, d.cin_stride, d.cout, d.cout_stride = min(cin_stride, 108), cin_stride, 64, 64
+            d.KH = d.KW = K
+            d.stride, d.pad, d.pad_mode, d.transposed = 1, K // 2, L.PAD_REFLECT, 0
+            d.dtype, d.out_mode, d.act, d.act_param, d.out_scale = L.BF16, L.OUT_RAW_F32_NHWC, L.ACT_NONE, 0.0, 1.0
+            d.tile, d.splitk, d.prefetch, d.w_korder = tile, 1, 0, korder
+            return d
+        assert lib.v2v_conv2d(C.byref(desc(7, 128, 1, 120)), None) == 0, lib.v2v_last_error()
+        assert lib.v2v_conv_stats_rows(C.byref(desc(7, 128, 1, 120))) == 16 * 4        # 4 x 32 pixel tiles of the 64 x 128 image
+        d121 = desc(7, 128, 1, 121); d121.cout = d121.cout_stride = 128
+        assert lib.v2v_conv2d(C.byref(d121), None) == 0, lib.v2v_last_error()          # the 128-channel tile
+        assert lib.v2v_conv2d(C.byref(desc(3, 128, 1, 120)), None) != 0                # a 3x3 layer
+        assert lib.v2v_conv2d(C.byref(desc(7, 128, 0, 120)), None) != 0                # tap-major weights
+        assert lib.v2v_conv2d(C.byref(desc(7, 112, 1, 120)), None) != 0                # 112 channels: not whole 128-byte chunks
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()

@@ -412,7 +412,7 @@ PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33
               # K quads
               (92, 1), (93, 1), (92, 2), (93, 2),
               # single-chunk tiles (one patch buffer, three weight stages): bf16 layers with exactly 64 input channels
-              (94, 1), (95, 1)]
+              (94, 1), (95, 1), (96, 1)]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -443,7 +443,7 @@ def test_conv3x3_patch_kernel(case, prec):
     for it, (tile, S) in enumerate(PATCH_CFGS):
         if S > ncc:
             continue
-        if tile in (94, 95) and (ncc != 1 or prec != "bf16"):
+        if tile in (94, 95, 96) and (ncc != 1 or prec != "bf16"):
             continue
         k = it % 2
         eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, S, 12 if (tile <= 37 and it % 3 == 0) else 0)
@@ -464,6 +464,58 @@ def test_conv3x3_patch_kernel(case, prec):
     assert_close(eng.unpack(out).cpu(), F.leaky_relu(refs[0], 0.2), 1e-4 if prec == "fp32" else 1e-2, "act")
     if eng._sk_counter is not None:
         assert int(eng._sk_counter.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("case", [(64, 64, 24, 64, "reflect", 1), (128, 64, 33, 70, "reflect", 2), (128, 128, 16, 96, "zero", 1),
+                                  (192, 40, 9, 32, "reflect", 1), (64, 32, 64, 128, "reflect", 1)])
+def test_conv7x7_window_tiles(case):
+    """Tiles 120 / 121 (STAGED in round 4 for round 5; 120 ran green on a GPU at the end of round 4, 121 has not run yet): the single-phase patch kernel with a 7x7 window -- the dense 7x7 stems on
+    the pooled label encodings.  bf16, 1-3 channel chunks, aligned and ragged images, reflection / zero padding, batch 2, with and
+    without split-K over the chunks; raw output, per-tile statistics and the in-kernel norm finalize against torch and against the
+    generic implicit-GEMM tile (same products, different summation order: 2e-5 of the output scale); reproducible bit for bit."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, mode, N = case
+    torch.manual_seed(cin + H)
+    eng = _engine("bf16")
+    conv = nn.Conv2d(cin, cout, 7, padding=0 if mode == "reflect" else 3)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    xs = [torch.randn(N, cin, H, W) * (1.0 + i) for i in range(2)]
+    def ref_of(x):
+        xr = _round(x, "bf16")
+        if mode == "reflect":
+            xr = F.pad(xr, (3,) * 4, mode="reflect")
+        return F.conv2d(xr, _round(conv.weight.detach(), "bf16"), conv.bias.detach(), padding=0 if mode == "reflect" else 3)
+    refs = [ref_of(x) for x in xs]
+    conv = conv.to(DEV)
+    xa = [eng.pack(x.to(DEV)) for x in xs]
+    pm, po = (L.PAD_REFLECT, 3) if mode == "reflect" else (L.PAD_ZERO, None)
+    ncc = xa[0].Cs // 64
+    key = (cin, cout, 7, 1, 0)
+    eng.tile_override[key] = (10, 1, 0)
+    base = []
+    for k in range(2):
+        raw, _, (n_, OH, OW) = eng.conv(xa[k], conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
+        base.append(raw[:n_ * OH * OW * cout].view(n_, OH, OW, cout).permute(0, 3, 1, 2).clone())
+    for it, (tile, S) in enumerate([(120, 1), (121, 1), (120, 2), (121, 3)]):
+        if S > ncc:
+            continue
+        k = it % 2
+        eng.tile_override[key] = (tile, S, 0)
+        ss = torch.full((4 * cout,), float("nan"), device=DEV)
+        raw, rows, (n_, OH, OW) = eng.conv(xa[k], conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+        log = eng.conv_log[-1]
+        assert (log["tile"], log["splitk"]) == (tile, S), (tile, S, log)
+        got = raw[:n_ * OH * OW * cout].view(n_, OH, OW, cout).permute(0, 3, 1, 2).clone()
+        assert_close(got.cpu(), refs[k], 2e-4, "7x7 window tile %d S=%d vs torch" % (tile, S))
+        assert_close(got.cpu(), base[k].cpu(), 2e-5, "7x7 window tile %d S=%d vs the generic tile" % (tile, S))
+        st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].view(rows, cout, 2).sum(0).cpu()
+        assert_close(st[:, 0], refs[k].sum((0, 2, 3)), 1e-3, "stats tile %d" % tile)
+        assert_close(ss[2 * cout:3 * cout].cpu(), refs[k].mean((0, 2, 3)), 1e-3, "finalized mean tile %d" % tile)
+        raw2, _, _ = eng.conv(xa[k], conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
+        assert torch.equal(got, raw2[:n_ * OH * OW * cout].view(n_, OH, OW, cout).permute(0, 3, 1, 2)), "not reproducible"
+    eng.tile_override[key] = (120, 1, 0)
+    out, _, _ = eng.conv(xa[0], conv, pm, po, L.OUT_ACT_NHWC, L.ACT_LEAKY, 0.2)
+    assert_close(eng.unpack(out).cpu(), F.leaky_relu(refs[0], 0.2), 1e-2, "act")
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

@@ -34,12 +34,18 @@ constexpr int np_at(int tap, int GP, int NPT) {
     const int ppt = (GP + NPT - 1) / NPT;
     return tap < NPT ? cmin((tap + 1) * ppt, GP) - cmin(tap * ppt, GP) : 0;
 }
-constexpr int pending_at(int tap, int GP, int LB, int D) {
+constexpr int pending_at(int tap, int GP, int LB, int D, int NT = 9) {
     int x = (D - 2) * LB;
-    for (int u = 0; u < D - 1; ++u) x += np_at((tap - u + 18) % 9, GP, 9 - D);
+    for (int u = 0; u < D - 1; ++u) x += np_at((tap - u + 2 * NT) % NT, GP, NT - D);
     return x;
 }
 }  // namespace pp3
+
+// taps 0 .. NT-1 of one channel chunk on alternating fragment register sets (first set P0)
+template <int P0, typename F, int... I>
+__device__ __forceinline__ void pp3_run_chunk(F& it, std::integer_sequence<int, I...>) {
+    (it(std::integral_constant<int, I>{}, std::integral_constant<int, (P0 + I) & 1>{}), ...);
+}
 
 // ABL = 1: ablation instance (scripts/pp2_ablate.py): 1 / 2 hot operands, 4 no stores, 32 no fragment ds_reads,
 // 64 no MFMAs, 128 no LDS-DMA in the main loop, 256 no vmcnt wait in the main loop, 512 return at once, 1024 no main loop.  Results are wrong when set.
@@ -64,8 +70,13 @@ constexpr int pending_at(int tap, int GP, int LB, int D) {
 // would hide a tile's ~7 us of prologue / epilogue (mostly instruction issue: profiles/r04_d7_*) is therefore still untested for
 // this kernel; on the ping-pong kernel a 128-register cap did give two workgroups per CU, spilled 39 registers and was slower
 // (profiles/r04_d4_single_chunk_two_wg_per_cu.txt).
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false>
-__global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
+// KK = 7 (tiles 120 / 121, STAGED FOR ROUND 5 -- built, not yet run on a GPU): the same schedule for a KK x KK window, pad KK / 2 --
+// the dense 7x7 stems on the pooled label encodings (108 -> 64 / 32 at 1024x512, 108 -> 128 / 64 at 512x256 and edge2face's
+// 45 -> 128), which the 2048x1024 per-layer table puts first (1.47 ms on generic tiles that re-fetch their activations for each
+// of the 49 taps: profiles/r04_f3_per_layer_roofline_hires.txt).  NT = KK^2 tap steps per channel chunk over a (TH + KK - 1) x
+// (TW + KK - 1) patch; every pipeline constant that said 9 says NT, the tap offsets come from (tap / KK, tap % KK).
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false, int KK = 3>
+__device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     // grouped launch: which member and which tile this workgroup works on (the members have identical geometry, so the
     // tile count is known before the member is)
     int member = (int)blockIdx.z, lin_all;
@@ -80,7 +91,8 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     V2V_STAMP(p, 0);
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
-    constexpr int PW = TW + 2, PR = (TH + 2) * PW;
+    constexpr int NT = KK * KK, PADK = KK / 2;                // tap steps per channel chunk; padding of the window
+    constexpr int PW = TW + KK - 1, PR = (TH + KK - 1) * PW;
     constexpr int WGM = WGM_, WGN = WGN_, KS = KS_, NW = WGM * WGN * KS;
     constexpr int SS = 4 / KS;                                // K sub-steps (16 elements each) of a step that one wave multiplies
     constexpr int NG = (PR + 7) / 8;
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     constexpr int BST = BN * 128;
     constexpr int LB = BN / 8 / NW;                           // weight pieces per wave per slice
     constexpr int NSB = D;                                    // weight ring: slice j+D refills the stage of slice j
-    constexpr int NPT = 9 - D;                                // taps 0..NPT-1 carry next-chunk patch pieces
+    constexpr int NPT = NT - D;                               // taps 0..NPT-1 carry next-chunk patch pieces
     constexpr int PPT = (GP + NPT - 1) / NPT;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -101,10 +113,11 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile");
     static_assert(BN % (8 * NW) == 0 && LB >= 1, "weight loader rounds");
     static_assert(D >= 3 && D <= 5, "weight slices in flight");
+    static_assert((D - 2) * LB + (D - 1) * ((GP + NT - D - 1) / (NT - D)) <= 63, "vmcnt immediate range");
     constexpr int NPB = ONE ? 1 : 2;                          // patch buffers
     static_assert(!ONE || KS == 1, "single-chunk tiles: no accumulator exchange (it would need 64 KiB of scratch)");
     static_assert(NPB * PATCH + NSB * BST <= 160 * 1024 / (ONE ? 2 : 1), "LDS");
-    static_assert(NPB * PATCH >= 40960, "epilogue scratch (statistics rows + a 4 KiB transposition block per wave) lives in the patch buffers");
+    static_assert(NPB * PATCH >= 20480 + (NW > 4 ? 20480 : 0), "epilogue scratch (statistics rows + a 4 KiB transposition block per wave; the finalize flag at 16 KiB) lives in the patch buffers");
     typedef typename Mma<T>::Frag Frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     const int ncc_all = cs * (int)sizeof(T) / 128;
     int ccb, ncc;
     patch_chunk_range(ncc_all, slice, S, ccb, ncc);
-    const int nsteps = ncc * 9;
+    const int nsteps = ncc * NT;
     const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
     const char* const zp = p.zero_page;
 
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
         const int q = (k * NW + wid) * 8 + (lane >> 3);
         const int ls = (lane & 7) ^ ((q >> 1) & 7);
         const int pr = q / PW, pc = q - pr * PW;
-        int ih = oh0 + pr - 1, iw = ow0 + pc - 1;
+        int ih = oh0 + pr - PADK, iw = ow0 + pc - PADK;
         bool ok = q < PR;
         int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
         int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
         pp[k] = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
         pok |= (ok ? 1u : 0u) << k;
     }
-    auto issue_patch = [&](int k, int cc_local, char* buf) {
+    auto issue_patch = [&](int k, int cc_local, char* buf) __attribute__((always_inline)) {
         const int cg = cc_local < ncc ? cc_local : ncc - 1;    // tail: a harmless reload keeps the DMA counts uniform
         const char* src = (((pok >> k) & 1u) && !(ab & 1)) ? p.in + pp[k] + (ccb + cg) * 128 : zp;
         glds16(src, buf + (k * NW + wid) * 1024);
@@ -165,9 +178,9 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     for (int i = 0; i < LB; ++i) {
         long long r = (long long)nt * BN + lrow + NW * 8 * i;
         r = r < p.cout_p ? r : p.cout_p - 1;
-        wp[i] = p.w + ((long long)p.woff[0] + r * p.wrow[0] + lslot * VEC) * (long long)sizeof(T) + (long long)ccb * 9 * 128;
+        wp[i] = p.w + ((long long)p.woff[0] + r * p.wrow[0] + lslot * VEC) * (long long)sizeof(T) + (long long)ccb * NT * 128;
     }
-    auto issue_w_piece = [&](int i, int step, int stage) {
+    auto issue_w_piece = [&](int i, int step, int stage) __attribute__((always_inline)) {
         const int sg = step < nsteps ? step : nsteps - 1;      // tail duplicate into a free stage
         glds16(wp[i] + ((ab & 2) ? 0ll : (long long)sg * 128), bring + stage * BST + wid * 1024 + i * NW * 1024);
     };
@@ -235,11 +248,11 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     char* pn = smem + (ONE ? 0 : PATCH);                      // the other one (chunk cc+1 streams in; ONE: there is none)
 
     // iteration: multiply step `step` (tap TAP) from set PAR, fill set 1-PAR with step+1, issue the DMA of step+D
-    auto iteration = [&](auto tc, auto pc) {
+    auto iteration = [&](auto tc, auto pc) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tc)::value;
         constexpr int PAR = decltype(pc)::value;
-        constexpr int NT = (TAP + 1) % 9;                    // tap of the step whose fragments are read now
-        constexpr int tq = (NT / 3) * PW + (NT % 3);
+        constexpr int NTAP = (TAP + 1) % NT;                 // tap of the step whose fragments are read now
+        constexpr int tq = (NTAP / KK) * PW + (NTAP % KK);
         constexpr int k0 = pp3::cmin(TAP * PPT, GP);
         constexpr int npz = ONE ? 0 : pp3::np_at(TAP, GP, NPT);   // ONE: no next chunk (host check), no next patch
         constexpr int NDMA = LB + npz;
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
                                                              // the stage of slice `step` and its fragment reads are retired
         const char* arow[TM]; int ax[TM];
         {
-            const char* const pbuf = TAP == 8 ? pn : pa;     // step+1 belongs to the next chunk at tap 8
+            const char* const pbuf = TAP == NT - 1 ? pn : pa;     // step+1 belongs to the next chunk at the last tap
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 int qv = qb[i];
@@ -265,13 +278,13 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
         }
         const int nstage = stage + 1 == NSB ? 0 : stage + 1;
         const char* const pb = bring + nstage * BST + b_row_off;
-        auto dma = [&](auto dc) {
+        auto dma = [&](auto dc) __attribute__((always_inline)) {
             constexpr int d = decltype(dc)::value;
             if (ab & 128) return;
             if constexpr (d < LB) issue_w_piece(d, step + D, stage);       // slice step+D refills the stage of slice `step`
             else                  issue_patch(k0 + d - LB, cc + 1, pn);
         };
-        auto reads_of_slot = [&](auto mc) {
+        auto reads_of_slot = [&](auto mc) __attribute__((always_inline)) {
             constexpr int m = decltype(mc)::value;
             if (ab & 32) return;
             static_for<RPS>([&](auto rc) {
@@ -296,28 +309,33 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
         // whatever found no slot (short MFMA sequences with many pieces)
         constexpr int DMA_IN_SLOTS = pp3::cmin(NDMA, NMMA - 1 - RUSED > 0 ? NMMA - 1 - RUSED : 0);
         static_for<NDMA - DMA_IN_SLOTS>([&](auto dc) { dma(std::integral_constant<int, DMA_IN_SLOTS + decltype(dc)::value>{}); });
-        if (!(ab & 256)) wait_vmcnt<(ONE ? (D - 2) * LB : pp3::pending_at(TAP, GP, LB, D))>();
+        if (!(ab & 256)) wait_vmcnt<(ONE ? (D - 2) * LB : pp3::pending_at(TAP, GP, LB, D, NT))>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set 1-PAR is complete; the reads of slice step+1 are retired
         ++step;
         stage = nstage;
-        if constexpr (TAP == 8 && !ONE) {
+        if constexpr (TAP == NT - 1 && !ONE) {
             ++cc;
             const char* t = pa; pa = pn; pn = const_cast<char*>(t);
         }
     };
-    auto chunk = [&](auto par0c) {
+    static_assert(NT % 2 == 1, "an odd number of taps per chunk: the register-set parity flips from chunk to chunk");
+    auto chunk = [&](auto par0c) __attribute__((always_inline)) {
         constexpr int P0 = decltype(par0c)::value;
-        iteration(std::integral_constant<int, 0>{}, std::integral_constant<int, P0>{});
-        iteration(std::integral_constant<int, 1>{}, std::integral_constant<int, 1 - P0>{});
-        iteration(std::integral_constant<int, 2>{}, std::integral_constant<int, P0>{});
-        iteration(std::integral_constant<int, 3>{}, std::integral_constant<int, 1 - P0>{});
-        iteration(std::integral_constant<int, 4>{}, std::integral_constant<int, P0>{});
-        iteration(std::integral_constant<int, 5>{}, std::integral_constant<int, 1 - P0>{});
-        iteration(std::integral_constant<int, 6>{}, std::integral_constant<int, P0>{});
-        iteration(std::integral_constant<int, 7>{}, std::integral_constant<int, 1 - P0>{});
-        iteration(std::integral_constant<int, 8>{}, std::integral_constant<int, P0>{});
+        if constexpr (NT == 9) {                             // the 3x3 kernels exactly as they shipped in round 4
+            iteration(std::integral_constant<int, 0>{}, std::integral_constant<int, P0>{});
+            iteration(std::integral_constant<int, 1>{}, std::integral_constant<int, 1 - P0>{});
+            iteration(std::integral_constant<int, 2>{}, std::integral_constant<int, P0>{});
+            iteration(std::integral_constant<int, 3>{}, std::integral_constant<int, 1 - P0>{});
+            iteration(std::integral_constant<int, 4>{}, std::integral_constant<int, P0>{});
+            iteration(std::integral_constant<int, 5>{}, std::integral_constant<int, 1 - P0>{});
+            iteration(std::integral_constant<int, 6>{}, std::integral_constant<int, P0>{});
+            iteration(std::integral_constant<int, 7>{}, std::integral_constant<int, 1 - P0>{});
+            iteration(std::integral_constant<int, 8>{}, std::integral_constant<int, P0>{});
+        } else {
+            pp3_run_chunk<P0>(iteration, std::make_integer_sequence<int, NT>{});     // taps 0 .. NT-1, register sets P0, 1 - P0, P0, ...
+        }
     };
-    // 9 taps per chunk: the register-set parity flips from chunk to chunk
+    // NT (odd) taps per chunk: the register-set parity flips from chunk to chunk
     int c = (ab & 1024) ? ncc : 0;                            // ablation 1024: prologue + epilogue only
     for (; c + 1 < ncc; c += 2) {
         chunk(std::integral_constant<int, 0>{});
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     V2V_STAMP(p, 3);
 
     const bool tile_full = oh0 + TH <= H && ow0 + TW <= W;    // every row of the tile is a pixel of the layer (uniform: conv_epilogue's fast paths)
-    auto pix_of = [&](int row) -> int {        // TW is a power of two; N*OH*OW < 2^31 (host check)
+    auto pix_of = [&](int row) __attribute__((always_inline)) -> int {        // TW is a power of two; N*OH*OW < 2^31 (host check)
         const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
         if (oh >= H || ow >= W) return -1;
         return (n_img * H + oh) * W + ow;
@@ -397,12 +415,28 @@ __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(con
     }
 }
 
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2, int KS = 1, bool ONE = false>
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false>
+__global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
+    conv3x3_pp3_body<T, TH, TW, BN, D, ABL, WGM_, WGN_, KS_, ONE, 3>(p_in);
+}
+
+// 7x7 window: its own entry point, pinned to two waves per SIMD.  The lambdas of the body are always_inline: with 98 unrolled tap
+// steps the inliner otherwise leaves some of them as calls, their by-reference captures pin the argument block (a 700-byte struct)
+// and the pipeline state to scratch memory -- 85 registers + 1.8 KB of scratch per lane for the 128-channel tile, and a back end that
+// cannot honour the epilogue's SGPR pins ("illegal VGPR to SGPR copy") -- -Rpass-analysis=kernel-resource-usage before / after
+template <typename T, int TH, int TW, int BN, int D, int WGM_ = 4, int WGN_ = 2>
+__global__ __launch_bounds__(WGM_ * WGN_ * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv7x7_pp3_kernel(const ConvKArgs p_in) {
+    conv3x3_pp3_body<T, TH, TW, BN, D, 0, WGM_, WGN_, 1, false, 7>(p_in);
+}
+
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2, int KS = 1, bool ONE = false, int KK = 3>
 static int launch_pp3_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
     constexpr int NW = WGM * WGN * KS;
-    constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW;
+    constexpr int GP = (((TH + KK - 1) * (TW + KK - 1) + 7) / 8 + NW - 1) / NW;
     const size_t lds = (size_t)(ONE ? 1 : 2) * GP * NW * 1024 + (size_t)D * BN * 128;
-    auto kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN, KS, ONE>;
+    void (*kern)(const ConvKArgs);
+    if constexpr (KK == 7) kern = conv7x7_pp3_kernel<T, TH, TW, BN, D, WGM, WGN>;
+    else                   kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN, KS, ONE>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -421,6 +455,9 @@ static const PatchCfg kPp3Cfgs[] = {
     {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
     {92, 8, 32, 64}, {93, 4, 64, 64},      // K quads: 2 x 1 wave tiles of 128 x 64, four K quarters: 6 reads per 8 MFMAs
     {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 72 / 80 KiB
+    {96, 4, 32, 64},                       // single-chunk layers, FOUR waves (2 x 2, 64 x 32 wave tiles), 28 + 24 = 52 KiB, 167 + 32 registers: the
+                                           // tile that really puts two workgroups on a CU (staged for round 5; 94 / 95 never did: DESIGN 3.6 item 15)
+    {120, 4, 32, 64}, {121, 4, 32, 128},   // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk
 };
 static inline const PatchCfg* find_pp3_cfg(int id) {
     for (const PatchCfg& c : kPp3Cfgs)
@@ -443,6 +480,15 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 91: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 4, 1, 2>(k, groups, s);   // as 83 for 64-wide tile rows
         case 92: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 2, 1, 4>(k, groups, s);   // as 82, K quads
         case 93: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 2, 1, 4>(k, groups, s);   // as 83, K quads
+        case 120: case 121:                // 7x7 window: bf16 only for now (the fp32 instantiations double an 8-minute translation unit)
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                if (cfg == 120) return launch_pp3_cfg<T, 4, 32, 64, 4, 0, 4, 2, 1, false, 7>(k, 1, s);    // 128 px x  64, 2 x 48 + 32 = 128 KiB, 109 registers
+                return launch_pp3_cfg<T, 4, 32, 128, 3, 0, 4, 2, 1, false, 7>(k, 1, s);                   // 128 px x 128, 2 x 48 + 48 = 144 KiB, 163 registers
+            }
+            break;
+        case 96:                           // single-chunk, four waves: two co-resident workgroups per CU by registers (2 waves / SIMD) and LDS (52 KiB)
+            if constexpr (std::is_same<T, bf16_t>::value) return launch_pp3_cfg<T, 4, 32, 64, 3, 0, 2, 2, 1, true>(k, 1, s);
+            break;
         case 94: case 95:                  // single-chunk tiles: bf16 only (64 input channels = one 128-byte chunk), single launches only
             if constexpr (std::is_same<T, bf16_t>::value) {
                 if (cfg == 94) return launch_pp3_cfg<T, 8, 32, 64, 3, 0, 4, 2, 1, true>(k, 1, s);   // as 80 with 3 slices: 48 + 24 KiB

@@ -419,6 +419,7 @@ struct ConvOp : Op {
     long long slab_bytes; int sk_tickets;
     int groups = 1;      // 2: grouped launch (v2v_conv2d_pair), second member's tensors in k.g1
     int launch(hipStream_t s) override {
+        if (cfg >= 120) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, 1, s) : launch_pp3_f32(cfg, k, 1, s);    // 7x7 window on the single-phase kernel
         if (cfg >= 110) return dtype == V2V_BF16 ? launch_t2_bf16(cfg, k, s) : launch_t2_f32(cfg, k, s);
         if (cfg >= 100) return dtype == V2V_BF16 ? launch_s2_bf16(cfg, k, s) : launch_s2_f32(cfg, k, s);
         if (cfg >= 80) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, groups, s) : launch_pp3_f32(cfg, k, groups, s);
@@ -593,6 +594,23 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.m_tiles = d->N * k.tiles_h * k.tiles_w;
         k.n_tiles = 1;
         tile_bm = 256; tile_bn = 4;
+    } else if (op->cfg >= 120) {
+        // conv3x3_pp3_body with a 7x7 window (tile 120; staged for round 5): dense 7x7 / stride 1 / pad 3 Conv2d whose channel
+        // stride is a whole number of 128-byte chunks, weights channel-chunk major (korder 1), bf16
+        const PatchCfg* pc = find_pp3_cfg(op->cfg);
+        if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
+        if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->dtype != V2V_BF16 ||
+            d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 1 || d->out_mode == V2V_OUT_NORM_ACT_NHWC ||
+            (d->pad_mode == V2V_PAD_REFLECT && (d->H <= 3 || d->W <= 3)) ||
+            (long long)d->N * d->H * d->W * d->cin_stride * 2 >= (1ll << 32)) {
+            set_error("conv: tile config %d needs a bf16 7x7/s1/p3 Conv2d, cin_stride %% %d == 0, korder-1 weights, no fused norm",
+                      op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
+        }
+        k.tiles_h = (int)ceil_div(d->OH, pc->TH);
+        k.tiles_w = (int)ceil_div(d->OW, pc->TW);
+        k.m_tiles = d->N * k.tiles_h * k.tiles_w;
+        k.n_tiles = (int)ceil_div(d->cout, pc->BN);
+        tile_bm = pc->TH * pc->TW; tile_bn = pc->BN;
     } else if (op->cfg >= 110) {
         // conv3x3_t2_kernel: ConvTranspose2d(3x3, stride 2, padding 1), all four output-parity classes per workgroup, full-tap (korder 2) weights
         const PatchCfg* pc = find_t2_cfg(op->cfg);
@@ -636,7 +654,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
             set_error("conv: patch tile config %d needs a 3x3/s1/p1 Conv2d, cin_stride %% %d == 0 and korder-1 weights",
                       op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
         }
-        if ((op->cfg == 94 || op->cfg == 95) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
+        if ((op->cfg == 94 || op->cfg == 95 || op->cfg == 96) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
                                                  d->out_mode == V2V_OUT_NORM_ACT_NHWC)) {
             set_error("conv: tile config %d is a single-chunk tile: bf16, cin_stride exactly %d, no split-K, no fused norm", op->cfg, bke_of(d->dtype));
             return V2V_EINVAL;

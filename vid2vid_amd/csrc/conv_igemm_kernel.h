@@ -565,8 +565,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
         const bool raw_t = p.out_mode == V2V_OUT_RAW_ACT_NHWC;
         // uniform epilogue operands pinned in SGPRs: the unrolled store loops otherwise re-fetch them from the kernel-argument
         // segment per element (profiles/r02_isa_sload_report.txt: 32-128 s_load_dword + s_waitcnt per launch)
-        int e_act = raw_t ? V2V_ACT_NONE : p.act; float e_act_param = p.act_param;
-        int e_scale_bits = raw_t ? 0x3f800000 : __float_as_int(p.out_scale);     // (an integer select: a float one would be a VALU op)
+        // (readfirstlane: a no-op for values that already live in scalar registers -- every shipped instantiation; the 7x7-window
+        //  instantiation of the single-phase kernel is large enough that the argument block reaches here through vector registers)
+        int e_act = __builtin_amdgcn_readfirstlane(raw_t ? V2V_ACT_NONE : p.act);
+        float e_act_param = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.act_param)));
+        int e_scale_bits = __builtin_amdgcn_readfirstlane(raw_t ? 0x3f800000 : __float_as_int(p.out_scale));     // (an integer select: a float one would be a VALU op)
         asm volatile("" : "+s"(e_act), "+s"(e_act_param), "+s"(e_scale_bits));
         const float e_out_scale = __int_as_float(e_scale_bits);
         // NONE / RELU / LEAKY (every norm-less hidden layer) as one select with hoisted conditions: bit for bit apply_act()
@@ -654,7 +657,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
         }
     } else {                                       // planar fp32 NCHW (API-facing heads)
         float* const out = reinterpret_cast<float*>(p.out);
-        int e_act = p.act; float e_act_param = p.act_param, e_out_scale = p.out_scale;
+        int e_act = __builtin_amdgcn_readfirstlane(p.act);
+        float e_act_param = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.act_param)));
+        float e_out_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.out_scale)));
         asm volatile("" : "+s"(e_act), "+s"(e_act_param), "+s"(e_out_scale));
         const unsigned ohow = (unsigned)(p.OH * p.OW);
         if (p.N > 1) {                             // pixel index -> n * cout * OH*OW + pixel-in-image

@@ -347,18 +347,21 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               86: (4, 32, 128), 87: (2, 64, 128),      # 86 / 87: four waves, 64 x 64 wave tiles
               90: (8, 32, 64), 91: (4, 64, 64),        # 90 / 91: 82 / 83 with K pairs (8 fragment reads per 8 MFMAs)
               92: (8, 32, 64), 93: (4, 64, 64),        # 92 / 93: K quads (6 reads per 8 MFMAs)
-              94: (8, 32, 64), 95: (4, 64, 64)}        # 94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
+              94: (8, 32, 64), 95: (4, 64, 64), 96: (4, 32, 64)}        # 94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
 # stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
 S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
 # ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
 T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 64)}
+# dense 7x7 / stride 1 / pad 3 convolutions on the single-phase kernel with a 7x7 window (csrc/conv3x3_pp3_kernel.h, KK = 7): id -> (TH, TW, BN).
+# STAGED FOR ROUND 5: built and dry-run tested, not yet run on a GPU -- offered to the tile search only with V2V_S7_PATCH=1
+S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
 
 
 def is_patch_tile(t):
     """Tile ids of the LDS-patch 3x3 kernels (weights in K order 1): patch 32-48, ping-pong 50-57, ping-pong 2 70-79."""
-    return 32 <= t < 60 or 70 <= t < 96 or 100 <= t < 110
+    return 32 <= t < 60 or 70 <= t < 97 or 100 <= t < 110 or 120 <= t < 130
 
 
 def tile_korder(t):
@@ -1195,6 +1198,12 @@ class Engine:
         return (not d.transposed and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1
                 and d.cin_stride % bke == 0)
 
+    def s7_eligible(self, d):
+        """7x7-window tiles 120 / 121: dense bf16 7x7 / stride 1 / pad 3 Conv2d whose channel stride is a whole number of 128-byte chunks
+        (the stems on the pooled label encodings, edge2face's 45 -> 128 stem); opt-in until validated on a GPU."""
+        return (self.dtype == L.BF16 and not d.transposed and d.KH == 7 and d.KW == 7 and d.stride == 1 and d.pad == 3
+                and d.cin_stride % 64 == 0 and d.out_mode != L.OUT_NORM_ACT_NHWC and os.environ.get("V2V_S7_PATCH", "0") == "1")
+
     def s2_eligible(self, d):
         """conv3x3_s2_kernel: 3x3 / stride 2 / zero pad 1 Conv2d whose channel stride is a whole 128-byte chunk."""
         bke = 64 if self.dtype == L.BF16 else 32
@@ -1272,6 +1281,11 @@ class Engine:
                     if S == 1 and tiles < 64:
                         continue
                     cands.append((t, S, 0))
+        if mod is not None and role == "fwd" and self.s7_eligible(d):
+            for t, (th, tw, bn) in sorted(S7_CFGS.items()):
+                tiles = d.N * -(-d.OH // th) * -(-d.OW // tw) * -(-cout // bn)
+                if tiles >= 64 and (bn <= 64 or cout > 64):
+                    cands.append((t, 1, 0))
         if mod is not None and self.s2_eligible(d):
             for t, (th, tw, bn) in sorted(S2_CFGS.items()):
                 tiles = d.N * -(-d.OH // th) * -(-d.OW // tw) * -(-cout // bn)
