@@ -22,6 +22,7 @@ import torch.nn as nn
 from . import lib as L
 from .lib import lib, check, WgradDesc, ConvDesc
 from .engine import Act, pad_channels, _ptr, _stream, _TORCH_DTYPE
+from .parallel import note_use, note_done
 
 
 def _grad_ptr(p):
@@ -77,6 +78,11 @@ class ConvFn(torch.autograd.Function):
         cout = conv.out_channels
         ctx.cfg = cfg
         ctx.has_add = (add0_t is not None, add1_t is not None)
+        # parameters whose .grad this node's backward accumulates into: counted per gradient bucket so that the data-parallel
+        # runtime can all-reduce a bucket as soon as its last contribution of the pass is enqueued (parallel.BucketReady)
+        ctx.grad_params = [t for t in (weight, bias, gamma, beta) if t is not None and t.requires_grad] if any(ctx.needs_input_grad) else []
+        if ctx.grad_params:
+            note_use(ctx.grad_params)
         if norm is not None:
             N, H, W = x.N, x.H, x.W
             pc = eng.packed(conv, x.Cs)
@@ -183,6 +189,8 @@ class ConvFn(torch.autograd.Function):
             dx = _conv_backward_data(eng, cfg, conv, transposed, g, cout, x, N, OH, OW)
         d0 = dy if ctx.has_add[0] and ctx.needs_input_grad[6] else None
         d1 = dy if ctx.has_add[1] and ctx.needs_input_grad[7] else None
+        if ctx.grad_params:
+            note_done(ctx.grad_params)                       # every kernel that writes these gradients is enqueued
         return None, dx, None, None, None, None, d0, d1
 
 

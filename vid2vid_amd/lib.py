@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libv2v_hip.so")
+# V2V_LIB_PATH: another BUILD of the same library (A/B measurements of two builds on one box, scripts/gpu_r5.sh); never a fallback
+LIB_PATH = os.environ.get("V2V_LIB_PATH") or os.path.join(_HERE, "libv2v_hip.so")
 
 # dtype / mode codes (include/v2v_hip.h)
 F32, BF16 = 0, 1

@@ -179,8 +179,8 @@ class BaseModel(torch.nn.Module):
         learning rate of the new, never-stepped object while the captured one keeps the rate it had.
 
         Default here = exactly that behaviour, so that a run switched over from the reference produces the reference's
-        parameters: the captured FusedAdam is left alone (`self._optimizer_G_live` keeps a handle for checkpoints / gradient
-        sync), `self.optimizer_G` becomes an unstepped stand-in that takes (c), and the coarse-scale gradients of (b), which
+        parameters: the captured FusedAdam is left alone (`self._optimizer_G_live` keeps it reachable from the model -- e.g. for
+        `FusedAdam.state_dict()` -- nothing in the package reads it), `self.optimizer_G` becomes an unstepped stand-in that takes (c), and the coarse-scale gradients of (b), which
         nothing can observe, are not computed (`_train_coarse` stays False: the finest scale's gradient is identical with or
         without the detach).  `opt.fix_update_fixed_params` (or V2V_FIX_UPDATE_FIXED_PARAMS=1) selects what the reference's
         authors evidently meant instead: the captured optimizer is rebuilt IN PLACE over all scales (fresh moments, lr /
@@ -195,6 +195,10 @@ class BaseModel(torch.nn.Module):
         elif not isinstance(self.optimizer_G, _UnsteppedAdam):
             self._optimizer_G_live = self.optimizer_G
             self.optimizer_G = _UnsteppedAdam(lr=self.old_lr, betas=(self.opt.beta1, 0.999), n_params=sum(p.numel() for p in params))
+            print("vid2vid_amd: WARNING -- reference-compatible update_fixed_params (train.py keeps stepping the optimizer it captured "
+                  "at start-up): the coarse scales stay frozen and the generator's learning rate no longer decays from here on.  "
+                  "Set --fix_update_fixed_params (or V2V_FIX_UPDATE_FIXED_PARAMS=1) to train every scale, which is what the "
+                  "message below promises.")
         self.finetune_all = True
         print("------------ Now finetuning all scales -----------")
 

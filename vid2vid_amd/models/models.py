@@ -46,9 +46,12 @@ def _role_layout(opt):
         # one process per GPU: this process's device is the launcher's LOCAL_RANK (what parallel.init_distributed / bench.py
         # selected with torch.cuda.set_device), NOT an index into --gpu_ids -- two sequence groups on one node (8 processes,
         # --gpu_ids 0,1,2,3) would otherwise put ranks 4-7 on the GPUs of ranks 0-3
-        local = int(os.environ.get("LOCAL_RANK", layout.rank))
+        # LOCAL_RANK unset (srun / mpirun launchers): the global rank modulo the GPUs of this node -- the global rank itself would
+        # be out of range on every node after the first.  The user's --gpu_ids values are NOT a device map here (they
+        # only give the size of a sequence group): restrict / reorder devices with HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        local = int(os.environ["LOCAL_RANK"]) if "LOCAL_RANK" in os.environ else (layout.rank % ndev if ndev else layout.rank)
         if torch.cuda.is_available():
-            ndev = torch.cuda.device_count()
             if local >= ndev:
                 raise RuntimeError("role split: LOCAL_RANK %d but only %d GPUs are visible (one process per GPU)" % (local, ndev))
             torch.cuda.set_device(local)

@@ -41,6 +41,7 @@ class FlatBuffers:
         # update counter of THIS buffer: the fused optimizer writes flat_param from a HIP kernel (invisible to torch's
         # tensor version counters), so packed weight copies (engine.PackedConv) watch this box through the parameter
         self.epoch = [0]
+        self.ready = None                            # parallel.BucketReady once a GradSync is attached (sync_optimizers)
         # V2V_WEIGHTS_CL=1: 4-D (convolution) weights live CHANNELS-LAST in the flat buffers: physically [d0][KH][KW][d1],
         # logically still [d0][d1][KH][KW] (a permuted view, as torch.channels_last tensors are).  That is the column order the
         # weight-gradient kernel computes in -- an unsplit launch writes its tiles straight into .grad and a split one needs no
@@ -56,6 +57,7 @@ class FlatBuffers:
                 p.data = view
                 p.grad = self._view(self.flat_grad, p, o)
                 p._v2v_epoch = self.epoch
+                p._v2v_flat = self
 
     def _view(self, flat, p, o):
         seg = flat[o:o + p.numel()]
@@ -95,7 +97,11 @@ class FusedAdam(torch.optim.Optimizer):
             grp["lr"] = lr
         if betas is not None:
             grp["betas"] = tuple(betas)
+        had_ready = self.flat.ready is not None
         self.flat = FlatBuffers(params)
+        if had_ready and self.grad_sync is not None:
+            from .parallel import BucketReady
+            self.flat.ready = BucketReady(self.flat, self.grad_sync)
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.step_count = 0
@@ -131,6 +137,8 @@ class FusedAdam(torch.optim.Optimizer):
         if not g.is_cuda and not lib.v2v_get_dry_run():
             raise RuntimeError("FusedAdam runs on the MI355X only")
         check(lib.v2v_memset_zero(C.c_void_p(g.data_ptr()), g.numel() * 4, stream), "memset_zero")
+        if self.flat.ready is not None:
+            self.flat.ready.arm()                    # the backward pass that follows writes the gradients of THIS step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -156,8 +164,14 @@ class FusedAdam(torch.optim.Optimizer):
                                     float(grp["weight_decay"]), float(gscale), step_no, sptr), "adam_step")
 
         gs = self.grad_sync
+        rest = f.ready.finish() if (f.ready is not None and f.ready.armed) else None      # buckets not sent from inside the pass
         if gs is not None and f.flat_param.is_cuda and (gs.world > 1 or gs.force_collective):
-            gs.run_overlapped(f.flat_grad, adam, owner=self)     # RCCL all-reduce + Adam on the side stream, behind this backward pass
+            gs.run_overlapped(f.flat_grad, adam, owner=self, rest=rest)     # RCCL all-reduce + Adam on the side stream, behind this backward pass
+        elif gs is not None and rest is not None:
+            for b in rest:
+                gs.late_buckets += 1
+                gs.reduce_bucket(b)
+            adam(gs.grad_scale(), None)
         else:
             adam(gs.all_reduce(f.flat_grad) if gs is not None else 1.0, None)
         f.epoch[0] += 1                                      # packed copies of THESE parameters are now stale

@@ -55,13 +55,26 @@ class GradSync:
     which goes straight on to the next loss's backward -- G's 1.66 GB of fp32 gradients (~19 ms as a ring over 153 GB/s
     xGMI links) travel while the discriminators' backward passes run.  The compute stream waits for the side stream only
     where the updated parameters (or the gradient buffer) are next touched: the next forward of any model
-    (models.RankModel.forward -> wait_pending) and that optimizer's next zero_grad.  Gradients are NOT all-reduced
-    layer by layer inside a backward pass: the HIP backward kernels accumulate straight into the flat gradient views over
-    several frames and scales, so a bucket is only complete when its backward pass ends.
+    (models.RankModel.forward -> wait_pending) and that optimizer's next zero_grad.
+
+    Round 5 -- buckets INSIDE the backward pass ("bucketed, reverse order, overlapped with backward").  The HIP backward
+    kernels accumulate straight into the flat gradient views over several frames and scales, so autograd never sees a parameter
+    gradient and no hook fires.  `BucketReady` (below) counts instead: every autograd node that will write parameter gradients
+    (autograd.ConvFn, the only one) registers its parameters' buckets when the forward pass creates it and reports them when its
+    backward has enqueued its last kernel; once the optimizer is armed (zero_grad) a bucket whose count reaches zero has received
+    its last contribution of this pass -- with several frames per chunk that happens during the backward of the FIRST frame, the
+    last of the pass -- and its all-reduce is enqueued on the side stream behind an event of the compute stream, while the
+    backward pass goes on.  step() sends whatever is left and the Adam kernel.  A contribution that arrives for a bucket already
+    sent raises (it cannot happen while every gradient-writing node is counted; the check is what makes that a tested property).
     On CPU tensors (gloo tests) everything runs in order on the host."""
 
-    def __init__(self, group=None, bucket_bytes=64 << 20, force_collective=False, scale=None, wire_dtype=None):
+    def __init__(self, group=None, bucket_bytes=64 << 20, force_collective=False, scale=None, wire_dtype=None, in_backward=None):
         self.group = group
+        # in_backward: all-reduce each bucket as soon as its last gradient kernel of the pass has been enqueued (BucketReady);
+        # V2V_BUCKET_OVERLAP=0 falls back to one burst of buckets at step()
+        self.in_backward = (os.environ.get("V2V_BUCKET_OVERLAP", "1") != "0") if in_backward is None else bool(in_backward)
+        self.early_buckets = 0                       # buckets sent before step() (statistics, tests)
+        self.late_buckets = 0
         # wire_dtype=torch.bfloat16 (or V2V_GRAD_BF16=1): the buckets travel as bf16 -- half the bytes on the per-link-bound xGMI ring
         # (G's 1.66 GB: ~19 -> ~9.5 ms on 8 GPUs) for one rounding of every partial sum to 8 mantissa bits; the master gradient, the
         # moments and the update stay fp32.  Off by default: the reference sums fp32 gradients.
@@ -108,13 +121,49 @@ class GradSync:
                 w.wait()
         return 1.0 / world if self.scale is None else self.scale
 
+    def reduce_bucket(self, b):
+        """Sum ONE bucket over the ranks in place on the current stream (the building block of the in-backward path)."""
+        if self.world == 1 and not (self.force_collective and dist.is_initialized()):
+            return
+        if host_staged(b, self.group):
+            host = b.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            b.copy_(host)
+        elif self.wire_dtype is not None and self.wire_dtype != b.dtype:
+            w_ = b.to(self.wire_dtype)
+            dist.all_reduce(w_, op=dist.ReduceOp.SUM, group=self.group)
+            b.copy_(w_)
+        else:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+
+    def send_ready_bucket(self, b):
+        """Called by BucketReady from inside a backward pass: the kernels that wrote `b` are enqueued on the current stream.
+        GPU: the side stream waits for an event recorded now and runs the collective; the compute stream goes on."""
+        self.early_buckets += 1
+        if not b.is_cuda:
+            self.reduce_bucket(b)
+            return
+        cur = torch.cuda.current_stream(b.device)
+        side = self.side_stream(b.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self.reduce_bucket(b)
+
+    def collective_active(self):
+        return self.world > 1 or (self.force_collective and dist.is_initialized())
+
+    def grad_scale(self):
+        return (1.0 / self.world) if self.scale is None else self.scale
+
     # ---- overlap with the following backward pass (GPU only) ----
     def side_stream(self, device):
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=device)
         return self._stream
 
-    def run_overlapped(self, flat, fn, owner=None):
+    def run_overlapped(self, flat, fn, owner=None, rest=None):
         """Enqueue all_reduce(flat) followed by fn(grad_scale, stream) on the side stream, ordered after everything already
         on the current stream; returns immediately.  fn launches the optimizer kernel on the stream it is handed.  The
         completion event is filed under `owner` (the optimizer): that optimizer's next zero_grad waits for ITS event only,
@@ -123,7 +172,13 @@ class GradSync:
         side = self.side_stream(flat.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            scale = self.all_reduce(flat)
+            if rest is None:
+                scale = self.all_reduce(flat)
+            else:                                    # the in-backward path already sent the other buckets on this side stream
+                for b in rest:
+                    self.late_buckets += 1
+                    self.reduce_bucket(b)
+                scale = self.grad_scale()
             fn(scale, side)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -163,14 +218,86 @@ class GradSync:
                 dist.broadcast(flat, src=src, group=self.group)
 
 
+class BucketReady:
+    """Readiness bookkeeping of ONE flat gradient buffer (optim.FlatBuffers.ready): which buckets still expect gradient kernels.
+
+    open[k]  = autograd nodes alive that will write into bucket k (registered by the forward pass, reported by their backward);
+    armed    = between the optimizer's zero_grad() and step(): the pass that runs now writes THIS buffer's gradients for the step;
+    sent[k]  = bucket k was handed to the collective in this armed window.
+    A parameter that straddles a bucket boundary counts in every bucket it touches."""
+
+    def __init__(self, flat, sync):
+        self.flat, self.sync = flat, sync
+        self.be = sync.bucket_elems
+        self.n = (flat.numel + self.be - 1) // self.be
+        self.open = [0] * self.n
+        self.sent = [False] * self.n
+        self.armed = False
+        self.span = {}                               # id(param) -> range of bucket indices
+        for p_, o in zip(flat.params, flat.offsets):
+            self.span[id(p_)] = range(o // self.be, (o + max(p_.numel(), 1) - 1) // self.be + 1)
+
+    def bucket(self, k):
+        g = self.flat.flat_grad
+        return g[k * self.be:min((k + 1) * self.be, g.numel())]
+
+    def use(self, p_):
+        for k in self.span.get(id(p_), ()):
+            if self.armed and self.sent[k]:
+                raise RuntimeError("BucketReady: a gradient-writing node was created for a bucket that was already all-reduced in this pass")
+            self.open[k] += 1
+
+    def done(self, p_):
+        for k in self.span.get(id(p_), ()):
+            if self.armed and self.sent[k]:
+                raise RuntimeError("BucketReady: a gradient contribution arrived after its bucket had been all-reduced "
+                                   "(an uncounted gradient-writing node)")
+            self.open[k] -= 1
+            if self.open[k] < 0:                     # a node of a graph built before the counters were attached / reset
+                self.open[k] = 0
+                continue
+            if self.armed and self.open[k] == 0 and self.sync.in_backward and self.sync.collective_active():
+                self.sent[k] = True
+                self.sync.send_ready_bucket(self.bucket(k))
+
+    def arm(self):
+        self.armed = True
+        self.sent = [False] * self.n
+
+    def finish(self):
+        """step(): the buckets that were not sent from inside the pass; disarms and clears leaked counts."""
+        rest = [self.bucket(k) for k in range(self.n) if not self.sent[k]]
+        self.armed = False
+        self.sent = [False] * self.n
+        self.open = [0] * self.n
+        return rest
+
+
+def note_use(params):
+    """autograd.ConvFn.forward: this node will accumulate into the gradients of `params` when it runs backward."""
+    for p_ in params:
+        r = getattr(getattr(p_, "_v2v_flat", None), "ready", None)
+        if r is not None:
+            r.use(p_)
+
+
+def note_done(params):
+    """autograd.ConvFn.backward, after its last launch."""
+    for p_ in params:
+        r = getattr(getattr(p_, "_v2v_flat", None), "ready", None)
+        if r is not None:
+            r.done(p_)
+
+
 _ACTIVE_SYNCS = []
 
 
-def sync_optimizers(optimizers, group=None, bucket_bytes=64 << 20, force_collective=False):
+def sync_optimizers(optimizers, group=None, bucket_bytes=64 << 20, force_collective=False, in_backward=None):
     """Attach a GradSync to each FusedAdam and make every rank start from rank 0's parameters."""
-    gs = GradSync(group, bucket_bytes, force_collective)
+    gs = GradSync(group, bucket_bytes, force_collective, in_backward=in_backward)
     for opt in optimizers:
         opt.grad_sync = gs
+        opt.flat.ready = BucketReady(opt.flat, gs)   # in-backward bucket scheduling (counts start with the next forward pass)
         gs.broadcast(opt.flat.flat_param)
     _ACTIVE_SYNCS.append(gs)
     return gs
