@@ -21,10 +21,10 @@ import torch
 from . import vid2vid_oracle as O
 
 
-def _trainable(sd):
+def _trainable(sd, dtype=torch.float32):
     out = {}
     for k, v in sd.items():
-        v = v.detach().float().cpu().clone()
+        v = v.detach().to(dtype).cpu().clone() if v.is_floating_point() else v.detach().cpu().clone()
         if v.is_floating_point() and "running_" not in k:
             v.requires_grad_(True)
         out[k] = v
@@ -37,16 +37,18 @@ def _flat(named):
 
 def oracle_chunk(sds_G, sd_D, sd_DT, lab, inst, B, flow_ref, conf_ref, *, label_nc=35, fg=True, fg_labels=(26,),
                  n_down=3, n_blocks=9, n_blocks_local=3, n_frames_load=3, tG=3, tD=3, n_layers_D=3, num_D=2,
-                 lambda_feat=10.0, lambda_F=10.0, lambda_T=10.0, sd_vgg=None, param_names=None):
+                 lambda_feat=10.0, lambda_F=10.0, lambda_T=10.0, sd_vgg=None, param_names=None, dtype=torch.float32):
     """CPU side.  sds_G: state_dicts of netG0..netG{S-1}; lab / inst (1,T,1,H,W), B (1,T,3,H,W) with
     T = n_frames_load + tG - 1; flow_ref (1,n_frames_load,2,H,W), conf_ref (1,n_frames_load,1,H,W).
     param_names: {"G": [[names of netG0], ...], "D": [...], "DT": [...]} -- the parameter order the gradients are
     flattened in (the product's named_parameters() order)."""
     t0 = time.perf_counter()
     S = len(sds_G)
-    sds_G = [_trainable(sd) for sd in sds_G]
-    sd_D = _trainable(sd_D)
-    sd_DT = None if sd_DT is None else _trainable(sd_DT)
+    # dtype = torch.float64 (with torch.set_default_dtype(torch.float64) around the call): the exact-arithmetic stand-in that
+    # scripts/oracle_noise_floor.py measures the fp32 oracle itself against
+    sds_G = [_trainable(sd, dtype) for sd in sds_G]
+    sd_D = _trainable(sd_D, dtype)
+    sd_DT = None if sd_DT is None else _trainable(sd_DT, dtype)
     real_A = O.encode_input(lab, inst, label_nc)
     fake_B, fake_B_raw, flow, weight, fake_pyr = O.generate_frames_train(sds_G, real_A, B, fg, list(fg_labels), n_down, n_blocks,
                                                                          n_blocks_local, n_frames_load, tG, return_pyramid=True)
@@ -93,6 +95,8 @@ def oracle_chunk(sds_G, sd_D, sd_DT, lab, inst, B, flow_ref, conf_ref, *, label_
         losses={k: float(v.detach()) for k, v in list(losses.items()) + list(lt.items())},
         totals=dict(G=float(loss_G.detach()), D=float(loss_D.detach()), DT=None if loss_DT is None else float(loss_DT.detach())),
         grads=dict(G=_flat(gG), D=_flat(gD), DT=_flat(gDT)),
+        # (name, numel) of every tensor of the flattened gradients, in order: compare() attributes the L2 distance to tensors
+        grad_names=dict(G=[(n, g.numel()) for n, g in gG], D=[(n, g.numel()) for n, g in gD], DT=[(n, g.numel()) for n, g in gDT]),
         # fake_B_pyr of the chunk (finest scale first; the tG-1 given frames, then the generated ones): what a teacher-forced
         # product run starts every frame t > 0 from (hip_chunk(teacher=...))
         fake_pyr=fake_pyr,
@@ -190,6 +194,46 @@ def param_names_of(G, D):
     return names
 
 
+def attribute_grad_error(g, r, names, top=12):
+    """Where the relative L2 distance of a flattened gradient comes from: per parameter tensor
+    d_i = |g_i - r_i|^2, reported as its share of sum d, with the tensor's own relative error |g_i - r_i| / |r_i| and the
+    ratio of the norms; grouped by parameter kind (conv weight / conv bias / norm weight / norm bias) and by the sub-module the
+    tensor belongs to.  `share` sums to 1 over all tensors."""
+    rows, o = [], 0
+    for n, k in names:
+        gi, ri = g[o:o + k], r[o:o + k]
+        o += k
+        d2, r2, g2 = float((gi - ri).pow(2).sum()), float(ri.pow(2).sum()), float(gi.pow(2).sum())
+        rows.append((n, k, d2, r2, g2))
+    assert o == g.numel() == r.numel()
+    tot = sum(x[2] for x in rows) or 1e-300
+    rtot = sum(x[3] for x in rows) or 1e-300
+
+    def kind(n, k):
+        leaf = n.rsplit(".", 1)[-1]
+        # the smallest conv weight of these networks (16 -> 3, 7x7 aside: 3 x 16 x 49) is larger than the widest norm (1024)
+        return ("norm " if leaf == "weight" and k <= 1024 else "conv / norm " if leaf == "bias" else "conv ") + leaf
+
+    def group(n):
+        parts = n.split(".")
+        return ".".join(parts[:2]) if len(parts) > 2 else parts[0]      # "G0.model_down_seg", "scale0_layer0", ...
+    by_group, by_kind = {}, {}
+    for n, k, d2, r2, g2 in rows:
+        a = by_group.setdefault(group(n), [0.0, 0.0]); a[0] += d2; a[1] += r2
+        b = by_kind.setdefault(kind(n, k), [0.0, 0.0]); b[0] += d2; b[1] += r2
+    fmt = lambda v: float("%.3e" % v)
+    return {
+        "l2_rel_err": fmt((tot / rtot) ** 0.5),
+        "top_tensors": [{"name": n, "numel": k, "share": fmt(d2 / tot), "rel_err": fmt((d2 / max(r2, 1e-300)) ** 0.5),
+                         "norm_ratio": fmt((g2 / max(r2, 1e-300)) ** 0.5), "ref_norm_share": fmt((r2 / rtot) ** 0.5)}
+                        for n, k, d2, r2, g2 in sorted(rows, key=lambda x: -x[2])[:top]],
+        "by_module": {m: {"share": fmt(v[0] / tot), "rel_err": fmt((v[0] / max(v[1], 1e-300)) ** 0.5)}
+                      for m, v in sorted(by_group.items(), key=lambda kv: -kv[1][0])[:top]},
+        "by_kind": {m: {"share": fmt(v[0] / tot), "rel_err": fmt((v[0] / max(v[1], 1e-300)) ** 0.5)} for m, v in sorted(by_kind.items(), key=lambda kv: -kv[1][0])},
+        "tensors": len(rows),
+    }
+
+
 def compare(got, ref):
     """Errors of the product's chunk against the oracle's.  Per-pixel measure of the forward tensors as everywhere
     (|got-ref| / (|ref| + rms(ref)): maximum and mean); losses: |got-ref| / max(|ref|, 1e-3); gradients per optimizer:
@@ -221,6 +265,9 @@ def compare(got, ref):
                            "norm_rel_err": float("%.3e" % (abs(gn - rn) / max(rn, 1e-30))),
                            "l2_rel_err": float("%.3e" % ((g - r).norm().item() / max(rn, 1e-30))),
                            "finite": bool(torch.isfinite(g).all().item()), "numel": int(r.numel())}
+    if "grad_names" in ref:
+        out["grad_error_by_tensor"] = {k: attribute_grad_error(got["grads"][k], ref["grads"][k], ref["grad_names"][k])
+                                       for k in ("G", "D", "DT") if ref["grads"][k].numel() and got["grads"][k].numel()}
     out["max_forward"] = max(v["max_rel"] for v in out["forward"].values())
     out["max_forward_frame0"] = max(v["max_rel_frame0"] for v in out["forward"].values())
     out["max_loss"] = max(out["losses"].values())

@@ -1,0 +1,86 @@
+#!/bin/bash
+# Round-5 GPU visits.  scripts/gpu_r5.sh <tag> [parts...]   (every part writes under gpurun_out/<tag>_*)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=${1:-r5}; shift
+WHAT=${*:-alltests}
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+T0=$(date +%s)
+lap() { echo "[$(( $(date +%s) - T0 )) s] $1"; }
+LEAN="--no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3"
+if has benchdefault; then    # the driver's command, timed; the stdout line must be the LAST line of a 10 KB tail and parse
+  TB=$(date +%s)
+  timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default_line.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$? wall $(( $(date +%s) - TB )) s"
+  cp bench_full.json gpurun_out/${TAG}_bench_default_full.json 2>/dev/null
+  python - <<PY
+import json
+t = open("gpurun_out/${TAG}_bench_default_line.json").read()
+print("stdout bytes", len(t), "lines", t.count("\n"))
+j = json.loads(t[-10000:].strip().splitlines()[-1])
+print(json.dumps(j)[:6000])
+PY
+  tail -3 gpurun_out/${TAG}_bench_default.err | cut -c1-300
+  lap benchdefault
+fi
+if has ab; then    # two BUILDS of the library alternating on this box: round-4 main (libv2v_hip_r4main.so) vs the tree's build
+  for i in 1 2 3; do
+    for libn in libv2v_hip_r4main.so libv2v_hip.so; do
+      V2V_LIB_PATH=$R/vid2vid_amd/$libn timeout 300 python bench.py $LEAN --no-hires 2>gpurun_out/${TAG}_ab.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$libn run $i: 512x256', j['value'], 'frames/s', j['ms_per_step'], 'ms; dominant', j['roofline']['kernel'][:40], j['roofline'].get('eager_us'), 'us eager')"
+    done
+  done 2>&1 | tee gpurun_out/${TAG}_ab.txt
+  lap ab
+fi
+if has hires; then   # both resolutions with the 7x7-window tiles offered to the search: the cache copy forgets the dense 7x7 stems (raw output, whole-chunk
+                     # channel stride), everything else replays profiles/tune_cache.json; compare with the default line of this visit
+  python - <<PY
+import json
+d = json.load(open("profiles/tune_cache.json"))
+for dt, v in d.items():
+    for k in [k for k in v if k.split(",")[2] == "7" and k.split(",")[8] == "0" and int(k.split(",")[9]) % 64 == 0]:
+        del v[k]
+json.dump(d, open("gpurun_out/${TAG}_tune_s7.json", "w"))
+PY
+  V2V_S7_PATCH=1 V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune_s7.json timeout 900 python bench.py $LEAN 2>gpurun_out/${TAG}_hires_s7.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('V2V_S7_PATCH=1', {k: v for k, v in j.items() if not isinstance(v, (dict, list))})"
+  cp bench_full.json gpurun_out/${TAG}_hires_s7_full.json
+  python - <<PY
+import json
+d = json.load(open("gpurun_out/${TAG}_tune_s7.json"))
+for dt, v in d.items():
+    print(dt, {k: v[k] for k in v if k.split(",")[2] == "7" and k.split(",")[8] == "0" and int(k.split(",")[9]) % 64 == 0})
+PY
+  lap hires
+fi
+if has stem7; then
+  timeout 300 python scripts/stem7_bench.py 2>&1 | tee gpurun_out/${TAG}_stem7_bench.txt | cut -c1-260
+  timeout 300 python scripts/one_bench.py 2>&1 | tee gpurun_out/${TAG}_one_bench.txt | cut -c1-300
+  lap stem7
+fi
+if has stamp; then   # the V2V_STAMP_MASK=0x7f build -- which DETERMINISTIC kernel tests fail with it?
+  export V2V_LIB_PATH=$R/vid2vid_amd/libv2v_hip_stamp.so
+  timeout 420 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=line --timeout 120 -k "fp32 or not bf16" -p no:cacheprovider > gpurun_out/${TAG}_stamp_kernels.log 2>&1; echo "stamp kernels rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_stamp_kernels.log | cut -c1-260 | tail -40
+  for i in 1 2 3; do
+    timeout 120 python -m pytest tests/test_gpu_golden.py -m gpu -q -rf --tb=line -k "inference_api_vs_reference or flownet2_vs_reference" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|Error" | cut -c1-260
+  done 2>&1 | tee gpurun_out/${TAG}_stamp_golden.txt
+  unset V2V_LIB_PATH
+  lap stamp
+fi
+if has alltests; then
+  timeout 1700 python -m pytest tests -m gpu -q -rf --tb=short --timeout 900 --durations=15 > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_gpu.log | tail -20
+  lap alltests
+fi
+if has quicktests; then   # everything but the full-size CPU-oracle cases (those are ~11 of the suite's 13 minutes)
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 300 -k "not full_size and not full_width" > gpurun_out/${TAG}_pytest_quick.log 2>&1; echo "pytest(quick) rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_quick.log | tail -20
+  lap quicktests
+fi
+if has dom; then     # the dominant pair launch -- ring depth, one barrier per two steps, static priority, the two-sequence geometry
+  timeout 300 python scripts/dom_bench.py 2>&1 | tee gpurun_out/${TAG}_dom_bench.txt | cut -c1-200
+  timeout 200 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "fused_norm_pair or pair_equals or conv3x3_patch_kernel" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300 | tail -12
+  lap dom
+fi

@@ -45,5 +45,5 @@ with torch.no_grad():
             raw = eng.conv(x, mod, L.PAD_REFLECT, 3, L.OUT_RAW_F32_NHWC, want_stats=True)[0][:H * W * cout].clone()
             ref = raw if ref is None else ref
             gf = 2.0 * H * W * cin * cout * 49 / 1e9
-            out.append("t%d: %6.1f us %5.0f TF (d %.1e)" % (t, us, gf / us * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3, (raw - ref).abs().max().item()))
+            out.append("t%d: %6.1f us %5.0f TF (d %.1e)" % (t, us, gf / us * 1e3, (raw - ref).abs().max().item()))
         print("%-32s Cs %3d | %s" % (name, x.Cs, "  ".join(out)), flush=True)

@@ -39,6 +39,14 @@ constexpr int pending_at(int tap, int GP, int LB, int D, int NT = 9) {
     for (int u = 0; u < D - 1; ++u) x += np_at((tap - u + 2 * NT) % NT, GP, NT - D);
     return x;
 }
+// B2 (one barrier per two steps): pieces that may stay in flight behind the wait at the end of an ODD iteration i -- slices
+// i+4 .. i+D-1 and the patch pieces of iterations i+4-D .. i (slice i+3, the youngest that must have landed, was issued first in
+// iteration i+4-D)
+constexpr int pending_b2(int tap, int GP, int LB, int D, int NT = 9) {
+    int x = (D - 4) * LB;
+    for (int u = 0; u <= D - 4; ++u) x += np_at((tap - u + 2 * NT) % NT, GP, NT - D);
+    return x;
+}
 }  // namespace pp3
 
 // taps 0 .. NT-1 of one channel chunk on alternating fragment register sets (first set P0)
@@ -75,8 +83,26 @@ __device__ __forceinline__ void pp3_run_chunk(F& it, std::integer_sequence<int, 
 // 45 -> 128), which the 2048x1024 per-layer table puts first (1.47 ms on generic tiles that re-fetch their activations for each
 // of the 49 taps: profiles/r04_f3_per_layer_roofline_hires.txt).  NT = KK^2 tap steps per channel chunk over a (TH + KK - 1) x
 // (TW + KK - 1) patch; every pipeline constant that said 9 says NT, the tap offsets come from (tap / KK, tap % KK).
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false, int KK = 3>
+// FLAGS (round 5, experiments on the dominant 1024 -> 1024 pair; tiles 97-99):
+//   bit 0 "B2": ONE BARRIER PER TWO STEPS.  The barrier stays in front of the iterations that multiply from register set 0 (even
+//     iterations; the parity is the register-set parity, which is the iteration parity because NT is odd and chunks alternate).
+//     Between B_j and B_j+2 the waves may drift by up to two steps, so
+//       RAW  both slices read in the pair (j+1 in iteration j, j+2 in iteration j+1) are retired by every wave BEFORE B_j: the counted
+//            vmcnt wait sits at the end of the ODD iterations only and retires two slices;
+//       WAR  an iteration may only refill a stage whose reads ended before the last barrier: iteration i issues slice i+D-1 into the
+//            stage of slice i-1 (read in iteration i-2, in front of the barrier for either parity) -- one stage "older" than the
+//            single-step schedule, i.e. D stages hold D-1 slices in flight (the prologue issues D-1 slices); the fragment reads are
+//            drained (lgkmcnt(0)) at the end of the odd iterations, in front of the barrier that releases their stage;
+//       patch: chunk c+1 streams into the buffer of chunk c-1 (last read in iteration NT*c-2) from iteration NT*c on; a barrier lies
+//            between them for either parity of NT*c.  Its pieces (taps 0..NPT-1) are retired by the odd wait at most D-4+1
+//            iterations later, in front of the barrier before iteration NT*c+NT-1, the first that reads the new patch.
+//     Checked by scripts/pp_sched_sim.py pp3b2 (two drifting wave groups).
+//   bit 1: static priority -- the second-dispatched half of the waves runs at s_setprio 1 for the whole main loop
+//     (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false, int KK = 3, int FLAGS = 0>
 __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
+    constexpr bool B2 = (FLAGS & 1) != 0;
+    static_assert(!B2 || (!ONE && D >= 5), "B2: D stages hold D-1 slices in flight, two of them retired per barrier");
     // grouped launch: which member and which tile this workgroup works on (the members have identical geometry, so the
     // tile count is known before the member is)
     int member = (int)blockIdx.z, lin_all;
@@ -112,7 +138,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     static_assert(TW % 32 == 0 && (TW & (TW - 1)) == 0, "a 32-row fragment must lie inside one tile row");
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile");
     static_assert(BN % (8 * NW) == 0 && LB >= 1, "weight loader rounds");
-    static_assert(D >= 3 && D <= 5, "weight slices in flight");
+    static_assert(D >= 3 && D <= 7, "weight slices in flight");
     static_assert((D - 2) * LB + (D - 1) * ((GP + NT - D - 1) / (NT - D)) <= 63, "vmcnt immediate range");
     constexpr int NPB = ONE ? 1 : 2;                          // patch buffers
     static_assert(!ONE || KS == 1, "single-chunk tiles: no accumulator exchange (it would need 64 KiB of scratch)");
@@ -224,12 +250,16 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     // ---------------- prologue: patch 0 and weight slices 0 .. D-1; step 0's fragments into set 0 ----------------
 #pragma unroll
     for (int k = 0; k < GP; ++k) issue_patch(k, 0, smem);
+    constexpr int DP = B2 ? D - 1 : D;                        // slices the prologue issues (B2: iteration 0 issues slice D-1 itself)
 #pragma unroll
-    for (int t = 0; t < D; ++t)
+    for (int t = 0; t < DP; ++t)
 #pragma unroll
         for (int i = 0; i < LB; ++i) issue_w_piece(i, t, t);
+    if constexpr ((FLAGS & 2) != 0) {
+        if (wid >= NW / 2) __builtin_amdgcn_s_setprio(1);
+    }
     V2V_STAMP(p, 1);
-    wait_vmcnt<(D - 1) * LB>();                              // the patch and slice 0 have landed (this wave's share)
+    wait_vmcnt<(DP - 1) * LB>();                             // the patch and slice 0 have landed (this wave's share)
     __builtin_amdgcn_s_barrier();
     V2V_STAMP(p, 2);
     {
@@ -240,7 +270,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         if (!(ab & 32))
             static_for<NRD>([&](auto qc) { read_frag(qc, std::integral_constant<int, 0>{}, arow, ax, pb); });
     }
-    wait_vmcnt<(D - 2) * LB>();                              // slice 1: published by B_0
+    wait_vmcnt<(B2 ? (DP - 3) : (D - 2)) * LB>();            // slice 1 (B2: slices 1 and 2): published by B_0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     int step = 0, stage = 0, cc = 0;                          // step being multiplied, its weight stage, its chunk
@@ -262,8 +292,10 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         constexpr int RPS = (NRD + RSLOTS - 1) / RSLOTS;
         constexpr int RUSED = (NRD + RPS - 1) / RPS;          // slots that actually carry reads
 
-        __builtin_amdgcn_s_barrier();                        // B_step: slice step+1 (and at tap 8 the next patch) is visible,
+        if constexpr (!B2 || PAR == 0)
+            __builtin_amdgcn_s_barrier();                    // B_step: slice step+1 (and at tap 8 the next patch) is visible,
                                                              // the stage of slice `step` and its fragment reads are retired
+                                                             // (B2: only in front of the even iterations, for two steps at once)
         const char* arow[TM]; int ax[TM];
         {
             const char* const pbuf = TAP == NT - 1 ? pn : pa;     // step+1 belongs to the next chunk at the last tap
@@ -281,8 +313,10 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         auto dma = [&](auto dc) __attribute__((always_inline)) {
             constexpr int d = decltype(dc)::value;
             if (ab & 128) return;
-            if constexpr (d < LB) issue_w_piece(d, step + D, stage);       // slice step+D refills the stage of slice `step`
-            else                  issue_patch(k0 + d - LB, cc + 1, pn);
+            if constexpr (d < LB) {
+                if constexpr (B2) issue_w_piece(d, step + D - 1, stage == 0 ? NSB - 1 : stage - 1);   // slice step+D-1 refills the stage of slice step-1
+                else              issue_w_piece(d, step + D, stage);                                   // slice step+D refills the stage of slice `step`
+            } else                issue_patch(k0 + d - LB, cc + 1, pn);
         };
         auto reads_of_slot = [&](auto mc) __attribute__((always_inline)) {
             constexpr int m = decltype(mc)::value;
@@ -309,8 +343,15 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         // whatever found no slot (short MFMA sequences with many pieces)
         constexpr int DMA_IN_SLOTS = pp3::cmin(NDMA, NMMA - 1 - RUSED > 0 ? NMMA - 1 - RUSED : 0);
         static_for<NDMA - DMA_IN_SLOTS>([&](auto dc) { dma(std::integral_constant<int, DMA_IN_SLOTS + decltype(dc)::value>{}); });
-        if (!(ab & 256)) wait_vmcnt<(ONE ? (D - 2) * LB : pp3::pending_at(TAP, GP, LB, D, NT))>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set 1-PAR is complete; the reads of slice step+1 are retired
+        if constexpr (B2) {
+            if constexpr (PAR == 1) {                        // in front of the barrier: slices step+2, step+3 retired, all fragment reads drained
+                wait_vmcnt<pp3::pending_b2(TAP, GP, LB, D, NT)>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            if (!(ab & 256)) wait_vmcnt<(ONE ? (D - 2) * LB : pp3::pending_at(TAP, GP, LB, D, NT))>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set 1-PAR is complete; the reads of slice step+1 are retired
+        }
         ++step;
         stage = nstage;
         if constexpr (TAP == NT - 1 && !ONE) {
@@ -344,6 +385,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     if (c < ncc) chunk(std::integral_constant<int, 0>{});
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail duplicates must land before the LDS is reused
+    if constexpr ((FLAGS & 2) != 0) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     V2V_STAMP(p, 3);
 
@@ -415,9 +457,9 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     }
 }
 
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false>
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false, int FLAGS = 0>
 __global__ __launch_bounds__(WGM_ * WGN_ * KS_ * 64) void conv3x3_pp3_kernel(const ConvKArgs p_in) {
-    conv3x3_pp3_body<T, TH, TW, BN, D, ABL, WGM_, WGN_, KS_, ONE, 3>(p_in);
+    conv3x3_pp3_body<T, TH, TW, BN, D, ABL, WGM_, WGN_, KS_, ONE, 3, FLAGS>(p_in);
 }
 
 // 7x7 window: its own entry point, pinned to two waves per SIMD.  The lambdas of the body are always_inline: with 98 unrolled tap
@@ -429,14 +471,14 @@ __global__ __launch_bounds__(WGM_ * WGN_ * 64) __attribute__((amdgpu_waves_per_e
     conv3x3_pp3_body<T, TH, TW, BN, D, 0, WGM_, WGN_, 1, false, 7>(p_in);
 }
 
-template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2, int KS = 1, bool ONE = false, int KK = 3>
+template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM = 4, int WGN = 2, int KS = 1, bool ONE = false, int KK = 3, int FLAGS = 0>
 static int launch_pp3_cfg(const ConvKArgs& k, int groups, hipStream_t s) {
     constexpr int NW = WGM * WGN * KS;
     constexpr int GP = (((TH + KK - 1) * (TW + KK - 1) + 7) / 8 + NW - 1) / NW;
     const size_t lds = (size_t)(ONE ? 1 : 2) * GP * NW * 1024 + (size_t)D * BN * 128;
     void (*kern)(const ConvKArgs);
     if constexpr (KK == 7) kern = conv7x7_pp3_kernel<T, TH, TW, BN, D, WGM, WGN>;
-    else                   kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN, KS, ONE>;
+    else                   kern = conv3x3_pp3_kernel<T, TH, TW, BN, D, ABL, WGM, WGN, KS, ONE, FLAGS>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -455,6 +497,8 @@ static const PatchCfg kPp3Cfgs[] = {
     {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
     {92, 8, 32, 64}, {93, 4, 64, 64},      // K quads: 2 x 1 wave tiles of 128 x 64, four K quarters: 6 reads per 8 MFMAs
     {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 72 / 80 KiB
+    {97, 8, 32, 64}, {98, 8, 32, 64}, {99, 8, 32, 64},     // round-5 experiments on tile 90's geometry (K pairs): 97 one barrier per two steps
+                                           // (6 stages), 98 = 90 with 6 stages (the ring one deeper), 99 = 97 with 7 stages and static priority
     {96, 4, 32, 64},                       // single-chunk layers, FOUR waves (2 x 2, 64 x 32 wave tiles), 28 + 24 = 52 KiB, 167 + 32 registers: the
                                            // tile that really puts two workgroups on a CU (staged for round 5; 94 / 95 never did: DESIGN 3.6 item 15)
     {120, 4, 32, 64}, {121, 4, 32, 128},   // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk
@@ -478,6 +522,9 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 87: return launch_pp3_cfg<T, 2, 64, 128, 4, 0, 2, 2>(k, groups, s);   // same for 64-wide tile rows
         case 90: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 4, 1, 2>(k, groups, s);   // as 82 (256 px x 64, 5 slices), K pairs: 8 reads per 8 MFMAs
         case 91: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 4, 1, 2>(k, groups, s);   // as 83 for 64-wide tile rows
+        case 97: return launch_pp3_cfg<T, 8, 32, 64, 6, 0, 4, 1, 2, false, 3, 1>(k, groups, s);   // as 90, ONE BARRIER PER TWO STEPS, 6 stages (144 KiB)
+        case 98: return launch_pp3_cfg<T, 8, 32, 64, 6, 0, 4, 1, 2>(k, groups, s);                // as 90 with the weight ring one stage deeper (144 KiB)
+        case 99: return launch_pp3_cfg<T, 8, 32, 64, 7, 0, 4, 1, 2, false, 3, 3>(k, groups, s);   // as 97 with 7 stages (152 KiB) and static priority for waves 4-7
         case 92: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 2, 1, 4>(k, groups, s);   // as 82, K quads
         case 93: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 2, 1, 4>(k, groups, s);   // as 83, K quads
         case 120: case 121:                // 7x7 window: bf16 only for now (the fp32 instantiations double an 8-minute translation unit)

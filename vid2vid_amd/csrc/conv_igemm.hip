@@ -521,8 +521,8 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     }
     if (d->out_mode == V2V_OUT_NORM_ACT_NHWC) {
         if ((launching && (!d->fin_counter || !d->stats || !d->fin_scale_shift || d->fin_count <= 0)) || d->splitk > 1 || d->transposed ||
-            d->cout != d->cout_stride || !((d->tile >= 80 && d->tile < 88) || (d->tile >= 90 && d->tile <= 93)) || d->cout > 128 * 64) {
-            set_error("conv: fused norm needs tile 80..87 / 90..93, splitk <= 1, cout == cout_stride, stats, fin_counter (256 ints), fin_scale_shift, fin_count");
+            d->cout != d->cout_stride || !((d->tile >= 80 && d->tile < 88) || (d->tile >= 90 && d->tile <= 93) || (d->tile >= 97 && d->tile <= 99)) || d->cout > 128 * 64) {
+            set_error("conv: fused norm needs tile 80..87 / 90..93 / 97..99, splitk <= 1, cout == cout_stride, stats, fin_counter (256 ints), fin_scale_shift, fin_count");
             return V2V_EINVAL;
         }
         k.res0 = (const char*)d->res0; k.res1 = (const char*)d->res1;
@@ -840,8 +840,8 @@ extern "C" int v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, v
     int rc = build_conv(a, op.get());
     if (rc == 0) rc = build_conv(b, &ob);
     if (rc != 0) return rc;
-    if (op->cfg < 70 || op->cfg >= 94 || ob.cfg != op->cfg) {
-        set_error("conv pair: both members need the same grouped-launch tile config (70..93), got %d / %d", op->cfg, ob.cfg);
+    if (op->cfg < 70 || (op->cfg >= 94 && !(op->cfg >= 97 && op->cfg <= 99)) || ob.cfg != op->cfg) {
+        set_error("conv pair: both members need the same grouped-launch tile config (70..93, 97..99), got %d / %d", op->cfg, ob.cfg);
         return V2V_EINVAL;
     }
     const bool same =

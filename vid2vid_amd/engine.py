@@ -347,7 +347,10 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               86: (4, 32, 128), 87: (2, 64, 128),      # 86 / 87: four waves, 64 x 64 wave tiles
               90: (8, 32, 64), 91: (4, 64, 64),        # 90 / 91: 82 / 83 with K pairs (8 fragment reads per 8 MFMAs)
               92: (8, 32, 64), 93: (4, 64, 64),        # 92 / 93: K quads (6 reads per 8 MFMAs)
-              94: (8, 32, 64), 95: (4, 64, 64), 96: (4, 32, 64)}        # 94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
+              94: (8, 32, 64), 95: (4, 64, 64), 96: (4, 32, 64),
+              # round-5 experiments on tile 90's geometry (K pairs): 97 one barrier per two steps (6 weight stages), 98 the ring one
+              # stage deeper, 99 = 97 with 7 stages + static wave priority.  Offered to the tile searches only with V2V_EXP_TILES=1.
+              97: (8, 32, 64), 98: (8, 32, 64), 99: (8, 32, 64)}        # 94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
 # stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
 S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
 # ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
@@ -357,6 +360,9 @@ T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 6
 S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
+EXP_TILES = (97, 98, 99)
+if os.environ.get("V2V_EXP_TILES", "0") == "1":
+    PAIR_TILES = PAIR_TILES + EXP_TILES
 
 
 def is_patch_tile(t):
@@ -377,6 +383,14 @@ def _cfg3(v):
     if isinstance(v, (tuple, list)):
         return int(v[0]), int(v[1]), int(v[2])
     return int(v), 1, 0
+
+
+# Ticket words of one (lane, scratch set): [0, 256) the conv kernels' per-channel-tile arrive / depart tickets, [256, 256 + 64 * 128)
+# the row-group tickets of the two-level in-kernel finalize (conv_igemm_kernel.h: fin_counter + 256 + g * n_tiles + nt), then the
+# one-hot stems' per-slice tickets (onehot_stem.hip: fin_counter + blockIdx.y) in a region of their own (they used to
+# start at word 256, inside the row-group region -- safe only while launches of one lane are serialised).
+FIN_ONEHOT_OFFSET = 256 + 64 * 128
+FIN_COUNTER_WORDS = FIN_ONEHOT_OFFSET + 256
 
 
 class Engine:
@@ -646,9 +660,9 @@ class Engine:
             key = (self._lane, self._sset)
             fin_counter = self._fin_counters.get(key)
             if fin_counter is None:
-                fin_counter = self._fin_counters[key] = torch.zeros(256 + 64 * 128, dtype=torch.int32, device=self.device)
+                fin_counter = self._fin_counters[key] = torch.zeros(FIN_COUNTER_WORDS, dtype=torch.int32, device=self.device)
             fn = L.OneHotNorm()
-            fn.counter = fin_counter.data_ptr() + 4 * 256              # words 256..: clear of the conv kernels' per-tile tickets (0..255)
+            fn.counter = fin_counter.data_ptr() + 4 * FIN_ONEHOT_OFFSET  # own region: clear of the conv kernels' per-tile tickets (0..255) AND of the two-level finalize's row-group tickets (256 .. 256 + 64*128)
             fn.gamma = None if gamma is None else gamma.data_ptr()
             fn.beta = None if beta is None else beta.data_ptr()
             fn.scale_shift = ss.data_ptr()
@@ -768,7 +782,7 @@ class Engine:
                 fin_counter = self._fin_counters.get((self._lane, self._sset))
                 if fin_counter is None:
                     # [0,128) finalize tickets per channel tile, [128,256) fused-norm departures, [256, 256 + 64 * 128) row-group tickets
-                    fin_counter = self._fin_counters[(self._lane, self._sset)] = torch.zeros(256 + 64 * 128, dtype=torch.int32, device=self.device)
+                    fin_counter = self._fin_counters[(self._lane, self._sset)] = torch.zeros(FIN_COUNTER_WORDS, dtype=torch.int32, device=self.device)
                 d.fin_counter = fin_counter.data_ptr()
                 d.fin_gamma = None if gamma is None else gamma.data_ptr()
                 d.fin_beta = None if beta is None else beta.data_ptr()
@@ -869,7 +883,7 @@ class Engine:
             key = (self._lane, self._sset)
             fin_counter = self._fin_counters.get(key)
             if fin_counter is None:
-                fin_counter = self._fin_counters[key] = torch.zeros(256 + 64 * 128, dtype=torch.int32, device=self.device)
+                fin_counter = self._fin_counters[key] = torch.zeros(FIN_COUNTER_WORDS, dtype=torch.int32, device=self.device)
             d.fin_counter = fin_counter.data_ptr()
             d.fin_gamma = None if gamma is None else gamma.data_ptr()
             d.fin_beta = None if beta is None else beta.data_ptr()
@@ -897,7 +911,7 @@ class Engine:
         """V2V_OUT_NORM_ACT_NHWC (include/v2v_hip.h, "fused norm"): single-phase tiles, no split-K, every workgroup of the
         launch resident at once."""
         t, S = tile3[0], max(int(tile3[1]), 1)
-        if not (self.fused_norm and self.fused_finalize and (80 <= t < 88 or 90 <= t < 94) and S == 1 and cout % vec_of(self.dtype) == 0):
+        if not (self.fused_norm and self.fused_finalize and (80 <= t < 88 or 90 <= t < 94 or t in EXP_TILES) and S == 1 and cout % vec_of(self.dtype) == 0):
             return False
         th, tw, bn = PATCH_CFGS[t]
         if self._fused_norm_wgs is None:
@@ -1272,6 +1286,8 @@ class Engine:
         if mod is not None and role == "fwd" and self.patch_eligible(d):
             ncc = d.cin_stride // (64 if self.dtype == L.BF16 else 32)
             for t, (th, tw, bn) in sorted(PATCH_CFGS.items()):
+                if t in EXP_TILES and os.environ.get("V2V_EXP_TILES", "0") != "1":
+                    continue
                 if tw == 64 and d.OW % 64 != 0 and d.OW > 32:
                     pass                      # ragged tiles are legal, just wasteful; let the timing decide
                 tiles = d.N * -(-d.OH // th) * -(-d.OW // tw) * -(-cout // bn)
