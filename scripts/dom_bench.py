@@ -24,7 +24,7 @@ DEV = "cuda:0"
 eng = Engine(DEV, L.BF16)
 THRASH = torch.empty(96 << 20, dtype=torch.float32, device=DEV)
 ROUNDS = int(os.environ.get("DOM_ROUNDS", "9"))
-TILES = [int(t) for t in os.environ.get("DOM_TILES", "90,98,97,99,82,91").split(",")]
+TILES = [int(t) for t in os.environ.get("DOM_TILES", "90,98,97,99,132,130,131,82").split(",")]
 
 
 def timed(fn, cold):

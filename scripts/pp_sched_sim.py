@@ -163,15 +163,18 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pp3":
     sys.exit(0 if ok else 1)
 
 
-def simulate_pp3b2(GP, LB, D, ncc, NT=9, extra_pending=0, shift=1):
-    """conv3x3_pp3_body with FLAGS bit 0 ("B2"): ONE barrier per TWO steps (in front of the even iterations), waves drifting
-    freely in between.  Iteration i: [B_i if i even] | MFMA(i) || ds_read(step i+1: slice i+1, patch (i+1)//NT) || DMA issue
-    W(i+D-1) into the stage of slice i-1, then this tap's pieces of patch c+1 | [i odd: vmcnt(pending_b2), lgkmcnt(0)].
-    A piece retired by the wait at the end of iteration lp is visible to every wave from the first barrier > lp on."""
-    NPT = NT - D
+def simulate_pp3b2(GP, LB, D, ncc, NT=9, extra_pending=0, shift=None, BP=2, NPT=None):
+    """conv3x3_pp3_body with FLAGS bits 0-1 = BP - 1: ONE barrier per BP steps (in front of the iterations i with i % BP == 0), waves
+    drifting freely in between.  Iteration i: [B_i if i % BP == 0] | MFMA(i) || ds_read(step i+1: slice i+1, patch (i+1)//NT) || DMA
+    issue W(i+D-BP+1) into the stage of slice i-BP+1, then this tap's pieces of patch c+1 | [i % BP == BP-1: vmcnt(pending_bp),
+    lgkmcnt(0)].  A piece retired by the wait at the end of iteration lp is visible to every wave from the first barrier > lp on."""
+    if NPT is None:
+        NPT = 11 - D if BP == 3 else NT - D
+    if shift is None:
+        shift = BP - 1
     PPT = (GP + NPT - 1) // NPT
     nsteps = ncc * NT
-    bar = lambda i: i - (i % 2)                      # the last barrier at or in front of iteration i
+    bar = lambda i: i - (i % BP)                     # the last barrier at or in front of iteration i
 
     def npieces(tap):
         if tap >= NPT: return 0
@@ -179,7 +182,7 @@ def simulate_pp3b2(GP, LB, D, ncc, NT=9, extra_pending=0, shift=1):
     assert sum(npieces(t) for t in range(NT)) == GP
 
     def pending(tap):
-        return (D - 4) * LB + sum(npieces((tap - u + 2 * NT) % NT) for u in range(0, D - 3)) + extra_pending
+        return (D - 2 * BP) * LB + sum(npieces((tap - u + 2 * NT) % NT) for u in range(0, D - 2 * BP + 1)) + extra_pending
     errors, outstanding, cnt = [], [], {}
     landed, issued, last_read = {}, {}, {}
 
@@ -201,16 +204,17 @@ def simulate_pp3b2(GP, LB, D, ncc, NT=9, extra_pending=0, shift=1):
                 errors.append("RAW: %s piece %d read in iteration %s (behind barrier %s), retired at the end of %s" % (item, k, it_, bar(it_), lp))
         last_read[item] = max(last_read.get(item, -10), it_)
 
-    # prologue: patch 0, slices 0 .. D-2; wait (patch + slice 0), barrier, read step 0, wait (slices 1, 2), then B_0
+    # prologue: patch 0, slices 0 .. D-BP; wait (patch + slice 0), barrier, read step 0, wait (slices 1 .. BP), then B_0
+    DP = D - (BP - 1)
     issue(('P', 0), GP, -3)
-    for t in range(D - 1): issue(('W', t), LB, -3)
-    wait((D - 2) * LB, -3)
+    for t in range(DP): issue(('W', t), LB, -3)
+    wait((DP - 1) * LB, -3)
     for k in range(LB): assert landed.get((('W', 0), k)) == -3
-    wait((D - 4) * LB, -2)
+    wait((DP - 1 - BP) * LB, -2)
     last_read[('W', 0)] = -1; last_read[('P', 0)] = -1
     for j in range(nsteps):
         tap, c = j % NT, j // NT
-        new, old = ('W', j + D - 1), ('W', j - shift)     # shift = 0: the single-step schedule's stage choice (self-test: must be flagged)
+        new, old = ('W', j + D - shift), ('W', j - shift)     # shift = 0: the single-step schedule's stage choice (self-test: must be flagged)
         if old in last_read and not (bar(j) > last_read[old]):
             errors.append("WAR: %s issued in iteration %d (barrier %d), %s last read in iteration %s" % (new, j, bar(j), old, last_read[old]))
         issue(new, LB, j)
@@ -222,7 +226,7 @@ def simulate_pp3b2(GP, LB, D, ncc, NT=9, extra_pending=0, shift=1):
         if j + 1 < nsteps:
             read(('W', j + 1), LB, j)
             read(('P', (j + 1) // NT), GP, j)
-        if j % 2 == 1:
+        if j % BP == BP - 1:
             wait(pending(tap), j)
         if len(outstanding) > 63:
             errors.append("vmcnt range: %d pieces outstanding in iteration %d" % (len(outstanding), j))
@@ -231,12 +235,16 @@ def simulate_pp3b2(GP, LB, D, ncc, NT=9, extra_pending=0, shift=1):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pp3b2":
     ok = True
-    for D in (5, 6, 7):
-        for GP in (3, 5, 6, 7):
-            for LB in (1, 2):
-                for ncc in (1, 2, 3, 4):
-                    e = simulate_pp3b2(GP, LB, D, ncc)
-                    if e or ncc == 4:
-                        print("pp3b2 D=%d GP=%d LB=%d ncc=%d: %s" % (D, GP, LB, ncc, "OK" if not e else "%d errors, e.g. %s" % (len(e), e[0])))
-                    ok &= not e
+    for BP in (2, 3):
+        for D in range(2 * BP + 1, 9):
+            for GP in (3, 5, 6, 7):
+                for LB in (1, 2):
+                    for ncc in (1, 2, 3, 4, 5):
+                        e = simulate_pp3b2(GP, LB, D, ncc, BP=BP)
+                        if e or (ncc == 5 and GP == 6):
+                            print("pp3 BP=%d D=%d GP=%d LB=%d ncc=%d: %s" % (BP, D, GP, LB, ncc, "OK" if not e else "%d errors, e.g. %s" % (len(e), e[0])))
+                        ok &= not e
+    # self-test: the checks do fire -- one more piece left in flight, or the stage choice of the single-step schedule
+    assert simulate_pp3b2(6, 1, 6, 3, extra_pending=1) and simulate_pp3b2(6, 1, 6, 3, shift=0)
+    assert simulate_pp3b2(6, 1, 8, 3, extra_pending=1, BP=3) and simulate_pp3b2(6, 1, 8, 3, shift=1, BP=3)
     sys.exit(0 if ok else 1)

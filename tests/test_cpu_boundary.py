@@ -435,3 +435,41 @@ def test_conv7x7_window_tile_is_validated_by_the_library():
     finally:
         N.set_record_only(False)
         N._ENGINES.clear()
+
+
+def test_round5_experiment_tiles_are_reachable_through_the_engine():
+    """Tiles 97-99 / 130-132 (one barrier per two / three steps, deeper weight rings, static wave priority on tile 90's geometry):
+    the engine must hand them channel-chunk-major weights (tile_korder) and the library must accept them in dry-run mode for a
+    single launch, a paired launch and a paired launch with the norm fused -- the path scripts/dom_bench.py and the GPU parity tests
+    take.  (Round 5: 97-99 were first missing from engine.is_patch_tile and every launch failed on the GPU box.)"""
+    import torch.nn as nn
+    from vid2vid_amd import networks as N
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.engine import Engine, EXP_TILES, PATCH_CFGS, is_patch_tile, tile_korder
+    if torch.cuda.is_available():
+        pytest.skip("dry-run validation is a CPU-host check")
+    N.set_record_only(True)
+    try:
+        eng = Engine(torch.device("cpu"), L.BF16, record_only=True)
+        cin = cout = 128
+        convs = [nn.Conv2d(cin, cout, 3) for _ in range(2)]
+        norms = [nn.BatchNorm2d(cout) for _ in range(2)]
+        xs = [eng.pack(torch.randn(1, cin, 32, 64)) for _ in range(2)]
+        res = [eng.pack(torch.randn(1, cout, 32, 64)) for _ in range(2)]
+        for t in EXP_TILES:
+            assert t in PATCH_CFGS and is_patch_tile(t) and tile_korder(t) == 1, t
+            eng.tile_override[(cin, cout, 3, 1, 0)] = (t, 1, 0)
+            eng.conv(xs[0], convs[0], L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
+            assert eng.conv_log[-1]["tile"] == t
+            eng.pair_override = (t, 1)
+            assert eng.fused_norm_fits((t, 1, 0), 1, 32, 64, cout)
+            ssa = eng.scratch("scale_shift", 4 * cout)
+            with eng.scratch_set(1):
+                ssb = eng.scratch("scale_shift", 4 * cout)
+            ya, yb = eng.empty_act(1, 32, 64, cout), eng.empty_act(1, 32, 64, cout)
+            eng.conv_pair(xs[0], convs[0], xs[1], convs[1], L.PAD_REFLECT, 1, ((norms[0], ssa), (norms[1], ssb)), ("a", "b"),
+                          fuse=(L.ACT_NONE, 0.0, (res[0], None), (res[1], None), ya, yb))
+            assert eng.conv_log[-1]["tile"] == t and eng.conv_log[-1]["fused_norm"]
+    finally:
+        N.set_record_only(False)
+        N._ENGINES.clear()

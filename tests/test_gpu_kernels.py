@@ -413,6 +413,10 @@ PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33
               (92, 1), (93, 1), (92, 2), (93, 2),
               # round 5: one barrier per two steps (97: 6 weight stages; 99: 7 stages + static wave priority), 98: tile 90 with 6 stages
               (97, 1), (98, 1), (99, 1), (97, 2), (99, 3), (98, 2),
+              # one barrier per three steps (7 / 8 weight stages), per two steps with 8 stages
+              (130, 1), (131, 1), (132, 1), (130, 2), (131, 3),
+              # persistent, weights-resident single-chunk tile (csrc/conv3x3_one_kernel.h): bf16, 64 input channels, <= 64 output channels
+              (140, 1),
               # single-chunk tiles (one patch buffer, three weight stages): bf16 layers with exactly 64 input channels
               (94, 1), (95, 1), (96, 1)]
 
@@ -445,7 +449,9 @@ def test_conv3x3_patch_kernel(case, prec):
     for it, (tile, S) in enumerate(PATCH_CFGS):
         if S > ncc:
             continue
-        if tile in (94, 95, 96) and (ncc != 1 or prec != "bf16"):
+        if tile in (94, 95, 96, 140) and (ncc != 1 or prec != "bf16"):
+            continue
+        if tile == 140 and cout > 64:
             continue
         k = it % 2
         eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, S, 12 if (tile <= 37 and it % 3 == 0) else 0)
@@ -556,7 +562,7 @@ def test_conv2d_pair_equals_two_launches(case, prec):
     assert eng.pair_eligible(xa[0], convs[0], xa[1], convs[1])
     for tile, S in [(70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2),
                     (80, 1), (81, 1), (82, 1), (83, 1), (84, 1), (85, 1), (80, 2), (81, 2), (86, 1), (87, 1), (86, 2),
-                    (90, 1), (91, 1), (90, 2), (92, 1), (93, 1), (92, 2), (97, 1), (98, 1), (99, 1), (97, 2)]:
+                    (90, 1), (91, 1), (90, 2), (92, 1), (93, 1), (92, 2), (97, 1), (98, 1), (99, 1), (97, 2), (130, 1), (131, 1), (132, 1)]:
         if 2 * S > ncc:
             continue
         eng.pair_override = (tile, S)
@@ -608,7 +614,7 @@ def test_fused_norm_pair_equals_conv_plus_bn_apply(case, prec):
     xa = [eng.pack((torch.randn(N, cin, H, W) * (1.0 + i)).to(DEV)) for i in range(2)]
     ra = [eng.pack(torch.randn(N, cout, H, W).to(DEV)) for _ in range(2)]
     pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
-    for tile in (80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93, 97, 98, 99):
+    for tile in (80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93, 97, 98, 99, 130, 131, 132):
         eng.pair_override = (tile, 1)
         if not eng.fused_norm_fits((tile, 1, 0), N, H, W, cout):
             continue

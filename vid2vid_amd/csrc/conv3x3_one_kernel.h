@@ -1,0 +1,213 @@
+// 3x3 / stride 1 / pad 1 convolution of layers with ONE 128-byte channel chunk (64 bf16 input channels) and at most 64 output
+// channels -- the ResnetBlocks of the fine scales (models/networks.py:554-593 at ngf_s = 64: 12 layers of 64 -> 64 at 1024x512 in
+// the 2048x1024 frame, the foreground tower's 64 -> 64 at 512x256) -- as a PERSISTENT, WEIGHTS-RESIDENT kernel (gfx950).
+//
+// Why (profiles/r04_d7_fine_scale_conv_ablate.txt).  Such a layer is thousands of tiles of 9 tap steps (~3 us of
+// matrix work) each; on the single-phase tiles 94 / 95 every tile is its own workgroup: launch, index arithmetic, 48 KB of patch AND
+// the whole 72 KB weight matrix through LDS-DMA, a ring of barriers, the epilogue, exit -- 9.7 of a tile's 14.4 us are outside the
+// main loop, the workgroup is alone on its CU (167 VGPRs x 8 waves), so every latency in that chain is exposed.
+//
+// Here ONE workgroup per CU walks its tiles:
+//   * the 9 x [64 rows][128 B] weight slices are loaded ONCE (72 KB of LDS, the ring-stage layout of conv3x3_pp3_kernel) -- 60 % of
+//     the bytes a tile used to pull through the LDS-DMA path are gone, and with them every weight-ring hazard: the main loop has NO
+//     barrier, NO vmcnt wait and NO DMA, only ds_reads (two fragment register sets, step j+1 read under the MFMAs of step j) and MFMAs;
+//   * one 48 KB patch buffer.  Per tile: [patch landed] barrier | 9 steps | barrier [patch free] | issue the NEXT tile's patch |
+//     epilogue of this tile (its own 40 KB of LDS scratch) -- the next patch travels while the epilogue stores, so its latency is
+//     hidden without a second buffer (72 + 48 + 40 = 160 KB: all of the LDS);
+//   * tile -> workgroup mapping: workgroup b takes virtual block ids b, b + G, b + 2G, ... (G = grid size, a multiple of 8), each
+//     through xcd_remap: every XCD keeps a contiguous range of tiles (halo rows shared through its L2) as with one tile per workgroup.
+// Same MFMA order per accumulator as tiles 80 / 94 (taps 0..8, K sub-steps 0..3), same epilogue (conv_epilogue): bit-identical results.
+#pragma once
+#include "conv3x3_pp3_kernel.h"
+
+namespace v2v {
+
+template <typename T, int TH, int TW, int BN>
+__global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int BM = TH * TW;
+    constexpr int PW = TW + 2, PR = (TH + 2) * PW;
+    constexpr int WGM = 4, WGN = 2, NW = 8;
+    constexpr int SS = 4;                                     // K sub-steps (16 elements each) of a step
+    constexpr int NG = (PR + 7) / 8;
+    constexpr int GP = (NG + NW - 1) / NW;                    // patch pieces per wave
+    constexpr int PATCH = GP * NW * 1024;
+    constexpr int BST = BN * 128;                             // one weight slice: BN rows of one 128-byte chunk
+    constexpr int LB = BN / 8 / NW;                           // weight pieces per wave per slice
+    constexpr int WBYTES = 9 * BST;
+    constexpr int EPI = 40960;                                // conv_epilogue's scratch (statistics rows, transposition blocks, flag word)
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NMMA = SS * TM * TN, NRD = SS * (TM + TN);
+    static_assert(sizeof(T) == 2, "single-chunk persistent tile: bf16 (64 input channels = one 128-byte chunk)");
+    static_assert(TW % 32 == 0 && (TW & (TW - 1)) == 0 && WM % 32 == 0 && WN % 32 == 0 && LB >= 1, "tile geometry");
+    static_assert(WBYTES + PATCH + EPI <= 160 * 1024, "LDS");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wres = smem;                                  // resident weights: [tap][BN rows][128 B]
+    char* const patch = smem + WBYTES;
+    char* const epi = smem + WBYTES + PATCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int H = p.H, W = p.W, cs = p.cin_stride;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+    const char* const zp = p.zero_page;
+    const int ntot = p.m_tiles * p.n_tiles;                   // n_tiles == 1 (host check): the resident weights serve every tile
+    const int G = (int)gridDim.x;
+
+    // ---------------- weights: once ----------------
+    {
+        const int lrow = wid * 8 + (lane >> 3);
+        const int lslot = (lane & 7) ^ ((lrow >> 1) & 7);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            long long r = (long long)lrow + NW * 8 * i;
+            r = r < p.cout_p ? r : p.cout_p - 1;
+            const char* const wp = p.w + ((long long)p.woff[0] + r * p.wrow[0] + lslot * VEC) * (long long)sizeof(T);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) glds16(wp + tap * 128, wres + tap * BST + wid * 1024 + i * NW * 1024);
+        }
+    }
+
+    // ---------------- per-tile patch loader ----------------
+    auto issue_patch_of = [&](const int n_img, const int oh0, const int ow0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < GP; ++k) {
+            const int q = (k * NW + wid) * 8 + (lane >> 3);
+            const int ls = (lane & 7) ^ ((q >> 1) & 7);
+            const int pr = q / PW, pc = q - pr * PW;
+            int ih = oh0 + pr - 1, iw = ow0 + pc - 1;
+            bool ok = q < PR;
+            int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+            int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+            ih = reflect ? rh : ih;
+            iw = reflect ? rw : iw;
+            ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+            iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+            const unsigned off = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
+            glds16(ok ? p.in + off : zp, patch + (k * NW + wid) * 1024);
+        }
+    };
+
+    // ---------------- fragment addressing (tile independent) ----------------
+    const int lr = lane & 31, hi = lane >> 5;
+    int qb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m0 = wm * WM + i * 32;
+        qb[i] = (m0 / TW) * PW + (m0 % TW) + lr;
+    }
+    int foff[SS];
+#pragma unroll
+    for (int s = 0; s < SS; ++s) foff[s] = ((s * 2 + hi) ^ ((lr >> 1) & 7)) << 4;
+    const char* const wrow = wres + (wn * WN + lr) * 128;
+
+    Frag fa[2][SS][TM], fb[2][SS][TN];
+    auto read_step = [&](auto tapc, auto parc) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int PARN = decltype(parc)::value;
+        constexpr int tq = (TAP / 3) * PW + (TAP % 3);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int qv = qb[i];
+            asm volatile("" : "+v"(qv));                   // opaque: no hoisting of 9 x TM address sets out of the tile loop
+            const int q = qv + tq;
+            const char* const arow = patch + q * 128;
+            const int ax = (q >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < SS; ++s) fa[PARN][s][i] = *reinterpret_cast<const Frag*>(arow + (((s * 2 + hi) ^ ax) << 4));
+        }
+#pragma unroll
+        for (int s = 0; s < SS; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[PARN][s][j] = *reinterpret_cast<const Frag*>(wrow + TAP * BST + j * 32 * 128 + foff[s]);
+    };
+
+    // ---------------- first tile ----------------
+    int vb = (int)blockIdx.x;                                 // virtual block id of the current tile
+    int lin, slice, nt, mt, n_img, th, twi;
+    if (vb < ntot) {
+        patch_tile_index(p, xcd_remap(vb, ntot), lin, slice, nt, mt, n_img, th, twi);
+        issue_patch_of(n_img, th * TH, twi * TW);
+    }
+
+    while (vb < ntot) {
+        const int oh0 = th * TH, ow0 = twi * TW;
+        const int c_lin = lin, c_nt = nt, c_mt = mt, c_img = n_img;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the patch (first tile: and of the weights) have landed
+        __builtin_amdgcn_s_barrier();                        // ... everyone's: the patch is complete; the previous epilogue's scratch is retired
+        read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        // 9 steps, no barrier: step t multiplies set t & 1 while step t+1 is read into the other set
+        static_for<9>([&](auto tc) {
+            constexpr int TAP = decltype(tc)::value;
+            constexpr int PAR = TAP & 1;
+            static_for<NMMA>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int s = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+                Mma<T>::run(fa[PAR][s][i], fb[PAR][s][j], acc[i][j]);
+                if constexpr (m == 0 && TAP < 8) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_step(std::integral_constant<int, TAP + 1>{}, std::integral_constant<int, 1 - PAR>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // every wave has finished reading the patch
+
+        // the next tile's patch streams in under this tile's epilogue
+        vb += G;
+        if (vb < ntot) {
+            patch_tile_index(p, xcd_remap(vb, ntot), lin, slice, nt, mt, n_img, th, twi);
+            issue_patch_of(n_img, th * TH, twi * TW);
+        }
+
+        const bool tile_full = oh0 + TH <= H && ow0 + TW <= W;
+        auto pix_of = [&](int row) __attribute__((always_inline)) -> int {
+            const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
+            if (oh >= H || ow >= W) return -1;
+            return (c_img * H + oh) * W + ow;
+        };
+        conv_epilogue<T, BM, BN, WGM, WGN, false>(p, acc, epi, tid, wm, wn, false, 0, ntot, c_lin, 0, 1, c_nt, c_mt, pix_of, tile_full);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename T>
+static inline int launch_one_typed(int cfg, const ConvKArgs& k, int cus, hipStream_t s) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (cfg == 140) {
+            constexpr int TH = 8, TW = 32, BN = 64, NW = 8;
+            constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW;
+            const size_t lds = (size_t)9 * BN * 128 + (size_t)GP * NW * 1024 + 40960;
+            void (*kern)(const ConvKArgs) = conv3x3_one_kernel<T, TH, TW, BN>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done = true;
+            }
+            const int ntot = k.m_tiles * k.n_tiles;
+            if (cus < 8) cus = 256;
+            int g = ntot < cus ? ntot : cus;                   // one workgroup per CU (the LDS footprint allows no second one)
+            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), lds, s, k);
+            return check_launch();
+        }
+    }
+    set_error("conv: unknown persistent single-chunk tile config %d (bf16 only)", cfg);
+    return V2V_EINVAL;
+}
+
+}  // namespace v2v

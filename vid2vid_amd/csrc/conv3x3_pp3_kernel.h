@@ -39,12 +39,12 @@ constexpr int pending_at(int tap, int GP, int LB, int D, int NT = 9) {
     for (int u = 0; u < D - 1; ++u) x += np_at((tap - u + 2 * NT) % NT, GP, NT - D);
     return x;
 }
-// B2 (one barrier per two steps): pieces that may stay in flight behind the wait at the end of an ODD iteration i -- slices
-// i+4 .. i+D-1 and the patch pieces of iterations i+4-D .. i (slice i+3, the youngest that must have landed, was issued first in
-// iteration i+4-D)
-constexpr int pending_b2(int tap, int GP, int LB, int D, int NT = 9) {
-    int x = (D - 4) * LB;
-    for (int u = 0; u <= D - 4; ++u) x += np_at((tap - u + 2 * NT) % NT, GP, NT - D);
+// One barrier per BP steps (BP = 2, 3): pieces that may stay in flight behind the wait at the end of the LAST iteration i of a barrier
+// period -- slices i+BP+2 .. i+D-BP+1 and the patch pieces of iterations i+2BP-D .. i (slice i+BP+1, the youngest that must have
+// landed, was issued first in iteration i+2BP-D).  BP = 1 gives pending_at.
+constexpr int pending_bp(int tap, int GP, int LB, int D, int NT, int BP, int NPT) {
+    int x = (D - 2 * BP) * LB;
+    for (int u = 0; u <= D - 2 * BP; ++u) x += np_at((tap - u + 2 * NT) % NT, GP, NPT);
     return x;
 }
 }  // namespace pp3
@@ -84,7 +84,7 @@ __device__ __forceinline__ void pp3_run_chunk(F& it, std::integer_sequence<int, 
 // of the 49 taps: profiles/r04_f3_per_layer_roofline_hires.txt).  NT = KK^2 tap steps per channel chunk over a (TH + KK - 1) x
 // (TW + KK - 1) patch; every pipeline constant that said 9 says NT, the tap offsets come from (tap / KK, tap % KK).
 // FLAGS (round 5, experiments on the dominant 1024 -> 1024 pair; tiles 97-99):
-//   bit 0 "B2": ONE BARRIER PER TWO STEPS.  The barrier stays in front of the iterations that multiply from register set 0 (even
+//   bits 0-1 = BP - 1, the steps per barrier (1, 2 or 3).  BP = 2 ("B2"): ONE BARRIER PER TWO STEPS.  The barrier stays in front of the iterations that multiply from register set 0 (even
 //     iterations; the parity is the register-set parity, which is the iteration parity because NT is odd and chunks alternate).
 //     Between B_j and B_j+2 the waves may drift by up to two steps, so
 //       RAW  both slices read in the pair (j+1 in iteration j, j+2 in iteration j+1) are retired by every wave BEFORE B_j: the counted
@@ -97,12 +97,16 @@ __device__ __forceinline__ void pp3_run_chunk(F& it, std::integer_sequence<int, 
 //            between them for either parity of NT*c.  Its pieces (taps 0..NPT-1) are retired by the odd wait at most D-4+1
 //            iterations later, in front of the barrier before iteration NT*c+NT-1, the first that reads the new patch.
 //     Checked by scripts/pp_sched_sim.py pp3b2 (two drifting wave groups).
-//   bit 1: static priority -- the second-dispatched half of the waves runs at s_setprio 1 for the whole main loop
+//     BP = 3: the same with three steps per barrier (iteration i issues slice i+D-2 into the stage of slice i-2, three slices retired
+//     per barrier; NT = 9 makes iteration % 3 == tap % 3, so the barriers sit in front of taps 0, 3, 6 of every chunk).
+//   bit 2: static priority -- the second-dispatched half of the waves runs at s_setprio 1 for the whole main loop
 //     (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
 template <typename T, int TH, int TW, int BN, int D, int ABL = 0, int WGM_ = 4, int WGN_ = 2, int KS_ = 1, bool ONE = false, int KK = 3, int FLAGS = 0>
 __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
-    constexpr bool B2 = (FLAGS & 1) != 0;
-    static_assert(!B2 || (!ONE && D >= 5), "B2: D stages hold D-1 slices in flight, two of them retired per barrier");
+    constexpr int BP = 1 + (FLAGS & 3);                       // steps per barrier
+    constexpr bool B2 = BP > 1;                               // (the name of the first variant: one barrier per two steps)
+    static_assert(BP <= 3, "barrier period: a barrier must lie between the last read of a patch buffer (iteration NT*c-2) and its refill (NT*c)");
+    static_assert(!B2 || (!ONE && KK == 3 && D >= 2 * BP + 1), "BP steps per barrier: D stages hold D-BP+1 slices in flight, BP of them retired per barrier");
     // grouped launch: which member and which tile this workgroup works on (the members have identical geometry, so the
     // tile count is known before the member is)
     int member = (int)blockIdx.z, lin_all;
@@ -127,7 +131,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     constexpr int BST = BN * 128;
     constexpr int LB = BN / 8 / NW;                           // weight pieces per wave per slice
     constexpr int NSB = D;                                    // weight ring: slice j+D refills the stage of slice j
-    constexpr int NPT = NT - D;                               // taps 0..NPT-1 carry next-chunk patch pieces
+    constexpr int NPT = (FLAGS & 3) == 2 ? 11 - D : NT - D;   // taps 0..NPT-1 carry next-chunk patch pieces (BP = 3: retired in front of B_{NT*c+6})
     constexpr int PPT = (GP + NPT - 1) / NPT;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -138,7 +142,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     static_assert(TW % 32 == 0 && (TW & (TW - 1)) == 0, "a 32-row fragment must lie inside one tile row");
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile");
     static_assert(BN % (8 * NW) == 0 && LB >= 1, "weight loader rounds");
-    static_assert(D >= 3 && D <= 7, "weight slices in flight");
+    static_assert(D >= 3 && D <= 8, "weight slices in flight");
     static_assert((D - 2) * LB + (D - 1) * ((GP + NT - D - 1) / (NT - D)) <= 63, "vmcnt immediate range");
     constexpr int NPB = ONE ? 1 : 2;                          // patch buffers
     static_assert(!ONE || KS == 1, "single-chunk tiles: no accumulator exchange (it would need 64 KiB of scratch)");
@@ -250,12 +254,12 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     // ---------------- prologue: patch 0 and weight slices 0 .. D-1; step 0's fragments into set 0 ----------------
 #pragma unroll
     for (int k = 0; k < GP; ++k) issue_patch(k, 0, smem);
-    constexpr int DP = B2 ? D - 1 : D;                        // slices the prologue issues (B2: iteration 0 issues slice D-1 itself)
+    constexpr int DP = D - (BP - 1);                          // slices the prologue issues (BP > 1: iteration 0 issues slice D-BP+1 itself)
 #pragma unroll
     for (int t = 0; t < DP; ++t)
 #pragma unroll
         for (int i = 0; i < LB; ++i) issue_w_piece(i, t, t);
-    if constexpr ((FLAGS & 2) != 0) {
+    if constexpr ((FLAGS & 4) != 0) {
         if (wid >= NW / 2) __builtin_amdgcn_s_setprio(1);
     }
     V2V_STAMP(p, 1);
@@ -270,7 +274,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         if (!(ab & 32))
             static_for<NRD>([&](auto qc) { read_frag(qc, std::integral_constant<int, 0>{}, arow, ax, pb); });
     }
-    wait_vmcnt<(B2 ? (DP - 3) : (D - 2)) * LB>();            // slice 1 (B2: slices 1 and 2): published by B_0
+    wait_vmcnt<(DP - 1 - BP) * LB>();                        // slices 1 .. BP: published by B_0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     int step = 0, stage = 0, cc = 0;                          // step being multiplied, its weight stage, its chunk
@@ -292,7 +296,8 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         constexpr int RPS = (NRD + RSLOTS - 1) / RSLOTS;
         constexpr int RUSED = (NRD + RPS - 1) / RPS;          // slots that actually carry reads
 
-        if constexpr (!B2 || PAR == 0)
+        constexpr int PH = BP == 1 ? 0 : BP == 2 ? PAR : TAP % 3;      // position inside the barrier period (NT = 9: iteration % 3 == tap % 3)
+        if constexpr (PH == 0)
             __builtin_amdgcn_s_barrier();                    // B_step: slice step+1 (and at tap 8 the next patch) is visible,
                                                              // the stage of slice `step` and its fragment reads are retired
                                                              // (B2: only in front of the even iterations, for two steps at once)
@@ -314,7 +319,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
             constexpr int d = decltype(dc)::value;
             if (ab & 128) return;
             if constexpr (d < LB) {
-                if constexpr (B2) issue_w_piece(d, step + D - 1, stage == 0 ? NSB - 1 : stage - 1);   // slice step+D-1 refills the stage of slice step-1
+                if constexpr (B2) issue_w_piece(d, step + D - (BP - 1), stage >= BP - 1 ? stage - (BP - 1) : stage - (BP - 1) + NSB);   // slice step+D-BP+1 refills the stage of slice step-BP+1
                 else              issue_w_piece(d, step + D, stage);                                   // slice step+D refills the stage of slice `step`
             } else                issue_patch(k0 + d - LB, cc + 1, pn);
         };
@@ -344,8 +349,8 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         constexpr int DMA_IN_SLOTS = pp3::cmin(NDMA, NMMA - 1 - RUSED > 0 ? NMMA - 1 - RUSED : 0);
         static_for<NDMA - DMA_IN_SLOTS>([&](auto dc) { dma(std::integral_constant<int, DMA_IN_SLOTS + decltype(dc)::value>{}); });
         if constexpr (B2) {
-            if constexpr (PAR == 1) {                        // in front of the barrier: slices step+2, step+3 retired, all fragment reads drained
-                wait_vmcnt<pp3::pending_b2(TAP, GP, LB, D, NT)>();
+            if constexpr (PH == BP - 1) {                    // in front of the barrier: slices step+2 .. step+BP+1 retired, all fragment reads drained
+                wait_vmcnt<pp3::pending_bp(TAP, GP, LB, D, NT, BP, NPT)>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else {
@@ -385,7 +390,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     if (c < ncc) chunk(std::integral_constant<int, 0>{});
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail duplicates must land before the LDS is reused
-    if constexpr ((FLAGS & 2) != 0) __builtin_amdgcn_s_setprio(0);
+    if constexpr ((FLAGS & 4) != 0) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     V2V_STAMP(p, 3);
 
@@ -499,6 +504,8 @@ static const PatchCfg kPp3Cfgs[] = {
     {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 72 / 80 KiB
     {97, 8, 32, 64}, {98, 8, 32, 64}, {99, 8, 32, 64},     // round-5 experiments on tile 90's geometry (K pairs): 97 one barrier per two steps
                                            // (6 stages), 98 = 90 with 6 stages (the ring one deeper), 99 = 97 with 7 stages and static priority
+    {130, 8, 32, 64}, {131, 8, 32, 64}, {132, 8, 32, 64},  // 130 / 131: one barrier per THREE steps, 7 / 8 stages; 132: per two steps, 8 stages
+    {140, 8, 32, 64},                      // conv3x3_one_kernel.h: persistent, weights-resident single-chunk tile (geometry only; launched by launch_one_typed)
     {96, 4, 32, 64},                       // single-chunk layers, FOUR waves (2 x 2, 64 x 32 wave tiles), 28 + 24 = 52 KiB, 167 + 32 registers: the
                                            // tile that really puts two workgroups on a CU (staged for round 5; 94 / 95 never did: DESIGN 3.6 item 15)
     {120, 4, 32, 64}, {121, 4, 32, 128},   // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk
@@ -524,7 +531,10 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 91: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 4, 1, 2>(k, groups, s);   // as 83 for 64-wide tile rows
         case 97: return launch_pp3_cfg<T, 8, 32, 64, 6, 0, 4, 1, 2, false, 3, 1>(k, groups, s);   // as 90, ONE BARRIER PER TWO STEPS, 6 stages (144 KiB)
         case 98: return launch_pp3_cfg<T, 8, 32, 64, 6, 0, 4, 1, 2>(k, groups, s);                // as 90 with the weight ring one stage deeper (144 KiB)
-        case 99: return launch_pp3_cfg<T, 8, 32, 64, 7, 0, 4, 1, 2, false, 3, 3>(k, groups, s);   // as 97 with 7 stages (152 KiB) and static priority for waves 4-7
+        case 99: return launch_pp3_cfg<T, 8, 32, 64, 7, 0, 4, 1, 2, false, 3, 5>(k, groups, s);   // as 97 with 7 stages (152 KiB) and static priority for waves 4-7
+        case 130: return launch_pp3_cfg<T, 8, 32, 64, 7, 0, 4, 1, 2, false, 3, 2>(k, groups, s);  // as 90, ONE BARRIER PER THREE STEPS, 7 stages (152 KiB)
+        case 131: return launch_pp3_cfg<T, 8, 32, 64, 8, 0, 4, 1, 2, false, 3, 2>(k, groups, s);  // the same with 8 stages (160 KiB: all of the LDS)
+        case 132: return launch_pp3_cfg<T, 8, 32, 64, 8, 0, 4, 1, 2, false, 3, 1>(k, groups, s);  // one barrier per two steps, 8 stages
         case 92: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 2, 1, 4>(k, groups, s);   // as 82, K quads
         case 93: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 2, 1, 4>(k, groups, s);   // as 83, K quads
         case 120: case 121:                // 7x7 window: bf16 only for now (the fp32 instantiations double an 8-minute translation unit)

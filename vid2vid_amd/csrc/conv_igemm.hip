@@ -388,6 +388,7 @@ int launch_pp_f32(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_pp2_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp2_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp3_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
+int launch_one_bf16(int cfg, const ConvKArgs& k, int cus, hipStream_t s);     // persistent single-chunk tiles (conv3x3_one_kernel.h)
 int launch_pp3_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_s2_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_s2_f32(int cfg, const ConvKArgs& k, hipStream_t s);
@@ -419,6 +420,8 @@ struct ConvOp : Op {
     long long slab_bytes; int sk_tickets;
     int groups = 1;      // 2: grouped launch (v2v_conv2d_pair), second member's tensors in k.g1
     int launch(hipStream_t s) override {
+        if (cfg >= 140) return launch_one_bf16(cfg, k, device_cus(), s);        // persistent, weights-resident single-chunk tile (bf16: host check)
+        if (cfg >= 130) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, groups, s) : launch_pp3_f32(cfg, k, groups, s);    // round-5 experiment tiles of the 3x3 single-phase kernel
         if (cfg >= 120) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, 1, s) : launch_pp3_f32(cfg, k, 1, s);    // 7x7 window on the single-phase kernel
         if (cfg >= 110) return dtype == V2V_BF16 ? launch_t2_bf16(cfg, k, s) : launch_t2_f32(cfg, k, s);
         if (cfg >= 100) return dtype == V2V_BF16 ? launch_s2_bf16(cfg, k, s) : launch_s2_f32(cfg, k, s);
@@ -521,7 +524,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     }
     if (d->out_mode == V2V_OUT_NORM_ACT_NHWC) {
         if ((launching && (!d->fin_counter || !d->stats || !d->fin_scale_shift || d->fin_count <= 0)) || d->splitk > 1 || d->transposed ||
-            d->cout != d->cout_stride || !((d->tile >= 80 && d->tile < 88) || (d->tile >= 90 && d->tile <= 93) || (d->tile >= 97 && d->tile <= 99)) || d->cout > 128 * 64) {
+            d->cout != d->cout_stride || !((d->tile >= 80 && d->tile < 88) || (d->tile >= 90 && d->tile <= 93) || (d->tile >= 97 && d->tile <= 99) || (d->tile >= 130 && d->tile <= 139)) || d->cout > 128 * 64) {
             set_error("conv: fused norm needs tile 80..87 / 90..93 / 97..99, splitk <= 1, cout == cout_stride, stats, fin_counter (256 ints), fin_scale_shift, fin_count");
             return V2V_EINVAL;
         }
@@ -594,7 +597,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.m_tiles = d->N * k.tiles_h * k.tiles_w;
         k.n_tiles = 1;
         tile_bm = 256; tile_bn = 4;
-    } else if (op->cfg >= 120) {
+    } else if (op->cfg >= 120 && op->cfg < 130) {
         // conv3x3_pp3_body with a 7x7 window (tile 120; staged for round 5): dense 7x7 / stride 1 / pad 3 Conv2d whose channel
         // stride is a whole number of 128-byte chunks, weights channel-chunk major (korder 1), bf16
         const PatchCfg* pc = find_pp3_cfg(op->cfg);
@@ -611,7 +614,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.m_tiles = d->N * k.tiles_h * k.tiles_w;
         k.n_tiles = (int)ceil_div(d->cout, pc->BN);
         tile_bm = pc->TH * pc->TW; tile_bn = pc->BN;
-    } else if (op->cfg >= 110) {
+    } else if (op->cfg >= 110 && op->cfg < 120) {
         // conv3x3_t2_kernel: ConvTranspose2d(3x3, stride 2, padding 1), all four output-parity classes per workgroup, full-tap (korder 2) weights
         const PatchCfg* pc = find_t2_cfg(op->cfg);
         if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
@@ -628,7 +631,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
         k.woff[0] = 0; k.wrow[0] = 9 * d->cin_stride;          // the single full-tap matrix
         k.fin_rows = 4 * k.m_tiles;                            // every workgroup publishes one statistics row per class
         tile_bm = pc->TH * pc->TW; tile_bn = pc->BN;
-    } else if (op->cfg >= 100) {
+    } else if (op->cfg >= 100 && op->cfg < 110) {
         // conv3x3_s2_kernel: 3x3 / stride 2 / pad 1 (zero) Conv2d, channel stride a multiple of the 128-byte chunk, korder-1 weights
         const PatchCfg* pc = find_s2_cfg(op->cfg);
         if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
@@ -654,7 +657,11 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
             set_error("conv: patch tile config %d needs a 3x3/s1/p1 Conv2d, cin_stride %% %d == 0 and korder-1 weights",
                       op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
         }
-        if ((op->cfg == 94 || op->cfg == 95 || op->cfg == 96) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
+        if (op->cfg == 140 && d->cout > pc->BN) {
+            set_error("conv: tile config 140 (persistent, weights resident) serves layers of at most %d output channels", pc->BN);
+            return V2V_EINVAL;
+        }
+        if ((op->cfg == 94 || op->cfg == 95 || op->cfg == 96 || op->cfg == 140) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
                                                  d->out_mode == V2V_OUT_NORM_ACT_NHWC)) {
             set_error("conv: tile config %d is a single-chunk tile: bf16, cin_stride exactly %d, no split-K, no fused norm", op->cfg, bke_of(d->dtype));
             return V2V_EINVAL;
@@ -840,7 +847,7 @@ extern "C" int v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, v
     int rc = build_conv(a, op.get());
     if (rc == 0) rc = build_conv(b, &ob);
     if (rc != 0) return rc;
-    if (op->cfg < 70 || (op->cfg >= 94 && !(op->cfg >= 97 && op->cfg <= 99)) || ob.cfg != op->cfg) {
+    if (op->cfg < 70 || (op->cfg >= 94 && !(op->cfg >= 97 && op->cfg <= 99) && !(op->cfg >= 130 && op->cfg <= 139)) || ob.cfg != op->cfg) {
         set_error("conv pair: both members need the same grouped-launch tile config (70..93, 97..99), got %d / %d", op->cfg, ob.cfg);
         return V2V_EINVAL;
     }

@@ -2,6 +2,7 @@
 #include "conv3x3_pp_kernel.h"
 #include "conv3x3_pp2_kernel.h"
 #include "conv3x3_pp3_kernel.h"
+#include "conv3x3_one_kernel.h"
 #include "conv3x3_s2_kernel.h"
 #include "conv3x3_t2_kernel.h"
 #include "conv7x7_head_kernel.h"
@@ -12,6 +13,7 @@ int launch_patch_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launc
 int launch_pp_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_pp_typed<bf16_t>(cfg, k, s); }
 int launch_pp2_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s) { return launch_pp2_typed<bf16_t>(cfg, k, groups, s); }
 int launch_pp3_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s) { return launch_pp3_typed<bf16_t>(cfg, k, groups, s); }
+int launch_one_bf16(int cfg, const ConvKArgs& k, int cus, hipStream_t s) { return launch_one_typed<bf16_t>(cfg, k, cus, s); }
 int launch_s2_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_s2_typed<bf16_t>(cfg, k, s); }
 int launch_t2_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_t2_typed<bf16_t>(cfg, k, s); }
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s) { return launch_head_typed<bf16_t>(k, s); }

@@ -350,7 +350,11 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               94: (8, 32, 64), 95: (4, 64, 64), 96: (4, 32, 64),
               # round-5 experiments on tile 90's geometry (K pairs): 97 one barrier per two steps (6 weight stages), 98 the ring one
               # stage deeper, 99 = 97 with 7 stages + static wave priority.  Offered to the tile searches only with V2V_EXP_TILES=1.
-              97: (8, 32, 64), 98: (8, 32, 64), 99: (8, 32, 64)}        # 94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
+              97: (8, 32, 64), 98: (8, 32, 64), 99: (8, 32, 64),
+              130: (8, 32, 64), 131: (8, 32, 64), 132: (8, 32, 64),
+              # csrc/conv3x3_one_kernel.h (round 5): PERSISTENT, weights-resident tile for single-chunk layers with <= 64 output channels
+              # (one workgroup per CU walks its tiles; no barrier / DMA / wait inside a tile's 9 steps).  Experiment until measured.
+              140: (8, 32, 64)}     # 130 / 131: one barrier per three steps (7 / 8 stages), 132: per two steps, 8 stages.   94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
 # stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
 S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
 # ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
@@ -360,14 +364,15 @@ T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 6
 S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
-EXP_TILES = (97, 98, 99)
+EXP_TILES = (97, 98, 99, 130, 131, 132, 140)
 if os.environ.get("V2V_EXP_TILES", "0") == "1":
     PAIR_TILES = PAIR_TILES + EXP_TILES
 
 
 def is_patch_tile(t):
-    """Tile ids of the LDS-patch 3x3 kernels (weights in K order 1): patch 32-48, ping-pong 50-57, ping-pong 2 70-79."""
-    return 32 <= t < 60 or 70 <= t < 97 or 100 <= t < 110 or 120 <= t < 130
+    """Tile ids of the LDS-patch 3x3 kernels (weights in K order 1): patch 32-48, ping-pong 50-57, ping-pong 2 70-79, single-phase
+    80-99, its round-5 experiment tiles 130-139 and the persistent single-chunk tile 140; stride-2 100-109, 7x7 window 120-129."""
+    return 32 <= t < 60 or 70 <= t < 110 or 120 <= t < 150
 
 
 def tile_korder(t):
