@@ -84,3 +84,33 @@ if has dom; then     # the dominant pair launch -- ring depth
   timeout 200 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "fused_norm_pair or pair_equals or conv3x3_patch_kernel" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300 | tail -12
   lap dom
 fi
+if has frameexp; then   # both resolutions with the round-5 experiment tiles offered to the tile searches (V2V_EXP_TILES=1): the cache copy forgets the dominant
+                        # pair and the single-chunk 64 -> 64 layers (and, with S7=1, the dense 7x7 stems); baseline first, alternating twice
+  python - <<PY
+import json
+d = json.load(open("profiles/tune_cache.json"))
+drop7 = "${S7:-1}" == "1"
+for dt, v in d.items():
+    for k in list(v):
+        f = k.split(",")
+        if k.startswith("-2,1024,1024,1,32,64") or (f[0] == "64" and f[1] == "64" and f[2] == "3" and f[3] == "1" and f[5] == "1") or \
+           (drop7 and f[2] == "7" and f[8] == "0" and int(f[9]) % 64 == 0):
+            del v[k]
+json.dump(d, open("gpurun_out/${TAG}_tune_exp.json", "w"))
+PY
+  for i in 1 2; do
+    timeout 600 python bench.py $LEAN 2>gpurun_out/${TAG}_frame_base.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('baseline run $i:', j['value'], 'frames/s |', j.get('hires_value'), 'frames/s @2048x1024 | dominant eager', j['roofline'].get('eager_us'), 'us live', j['roofline'].get('in_graph_live_us'))"
+    V2V_EXP_TILES=1 V2V_S7_PATCH=${S7:-1} V2V_TUNE_CACHE=$R/gpurun_out/${TAG}_tune_exp.json timeout 900 python bench.py $LEAN 2>gpurun_out/${TAG}_frame_exp.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('experiment tiles run $i:', j['value'], 'frames/s |', j.get('hires_value'), 'frames/s @2048x1024 | dominant', j['roofline']['kernel'][:70], 'eager', j['roofline'].get('eager_us'), 'us live', j['roofline'].get('in_graph_live_us'))"
+    cp bench_full.json gpurun_out/${TAG}_frame_exp_full.json
+  done 2>&1 | tee gpurun_out/${TAG}_frameexp.txt
+  python - <<PY
+import json
+d = json.load(open("gpurun_out/${TAG}_tune_exp.json"))
+b = json.load(open("profiles/tune_cache.json"))
+for dt, v in d.items():
+    print(dt, {k: (b.get(dt, {}).get(k), v[k]) for k in v if b.get(dt, {}).get(k) != v[k]})
+PY
+  lap frameexp
+fi

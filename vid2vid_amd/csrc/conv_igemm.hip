@@ -378,6 +378,16 @@ struct PackOp : Op {
 
 // per-dtype launchers live in conv_igemm_bf16.hip / conv_igemm_f32.hip (one translation unit per dtype
 // keeps the build parallel)
+// compute units of the current device (no device -- dry run on a CPU host: the MI355X's 256 CUs are assumed)
+static int device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else { (void)hipGetLastError(); cus = 256; }
+    }
+    return cus;
+}
 int launch_conv_bf16(int cfg, const ConvKArgs& k, int ncls, hipStream_t s);
 int launch_conv_f32(int cfg, const ConvKArgs& k, int ncls, hipStream_t s);
 bool conv_cfg_has_helper(int cfg);
@@ -800,15 +810,6 @@ extern "C" int v2v_conv_tile_config(const v2v_conv_desc* d) {
 
 // Fused norm: the spin barrier needs every workgroup of the launch on the chip at once (one workgroup per CU at these
 // LDS sizes).  No device (dry run on a CPU host): the MI355X's 256 CUs are assumed.
-static int device_cus() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else { (void)hipGetLastError(); cus = 256; }
-    }
-    return cus;
-}
 
 // Division of 0 <= n < 2^31 by a constant 1 <= d < 2^31 as q = (umulhi(M, n) + n) >> l  (Granlund & Montgomery, "Division by invariant
 // integers using multiplication", the round-up form): l = ceil(log2 d), M = floor(2^32 (2^l - d) / d) + 1 < 2^32; umulhi(M, n) < n, so
