@@ -19,6 +19,7 @@ ap.add_argument("--k", type=int, default=3)
 ap.add_argument("--H", type=int, default=32)
 ap.add_argument("--W", type=int, default=64)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--batch", type=int, default=1, help="images per launch (2 = the geometry of a two-sequence launch: 256 workgroups of tile 90)")
 ap.add_argument("--pair", action="store_true", help="paired launch (v2v_conv2d_pair) of two layers of this shape")
 ap.add_argument("--fused", action="store_true", help="with --pair: norm + ReLU + residual inside the launch (V2V_OUT_NORM_ACT_NHWC), as the frame runs it")
 a = ap.parse_args()
@@ -26,7 +27,7 @@ cfg = tuple(int(v) for v in a.cfg.split(","))
 eng = Engine("cuda:0", L.BF16)
 mod = nn.Conv2d(a.cin, a.cout, a.k, padding=0).to("cuda:0")
 norm = nn.BatchNorm2d(a.cout).to("cuda:0")
-x = eng.pack(torch.randn(1, a.cin, a.H, a.W, device="cuda:0"))
+x = eng.pack(torch.randn(a.batch, a.cin, a.H, a.W, device="cuda:0"))
 ss = torch.zeros(4 * a.cout, device="cuda:0")
 eng.tile_override[(a.cin, a.cout, a.k, 1, 0)] = cfg
 thrash = torch.empty(96 << 20, dtype=torch.float32, device="cuda:0")
@@ -47,6 +48,6 @@ with torch.no_grad():
         elif a.pair:
             eng.conv_pair(x, mod, x2, mod2, L.PAD_REFLECT, a.k // 2, ((norm, ss), (norm, ss2)), ("a", "b"))
         else:
-            eng.conv(x, mod, L.PAD_REFLECT, a.k // 2, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+            eng.conv(x, mod, L.PAD_REFLECT, a.k // 2, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss) if a.batch == 1 else None)
 torch.cuda.synchronize()
 print("ran %d launches of %s" % (a.reps, eng.conv_log[-1]))

@@ -114,3 +114,42 @@ for dt, v in d.items():
 PY
   lap frameexp
 fi
+if has mfma; then    # what the whole chip shares when every CU runs the matrix pipe: pure-register MFMA stream on 64 .. 512 workgroups
+  timeout 120 scripts/mfma_rate.bin 2>&1 | tee gpurun_out/${TAG}_mfma_rate.txt
+  lap mfma
+fi
+if has tcc; then     # L2 hit / miss / fabric read requests of the 1024 -> 1024 kernel on 128 workgroups (N = 1) and 256 (N = 2)
+  cd /tmp
+  for b in 1 2; do
+    for pass in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES"; do
+      tag=$(echo $pass | cut -d' ' -f1)
+      timeout 200 rocprofv3 --kernel-trace --pmc $pass -d /tmp/tcc_${b}_$tag -o pmc -- python $R/scripts/conv_layer_run.py --cfg 90,1,0 --batch $b --reps 12 > $R/gpurun_out/${TAG}_tcc_${b}_$tag.log 2>&1; echo "tcc batch $b $tag rc=$?"
+      python $R/scripts/pmc_summary.py $(find /tmp/tcc_${b}_$tag -name "*.db" | head -1) "# batch $b (tile 90, $((128 * b)) workgroups): rocprofv3 --kernel-trace --pmc $pass -- python scripts/conv_layer_run.py --cfg 90,1,0 --batch $b" 2>>$R/gpurun_out/${TAG}_tcc_${b}_$tag.log | grep -E "^#|conv3x3" | cut -c1-20,60-200
+    done
+  done 2>&1 | tee $R/gpurun_out/${TAG}_tcc.txt
+  cd $R
+  lap tcc
+fi
+if has stampdiag; then   # the stamp build's flaky golden tests -- WHICH tile selections do the failing runs replay?
+  for i in 1 2 3 4 5 6 7 8; do
+    rm -f /tmp/stamp_tune_$i.json
+    V2V_LIB_PATH=$R/vid2vid_amd/libv2v_hip_stamp.so V2V_TUNE_CACHE=/tmp/stamp_tune_$i.json timeout 120 python -m pytest tests/test_gpu_golden.py -m gpu -q --tb=line -k "inference_api_vs_reference or flownet2_vs_reference" -p no:cacheprovider 2>&1 | grep -E "passed|failed" | tail -1 > /tmp/stamp_res_$i.txt
+    echo "stamp run $i: $(cat /tmp/stamp_res_$i.txt)"; cp /tmp/stamp_tune_$i.json gpurun_out/${TAG}_stamp_tune_$i.json 2>/dev/null
+  done 2>&1 | tee gpurun_out/${TAG}_stampdiag.txt
+  # replay every run's selections with the PRODUCT build: does a selection that failed on the stamp build fail here too?
+  for i in 1 2 3 4 5 6 7 8; do
+    cp /tmp/stamp_tune_$i.json /tmp/replay_$i.json 2>/dev/null || continue
+    echo "product build replaying the selections of stamp run $i ($(cat /tmp/stamp_res_$i.txt)): $(V2V_TUNE_CACHE=/tmp/replay_$i.json timeout 120 python -m pytest tests/test_gpu_golden.py -m gpu -q --tb=line -k 'inference_api_vs_reference or flownet2_vs_reference' -p no:cacheprovider 2>&1 | grep -E 'passed|failed' | tail -1)"
+    echo "stamp build replaying its own selections of run $i: $(V2V_LIB_PATH=$R/vid2vid_amd/libv2v_hip_stamp.so V2V_TUNE_CACHE=/tmp/replay_$i.json timeout 120 python -m pytest tests/test_gpu_golden.py -m gpu -q --tb=line -k 'inference_api_vs_reference or flownet2_vs_reference' -p no:cacheprovider 2>&1 | grep -E 'passed|failed' | tail -1)"
+  done 2>&1 | tee -a gpurun_out/${TAG}_stampdiag.txt
+  lap stampdiag
+fi
+if has newtests; then   # the tests that failed in visit 1 only because tiles 97-99 were not reachable + the new tiles
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "conv3x3_patch_kernel or pair_equals or fused_norm_pair or persistent_single_chunk or conv7x7_window" -p no:cacheprovider > gpurun_out/${TAG}_newtests.log 2>&1; echo "newtests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_newtests.log | cut -c1-300 | tail -25
+  lap newtests
+fi
+if has onebench; then
+  timeout 300 python scripts/one_bench.py 2>&1 | tee gpurun_out/${TAG}_one_bench.txt | cut -c1-400
+  lap onebench
+fi

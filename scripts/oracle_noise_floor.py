@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--ngf", type=int, default=128)
     ap.add_argument("--num-D", type=int, default=2)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--vgg", action="store_true", help="with the VGG19 perceptual loss (seeded stand-in weights of tests/util.py), as bench.py's train leg runs it")
     args = ap.parse_args()
     if args.threads:
         torch.set_num_threads(args.threads)
@@ -61,6 +62,11 @@ def main():
              "D": [n for n, p in netD.named_parameters() if p.requires_grad],
              "DT": [n for n, p in netDT.named_parameters() if p.requires_grad]}
     has_T = nfl >= opt.n_frames_D
+    sd_vgg = None
+    if args.vgg:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from util import seeded_vgg19_features, vgg19_slice_state_dict
+        sd_vgg = vgg19_slice_state_dict(seeded_vgg19_features(77))
 
     def run(dtype):
         torch.set_default_dtype(dtype)
@@ -70,7 +76,8 @@ def main():
             out = TP.oracle_chunk([cast(sd(netG))], cast(sd(netD)), cast(sd(netDT)) if has_T else None,
                                   lab.view(1, nT, 1, H, W).to(dtype), inst.view(1, nT, 1, H, W).to(dtype), frames.to(dtype),
                                   flow_ref.to(dtype), conf_ref.to(dtype), n_down=opt.n_downsample_G, n_blocks=opt.n_blocks,
-                                  n_blocks_local=opt.n_blocks_local, n_frames_load=nfl, num_D=args.num_D, sd_vgg=None, param_names=names,
+                                  n_blocks_local=opt.n_blocks_local, n_frames_load=nfl, num_D=args.num_D,
+                                  sd_vgg=None if sd_vgg is None else cast(sd_vgg), param_names=names,
                                   dtype=dtype)
             out["seconds"] = time.perf_counter() - t0
             return out

@@ -449,9 +449,9 @@ def test_conv3x3_patch_kernel(case, prec):
     for it, (tile, S) in enumerate(PATCH_CFGS):
         if S > ncc:
             continue
-        if tile in (94, 95, 96, 140) and (ncc != 1 or prec != "bf16"):
+        if tile in (94, 95, 96) and (ncc != 1 or prec != "bf16"):
             continue
-        if tile == 140 and cout > 64:
+        if tile == 140:                                        # its own test below (one output mode, full tiles, no in-kernel finalize)
             continue
         k = it % 2
         eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, S, 12 if (tile <= 37 and it % 3 == 0) else 0)
@@ -472,6 +472,55 @@ def test_conv3x3_patch_kernel(case, prec):
     assert_close(eng.unpack(out).cpu(), F.leaky_relu(refs[0], 0.2), 1e-4 if prec == "fp32" else 1e-2, "act")
     if eng._sk_counter is not None:
         assert int(eng._sk_counter.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("case", [(64, 64, 64, 128, "reflect", 1), (64, 32, 16, 64, "zero", 2), (64, 64, 24, 96, "reflect", 2), (64, 48, 8, 32, "zero", 1),
+                                  (64, 64, 256, 512, "reflect", 1)])
+def test_conv3x3_persistent_single_chunk_tile(case):
+    """Tile 140 (csrc/conv3x3_one_kernel.h): the persistent, weights-resident kernel for single-chunk layers (64 bf16 input channels,
+    <= 64 output channels) -- one workgroup per CU walks its tiles, one output mode (raw fp32 NHWC + a statistics row per tile).
+    Against torch on bf16-rounded operands, and BIT FOR BIT against the single-phase tile 94 (same MFMA order per accumulator, same
+    epilogue arithmetic): raw output and statistics rows; border and interior tiles, reflection and zero padding, batch 2, fewer
+    tiles than CUs and (last case, 1024 tiles) four tiles per workgroup; launched twice with different inputs (the resident weights
+    and the patch buffer of a previous launch must not leak).  Geometries the kernel does not serve are refused by the library."""
+    from vid2vid_amd import lib as L
+    cin, cout, H, W, mode, N = case
+    torch.manual_seed(cout + H)
+    eng = _engine("bf16")
+    conv = nn.Conv2d(cin, cout, 3, padding=0 if mode == "reflect" else 1)
+    xs = [torch.randn(N, cin, H, W) * (1.0 + i) for i in range(2)]
+    def ref_of(x):
+        xr = _round(x, "bf16")
+        if mode == "reflect":
+            xr = F.pad(xr, (1,) * 4, mode="reflect")
+        return F.conv2d(xr, _round(conv.weight.detach(), "bf16"), conv.bias.detach(), padding=0 if mode == "reflect" else 1)
+    conv = conv.to(DEV)
+    pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
+    for x in xs:
+        xa = eng.pack(x.to(DEV))
+        got = {}
+        for tile in (94, 140):
+            eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, 1, 0)
+            raw, rows, (n_, OH, OW) = eng.conv(xa, conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
+            assert eng.conv_log[-1]["tile"] == tile
+            cs_raw = (cout + 3) // 4 * 4
+            st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].clone()
+            got[tile] = (raw[:n_ * OH * OW * cs_raw].clone(), st, rows)
+        assert got[140][2] == got[94][2]
+        assert torch.equal(got[140][0], got[94][0]), "raw output differs from tile 94"
+        assert torch.equal(got[140][1], got[94][1]), "statistics rows differ from tile 94"
+        cs_raw = (cout + 3) // 4 * 4
+        r = got[140][0].view(N, H, W, cs_raw)[..., :cout].permute(0, 3, 1, 2)
+        assert_close(r.cpu(), ref_of(x), 1e-4, "tile 140 vs torch")
+    # refused: ragged tiles, more than 64 output channels, in-kernel finalize
+    eng.tile_override[(cin, cout, 3, 1, 0)] = (140, 1, 0)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    ss = torch.zeros(4 * cout, device=DEV)
+    with pytest.raises(RuntimeError):
+        eng.conv(eng.pack(torch.randn(1, cin, 12, 40, device=DEV)), conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
+    if H * W * N <= 32768:
+        with pytest.raises(RuntimeError):
+            eng.conv(eng.pack(xs[0].to(DEV)), conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
 
 
 @pytest.mark.parametrize("case", [(64, 64, 24, 64, "reflect", 1), (128, 64, 33, 70, "reflect", 2), (128, 128, 16, 96, "zero", 1),

@@ -12,11 +12,17 @@
 //     the bytes a tile used to pull through the LDS-DMA path are gone, and with them every weight-ring hazard: the main loop has NO
 //     barrier, NO vmcnt wait and NO DMA, only ds_reads (two fragment register sets, step j+1 read under the MFMAs of step j) and MFMAs;
 //   * one 48 KB patch buffer.  Per tile: [patch landed] barrier | 9 steps | barrier [patch free] | issue the NEXT tile's patch |
-//     epilogue of this tile (its own 40 KB of LDS scratch) -- the next patch travels while the epilogue stores, so its latency is
-//     hidden without a second buffer (72 + 48 + 40 = 160 KB: all of the LDS);
+//     epilogue of this tile (its own 34 KB of LDS scratch) -- the next patch travels while the epilogue stores, so its latency is
+//     hidden without a second buffer (72 + 48 + 34 = 154 KB of LDS);
+//   * ONE output mode per instantiation (raw fp32 NHWC + a statistics row, full tiles): the shared conv_epilogue dispatches on the
+//     output mode, the activation, ragged rows and channels, split-K and the in-kernel finalize at run time -- ~900 vector
+//     instructions per wave and a kernel at the SGPR ceiling; here the tail is the ~150 instructions this mode needs;
+//   * interior tiles (no patch pixel outside the image) take their source offsets from a per-kernel table: one add per piece
+//     instead of the reflect / clamp arithmetic;
 //   * tile -> workgroup mapping: workgroup b takes virtual block ids b, b + G, b + 2G, ... (G = grid size, a multiple of 8), each
 //     through xcd_remap: every XCD keeps a contiguous range of tiles (halo rows shared through its L2) as with one tile per workgroup.
-// Same MFMA order per accumulator as tiles 80 / 94 (taps 0..8, K sub-steps 0..3), same epilogue (conv_epilogue): bit-identical results.
+// Same MFMA order per accumulator as tiles 80 / 94 (taps 0..8, K sub-steps 0..3), the same epilogue arithmetic in the same order as
+// conv_epilogue's fast path: bit-identical results (raw output and statistics rows).
 #pragma once
 #include "conv3x3_pp3_kernel.h"
 
@@ -35,28 +41,30 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     constexpr int BST = BN * 128;                             // one weight slice: BN rows of one 128-byte chunk
     constexpr int LB = BN / 8 / NW;                           // weight pieces per wave per slice
     constexpr int WBYTES = 9 * BST;
-    constexpr int EPI = 40960;                                // conv_epilogue's scratch (statistics rows, transposition blocks, flag word)
+    constexpr int RED = WGM * BN * 2 * 4;                     // per-row-of-waves (sum, sum^2) partials
+    constexpr int EPI = RED + NW * 4096;                      // + one 4 KiB transposition block per wave
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int NMMA = SS * TM * TN, NRD = SS * (TM + TN);
+    constexpr int NMMA = SS * TM * TN;
     static_assert(sizeof(T) == 2, "single-chunk persistent tile: bf16 (64 input channels = one 128-byte chunk)");
-    static_assert(TW % 32 == 0 && (TW & (TW - 1)) == 0 && WM % 32 == 0 && WN % 32 == 0 && LB >= 1, "tile geometry");
+    static_assert(TW == 32 && WM % 32 == 0 && WN == 32 && TN == 1 && LB >= 1, "tile geometry (one 32-pixel tile row per row fragment)");
     static_assert(WBYTES + PATCH + EPI <= 160 * 1024, "LDS");
     typedef typename Mma<T>::Frag Frag;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wres = smem;                                  // resident weights: [tap][BN rows][128 B]
     char* const patch = smem + WBYTES;
-    char* const epi = smem + WBYTES + PATCH;
+    float* const red = reinterpret_cast<float*>(smem + WBYTES + PATCH);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WGN, wn = wid % WGN;
+    float* const tw = reinterpret_cast<float*>(smem + WBYTES + PATCH + RED) + wid * 1024;
     const int H = p.H, W = p.W, cs = p.cin_stride;
     const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
     const char* const zp = p.zero_page;
-    const int ntot = p.m_tiles * p.n_tiles;                   // n_tiles == 1 (host check): the resident weights serve every tile
+    const int ntot = p.m_tiles;                               // n_tiles == 1 (host check): the resident weights serve every tile
     const int G = (int)gridDim.x;
 
     // ---------------- weights: once ----------------
@@ -73,24 +81,41 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
         }
     }
 
-    // ---------------- per-tile patch loader ----------------
-    auto issue_patch_of = [&](const int n_img, const int oh0, const int ow0) __attribute__((always_inline)) {
+    // ---------------- patch loader ----------------
+    // piece k of this wave = 8 patch pixels x 128 B; pixel q of the (TH+2) x (TW+2) patch sits at row pr, column pc.  For an INTERIOR
+    // tile (no pixel of the patch outside the image) the source offset is tile base + a tile-independent term: one add per piece.
+    int rel[GP];                                              // ((pr - 1) * W + (pc - 1)) * cs * 2 + swizzled 16-byte slot, or < 0: no such pixel
 #pragma unroll
-        for (int k = 0; k < GP; ++k) {
-            const int q = (k * NW + wid) * 8 + (lane >> 3);
-            const int ls = (lane & 7) ^ ((q >> 1) & 7);
-            const int pr = q / PW, pc = q - pr * PW;
-            int ih = oh0 + pr - 1, iw = ow0 + pc - 1;
-            bool ok = q < PR;
-            int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
-            int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
-            ih = reflect ? rh : ih;
-            iw = reflect ? rw : iw;
-            ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
-            iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
-            const unsigned off = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
-            glds16(ok ? p.in + off : zp, patch + (k * NW + wid) * 1024);
+    for (int k = 0; k < GP; ++k) {
+        const int q = (k * NW + wid) * 8 + (lane >> 3);
+        const int ls = (lane & 7) ^ ((q >> 1) & 7);
+        const int pr = q / PW, pc = q - pr * PW;
+        rel[k] = q < PR ? ((pr - 1) * W + (pc - 1)) * cs * (int)sizeof(T) + ls * 16 : -1;
+    }
+    auto issue_patch_of = [&](const int n_img, const int oh0, const int ow0) __attribute__((always_inline)) {
+        const bool interior = oh0 >= 1 && ow0 >= 1 && oh0 + TH + 1 <= H && ow0 + TW + 1 <= W;     // wave-uniform
+        if (interior) {
+            const char* const base = p.in + ((long long)(n_img * H + oh0) * W + ow0) * cs * (long long)sizeof(T);
+#pragma unroll
+            for (int k = 0; k < GP; ++k) glds16(rel[k] != -1 ? base + rel[k] : zp, patch + (k * NW + wid) * 1024);
+        } else {
+#pragma unroll
+            for (int k = 0; k < GP; ++k) {
+                const int q = (k * NW + wid) * 8 + (lane >> 3);
+                const int ls = (lane & 7) ^ ((q >> 1) & 7);
+                const int pr = q / PW, pc = q - pr * PW;
+                int ih = oh0 + pr - 1, iw = ow0 + pc - 1;
+                bool ok = q < PR;
+                int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+                int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+                ih = reflect ? rh : ih;
+                iw = reflect ? rw : iw;
+                ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+                iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+                const unsigned off = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
+                glds16(ok ? p.in + off : zp, patch + (k * NW + wid) * 1024);
+            }
         }
     };
 
@@ -123,10 +148,19 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
             for (int s = 0; s < SS; ++s) fa[PARN][s][i] = *reinterpret_cast<const Frag*>(arow + (((s * 2 + hi) ^ ax) << 4));
         }
 #pragma unroll
-        for (int s = 0; s < SS; ++s)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[PARN][s][j] = *reinterpret_cast<const Frag*>(wrow + TAP * BST + j * 32 * 128 + foff[s]);
+        for (int s = 0; s < SS; ++s) fb[PARN][s][0] = *reinterpret_cast<const Frag*>(wrow + TAP * BST + foff[s]);
     };
+
+    // ---------------- epilogue operands (tile independent) ----------------
+    // ONE output mode: raw fp32 NHWC + one (sum, sum^2) statistics row per tile; full tiles only (host check), so no element carries a
+    // predicate.  The arithmetic and its order are conv_epilogue's fast path: bit-identical to tiles 80 / 94.
+    float* const out = reinterpret_cast<float*>(p.out);
+    const unsigned cs_out = (unsigned)p.cout_stride;
+    const int ccol = wn * WN + lr;                            // this lane's output channel in the accumulator layout
+    const float bv = (p.bias != nullptr && ccol < p.cout) ? p.bias[ccol] : 0.f;
+    const int vcol = wn * WN + 4 * (lane & 7);                // first channel of the 16-byte vectors this lane stores
+    const bool vfull = vcol + 4 <= p.cout;                    // cout % 4 == 0 and 16-byte aligned rows (host check)
+    const bool want_stats = p.stats != nullptr;
 
     // ---------------- first tile ----------------
     int vb = (int)blockIdx.x;                                 // virtual block id of the current tile
@@ -138,17 +172,15 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
 
     while (vb < ntot) {
         const int oh0 = th * TH, ow0 = twi * TW;
-        const int c_lin = lin, c_nt = nt, c_mt = mt, c_img = n_img;
-        f32x16 acc[TM][TN];
+        const int c_mt = mt, c_img = n_img;
+        f32x16 acc[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the patch (first tile: and of the weights) have landed
-        __builtin_amdgcn_s_barrier();                        // ... everyone's: the patch is complete; the previous epilogue's scratch is retired
+        __builtin_amdgcn_s_barrier();                        // ... everyone's: the patch is complete; the previous tile's `red` rows are retired
         read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         // 9 steps, no barrier: step t multiplies set t & 1 while step t+1 is read into the other set
         static_for<9>([&](auto tc) {
@@ -156,8 +188,8 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
             constexpr int PAR = TAP & 1;
             static_for<NMMA>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                constexpr int s = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
-                Mma<T>::run(fa[PAR][s][i], fb[PAR][s][j], acc[i][j]);
+                constexpr int s = m / TM, i = m % TM;
+                Mma<T>::run(fa[PAR][s][i], fb[PAR][s][0], acc[i]);
                 if constexpr (m == 0 && TAP < 8) {
                     __builtin_amdgcn_sched_barrier(0);
                     read_step(std::integral_constant<int, TAP + 1>{}, std::integral_constant<int, 1 - PAR>{});
@@ -175,13 +207,46 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
             issue_patch_of(n_img, th * TH, twi * TW);
         }
 
-        const bool tile_full = oh0 + TH <= H && ow0 + TW <= W;
-        auto pix_of = [&](int row) __attribute__((always_inline)) -> int {
-            const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
-            if (oh >= H || ow >= W) return -1;
-            return (c_img * H + oh) * W + ow;
-        };
-        conv_epilogue<T, BM, BN, WGM, WGN, false>(p, acc, epi, tid, wm, wn, false, 0, ntot, c_lin, 0, 1, c_nt, c_mt, pix_of, tile_full);
+        // ---- epilogue: statistics + 16-byte stores through the wave's transposition block ----
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][r] + bv;
+                s1 += v;
+                s2 = __builtin_fmaf(v, v, s2);
+                tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lr] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // rows wm * WM + i * 32 .. + 31 of the tile = tile row wm * (WM / TW) + i (TW == 32), columns 0 .. 31
+            float* const orow = out + ((unsigned)((c_img * H + oh0 + wm * (WM / TW) + i) * W + ow0)) * cs_out + (unsigned)vcol;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + ((lane >> 3) + 8 * k) * 32 + 4 * (lane & 7));
+                if (vfull) *reinterpret_cast<f32x4*>(orow + (unsigned)((lane >> 3) + 8 * k) * cs_out) = v4;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the block is in registers before the next one overwrites it
+        }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hi == 0) {
+                red[(wm * BN + ccol) * 2 + 0] = s1;
+                red[(wm * BN + ccol) * 2 + 1] = s2;
+            }
+            __syncthreads();
+            if (tid < BN && tid < p.cout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid) * 2 + 0]; t2 += red[(q * BN + tid) * 2 + 1]; }
+                float* const dst = p.stats + ((long long)c_mt * p.cout + tid) * 2;
+                dst[0] = t1;
+                dst[1] = t2;
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -192,7 +257,7 @@ static inline int launch_one_typed(int cfg, const ConvKArgs& k, int cus, hipStre
         if (cfg == 140) {
             constexpr int TH = 8, TW = 32, BN = 64, NW = 8;
             constexpr int GP = (((TH + 2) * (TW + 2) + 7) / 8 + NW - 1) / NW;
-            const size_t lds = (size_t)9 * BN * 128 + (size_t)GP * NW * 1024 + 40960;
+            const size_t lds = (size_t)9 * BN * 128 + (size_t)GP * NW * 1024 + (size_t)(4 * BN * 2 * 4 + NW * 4096);
             void (*kern)(const ConvKArgs) = conv3x3_one_kernel<T, TH, TW, BN>;
             static bool attr_done = false;
             if (!attr_done) {
