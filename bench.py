@@ -840,7 +840,14 @@ def main():
         return acc, rows, convs, launches, mfma_log, total_ms
 
     def tile_label(dom, fused=False):
-        from vid2vid_amd.engine import TILE_CFGS, PATCH_CFGS, S2_CFGS, T2_CFGS
+        from vid2vid_amd.engine import TILE_CFGS, PATCH_CFGS, S2_CFGS, T2_CFGS, S7_CFGS
+        if dom[0] in S7_CFGS:
+            th_, tw_, bn = S7_CFGS[dom[0]]
+            return "conv7x7_pp3_kernel", "%dx%d px x %d (7x7 window, single-phase schedule),splitK=%d" % (th_, tw_, bn, dom[1])
+        if dom[0] in (140, 141):
+            th_, tw_, bn = PATCH_CFGS[dom[0]]
+            return "conv3x3_one_kernel" if dom[0] == 140 else "conv3x3_one_db_kernel", \
+                   "%dx%d px x %d (persistent, weights resident%s),splitK=1" % (th_, tw_, bn, ", two patch buffers" if dom[0] == 141 else "")
         if dom[0] in T2_CFGS:
             th_, tw_, bn = T2_CFGS[dom[0]]
             return "conv3x3_t2_kernel", "%dx%d positions x %d x 4 classes (transposed stride 2),splitK=1" % (th_, tw_, bn)

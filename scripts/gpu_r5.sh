@@ -153,3 +153,24 @@ if has onebench; then
   timeout 300 python scripts/one_bench.py 2>&1 | tee gpurun_out/${TAG}_one_bench.txt | cut -c1-400
   lap onebench
 fi
+if has stampbisect; then   # which (shape -> tile, split-K) entry makes the stamp build fail?  (scripts/stamp_bisect.py)
+  timeout 600 python scripts/stamp_bisect.py profiles/r05_v2_stamp_tune_fail.json profiles/r05_v2_stamp_tune_pass.json 2>&1 | tee gpurun_out/${TAG}_stamp_bisect.txt | cut -c1-300
+  lap stampbisect
+fi
+if has trainsplit; then   # is model_final_flow's gradient error (4x the fp32 oracle's own) the length of the fp32 accumulation chains of the
+                          # split-K weight-gradient kernel?  Same chunk, 8x more K splits (V2V_WGRAD_WGS): per-tensor table of both runs
+  for wgs in 1024 8192; do
+    V2V_WGRAD_WGS=$wgs timeout 600 python bench.py --mode train --steps 2 --warmup 1 --no-autotune > gpurun_out/${TAG}_trainsplit_$wgs.json 2> gpurun_out/${TAG}_trainsplit_$wgs.err; echo "train (V2V_WGRAD_WGS=$wgs) rc=$?"
+    cp bench_full.json gpurun_out/${TAG}_trainsplit_${wgs}_full.json
+    python - <<PY
+import json
+f = json.load(open("gpurun_out/${TAG}_trainsplit_${wgs}_full.json"))
+p = f["parity"]["fp32"]
+print("V2V_WGRAD_WGS=$wgs: grads", {k: (v["norm_rel_err"], v["l2_rel_err"]) for k, v in p["grads"].items()})
+g = p["grad_error_by_tensor"]["G"]
+print("   G by module", {m: v for m, v in list(g["by_module"].items())[:4]})
+print("   top", [(t["name"], t["share"], t["rel_err"]) for t in g["top_tensors"][:3]])
+PY
+  done 2>&1 | tee gpurun_out/${TAG}_trainsplit.txt
+  lap trainsplit
+fi

@@ -251,6 +251,241 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Tile 141: the same kernel with TWO patch buffers (round 5, second step).  Tile 140 hides the next patch only behind the epilogue
+// (~1.5 us); measured 72 us on the 64 -> 64 layer at 1024x512 (tile 94: 89.5, HBM bound 32): per tile ~3 us of patch latency + 2.5 us
+// of steps + the epilogue are still in series.  Here the patch of tile i+1 travels during the WHOLE of tile i (steps + epilogue):
+//   LDS = 72 KB weights + 2 x 43 KB patches (exactly the 43 groups of 8 pixels a (8+2) x (32+2) patch has, not rounded up to the
+//   waves) + 2 KB statistics partials = 160 KB: all of it -- so the epilogue's 8 x 4 KB transposition blocks live in the patch buffer
+//   the steps have just finished with; the patch of tile i+2 is issued into that buffer after the epilogue.
+//   vmcnt: at the top of tile i+1 only the pieces of tile i+2 (issued last) may stay in flight -- `vmcnt(n)` with n = this wave's
+//   pieces per patch; the stores of tile i's epilogue are older and retire with the wait (no store count enters the immediate, so a
+//   channel tile whose stores are branched around cannot break it).  A workgroup without a tile i+2 issues the same number of
+//   dummy pieces (zero page) so that the count holds in the tail.
+template <typename T, int TH, int TW, int BN>
+__global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int BM = TH * TW;
+    constexpr int PW = TW + 2, PR = (TH + 2) * PW;
+    constexpr int WGM = 4, WGN = 2, NW = 8;
+    constexpr int SS = 4;
+    constexpr int NG = (PR + 7) / 8;                          // groups of 8 patch pixels (1 KB each)
+    constexpr int GP = (NG + NW - 1) / NW;                    // pieces of the fullest waves
+    constexpr int NFULL = NG - (GP - 1) * NW;                 // waves 0 .. NFULL-1 carry GP pieces, the others GP - 1
+    constexpr int PATCH = NG * 1024;
+    constexpr int BST = BN * 128;
+    constexpr int LB = BN / 8 / NW;
+    constexpr int WBYTES = 9 * BST;
+    constexpr int RED = WGM * BN * 2 * 4;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NMMA = SS * TM * TN;
+    static_assert(sizeof(T) == 2 && TW == 32 && WM % 32 == 0 && WN == 32 && TN == 1 && LB >= 1, "tile geometry");
+    static_assert(WBYTES + 2 * PATCH + RED <= 160 * 1024, "LDS");
+    static_assert(PATCH >= NW * 4096, "the epilogue's transposition blocks live in the patch buffer the steps are done with");
+    static_assert(NFULL >= 1 && NFULL <= NW && GP >= 2, "piece split");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wres = smem;
+    char* const pbase = smem + WBYTES;                        // patch buffers at pbase, pbase + PATCH
+    float* const red = reinterpret_cast<float*>(smem + WBYTES + 2 * PATCH);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int H = p.H, W = p.W, cs = p.cin_stride;
+    const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+    const char* const zp = p.zero_page;
+    const int ntot = p.m_tiles;
+    const int G = (int)gridDim.x;
+    const bool full_wave = wid < NFULL;                       // wave-uniform: this wave carries GP pieces per patch
+
+    {   // weights: once
+        const int lrow = wid * 8 + (lane >> 3);
+        const int lslot = (lane & 7) ^ ((lrow >> 1) & 7);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            long long r = (long long)lrow + NW * 8 * i;
+            r = r < p.cout_p ? r : p.cout_p - 1;
+            const char* const wp = p.w + ((long long)p.woff[0] + r * p.wrow[0] + lslot * VEC) * (long long)sizeof(T);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) glds16(wp + tap * 128, wres + tap * BST + wid * 1024 + i * NW * 1024);
+        }
+    }
+
+    int rel[GP];
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+        const int q = (k * NW + wid) * 8 + (lane >> 3);
+        const int ls = (lane & 7) ^ ((q >> 1) & 7);
+        const int pr = q / PW, pc = q - pr * PW;
+        rel[k] = q < PR ? ((pr - 1) * W + (pc - 1)) * cs * (int)sizeof(T) + ls * 16 : -1;
+    }
+    // `vbn` >= ntot: no such tile -- the same number of pieces from the zero page (the vmcnt immediates count them)
+    auto issue_patch_vb = [&](const int vbn, char* const buf) __attribute__((always_inline)) {
+        int l_, s_, nt_, mt_, n_img = 0, th_ = 0, tw_ = 0;
+        const bool real = vbn < ntot;
+        if (real) patch_tile_index(p, xcd_remap(vbn, ntot), l_, s_, nt_, mt_, n_img, th_, tw_);
+        const int oh0 = th_ * TH, ow0 = tw_ * TW;
+        const bool interior = real && oh0 >= 1 && ow0 >= 1 && oh0 + TH + 1 <= H && ow0 + TW + 1 <= W;     // wave-uniform
+        if (!real) {
+#pragma unroll
+            for (int k = 0; k < GP; ++k)
+                if (k < GP - 1 || full_wave) glds16(zp, buf + (k * NW + wid) * 1024);
+        } else if (interior) {
+            const char* const base = p.in + ((long long)(n_img * H + oh0) * W + ow0) * cs * (long long)sizeof(T);
+#pragma unroll
+            for (int k = 0; k < GP; ++k)
+                if (k < GP - 1 || full_wave) glds16(rel[k] != -1 ? base + rel[k] : zp, buf + (k * NW + wid) * 1024);
+        } else {
+#pragma unroll
+            for (int k = 0; k < GP; ++k) {
+                if (!(k < GP - 1 || full_wave)) continue;
+                const int q = (k * NW + wid) * 8 + (lane >> 3);
+                const int ls = (lane & 7) ^ ((q >> 1) & 7);
+                const int pr = q / PW, pc = q - pr * PW;
+                int ih = oh0 + pr - 1, iw = ow0 + pc - 1;
+                bool ok = q < PR;
+                int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
+                int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
+                ih = reflect ? rh : ih;
+                iw = reflect ? rw : iw;
+                ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+                iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+                const unsigned off = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
+                glds16(ok ? p.in + off : zp, buf + (k * NW + wid) * 1024);
+            }
+        }
+    };
+
+    const int lr = lane & 31, hi = lane >> 5;
+    int qb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m0 = wm * WM + i * 32;
+        qb[i] = (m0 / TW) * PW + (m0 % TW) + lr;
+    }
+    int foff[SS];
+#pragma unroll
+    for (int s = 0; s < SS; ++s) foff[s] = ((s * 2 + hi) ^ ((lr >> 1) & 7)) << 4;
+    const char* const wrow = wres + (wn * WN + lr) * 128;
+
+    Frag fa[2][SS][TM], fb[2][SS][TN];
+    auto read_step = [&](auto tapc, auto parc, const char* const patch) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int PARN = decltype(parc)::value;
+        constexpr int tq = (TAP / 3) * PW + (TAP % 3);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int qv = qb[i];
+            asm volatile("" : "+v"(qv));
+            const int q = qv + tq;
+            const char* const arow = patch + q * 128;
+            const int ax = (q >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < SS; ++s) fa[PARN][s][i] = *reinterpret_cast<const Frag*>(arow + (((s * 2 + hi) ^ ax) << 4));
+        }
+#pragma unroll
+        for (int s = 0; s < SS; ++s) fb[PARN][s][0] = *reinterpret_cast<const Frag*>(wrow + TAP * BST + foff[s]);
+    };
+
+    float* const out = reinterpret_cast<float*>(p.out);
+    const unsigned cs_out = (unsigned)p.cout_stride;
+    const int ccol = wn * WN + lr;
+    const float bv = (p.bias != nullptr && ccol < p.cout) ? p.bias[ccol] : 0.f;
+    const int vcol = wn * WN + 4 * (lane & 7);
+    const bool vfull = vcol + 4 <= p.cout;
+    const bool want_stats = p.stats != nullptr;
+
+    int vb = (int)blockIdx.x;
+    if (vb >= ntot) return;                                   // (the host launches min(tiles, CUs) workgroups)
+    issue_patch_vb(vb, pbase);
+    issue_patch_vb(vb + G, pbase + PATCH);
+    int cur = 0;
+    while (vb < ntot) {
+        int lin, slice, nt, mt, n_img, th, twi;
+        patch_tile_index(p, xcd_remap(vb, ntot), lin, slice, nt, mt, n_img, th, twi);
+        const int oh0 = th * TH, ow0 = twi * TW;
+        char* const patch = pbase + cur * PATCH;
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+        // only the patch issued LAST (tile i+1, or its dummy) may still be in flight: this tile's patch, the weights and the stores of
+        // the previous epilogue are older
+        if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP) : "memory");
+        else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, patch);
+        static_for<9>([&](auto tc) {
+            constexpr int TAP = decltype(tc)::value;
+            constexpr int PAR = TAP & 1;
+            static_for<NMMA>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int s = m / TM, i = m % TM;
+                Mma<T>::run(fa[PAR][s][i], fb[PAR][s][0], acc[i]);
+                if constexpr (m == 0 && TAP < 8) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_step(std::integral_constant<int, TAP + 1>{}, std::integral_constant<int, 1 - PAR>{}, patch);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // every wave has finished reading this patch: the buffer becomes epilogue scratch
+
+        float* const tw = reinterpret_cast<float*>(patch) + wid * 1024;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][r] + bv;
+                s1 += v;
+                s2 = __builtin_fmaf(v, v, s2);
+                tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lr] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float* const orow = out + ((unsigned)((n_img * H + oh0 + wm * (WM / TW) + i) * W + ow0)) * cs_out + (unsigned)vcol;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + ((lane >> 3) + 8 * k) * 32 + 4 * (lane & 7));
+                if (vfull) *reinterpret_cast<f32x4*>(orow + (unsigned)((lane >> 3) + 8 * k) * cs_out) = v4;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hi == 0) {
+                red[(wm * BN + ccol) * 2 + 0] = s1;
+                red[(wm * BN + ccol) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();                                     // every wave's transposition block is retired; the partials are complete
+        if (want_stats && tid < BN && tid < p.cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid) * 2 + 0]; t2 += red[(q * BN + tid) * 2 + 1]; }
+            float* const dst = p.stats + ((long long)mt * p.cout + tid) * 2;
+            dst[0] = t1;
+            dst[1] = t2;
+        }
+        // the patch of tile i+2 into the buffer this tile is done with (`red` is read above by wave 0 only and rewritten behind the
+        // next tile's two barriers)
+        issue_patch_vb(vb + 2 * G, patch);
+        vb += G;
+        cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <typename T>
 static inline int launch_one_typed(int cfg, const ConvKArgs& k, int cus, hipStream_t s) {
     if constexpr (std::is_same<T, bf16_t>::value) {
@@ -267,6 +502,24 @@ static inline int launch_one_typed(int cfg, const ConvKArgs& k, int cus, hipStre
             const int ntot = k.m_tiles * k.n_tiles;
             if (cus < 8) cus = 256;
             int g = ntot < cus ? ntot : cus;                   // one workgroup per CU (the LDS footprint allows no second one)
+            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), lds, s, k);
+            return check_launch();
+        }
+    }
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (cfg == 141) {
+            constexpr int TH = 8, TW = 32, BN = 64, NW = 8;
+            constexpr int NG = ((TH + 2) * (TW + 2) + 7) / 8;
+            const size_t lds = (size_t)9 * BN * 128 + (size_t)2 * NG * 1024 + (size_t)(4 * BN * 2 * 4);
+            void (*kern)(const ConvKArgs) = conv3x3_one_db_kernel<T, TH, TW, BN>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done = true;
+            }
+            const int ntot = k.m_tiles * k.n_tiles;
+            if (cus < 8) cus = 256;
+            int g = ntot < cus ? ntot : cus;
             hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), lds, s, k);
             return check_launch();
         }

@@ -354,17 +354,17 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               130: (8, 32, 64), 131: (8, 32, 64), 132: (8, 32, 64),
               # csrc/conv3x3_one_kernel.h (round 5): PERSISTENT, weights-resident tile for single-chunk layers with <= 64 output channels
               # (one workgroup per CU walks its tiles; no barrier / DMA / wait inside a tile's 9 steps).  Experiment until measured.
-              140: (8, 32, 64)}     # 130 / 131: one barrier per three steps (7 / 8 stages), 132: per two steps, 8 stages.   94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
+              140: (8, 32, 64), 141: (8, 32, 64)}     # (141: two patch buffers) 130 / 131: one barrier per three steps (7 / 8 stages), 132: per two steps, 8 stages.   94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
 # stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
 S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
 # ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
 T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 64)}
 # dense 7x7 / stride 1 / pad 3 convolutions on the single-phase kernel with a 7x7 window (csrc/conv3x3_pp3_kernel.h, KK = 7): id -> (TH, TW, BN).
-# STAGED FOR ROUND 5: built and dry-run tested, not yet run on a GPU -- offered to the tile search only with V2V_S7_PATCH=1
+# Round 5: validated on the GPU (tests/test_gpu_kernels.py::test_conv7x7_window_tiles), offered to the tile search unless V2V_S7_PATCH=0
 S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
-EXP_TILES = (97, 98, 99, 130, 131, 132, 140)
+EXP_TILES = (97, 98, 99, 130, 131, 132, 140, 141)
 if os.environ.get("V2V_EXP_TILES", "0") == "1":
     PAIR_TILES = PAIR_TILES + EXP_TILES
 
@@ -1219,9 +1219,10 @@ class Engine:
 
     def s7_eligible(self, d):
         """7x7-window tiles 120 / 121: dense bf16 7x7 / stride 1 / pad 3 Conv2d whose channel stride is a whole number of 128-byte chunks
-        (the stems on the pooled label encodings, edge2face's 45 -> 128 stem); opt-in until validated on a GPU."""
+        (the stems on the pooled label encodings, edge2face's 45 -> 128 stem).  Round 5: validated on three boxes (parity test, 1.1-1.7x on
+        the 64 / 128-channel stems: profiles/r05_v1_stem7_bench.txt) -- ON by default, V2V_S7_PATCH=0 takes them out of the search."""
         return (self.dtype == L.BF16 and not d.transposed and d.KH == 7 and d.KW == 7 and d.stride == 1 and d.pad == 3
-                and d.cin_stride % 64 == 0 and d.out_mode != L.OUT_NORM_ACT_NHWC and os.environ.get("V2V_S7_PATCH", "0") == "1")
+                and d.cin_stride % 64 == 0 and d.out_mode != L.OUT_NORM_ACT_NHWC and os.environ.get("V2V_S7_PATCH", "1") != "0")
 
     def s2_eligible(self, d):
         """conv3x3_s2_kernel: 3x3 / stride 2 / zero pad 1 Conv2d whose channel stride is a whole 128-byte chunk."""
