@@ -1018,6 +1018,43 @@ def test_batchnorm_training_mode_and_resblock(prec):
     assert_close(got, ref, tol, "stem+instancenorm")
 
 
+@pytest.mark.parametrize("act", ["none", "relu", "leaky"])
+@pytest.mark.parametrize("geom", [(64, 4099), (1024, 2048), (128, 70000)])
+def test_bn_apply_dense_fast_path_equals_general_path(geom, act):
+    """v2v_bn_apply, bf16 activations: the dense fast path (round 5: C % 8 == 0 and no channel padding -> linear 16-byte vectors, no
+    division, scale / shift in registers, 16-byte residual loads) against the general loop, which a padded channel stride selects:
+    the same values bit for bit, with zero, one and two residual operands; and against the fp32 expression in torch."""
+    import ctypes as C
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, check
+    Cc, P = geom
+    torch.manual_seed(Cc + P)
+    code = {"none": L.ACT_NONE, "relu": L.ACT_RELU, "leaky": L.ACT_LEAKY}[act]
+    raw = torch.randn(P, Cc, device=DEV)
+    ss = torch.cat([torch.randn(Cc, device=DEV) * 0.5 + 1.0, torch.randn(Cc, device=DEV), torch.zeros(2 * Cc, device=DEV)])
+    adds = [torch.randn(P, Cc, device=DEV).to(torch.bfloat16) for _ in range(2)]
+    cs_pad = Cc + 8
+    pad = lambda t: torch.cat([t, torch.zeros(P, 8, device=DEV, dtype=t.dtype)], 1).contiguous()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n_add in (0, 1, 2):
+        a0 = adds[0] if n_add >= 1 else None
+        a1 = adds[1] if n_add >= 2 else None
+        y_fast = torch.full((P, Cc), 7.0, device=DEV, dtype=torch.bfloat16)
+        check(lib.v2v_bn_apply(ptr(raw), Cc, ptr(ss), ptr(a0), ptr(a1), ptr(y_fast), P, Cc, Cc, code, 0.2, L.BF16, st), "bn_apply dense")
+        y_gen = torch.full((P, cs_pad), 7.0, device=DEV, dtype=torch.bfloat16)
+        check(lib.v2v_bn_apply(ptr(raw), Cc, ptr(ss), ptr(None if a0 is None else pad(a0)), ptr(None if a1 is None else pad(a1)), ptr(y_gen),
+                               P, Cc, cs_pad, code, 0.2, L.BF16, st), "bn_apply padded")
+        assert torch.equal(y_fast, y_gen[:, :Cc]), "dense fast path differs from the general loop (%s, %d residuals)" % (act, n_add)
+        assert int(y_gen[:, Cc:].float().abs().sum().item()) == 0
+        t = torch.addcmul(ss[Cc:2 * Cc], raw, ss[:Cc])                      # fma(raw, scale, shift)
+        t = t if act == "none" else torch.relu(t) if act == "relu" else torch.where(t > 0, t, t * 0.2)
+        for a_ in (a0, a1):
+            if a_ is not None:
+                t = t + a_.float()
+        assert_close(y_fast.float().cpu(), t.to(torch.bfloat16).float().cpu(), 8e-3, "bn_apply vs torch")
+
+
 def test_bn_running_stats_update():
     from vid2vid_amd import lib as L
     torch.manual_seed(4)
