@@ -174,3 +174,23 @@ PY
   done 2>&1 | tee gpurun_out/${TAG}_trainsplit.txt
   lap trainsplit
 fi
+if has final; then      # evidence for the committed line: in-graph duration (rocprofv3 kernel trace of the bench command) + PMC traffic of the dominant paired
+                        # tile, copied where bench.py looks, then the driver's command
+  DOM=${DOM:-90,1,2} WGS=256 NEEDLE=${NEEDLE:-conv3x3_pp3_kernelIDF16bLi8ELi32ELi64ELi5ELi0ELi4ELi1ELi2} bash scripts/gpu_r2.sh ${TAG} prof2
+  cp gpurun_out/${TAG}_in_graph.json profiles/${TAG}_in_graph.json; cp gpurun_out/${TAG}_traffic.json profiles/${TAG}_traffic.json
+  TB=$(date +%s)
+  timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default_line.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$? wall $(( $(date +%s) - TB )) s"
+  cp bench_full.json gpurun_out/${TAG}_bench_default_full.json 2>/dev/null
+  python - <<PY
+import json
+t = open("gpurun_out/${TAG}_bench_default_line.json").read()
+print("stdout bytes", len(t), "lines", t.count("\n"))
+j = json.loads(t[-10000:].strip().splitlines()[-1])
+print({k: v for k, v in j.items() if not isinstance(v, (dict, list))})
+print("roofline", j["roofline"]); print("cpu_baseline", j["cpu_baseline"]); print("leg_seconds", j.get("leg_seconds"))
+f = json.load(open("gpurun_out/${TAG}_bench_default_full.json"))
+print("hires per_kernel_ms", f["hires"]["roofline"]["per_kernel_ms"]); print("512x256 per_kernel_ms", f["roofline"]["per_kernel_ms"])
+PY
+  tail -3 gpurun_out/${TAG}_bench_default.err | cut -c1-300
+  lap final
+fi
