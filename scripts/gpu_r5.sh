@@ -194,3 +194,16 @@ PY
   tail -3 gpurun_out/${TAG}_bench_default.err | cut -c1-300
   lap final
 fi
+if has ab2; then    # round-4 main build + round-4 tile cache vs the tree's build + the tree's cache, alternating on this box, both resolutions
+  for i in 1 2 3; do
+    V2V_LIB_PATH=$R/vid2vid_amd/libv2v_hip_r4main.so V2V_TUNE_CACHE=$R/scripts/ab/tune_cache_r4.json V2V_S7_PATCH=0 timeout 400 python bench.py $LEAN 2>gpurun_out/${TAG}_ab2.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('round-4 build run $i: 512x256', j['value'], 'frames/s | 2048x1024', j.get('hires_value'), '| dominant eager', j['roofline'].get('eager_us'), 'live', j['roofline'].get('in_graph_live_us'))"
+    timeout 400 python bench.py $LEAN 2>gpurun_out/${TAG}_ab2.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tree build    run $i: 512x256', j['value'], 'frames/s | 2048x1024', j.get('hires_value'), '| dominant eager', j['roofline'].get('eager_us'), 'live', j['roofline'].get('in_graph_live_us'))"
+  done 2>&1 | tee gpurun_out/${TAG}_ab2.txt
+  lap ab2
+fi
+if has bntest; then
+  timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "bn_apply or batchnorm or splitk_on_a_tiny" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300 | tail -12
+  lap bntest
+fi

@@ -1078,8 +1078,9 @@ def test_bn_apply_dense_fast_path_equals_general_path(geom, act):
         y_fast = torch.full((P, Cc), 7.0, device=DEV, dtype=torch.bfloat16)
         check(lib.v2v_bn_apply(ptr(raw), Cc, ptr(ss), ptr(a0), ptr(a1), ptr(y_fast), P, Cc, Cc, code, 0.2, L.BF16, st), "bn_apply dense")
         y_gen = torch.full((P, cs_pad), 7.0, device=DEV, dtype=torch.bfloat16)
-        check(lib.v2v_bn_apply(ptr(raw), Cc, ptr(ss), ptr(None if a0 is None else pad(a0)), ptr(None if a1 is None else pad(a1)), ptr(y_gen),
-                               P, Cc, cs_pad, code, 0.2, L.BF16, st), "bn_apply padded")
+        p0 = None if a0 is None else pad(a0)                  # (named: the launch is asynchronous, a temporary would be freed -- and its
+        p1 = None if a1 is None else pad(a1)                  #  memory handed to the next one -- before the kernel reads it)
+        check(lib.v2v_bn_apply(ptr(raw), Cc, ptr(ss), ptr(p0), ptr(p1), ptr(y_gen), P, Cc, cs_pad, code, 0.2, L.BF16, st), "bn_apply padded")
         assert torch.equal(y_fast, y_gen[:, :Cc]), "dense fast path differs from the general loop (%s, %d residuals)" % (act, n_add)
         assert int(y_gen[:, Cc:].float().abs().sum().item()) == 0
         t = torch.addcmul(ss[Cc:2 * Cc], raw, ss[:Cc])                      # fma(raw, scale, shift)

@@ -68,11 +68,19 @@ struct ConvKArgs {
 };
 
 // phase stamp k of this workgroup (thread 0): 0 entry, 1 prologue set up (first loads issued), 2 first tile landed, 3 main loop done,
-// 4 outputs stored, 5 statistics row published, 6 exit.  COMPILED OUT of the product build (V2V_STAMP_MASK = 0): with the stamps
-// compiled in -- even with a NULL buffer, i.e. never executed -- most kernels sit at the 106-SGPR ceiling and the fp32 golden tests
-// turn flaky (profiles/r04_a4_stamps_flaky.txt: 1-2 of 3 tests fail per run with the stamps in, 0 of 18 without), so the
-// instrumented library is a PROFILING build only:  touch conv_igemm_kernel.h && make -C vid2vid_amd/csrc EXTRA=-DV2V_STAMP_MASK=0x7f,
-// run scripts/kernel_phases.py, rebuild without EXTRA.  Its timings are what it is for; its results are not to be trusted.
+// 4 outputs stored, 5 statistics row published, 6 exit.  COMPILED OUT of the product build (V2V_STAMP_MASK = 0).  The instrumented
+// library is a PROFILING build only:  touch conv_igemm_kernel.h && make -C vid2vid_amd/csrc EXTRA=-DV2V_STAMP_MASK=0x7f, run
+// scripts/kernel_phases.py, rebuild without EXTRA.  Its timings are what it is for; its RESULTS ARE NOT TO BE TRUSTED:
+//   round 4 saw its fp32 golden tests fail "intermittently" (profiles/r04_a4_stamps_flaky.txt) and suspected a latent race that the
+//   product build only hides.  Round 5 took it apart (profiles/r05_v2_stampdiag.txt, r05_v3_stamp_bisect.txt):
+//   (1) every deterministic kernel test passes on the stamp build; (2) a failing run's tile selections (V2V_TUNE_CACHE) replayed
+//   on the stamp build fail EVERY time (8 of 8), the selections of a passing run pass every time -- the run-to-run variation is the
+//   timing-based tile search, not a race; (3) the same selections pass on the product build 8 of 8; (4) delta debugging the 49
+//   entries in which a failing and a passing selection differ leaves ONE: the 32 -> 32 3x3 layer at 8x16 pixels, fp32, on tile 10
+//   (64 x 64, no prefetch wave) with split-K 2 instead of tile 9 -- one instantiation x one split of the stamp build computes that layer
+//   wrong, deterministically (no register or scalar spills in it: llvm-readelf --notes; the product build's copy of the same
+//   configuration is pinned by tests/test_gpu_kernels.py::test_conv2d_splitk_on_a_tiny_layer_every_small_tile).  Why the stamp
+//   build's copy differs was not pursued further: it is code that never ships.
 #ifndef V2V_STAMP_MASK
 #define V2V_STAMP_MASK 0
 #endif
