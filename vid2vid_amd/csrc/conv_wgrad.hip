@@ -568,12 +568,12 @@ static int wgrad_plan(const v2v_wgrad_desc* d, int* m_tiles, int* n_tiles, int* 
     *n_tiles = (int)ceil_div(ncols, WG_BN);
     const long long tiles = (long long)*m_tiles * *n_tiles;
     static const int target = [] { const char* e = getenv("V2V_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-    // fp32 (the parity path, not a throughput path): 8x more K splits.  Each split accumulates its pixels in ONE chain of fp32 MFMA
-    // accumulations; the chain length is what the rounding error of a weight gradient grows with (a CPU GEMM blocks K by a few hundred).
-    // Measured on the 512x256 / 3-frame chunk against the CPU oracle (profiles/r05_v3_trainsplit.txt): relative L2 distance of the
-    // whole G gradient 3.5e-3 -> 2.7e-3, model_final_flow's 2.7e-3 -> 2.0e-3, the stride-2 towers' 9.1e-3 -> 7.5e-3.
-    const long long tgt = d->dtype == V2V_F32 ? 8ll * target : (long long)target;
-    long long s = ceil_div(tgt, tiles);                  // bf16: ~4 workgroups per CU (512 measured slower: profiles/r01 q1 vs q2)
+    // (Round 5 tried 8x more K splits for the fp32 parity path -- shorter fp32 accumulation chains per split: one pair of runs moved the
+    // G gradient's L2 distance to the CPU oracle from 3.5e-3 to 2.7e-3 (profiles/r05_v3_trainsplit.txt), the default bench line with the
+    // change built in did not reproduce it (3.31e-3 -> 3.32e-3, profiles/r05_v1 / r05_v4_bench_default_full.json): the run-to-run spread
+    // of that measure is as large as the effect, because the timing-based tile search changes the forward's fp32 summation orders.
+    // Inconclusive: not adopted.  V2V_WGRAD_WGS=8192 reproduces the experiment.)
+    long long s = ceil_div(target, tiles);               // ~4 workgroups per CU (512 measured slower: profiles/r01 q1 vs q2)
     // channels-last gradient with q_stride == cols: an unsplit launch writes its tiles straight into .grad (no slab, no
     // reduce pass) -- worth more than the extra workgroups of a split once the tiles alone cover the chip twice
     if (((d->accumulate >> 1) & 1) && d->q_stride == d->cols && tiles >= 1024) s = 1;
