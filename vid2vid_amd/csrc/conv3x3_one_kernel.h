@@ -28,6 +28,17 @@
 
 namespace v2v {
 
+// Start-up stagger (experiment, V2V_ONE_STAGGER=<units>[,<groups>]; units of ~0.5 us, 0 = off): persistent workgroups start together,
+// do identical work and therefore stay in lockstep -- every CU loads, then every CU computes, then every CU stores, and the HBM and the
+// matrix pipes are never busy at the same time.  Group g = (blockIdx.x >> 3) % groups waits g x units once, after its first loads are
+// in flight (bits 16.. of ConvKArgs::ablate carry units | groups << 8; the host packs them in launch_one_typed).
+__device__ __forceinline__ void one_stagger(const ConvKArgs& p) {
+    const int units = (p.ablate >> 16) & 0xff, groups = (p.ablate >> 24) & 0x7f;
+    if (units == 0 || groups < 2) return;
+    const int g = ((int)blockIdx.x >> 3) % groups;
+    for (int i = 0; i < g * units; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 template <typename T, int TH, int TW, int BN>
 __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
         patch_tile_index(p, xcd_remap(vb, ntot), lin, slice, nt, mt, n_img, th, twi);
         issue_patch_of(n_img, th * TH, twi * TW);
     }
+    one_stagger(p);
 
     while (vb < ntot) {
         const int oh0 = th * TH, ow0 = twi * TW;
@@ -237,7 +249,8 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
                 red[(wm * BN + ccol) * 2 + 0] = s1;
                 red[(wm * BN + ccol) * 2 + 1] = s2;
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (NOT __syncthreads(): its fence is a vmcnt(0) -- it would drain the next
+            __builtin_amdgcn_s_barrier();                        //  patch's LDS-DMA and this tile's stores every tile)
             if (tid < BN && tid < p.cout) {
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -261,7 +274,14 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
 //   pieces per patch; the stores of tile i's epilogue are older and retire with the wait (no store count enters the immediate, so a
 //   channel tile whose stores are branched around cannot break it).  A workgroup without a tile i+2 issues the same number of
 //   dummy pieces (zero page) so that the count holds in the tail.
-template <typename T, int TH, int TW, int BN>
+// ASYNC (tile 142): the tile's output leaves the accumulators with plain 4-byte stores (a lane's 32 channels x 4 B = one 128-byte line per
+// row and half-wave) instead of passing the wave's LDS transposition block -- the patch buffer is then free the moment the steps end,
+// the patch of tile i+2 is issued BEFORE the epilogue's stores, and the counted wait at the top of tile i+1 leaves those stores in flight
+// together with that patch: `vmcnt(n + 32)` (32 stores per wave and tile, unconditional: the host admits exactly 64 output channels).  A
+// wave then never waits for its own stores; with tile 141 it did (they are older than the prefetch it must not wait for), which is why
+// the second patch buffer alone bought nothing: load, steps and store phases stayed in series inside every workgroup, and because all
+// workgroups run in lockstep the HBM and the matrix pipes were never busy at the same time.
+template <typename T, int TH, int TW, int BN, bool ASYNC = false>
 __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
@@ -403,7 +423,9 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
     if (vb >= ntot) return;                                   // (the host launches min(tiles, CUs) workgroups)
     issue_patch_vb(vb, pbase);
     issue_patch_vb(vb + G, pbase + PATCH);
+    one_stagger(p);
     int cur = 0;
+    bool first = true;
     while (vb < ntot) {
         int lin, slice, nt, mt, n_img, th, twi;
         patch_tile_index(p, xcd_remap(vb, ntot), lin, slice, nt, mt, n_img, th, twi);
@@ -417,8 +439,14 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
 
         // only the patch issued LAST (tile i+1, or its dummy) may still be in flight: this tile's patch, the weights and the stores of
         // the previous epilogue are older
-        if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP) : "memory");
-        else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1) : "memory");
+        if (ASYNC && !first) {                               // ... and, ASYNC, the 32 stores of the previous tile's epilogue, issued behind that patch
+            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP + 32) : "memory");
+            else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1 + 32) : "memory");
+        } else {
+            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP) : "memory");
+            else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1) : "memory");
+        }
+        first = false;
         __builtin_amdgcn_s_barrier();
         read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, patch);
         static_for<9>([&](auto tc) {
@@ -438,8 +466,22 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // every wave has finished reading this patch: the buffer becomes epilogue scratch
 
-        float* const tw = reinterpret_cast<float*>(patch) + wid * 1024;
         float s1 = 0.f, s2 = 0.f;
+        if constexpr (ASYNC) {
+            issue_patch_vb(vb + 2 * G, patch);               // the buffer is free: nothing of the epilogue touches it
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float* const orow = out + ((unsigned)((n_img * H + oh0 + wm * (WM / TW) + i) * W + ow0)) * cs_out + (unsigned)ccol;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][r] + bv;
+                    s1 += v;
+                    s2 = __builtin_fmaf(v, v, s2);
+                    orow[(unsigned)((r & 3) + 8 * (r >> 2) + 4 * hi) * cs_out] = v;      // 32 lanes = 32 consecutive channels = one 128-byte line
+                }
+            }
+        } else {
+        float* const tw = reinterpret_cast<float*>(patch) + wid * 1024;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -460,6 +502,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        }
         if (want_stats) {
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
@@ -468,7 +511,8 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
                 red[(wm * BN + ccol) * 2 + 1] = s2;
             }
         }
-        __syncthreads();                                     // every wave's transposition block is retired; the partials are complete
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave's transposition block is retired; the partials are complete
+        __builtin_amdgcn_s_barrier();                        // (NOT __syncthreads(): its fence is a vmcnt(0) -- prefetch and stores must stay in flight)
         if (want_stats && tid < BN && tid < p.cout) {
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -479,7 +523,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
         }
         // the patch of tile i+2 into the buffer this tile is done with (`red` is read above by wave 0 only and rewritten behind the
         // next tile's two barriers)
-        issue_patch_vb(vb + 2 * G, patch);
+        if constexpr (!ASYNC) issue_patch_vb(vb + 2 * G, patch);
         vb += G;
         cur ^= 1;
     }
@@ -487,7 +531,16 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
 }
 
 template <typename T>
-static inline int launch_one_typed(int cfg, const ConvKArgs& k, int cus, hipStream_t s) {
+static inline int launch_one_typed(int cfg, const ConvKArgs& k_in, int cus, hipStream_t s) {
+    static const int stag = [] {                              // V2V_ONE_STAGGER=<units>[,<groups>] (experiment; default off)
+        const char* e = getenv("V2V_ONE_STAGGER");
+        if (!e) return 0;
+        int u = 0, g = 2;
+        sscanf(e, "%d,%d", &u, &g);
+        return (u & 0xff) | ((g & 0x7f) << 8);
+    }();
+    ConvKArgs k = k_in;
+    k.ablate = (k.ablate & 0xffff) | (stag << 16);
     if constexpr (std::is_same<T, bf16_t>::value) {
         if (cfg == 140) {
             constexpr int TH = 8, TW = 32, BN = 64, NW = 8;
@@ -507,15 +560,15 @@ static inline int launch_one_typed(int cfg, const ConvKArgs& k, int cus, hipStre
         }
     }
     if constexpr (std::is_same<T, bf16_t>::value) {
-        if (cfg == 141) {
+        if (cfg == 141 || cfg == 142) {
             constexpr int TH = 8, TW = 32, BN = 64, NW = 8;
             constexpr int NG = ((TH + 2) * (TW + 2) + 7) / 8;
             const size_t lds = (size_t)9 * BN * 128 + (size_t)2 * NG * 1024 + (size_t)(4 * BN * 2 * 4);
-            void (*kern)(const ConvKArgs) = conv3x3_one_db_kernel<T, TH, TW, BN>;
-            static bool attr_done = false;
-            if (!attr_done) {
+            void (*kern)(const ConvKArgs) = cfg == 142 ? conv3x3_one_db_kernel<T, TH, TW, BN, true> : conv3x3_one_db_kernel<T, TH, TW, BN, false>;
+            static bool attr_done[2] = {false, false};
+            if (!attr_done[cfg - 141]) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_done = true;
+                attr_done[cfg - 141] = true;
             }
             const int ntot = k.m_tiles * k.n_tiles;
             if (cus < 8) cus = 256;
