@@ -214,3 +214,13 @@ if has stagger; then   # persistent single-chunk kernels: start-up stagger of wo
   done | tee gpurun_out/${TAG}_stagger.txt
   lap stagger
 fi
+if has onepmc; then    # where do the persistent single-chunk kernels' wave cycles go?  (one counter group per pass)
+  cd /tmp
+  for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+    tag=$(echo $pass | cut -d' ' -f1)
+    ONE_TILES=94,140,141 timeout 200 rocprofv3 --kernel-trace --pmc $pass -d /tmp/onepmc_$tag -o pmc -- python $R/scripts/one_bench.py > $R/gpurun_out/${TAG}_onepmc_$tag.log 2>&1; echo "onepmc $tag rc=$?"
+    python $R/scripts/pmc_summary.py $(find /tmp/onepmc_$tag -name "*.db" | head -1) "# ONE_TILES=94,140,141 rocprofv3 --kernel-trace --pmc $pass -- python scripts/one_bench.py (four layer shapes per tile: per-dispatch averages mix them; the 1024x512 layer dominates)" 2>>$R/gpurun_out/${TAG}_onepmc_$tag.log | grep -E "^#|conv3x3_one|ELb1EEEvNS_9ConvKArgsE |Li3ELi0ELi4ELi2ELi1ELb1E" | cut -c1-40,70-200
+  done 2>&1 | tee $R/gpurun_out/${TAG}_onepmc.txt
+  cd $R
+  lap onepmc
+fi
