@@ -210,7 +210,7 @@ fi
 if has stagger; then   # persistent single-chunk kernels: start-up stagger of workgroup groups (V2V_ONE_STAGGER=<units of ~0.5 us>,<groups>) -- do lockstep phases
                        # (every CU loads, then computes, then stores) explain the 70 us of tile 140 against a 32 us HBM bound?
   for st in 0 "4,2" "8,2" "12,2" "16,2" "4,4" "8,4" "3,8" "6,8"; do
-    echo "V2V_ONE_STAGGER=$st"; V2V_ONE_STAGGER=$st ONE_TILES=94,140,141,142 timeout 120 python scripts/one_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
+    echo "V2V_ONE_STAGGER=$st"; V2V_ONE_STAGGER=$st ONE_TILES=94,140,141,142,143 timeout 120 python scripts/one_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
   done | tee gpurun_out/${TAG}_stagger.txt
   lap stagger
 fi

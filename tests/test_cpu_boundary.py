@@ -458,9 +458,9 @@ def test_round5_experiment_tiles_are_reachable_through_the_engine():
         res = [eng.pack(torch.randn(1, cout, 32, 64)) for _ in range(2)]
         conv64 = nn.Conv2d(64, 64, 3)
         x64 = eng.pack(torch.randn(1, 64, 32, 64))
-        for t in EXP_TILES + (140,):
+        for t in EXP_TILES + (140, 141):
             assert t in PATCH_CFGS and is_patch_tile(t) and tile_korder(t) == 1, t
-            if t in (140, 141, 142):                                  # persistent single-chunk tile: 64 input channels, <= 64 output channels, single launches
+            if t in (140, 141, 142, 143):                                  # persistent single-chunk tile: 64 input channels, <= 64 output channels, single launches
                 eng.tile_override[(64, 64, 3, 1, 0)] = (t, 1, 0)
                 eng.conv(x64, conv64, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
                 assert eng.conv_log[-1]["tile"] == t

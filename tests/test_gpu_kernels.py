@@ -451,7 +451,7 @@ PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33
               # one barrier per three steps (7 / 8 weight stages), per two steps with 8 stages
               (130, 1), (131, 1), (132, 1), (130, 2), (131, 3),
               # persistent, weights-resident single-chunk tile (csrc/conv3x3_one_kernel.h): bf16, 64 input channels, <= 64 output channels
-              (140, 1), (141, 1), (142, 1),
+              (140, 1), (141, 1), (142, 1), (143, 1),
               # single-chunk tiles (one patch buffer, three weight stages): bf16 layers with exactly 64 input channels
               (94, 1), (95, 1), (96, 1)]
 
@@ -486,7 +486,7 @@ def test_conv3x3_patch_kernel(case, prec):
             continue
         if tile in (94, 95, 96) and (ncc != 1 or prec != "bf16"):
             continue
-        if tile in (140, 141, 142):                            # their own test below (one output mode, full tiles, no in-kernel finalize)
+        if tile in (140, 141, 142, 143):                            # their own test below (one output mode, full tiles, no in-kernel finalize)
             continue
         k = it % 2
         eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, S, 12 if (tile <= 37 and it % 3 == 0) else 0)
@@ -535,7 +535,7 @@ def test_conv3x3_persistent_single_chunk_tile(case):
     for x, ref in zip(xs, refs):
         xa = eng.pack(x.to(DEV))
         got = {}
-        for tile in (94, 140, 141) + ((142,) if cout == 64 else ()):
+        for tile in (94, 140, 141) + ((142, 143) if cout == 64 else ()):
             eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, 1, 0)
             raw, rows, (n_, OH, OW) = eng.conv(xa, conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
             assert eng.conv_log[-1]["tile"] == tile
@@ -543,7 +543,7 @@ def test_conv3x3_persistent_single_chunk_tile(case):
             st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].clone()
             got[tile] = (raw[:n_ * OH * OW * cs_raw].clone(), st, rows)
         cs_raw = (cout + 3) // 4 * 4
-        for t in (140, 141) + ((142,) if cout == 64 else ()):      # 141: two patch buffers; 142: + stores from the accumulators, left in flight
+        for t in (140, 141) + ((142, 143) if cout == 64 else ()):      # 141: two patch buffers; 142: + stores from the accumulators, left in flight
             assert got[t][2] == got[94][2]
             assert torch.equal(got[t][0], got[94][0]), "raw output of tile %d differs from tile 94" % t
             assert torch.equal(got[t][1], got[94][1]), "statistics rows of tile %d differ from tile 94" % t

@@ -274,14 +274,18 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
 //   pieces per patch; the stores of tile i's epilogue are older and retire with the wait (no store count enters the immediate, so a
 //   channel tile whose stores are branched around cannot break it).  A workgroup without a tile i+2 issues the same number of
 //   dummy pieces (zero page) so that the count holds in the tail.
-// ASYNC (tile 142): the tile's output leaves the accumulators with plain 4-byte stores (a lane's 32 channels x 4 B = one 128-byte line per
+// ASYNC 2 (tile 143): tile 141's order and 16-byte stores, but the counted wait at the top of tile i+1 is `vmcnt(n + 8)`: this tile's patch is
+// OLDER than the 8 stores of tile i's epilogue and the patch of tile i+2 behind them, so both may stay in flight -- a wave no longer
+// waits for its own stores right after issuing them (tile 141's `vmcnt(n)` did: 39 % of its wave cycles were parked,
+// profiles/r05_v7_onepmc.txt).  The stores are unconditional (the immediate counts them): exactly 64 output channels (host check).
+// ASYNC 1 (tile 142): the tile's output leaves the accumulators with plain 4-byte stores (a lane's 32 channels x 4 B = one 128-byte line per
 // row and half-wave) instead of passing the wave's LDS transposition block -- the patch buffer is then free the moment the steps end,
 // the patch of tile i+2 is issued BEFORE the epilogue's stores, and the counted wait at the top of tile i+1 leaves those stores in flight
 // together with that patch: `vmcnt(n + 32)` (32 stores per wave and tile, unconditional: the host admits exactly 64 output channels).  A
 // wave then never waits for its own stores; with tile 141 it did (they are older than the prefetch it must not wait for), which is why
 // the second patch buffer alone bought nothing: load, steps and store phases stayed in series inside every workgroup, and because all
 // workgroups run in lockstep the HBM and the matrix pipes were never busy at the same time.
-template <typename T, int TH, int TW, int BN, bool ASYNC = false>
+template <typename T, int TH, int TW, int BN, int ASYNC = 0>
 __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
     constexpr int BM = TH * TW;
@@ -439,9 +443,11 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
 
         // only the patch issued LAST (tile i+1, or its dummy) may still be in flight: this tile's patch, the weights and the stores of
         // the previous epilogue are older
-        if (ASYNC && !first) {                               // ... and, ASYNC, the 32 stores of the previous tile's epilogue, issued behind that patch
-            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP + 32) : "memory");
-            else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1 + 32) : "memory");
+        constexpr int NST = ASYNC == 1 ? 32 : 8;             // stores per wave and tile: 4-byte (ASYNC 1) or 16-byte through the LDS block
+        if (ASYNC != 0 && !first) {                          // ... and, ASYNC, the stores of the previous tile's epilogue (ASYNC 1: issued behind
+            // that patch; ASYNC 2 (tile 143): in front of it -- either way they are YOUNGER than this tile's patch, so they may stay in flight)
+            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP + NST) : "memory");
+            else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1 + NST) : "memory");
         } else {
             if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP) : "memory");
             else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1) : "memory");
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
         __builtin_amdgcn_s_barrier();                        // every wave has finished reading this patch: the buffer becomes epilogue scratch
 
         float s1 = 0.f, s2 = 0.f;
-        if constexpr (ASYNC) {
+        if constexpr (ASYNC == 1) {
             issue_patch_vb(vb + 2 * G, patch);               // the buffer is free: nothing of the epilogue touches it
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + ((lane >> 3) + 8 * k) * 32 + 4 * (lane & 7));
-                if (vfull) *reinterpret_cast<f32x4*>(orow + (unsigned)((lane >> 3) + 8 * k) * cs_out) = v4;
+                if (ASYNC == 2 || vfull) *reinterpret_cast<f32x4*>(orow + (unsigned)((lane >> 3) + 8 * k) * cs_out) = v4;   // ASYNC 2: exactly 64 channels (host check): unconditional, the vmcnt immediate counts them
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
         }
         // the patch of tile i+2 into the buffer this tile is done with (`red` is read above by wave 0 only and rewritten behind the
         // next tile's two barriers)
-        if constexpr (!ASYNC) issue_patch_vb(vb + 2 * G, patch);
+        if constexpr (ASYNC != 1) issue_patch_vb(vb + 2 * G, patch);
         vb += G;
         cur ^= 1;
     }
@@ -560,12 +566,13 @@ static inline int launch_one_typed(int cfg, const ConvKArgs& k_in, int cus, hipS
         }
     }
     if constexpr (std::is_same<T, bf16_t>::value) {
-        if (cfg == 141 || cfg == 142) {
+        if (cfg >= 141 && cfg <= 143) {
             constexpr int TH = 8, TW = 32, BN = 64, NW = 8;
             constexpr int NG = ((TH + 2) * (TW + 2) + 7) / 8;
             const size_t lds = (size_t)9 * BN * 128 + (size_t)2 * NG * 1024 + (size_t)(4 * BN * 2 * 4);
-            void (*kern)(const ConvKArgs) = cfg == 142 ? conv3x3_one_db_kernel<T, TH, TW, BN, true> : conv3x3_one_db_kernel<T, TH, TW, BN, false>;
-            static bool attr_done[2] = {false, false};
+            void (*kern)(const ConvKArgs) = cfg == 142 ? conv3x3_one_db_kernel<T, TH, TW, BN, 1> : cfg == 143 ? conv3x3_one_db_kernel<T, TH, TW, BN, 2>
+                                                                                                   : conv3x3_one_db_kernel<T, TH, TW, BN, 0>;
+            static bool attr_done[3] = {false, false, false};
             if (!attr_done[cfg - 141]) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_done[cfg - 141] = true;

@@ -505,7 +505,7 @@ static const PatchCfg kPp3Cfgs[] = {
     {97, 8, 32, 64}, {98, 8, 32, 64}, {99, 8, 32, 64},     // round-5 experiments on tile 90's geometry (K pairs): 97 one barrier per two steps
                                            // (6 stages), 98 = 90 with 6 stages (the ring one deeper), 99 = 97 with 7 stages and static priority
     {130, 8, 32, 64}, {131, 8, 32, 64}, {132, 8, 32, 64},  // 130 / 131: one barrier per THREE steps, 7 / 8 stages; 132: per two steps, 8 stages
-    {140, 8, 32, 64}, {141, 8, 32, 64}, {142, 8, 32, 64},    // conv3x3_one_kernel.h: persistent, weights-resident single-chunk tile (geometry only; launched by launch_one_typed)
+    {140, 8, 32, 64}, {141, 8, 32, 64}, {142, 8, 32, 64}, {143, 8, 32, 64},    // conv3x3_one_kernel.h: persistent, weights-resident single-chunk tile (geometry only; launched by launch_one_typed)
     {96, 4, 32, 64},                       // single-chunk layers, FOUR waves (2 x 2, 64 x 32 wave tiles), 28 + 24 = 52 KiB, 167 + 32 registers: the
                                            // tile that really puts two workgroups on a CU (staged for round 5; 94 / 95 never did: DESIGN 3.6 item 15)
     {120, 4, 32, 64}, {121, 4, 32, 128},   // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk

@@ -667,14 +667,14 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
             set_error("conv: patch tile config %d needs a 3x3/s1/p1 Conv2d, cin_stride %% %d == 0 and korder-1 weights",
                       op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
         }
-        if ((op->cfg >= 140 && op->cfg <= 142) && ((op->cfg == 142 && d->cout != pc->BN) || d->cout > pc->BN || (d->cout & 3) || (d->cout_stride & 3) || ((unsigned long long)d->out & 15ull) ||
+        if ((op->cfg >= 140 && op->cfg <= 143) && ((op->cfg >= 142 && d->cout != pc->BN) || d->cout > pc->BN || (d->cout & 3) || (d->cout_stride & 3) || ((unsigned long long)d->out & 15ull) ||
                                d->out_mode != V2V_OUT_RAW_F32_NHWC || d->fin_counter != nullptr || d->OH % pc->TH != 0 || d->OW % pc->TW != 0)) {
             // conv3x3_one_kernel.h: ONE output mode (raw fp32 NHWC + statistics rows, finalize in its own launch), full tiles only
             set_error("conv: tile configs 140 - 142 (persistent, weights resident) need cout <= %d (142: exactly) and %% 4 == 0, raw fp32 NHWC output (16-byte aligned rows), "
                       "no in-kernel finalize, OH %% %d == 0 and OW %% %d == 0", pc->BN, pc->TH, pc->TW);
             return V2V_EINVAL;
         }
-        if ((op->cfg == 94 || op->cfg == 95 || op->cfg == 96 || (op->cfg >= 140 && op->cfg <= 142)) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
+        if ((op->cfg == 94 || op->cfg == 95 || op->cfg == 96 || (op->cfg >= 140 && op->cfg <= 143)) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
                                                  d->out_mode == V2V_OUT_NORM_ACT_NHWC)) {
             set_error("conv: tile config %d is a single-chunk tile: bf16, cin_stride exactly %d, no split-K, no fused norm", op->cfg, bke_of(d->dtype));
             return V2V_EINVAL;

@@ -354,8 +354,10 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               130: (8, 32, 64), 131: (8, 32, 64), 132: (8, 32, 64),
               # csrc/conv3x3_one_kernel.h (round 5): PERSISTENT, weights-resident tile for single-chunk layers with <= 64 output channels
               # (one workgroup per CU walks its tiles; no barrier / DMA / wait inside a tile's 9 steps).  140: bit-identical to tile 94 and
-              # 18-20 % faster (profiles/r05_v2_one_bench.txt, r05_v3_one_bench.txt); 141 (two patch buffers) measured no better: experiment.
-              140: (8, 32, 64), 141: (8, 32, 64), 142: (8, 32, 64)}     # (141: two patch buffers; 142: + stores straight from the accumulators, left in flight) 130 / 131: one barrier per three steps (7 / 8 stages), 132: per two steps, 8 stages.   94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
+              # 18-20 % faster (profiles/r05_v2_one_bench.txt, r05_v3_one_bench.txt); 141 (two patch buffers): another 5 % on the 2048-tile
+              # layer, 5-7 % slower on the small ones (profiles/r05_v6_stagger.txt) -- both are offered, the search decides per shape;
+              # 142 (stores from the accumulators, left in flight) is slower: experiment.
+              140: (8, 32, 64), 141: (8, 32, 64), 142: (8, 32, 64), 143: (8, 32, 64)}     # (141: two patch buffers; 142: + stores straight from the accumulators, left in flight) 130 / 131: one barrier per three steps (7 / 8 stages), 132: per two steps, 8 stages.   94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
 # stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
 S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
 # ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
@@ -365,7 +367,7 @@ T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 6
 S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
-EXP_TILES = (97, 98, 99, 130, 131, 132, 141, 142)          # (140: validated and faster -- a regular tile since visit r05_v3)
+EXP_TILES = (97, 98, 99, 130, 131, 132, 142, 143)               # (140 / 141: validated and faster -- regular tiles since visits r05_v3 / r05_v6)
 if os.environ.get("V2V_EXP_TILES", "0") == "1":
     PAIR_TILES = PAIR_TILES + EXP_TILES
 
