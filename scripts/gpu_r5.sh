@@ -207,6 +207,20 @@ if has bntest; then
   timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "bn_apply or batchnorm or splitk_on_a_tiny" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300 | tail -12
   lap bntest
 fi
+if has onefin; then     # persistent tiles: one statistics row per workgroup (no bn_partial_reduce) + finalize in the launch (V2V_ONE_FIN=0: separate bn_finalize), alternating
+  for i in 1 2; do
+    for f in 0 1; do
+      V2V_ONE_FIN=$f timeout 400 python bench.py $LEAN 2>gpurun_out/${TAG}_onefin.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('V2V_ONE_FIN=$f run $i: 512x256', j['value'], 'frames/s | 2048x1024', j.get('hires_value'), 'frames/s')"
+    done
+  done 2>&1 | tee gpurun_out/${TAG}_onefin.txt
+  python - <<PY
+import json
+f = json.load(open("bench_full.json"))
+print("hires per_kernel_ms", f["hires"]["roofline"]["per_kernel_ms"])
+PY
+  lap onefin
+fi
 if has stagger; then   # persistent single-chunk kernels: start-up stagger of workgroup groups (V2V_ONE_STAGGER=<units of ~0.5 us>,<groups>) -- do lockstep phases
                        # (every CU loads, then computes, then stores) explain the 70 us of tile 140 against a 32 us HBM bound?
   for st in 0 "4,2" "8,2" "12,2" "16,2" "4,4" "8,4" "3,8" "6,8"; do

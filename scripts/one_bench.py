@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn as nn
 from vid2vid_amd import lib as L
-from vid2vid_amd.engine import Engine
+from vid2vid_amd.engine import Engine, _ptr, _stream
 
 eng = Engine("cuda:0", L.BF16)
 thrash = torch.empty(96 << 20, dtype=torch.float32, device="cuda:0")
@@ -50,3 +50,28 @@ with torch.no_grad():
             out.append("t%d: %6.1f us (d %.1e)" % (cfg[0], us, d))
         gf = 2.0 * H * W * cin * cout * 9 / 1e9
         print("%-28s %6.1f GF | %s" % (name, gf, "  ".join(out)), flush=True)
+        # conv + statistics finalize as the frame chains them: separate launches (bn_partial_reduce + bn_finalize above 512 rows) for the
+        # one-row-per-tile kernels, inside the launch for the persistent tiles (one row per workgroup, last workgroup finalizes)
+        norm = nn.BatchNorm2d(cout).to("cuda:0")
+        ss = torch.zeros(4 * cout, device="cuda:0")
+        out = []
+        for cfg in [c for c in TILES if c[0] in (94, 140, 141, 143)]:
+            if cout > 64:
+                break
+            eng.tile_override[(cin, cout, 3, 1, 0)] = cfg
+            def chain():
+                raw, rows, shp = eng.conv(x, mod, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+                if not eng.last_finalized:
+                    st = eng.scratch("stats", rows * cout * 2)
+                    groups = L.lib.v2v_bn_finalize_groups(rows)
+                    ws = eng.scratch("bn_ws", groups * cout * 2, torch.float64) if groups > 0 else None
+                    L.check(L.lib.v2v_bn_finalize(_ptr(st), rows, cout, H * W, _ptr(norm.weight.detach()), _ptr(norm.bias.detach()), norm.eps,
+                                                  _ptr(ss), None, None, 0.1, _ptr(ws), _stream()), "bn_finalize")
+                return rows
+            try:
+                us = timed(chain)
+                out.append("t%d: %6.1f us (%d rows, finalize %s)" % (cfg[0], us, chain(), "in the launch" if eng.last_finalized else "separate"))
+            except Exception as e:
+                out.append("t%d: n/a (%s)" % (cfg[0], str(e)[:60]))
+        if out:
+            print("%-28s   + finalize | %s" % ("", "  ".join(out)), flush=True)

@@ -462,8 +462,12 @@ def test_round5_experiment_tiles_are_reachable_through_the_engine():
             assert t in PATCH_CFGS and is_patch_tile(t) and tile_korder(t) == 1, t
             if t in (140, 141, 142, 143):                                  # persistent single-chunk tile: 64 input channels, <= 64 output channels, single launches
                 eng.tile_override[(64, 64, 3, 1, 0)] = (t, 1, 0)
-                eng.conv(x64, conv64, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
-                assert eng.conv_log[-1]["tile"] == t
+                _, rows, _ = eng.conv(x64, conv64, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
+                assert eng.conv_log[-1]["tile"] == t and rows == 8          # 8 tiles of 8 x 32 pixels, one statistics row per WORKGROUP
+                big = eng.pack(torch.randn(1, 64, 256, 512))                # 2048 tiles on (dry run: assumed) 256 CUs: 256 rows, and the
+                ss = torch.zeros(4 * 64)                                    # finalize stays in the launch although the layer is large
+                _, rows, _ = eng.conv(big, conv64, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(nn.BatchNorm2d(64), ss))
+                assert rows == 256 and eng.last_finalized
                 eng.tile_override[(cin, cout, 3, 1, 0)] = (t, 1, 0)
                 with pytest.raises(RuntimeError):         # 128 channels: refused by the library
                     eng.conv(xs[0], convs[0], L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)

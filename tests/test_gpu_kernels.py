@@ -512,13 +512,17 @@ def test_conv3x3_patch_kernel(case, prec):
 @pytest.mark.parametrize("case", [(64, 64, 64, 128, "reflect", 1), (64, 32, 16, 64, "zero", 2), (64, 64, 24, 96, "reflect", 2), (64, 48, 8, 32, "zero", 1),
                                   (64, 64, 256, 512, "reflect", 1)])
 def test_conv3x3_persistent_single_chunk_tile(case):
-    """Tile 140 (csrc/conv3x3_one_kernel.h): the persistent, weights-resident kernel for single-chunk layers (64 bf16 input channels,
-    <= 64 output channels) -- one workgroup per CU walks its tiles, one output mode (raw fp32 NHWC + a statistics row per tile).
-    Against torch on bf16-rounded operands, and BIT FOR BIT against the single-phase tile 94 (same MFMA order per accumulator, same
-    epilogue arithmetic): raw output and statistics rows; border and interior tiles, reflection and zero padding, batch 2, fewer
-    tiles than CUs and (last case, 1024 tiles) four tiles per workgroup; launched twice with different inputs (the resident weights
-    and the patch buffer of a previous launch must not leak).  Geometries the kernel does not serve are refused by the library."""
+    """Tiles 140 / 141 (/ 142 / 143) (csrc/conv3x3_one_kernel.h): the persistent, weights-resident kernels for single-chunk layers (64
+    bf16 input channels, <= 64 output channels) -- one workgroup per CU walks its tiles, one output mode (raw fp32 NHWC + ONE statistics
+    row per WORKGROUP, finalized by the last workgroup when asked).  Against torch on bf16-rounded operands, and the raw output BIT FOR
+    BIT against the single-phase tile 94 (same MFMA order per accumulator, same epilogue arithmetic); the statistics rows (<= CUs of
+    them, whatever the tile count) sum to tile 94's per-tile rows (fp32 partial sums in another order: 1e-5 of the column's scale);
+    the in-kernel finalize equals v2v_bn_finalize over the same rows.  Border and interior tiles, reflection and zero padding, batch
+    2, fewer tiles than CUs and (last case, 1024 tiles) four tiles per workgroup; launched twice with different inputs (the resident
+    weights and the patch buffer of a previous launch must not leak).  Geometries the kernel does not serve are refused."""
     from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.engine import _ptr, _stream
     cin, cout, H, W, mode, N = case
     torch.manual_seed(cout + H)
     eng = _engine("bf16")
@@ -531,33 +535,57 @@ def test_conv3x3_persistent_single_chunk_tile(case):
         return F.conv2d(xr, _round(conv.weight.detach(), "bf16"), conv.bias.detach(), padding=0 if mode == "reflect" else 1)
     refs = [ref_of(x) for x in xs]
     conv = conv.to(DEV)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    with torch.no_grad():
+        norm.weight.normal_(1, 0.2); norm.bias.normal_(0, 0.2)
     pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = N * (H // 8) * (W // 32)
+    one_tiles = (140, 141) + ((142, 143) if cout == 64 else ())      # 141: two patch buffers; 142: + stores from the accumulators; 143: 141 with its stores left in flight
     for x, ref in zip(xs, refs):
         xa = eng.pack(x.to(DEV))
         got = {}
-        for tile in (94, 140, 141) + ((142, 143) if cout == 64 else ()):
+        for tile in (94,) + one_tiles:
             eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, 1, 0)
             raw, rows, (n_, OH, OW) = eng.conv(xa, conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
-            assert eng.conv_log[-1]["tile"] == tile
+            assert eng.conv_log[-1]["tile"] == tile and not eng.last_finalized
             cs_raw = (cout + 3) // 4 * 4
             st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].clone()
-            got[tile] = (raw[:n_ * OH * OW * cs_raw].clone(), st, rows)
+            got[tile] = (raw[:n_ * OH * OW * cs_raw].clone(), st.view(rows, cout, 2), rows)
         cs_raw = (cout + 3) // 4 * 4
-        for t in (140, 141) + ((142, 143) if cout == 64 else ()):      # 141: two patch buffers; 142: + stores from the accumulators, left in flight
-            assert got[t][2] == got[94][2]
+        assert got[94][2] == tiles
+        col94 = got[94][1].double().sum(0)
+        for t in one_tiles:
+            assert got[t][2] == min(tiles, cus), "one statistics row per workgroup"
             assert torch.equal(got[t][0], got[94][0]), "raw output of tile %d differs from tile 94" % t
-            assert torch.equal(got[t][1], got[94][1]), "statistics rows of tile %d differ from tile 94" % t
+            col = got[t][1].double().sum(0)
+            scale = got[94][1].double().abs().sum(0) + 1e-30
+            assert float(((col - col94).abs() / scale).max()) < 1e-5, "statistics of tile %d vs tile 94" % t
             r = got[t][0].view(N, H, W, cs_raw)[..., :cout].permute(0, 3, 1, 2)
             assert_close(r.cpu(), ref, 1e-4, "tile %d vs torch" % t)
-    # refused: ragged tiles, more than 64 output channels, in-kernel finalize
+            # in-kernel finalize (last workgroup) == v2v_bn_finalize over the rows the same launch left; at any layer size
+            eng.tile_override[(cin, cout, 3, 1, 0)] = (t, 1, 0)
+            for rep in range(2):
+                ss = torch.full((4 * cout,), float("nan"), device=DEV)
+                raw, rows, (n_, OH, OW) = eng.conv(xa, conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+                assert eng.last_finalized and rows == min(tiles, cus)
+                refss = torch.empty(4 * cout, device=DEV)
+                st = eng.scratch("stats", rows * cout * 2)
+                L.check(lib.v2v_bn_finalize(_ptr(st), rows, cout, n_ * OH * OW, _ptr(norm.weight.detach()), _ptr(norm.bias.detach()),
+                                            norm.eps, _ptr(refss), None, None, 0.1, None, _stream()), "bn_finalize")
+                torch.cuda.synchronize()
+                assert torch.isfinite(ss).all(), "tile %d: finalize did not run for every channel" % t
+                assert torch.allclose(ss, refss, rtol=1e-6, atol=1e-7), "tile %d: in-kernel finalize vs bn_finalize: %g" % (t, float((ss - refss).abs().max()))
+                assert torch.equal(raw[:n_ * OH * OW * cs_raw], got[t][0])
+                assert int(eng._fin_counter.abs().sum().item()) == 0, "tickets must be re-armed"
+            y = ref.double()
+            mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+            assert_close(ss[2 * cout:3 * cout].cpu(), mean.float(), 1e-3, "mean")
+            assert_close(ss[3 * cout:].cpu(), (1.0 / torch.sqrt(var + norm.eps)).float(), 1e-3, "invstd")
+    # refused: ragged tiles
     eng.tile_override[(cin, cout, 3, 1, 0)] = (141, 1, 0)
-    norm = nn.BatchNorm2d(cout).to(DEV)
-    ss = torch.zeros(4 * cout, device=DEV)
     with pytest.raises(RuntimeError):
         eng.conv(eng.pack(torch.randn(1, cin, 12, 40, device=DEV)), conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
-    if H * W * N <= 32768:
-        with pytest.raises(RuntimeError):
-            eng.conv(eng.pack(xs[0].to(DEV)), conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
 
 
 @pytest.mark.parametrize("case", [(64, 64, 24, 64, "reflect", 1), (128, 64, 33, 70, "reflect", 2), (128, 128, 16, 96, "zero", 1),

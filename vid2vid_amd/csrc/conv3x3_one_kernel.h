@@ -39,6 +39,81 @@ __device__ __forceinline__ void one_stagger(const ConvKArgs& p) {
     for (int i = 0; i < g * units; ++i) __builtin_amdgcn_s_sleep(16);
 }
 
+// Statistics of a persistent workgroup (round 5, third step): ONE (sum, sum^2) row per WORKGROUP, not per tile.  Every lane keeps its
+// channel's two running sums in registers across all the tiles its workgroup walks; after the last tile the 2 x WGM wave partials are
+// combined through `red` and row blockIdx.x of p.stats is written: a 2048-tile layer leaves 256 rows (v2v_conv_stats_rows reports the
+// grid size), so the layer's finalize needs no bn_partial_reduce launch -- and, with p.fin_counter, no launch at all: the LAST
+// workgroup to publish its row reduces the <= 256 rows and writes the scale / shift record (the hand-off and the arithmetic of
+// conv_epilogue's single-level in-kernel finalize, conv_igemm_kernel.h: 8-byte agent-scope row stores, vmcnt(0), barrier, one relaxed
+// ticket; rows summed in fp64 in a fixed order, whichever workgroup happens to be last).  The per-tile statistics exchange (LDS
+// partials + a workgroup barrier + 64 global stores per tile) is gone from the tile loop.
+// `scratch`: >= 8 KiB of LDS nobody reads any more (a patch buffer: every wave has passed its last step barrier and drained its DMA).
+template <int BN, int WGM, int NW>
+__device__ __forceinline__ void one_stats_finish(const ConvKArgs& p, float s1, float s2, float* const red, char* const scratch,
+                                                 const int wm, const int ccol, const int hi, const int tid) {
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (hi == 0) {
+        red[(wm * BN + ccol) * 2 + 0] = s1;
+        red[(wm * BN + ccol) * 2 + 1] = s2;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's last stores and (tail) dummy patch pieces are done
+    __builtin_amdgcn_s_barrier();
+    const bool fin = p.fin_counter != nullptr;
+    if (tid < BN && tid < p.cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid) * 2 + 0]; t2 += red[(q * BN + tid) * 2 + 1]; }
+        float* const dst = p.stats + ((long long)blockIdx.x * p.cout + tid) * 2;
+        if (fin) {
+            const unsigned long long bits = (unsigned long long)__float_as_uint(t1) | ((unsigned long long)__float_as_uint(t2) << 32);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            dst[0] = t1;
+            dst[1] = t2;
+        }
+    }
+    if (!fin) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(scratch + 8192);
+    const int total = (int)gridDim.x;
+    if (tid == 0) {
+        const int tk = __hip_atomic_fetch_add(p.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == total - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(p.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    constexpr int PH = NW * 64 / BN;
+    double* const acc2 = reinterpret_cast<double*>(scratch);      // [PH][BN][2] fp64 = 8 KiB
+    const int c = tid % BN, ph = tid / BN;
+    double d1 = 0.0, d2 = 0.0;
+    if (c < p.cout) sum_stat_rows<8>(p.stats, (long long)c * 2, (long long)p.cout * 2, ph, PH, total, d1, d2);
+    acc2[(ph * BN + c) * 2 + 0] = d1;
+    acc2[(ph * BN + c) * 2 + 1] = d2;
+    __syncthreads();
+    if (ph == 0 && c < p.cout) {
+        d1 = 0.0; d2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < PH; ++q) { d1 += acc2[(q * BN + c) * 2 + 0]; d2 += acc2[(q * BN + c) * 2 + 1]; }
+        const double mean = d1 * p.fin_inv_count;
+        double var = d2 * p.fin_inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)p.fin_eps);
+        const double g = p.fin_gamma ? (double)p.fin_gamma[c] : 1.0;
+        const double b = p.fin_beta ? (double)p.fin_beta[c] : 0.0;
+        const double sc = g * invstd;
+        p.fin_out[c] = (float)sc;
+        p.fin_out[p.cout + c] = (float)(b - mean * sc);
+        p.fin_out[2 * p.cout + c] = (float)mean;
+        p.fin_out[3 * p.cout + c] = (float)invstd;
+        if (p.fin_rmean) p.fin_rmean[c] = (1.f - p.fin_momentum) * p.fin_rmean[c] + p.fin_momentum * (float)mean;
+        if (p.fin_rvar)  p.fin_rvar[c]  = (1.f - p.fin_momentum) * p.fin_rvar[c] + p.fin_momentum * (float)(var * p.fin_unbias);
+    }
+}
+
 template <typename T, int TH, int TW, int BN>
 __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
@@ -182,9 +257,10 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     }
     one_stagger(p);
 
+    float s1 = 0.f, s2 = 0.f;                                 // this lane's channel, over every tile of this workgroup (one_stats_finish)
     while (vb < ntot) {
         const int oh0 = th * TH, ow0 = twi * TW;
-        const int c_mt = mt, c_img = n_img;
+        const int c_img = n_img;
         f32x16 acc[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -220,7 +296,6 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
         }
 
         // ---- epilogue: statistics + 16-byte stores through the wave's transposition block ----
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -242,25 +317,12 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the block is in registers before the next one overwrites it
         }
-        if (want_stats) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (hi == 0) {
-                red[(wm * BN + ccol) * 2 + 0] = s1;
-                red[(wm * BN + ccol) * 2 + 1] = s2;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (NOT __syncthreads(): its fence is a vmcnt(0) -- it would drain the next
-            __builtin_amdgcn_s_barrier();                        //  patch's LDS-DMA and this tile's stores every tile)
-            if (tid < BN && tid < p.cout) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid) * 2 + 0]; t2 += red[(q * BN + tid) * 2 + 1]; }
-                float* const dst = p.stats + ((long long)c_mt * p.cout + tid) * 2;
-                dst[0] = t1;
-                dst[1] = t2;
-            }
-        }
     }
+    // (no workgroup barrier between a tile's epilogue and the next tile's steps is needed: the transposition blocks are wave private,
+    //  the next patch was issued into a buffer every wave had finished reading, and the statistics stay in registers.  NOTE for any
+    //  barrier added to this loop: `s_waitcnt lgkmcnt(0)` + `s_barrier`, NOT __syncthreads() -- its fence is a vmcnt(0), it would drain
+    //  the next patch's LDS-DMA and this tile's stores every tile)
+    if (want_stats) one_stats_finish<BN, WGM, NW>(p, s1, s2, red, patch, wm, ccol, hi, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -430,6 +492,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
     one_stagger(p);
     int cur = 0;
     bool first = true;
+    float s1 = 0.f, s2 = 0.f;                                 // this lane's channel, over every tile of this workgroup (one_stats_finish)
     while (vb < ntot) {
         int lin, slice, nt, mt, n_img, th, twi;
         patch_tile_index(p, xcd_remap(vb, ntot), lin, slice, nt, mt, n_img, th, twi);
@@ -472,7 +535,6 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // every wave has finished reading this patch: the buffer becomes epilogue scratch
 
-        float s1 = 0.f, s2 = 0.f;
         if constexpr (ASYNC == 1) {
             issue_patch_vb(vb + 2 * G, patch);               // the buffer is free: nothing of the epilogue touches it
 #pragma unroll
@@ -509,31 +571,22 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         }
-        if (want_stats) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (hi == 0) {
-                red[(wm * BN + ccol) * 2 + 0] = s1;
-                red[(wm * BN + ccol) * 2 + 1] = s2;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave's transposition block is retired; the partials are complete
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave's transposition block is retired
         __builtin_amdgcn_s_barrier();                        // (NOT __syncthreads(): its fence is a vmcnt(0) -- prefetch and stores must stay in flight)
-        if (want_stats && tid < BN && tid < p.cout) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid) * 2 + 0]; t2 += red[(q * BN + tid) * 2 + 1]; }
-            float* const dst = p.stats + ((long long)mt * p.cout + tid) * 2;
-            dst[0] = t1;
-            dst[1] = t2;
-        }
-        // the patch of tile i+2 into the buffer this tile is done with (`red` is read above by wave 0 only and rewritten behind the
-        // next tile's two barriers)
+        // the patch of tile i+2 into the buffer this tile is done with
         if constexpr (ASYNC != 1) issue_patch_vb(vb + 2 * G, patch);
         vb += G;
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (want_stats) one_stats_finish<BN, WGM, NW>(p, s1, s2, red, pbase, wm, ccol, hi, tid);
+}
+
+// Grid of the persistent tiles = statistics rows they leave (v2v_conv_stats_rows): one workgroup per CU (the LDS footprint allows no
+// second one), never more workgroups than tiles.
+static inline int one_grid_size(int ntot, int cus) {
+    if (cus < 8) cus = 256;
+    return ntot < cus ? ntot : cus;
 }
 
 template <typename T>
@@ -558,9 +611,7 @@ static inline int launch_one_typed(int cfg, const ConvKArgs& k_in, int cus, hipS
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_done = true;
             }
-            const int ntot = k.m_tiles * k.n_tiles;
-            if (cus < 8) cus = 256;
-            int g = ntot < cus ? ntot : cus;                   // one workgroup per CU (the LDS footprint allows no second one)
+            const int g = one_grid_size(k.m_tiles * k.n_tiles, cus);
             hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), lds, s, k);
             return check_launch();
         }
@@ -577,9 +628,7 @@ static inline int launch_one_typed(int cfg, const ConvKArgs& k_in, int cus, hipS
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_done[cfg - 141] = true;
             }
-            const int ntot = k.m_tiles * k.n_tiles;
-            if (cus < 8) cus = 256;
-            int g = ntot < cus ? ntot : cus;
+            const int g = one_grid_size(k.m_tiles * k.n_tiles, cus);
             hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), lds, s, k);
             return check_launch();
         }

@@ -399,6 +399,7 @@ int launch_pp2_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp2_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_pp3_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_one_bf16(int cfg, const ConvKArgs& k, int cus, hipStream_t s);     // persistent single-chunk tiles (conv3x3_one_kernel.h)
+int one_grid(int ntot, int cus);                                              // ... their grid = the statistics rows they leave
 int launch_pp3_f32(int cfg, const ConvKArgs& k, int groups, hipStream_t s);
 int launch_s2_bf16(int cfg, const ConvKArgs& k, hipStream_t s);
 int launch_s2_f32(int cfg, const ConvKArgs& k, hipStream_t s);
@@ -668,10 +669,10 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
                       op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
         }
         if ((op->cfg >= 140 && op->cfg <= 143) && ((op->cfg >= 142 && d->cout != pc->BN) || d->cout > pc->BN || (d->cout & 3) || (d->cout_stride & 3) || ((unsigned long long)d->out & 15ull) ||
-                               d->out_mode != V2V_OUT_RAW_F32_NHWC || d->fin_counter != nullptr || d->OH % pc->TH != 0 || d->OW % pc->TW != 0)) {
-            // conv3x3_one_kernel.h: ONE output mode (raw fp32 NHWC + statistics rows, finalize in its own launch), full tiles only
-            set_error("conv: tile configs 140 - 142 (persistent, weights resident) need cout <= %d (142: exactly) and %% 4 == 0, raw fp32 NHWC output (16-byte aligned rows), "
-                      "no in-kernel finalize, OH %% %d == 0 and OW %% %d == 0", pc->BN, pc->TH, pc->TW);
+                               d->out_mode != V2V_OUT_RAW_F32_NHWC || d->fin_workspace != nullptr || d->OH % pc->TH != 0 || d->OW % pc->TW != 0)) {
+            // conv3x3_one_kernel.h: ONE output mode (raw fp32 NHWC + one statistics row per workgroup, single-level in-kernel finalize), full tiles only
+            set_error("conv: tile configs 140 - 143 (persistent, weights resident) need cout <= %d (142 / 143: exactly) and %% 4 == 0, raw fp32 NHWC output (16-byte aligned rows), "
+                      "no two-level finalize workspace, OH %% %d == 0 and OW %% %d == 0", pc->BN, pc->TH, pc->TW);
             return V2V_EINVAL;
         }
         if ((op->cfg == 94 || op->cfg == 95 || op->cfg == 96 || (op->cfg >= 140 && op->cfg <= 143)) && (d->dtype != V2V_BF16 || d->cin_stride != bke_of(d->dtype) || d->splitk > 1 ||
@@ -795,6 +796,7 @@ extern "C" int v2v_conv_debug_clocks(void* device_buffer) {
 extern "C" int v2v_conv_stats_rows(const v2v_conv_desc* d) {
     ConvOp op;
     if (build_conv(d, &op, false) != 0) return V2V_EINVAL;
+    if (op.cfg >= 140) return one_grid(op.k.m_tiles * op.k.n_tiles, device_cus());     // persistent tiles: one row per workgroup
     return op.ncls * op.k.m_tiles;
 }
 

@@ -14,6 +14,7 @@ int launch_pp_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_p
 int launch_pp2_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s) { return launch_pp2_typed<bf16_t>(cfg, k, groups, s); }
 int launch_pp3_bf16(int cfg, const ConvKArgs& k, int groups, hipStream_t s) { return launch_pp3_typed<bf16_t>(cfg, k, groups, s); }
 int launch_one_bf16(int cfg, const ConvKArgs& k, int cus, hipStream_t s) { return launch_one_typed<bf16_t>(cfg, k, cus, s); }
+int one_grid(int ntot, int cus) { return one_grid_size(ntot, cus); }
 int launch_s2_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_s2_typed<bf16_t>(cfg, k, s); }
 int launch_t2_bf16(int cfg, const ConvKArgs& k, hipStream_t s) { return launch_t2_typed<bf16_t>(cfg, k, s); }
 int launch_head_bf16(const ConvKArgs& k, hipStream_t s) { return launch_head_typed<bf16_t>(k, s); }

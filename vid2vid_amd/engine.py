@@ -367,6 +367,8 @@ T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 6
 S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
+ONE_TILES = (140, 141, 142, 143)                                # persistent, weights-resident single-chunk tiles (csrc/conv3x3_one_kernel.h)
+ONE_FIN = os.environ.get("V2V_ONE_FIN", "1") != "0"             # ... finalize their <= 256 statistics rows in the launch (0: separate bn_finalize launch, for A/B)
 EXP_TILES = (97, 98, 99, 130, 131, 132, 142, 143)               # (140 / 141: validated and faster -- regular tiles since visits r05_v3 / r05_v6)
 if os.environ.get("V2V_EXP_TILES", "0") == "1":
     PAIR_TILES = PAIR_TILES + EXP_TILES
@@ -781,8 +783,9 @@ class Engine:
             # (not for the 7x7 layers: their halo-patch tiles 60 / 61 have no in-kernel finalize and must stay eligible)
             two_level = bool(fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS and self.fused_finalize2 and rows > 512
                              and pc.KH != 7 and d.tile not in (60, 61))
-            if fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS and not two_level:
+            if fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS and not two_level and not (d.tile in ONE_TILES and ONE_FIN):
                 fin = None             # one workgroup walking >1000 rows costs 0.1-1 ms (profiles/r01_v15_finalize_tail.txt)
+                                       # (the persistent tiles leave one row per WORKGROUP, <= 256: they finalize in the launch at any size)
             self.last_finalized = fin is not None
             if fin is not None:
                 norm, ss = fin
