@@ -102,7 +102,7 @@ typedef struct v2v_conv_desc {
     int32_t prefetch;       /* 0 = off; P > 0: weight-prefetch helper wave, P K-chunks ahead (see below) */
     void*   slabs;          /* splitk > 1: v2v_conv_splitk_workspace() bytes of scratch              */
     int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
-    int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major */
+    int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major, 2 full-tap chunk-major (transposed), 3 paired-x (below) */
     int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA), 512 = return at once (launch floor), 1024 = no main loop (prologue + epilogue), 2048 = one workgroup per channel tile stays away from the fused-norm barrier (exercises its give-up path: NaN outputs + v2v_device_status bit 0) */
     const void* res0;       /* V2V_OUT_NORM_ACT_NHWC: NULL or a residual [N][OH][OW][cout_stride] (activation dtype) added after the activation */
     const void* res1;       /* second residual, NULL or as res0                                                   */
@@ -165,9 +165,16 @@ int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t ci
  * k = (chunk * KH*KW + tap) * E + c_in_chunk with E = elements per 128 bytes and channel c = chunk*E + c_in_chunk
  * (channel-chunk outer, tap inner; Conv2d with cin_stride % E == 0 only; same element count): the layout of the
  * LDS-resident-patch 3x3 kernel (tile ids 32..37, csrc/conv3x3_patch_kernel.h), which fetches the input patch of
- * a channel chunk once and walks the 9 taps over it. */
+ * a channel chunk once and walks the 9 taps over it.
+ * v2v_conv_desc.w_korder 3 (no packing mode of its own): the PAIRED-X view of a 3x3 / stride 1 / pad 1 Conv2d with <= 32 input and
+ * exactly 32 output channels (models/networks.py:554-593 at ngf_s = 32: 64-byte bf16 pixels), read by tile ids 140..143 when
+ * cin_stride == 32.  The NHWC tensors [H][W][32] ARE [H][W/2][64] (paired pixel X = pixels 2X, 2X+1); `w` is the korder-1 packing of
+ * the 64 -> 64 weight W'[a*32+co][b*32+ci][ky][kX] = W[co][ci][ky][2kX+b-a-1] (zero outside 0..2) that the caller assembled; the
+ * descriptor keeps the layer's own geometry (cin <= 32, cin_stride = cout = cout_stride = 32, W even, V2V_OUT_RAW_F32_NHWC), `bias`
+ * its 32 values, the statistics rows / finalize record its 32 channels.  Horizontal reflection becomes a clamp inside the kernel. */
 
-/* Number of statistics rows (n_classes * m_tiles) the launch described by `d` writes. */
+/* Number of statistics rows the launch described by `d` writes: n_classes * m_tiles -- except for the persistent tile ids 140..143,
+ * which keep their sums in registers across the tiles a workgroup walks and leave ONE row per workgroup (min(tiles, compute units)). */
 int     v2v_conv_stats_rows(const v2v_conv_desc* d);
 /* Bytes of `slabs` scratch (and number of `sk_counter` ints via *tickets) the launch needs; 0 when splitk <= 1. */
 int64_t v2v_conv_splitk_workspace(const v2v_conv_desc* d, int32_t* tickets);

@@ -207,6 +207,17 @@ if has bntest; then
   timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "bn_apply or batchnorm or splitk_on_a_tiny" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300 | tail -12
   lap bntest
 fi
+if has ops; then        # per-op dumps of both resolutions -> per-layer roofline tables (every conv alone on the chip)
+  timeout 600 python bench.py $LEAN --dump-ops gpurun_out/${TAG}_ops_bf16.json > gpurun_out/${TAG}_benchq.json 2> gpurun_out/${TAG}_benchq.err; echo "benchq rc=$?"
+  python scripts/per_layer_roofline.py gpurun_out/${TAG}_ops_bf16.json > gpurun_out/${TAG}_per_layer_roofline.txt 2>&1; tail -3 gpurun_out/${TAG}_per_layer_roofline.txt | cut -c1-300
+  python scripts/per_layer_roofline_hires.py gpurun_out/${TAG}_ops_bf16.json.hires.json > gpurun_out/${TAG}_per_layer_roofline_hires.txt 2>&1; tail -3 gpurun_out/${TAG}_per_layer_roofline_hires.txt | cut -c1-600
+  lap ops
+fi
+if has onetest; then
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "persistent_single_chunk or paired_x" -p no:cacheprovider > gpurun_out/${TAG}_onetest.log 2>&1; echo "onetest rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_onetest.log | cut -c1-300 | tail -25
+  lap onetest
+fi
 if has onefin; then     # persistent tiles: one statistics row per workgroup (no bn_partial_reduce) + finalize in the launch (V2V_ONE_FIN=0: separate bn_finalize), alternating
   for i in 1 2; do
     for f in 0 1; do

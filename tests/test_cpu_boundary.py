@@ -487,3 +487,50 @@ def test_round5_experiment_tiles_are_reachable_through_the_engine():
     finally:
         N.set_record_only(False)
         N._ENGINES.clear()
+
+
+def test_paired_x_view_of_32_channel_layers():
+    """engine.PairedXConv: a <= 32 -> 32 channel 3x3 layer as a 64 -> 64 layer over PAIRS of horizontally adjacent pixels (the NHWC
+    tensor [H][W][32] is [H][W/2][64]) -- what puts the 64-byte-pixel ResnetBlocks (models/networks.py:554-593 at ngf_s = 32) on the
+    persistent single-chunk kernels.  (1) The assembled weight reproduces the layer in torch, with reflection (vertical: reflection;
+    horizontal: a clamp in the paired domain) and zero padding, 32 and fewer input channels.  (2) Dry run: the engine hands tiles
+    140 / 141 the paired-x packing (w_korder 3), the library accepts the launch, reports one statistics row per workgroup and keeps the
+    finalize in the launch; shapes the view does not cover are refused."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from vid2vid_amd import networks as N
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.engine import Engine, PairedXConv
+    torch.manual_seed(0)
+    for cin in (32, 27):
+        conv = nn.Conv2d(cin, 32, 3).requires_grad_(False)
+        x = torch.randn(2, cin, 12, 16)
+        px = PairedXConv(conv)
+        xp = F.pad(x, (0, 0, 0, 0, 0, 32 - cin))
+        n, c, H, W = xp.shape
+        xpair = xp.permute(0, 2, 3, 1).reshape(n, H, W // 2, 64).permute(0, 3, 1, 2)
+        unpair = lambda y: y.permute(0, 2, 3, 1).reshape(n, H, W, 32).permute(0, 3, 1, 2)
+        t = F.pad(F.pad(xpair, (0, 0, 1, 1), mode="reflect"), (1, 1, 0, 0), mode="replicate")
+        ref = F.conv2d(F.pad(x, (1,) * 4, mode="reflect"), conv.weight, conv.bias)
+        assert float((unpair(F.conv2d(t, px.weight, px.bias)) - ref).abs().max()) < 1e-5
+        refz = F.conv2d(x, conv.weight, conv.bias, padding=1)
+        assert float((unpair(F.conv2d(xpair, px.weight, px.bias, padding=1)) - refz).abs().max()) < 1e-5
+    with pytest.raises(ValueError):
+        PairedXConv(nn.Conv2d(32, 16, 3))
+    if torch.cuda.is_available():
+        return                                       # the dry-run half is a CPU-host check
+    N.set_record_only(True)
+    try:
+        eng = Engine(torch.device("cpu"), L.BF16, record_only=True)
+        conv = nn.Conv2d(32, 32, 3)
+        x = eng.pack(torch.randn(1, 32, 64, 1024))
+        assert x.Cs == 32
+        for t in (140, 141):
+            eng.tile_override[(32, 32, 3, 1, 0)] = (t, 1, 0)
+            ss = torch.zeros(4 * 32)
+            _, rows, _ = eng.conv(x, conv, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(nn.BatchNorm2d(32), ss))
+            assert eng.conv_log[-1]["tile"] == t and rows == 128 and eng.last_finalized      # 8 x 16 tiles of 8 x 32 PAIRED pixels
+            with pytest.raises(RuntimeError):        # odd paired width (1000 / 2 = 500 is not a multiple of 32)
+                eng.conv(eng.pack(torch.randn(1, 32, 64, 1000)), conv, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
+    finally:
+        N.set_record_only(False)

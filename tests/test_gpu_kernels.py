@@ -588,6 +588,73 @@ def test_conv3x3_persistent_single_chunk_tile(case):
         eng.conv(eng.pack(torch.randn(1, cin, 12, 40, device=DEV)), conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
 
 
+@pytest.mark.parametrize("case", [(32, 16, 128, "reflect", 1), (27, 8, 64, "zero", 2), (32, 64, 512, "reflect", 1), (32, 256, 1024, "reflect", 1)])
+def test_paired_x_persistent_tiles_on_32_channel_layers(case):
+    """The persistent single-chunk tiles 140 / 141 on layers with 64-byte pixels (<= 32 -> 32 channels: the finest foreground tower's
+    ResnetBlocks, models/networks.py:554-593 at ngf_s = 32) through the PAIRED-X view (engine.PairedXConv, w_korder 3: pairs of
+    horizontally adjacent pixels as one 128-byte pixel of a 64 -> 64 layer whose non-zero products are the layer's own).  Raw output
+    against torch on bf16-rounded operands and against the generic tile 4 (same products; fp32 sums in another order: 2e-5 of the
+    output scale); statistics columns (32 channels, halves of the paired accumulator folded) against tile 4's; in-kernel finalize
+    against v2v_bn_finalize; reflection (the image border columns: a clamp in the paired domain) and zero padding, fewer than 32 real
+    input channels, batch 2, one to two tiles per workgroup; two different inputs in a row."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.engine import _ptr, _stream
+    cin, H, W, mode, N = case
+    cout = 32
+    torch.manual_seed(cin + H)
+    eng = _engine("bf16")
+    conv = nn.Conv2d(cin, cout, 3, padding=0 if mode == "reflect" else 1)
+    xs = [torch.randn(N, cin, H, W) * (1.0 + i) for i in range(2)]
+    def ref_of(x):
+        xr = _round(x, "bf16")
+        if mode == "reflect":
+            xr = F.pad(xr, (1,) * 4, mode="reflect")
+        return F.conv2d(xr, _round(conv.weight.detach(), "bf16"), conv.bias.detach(), padding=0 if mode == "reflect" else 1)
+    refs = [ref_of(x) for x in xs]
+    conv = conv.to(DEV)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    with torch.no_grad():
+        norm.weight.normal_(1, 0.2); norm.bias.normal_(0, 0.2)
+    pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = N * (H // 8) * (W // 64)
+    for x, ref in zip(xs, refs):
+        xa = eng.pack(x.to(DEV))
+        assert xa.Cs == 32
+        got = {}
+        for tile in (4, 140, 141):
+            eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, 1, 0)
+            raw, rows, (n_, OH, OW) = eng.conv(xa, conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True)
+            assert eng.conv_log[-1]["tile"] == tile
+            st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].clone()
+            got[tile] = (raw[:n_ * OH * OW * cout].clone(), st.view(rows, cout, 2), rows)
+        col4 = got[4][1].double().sum(0)
+        scale = float(got[4][0].abs().max())
+        for t in (140, 141):
+            assert got[t][2] == min(tiles, cus)
+            r = got[t][0].view(N, H, W, cout).permute(0, 3, 1, 2)
+            assert_close(r.cpu(), ref, 1e-4, "tile %d (paired-x) vs torch" % t)
+            assert float((got[t][0] - got[4][0]).abs().max()) <= 2e-5 * scale, "tile %d vs tile 4" % t
+            col = got[t][1].double().sum(0)
+            assert float(((col - col4).abs() / (got[4][1].double().abs().sum(0) + 1e-30)).max()) < 1e-5, "statistics of tile %d vs tile 4" % t
+            eng.tile_override[(cin, cout, 3, 1, 0)] = (t, 1, 0)
+            ss = torch.full((4 * cout,), float("nan"), device=DEV)
+            raw, rows, (n_, OH, OW) = eng.conv(xa, conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+            assert eng.last_finalized
+            refss = torch.empty(4 * cout, device=DEV)
+            st = eng.scratch("stats", rows * cout * 2)
+            L.check(lib.v2v_bn_finalize(_ptr(st), rows, cout, n_ * OH * OW, _ptr(norm.weight.detach()), _ptr(norm.bias.detach()),
+                                        norm.eps, _ptr(refss), None, None, 0.1, None, _stream()), "bn_finalize")
+            torch.cuda.synchronize()
+            assert torch.isfinite(ss).all()
+            assert torch.allclose(ss, refss, rtol=1e-6, atol=1e-7), "tile %d: in-kernel finalize vs bn_finalize: %g" % (t, float((ss - refss).abs().max()))
+            assert torch.equal(raw[:n_ * OH * OW * cout], got[t][0])
+            y = ref.double()
+            assert_close(ss[2 * cout:3 * cout].cpu(), y.mean((0, 2, 3)).float(), 1e-3, "mean")
+            assert_close(ss[3 * cout:].cpu(), (1.0 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + norm.eps)).float(), 1e-3, "invstd")
+
+
 @pytest.mark.parametrize("case", [(64, 64, 24, 64, "reflect", 1), (128, 64, 33, 70, "reflect", 2), (128, 128, 16, 96, "zero", 1),
                                   (192, 40, 9, 32, "reflect", 1), (64, 32, 64, 128, "reflect", 1)])
 def test_conv7x7_window_tiles(case):

@@ -60,11 +60,17 @@ __device__ __forceinline__ void one_stats_finish(const ConvKArgs& p, float s1, f
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's last stores and (tail) dummy patch pieces are done
     __builtin_amdgcn_s_barrier();
     const bool fin = p.fin_counter != nullptr;
-    if (tid < BN && tid < p.cout) {
+    const bool pairx = p.pair_x != 0;
+    const int cs = pairx ? 32 : p.cout;                           // statistics columns (paired-x: accumulator columns c and c + 32 are one channel)
+    if (tid < BN && tid < cs) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid) * 2 + 0]; t2 += red[(q * BN + tid) * 2 + 1]; }
-        float* const dst = p.stats + ((long long)blockIdx.x * p.cout + tid) * 2;
+        if (pairx) {
+#pragma unroll
+            for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid + 32) * 2 + 0]; t2 += red[(q * BN + tid + 32) * 2 + 1]; }
+        }
+        float* const dst = p.stats + ((long long)blockIdx.x * cs + tid) * 2;
         if (fin) {
             const unsigned long long bits = (unsigned long long)__float_as_uint(t1) | ((unsigned long long)__float_as_uint(t2) << 32);
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -90,11 +96,11 @@ __device__ __forceinline__ void one_stats_finish(const ConvKArgs& p, float s1, f
     double* const acc2 = reinterpret_cast<double*>(scratch);      // [PH][BN][2] fp64 = 8 KiB
     const int c = tid % BN, ph = tid / BN;
     double d1 = 0.0, d2 = 0.0;
-    if (c < p.cout) sum_stat_rows<8>(p.stats, (long long)c * 2, (long long)p.cout * 2, ph, PH, total, d1, d2);
+    if (c < cs) sum_stat_rows<8>(p.stats, (long long)c * 2, (long long)cs * 2, ph, PH, total, d1, d2);
     acc2[(ph * BN + c) * 2 + 0] = d1;
     acc2[(ph * BN + c) * 2 + 1] = d2;
     __syncthreads();
-    if (ph == 0 && c < p.cout) {
+    if (ph == 0 && c < cs) {
         d1 = 0.0; d2 = 0.0;
 #pragma unroll
         for (int q = 0; q < PH; ++q) { d1 += acc2[(q * BN + c) * 2 + 0]; d2 += acc2[(q * BN + c) * 2 + 1]; }
@@ -106,9 +112,9 @@ __device__ __forceinline__ void one_stats_finish(const ConvKArgs& p, float s1, f
         const double b = p.fin_beta ? (double)p.fin_beta[c] : 0.0;
         const double sc = g * invstd;
         p.fin_out[c] = (float)sc;
-        p.fin_out[p.cout + c] = (float)(b - mean * sc);
-        p.fin_out[2 * p.cout + c] = (float)mean;
-        p.fin_out[3 * p.cout + c] = (float)invstd;
+        p.fin_out[cs + c] = (float)(b - mean * sc);
+        p.fin_out[2 * cs + c] = (float)mean;
+        p.fin_out[3 * cs + c] = (float)invstd;
         if (p.fin_rmean) p.fin_rmean[c] = (1.f - p.fin_momentum) * p.fin_rmean[c] + p.fin_momentum * (float)mean;
         if (p.fin_rvar)  p.fin_rvar[c]  = (1.f - p.fin_momentum) * p.fin_rvar[c] + p.fin_momentum * (float)(var * p.fin_unbias);
     }
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     float* const tw = reinterpret_cast<float*>(smem + WBYTES + PATCH + RED) + wid * 1024;
     const int H = p.H, W = p.W, cs = p.cin_stride;
     const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+    const bool pairx = p.pair_x != 0;
     const char* const zp = p.zero_page;
     const int ntot = p.m_tiles;                               // n_tiles == 1 (host check): the resident weights serve every tile
     const int G = (int)gridDim.x;
@@ -195,8 +202,8 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
                 int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
                 int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
                 ih = reflect ? rh : ih;
-                iw = reflect ? rw : iw;
-                ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                iw = (reflect && !pairx) ? rw : iw;                     // paired-x: pixel -1 = pixel 1 lives in paired pixel 0 (clamp below)
+                ok = ok && (unsigned)ih < (unsigned)H && ((unsigned)iw < (unsigned)W || (reflect && pairx));
                 ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
                 iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
                 const unsigned off = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     float* const out = reinterpret_cast<float*>(p.out);
     const unsigned cs_out = (unsigned)p.cout_stride;
     const int ccol = wn * WN + lr;                            // this lane's output channel in the accumulator layout
-    const float bv = (p.bias != nullptr && ccol < p.cout) ? p.bias[ccol] : 0.f;
+    const float bv = (p.bias != nullptr && ccol < p.cout) ? p.bias[pairx ? (ccol & 31) : ccol] : 0.f;
     const int vcol = wn * WN + 4 * (lane & 7);                // first channel of the 16-byte vectors this lane stores
     const bool vfull = vcol + 4 <= p.cout;                    // cout % 4 == 0 and 16-byte aligned rows (host check)
     const bool want_stats = p.stats != nullptr;
@@ -382,6 +389,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
     const int wm = wid / WGN, wn = wid % WGN;
     const int H = p.H, W = p.W, cs = p.cin_stride;
     const bool reflect = p.pad_mode == V2V_PAD_REFLECT;
+    const bool pairx = p.pair_x != 0;
     const char* const zp = p.zero_page;
     const int ntot = p.m_tiles;
     const int G = (int)gridDim.x;
@@ -436,8 +444,8 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
                 int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
                 int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
                 ih = reflect ? rh : ih;
-                iw = reflect ? rw : iw;
-                ok = ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                iw = (reflect && !pairx) ? rw : iw;                     // paired-x: pixel -1 = pixel 1 lives in paired pixel 0 (clamp below)
+                ok = ok && (unsigned)ih < (unsigned)H && ((unsigned)iw < (unsigned)W || (reflect && pairx));
                 ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
                 iw = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
                 const unsigned off = (unsigned)(((long long)((n_img * H + ih) * W + iw) * cs + ls * VEC) * (long long)sizeof(T));
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
     float* const out = reinterpret_cast<float*>(p.out);
     const unsigned cs_out = (unsigned)p.cout_stride;
     const int ccol = wn * WN + lr;
-    const float bv = (p.bias != nullptr && ccol < p.cout) ? p.bias[ccol] : 0.f;
+    const float bv = (p.bias != nullptr && ccol < p.cout) ? p.bias[pairx ? (ccol & 31) : ccol] : 0.f;
     const int vcol = wn * WN + 4 * (lane & 7);
     const bool vfull = vcol + 4 <= p.cout;
     const bool want_stats = p.stats != nullptr;

@@ -467,8 +467,28 @@ static int* status_word() {
     return dev;
 }
 
-static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true) {
+static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = true) {
+    const v2v_conv_desc* d = d_in;
     if (!d || !d->in || !d->w || !d->out || !d->zero_page) { set_error("conv: null pointer"); return V2V_EINVAL; }
+    // Persistent single-chunk tiles (140 - 143) on a layer with 64-byte pixels: the PAIRED-X view (include/v2v_hip.h, w_korder 3).  The
+    // NHWC tensors [H][W][32] are [H][W/2][64]; the caller packed the 64 -> 64 matrix of that view (engine.PairedXConv) chunk-major.
+    v2v_conv_desc dd;
+    bool pair_x = false;
+    if (d->tile >= 140 && d->tile <= 143 && d->cin_stride == 32) {
+        if (d->dtype != V2V_BF16 || d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->cin > 32 || d->cout != 32 ||
+            d->cout_stride != 32 || d->out_mode != V2V_OUT_RAW_F32_NHWC || d->w_korder != 3 || (d->W & 1) || d->OW != d->W || d->OH != d->H) {
+            set_error("conv: tile configs 140 - 143 on 64-byte pixels (paired-x view) need a bf16 3x3/s1/p1 Conv2d, <= 32 -> exactly 32 channels, "
+                      "dense raw fp32 NHWC output, an even width and paired-x weights (w_korder 3)");
+            return V2V_EINVAL;
+        }
+        dd = *d;
+        dd.W = d->W / 2; dd.OW = d->OW / 2;
+        dd.cin = 64; dd.cin_stride = 64; dd.cout = 64; dd.cout_stride = 64; dd.w_korder = 1;
+        d = &dd;
+        pair_x = true;
+    } else if (d->w_korder == 3) {
+        set_error("conv: paired-x weights (w_korder 3) are read by tile configs 140 - 143 on layers with a 32-channel stride only"); return V2V_EINVAL;
+    }
     if (d->dtype != V2V_F32 && d->dtype != V2V_BF16) { set_error("conv: bad dtype"); return V2V_EINVAL; }
     const int vec = d->dtype == V2V_BF16 ? 8 : 4;
     if (d->cin_stride % vec != 0 || d->cin > d->cin_stride) { set_error("conv: cin_stride %d not a multiple of %d", d->cin_stride, vec); return V2V_EINVAL; }
@@ -492,6 +512,7 @@ static int build_conv(const v2v_conv_desc* d, ConvOp* op, bool launching = true)
     conv_geom(d->cin_stride, d->cout, d->KH, d->KW, d->transposed, d->stride, d->pad, d->dtype, &g);
     ConvKArgs& k = op->k;
     memset(&k, 0, sizeof(k));
+    k.pair_x = pair_x ? 1 : 0;
     k.in = (const char*)d->in; k.w = (const char*)d->w; k.zero_page = (const char*)d->zero_page;
     k.bias = d->bias; k.out = (char*)d->out; k.stats = d->stats;
     k.N = d->N; k.H = d->H; k.W = d->W; k.cin_stride = d->cin_stride;

@@ -65,6 +65,10 @@ struct ConvKArgs {
     // (v2v_fastdiv_magic) -- three scalar instructions each instead of the ~30 of a run-time division, which every wave of every
     // workgroup executed four times before its first load (and two 64-bit divisions for the split-K chunk range, now behind S > 1)
     unsigned idx_m[3]; int idx_l[3];
+    // persistent single-chunk tiles on a layer with 64-byte pixels (v2v_conv_desc.w_korder 3): this launch is the PAIRED-X view of a
+    // <= 32 -> 32 channel layer (W, OW = half the layer's, 64 -> 64 channels, structured weights): horizontal reflection is a clamp,
+    // bias index and statistics column = channel & 31 (the two halves of a paired pixel are the same 32 channels)
+    int pair_x;
 };
 
 // phase stamp k of this workgroup (thread 0): 0 entry, 1 prologue set up (first loads issued), 2 first tile landed, 3 main loop done,

@@ -110,7 +110,12 @@ class PackedConv:
     def __init__(self, eng, mod, cin_stride, role="fwd", reflect=False, korder=0):
         self.mod = mod
         self.role = role
-        self.korder = korder      # 0: tap-major K (implicit-GEMM tiles), 1: channel-chunk-major (patch kernel)
+        self.korder = korder      # 0: tap-major K (implicit-GEMM tiles), 1: channel-chunk-major (patch kernel), 3: paired-x (PairedXConv)
+        self.src_mod = None       # korder 3: the geometry below is the layer's own, the packed matrix its PairedXConv's (64 x 9 x 64, chunk-major)
+        if korder == 3:
+            if role != "fwd" or cin_stride != 32:
+                raise ValueError("paired-x packing: forward operator of a layer with 64-byte pixels")
+            self.src_mod = PairedXConv(mod)
         mod_t = getattr(mod, "is_transposed", isinstance(mod, nn.ConvTranspose2d))
         w = mod.weight
         self.KH, self.KW = mod.kernel_size
@@ -132,8 +137,9 @@ class PackedConv:
         self.out_pad = mod.output_padding[0] if mod_t else 0
         self.cin_stride = cin_stride
         self.dtype = eng.dtype
-        n = lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, self.KH, self.KW,
-                                      int(self.transposed), self.stride, self.pad, eng.dtype)
+        n = (lib.v2v_conv_packed_elems(64, 64, 64, 3, 3, 0, 1, self.pad, eng.dtype) if korder == 3 else
+             lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, self.KH, self.KW,
+                                       int(self.transposed), self.stride, self.pad, eng.dtype))
         self.buf = torch.empty(n, dtype=_TORCH_DTYPE[eng.dtype], device=eng.device)
         self.bias = None
         self.version = None
@@ -141,6 +147,16 @@ class PackedConv:
 
     def refresh(self, force=False):
         """(Re)pack if the parameter changed (optimizer step / load_state_dict)."""
+        if self.src_mod is not None:               # paired-x: the 64 -> 64 matrix of the PairedXConv, as a chunk-major (korder 1) packing
+            ver = self.src_mod.version_key()
+            if not force and ver == self.version:
+                return
+            w32 = self.src_mod.weight.contiguous()
+            check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), 64, 64, 64, 3, 3, 0, 1, self.pad, self.dtype, 1, _stream()),
+                  "conv_pack_weights (paired-x)")
+            self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()      # the layer's own 32 values (the kernel folds the index)
+            self.version = ver
+            return
         if hasattr(self.mod, "version_key"):       # MergedConv: `weight` is a fresh torch.cat on every read (version 0, recycled
             ver = self.mod.version_key()           # address) -- the key comes from the two source layers (ADVICE r2)
             if not force and ver == self.version:
@@ -229,6 +245,48 @@ class X3Conv:
     @property
     def bias(self):
         return None if self.src.bias is None else self.src.bias.detach()
+
+
+class PairedXConv:
+    """A 3x3 / stride 1 nn.Conv2d with <= 32 input and exactly 32 output channels, seen as a 64 -> 64 convolution over PAIRS of
+    horizontally adjacent pixels: the NHWC tensor [H][W][32] IS [H][W/2][64] (paired pixel X = pixels 2X, 2X+1), and
+        out[y][X][a*32+co] = sum W'[a*32+co][b*32+ci][ky][kX] in[y+ky-1][X+kX-1][b*32+ci],   W'[..][ky][kX] = W[co][ci][ky][2kX+b-a-1]
+    (zero where that tap index falls outside 0..2).  That puts the 32-channel ResnetBlocks of the finest foreground tower
+    (models/networks.py:554-593 at ngf_s = 32: 64-byte pixels, half an LDS-DMA row) on the persistent single-chunk kernels
+    (csrc/conv3x3_one_kernel.h) unchanged; the products that are not structural zeros are the layer's own, in the layer's own K order.
+    Horizontal reflection in the paired domain is a CLAMP (pixel -1 = pixel 1 is the b = 1 half of paired pixel 0; the other half
+    meets zero weights) -- the kernel's pair_x mode.  What PackedConv needs of an nn.Conv2d, assembled on read (include/v2v_hip.h,
+    w_korder 3)."""
+
+    def __init__(self, conv):
+        if isinstance(conv, nn.ConvTranspose2d) or tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1) or conv.out_channels != 32 \
+                or conv.in_channels > 32 or conv.groups != 1:
+            raise ValueError("paired-x packing: 3x3 / stride 1 Conv2d, <= 32 -> 32 channels")
+        self.src = conv
+        self.is_transposed = False
+        self.kernel_size, self.stride, self.padding, self.groups = conv.kernel_size, conv.stride, conv.padding, conv.groups
+        self.in_channels, self.out_channels = 64, 64
+        self.output_padding = (0, 0)
+
+    def version_key(self):
+        return _param_version(self.src)
+
+    @property
+    def weight(self):
+        w = self.src.weight.detach().float()                     # [32][cin][3][3]
+        cin = w.shape[1]
+        wp = torch.zeros(2, 32, 2, 32, 3, 3, dtype=torch.float32, device=w.device)      # [a][co][b][ci][ky][kX]
+        for a in range(2):
+            for b in range(2):
+                for kX in range(3):
+                    kx = 2 * kX + b - a - 1
+                    if 0 <= kx <= 2:
+                        wp[a, :, b, :cin, :, kX] = w[:, :, :, kx]
+        return wp.view(64, 64, 3, 3)
+
+    @property
+    def bias(self):
+        return None if self.src.bias is None else torch.cat([self.src.bias.detach(), self.src.bias.detach()], 0)
 
 
 class PackedOneHot:
@@ -1209,6 +1267,8 @@ class Engine:
         return pc
 
     def _use_korder(self, d, mod, cin_stride, korder, role="fwd", reflect=False):
+        if d.tile in ONE_TILES and cin_stride == 32 and role == "fwd":
+            korder = 3            # 64-byte pixels on the persistent single-chunk tiles: paired-x packing (PairedXConv; pairx_eligible)
         pc = self.packed(mod, cin_stride, role=role, reflect=reflect, korder=korder)
         d.w, d.w_korder = pc.buf.data_ptr(), korder
         return pc
@@ -1222,6 +1282,13 @@ class Engine:
         bke = 64 if self.dtype == L.BF16 else 32
         return (not d.transposed and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1
                 and d.cin_stride % bke == 0)
+
+    def pairx_eligible(self, d):
+        """Persistent single-chunk tiles 140 / 141 (/ 143) on a layer with 64-byte pixels (<= 32 -> 32 channels, bf16, raw fp32 output): the
+        paired-x view (PairedXConv) -- pairs of pixels as one 128-byte pixel of a 64 -> 64 layer."""
+        return (self.dtype == L.BF16 and not d.transposed and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1
+                and d.cin_stride == 32 and d.cout == 32 and d.out_mode == L.OUT_RAW_F32_NHWC and d.W % 2 == 0 and (d.W // 2) % 32 == 0
+                and d.H % 8 == 0 and os.environ.get("V2V_PAIRX", "1") != "0")
 
     def s7_eligible(self, d):
         """7x7-window tiles 120 / 121: dense bf16 7x7 / stride 1 / pad 3 Conv2d whose channel stride is a whole number of 128-byte chunks
@@ -1309,6 +1376,10 @@ class Engine:
                     if S == 1 and tiles < 64:
                         continue
                     cands.append((t, S, 0))
+        if mod is not None and role == "fwd" and self.pairx_eligible(d) and d.N * (d.H // 8) * (d.W // 64) >= 64:
+            for t in ONE_TILES:
+                if t not in EXP_TILES or os.environ.get("V2V_EXP_TILES", "0") == "1":
+                    cands.append((t, 1, 0))
         if mod is not None and role == "fwd" and self.s7_eligible(d):
             for t, (th, tw, bn) in sorted(S7_CFGS.items()):
                 tiles = d.N * -(-d.OH // th) * -(-d.OW // tw) * -(-cout // bn)
