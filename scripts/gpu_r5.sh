@@ -214,9 +214,13 @@ if has ops; then        # per-op dumps of both resolutions -> per-layer roofline
   lap ops
 fi
 if has onetest; then
-  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "persistent_single_chunk or paired_x" -p no:cacheprovider > gpurun_out/${TAG}_onetest.log 2>&1; echo "onetest rc=$?"
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "persistent_single_chunk or paired_x or stride2_persistent" -p no:cacheprovider > gpurun_out/${TAG}_onetest.log 2>&1; echo "onetest rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_onetest.log | cut -c1-300 | tail -25
   lap onetest
+fi
+if has t2bench; then
+  T2_ONLY=1 timeout 300 python scripts/s2_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_t2_bench.txt | cut -c1-300
+  lap t2bench
 fi
 if has onefin; then     # persistent tiles: one statistics row per workgroup (no bn_partial_reduce) + finalize in the launch (V2V_ONE_FIN=0: separate bn_finalize), alternating
   for i in 1 2; do

@@ -532,5 +532,16 @@ def test_paired_x_view_of_32_channel_layers():
             assert eng.conv_log[-1]["tile"] == t and rows == 128 and eng.last_finalized      # 8 x 16 tiles of 8 x 32 PAIRED pixels
             with pytest.raises(RuntimeError):        # odd paired width (1000 / 2 = 500 is not a multiple of 32)
                 eng.conv(eng.pack(torch.randn(1, 32, 64, 1000)), conv, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
+        # tile 114: the persistent transposed stride-2 tile (64 -> <= 32 channels): full-tap packing (korder 2), one row per workgroup
+        up = nn.ConvTranspose2d(64, 32, 3, stride=2, padding=1, output_padding=1)
+        eng.tile_override[(64, 32, 3, 2, 1)] = (114, 1, 0)
+        ss = torch.zeros(4 * 32)
+        _, rows, (n_, OH, OW) = eng.conv(eng.pack(torch.randn(1, 64, 512, 1024)), up, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True,
+                                         fin=(nn.BatchNorm2d(32), ss))
+        assert eng.conv_log[-1]["tile"] == 114 and rows == 256 and (OH, OW) == (1024, 2048) and eng.last_finalized
+        with pytest.raises(RuntimeError):            # 64 output channels: refused
+            eng.tile_override[(64, 64, 3, 2, 1)] = (114, 1, 0)
+            eng.conv(eng.pack(torch.randn(1, 64, 16, 64)), nn.ConvTranspose2d(64, 64, 3, stride=2, padding=1, output_padding=1), L.PAD_ZERO, None,
+                     L.OUT_RAW_F32_NHWC, want_stats=True)
     finally:
         N.set_record_only(False)

@@ -320,6 +320,75 @@ def test_conv_transpose_stride2_patch_kernel(geom, tile, prec):
         assert_close(raw3[:n_ * OH * OW * cs].view(n_, OH, OW, cs)[..., :cout].permute(0, 3, 1, 2).cpu(), got.cpu(), 2e-5, "vs generic tile")
 
 
+@pytest.mark.parametrize("geom", [(64, 32, 16, 64, 1), (64, 32, 8, 32, 2), (64, 24, 24, 96, 1), (57, 32, 64, 128, 1), (64, 32, 256, 512, 1)])
+def test_conv_transpose_stride2_persistent_tile(geom):
+    """Tile 114 (csrc/conv3x3_one_kernel.h, conv3x3_t2_one_kernel): ConvTranspose2d(3x3, stride 2, padding 1, output_padding 1) of a
+    single-chunk layer (<= 64 bf16 input channels) with <= 32 output channels -- the last up-sampling stage of the finest generators
+    (models/networks.py:254-260 at ngf_s = 32) -- persistent, weights resident, all four output-parity classes per tile, one
+    statistics row per workgroup.  Raw output against torch and BIT FOR BIT against the one-workgroup-per-tile kernel (tile 112: same
+    step table, same order per accumulator); statistics columns against tile 112's 4 x m_tiles rows; the in-kernel finalize against
+    v2v_bn_finalize; the image's last row / column of tiles (zero beyond the input), fewer real input / output channels than the
+    tile, batch 2, one to four tiles per workgroup; two inputs in a row."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.engine import _ptr, _stream
+    cin, cout, H, W, N = geom
+    torch.manual_seed(cin + cout + H)
+    eng = _engine("bf16")
+    conv = nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.1); conv.bias.normal_(0, 0.5)
+    xs = [torch.randn(N, cin, H, W) * (1.0 + i) for i in range(2)]
+    refs = [F.conv_transpose2d(_round(x, "bf16"), _round(conv.weight.detach(), "bf16"), conv.bias.detach(), stride=2, padding=1, output_padding=1) for x in xs]
+    conv = conv.to(DEV)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    with torch.no_grad():
+        norm.weight.normal_(1, 0.2); norm.bias.normal_(0, 0.2)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = N * (H // 8) * (W // 32)
+    cs = (cout + 3) // 4 * 4
+    with torch.no_grad():
+        for x, ref in zip(xs, refs):
+            xa = eng.pack(x.to(DEV))
+            assert xa.Cs == 64
+            got = {}
+            for tile in (112, 114):
+                eng.tile_override[(cin, cout, 3, 2, 1)] = (tile, 1, 0)
+                raw, rows, (n_, OH, OW) = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+                assert eng.conv_log[-1]["tile"] == tile and (OH, OW) == (2 * H, 2 * W)
+                st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].clone()
+                got[tile] = (raw[:n_ * OH * OW * cs].clone(), st.view(rows, cout, 2), rows)
+            assert got[112][2] == 4 * tiles and got[114][2] == min(tiles, cus)
+            assert torch.equal(got[114][0], got[112][0]), "raw output of tile 114 differs from tile 112"
+            r = got[114][0].view(N, 2 * H, 2 * W, cs)[..., :cout].permute(0, 3, 1, 2)
+            assert_close(r.cpu(), ref, 1e-4, "tile 114 vs torch")
+            col, col112 = got[114][1].double().sum(0), got[112][1].double().sum(0)
+            assert float(((col - col112).abs() / (got[112][1].double().abs().sum(0) + 1e-30)).max()) < 1e-5, "statistics of tile 114 vs tile 112"
+            eng.tile_override[(cin, cout, 3, 2, 1)] = (114, 1, 0)
+            ss = torch.full((4 * cout,), float("nan"), device=DEV)
+            raw, rows, (n_, OH, OW) = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+            assert eng.last_finalized and rows == min(tiles, cus)
+            refss = torch.empty(4 * cout, device=DEV)
+            st = eng.scratch("stats", rows * cout * 2)
+            L.check(lib.v2v_bn_finalize(_ptr(st), rows, cout, n_ * OH * OW, _ptr(norm.weight.detach()), _ptr(norm.bias.detach()),
+                                        norm.eps, _ptr(refss), None, None, 0.1, None, _stream()), "bn_finalize")
+            torch.cuda.synchronize()
+            assert torch.isfinite(ss).all()
+            assert torch.allclose(ss, refss, rtol=1e-6, atol=1e-7), "in-kernel finalize vs bn_finalize: %g" % float((ss - refss).abs().max())
+            assert torch.equal(raw[:n_ * OH * OW * cs], got[114][0])
+            y = ref.double()
+            assert_close(ss[2 * cout:3 * cout].cpu(), y.mean((0, 2, 3)).float(), 1e-3, "mean")
+            assert_close(ss[3 * cout:].cpu(), (1.0 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + norm.eps)).float(), 1e-3, "invstd")
+        # refused: ragged tiles, more than 32 output channels
+        eng.tile_override[(cin, cout, 3, 2, 1)] = (114, 1, 0)
+        with pytest.raises(RuntimeError):
+            eng.conv(eng.pack(torch.randn(1, cin, 12, 40, device=DEV)), conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+        conv64 = nn.ConvTranspose2d(64, 64, 3, stride=2, padding=1, output_padding=1).to(DEV)
+        eng.tile_override[(64, 64, 3, 2, 1)] = (114, 1, 0)
+        with pytest.raises(RuntimeError):
+            eng.conv(eng.pack(torch.randn(1, 64, 16, 64, device=DEV)), conv64, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+
+
 # (tile, splitk, prefetch): split-K slices that start mid-tap, the prefetch helper wave on 4- and 8-wave tiles,
 # large wave tiles; cin chosen so that both the uniform tap walk (cs % chunk == 0) and the per-lane walk run
 SPLITK_CFGS = [(2, 2, 0), (2, 3, 12), (3, 4, 12), (13, 2, 12), (13, 1, 12), (17, 3, 12), (1, 2, 0), (5, 4, 12), (7, 1, 4),

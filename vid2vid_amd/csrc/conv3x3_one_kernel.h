@@ -25,6 +25,7 @@
 // conv_epilogue's fast path: bit-identical results (raw output and statistics rows).
 #pragma once
 #include "conv3x3_pp3_kernel.h"
+#include "conv3x3_t2_kernel.h"
 
 namespace v2v {
 
@@ -590,6 +591,194 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
     if (want_stats) one_stats_finish<BN, WGM, NW>(p, s1, s2, red, pbase, wm, ccol, hi, tid);
 }
 
+// Tile 114: ConvTranspose2d(3x3, stride 2, padding 1, output_padding 1) of a single-chunk layer (64 bf16 input channels) with at most 32
+// output channels -- the last up-sampling stage of the finest generators (models/networks.py:254-260 at ngf_s = 32: 64 -> 32 at
+// 1024x512 -> 2048x1024, twice per frame; the foreground tower's 64 -> 32 one scale below) -- as a PERSISTENT, WEIGHTS-RESIDENT kernel:
+// conv3x3_t2_kernel.h's arithmetic (all four output-parity classes of a tile of INPUT positions per workgroup, t2k's step table:
+// same products, same order per accumulator -- bit-identical raw output) on conv3x3_one_db_kernel's skeleton.
+//   On tile 112 such a layer is 2048 workgroups of 26 us each (210 us; HBM bound 53): half of every workgroup's MFMAs multiply the 32
+//   padding columns of its 64-wide channel tile, 36 KB of weights and the prologue / four passes of the shared epilogue (one per class,
+//   a workgroup barrier each) are paid per tile.  Here: 9 x [32 rows][128 B] weight slices resident (36 KB), two exact-size patch
+//   buffers ((TH+1) x (TW+1) input pixels = 38 KB each; the patch of tile i+1 travels during the whole of tile i), 8 waves x one tile
+//   row of 32 positions x 32 channels x 4 classes (4 accumulators per wave, no padding columns), 9 barrier-free steps, a lean epilogue
+//   per class through the wave's 4 KB transposition block (inside the patch buffer the steps are done with): 16-byte stores, each
+//   8-lane group one 128-byte output pixel; statistics in registers across classes and tiles, one row per workgroup
+//   (one_stats_finish).  Full tiles only (H % TH == 0, W % TW == 0, OH = 2H, OW = 2W: host check).
+template <typename T, int TH, int TW, int BN>
+__global__ __launch_bounds__(512) void conv3x3_t2_one_kernel(const ConvKArgs p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    constexpr int NW = 8, SS = 4;
+    constexpr int PW = TW + 1, PR = (TH + 1) * PW;
+    constexpr int NG = (PR + 7) / 8;
+    constexpr int GP = (NG + NW - 1) / NW;
+    constexpr int NFULL = NG - (GP - 1) * NW;
+    constexpr int PATCH = NG * 1024;
+    constexpr int BST = BN * 128;
+    constexpr int WBYTES = 9 * BST;
+    constexpr int WPIECES = 9 * BN / 8;                       // 1 KiB pieces (8 rows of one tap) of the resident weights
+    constexpr int WPW = (WPIECES + NW - 1) / NW;
+    constexpr int RED = NW * BN * 2 * 4;
+    static_assert(sizeof(T) == 2 && TW == 32 && TH == NW && BN == 32, "one tile row of 32 positions x 32 channels x 4 classes per wave");
+    static_assert(WBYTES + 2 * PATCH + RED <= 160 * 1024 && PATCH >= NW * 4096 && NFULL >= 1 && NFULL <= NW && GP >= 2, "LDS / piece split");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wres = smem;
+    char* const pbase = smem + WBYTES;
+    float* const red = reinterpret_cast<float*>(smem + WBYTES + 2 * PATCH);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W, cs = p.cin_stride;
+    const char* const zp = p.zero_page;
+    const int ntot = p.m_tiles;
+    const int G = (int)gridDim.x;
+    const bool full_wave = wid < NFULL;
+
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {                           // weights: once (full-tap chunk-major rows: tap ky * 3 + kx at byte 128 (ky * 3 + kx))
+        const int j = wid + NW * i;
+        if (j < WPIECES) {
+            const int tap = j / (BN / 8);
+            long long r = (j % (BN / 8)) * 8 + (lane >> 3);
+            const int lslot = (lane & 7) ^ (((int)r >> 1) & 7);
+            r = r < p.cout_p ? r : p.cout_p - 1;
+            glds16(p.w + ((long long)p.woff[0] + r * p.wrow[0] + lslot * VEC) * (long long)sizeof(T) + tap * 128, wres + j * 1024);
+        }
+    }
+
+    int rel[GP];                                              // (pr * W + pc) * cs * 2 + swizzled slot of this lane's patch pixel, or -1
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+        const int q = (k * NW + wid) * 8 + (lane >> 3);
+        const int ls = (lane & 7) ^ ((q >> 1) & 7);
+        const int pr = q / PW, pc = q - pr * PW;
+        rel[k] = q < PR ? (pr * W + pc) * cs * (int)sizeof(T) + ls * 16 : -1;
+    }
+    auto issue_patch_vb = [&](const int vbn, char* const buf) __attribute__((always_inline)) {
+        int l_, s_, nt_, mt_, n_img = 0, th_ = 0, tw_ = 0;
+        const bool real = vbn < ntot;
+        if (real) patch_tile_index(p, xcd_remap(vbn, ntot), l_, s_, nt_, mt_, n_img, th_, tw_);
+        const int a0 = th_ * TH, b0 = tw_ * TW;
+        const bool interior = real && a0 + TH < H && b0 + TW < W;                  // the patch's extra row and column are inside the image
+        const char* const base = p.in + ((long long)(n_img * H + a0) * W + b0) * cs * (long long)sizeof(T);
+#pragma unroll
+        for (int k = 0; k < GP; ++k) {
+            if (!(k < GP - 1 || full_wave)) continue;
+            bool ok = real && rel[k] != -1;
+            if (!interior && ok) {
+                const int q = (k * NW + wid) * 8 + (lane >> 3);
+                const int pr = q / PW, pc = q - pr * PW;
+                ok = a0 + pr < H && b0 + pc < W;                                  // zero beyond the image (the transposed layer's padding)
+            }
+            glds16(ok ? base + rel[k] : zp, buf + (k * NW + wid) * 1024);
+        }
+    };
+
+    const int lr = lane & 31, hi = lane >> 5;
+    const int qb = wid * PW + lr;                             // this lane's input position in the patch (tile row = wave)
+    int foff[SS];
+#pragma unroll
+    for (int s = 0; s < SS; ++s) foff[s] = ((s * 2 + hi) ^ ((lr >> 1) & 7)) << 4;
+    const char* const wrow = wres + lr * 128;
+
+    Frag fa[2][SS], fb[2][SS];
+    auto read_step = [&](auto tapc, auto parc, const char* const patch) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int PARN = decltype(parc)::value;
+        constexpr int tq = t2k::DY[TAP] * PW + t2k::DX[TAP];
+        int qv = qb;
+        asm volatile("" : "+v"(qv));
+        const int q = qv + tq;
+        const char* const arow = patch + q * 128;
+        const int ax = (q >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < SS; ++s) fa[PARN][s] = *reinterpret_cast<const Frag*>(arow + (((s * 2 + hi) ^ ax) << 4));
+#pragma unroll
+        for (int s = 0; s < SS; ++s) fb[PARN][s] = *reinterpret_cast<const Frag*>(wrow + t2k::KK[TAP] * BST + foff[s]);
+    };
+
+    float* const out = reinterpret_cast<float*>(p.out);
+    const unsigned cs_out = (unsigned)p.cout_stride;
+    const int OH = p.OH, OW = p.OW;
+    const float bv = (p.bias != nullptr && lr < p.cout) ? p.bias[lr] : 0.f;
+    const int vcol = 4 * (lane & 7);
+    const bool vfull = vcol + 4 <= p.cout;
+    const bool want_stats = p.stats != nullptr;
+
+    int vb = (int)blockIdx.x;
+    if (vb >= ntot) return;                                   // (the host launches min(tiles, CUs) workgroups)
+    issue_patch_vb(vb, pbase);
+    issue_patch_vb(vb + G, pbase + PATCH);
+    int cur = 0;
+    float s1 = 0.f, s2 = 0.f;                                 // this lane's channel (lr), over the 4 classes of every tile of this workgroup
+    while (vb < ntot) {
+        int lin, slice, nt, mt, n_img, th, twi;
+        patch_tile_index(p, xcd_remap(vb, ntot), lin, slice, nt, mt, n_img, th, twi);
+        const int a0 = th * TH, b0 = twi * TW;
+        char* const patch = pbase + cur * PATCH;
+        f32x16 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+        // only the patch issued LAST (tile i+1, or its dummy) may still be in flight: this tile's patch, the weights and the stores of the
+        // previous epilogue are older
+        if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP) : "memory");
+        else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, patch);
+        static_for<9>([&](auto tc) {
+            constexpr int TAP = decltype(tc)::value;
+            constexpr int PAR = TAP & 1;
+            constexpr int CL = t2k::CLS[TAP];
+            static_for<SS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                Mma<T>::run(fa[PAR][s], fb[PAR][s], acc[CL]);
+                if constexpr (s == 0 && TAP < 8) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_step(std::integral_constant<int, (TAP < 8 ? TAP + 1 : 8)>{}, std::integral_constant<int, 1 - PAR>{}, patch);    // (the discarded branch of TAP 8 is still instantiated: keep the table index in range)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // every wave has finished reading this patch: the buffer becomes epilogue scratch
+
+        float* const tw = reinterpret_cast<float*>(patch) + wid * 1024;
+        static_for<4>([&](auto cc_) {
+            constexpr int CL = decltype(cc_)::value;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[CL][r] + bv;
+                s1 += v;
+                s2 = __builtin_fmaf(v, v, s2);
+                tw[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lr] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // block row m = input position (a0 + wid, b0 + m) -> output pixel (2 (a0 + wid) + py, 2 (b0 + m) + px)
+            float* const orow = out + ((unsigned)((n_img * OH + 2 * (a0 + wid) + (CL >> 1)) * OW + 2 * b0 + (CL & 1))) * cs_out + (unsigned)vcol;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + ((lane >> 3) + 8 * k) * 32 + 4 * (lane & 7));
+                if (vfull) *reinterpret_cast<f32x4*>(orow + (unsigned)(2 * ((lane >> 3) + 8 * k)) * cs_out) = v4;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // (NOT __syncthreads(): its fence is a vmcnt(0) -- prefetch and stores must stay in flight)
+        issue_patch_vb(vb + 2 * G, patch);
+        vb += G;
+        cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (want_stats) one_stats_finish<BN, NW, NW>(p, s1, s2, red, pbase, wid, lr, hi, tid);
+}
+
 // Grid of the persistent tiles = statistics rows they leave (v2v_conv_stats_rows): one workgroup per CU (the LDS footprint allows no
 // second one), never more workgroups than tiles.
 static inline int one_grid_size(int ntot, int cus) {
@@ -635,6 +824,22 @@ static inline int launch_one_typed(int cfg, const ConvKArgs& k_in, int cus, hipS
             if (!attr_done[cfg - 141]) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_done[cfg - 141] = true;
+            }
+            const int g = one_grid_size(k.m_tiles * k.n_tiles, cus);
+            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), lds, s, k);
+            return check_launch();
+        }
+    }
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (cfg == 114) {
+            constexpr int TH = 8, TW = 32, BN = 32, NW = 8;
+            constexpr int NG = ((TH + 1) * (TW + 1) + 7) / 8;
+            const size_t lds = (size_t)9 * BN * 128 + (size_t)2 * NG * 1024 + (size_t)(NW * BN * 2 * 4);
+            void (*kern)(const ConvKArgs) = conv3x3_t2_one_kernel<T, TH, TW, BN>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done = true;
             }
             const int g = one_grid_size(k.m_tiles * k.n_tiles, cus);
             hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), lds, s, k);

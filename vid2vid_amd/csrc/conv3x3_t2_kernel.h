@@ -284,7 +284,8 @@ static int launch_t2_cfg(const ConvKArgs& k, hipStream_t s) {
 }
 
 // transposed stride-2 patch tile configurations (ids 110..113): (TH, TW) = tile of INPUT positions
-static const PatchCfg kT2Cfgs[] = {{110, 4, 32, 64}, {111, 4, 32, 128}, {112, 8, 32, 64}, {113, 4, 32, 64}};
+static const PatchCfg kT2Cfgs[] = {{110, 4, 32, 64}, {111, 4, 32, 128}, {112, 8, 32, 64}, {113, 4, 32, 64},
+                                   {114, 8, 32, 32}};    // 114: geometry only -- the persistent kernel of conv3x3_one_kernel.h (launch_one_typed)
 static inline const PatchCfg* find_t2_cfg(int id) {
     for (const PatchCfg& c : kT2Cfgs)
         if (c.id == id) return &c;

@@ -431,7 +431,7 @@ struct ConvOp : Op {
     long long slab_bytes; int sk_tickets;
     int groups = 1;      // 2: grouped launch (v2v_conv2d_pair), second member's tensors in k.g1
     int launch(hipStream_t s) override {
-        if (cfg >= 140) return launch_one_bf16(cfg, k, device_cus(), s);        // persistent, weights-resident single-chunk tile (bf16: host check)
+        if (cfg >= 140 || cfg == 114) return launch_one_bf16(cfg, k, device_cus(), s);     // persistent, weights-resident single-chunk tiles (bf16: host check); 114: the transposed stride-2 one
         if (cfg >= 130) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, groups, s) : launch_pp3_f32(cfg, k, groups, s);    // round-5 experiment tiles of the 3x3 single-phase kernel
         if (cfg >= 120) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, 1, s) : launch_pp3_f32(cfg, k, 1, s);    // 7x7 window on the single-phase kernel
         if (cfg >= 110) return dtype == V2V_BF16 ? launch_t2_bf16(cfg, k, s) : launch_t2_f32(cfg, k, s);
@@ -660,8 +660,16 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
         k.tiles_w = (int)ceil_div((d->OW + 1) / 2, pc->TW);
         k.m_tiles = d->N * k.tiles_h * k.tiles_w;
         k.n_tiles = (int)ceil_div(d->cout, pc->BN);
+        if (op->cfg == 114 && (d->dtype != V2V_BF16 || d->cin_stride != 64 || d->cout > pc->BN || (d->cout & 3) || (d->cout_stride & 3) || ((unsigned long long)d->out & 15ull) ||
+                               d->out_mode != V2V_OUT_RAW_F32_NHWC || d->fin_workspace != nullptr || d->H % pc->TH != 0 || d->W % pc->TW != 0 ||
+                               d->OH != 2 * d->H || d->OW != 2 * d->W)) {
+            // conv3x3_one_kernel.h, conv3x3_t2_one_kernel: ONE output mode (raw fp32 NHWC + one statistics row per workgroup), full tiles only
+            set_error("conv: tile config 114 (persistent transposed stride-2 tile) needs bf16, cin_stride 64, cout <= %d and %% 4 == 0, raw fp32 NHWC output (16-byte aligned "
+                      "rows), no two-level finalize workspace, H %% %d == 0, W %% %d == 0, OH = 2 H, OW = 2 W", pc->BN, pc->TH, pc->TW);
+            return V2V_EINVAL;
+        }
         k.woff[0] = 0; k.wrow[0] = 9 * d->cin_stride;          // the single full-tap matrix
-        k.fin_rows = 4 * k.m_tiles;                            // every workgroup publishes one statistics row per class
+        k.fin_rows = op->cfg == 114 ? 0 : 4 * k.m_tiles;       // every workgroup publishes one statistics row per class (114: one per workgroup, all classes)
         tile_bm = pc->TH * pc->TW; tile_bn = pc->BN;
     } else if (op->cfg >= 100 && op->cfg < 110) {
         // conv3x3_s2_kernel: 3x3 / stride 2 / pad 1 (zero) Conv2d, channel stride a multiple of the 128-byte chunk, korder-1 weights
@@ -817,7 +825,7 @@ extern "C" int v2v_conv_debug_clocks(void* device_buffer) {
 extern "C" int v2v_conv_stats_rows(const v2v_conv_desc* d) {
     ConvOp op;
     if (build_conv(d, &op, false) != 0) return V2V_EINVAL;
-    if (op.cfg >= 140) return one_grid(op.k.m_tiles * op.k.n_tiles, device_cus());     // persistent tiles: one row per workgroup
+    if (op.cfg >= 140 || op.cfg == 114) return one_grid(op.k.m_tiles * op.k.n_tiles, device_cus());     // persistent tiles: one row per workgroup
     return op.ncls * op.k.m_tiles;
 }
 

@@ -419,13 +419,15 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
 # stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
 S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
 # ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
-T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 64)}
+T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 64),
+           114: (8, 32, 32)}     # 114: persistent, weights resident, single chunk (64 input channels), <= 32 output channels (csrc/conv3x3_one_kernel.h)
 # dense 7x7 / stride 1 / pad 3 convolutions on the single-phase kernel with a 7x7 window (csrc/conv3x3_pp3_kernel.h, KK = 7): id -> (TH, TW, BN).
 # Round 5: validated on the GPU (tests/test_gpu_kernels.py::test_conv7x7_window_tiles), offered to the tile search unless V2V_S7_PATCH=0
 S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
 ONE_TILES = (140, 141, 142, 143)                                # persistent, weights-resident single-chunk tiles (csrc/conv3x3_one_kernel.h)
+PERSISTENT_TILES = ONE_TILES + (114,)                           # ... and the transposed stride-2 one: ONE statistics row per workgroup, finalize in the launch at any size
 ONE_FIN = os.environ.get("V2V_ONE_FIN", "1") != "0"             # ... finalize their <= 256 statistics rows in the launch (0: separate bn_finalize launch, for A/B)
 EXP_TILES = (97, 98, 99, 130, 131, 132, 142, 143)               # (140 / 141: validated and faster -- regular tiles since visits r05_v3 / r05_v6)
 if os.environ.get("V2V_EXP_TILES", "0") == "1":
@@ -841,7 +843,7 @@ class Engine:
             # (not for the 7x7 layers: their halo-patch tiles 60 / 61 have no in-kernel finalize and must stay eligible)
             two_level = bool(fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS and self.fused_finalize2 and rows > 512
                              and pc.KH != 7 and d.tile not in (60, 61))
-            if fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS and not two_level and not (d.tile in ONE_TILES and ONE_FIN):
+            if fin is not None and N * OH * OW > FUSE_FINALIZE_MAX_PIXELS and not two_level and not (d.tile in PERSISTENT_TILES and ONE_FIN):
                 fin = None             # one workgroup walking >1000 rows costs 0.1-1 ms (profiles/r01_v15_finalize_tail.txt)
                                        # (the persistent tiles leave one row per WORKGROUP, <= 256: they finalize in the launch at any size)
             self.last_finalized = fin is not None
