@@ -218,6 +218,18 @@ if has onetest; then
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_onetest.log | cut -c1-300 | tail -25
   lap onetest
 fi
+if has frames; then      # both frame rates, twice
+  for i in 1 2; do
+    timeout 400 python bench.py $LEAN 2>gpurun_out/${TAG}_frames.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('run $i: 512x256', j['value'], 'frames/s | 2048x1024', j.get('hires_value'), 'frames/s | dominant eager', j['roofline'].get('eager_us'), 'live', j['roofline'].get('in_graph_live_us'))"
+  done 2>&1 | tee gpurun_out/${TAG}_frames.txt
+  python - <<PY
+import json
+f = json.load(open("bench_full.json"))
+print("hires per_kernel_ms", f["hires"]["roofline"]["per_kernel_ms"])
+PY
+  lap frames
+fi
 if has t2bench; then
   T2_ONLY=1 timeout 300 python scripts/s2_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_t2_bench.txt | cut -c1-300
   lap t2bench
