@@ -171,7 +171,11 @@ int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t ci
  * cin_stride == 32.  The NHWC tensors [H][W][32] ARE [H][W/2][64] (paired pixel X = pixels 2X, 2X+1); `w` is the korder-1 packing of
  * the 64 -> 64 weight W'[a*32+co][b*32+ci][ky][kX] = W[co][ci][ky][2kX+b-a-1] (zero outside 0..2) that the caller assembled; the
  * descriptor keeps the layer's own geometry (cin <= 32, cin_stride = cout = cout_stride = 32, W even, V2V_OUT_RAW_F32_NHWC), `bias`
- * its 32 values, the statistics rows / finalize record its 32 channels.  Horizontal reflection becomes a clamp inside the kernel. */
+ * its 32 values, the statistics rows / finalize record its 32 channels.  Horizontal reflection becomes a clamp inside the kernel.
+ * Transposed counterpart (tile id 114 when cin_stride == 32): ConvTranspose2d(3x3, s2, p1, op1) with <= 32 input and exactly 16 output
+ * channels (models/networks.py:254-260 at ngf_s = 16) as the 64 -> 32 transposed layer over [H][W/2][64] -> [2H][W][32] whose weight
+ * W3[b*32+ci][e*16+co][ky][kx'] = W[ci][co][ky][kx] (kx = e+1-2b, 3+e-2b, e-1-2b for kx' = 1, 2, 0; zero outside 0..2) the caller packed
+ * with korder 2; descriptor: the layer's own geometry (cin_stride 32, cout = cout_stride = 16, OW = 2 W), 16 bias values, 16 statistics columns. */
 
 /* Number of statistics rows the launch described by `d` writes: n_classes * m_tiles -- except for the persistent tile ids 140..143,
  * which keep their sums in registers across the tiles a workgroup walks and leave ONE row per workgroup (min(tiles, compute units)). */

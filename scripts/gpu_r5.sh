@@ -214,7 +214,7 @@ if has ops; then        # per-op dumps of both resolutions -> per-layer roofline
   lap ops
 fi
 if has onetest; then
-  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "persistent_single_chunk or paired_x or stride2_persistent" -p no:cacheprovider > gpurun_out/${TAG}_onetest.log 2>&1; echo "onetest rc=$?"
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short --timeout 300 -k "persistent_single_chunk or paired_x or stride2_persistent or transposed_persistent" -p no:cacheprovider > gpurun_out/${TAG}_onetest.log 2>&1; echo "onetest rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_onetest.log | cut -c1-300 | tail -25
   lap onetest
 fi

@@ -28,7 +28,8 @@ def timed(run, reps=9):
 
 TSHAPES = [("up 1024->512 @64x32", 1024, 512, 32, 64), ("up 512->256 @128x64", 512, 256, 64, 128), ("up 256->128 @256x128", 256, 128, 128, 256),
            ("fg up 512->256 @64x32", 512, 256, 32, 64), ("fg up 256->128 @128x64", 256, 128, 64, 128), ("fg up 128->64 @256x128", 128, 64, 128, 256),
-           ("s1 up 128->64 @512x256", 128, 64, 256, 512), ("s2 up 64->32 @1024x512", 64, 32, 512, 1024), ("s1 fg up 64->32 @512x256", 64, 32, 256, 512)]
+           ("s1 up 128->64 @512x256", 128, 64, 256, 512), ("s2 up 64->32 @1024x512", 64, 32, 512, 1024), ("s1 fg up 64->32 @512x256", 64, 32, 256, 512),
+           ("s2 fg up 32->16 @1024x512", 32, 16, 512, 1024)]      # 64-byte pixels: tile 114 through the paired-x view (engine.PairedXConvT)
 SHAPES = [("down 128->256 @512x256", 128, 256, 256, 512), ("down 256->512 @256x128", 256, 512, 128, 256),
           ("down 512->1024 @128x64", 512, 1024, 64, 128), ("fg 64->128 @512x256", 64, 128, 256, 512),
           ("fg 128->256 @256x128", 128, 256, 128, 256), ("fg 256->512 @128x64", 256, 512, 64, 128),
@@ -58,8 +59,8 @@ with torch.no_grad():
         x = eng.pack(torch.randn(1, cin, H, W, device="cuda:0"))
         gf = 2.0 * H * W * cout * cin * 9 / 1e9
         out = []
-        for cfg in [(13, 1, 0), (14, 1, 0), (17, 1, 0), (10, 1, 0), (9, 1, 0), (110, 1, 0), (111, 1, 0), (112, 1, 0), (113, 1, 0), (114, 1, 0)]:
-            if os.environ.get("T2_ONLY") and cfg[0] < 110:
+        for cfg in [(4, 1, 0), (13, 1, 0), (14, 1, 0), (17, 1, 0), (10, 1, 0), (9, 1, 0), (110, 1, 0), (111, 1, 0), (112, 1, 0), (113, 1, 0), (114, 1, 0)]:
+            if os.environ.get("T2_ONLY") and cfg[0] < 110 and not (cfg[0] == 4 and cout <= 32):
                 continue
             eng.tile_override[(cin, cout, 3, 2, 1)] = cfg
             try:

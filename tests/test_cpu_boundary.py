@@ -517,6 +517,20 @@ def test_paired_x_view_of_32_channel_layers():
         assert float((unpair(F.conv2d(xpair, px.weight, px.bias, padding=1)) - refz).abs().max()) < 1e-5
     with pytest.raises(ValueError):
         PairedXConv(nn.Conv2d(32, 16, 3))
+    # transposed counterpart: ConvTranspose2d <= 32 -> 16 as the 64 -> 32 transposed layer over paired pixels
+    from vid2vid_amd.engine import PairedXConvT
+    for cin in (32, 25):
+        up = nn.ConvTranspose2d(cin, 16, 3, stride=2, padding=1, output_padding=1).requires_grad_(False)
+        x = torch.randn(2, cin, 6, 8)
+        px = PairedXConvT(up)
+        xp = F.pad(x, (0, 0, 0, 0, 0, 32 - cin))
+        n, c, H, W = xp.shape
+        xpair = xp.permute(0, 2, 3, 1).reshape(n, H, W // 2, 64).permute(0, 3, 1, 2)
+        y = F.conv_transpose2d(xpair, px.weight, px.bias, stride=2, padding=1, output_padding=1)       # [n][32][2H][W]
+        yo = y.permute(0, 2, 3, 1).reshape(n, 2 * H, 2 * W, 16).permute(0, 3, 1, 2)
+        assert float((yo - up(x)).abs().max()) < 1e-5
+    with pytest.raises(ValueError):
+        PairedXConvT(nn.ConvTranspose2d(32, 32, 3, stride=2, padding=1, output_padding=1))
     if torch.cuda.is_available():
         return                                       # the dry-run half is a CPU-host check
     N.set_record_only(True)
@@ -539,6 +553,12 @@ def test_paired_x_view_of_32_channel_layers():
         _, rows, (n_, OH, OW) = eng.conv(eng.pack(torch.randn(1, 64, 512, 1024)), up, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True,
                                          fin=(nn.BatchNorm2d(32), ss))
         assert eng.conv_log[-1]["tile"] == 114 and rows == 256 and (OH, OW) == (1024, 2048) and eng.last_finalized
+        up16 = nn.ConvTranspose2d(32, 16, 3, stride=2, padding=1, output_padding=1)      # 64-byte pixels: the paired-x view of tile 114
+        eng.tile_override[(32, 16, 3, 2, 1)] = (114, 1, 0)
+        ss = torch.zeros(4 * 16)
+        _, rows, (n_, OH, OW) = eng.conv(eng.pack(torch.randn(1, 32, 64, 1024)), up16, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True,
+                                         fin=(nn.BatchNorm2d(16), ss))
+        assert eng.conv_log[-1]["tile"] == 114 and rows == 128 and (OH, OW) == (128, 2048) and eng.last_finalized
         with pytest.raises(RuntimeError):            # 64 output channels: refused
             eng.tile_override[(64, 64, 3, 2, 1)] = (114, 1, 0)
             eng.conv(eng.pack(torch.randn(1, 64, 16, 64)), nn.ConvTranspose2d(64, 64, 3, stride=2, padding=1, output_padding=1), L.PAD_ZERO, None,

@@ -389,6 +389,63 @@ def test_conv_transpose_stride2_persistent_tile(geom):
             eng.conv(eng.pack(torch.randn(1, 64, 16, 64, device=DEV)), conv64, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
 
 
+@pytest.mark.parametrize("geom", [(32, 16, 128, 1), (25, 8, 64, 2), (32, 64, 512, 1), (32, 256, 1024, 1)])
+def test_paired_x_transposed_persistent_tile_on_32_channel_layers(geom):
+    """Tile 114 on a ConvTranspose2d(3x3, s2, p1, op1) with 64-byte pixels (<= 32 -> 16 channels: the finest foreground tower's last
+    up-sampling stage, models/networks.py:254-260 at ngf_s = 16) through the paired-x view (engine.PairedXConvT, w_korder 3): raw output
+    against torch and the generic tile 4 (2e-5 of the output scale), the 16 statistics columns (four accumulator column groups
+    folded), the in-kernel finalize against v2v_bn_finalize; 25 input channels, batch 2, one to two tiles per workgroup."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.engine import _ptr, _stream
+    cin, H, W, N = geom
+    cout = 16
+    torch.manual_seed(cin + H)
+    eng = _engine("bf16")
+    conv = nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.1); conv.bias.normal_(0, 0.5)
+    xs = [torch.randn(N, cin, H, W) * (1.0 + i) for i in range(2)]
+    refs = [F.conv_transpose2d(_round(x, "bf16"), _round(conv.weight.detach(), "bf16"), conv.bias.detach(), stride=2, padding=1, output_padding=1) for x in xs]
+    conv = conv.to(DEV)
+    norm = nn.BatchNorm2d(cout).to(DEV)
+    with torch.no_grad():
+        norm.weight.normal_(1, 0.2); norm.bias.normal_(0, 0.2)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = N * (H // 8) * (W // 64)
+    with torch.no_grad():
+        for x, ref in zip(xs, refs):
+            xa = eng.pack(x.to(DEV))
+            assert xa.Cs == 32
+            got = {}
+            for tile in (4, 114):
+                eng.tile_override[(cin, cout, 3, 2, 1)] = (tile, 1, 0)
+                raw, rows, (n_, OH, OW) = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True)
+                assert eng.conv_log[-1]["tile"] == tile and (OH, OW) == (2 * H, 2 * W)
+                st = eng.scratch("stats", rows * cout * 2)[:rows * cout * 2].clone()
+                got[tile] = (raw[:n_ * OH * OW * cout].clone(), st.view(rows, cout, 2), rows)
+            assert got[114][2] == min(tiles, cus)
+            r = got[114][0].view(N, 2 * H, 2 * W, cout).permute(0, 3, 1, 2)
+            assert_close(r.cpu(), ref, 1e-4, "tile 114 (paired-x) vs torch")
+            assert float((got[114][0] - got[4][0]).abs().max()) <= 2e-5 * float(got[4][0].abs().max()), "tile 114 vs tile 4"
+            col, col4 = got[114][1].double().sum(0), got[4][1].double().sum(0)
+            assert float(((col - col4).abs() / (got[4][1].double().abs().sum(0) + 1e-30)).max()) < 1e-5, "statistics of tile 114 vs tile 4"
+            ss = torch.full((4 * cout,), float("nan"), device=DEV)
+            raw, rows, (n_, OH, OW) = eng.conv(xa, conv, L.PAD_ZERO, None, L.OUT_RAW_F32_NHWC, want_stats=True, fin=(norm, ss))
+            assert eng.last_finalized
+            refss = torch.empty(4 * cout, device=DEV)
+            st = eng.scratch("stats", rows * cout * 2)
+            L.check(lib.v2v_bn_finalize(_ptr(st), rows, cout, n_ * OH * OW, _ptr(norm.weight.detach()), _ptr(norm.bias.detach()),
+                                        norm.eps, _ptr(refss), None, None, 0.1, None, _stream()), "bn_finalize")
+            torch.cuda.synchronize()
+            assert torch.isfinite(ss).all()
+            assert torch.allclose(ss, refss, rtol=1e-6, atol=1e-7), "in-kernel finalize vs bn_finalize: %g" % float((ss - refss).abs().max())
+            assert torch.equal(raw[:n_ * OH * OW * cout], got[114][0])
+            y = ref.double()
+            assert_close(ss[2 * cout:3 * cout].cpu(), y.mean((0, 2, 3)).float(), 1e-3, "mean")
+            assert_close(ss[3 * cout:].cpu(), (1.0 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + norm.eps)).float(), 1e-3, "invstd")
+
+
 # (tile, splitk, prefetch): split-K slices that start mid-tap, the prefetch helper wave on 4- and 8-wave tiles,
 # large wave tiles; cin chosen so that both the uniform tap walk (cs % chunk == 0) and the per-lane walk run
 SPLITK_CFGS = [(2, 2, 0), (2, 3, 12), (3, 4, 12), (13, 2, 12), (13, 1, 12), (17, 3, 12), (1, 2, 0), (5, 4, 12), (7, 1, 4),

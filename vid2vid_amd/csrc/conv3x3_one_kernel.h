@@ -62,14 +62,16 @@ __device__ __forceinline__ void one_stats_finish(const ConvKArgs& p, float s1, f
     __builtin_amdgcn_s_barrier();
     const bool fin = p.fin_counter != nullptr;
     const bool pairx = p.pair_x != 0;
-    const int cs = pairx ? 32 : p.cout;                           // statistics columns (paired-x: accumulator columns c and c + 32 are one channel)
+    const int cs = p.pair_x == 1 ? 32 : p.pair_x == 2 ? 16 : p.cout;   // statistics columns (paired-x views: accumulator columns c, c + cs, .. are one channel)
     if (tid < BN && tid < cs) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid) * 2 + 0]; t2 += red[(q * BN + tid) * 2 + 1]; }
         if (pairx) {
+            for (int c2 = tid + cs; c2 < BN; c2 += cs) {
 #pragma unroll
-            for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + tid + 32) * 2 + 0]; t2 += red[(q * BN + tid + 32) * 2 + 1]; }
+                for (int q = 0; q < WGM; ++q) { t1 += red[(q * BN + c2) * 2 + 0]; t2 += red[(q * BN + c2) * 2 + 1]; }
+            }
         }
         float* const dst = p.stats + ((long long)blockIdx.x * cs + tid) * 2;
         if (fin) {
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(512) void conv3x3_t2_one_kernel(const ConvKArgs p) 
     float* const out = reinterpret_cast<float*>(p.out);
     const unsigned cs_out = (unsigned)p.cout_stride;
     const int OH = p.OH, OW = p.OW;
-    const float bv = (p.bias != nullptr && lr < p.cout) ? p.bias[lr] : 0.f;
+    const float bv = (p.bias != nullptr && lr < p.cout) ? p.bias[p.pair_x ? (lr & 15) : lr] : 0.f;      // (paired-x view: 32 columns = 2 pixels x 16 channels)
     const int vcol = 4 * (lane & 7);
     const bool vfull = vcol + 4 <= p.cout;
     const bool want_stats = p.stats != nullptr;

@@ -486,8 +486,21 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
         dd.cin = 64; dd.cin_stride = 64; dd.cout = 64; dd.cout_stride = 64; dd.w_korder = 1;
         d = &dd;
         pair_x = true;
+    } else if (d->tile == 114 && d->cin_stride == 32) {
+        // ... and the transposed counterpart: ConvTranspose2d <= 32 -> 16 over [H][W][32] as 64 -> 32 over [H][W/2][64], output [2H][2W][16] = [2H][W][32]
+        if (d->dtype != V2V_BF16 || !d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->cin > 32 || d->cout != 16 ||
+            d->cout_stride != 16 || d->out_mode != V2V_OUT_RAW_F32_NHWC || d->w_korder != 3 || (d->W & 1) || d->OW != 2 * d->W || d->OH != 2 * d->H) {
+            set_error("conv: tile config 114 on 64-byte pixels (paired-x view) needs a bf16 ConvTranspose2d(3x3, s2, p1, op1), <= 32 -> exactly 16 channels, "
+                      "dense raw fp32 NHWC output, an even width and paired-x weights (w_korder 3)");
+            return V2V_EINVAL;
+        }
+        dd = *d;
+        dd.W = d->W / 2; dd.OW = d->OW / 2;
+        dd.cin = 64; dd.cin_stride = 64; dd.cout = 32; dd.cout_stride = 32; dd.w_korder = 2;
+        d = &dd;
+        pair_x = true;
     } else if (d->w_korder == 3) {
-        set_error("conv: paired-x weights (w_korder 3) are read by tile configs 140 - 143 on layers with a 32-channel stride only"); return V2V_EINVAL;
+        set_error("conv: paired-x weights (w_korder 3) are read by tile configs 140 - 143 / 114 on layers with a 32-channel stride only"); return V2V_EINVAL;
     }
     if (d->dtype != V2V_F32 && d->dtype != V2V_BF16) { set_error("conv: bad dtype"); return V2V_EINVAL; }
     const int vec = d->dtype == V2V_BF16 ? 8 : 4;
@@ -512,7 +525,7 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
     conv_geom(d->cin_stride, d->cout, d->KH, d->KW, d->transposed, d->stride, d->pad, d->dtype, &g);
     ConvKArgs& k = op->k;
     memset(&k, 0, sizeof(k));
-    k.pair_x = pair_x ? 1 : 0;
+    k.pair_x = pair_x ? (d->transposed ? 2 : 1) : 0;            // 1: statistics columns / bias index = channel & 31, 2 (transposed view): & 15
     k.in = (const char*)d->in; k.w = (const char*)d->w; k.zero_page = (const char*)d->zero_page;
     k.bias = d->bias; k.out = (char*)d->out; k.stats = d->stats;
     k.N = d->N; k.H = d->H; k.W = d->W; k.cin_stride = d->cin_stride;

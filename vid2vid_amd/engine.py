@@ -115,7 +115,7 @@ class PackedConv:
         if korder == 3:
             if role != "fwd" or cin_stride != 32:
                 raise ValueError("paired-x packing: forward operator of a layer with 64-byte pixels")
-            self.src_mod = PairedXConv(mod)
+            self.src_mod = PairedXConvT(mod) if isinstance(mod, nn.ConvTranspose2d) else PairedXConv(mod)
         mod_t = getattr(mod, "is_transposed", isinstance(mod, nn.ConvTranspose2d))
         w = mod.weight
         self.KH, self.KW = mod.kernel_size
@@ -137,7 +137,8 @@ class PackedConv:
         self.out_pad = mod.output_padding[0] if mod_t else 0
         self.cin_stride = cin_stride
         self.dtype = eng.dtype
-        n = (lib.v2v_conv_packed_elems(64, 64, 64, 3, 3, 0, 1, self.pad, eng.dtype) if korder == 3 else
+        n = ((lib.v2v_conv_packed_elems(64, 64, 32, 3, 3, 1, 2, 1, eng.dtype) if mod_t else lib.v2v_conv_packed_elems(64, 64, 64, 3, 3, 0, 1, self.pad, eng.dtype))
+             if korder == 3 else
              lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, self.KH, self.KW,
                                        int(self.transposed), self.stride, self.pad, eng.dtype))
         self.buf = torch.empty(n, dtype=_TORCH_DTYPE[eng.dtype], device=eng.device)
@@ -152,8 +153,12 @@ class PackedConv:
             if not force and ver == self.version:
                 return
             w32 = self.src_mod.weight.contiguous()
-            check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), 64, 64, 64, 3, 3, 0, 1, self.pad, self.dtype, 1, _stream()),
-                  "conv_pack_weights (paired-x)")
+            if self.src_mod.is_transposed:           # 64 -> 32 transposed: the full-tap chunk-major matrix (korder 2) tile 114 reads
+                check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), 64, 64, 32, 3, 3, 1, 2, 1, self.dtype, 2, _stream()),
+                      "conv_pack_weights (paired-x, transposed)")
+            else:
+                check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), 64, 64, 64, 3, 3, 0, 1, self.pad, self.dtype, 1, _stream()),
+                      "conv_pack_weights (paired-x)")
             self.bias = None if self.mod.bias is None else self.mod.bias.detach().float().contiguous()      # the layer's own 32 values (the kernel folds the index)
             self.version = ver
             return
@@ -283,6 +288,44 @@ class PairedXConv:
                     if 0 <= kx <= 2:
                         wp[a, :, b, :cin, :, kX] = w[:, :, :, kx]
         return wp.view(64, 64, 3, 3)
+
+    @property
+    def bias(self):
+        return None if self.src.bias is None else torch.cat([self.src.bias.detach(), self.src.bias.detach()], 0)
+
+
+class PairedXConvT:
+    """The transposed counterpart of PairedXConv: a ConvTranspose2d(3x3, stride 2, padding 1, output_padding 1) with <= 32 input and
+    exactly 16 output channels (models/networks.py:254-260 at ngf_s = 16: the finest foreground tower's last up-sampling stage), seen
+    as a ConvTranspose2d 64 -> 32 over pairs of horizontally adjacent pixels: input [H][W][32] = [H][W/2][64], output [2H][2W][16] =
+    [2H][W][32] (paired output pixel = output pixels 2x', 2x'+1; channel e*16+co), with
+        W3[b*32+ci][e*16+co][ky][kx'] = W[ci][co][ky][kx],   kx = e+1-2b (kx' = 1),  3+e-2b (kx' = 2),  e-1-2b (kx' = 0)
+    (zero where kx falls outside 0..2) -- the persistent transposed tile 114 unchanged."""
+
+    def __init__(self, conv):
+        if not isinstance(conv, nn.ConvTranspose2d) or tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (2, 2) \
+                or tuple(conv.padding) != (1, 1) or tuple(conv.output_padding) != (1, 1) or conv.out_channels != 16 or conv.in_channels > 32 or conv.groups != 1:
+            raise ValueError("paired-x packing: ConvTranspose2d(3x3, s2, p1, op1), <= 32 -> 16 channels")
+        self.src = conv
+        self.is_transposed = True
+        self.kernel_size, self.stride, self.padding, self.groups = conv.kernel_size, conv.stride, conv.padding, conv.groups
+        self.in_channels, self.out_channels = 64, 32
+        self.output_padding = (1, 1)
+
+    def version_key(self):
+        return _param_version(self.src)
+
+    @property
+    def weight(self):
+        w = self.src.weight.detach().float()                     # [cin][16][3][3]
+        cin = w.shape[0]
+        w3 = torch.zeros(2, 32, 2, 16, 3, 3, dtype=torch.float32, device=w.device)      # [b][ci][e][co][ky][kx']
+        for b in range(2):
+            for e in range(2):
+                for kxp, kx in ((1, e + 1 - 2 * b), (2, 3 + e - 2 * b), (0, e - 1 - 2 * b)):
+                    if 0 <= kx <= 2:
+                        w3[b, :cin, e, :, :, kxp] = w[:, :, :, kx]
+        return w3.view(64, 32, 3, 3)
 
     @property
     def bias(self):
@@ -1269,7 +1312,7 @@ class Engine:
         return pc
 
     def _use_korder(self, d, mod, cin_stride, korder, role="fwd", reflect=False):
-        if d.tile in ONE_TILES and cin_stride == 32 and role == "fwd":
+        if d.tile in PERSISTENT_TILES and cin_stride == 32 and role == "fwd":
             korder = 3            # 64-byte pixels on the persistent single-chunk tiles: paired-x packing (PairedXConv; pairx_eligible)
         pc = self.packed(mod, cin_stride, role=role, reflect=reflect, korder=korder)
         d.w, d.w_korder = pc.buf.data_ptr(), korder
@@ -1291,6 +1334,12 @@ class Engine:
         return (self.dtype == L.BF16 and not d.transposed and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1
                 and d.cin_stride == 32 and d.cout == 32 and d.out_mode == L.OUT_RAW_F32_NHWC and d.W % 2 == 0 and (d.W // 2) % 32 == 0
                 and d.H % 8 == 0 and os.environ.get("V2V_PAIRX", "1") != "0")
+
+    def pairx_t_eligible(self, d):
+        """Persistent transposed tile 114 on a layer with 64-byte pixels (<= 32 -> 16 channels): the paired-x view (PairedXConvT)."""
+        return (self.dtype == L.BF16 and bool(d.transposed) and d.KH == 3 and d.KW == 3 and d.stride == 2 and d.pad == 1
+                and d.cin_stride == 32 and d.cout == 16 and d.out_mode == L.OUT_RAW_F32_NHWC and d.W % 2 == 0 and (d.W // 2) % 32 == 0
+                and d.H % 8 == 0 and d.OH == 2 * d.H and d.OW == 2 * d.W and os.environ.get("V2V_PAIRX", "1") != "0")
 
     def s7_eligible(self, d):
         """7x7-window tiles 120 / 121: dense bf16 7x7 / stride 1 / pad 3 Conv2d whose channel stride is a whole number of 128-byte chunks
@@ -1382,6 +1431,8 @@ class Engine:
             for t in ONE_TILES:
                 if t not in EXP_TILES or os.environ.get("V2V_EXP_TILES", "0") == "1":
                     cands.append((t, 1, 0))
+        if mod is not None and role == "fwd" and self.pairx_t_eligible(d) and d.N * (d.H // 8) * (d.W // 64) >= 48:
+            cands.append((114, 1, 0))
         if mod is not None and role == "fwd" and self.s7_eligible(d):
             for t, (th, tw, bn) in sorted(S7_CFGS.items()):
                 tiles = d.N * -(-d.OH // th) * -(-d.OW // tw) * -(-cout // bn)
