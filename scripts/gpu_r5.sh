@@ -230,6 +230,11 @@ print("hires per_kernel_ms", f["hires"]["roofline"]["per_kernel_ms"])
 PY
   lap frames
 fi
+if has ohtest; then
+  timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 300 -k "onehot or encode_labels or inference_api_vs_reference or composite_generator" -p no:cacheprovider > gpurun_out/${TAG}_ohtest.log 2>&1; echo "ohtest rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_ohtest.log | cut -c1-300 | tail -25
+  lap ohtest
+fi
 if has t2bench; then
   T2_ONLY=1 timeout 300 python scripts/s2_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_t2_bench.txt | cut -c1-300
   lap t2bench

@@ -1372,7 +1372,7 @@ def test_encode_labels_few_classes(nc, use_inst, prec):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(64, 37, 70, True, 0), (128, 40, 96, True, 64), (128, 40, 96, False, 32), (48, 19, 33, True, 64),
-                                  (100, 64, 64, False, 0)])
+                                  (100, 64, 64, False, 0), (16, 37, 70, True, 0), (12, 24, 40, False, 0)])     # <= 16 channels: 16-wide slices by default (round 5)
 @torch.no_grad()
 def test_onehot_stem_equals_dense_conv_on_the_encoding(case, prec):
     """csrc/onehot_stem.hip: the 7x7 reflection-padded stem over encoded label maps as a weight gather-sum.  Checked
@@ -1412,6 +1412,11 @@ def test_onehot_stem_equals_dense_conv_on_the_encoding(case, prec):
         if u8:
             assert torch.equal(got, first)
         first = got
+    if cout <= 16 and slice_ == 0:                          # 16-channel slices (the default at this width) vs 32-channel slices: the same bits
+        eng.onehot_slice = 32
+        raw32, rows32, _ = eng.onehot_conv(x, conv, label="stem")
+        assert rows32 == rows and torch.equal(raw32[:H * W * cs].view(H, W, cs)[..., :cout].permute(2, 0, 1).cpu(), first)
+        eng.onehot_slice = 0
     # the 1-byte label | edge map (v2v_label_codes) the frame plan stages the stems from: same result bit for bit
     assert x.onehot.codes is None
     assert eng.label_codes(x.onehot, H, W) is not None
