@@ -235,6 +235,13 @@ if has ohtest; then
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_ohtest.log | cut -c1-300 | tail -25
   lap ohtest
 fi
+if has ohab; then       # one-hot stems: the previous epilogue (one pass, 37.8 KB of LDS, 32-wide slices only) vs the tree's, alternating on this box
+  for i in 1 2 3; do
+    V2V_LIB_PATH=$R/vid2vid_amd/libv2v_hip_oldoh.so timeout 120 python scripts/onehot_ab.py 2>&1 | grep -v amdgpu.ids
+    timeout 120 python scripts/onehot_ab.py 2>&1 | grep -v amdgpu.ids
+  done | tee gpurun_out/${TAG}_ohab.txt
+  lap ohab
+fi
 if has t2bench; then
   T2_ONLY=1 timeout 300 python scripts/s2_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_t2_bench.txt | cut -c1-300
   lap t2bench

@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 }
 
 constexpr int OS_TH = 8, OS_TW = 32, OS_PH = OS_TH + 6, OS_PW = OS_TW + 6, OS_PHW = OS_PH * OS_PW;
-constexpr size_t OS_EPI_LDS = (128 * 33 + 8 * 32 * 2 + 4) * sizeof(float);    // epilogue tile (half of the pixels at a time) + partial sums + finalize flag
+constexpr size_t OS_EPI_LDS = (256 * 33 + 8 * 32 * 2 + 4) * sizeof(float);    // epilogue tile + partial sums + finalize flag
 
 __host__ __device__ constexpr int os_rowb(int cs, int es) { return cs * es + 16; }
 __host__ __device__ inline int os_blob(int rows, int cs, int es) { return ((rows + 1) * os_rowb(cs, es) + 1023) / 1024 * 1024; }
@@ -230,94 +230,87 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
         for (int c = 0; c < CS; ++c) acc[c] += c0 + c < a.cout ? a.bias[c0 + c] : 0.f;
     }
     __syncthreads();                                       // the table buffers are free
-    // The tile passes LDS in two HALVES of 128 pixels (waves 0-1, then waves 2-3): [128 pixels][33] fp32 = 17 KB instead of 34 KB, which
-    // was what set the workgroup's LDS footprint (37.8 KB: 4 workgroups = 4 waves per SIMD on a CU; now 26.8 KB: 6).  Same values, same
-    // summation order of the statistics (8 parts of 32 pixels in order, parts 0-3 from the first half) as the one-pass epilogue.
-    float* const tile = reinterpret_cast<float*>(smem);    // [128 pixels][33]: stride 33 keeps the per-pixel writes conflict-free
-    float* const red = tile + 128 * 33;                    // [8 parts][32][2]
+    float* const tile = reinterpret_cast<float*>(smem);    // [256 pixels][33]: stride 33 keeps the per-pixel writes conflict-free
+    float* const red = tile + 256 * 33;                    // [8 parts][32][2]
     const bool valid = oh0 + py < H && ow0 + px < W;
+    const bool ragged = oh0 + OS_TH > H || ow0 + OS_TW > W;
     const bool do_emfma = use_emfma && *eflag != 0;        // no edge pixel in the tile + halo: nothing to add
-    constexpr int NCH = (CS + 31) / 32, CW = CS < 32 ? CS : 32;       // 32-channel chunks of the slice; real channels per chunk
+    constexpr int NCH = (CS + 31) / 32, CW = CS < 32 ? CS : 32;       // 32-channel chunks of the slice; real channels per chunk (16-channel slices: 16)
+    // (round 5 tried the tile in two halves of 128 pixels -- 26.8 KB of LDS per workgroup, 6 instead of 4 workgroups per CU: 6-13 % SLOWER on
+    //  the 512x256 stems, profiles/r05_v16_ohab.txt: occupancy is not what this kernel lacks)
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool mine = (wid >> 1) == h;             // wave-uniform: this wave's 64 pixels are in this half
-            const int lrow = tid & 127;
-            __syncthreads();                               // the tile is free (first round: the table buffers; later: the previous half's readers)
-            if (mine) {
+        for (int i = 0; i < CW; ++i) tile[tid * 33 + i] = acc[k * 32 + i];
+        if constexpr (ES == 2) {
+            if (do_emfma) {
+                // edge planes of this 32-channel chunk: E[pixel][c] = sum_k e[pixel][k] W_edge[k][c], k = (frame, tap), as
+                // v_mfma_f32_32x32x16_bf16: A = 0 / 1 edge bits of the wave's 2 x 32 pixels gathered from LDS, B = the packed
+                // edge-row fragments (global, L2-resident), C added to the pixel-major tile (one owner lane per element)
+                f32x16_t cm[2];
 #pragma unroll
-                for (int i = 0; i < CW; ++i) tile[lrow * 33 + i] = acc[k * 32 + i];
-            }
-            if constexpr (ES == 2) {
-                if (do_emfma) {
-                    // edge planes of this 32-channel chunk: E[pixel][c] = sum_k e[pixel][k] W_edge[k][c], k = (frame, tap), as
-                    // v_mfma_f32_32x32x16_bf16: A = 0 / 1 edge bits of 32 of the wave's pixels gathered from LDS, B = the packed
-                    // edge-row fragments (global, L2-resident), C added to the pixel-major tile (one owner lane per element).
-                    // One 32-pixel row at a time (16 accumulator registers live beside the wave's own: no spills at 6 waves per SIMD).
-                    __syncthreads();                       // every thread's own accumulators are in the tile
-                    if (mine) {
-                        const int kg = lane >> 5;
-                        const char* bsrc = a.etab + (((long long)blockIdx.y * NCH + k) * a.ksteps * 64 + lane) * 16;
-#pragma unroll 1
-                        for (int m = 0; m < 2; ++m) {
-                            f32x16_t cm;
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) cm[r] = 0.f;
-                            const int qm = (2 * wid + m) * OS_PW + (lane & 31);
-                            for (int ks = 0; ks < a.ksteps; ++ks) {
-                                const bf16x8_t bfrag = *reinterpret_cast<const bf16x8_t*>(bsrc + (long long)ks * 64 * 16);
-                                const uint4 ko = *reinterpret_cast<const uint4*>(koff_s + ks * 16 + kg * 8);
-                                const unsigned kk[8] = {ko.x & 0xffffu, ko.x >> 16, ko.y & 0xffffu, ko.y >> 16, ko.z & 0xffffu, ko.z >> 16, ko.w & 0xffffu, ko.w >> 16};
-                                unsigned w4[4];
+                    for (int r = 0; r < 16; ++r) cm[m][r] = 0.f;
+                const int kg = lane >> 5;
+                const char* bsrc = a.etab + (((long long)blockIdx.y * NCH + k) * a.ksteps * 64 + lane) * 16;
+                const int qm0 = (2 * wid) * OS_PW + (lane & 31);
+                for (int ks = 0; ks < a.ksteps; ++ks) {
+                    const bf16x8_t bfrag = *reinterpret_cast<const bf16x8_t*>(bsrc + (long long)ks * 64 * 16);
+                    const uint4 ko = *reinterpret_cast<const uint4*>(koff_s + ks * 16 + kg * 8);
+                    const unsigned kk[8] = {ko.x & 0xffffu, ko.x >> 16, ko.y & 0xffffu, ko.y >> 16, ko.z & 0xffffu, ko.z >> 16, ko.w & 0xffffu, ko.w >> 16};
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const unsigned lo = kk[2 * j] != 0xffffu && ebit_s[kk[2 * j] + qm] ? 0x3f80u : 0u;
-                                    const unsigned hi = kk[2 * j + 1] != 0xffffu && ebit_s[kk[2 * j + 1] + qm] ? 0x3f800000u : 0u;
-                                    w4[j] = lo | hi;
-                                }
-                                const uint4 au = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                                cm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, au), bfrag, cm, 0, 0, 0);
-                            }
+                    for (int m = 0; m < 2; ++m) {
+                        const int qm = qm0 + m * OS_PW;
+                        unsigned w4[4];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int prow = 8 * (r >> 2) + 4 * kg + (r & 3);      // C layout of the 32x32 MFMA: row, col = lane & 31
-                                if ((lane & 31) < CW) tile[((wid & 1) * 64 + m * 32 + prow) * 33 + (lane & 31)] += cm[r];
-                            }
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned lo = kk[2 * j] != 0xffffu && ebit_s[kk[2 * j] + qm] ? 0x3f80u : 0u;
+                            const unsigned hi = kk[2 * j + 1] != 0xffffu && ebit_s[kk[2 * j + 1] + qm] ? 0x3f800000u : 0u;
+                            w4[j] = lo | hi;
                         }
+                        const uint4 au = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        cm[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, au), bfrag, cm[m], 0, 0, 0);
                     }
                 }
-            }
-            __syncthreads();
-            if (mine && !valid) {                          // pixels beyond the image: out of the statistics
+                __syncthreads();                           // every thread's own accumulators are in the tile
 #pragma unroll
-                for (int i = 0; i < CW; ++i) tile[lrow * 33 + i] = 0.f;
-            }
-            __syncthreads();
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {               // 8 lanes x float4 = the 128 bytes of one pixel's chunk
-                const int idx = it * 256 + tid;
-                const int pl = idx >> 3, c4 = (idx & 7) * 4;
-                const int p = h * 128 + pl;
-                const int oh = oh0 + (p >> 5), ow = ow0 + (p & 31);
-                const int c = c0 + k * 32 + c4;
-                if (oh < H && ow < W && c4 < CW && c < a.cout) {
-                    float* op = a.out + ((long long)oh * W + ow) * a.cout_stride + c;
-                    const float* tp = tile + pl * 33 + c4;
-                    if (c + 4 <= a.cout && (a.cout_stride & 3) == 0) *reinterpret_cast<float4*>(op) = make_float4(tp[0], tp[1], tp[2], tp[3]);
-                    else for (int e = 0; e < 4 && c + e < a.cout; ++e) op[e] = tp[e];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int prow = 8 * (r >> 2) + 4 * kg + (r & 3);          // C layout of the 32x32 MFMA: row, col = lane & 31
+                        if ((lane & 31) < CW) tile[(wid * 64 + m * 32 + prow) * 33 + (lane & 31)] += cm[m][r];
+                    }
             }
-            if (a.stats && (tid >> 7) == h) {              // thread (channel tid & 31, part tid >> 5): 32 pixels in order
-                const int c = tid & 31, part = tid >> 5;
-                float s1 = 0.f, s2 = 0.f;
-                if (c < CW) {
+        }
+        __syncthreads();
+        if (!valid) {                                      // pixels beyond the image: out of the statistics
+#pragma unroll
+            for (int i = 0; i < CW; ++i) tile[tid * 33 + i] = 0.f;
+        }
+        if (ragged) __syncthreads();                       // (uniform: the tile overhangs the image)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                   // 8 lanes x float4 = the 128 bytes of one pixel's chunk
+            const int idx = it * 256 + tid;
+            const int p = idx >> 3, c4 = (idx & 7) * 4;
+            const int oh = oh0 + (p >> 5), ow = ow0 + (p & 31);
+            const int c = c0 + k * 32 + c4;
+            if (oh < H && ow < W && c4 < CW && c < a.cout) {
+                float* op = a.out + ((long long)oh * W + ow) * a.cout_stride + c;
+                const float* tp = tile + p * 33 + c4;
+                if (c + 4 <= a.cout && (a.cout_stride & 3) == 0) *reinterpret_cast<float4*>(op) = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                else for (int e = 0; e < 4 && c + e < a.cout; ++e) op[e] = tp[e];
+            }
+        }
+        if (a.stats) {                                     // thread (channel tid & 31, part tid >> 5): 32 pixels in order
+            const int c = tid & 31, part = tid >> 5;
+            float s1 = 0.f, s2 = 0.f;
+            if (c < CW) {
 #pragma unroll 8
-                    for (int i = 0; i < 32; ++i) { const float v = tile[((part & 3) * 32 + i) * 33 + c]; s1 += v; s2 += v * v; }
-                }
-                red[(part * 32 + c) * 2] = s1;
-                red[(part * 32 + c) * 2 + 1] = s2;
+                for (int i = 0; i < 32; ++i) { const float v = tile[(part * 32 + i) * 33 + c]; s1 += v; s2 += v * v; }
             }
+            red[(part * 32 + c) * 2] = s1;
+            red[(part * 32 + c) * 2 + 1] = s2;
         }
         __syncthreads();
         if (a.stats && tid < CW && c0 + k * 32 + tid < a.cout) {
