@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256, CS == 64 ? 4 : 6) void onehot_conv7x7_kernel(c
     const bool do_emfma = use_emfma && *eflag != 0;        // no edge pixel in the tile + halo: nothing to add
     constexpr int NCH = (CS + 31) / 32, CW = CS < 32 ? CS : 32;       // 32-channel chunks of the slice; real channels per chunk (16-channel slices: 16)
     // (round 5 tried the tile in two halves of 128 pixels -- 26.8 KB of LDS per workgroup, 6 instead of 4 workgroups per CU: 6-13 % SLOWER on
-    //  the 512x256 stems, profiles/r05_v16_ohab.txt: occupancy is not what this kernel lacks)
+    //  the 512x256 stems, profiles/r05_v16_ohab.txt: occupancy is not what this kernel lacks; and a third table buffer -- the blob of tap
+    //  t + 2 in flight, counted vmcnt, raw s_barrier: 2-4 % slower, profiles/r05_v18_ohab.txt: nor is the blob's latency)
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
 #pragma unroll
