@@ -342,7 +342,9 @@ int v2v_encode_labels_u8(const uint8_t* labels, const int32_t* inst, void* out, 
 /* encode_input + get_edges + ONE level of build_pyr (AvgPool2d(3, 2, 1, count_include_pad=False), base_model.py:122-134) straight
  * from the label / instance maps (fp32-encoded integers, or uint8 / int32 with maps_u8): out is NHWC [(H-1)/2+1][(W-1)/2+1][c_stride],
  * bit-identical to v2v_avgpool3s2_nhwc of the v2v_encode_labels output, which is never materialised; mask (optional) is the
- * FULL-resolution foreground mask [H][W] as v2v_encode_labels writes it. */
+ * FULL-resolution foreground mask [H][W] as v2v_encode_labels writes it.
+ * maps_u8 == 2: `labels` are the [T][H][W] 1-byte codes of v2v_label_codes (label | edge << 7; label_nc <= 126); `inst` is not read,
+ * non-NULL says that the frames carry an edge channel.  Same output bit for bit, nine independent byte loads per frame and thread. */
 int v2v_encode_labels_pooled(const void* labels, const void* inst, void* out, float* mask,
                              int32_t T, int32_t H, int32_t W, int32_t label_nc, int32_t c_stride,
                              const int32_t* fg_labels_dev, int32_t n_fg, int32_t dtype, int32_t maps_u8, void* stream);

@@ -231,7 +231,7 @@ PY
   lap frames
 fi
 if has ohtest; then
-  timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 300 -k "onehot or encode_labels or inference_api_vs_reference or composite_generator" -p no:cacheprovider > gpurun_out/${TAG}_ohtest.log 2>&1; echo "ohtest rc=$?"
+  timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 300 -k "onehot or encode_labels or inference_api_vs_reference or composite_generator or three_scales or uint8_labels" -p no:cacheprovider > gpurun_out/${TAG}_ohtest.log 2>&1; echo "ohtest rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_ohtest.log | cut -c1-300 | tail -25
   lap ohtest
 fi

@@ -1743,6 +1743,20 @@ def test_encode_labels_pooled_equals_pooling_the_encoding(size, u8, prec):
     assert p2.t.shape == pooled.t.shape and p2.C == pooled.C and x0.onehot is not None and x0.t.shape == x.t.shape
     assert torch.equal(p2.t, pooled.t), "pooled encoding differs from pooling the encoding"
     assert torch.equal(mask2, mask)
+    # round 5: from the 1-byte label | edge codes the frame plan computes first for the gather-sum stems (v2v_label_codes): the same bits
+    from vid2vid_amd.engine import LabelSource
+    src = LabelSource(labd, instd, T, nc)
+    assert eng.label_codes(src, H, W) is not None
+    x0c, p3, mask3 = eng.encode_labels_pooled(labd, instd, T, H, W, nc, [26, 3], True, chunk_stride=True, source=src)
+    assert eng.conv_log is not None and torch.equal(p3.t, pooled.t), "pooled encoding from the codes differs"
+    assert torch.equal(mask3, mask)
+    lab_out = lab.clone(); lab_out[0, :1, :2] = 200 if u8 else 300              # out-of-range ids: no plane is hot, on both paths
+    labo = lab_out.to(torch.uint8).to(DEV) if u8 else lab_out.float().to(DEV)
+    src2 = LabelSource(labo, instd, T, nc)
+    eng.label_codes(src2, H, W)
+    _, p4, _ = eng.encode_labels_pooled(labo, instd, T, H, W, nc, [26, 3], True, chunk_stride=True, source=src2)
+    _, p5, _ = eng.encode_labels_pooled(labo, instd, T, H, W, nc, [26, 3], True, chunk_stride=True)
+    assert torch.equal(p4.t, p5.t)
     enc = O.encode_input(lab.float().view(1, T, 1, H, W), inst.float().view(1, T, 1, H, W), nc).reshape(1, -1, H, W)
     ref = F.avg_pool2d(enc, 3, 2, 1, count_include_pad=False)
     assert_close(eng.unpack(p2).cpu(), ref, 1e-6 if prec == "fp32" else 4e-3, "pooled encoding vs torch")

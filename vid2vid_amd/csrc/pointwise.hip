@@ -195,13 +195,101 @@ __global__ __launch_bounds__(256) void encode_labels_pooled_kernel(const EncodeA
     }
 }
 
+// The same from the 1-byte label | edge << 7 codes (v2v_label_codes; 127 = no label plane) that the frame plan computes first for the
+// gather-sum stems (round 5).  The kernel above walks its window with one dependent load after another -- a label load, five
+// instance-map loads for an edge channel, a data-dependent add, the next pixel: ~30 us of serialized latency per thread, 394 us for
+// the 1024x512 level of the 2048x1024 frame (HBM bound of its 117 MB output: 20 us).  Here the nine codes of a frame's window are nine
+// INDEPENDENT byte loads from clamped coordinates (the edge tests were done once per pixel by v2v_label_codes), then arithmetic only.
+// Same counts, same division: bit-identical output.  a.labels = the codes; a.inst != NULL only says "the frames have an edge channel".
+template <typename T>
+__global__ __launch_bounds__(256) void encode_codes_pooled_kernel(const EncodeArgs a) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int OH = (a.H - 1) / 2 + 1, OW = (a.W - 1) / 2 + 1;
+    const unsigned vpr = (unsigned)(a.c_stride / VEC);
+    const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+    const unsigned nvec = (unsigned)OH * (unsigned)OW * vpr;
+    const int per_frame = a.label_nc + (a.inst ? 1 : 0);
+    const unsigned stride = gridDim.x * blockDim.x;
+    const unsigned char* const codes = reinterpret_cast<const unsigned char*>(a.labels);
+    T* out = reinterpret_cast<T*>(a.out);
+    for (unsigned v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        const unsigned opix = v / vpr;
+        const int c0 = (int)(v - opix * vpr) * VEC;
+        const int oy = (int)(opix / (unsigned)OW), ox = (int)(opix - (unsigned)oy * (unsigned)OW);
+        const int y0 = max(2 * oy - 1, 0), y1 = min(2 * oy + 1, a.H - 1), x0 = max(2 * ox - 1, 0), x1 = min(2 * ox + 1, a.W - 1);
+        // the 3 x 3 window as clamped coordinates + validity: rows 2 oy - 1 .. 2 oy + 1 (the first may be outside, the last two may be)
+        unsigned rowo[3], colo[3];
+        bool rv[3], cv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int y = 2 * oy - 1 + j, x = 2 * ox - 1 + j;
+            rv[j] = y >= 0 && y < a.H;
+            cv[j] = x >= 0 && x < a.W;
+            rowo[j] = (unsigned)min(max(y, 0), a.H - 1) * (unsigned)a.W;
+            colo[j] = (unsigned)min(max(x, 0), a.W - 1);
+        }
+        const int t_first = c0 / per_frame, t_last = min((c0 + VEC - 1) / per_frame, a.T - 1);
+        unsigned long long acc = 0ull;
+        for (int t = t_first; t <= t_last; ++t) {
+            const unsigned char* const cp = codes + (unsigned)t * hw;
+            unsigned code[9];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) code[j * 3 + i] = cp[rowo[j] + colo[i]];
+            const int base = t * per_frame - c0;                  // field of the frame's channel 0 inside this vector
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const unsigned cd = code[j * 3 + i];
+                    const bool ok = rv[j] && cv[i];
+                    const int lab = (int)(cd & 127u);
+                    const int fl = base + lab;
+                    if (ok && lab < a.label_nc && fl >= 0 && fl < VEC) acc += 1ull << (8 * fl);
+                    const int fe = base + a.label_nc;
+                    if (ok && a.inst != nullptr && (cd & 128u) && fe >= 0 && fe < VEC) acc += 1ull << (8 * fe);
+                }
+        }
+        const int cnt = (y1 - y0 + 1) * (x1 - x0 + 1);
+        float sv[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) sv[q] = (float)((acc >> (8 * q)) & 0xffull);
+        const float fc = (float)cnt;
+        T* const o = out + (size_t)opix * a.c_stride + c0;
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(sv[0] / fc, sv[1] / fc, sv[2] / fc, sv[3] / fc);
+        } else {
+            uint4 pk;
+            pk.x = pack_bf16x2(sv[0] / fc, sv[1] / fc);
+            pk.y = pack_bf16x2(sv[2] / fc, sv[3] / fc);
+            pk.z = pack_bf16x2(sv[4] / fc, sv[5] / fc);
+            pk.w = pack_bf16x2(sv[6] / fc, sv[7] / fc);
+            *reinterpret_cast<uint4*>(o) = pk;
+        }
+        if (a.mask && c0 == 0) {
+            // compute_mask (models/vid2vid_model_G.py:322-330) on the last frame, FULL resolution: the 2 x 2 pixels this output pixel owns
+            for (int yy = 2 * oy; yy < min(2 * oy + 2, a.H); ++yy)
+                for (int xx = 2 * ox; xx < min(2 * ox + 2, a.W); ++xx) {
+                    const int lab = (int)(codes[(unsigned)(a.T - 1) * hw + (unsigned)yy * (unsigned)a.W + (unsigned)xx] & 127u);
+                    float m = 0.f;
+                    for (int i = 0; i < a.n_fg; ++i) m += (a.fg[i] == lab) ? 1.f : 0.f;
+                    a.mask[(unsigned)yy * (unsigned)a.W + (unsigned)xx] = fminf(fmaxf(m, 0.f), 1.f);
+                }
+        }
+    }
+}
+
 struct EncodePooledOp : Op {
     EncodeArgs a; int dtype; int in_u8 = 0;
     int launch(hipStream_t s) override {
         const int vec = dtype == V2V_BF16 ? 8 : 4;
         const long long nvec = (long long)((a.H - 1) / 2 + 1) * ((a.W - 1) / 2 + 1) * (a.c_stride / vec);
         const dim3 g(grid_for(nvec, 256, 16384)), b(256);
-        if (in_u8) {
+        if (in_u8 == 2) {
+            if (dtype == V2V_BF16) hipLaunchKernelGGL((encode_codes_pooled_kernel<bf16_t>), g, b, 0, s, a);
+            else                   hipLaunchKernelGGL((encode_codes_pooled_kernel<float>), g, b, 0, s, a);
+        } else if (in_u8) {
             if (dtype == V2V_BF16) hipLaunchKernelGGL((encode_labels_pooled_kernel<bf16_t, unsigned char, int>), g, b, 0, s, a);
             else                   hipLaunchKernelGGL((encode_labels_pooled_kernel<float, unsigned char, int>), g, b, 0, s, a);
         } else {
@@ -917,13 +1005,14 @@ extern "C" int v2v_encode_labels_pooled(const void* labels, const void* inst, vo
     const int vec = dtype == V2V_BF16 ? 8 : 4;
     const int need = T * (label_nc + (inst ? 1 : 0));
     if (!labels || !out || T < 1 || H < 1 || W < 1 || label_nc < 1 || c_stride % vec != 0 || need > c_stride || (maps_u8 && label_nc > 256) ||
-        (mask && n_fg > 0 && !fg_labels_dev) || ((uintptr_t)out & 15) != 0 || ((uintptr_t)inst & 3) != 0 ||
+        maps_u8 < 0 || maps_u8 > 2 || (maps_u8 == 2 && label_nc > 126) ||
+        (mask && n_fg > 0 && !fg_labels_dev) || ((uintptr_t)out & 15) != 0 || (maps_u8 != 2 && ((uintptr_t)inst & 3) != 0) ||
         (long long)T * H * W >= (1ll << 31) || (long long)((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (c_stride / vec) >= (1ll << 31)) {
         set_error("encode_labels_pooled: bad argument"); return V2V_EINVAL;
     }
     auto op = std::make_unique<EncodePooledOp>();
     op->a = EncodeArgs{labels, inst, out, mask, T, H, W, label_nc, c_stride, fg_labels_dev, n_fg};
-    op->dtype = dtype; op->in_u8 = maps_u8 ? 1 : 0;
+    op->dtype = dtype; op->in_u8 = maps_u8;
     return submit(std::move(op), stream);
 }
 

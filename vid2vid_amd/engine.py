@@ -1778,8 +1778,16 @@ class Engine:
             raise TypeError("uint8 label maps go with int32 instance maps")
         if not u8 and (labels.dtype != torch.float32 or (inst is not None and inst.dtype != torch.float32)):
             raise TypeError("label / instance maps must be fp32-encoded integers, or uint8 + int32")
-        check(lib.v2v_encode_labels_pooled(_ptr(labels), _ptr(inst), _ptr(pooled), _ptr(mask), T, H, W, label_nc, cs, _ptr(fg),
-                                           0 if fg is None else fg.numel(), self.dtype, int(u8), _stream()), "encode_labels_pooled")
+        codes = getattr(source, "codes", None) if source is not None else None
+        if codes is not None and os.environ.get("V2V_POOLED_FROM_CODES", "1") != "0":
+            # the frame plan has the 1-byte label | edge codes already (label_codes, for the gather-sum stems): nine independent byte
+            # loads per frame instead of a chain of label / instance-map loads (394 -> see profiles/r05_*): same bits
+            self._keep(codes)
+            check(lib.v2v_encode_labels_pooled(_ptr(codes), _ptr(inst), _ptr(pooled), _ptr(mask), T, H, W, label_nc, cs, _ptr(fg),
+                                               0 if fg is None else fg.numel(), self.dtype, 2, _stream()), "encode_labels_pooled (codes)")
+        else:
+            check(lib.v2v_encode_labels_pooled(_ptr(labels), _ptr(inst), _ptr(pooled), _ptr(mask), T, H, W, label_nc, cs, _ptr(fg),
+                                               0 if fg is None else fg.numel(), self.dtype, int(u8), _stream()), "encode_labels_pooled")
         self.label("encode_labels_pooled")
         x0 = Act(lazy, T * per)
         x0.onehot = source if source is not None else LabelSource(labels, inst, T, label_nc)
