@@ -209,7 +209,7 @@ if has bntest; then
 fi
 if has ops; then        # per-op dumps of both resolutions -> per-layer roofline tables (every conv alone on the chip)
   timeout 600 python bench.py $LEAN --dump-ops gpurun_out/${TAG}_ops_bf16.json > gpurun_out/${TAG}_benchq.json 2> gpurun_out/${TAG}_benchq.err; echo "benchq rc=$?"
-  python scripts/per_layer_roofline.py gpurun_out/${TAG}_ops_bf16.json > gpurun_out/${TAG}_per_layer_roofline.txt 2>&1; tail -3 gpurun_out/${TAG}_per_layer_roofline.txt | cut -c1-300
+  # (the 512x256 table joins the dump with a record-only census: run  python scripts/per_layer_roofline.py gpurun_out/${TAG}_ops_bf16.json  on a CPU host afterwards)
   python scripts/per_layer_roofline_hires.py gpurun_out/${TAG}_ops_bf16.json.hires.json > gpurun_out/${TAG}_per_layer_roofline_hires.txt 2>&1; tail -3 gpurun_out/${TAG}_per_layer_roofline_hires.txt | cut -c1-600
   lap ops
 fi
