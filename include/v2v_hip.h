@@ -177,8 +177,10 @@ int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t ci
  * W3[b*32+ci][e*16+co][ky][kx'] = W[ci][co][ky][kx] (kx = e+1-2b, 3+e-2b, e-1-2b for kx' = 1, 2, 0; zero outside 0..2) the caller packed
  * with korder 2; descriptor: the layer's own geometry (cin_stride 32, cout = cout_stride = 16, OW = 2 W), 16 bias values, 16 statistics columns. */
 
-/* Number of statistics rows the launch described by `d` writes: n_classes * m_tiles -- except for the persistent tile ids 140..143,
- * which keep their sums in registers across the tiles a workgroup walks and leave ONE row per workgroup (min(tiles, compute units)). */
+/* Number of statistics rows the launch described by `d` writes: n_classes * m_tiles -- except for the persistent tile ids 140..143 and
+ * 114, which keep their sums in registers across the tiles (114: and the four parity classes) a workgroup walks and leave ONE row per
+ * workgroup (min(tiles, compute units)); with fin_counter they also write the scale / shift record themselves (last workgroup), at any
+ * layer size. */
 int     v2v_conv_stats_rows(const v2v_conv_desc* d);
 /* Bytes of `slabs` scratch (and number of `sk_counter` ints via *tickets) the launch needs; 0 when splitk <= 1. */
 int64_t v2v_conv_splitk_workspace(const v2v_conv_desc* d, int32_t* tickets);
