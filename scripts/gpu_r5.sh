@@ -242,6 +242,12 @@ if has ohab; then       # one-hot stems: the previous epilogue (one pass, 37.8 K
   done | tee gpurun_out/${TAG}_ohab.txt
   lap ohab
 fi
+if has c8; then         # head_epilogue's raw path with 16-byte stores: tiles 60 / 61 (tests + micro-benchmark)
+  timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_golden.py -m gpu -q -rf --tb=short --timeout 300 -k "conv7x7 or head or c8 or raw_stats or first_frame or composite_local or three_scales" -p no:cacheprovider > gpurun_out/${TAG}_c8test.log 2>&1; echo "c8test rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_c8test.log | cut -c1-300 | tail -25
+  timeout 200 python scripts/c8_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_c8_bench.txt | cut -c1-300
+  lap c8
+fi
 if has t2bench; then
   T2_ONLY=1 timeout 300 python scripts/s2_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_t2_bench.txt | cut -c1-300
   lap t2bench

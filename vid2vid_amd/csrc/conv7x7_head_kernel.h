@@ -50,6 +50,53 @@ __device__ __forceinline__ void head_epilogue(const ConvKArgs& p, f32x4 (&acc)[4
     const int H = p.H, W = p.W;
     const bool raw_mode = p.out_mode == V2V_OUT_RAW_F32_NHWC;
     const long long hw = (long long)H * W;
+    // Round 5: raw fp32 NHWC output leaves with 16-BYTE stores through a wave-private LDS block (one tile row of 32 pixels x up to 32
+    // channels at a time: [32][36] fp32 = 4.5 KiB per wave), as in every other convolution kernel of the library.  The element-wise path
+    // below writes 4 bytes per lane, 64-byte runs at a 128-byte pitch: 268 MB of the 6 -> 32 stem at 2048x1024 as 67 M four-byte stores
+    // (173 us for 47 us of HBM time).  Same values, the statistics are summed from the registers in the same order: bit-identical.
+    // (wave-uniform condition; whole float4 groups are valid or invalid together when cout % 4 == 0)
+    const bool fast_raw = raw_mode && (p.cout & 3) == 0 && (p.cout_stride & 3) == 0 && (((unsigned long long)p.out) & 15ull) == 0 && !(p.ablate & 4);
+    if (fast_raw) {
+        const int lane = tid & 63;
+        __syncthreads();                                              // the patch is dead: LDS becomes scratch
+        float* const tw = reinterpret_cast<float*>(smem) + wid * (32 * 36);
+        float* const outp = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int oh = oh0 + 2 * wid + h;
+#pragma unroll
+            for (int n2 = 0; n2 < (NT + 1) / 2; ++n2) {
+                const int nn_cnt = NT - 2 * n2 >= 2 ? 2 : 1;          // n-tiles (16 channels each) in this round
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) {
+                        if (nn < nn_cnt) {
+                            const int n = 2 * n2 + nn;
+                            const int co = n * 16 + lp;
+                            const float bv = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) tw[(gi * 16 + kg * 4 + r) * 36 + nn * 16 + lp] = acc[2 * h + gi][n < NT ? n : 0][r] + bv;
+                        }
+                    }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int lpp = nn_cnt * 4;                           // lanes per pixel (16 bytes each)
+                const int ppp = 64 / lpp;                             // pixels per pass
+                const int pl0 = lane / lpp, c4 = (lane % lpp) * 4;
+                for (int pl = pl0; pl < 32; pl += ppp) {
+                    const int ow = ow0 + pl;
+                    const int co = n2 * 32 + c4;
+                    if (oh < H && ow < W && co < p.cout) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + pl * 36 + c4);
+                        *reinterpret_cast<f32x4*>(outp + (((long long)n_img * H + oh) * W + ow) * p.cout_stride + co) = v4;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    }
     float s1[NT], s2[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -72,7 +119,7 @@ __device__ __forceinline__ void head_epilogue(const ConvKArgs& p, f32x4 (&acc)[4
                     if (raw_mode) {
                         s1[n] += v;
                         s2[n] += v * v;
-                        reinterpret_cast<float*>(p.out)[(((long long)n_img * H + oh) * W + ow) * p.cout_stride + co] = v;
+                        if (!fast_raw) reinterpret_cast<float*>(p.out)[(((long long)n_img * H + oh) * W + ow) * p.cout_stride + co] = v;
                     } else {
                         v = apply_act(v, act, act_param) * out_scale;
                         reinterpret_cast<float*>(p.out)[((long long)n_img * p.cout + co) * hw + (long long)oh * W + ow] = v;
@@ -308,7 +355,8 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const ConvKArgs p, cons
 template <typename T>
 static inline int launch_c8_typed(const ConvKArgs& k, hipStream_t s) {
     constexpr int PR = (8 + 6) * (32 + 6);
-    const size_t lds = (size_t)((PR + 63) / 64) * 1024;               // 9 KiB (the statistics scratch of the epilogue needs 4 x 16 NT x 8 B <= 4 KiB)
+    const size_t lds = 4 * 32 * 36 * sizeof(float);                   // 18 KiB: the epilogue's four [32][36] fp32 transposition blocks (the patch needs 9 KiB, the statistics scratch <= 4 KiB)
+    static_assert(((PR + 63) / 64) * 1024 <= 4 * 32 * 36 * sizeof(float), "patch fits");
     const dim3 g((unsigned)k.m_tiles), b(256);
     const T* w = reinterpret_cast<const T*>(k.w);
     if (k.cout <= 16)      hipLaunchKernelGGL((conv7x7_c8_kernel<T, 1>), g, b, lds, s, k, w);
