@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void conv7x7_head_kernel(const ConvKArgs p, co
 // 16 bytes of pixel (p + tap offset) from a 8.5-KB LDS halo patch (A) and the 16 bytes W[cout][tap][8] from the tap-major packed
 // weights (B; 13 steps cover the 49 taps, the padding taps hit zero weights).  The pixel tile, the wave / accumulator layout and
 // the epilogue (raw fp32 NHWC + per-tile statistics, or planar fp32 + activation) are those of conv7x7_head_kernel.
-template <typename T, int NT>
+template <typename T, int NT, bool WLDS = false>
 __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const ConvKArgs p, const T* __restrict__ w_ro) {
     constexpr int VEC = ElemTraits<T>::VEC;                           // 8 bf16 / 4 fp32 = the whole channel stride
     constexpr int TH = 8, TW = 32, HALO = 3, KS = 7;
@@ -323,6 +323,34 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const ConvKArgs p, cons
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int n = 0; n < NT; ++n) { acc[g][n][0] = 0.f; acc[g][n][1] = 0.f; acc[g][n][2] = 0.f; acc[g][n][3] = 0.f; }
+    if constexpr (WLDS) {
+        // Round 5: ALL weight fragments of the layer (13 steps x NT, 1 KiB each: a fragment IS 64 lanes x 16 bytes) go to LDS once, by
+        // LDS-DMA next to the patch, lane-contiguous -- each step then takes its B fragments with one conflict-free ds_read_b128 per N
+        // tile instead of a dependent L2 round trip per step (13 of them in series were most of a tile's life).  Same fragments, same
+        // MFMA order: bit-identical.
+        char* const wl = smem + NG * 1024;
+        for (int f = wid; f < STEPS * NT; f += NW) {                  // fragment f = step * NT + n
+            const int sstep = f / NT, n = f - sstep * NT;
+            glds16(reinterpret_cast<const char*>(wlane + n * wnt + sstep * 4 * VEC), wl + f * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            Frag bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const Frag*>(wl + (s * NT + n) * 1024 + lane * 16);
+            int t = 4 * s + kg;
+            t = t < KS * KS ? t : KS * KS - 1;
+            const int toff = (t / KS) * PW + (t % KS);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const Frag a = *reinterpret_cast<const Frag*>(smem + (qg[g] + toff) * 16);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) Mma16<T>::run(a, bf[n], acc[g][n]);
+            }
+        }
+    } else {
     Frag bf[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const Frag*>(wlane + n * wnt);
@@ -349,6 +377,7 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const ConvKArgs p, cons
             for (int n = 0; n < NT; ++n) bf[n] = nb[n];
         }
     }
+    }
     head_epilogue<T, NT>(p, acc, smem, tid, wid, lp, kg, mt, n_img, oh0, ow0);
 }
 
@@ -359,6 +388,25 @@ static inline int launch_c8_typed(const ConvKArgs& k, hipStream_t s) {
     static_assert(((PR + 63) / 64) * 1024 <= 4 * 32 * 36 * sizeof(float), "patch fits");
     const dim3 g((unsigned)k.m_tiles), b(256);
     const T* w = reinterpret_cast<const T*>(k.w);
+    if constexpr (sizeof(T) == 2) {
+        // bf16: the weight fragments in LDS (9 KiB patch + 13 NT KiB; cout <= 64: at most 61 KiB, two workgroups per CU).  V2V_C8_WLDS=0: the
+        // fragments from L2 step by step (A/B)
+        static const bool wlds = [] { const char* e = getenv("V2V_C8_WLDS"); return !(e && e[0] == '0'); }();
+        if (wlds && k.cout <= 64) {
+            const int nt = k.cout <= 16 ? 1 : k.cout <= 32 ? 2 : 4;
+            const size_t need = (size_t)((PR + 63) / 64) * 1024 + (size_t)13 * nt * 1024;
+            const size_t l2 = need > lds ? need : lds;
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv7x7_c8_kernel<T, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                attr_done = true;
+            }
+            if (nt == 1)      hipLaunchKernelGGL((conv7x7_c8_kernel<T, 1, true>), g, b, l2, s, k, w);
+            else if (nt == 2) hipLaunchKernelGGL((conv7x7_c8_kernel<T, 2, true>), g, b, l2, s, k, w);
+            else              hipLaunchKernelGGL((conv7x7_c8_kernel<T, 4, true>), g, b, l2, s, k, w);
+            return check_launch();
+        }
+    }
     if (k.cout <= 16)      hipLaunchKernelGGL((conv7x7_c8_kernel<T, 1>), g, b, lds, s, k, w);
     else if (k.cout <= 32) hipLaunchKernelGGL((conv7x7_c8_kernel<T, 2>), g, b, lds, s, k, w);
     else if (k.cout <= 64) hipLaunchKernelGGL((conv7x7_c8_kernel<T, 4>), g, b, lds, s, k, w);
