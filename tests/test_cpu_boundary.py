@@ -565,3 +565,46 @@ def test_paired_x_view_of_32_channel_layers():
                      L.OUT_RAW_F32_NHWC, want_stats=True)
     finally:
         N.set_record_only(False)
+
+
+def test_round5_label_paths_dry_run():
+    """Round 5, host side of two label-path changes (CPU dry run; the GPU parity is in tests/test_gpu_kernels.py):
+    (1) gather-sum stems with <= 16 output channels take 16-channel slices by default -- the table the library asks for has that
+    geometry ([49 taps][1 slice][(cin + 1) rows x (16 x 2 + 16) bytes, rounded to 1 KiB] + the edge-row fragments of one 32-column MFMA
+    tile), wider layers keep 32-channel slices, an explicit slice width is honoured;
+    (2) the pooled label encoding is computed from the 1-byte label | edge codes when the frame plan has them (maps_u8 = 2), from the
+    maps otherwise; label_nc > 126 cannot be coded and is refused on that path."""
+    import ctypes as C
+    from vid2vid_amd import networks as N
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib
+    from vid2vid_amd.engine import Engine, LabelSource
+    T, nc = 3, 35
+    cin = T * (nc + 1)
+    blob16 = ((cin + 1) * (16 * 2 + 16) + 1023) // 1024 * 1024
+    blob32 = ((cin + 1) * (32 * 2 + 16) + 1023) // 1024 * 1024
+    etab = lambda slices, ntiles: slices * ntiles * ((49 * T + 15) // 16) * 64 * 16
+    assert lib.v2v_onehot_conv_table_bytes(cin, 16, L.BF16, 0, T, nc) == 49 * blob16 + etab(1, 1)
+    assert lib.v2v_onehot_conv_table_bytes(cin, 12, L.BF16, 0, T, nc) == 49 * blob16 + etab(1, 1)
+    assert lib.v2v_onehot_conv_table_bytes(cin, 16, L.BF16, 32, T, nc) == 49 * blob32 + etab(1, 1)      # explicit 32-wide slices
+    assert lib.v2v_onehot_conv_table_bytes(cin, 32, L.BF16, 0, T, nc) == 49 * blob32 + etab(1, 1)
+    assert lib.v2v_onehot_conv_table_bytes(cin, 128, L.BF16, 0, T, nc) == 49 * 4 * blob32 + etab(4, 1)
+    if torch.cuda.is_available():
+        return
+    N.set_record_only(True)
+    try:
+        eng = Engine(torch.device("cpu"), L.BF16, record_only=True)
+        H, W = 64, 96
+        lab = torch.randint(0, nc, (T, H, W)).to(torch.uint8)
+        inst = torch.randint(0, 5, (T, H, W)).to(torch.int32)
+        src = LabelSource(lab, inst, T, nc)
+        assert eng.label_codes(src, H, W) is not None and src.codes is not None
+        x0, pooled, mask = eng.encode_labels_pooled(lab, inst, T, H, W, nc, [26], True, chunk_stride=True, source=src)     # from the codes
+        assert pooled.t.shape == (1, H // 2, W // 2, 128) and mask.shape == (1, 1, H, W) and x0.onehot is src
+        x0, pooled, _ = eng.encode_labels_pooled(lab, inst, T, H, W, nc, [26], True, chunk_stride=True)                     # from the maps
+        assert pooled.t.shape == (1, H // 2, W // 2, 128)
+        out = torch.empty(1, H // 2, W // 2, 1024, dtype=torch.bfloat16)
+        rc = lib.v2v_encode_labels_pooled(C.c_void_p(src.codes.data_ptr()), None, C.c_void_p(out.data_ptr()), None, T, H, W, 200, 1024, None, 0, L.BF16, 2, None)
+        assert rc != 0                                  # 200 labels do not fit the 7-bit code
+    finally:
+        N.set_record_only(False)
