@@ -1,0 +1,74 @@
+#!/bin/bash
+# Round-6 GPU visits.  scripts/gpu_r6.sh <tag> [parts...]   (every part writes under gpurun_out/<tag>_*)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=${1:-r6}; shift
+WHAT=${*:-alltests}
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+T0=$(date +%s)
+lap() { echo "[$(( $(date +%s) - T0 )) s] $1"; }
+LEAN="--no-cpu-baseline --no-train-line --no-train-hires --no-c1 --no-c4 --no-train-c3"
+if has fn2tests; then    # FlowNet2 at BASELINE sizes, and its real output inside the 512x256 training-chunk parity
+  timeout 1500 python -m pytest tests/test_gpu_golden.py -m gpu -q -rf --tb=short -s -k "flownet2_at_baseline_size or full_width_training_chunk_512x256" -p no:cacheprovider > gpurun_out/${TAG}_fn2tests.log 2>&1; echo "fn2tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|flownet2 fp32 at|^E  |forward|losses|grads  " gpurun_out/${TAG}_fn2tests.log | cut -c1-400 | tail -40
+  lap fn2tests
+fi
+if has trainprof; then   # steady-state rocprofv3 table of the training step (a first run fills the tile cache, the profiled second run replays it)
+  GEO=${GEO:-}
+  rm -f /tmp/tune_train.json
+  V2V_TUNE_CACHE=/tmp/tune_train.json timeout 900 python bench.py --mode train --steps 4 --warmup 1 --no-train-parity $GEO > gpurun_out/${TAG}_train_first.json 2> gpurun_out/${TAG}_train_first.err; echo "train(first) rc=$?"
+  cd /tmp
+  V2V_TUNE_CACHE=/tmp/tune_train.json timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_tr_$TAG -o tr -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-train-parity $GEO > $R/gpurun_out/${TAG}_train.json 2> $R/gpurun_out/${TAG}_train.err; echo "train(profiled) rc=$?"
+  DB=$(find /tmp/prof_tr_$TAG -name "*.db" | head -1)
+  python $R/scripts/rocprof_summary.py $DB "# round 6, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --mode train --steps 6 --warmup 2 --no-train-parity $GEO (bf16, VGG on; tile selections replayed from a cache filled by a previous run)" > $R/gpurun_out/${TAG}_train_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_train.err
+  python $R/scripts/rocprof_by_grid.py $DB > $R/gpurun_out/${TAG}_train_by_grid.txt 2>> $R/gpurun_out/${TAG}_train.err
+  head -45 $R/gpurun_out/${TAG}_train_kernel_stats.txt | cut -c1-200
+  head -60 $R/gpurun_out/${TAG}_train_by_grid.txt | cut -c1-200
+  python -c "
+import json
+for f in ('first', ''):
+    j = json.load(open('$R/gpurun_out/${TAG}_train' + ('_first' if f else '') + '.json')); print('train', f or 'profiled', j['value'], j['ms_per_step'], j['roofline']['frac'], j['config'].get('autotune_s'), j['roofline'].get('conv_launches_per_step'))"
+  cd $R
+  lap trainprof
+fi
+if has wgradbench; then
+  timeout 300 python scripts/wgrad_bench.py 2>&1 | tee gpurun_out/${TAG}_wgrad_bench.txt | cut -c1-250
+  lap wgradbench
+fi
+if has trainops; then
+  timeout 900 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/${TAG}_trainops.log 2>&1; echo "trainops rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_trainops.log | cut -c1-300 | tail -30
+  lap trainops
+fi
+if has train; then       # the three training geometries of the default line, timed only
+  for geo in "" "--width 1024 --height 512 --scales 2 --num-D 3" ; do
+    timeout 600 python bench.py --mode train --steps 6 --warmup 2 --no-train-parity $geo 2>gpurun_out/${TAG}_train_t.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train $geo:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', j['roofline'].get('frac'))"
+  done 2>&1 | tee gpurun_out/${TAG}_train_values.txt
+  lap train
+fi
+if has benchdefault; then    # the driver's command, timed; the stdout line must be the LAST line of a 10 KB tail and parse
+  TB=$(date +%s)
+  timeout 1500 python bench.py > gpurun_out/${TAG}_bench_default_line.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$? wall $(( $(date +%s) - TB )) s"
+  cp bench_full.json gpurun_out/${TAG}_bench_default_full.json 2>/dev/null
+  python - <<PY
+import json
+t = open("gpurun_out/${TAG}_bench_default_line.json").read()
+print("stdout bytes", len(t), "lines", t.count("\n"))
+j = json.loads(t[-10000:].strip().splitlines()[-1])
+print(json.dumps(j)[:6000])
+PY
+  tail -3 gpurun_out/${TAG}_bench_default.err | cut -c1-300
+  lap benchdefault
+fi
+if has alltests; then
+  timeout 1700 python -m pytest tests -m gpu -q -rf --tb=short --timeout 900 --durations=15 > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_gpu.log | tail -20
+  lap alltests
+fi
+if has quicktests; then   # everything but the full-size CPU-oracle cases
+  timeout 900 python -m pytest tests -m gpu -q -rf --tb=short --timeout 300 -k "not full_size and not full_width" > gpurun_out/${TAG}_pytest_quick.log 2>&1; echo "pytest(quick) rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_quick.log | tail -20
+  lap quicktests
+fi

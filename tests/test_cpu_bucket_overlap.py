@@ -74,9 +74,9 @@ def _worker(rank, world, port, q):
             order = []
             send = gs.send_ready_bucket
 
-            def spy(b, _send=send, _flat=opt.flat.flat_grad):
+            def spy(b, key=None, _send=send, _flat=opt.flat.flat_grad):
                 order.append((b.data_ptr() - _flat.data_ptr()) // 4 // 64)
-                _send(b)
+                _send(b, key)
             gs.send_ready_bucket = spy
             loss = _chunk(ws, rank, frames=2)
             assert sum(opt.flat.ready.open) >= 2 * len(ws)            # every node registered its buckets
@@ -87,7 +87,8 @@ def _worker(rank, world, port, q):
             if mode:
                 # reverse PARAMETER order (a parameter that spans several buckets completes them together, lowest first):
                 # the last layer's bucket leaves first, the first layer's last
-                assert sorted(order) == list(range(n_b)) and order[0] == n_b - 1 and order[-1] == 0 and gs.early_buckets == n_b, (order, n_b)
+                # ... and since round 6 in ONE fixed order, descending bucket index, whatever the graph
+                assert order == list(range(n_b - 1, -1, -1)) and gs.early_buckets == n_b, (order, n_b)
                 spans = [opt.flat.ready.span[id(w)] for w in ws]     # per parameter: its buckets leave no later than those of the parameter in front of it
                 last_sent = [max(order.index(k) for k in sp) for sp in spans]
                 assert all(last_sent[i] >= last_sent[i + 1] for i in range(len(ws) - 1)), (order, last_sent)
@@ -104,6 +105,40 @@ def _worker(rank, world, port, q):
             assert all(o == all_orders[0] for o in all_orders)        # collectives issued in the same order on every rank
             parallel._ACTIVE_SYNCS.clear()
         assert torch.equal(results[True], results[False])             # bit-identical to the end-of-pass all-reduce
+
+        # ---- rank-divergent graphs: rank 1 holds a counted node that its backward never reaches (a branch
+        # the loss does not depend on), so ITS bucket of layer 3 never completes inside the pass while rank 0 completes all of
+        # them.  The issue order must still be the same on both ranks -- descending, the held bucket and everything below it
+        # at step() -- and the sums right; before the fix rank 0 sent all buckets early and rank 1 paired other buckets with them.
+        torch.manual_seed(5)
+        ws = [nn.Parameter(torch.randn(n)) for n in sizes]
+        opt = FusedAdam(ws)
+        gs = parallel.sync_optimizers([opt], bucket_bytes=64 * 4, in_backward=True)
+        issued = []
+        reduce_ = gs.reduce_bucket
+
+        def spy_reduce(b, _r=reduce_, _flat=opt.flat.flat_grad):
+            issued.append((b.data_ptr() - _flat.data_ptr()) // 4 // 64)
+            _r(b)
+        gs.reduce_bucket = spy_reduce
+        loss = _chunk(ws, rank, frames=2)
+        if rank == 1:
+            _DepositFn.apply(torch.zeros(1, requires_grad=True), ws[3], 99.0, True)      # registered, never walked
+        opt.zero_grad()
+        opt.flat.flat_grad.zero_()
+        loss.backward()
+        n_b = opt.flat.ready.n
+        held = min(opt.flat.ready.span[id(ws[3])])
+        if rank == 0:
+            assert gs.early_buckets == n_b
+        else:
+            assert gs.early_buckets == n_b - 1 - max(opt.flat.ready.span[id(ws[3])]) < n_b, (gs.early_buckets, held)
+        opt.step()
+        assert issued == list(range(n_b - 1, -1, -1)), issued            # every rank: the same order, whatever was early or late
+        for i, w in enumerate(ws):
+            expect = sum((rk + 1) * (i + 1) * (t + 1) for rk in range(world) for t in range(2))
+            assert torch.equal(w.grad, torch.full_like(w.grad, float(expect))), ("divergent", i)
+        parallel._ACTIVE_SYNCS.clear()
 
         # an uncounted gradient-writing node: its bucket leaves early, the late contribution must raise
         ws = [nn.Parameter(torch.randn(n)) for n in sizes]

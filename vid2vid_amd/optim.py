@@ -80,6 +80,7 @@ class FusedAdam(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise NotImplementedError("FusedAdam keeps one flat buffer: pass a single parameter list")
         self.flat = FlatBuffers(self.param_groups[0]["params"])
+        self.flat.owner_key = id(self)               # parallel.GradSync files in-flight collectives of this buffer under the optimizer
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.step_count = 0
@@ -99,6 +100,7 @@ class FusedAdam(torch.optim.Optimizer):
             grp["betas"] = tuple(betas)
         had_ready = self.flat.ready is not None
         self.flat = FlatBuffers(params)
+        self.flat.owner_key = id(self)
         if had_ready and self.grad_sync is not None:
             from .parallel import BucketReady
             self.flat.ready = BucketReady(self.flat, self.grad_sync)

@@ -64,8 +64,8 @@ class GradSync:
     backward has enqueued its last kernel; once the optimizer is armed (zero_grad) a bucket whose count reaches zero has received
     its last contribution of this pass -- with several frames per chunk that happens during the backward of the FIRST frame, the
     last of the pass -- and its all-reduce is enqueued on the side stream behind an event of the compute stream, while the
-    backward pass goes on.  step() sends whatever is left and the Adam kernel.  A contribution that arrives for a bucket already
-    sent raises (it cannot happen while every gradient-writing node is counted; the check is what makes that a tested property).
+    backward pass goes on (always in descending bucket order, see BucketReady).  step() sends whatever is left and the Adam kernel.
+    A contribution that arrives for a bucket already sent raises (it cannot happen while every gradient-writing node is counted; the check is what makes that a tested property).
     On CPU tensors (gloo tests) everything runs in order on the host."""
 
     def __init__(self, group=None, bucket_bytes=64 << 20, force_collective=False, scale=None, wire_dtype=None, in_backward=None):
@@ -136,9 +136,12 @@ class GradSync:
         else:
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
 
-    def send_ready_bucket(self, b):
+    def send_ready_bucket(self, b, owner_key=None):
         """Called by BucketReady from inside a backward pass: the kernels that wrote `b` are enqueued on the current stream.
-        GPU: the side stream waits for an event recorded now and runs the collective; the compute stream goes on."""
+        GPU: the side stream waits for an event recorded now and runs the collective; the compute stream goes on.  The
+        completion event is filed under the owning optimizer: if step() never comes (overflow skip, an exception
+        between backward and step, a second zero_grad) that optimizer's next zero_grad / wait_pending still waits for the
+        in-flight all-reduce before the gradient memory is written again."""
         self.early_buckets += 1
         if not b.is_cuda:
             self.reduce_bucket(b)
@@ -150,6 +153,9 @@ class GradSync:
         side.wait_event(ev)
         with torch.cuda.stream(side):
             self.reduce_bucket(b)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._pending[owner_key] = done              # one side stream: the newest event covers every earlier send of this owner
 
     def collective_active(self):
         return self.world > 1 or (self.force_collective and dist.is_initialized())
@@ -223,8 +229,16 @@ class BucketReady:
 
     open[k]  = autograd nodes alive that will write into bucket k (registered by the forward pass, reported by their backward);
     armed    = between the optimizer's zero_grad() and step(): the pass that runs now writes THIS buffer's gradients for the step;
+    ready[k] = bucket k has received its last contribution of this pass;
     sent[k]  = bucket k was handed to the collective in this armed window.
-    A parameter that straddles a bucket boundary counts in every bucket it touches."""
+    A parameter that straddles a bucket boundary counts in every bucket it touches.
+
+    ISSUE ORDER IS RANK-INVARIANT: buckets are handed to the collective in ONE fixed order -- descending
+    index, n-1 first -- on every rank, whatever order the rank's own autograd graph completes them in.  A complete bucket is
+    held until every higher-index bucket has been sent (`next`), and finish() continues the same descending walk.  Same-sized
+    RCCL collectives on the side stream are therefore always paired bucket k with bucket k, even if one rank's graph lacks a
+    node another rank's has (data-dependent branch, another chunk position); with identical graphs -- backward visits the
+    parameters in reverse order -- nothing is held back and the overlap is unchanged."""
 
     def __init__(self, flat, sync):
         self.flat, self.sync = flat, sync
@@ -232,6 +246,8 @@ class BucketReady:
         self.n = (flat.numel + self.be - 1) // self.be
         self.open = [0] * self.n
         self.sent = [False] * self.n
+        self.ready = [False] * self.n
+        self.next = self.n - 1                       # the only bucket that may be sent now
         self.armed = False
         self.span = {}                               # id(param) -> range of bucket indices
         for p_, o in zip(flat.params, flat.offsets):
@@ -246,6 +262,15 @@ class BucketReady:
             if self.armed and self.sent[k]:
                 raise RuntimeError("BucketReady: a gradient-writing node was created for a bucket that was already all-reduced in this pass")
             self.open[k] += 1
+            self.ready[k] = False
+
+    def _drain(self):
+        """Send every complete bucket that is next in the fixed descending order."""
+        while self.next >= 0 and self.ready[self.next]:
+            k = self.next
+            self.sent[k] = True
+            self.next -= 1
+            self.sync.send_ready_bucket(self.bucket(k), getattr(self.flat, "owner_key", None))
 
     def done(self, p_):
         for k in self.span.get(id(p_), ()):
@@ -257,18 +282,25 @@ class BucketReady:
                 self.open[k] = 0
                 continue
             if self.armed and self.open[k] == 0 and self.sync.in_backward and self.sync.collective_active():
-                self.sent[k] = True
-                self.sync.send_ready_bucket(self.bucket(k))
+                self.ready[k] = True
+        if self.armed:
+            self._drain()
 
     def arm(self):
         self.armed = True
         self.sent = [False] * self.n
+        self.ready = [False] * self.n
+        self.next = self.n - 1
 
     def finish(self):
-        """step(): the buckets that were not sent from inside the pass; disarms and clears leaked counts."""
-        rest = [self.bucket(k) for k in range(self.n) if not self.sent[k]]
+        """step(): the buckets that were not sent from inside the pass, in the SAME descending order the in-pass sends follow
+        (the sent ones are exactly n-1 .. next+1); disarms and clears leaked counts."""
+        rest = [self.bucket(k) for k in range(self.next, -1, -1)]
+        assert all(self.sent[k] for k in range(self.next + 1, self.n)) and not any(self.sent[k] for k in range(self.next + 1))
         self.armed = False
         self.sent = [False] * self.n
+        self.ready = [False] * self.n
+        self.next = self.n - 1
         self.open = [0] * self.n
         return rest
 
