@@ -189,6 +189,10 @@ def parse():
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps frames each; `value` is the MEDIAN window")
     ap.add_argument("--min-warmup-s", type=float, default=0.5, help="warm up for at least this long (and at least --warmup frames) before the first window")
     ap.add_argument("--no-hires", action="store_true", help="infer: skip the 2048x1024 / 3-scale companion run reported under \"hires\"")
+    ap.add_argument("--train-graph", action="store_true", help="train: replay each chunk kind as ONE captured hipGraph (vid2vid_amd/graphed.py) instead of "
+                    "eager launches.  Measured equal (68.6 vs 69.0 ms per 512x256 chunk, profiles/r06_v3_traingraph.txt): the step is bound by the "
+                    "device's kernel-to-kernel turnaround of ~4000 dependent launches, not by host time -- off by default")
+    ap.add_argument("--no-train-graph", action="store_true", help="(default; kept for callers of the first round-6 builds)")
     ap.add_argument("--no-train-parity", action="store_true", help="train: skip the fp32 chunk-vs-oracle parity leg (outputs, losses, gradient norms)")
     ap.add_argument("--no-c4", action="store_true", help="infer: skip the BASELINE configs[3] leg (edge2face 512x512) reported under \"c4\"")
     ap.add_argument("--no-train-c3", action="store_true", help="infer: skip the BASELINE configs[2] geometry training leg (1024x512, 2 scales) reported under \"train_c3\"")
@@ -373,6 +377,33 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
         state["loss"] = (loss_G.detach(), loss_D.detach(), t_act)
         state["i"] = i + n_frames_load if (i // n_frames_load + 1) < chunks_per_seq else 0
 
+    # Round 6 (--train-graph): the chunk's whole launch sequence (G forward, FlowNet2, D / D_T, losses, the zero_grad / backward /
+    # Adam triples) captured once per chunk kind (= position of the chunk in its sequence) and replayed as ONE hipGraph
+    # (vid2vid_amd/graphed.py).  The eager step leaves the device idle 30 % of a chunk (profiles/r06_v1_train_by_grid.txt), but
+    # the replay takes the same time: the idle share is the device's turnaround between dependent launches, not the host.
+    # Single process only: RCCL collectives and the role mode's point-to-point transfers stay on the eager path.
+    from vid2vid_amd.graphed import ChunkGraphs
+    use_graph = bool(world == 1 and not role_mode and getattr(args, "train_graph", False) and not args.no_train_graph)
+    graphs = ChunkGraphs([optimizer_G, optimizer_D] + list(optimizer_D_T), device=dev, enabled=False)
+    step_eager = step
+    graph_logs = {}                                                 # chunk kind -> (conv_log entries, FlowNet2 flops, FlowNet2 convs) of one replay
+    fnm = flowNet.module if hasattr(flowNet, "module") else flowNet
+
+    def step():
+        if not graphs.enabled:
+            return step_eager()
+        key = state["i"]
+        if key not in graphs.graphs:
+            n0, f0, c0 = len(eng.conv_log), fnm.flops_launched, fnm.convs_launched
+            graphs.step(key, step_eager, lambda: dict(state), state.update)
+            graph_logs[key] = (list(eng.conv_log[n0:]), fnm.flops_launched - f0, fnm.convs_launched - c0)
+        else:
+            graphs.step(key, step_eager, lambda: dict(state), state.update)
+            log, fl, nc = graph_logs[key]
+            eng.conv_log.extend(log)                               # what this replay launched (the roofline's FLOP count)
+            fnm.flops_launched += fl
+            fnm.convs_launched += nc
+
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -396,6 +427,19 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
     eng.autotune = False
     barrier()
     t_tune = time.perf_counter() - t_tune
+    t_capture = 0.0
+    if use_graph:
+        for _ in range(chunks_per_seq):                             # one more eager sequence: steady state (every packed weight stale as in
+            step()                                                  # any later chunk), state["i"] back at the start of a sequence
+        barrier()
+        t_capture = time.perf_counter()
+        graphs.enabled = True
+        for o in graphs.optimizers:
+            o.make_capturable()
+        for _ in range(chunks_per_seq):                             # capture every chunk kind, in sequence order
+            step()
+        barrier()
+        t_capture = time.perf_counter() - t_capture
     for _ in range(args.warmup):
         step()
     eng.conv_log = []
@@ -456,8 +500,10 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "flop_per_step": flop_step, "conv_launches_per_step": n_launch // args.steps,
             "gflop_per_step_by_kind": {k: round(v / args.steps / 1e9, 1) for k, v in sorted(by_kind.items())},
-            "note": "algorithmic conv FLOP of one chunk / wall time of one chunk (host launch time included: the "
-                    "training step is an eager autograd graph of v2v custom ops, not a hipGraph)"
+            "note": ("algorithmic conv FLOP of one chunk / wall time of one chunk; the chunk's whole launch sequence is replayed as one "
+                     "hipGraph per chunk kind (vid2vid_amd/graphed.py)" if graphs.enabled else
+                     "algorithmic conv FLOP of one chunk / wall time of one chunk (host launch time included: the "
+                     "training step is an eager autograd graph of v2v custom ops, not a hipGraph)")
                     + ("; role mode: only THIS rank's launches (generator rank 0) are counted" if role_mode else ""),
         }
         out = {
@@ -473,6 +519,8 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
                                       sum(q.numel() for q in modelD.module.parameters()) / 1e6),
                        "frames_per_step": n_frames_load, "active_temporal_scales_last_step": int(t_act),
                        "autotune_s": round(t_tune, 1),
+                       "train_graph": {"enabled": bool(graphs.enabled), "chunk_kinds": len(graphs.graphs), "capture_s": round(t_capture, 1),
+                                       "replays": graphs.replays},
                        "parallelism": ("%d sequence group(s) x (%d generator + %d discriminator ranks): frames of a chunk split over the generator "
                                        "ranks, RCCL point-to-point for frames / gradients, all-reduce per role (vid2vid_amd/roles.py)"
                                        % (n_seqs, n_gen, group - n_gen)) if role_mode else

@@ -483,6 +483,14 @@ int v2v_loss_backward(int32_t kind, const void* a, const void* b, const float* m
 int v2v_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                   int32_t step, void* stream);
+/* The same update with its step count and learning rate in DEVICE memory: `state` = {int32 step; float lr} (8 bytes, owned
+ * by the caller, step = number of updates done so far).  The launch increments `step` first, then applies update number
+ * `step` -- so a launch captured into a hipGraph (stream capture of a whole training chunk) advances the bias corrections on
+ * every replay, and the host changes the learning rate by writing state->lr (torch.optim.Adam(capturable=True) is the
+ * reference-side analogue; the reference's optimizers are models/vid2vid_model_G.py:84, vid2vid_model_D.py:86-91). */
+int v2v_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                      void* state, void* stream);
 int v2v_memset_zero(void* p, int64_t bytes, void* stream);
 
 /* ---- plan executor: a recorded launch sequence replayed as one call / one hipGraph ---- */

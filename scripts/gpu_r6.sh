@@ -32,7 +32,17 @@ for f in ('first', ''):
   cd $R
   lap trainprof
 fi
+if has traingraph; then   # whole-chunk hipGraphs (vid2vid_amd/graphed.py): eager vs graph on this box, then the capturable-Adam test
+  for flag in "" "--train-graph"; do
+    timeout 900 python bench.py --mode train --steps 12 --warmup 3 --no-train-parity $flag $GEO 2>gpurun_out/${TAG}_traingraph${flag}.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train [$flag]:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', j['roofline'].get('frac'), j['config'].get('train_graph'), 'loss_G', j['config'].get('loss_G'), j['config'].get('loss_D'), 'peak GB', j['config'].get('peak_memory_gb'))"
+    tail -4 gpurun_out/${TAG}_traingraph${flag}.err | cut -c1-300
+  done 2>&1 | tee gpurun_out/${TAG}_traingraph.txt
+  timeout 300 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short -k "adam" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300 | tail -12
+  lap traingraph
+fi
 if has wgradbench; then
+  timeout 300 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short -s -k "nine_tap" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  |nine-tap" | cut -c1-300 | tail -20
   timeout 300 python scripts/wgrad_bench.py 2>&1 | tee gpurun_out/${TAG}_wgrad_bench.txt | cut -c1-250
   lap wgradbench
 fi
@@ -40,6 +50,16 @@ if has trainops; then
   timeout 900 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/${TAG}_trainops.log 2>&1; echo "trainops rc=$?"
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_trainops.log | cut -c1-300 | tail -30
   lap trainops
+fi
+if has trainab; then     # one-stream vs side-stream weight gradients, GEMM-view vs nine-tap kernel, alternating on this box
+  for rep in 1 2; do
+    for cfg in "V2V_WGRAD_STREAM=0 V2V_WGRAD3=0" "V2V_WGRAD_STREAM=0 V2V_WGRAD3=1" "V2V_WGRAD_STREAM=1 V2V_WGRAD3=0" "V2V_WGRAD_STREAM=1 V2V_WGRAD3=1"; do
+      env $cfg timeout 600 python bench.py --mode train --steps 9 --warmup 3 --no-train-parity $GEO 2>gpurun_out/${TAG}_trainab.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train [$cfg] run $rep:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', 'loss_G', j['config'].get('loss_G'), j['config'].get('loss_D'))"
+    done
+  done 2>&1 | tee gpurun_out/${TAG}_trainab.txt
+  tail -3 gpurun_out/${TAG}_trainab.err | cut -c1-300
+  lap trainab
 fi
 if has train; then       # the three training geometries of the default line, timed only
   for geo in "" "--width 1024 --height 512 --scales 2 --num-D 3" ; do

@@ -34,6 +34,30 @@ def main(path, pats):
     print("# source: %s ; columns of the grid: %s ; workgroup: %s" % (path, gcols, wcols))
     print("# device busy over the second half of the trace: %.1f ms of %.1f ms = %.3f (union of kernel intervals / span)"
           % (busy / 1e6, (t1 - t0) / 1e6, busy / max(t1 - t0, 1)))
+    # per training chunk: the largest Adam launch (G's flat buffer) ends a chunk's G phase -- the intervals between two of them
+    # are whole chunks; busy = union of kernel intervals inside
+    if gcols:
+        ad = c.execute("select start, end, %s from kernels where name like '%%adam_step%%' order by start" % gcols[0]).fetchall()
+        if ad:
+            gmax = max(r[2] for r in ad)
+            marks = [r[1] for r in ad if r[2] == gmax]
+            rows_c = []
+            for a, b in zip(marks[:-1], marks[1:]):
+                busy_c, ce, n_k = 0, None, 0
+                for s_, e_ in iv:
+                    if e_ <= a or s_ >= b:
+                        continue
+                    s2, e2 = max(s_, a), min(e_, b)
+                    n_k += 1
+                    if ce is None or s2 > ce:
+                        busy_c += e2 - s2
+                        ce = e2
+                    elif e2 > ce:
+                        busy_c += e2 - ce
+                        ce = e2
+                rows_c.append(((b - a) / 1e6, busy_c / 1e6, n_k))
+            print("# chunks (between consecutive G-optimizer Adam launches): span ms / busy ms / kernels: "
+                  + "  ".join("%.1f/%.1f/%d" % r for r in rows_c[-12:]))
     print("%-72s %-22s %7s %11s %9s %9s %9s %6s" % ("kernel", "grid/wg", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
     n = 0
     for r in rows:

@@ -58,6 +58,7 @@ CASES = [  # R(cout) Cc(cin) K stride pad mode  N  OH  OW   (x is OH*stride.. si
 ]
 torch.manual_seed(0)
 worst = 0.0
+os.environ["V2V_WGRAD3"] = "0"          # first table: the GEMM-view kernel + reduce on every shape
 for (R, Cc, K, s, p, mode, N, OH, OW) in CASES:
     H, W = (OH - 1) * s + K - 2 * p, (OW - 1) * s + K - 2 * p
     Rs, Cs = (R + 7) // 8 * 8, (Cc + 7) // 8 * 8
@@ -74,3 +75,22 @@ for (R, Cc, K, s, p, mode, N, OH, OW) in CASES:
           % (R, Cc, K, s, N, OH, OW, ms16, flops / ms16 / 1e9, ms32, flops / ms32 / 1e9, err))
 print("worst", worst)
 assert worst < 2e-3, "bf16-MFMA wgrad disagrees with the exact-fp32 kernel on identical (bf16-representable) operands"
+
+# ---- round 6: the nine-tap 3x3 kernel (conv_wgrad3x3_bf16_kernel) beside the GEMM-view kernel + reduce, same operands ----
+NINE = [(1024, 1024, 1, 32, 64, (1, 2)), (512, 512, 1, 32, 64, (2, 4, 8)), (1024, 1024, 1, 64, 64, (1, 2)), (256, 256, 1, 64, 128, (4, 8)),
+        (128, 128, 1, 256, 512, (8,)), (64, 64, 1, 256, 512, (8,))]
+for (R, Cc, N, OH, OW, splits) in NINE:
+    dy = torch.randn(N, OH, OW, R, device=dev).bfloat16()
+    x = torch.randn(N, OH, OW, Cc, device=dev).bfloat16()
+    flops = 2.0 * N * OH * OW * R * Cc * 9
+    os.environ["V2V_WGRAD3"] = "0"
+    ref, ms0 = run(dy, x, 3, 1, 1, L.PAD_REFLECT, L.BF16, reps=11)
+    os.environ["V2V_WGRAD3"] = "1"
+    line = "wgrad 3x3 R=%4d C=%4d %dx%dx%d: GEMM view + reduce %.3f ms (%.0f TFLOP/s)" % (R, Cc, N, OH, OW, ms0, flops / ms0 / 1e9)
+    for sp in splits:
+        os.environ["V2V_WGRAD3_SPLITS"] = str(sp)
+        got, ms = run(dy, x, 3, 1, 1, L.PAD_REFLECT, L.BF16, reps=11)
+        err = (got - ref).abs().max().item() / (ref.pow(2).mean().sqrt().item() + 1e-12)
+        line += " | nine-tap x%d splits %.3f ms (%.0f TFLOP/s, diff %.1e)" % (sp, ms, flops / ms / 1e9, err)
+    os.environ.pop("V2V_WGRAD3_SPLITS")
+    print(line)

@@ -105,6 +105,80 @@ def test_conv2d_backward(case, prec, layout, monkeypatch):
     assert_close(conv.weight.grad.cpu(), 2 * cref.weight.grad, tol, "dW accumulate " + str(case))
 
 
+WGRAD3_CASES = [
+    # rows (cout), cols (cin), H, W, N, mode, forced splits (0 = the library's choice), channels-last gradient
+    (1024, 1024, 32, 64, 1, "reflect", 0, False),     # the 36 ResnetBlock layers of the 512x256 frame: 256 tiles, unsplit
+    (512, 512, 32, 64, 1, "reflect", 0, False),       # foreground tower: 64 tiles x 4 in-order K splits
+    (96, 72, 19, 70, 2, "zero", 3, False),            # ragged rows / cols / width (second segment: 6 pixels), splits that cross the image boundary
+    (64, 40, 5, 33, 1, "reflect", 1, True),           # channels-last gradient, one partial segment
+    (160, 64, 9, 130, 1, "zero", 4, True),            # three segments, split, channels-last
+    (64, 64, 2, 16, 3, "reflect", 2, False),          # two-row images (reflect of both neighbours), batch 3
+]
+
+
+@pytest.mark.parametrize("case", WGRAD3_CASES)
+def test_wgrad_nine_tap_kernel(case, monkeypatch):
+    """conv_wgrad3x3_bf16_kernel (round 6; 3x3 / stride 1 / pad 1, all nine taps per workgroup, the gradient written straight
+    into .grad, in-order K splits) against torch's weight gradient of the same bf16-rounded operands and against the GEMM-view
+    kernel + reduce it replaces (V2V_WGRAD3=0): overwrite and accumulate, PyTorch layout and channels-last, reflect and zero
+    padding, ragged tiles, several images, splits crossing image boundaries; the split tickets re-arm (second launch)."""
+    import ctypes as C
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, WgradDesc, check
+    R, Cc, H, W, N, mode, splits, cl = case
+    torch.manual_seed(R + Cc + W)
+    Rs, Cs = (R + 7) // 8 * 8, (Cc + 7) // 8 * 8
+    dy = torch.zeros(N, H, W, Rs, device=DEV); dy[..., :R] = torch.randn(N, H, W, R, device=DEV)
+    x = torch.zeros(N, H, W, Cs, device=DEV); x[..., :Cc] = torch.randn(N, H, W, Cc, device=DEV)
+    dyb, xb = dy.bfloat16(), x.bfloat16()
+    zero = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(grad, accumulate):
+        d = WgradDesc()
+        d.p, d.q = dyb.data_ptr(), xb.data_ptr()
+        d.N, d.OH, d.OW, d.QH, d.QW = N, H, W, H, W
+        d.rows, d.cols, d.p_stride, d.q_stride = R, Cc, Rs, Cs
+        d.KH = d.KW = 3
+        d.stride, d.pad, d.pad_mode = 1, 1, L.PAD_REFLECT if mode == "reflect" else L.PAD_ZERO
+        d.dtype, d.accumulate = L.BF16, (1 if accumulate else 0) + (2 if cl else 0)
+        d.grad, d.zero_page = grad.data_ptr(), zero.data_ptr()
+        nbytes = lib.v2v_conv_wgrad_workspace(C.byref(d))
+        assert nbytes > 0
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=DEV)
+        d.workspace = ws.data_ptr()
+        check(lib.v2v_conv_wgrad(C.byref(d), st), "wgrad")
+        torch.cuda.synchronize()
+
+    shape = (R, 3, 3, Cc) if cl else (R, Cc, 3, 3)
+    logical = (lambda g: g.permute(0, 3, 1, 2)) if cl else (lambda g: g)
+    # torch: dW of F.conv2d over the padded input, fp32 arithmetic on the bf16-rounded operands
+    xr = xb[..., :Cc].float().permute(0, 3, 1, 2).contiguous()
+    dyr = dyb[..., :R].float().permute(0, 3, 1, 2).contiguous()
+    xp = F.pad(xr, (1, 1, 1, 1), mode="reflect") if mode == "reflect" else F.pad(xr, (1, 1, 1, 1))
+    ref = torch.nn.grad.conv2d_weight(xp.double(), (R, Cc, 3, 3), dyr.double()).float().cpu()
+    if splits:
+        monkeypatch.setenv("V2V_WGRAD3_SPLITS", str(splits))
+    g_new = torch.full(shape, 7.0, device=DEV)                             # overwrite mode must not read the buffer
+    run(g_new, False)
+    monkeypatch.setenv("V2V_WGRAD3", "0")
+    g_old = torch.zeros(shape, device=DEV)
+    run(g_old, False)
+    monkeypatch.setenv("V2V_WGRAD3", "1")
+    rms = ref.pow(2).mean().sqrt().item()
+    e_ref = (logical(g_new).cpu() - ref).abs().max().item() / rms
+    e_old = (g_new - g_old).abs().max().item() / rms
+    print("nine-tap wgrad %s: vs torch %.2e, vs the GEMM-view kernel %.2e (of the gradient's rms)" % (str(case), e_ref, e_old))
+    assert e_ref < 2e-5 and e_old < 2e-5
+    base = torch.randn(shape, device=DEV)
+    g_acc = base.clone()
+    run(g_acc, True)                                                       # accumulate into .grad; also the second use of the tickets
+    assert (g_acc - base - g_new).abs().max().item() / rms < 1e-6
+    g_again = torch.empty(shape, device=DEV)
+    run(g_again, False)
+    assert torch.equal(g_again, g_new)                                     # deterministic (in-order splits), tickets re-armed
+
+
 CONVT_CASES = [
     # cin, cout, k, pad, out_pad, H, W, N
     (32, 16, 3, 1, 1, 12, 20, 2),      # generator up path (networks.py:176)
@@ -438,6 +512,58 @@ def test_fused_adam_matches_torch():
     p1.grad = torch.arange(5.0); p2.grad.copy_(torch.arange(5.0).to(DEV))
     o1.step(); o2.step()
     assert_close(p2.detach().cpu(), p1.detach(), 1e-6, "adam ttur")
+
+
+def test_fused_adam_capturable_replays_in_a_hipgraph():
+    """optim.FusedAdam(capturable): step count / learning rate in device memory (v2v_adam_step_dev).  A step captured ONCE by
+    stream capture and replayed N times equals N eager steps of torch.optim.Adam -- the bias corrections advance with the
+    device counter, a learning-rate change on the host reaches the replays (sync_hyper), the checkpointed step count is the
+    device's."""
+    from vid2vid_amd.optim import FusedAdam
+    torch.manual_seed(32)
+    shapes = [(7, 5, 3, 3), (13,), (4, 9)]
+    ref_p = [nn.Parameter(torch.randn(*s)) for s in shapes]
+    dev_p = [nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    ref_opt = torch.optim.Adam(ref_p, lr=2e-4, betas=(0.5, 0.999))
+    opt = FusedAdam(dev_p, lr=2e-4, betas=(0.5, 0.999))
+    gbuf = [torch.zeros(*s, device=DEV) for s in shapes]                 # static gradient source of the captured step
+
+    def body():
+        opt.zero_grad()
+        for p, g in zip(dev_p, gbuf):
+            p.grad.add_(g)
+        opt.step()
+
+    def ref_step(grads):
+        ref_opt.zero_grad()
+        for p, g in zip(ref_p, grads):
+            p.grad = g.clone()
+        ref_opt.step()
+
+    for it in range(2):                                                  # two eager steps first (host counter = 2)
+        grads = [torch.randn(*s) for s in shapes]
+        for b, g in zip(gbuf, grads):
+            b.copy_(g)
+        body(); ref_step(grads)
+    opt.make_capturable()
+    assert opt.device_step() == 2
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    for it in range(5):
+        if it == 3:                                                      # update_learning_rate (models/base_model.py:154-160)
+            for o in (opt, ref_opt):
+                o.param_groups[0]["lr"] = 5e-5
+            opt.sync_hyper()
+        grads = [torch.randn(*s) for s in shapes]
+        for b, gr in zip(gbuf, grads):
+            b.copy_(gr)
+        g.replay(); ref_step(grads)
+    torch.cuda.synchronize()
+    assert opt.device_step() == 7 and opt.state_dict()["step"] == 7
+    for p, q in zip(dev_p, ref_p):
+        assert_close(p.detach().cpu(), q.detach(), 2e-6, "capturable adam parameter after 2 eager + 5 replayed steps")
 
 
 def test_fused_adam_grad_scale_is_the_mean_of_summed_gradients():

@@ -180,8 +180,21 @@ class ConvFn(torch.autograd.Function):
             nbytes = lib.v2v_conv_wgrad_workspace(C.byref(d))
             if nbytes <= 0:
                 check(int(nbytes) or -1, "conv_wgrad_workspace " + cfg.label)
-            d.workspace = eng.scratch("wgrad_ws", (nbytes + 3) // 4).data_ptr()
-            check(lib.v2v_conv_wgrad(C.byref(d), st), "conv_wgrad " + cfg.label)
+            side = eng.wgrad_side_stream()
+            if side is None:
+                d.workspace = eng.scratch("wgrad_ws", (nbytes + 3) // 4).data_ptr()
+                check(lib.v2v_conv_wgrad(C.byref(d), st), "conv_wgrad " + cfg.label)
+            else:
+                # dW is a leaf: its kernels run on the side stream, beside the serial norm-backward / backward-data chain
+                # (engine.wgrad_side_stream).  Ordered behind everything on this stream so far (g, x, the zeroed .grad); the
+                # operands are marked as in use there; the pass's end joins the streams (engine.queue_wgrad_join).
+                side.wait_stream(torch.cuda.current_stream(eng.device))
+                with torch.cuda.stream(side):
+                    d.workspace = eng.scratch("wgrad_ws", (nbytes + 3) // 4).data_ptr()      # (slab scratch: used on this stream only)
+                    check(lib.v2v_conv_wgrad(C.byref(d), C.c_void_p(side.cuda_stream)), "conv_wgrad " + cfg.label)
+                g.record_stream(side)
+                x_t.record_stream(side)
+                eng.queue_wgrad_join()
             eng.log_backward("wgrad", cfg.label, conv, cfg.cin, cout, N, x.H * x.W if transposed else OH * OW)
         # ---- input ----
         dx = None

@@ -406,6 +406,246 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(const WgradKAr
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: 3x3 / stride 1 / pad 1 weight gradient with ALL NINE TAPS per workgroup (bf16 operands, fp32 accumulate).
+//
+// The GEMM-view kernel above gives every (tap, channel chunk) column block its own workgroup, so the nine taps of a layer
+// pull the same X pixels through L2 nine times and a 128 x 128 tile moves 16 KB of operands per 1.05 MFLOP: 64 FLOP per byte
+// of L2 -> LDS traffic, i.e. ~5.5 TB/s of L2 reads at the 320-380 TFLOP/s it reaches (profiles/r06_v1_wgrad_bench.txt) --
+// it is L2-bandwidth-bound at 13-15 % of the matrix peak, and its K split leaves fp32 slabs that a second kernel folds
+// into .grad (wgrad + wgrad_reduce were 25 % of the 512x256 training chunk, profiles/r06_v1_train_by_grid.txt).
+//
+// Here a workgroup owns 64 gradient rows (dY channels) x 64 columns (X channels) x the 9 taps = 36864 fp32 accumulators
+// (4 waves, each 32 x 32 x 9 taps = 9 MFMA tiles = 144 registers) and walks the pixels of its K range image row by image
+// row in 64-pixel segments: per step one 64-pixel dY row segment [64 px][64 ch] (8 KB) and ONE new X row [66 px][64 ch]
+// (8.3 KB) enter LDS by LDS-DMA -- X rows stay in a five-slot ring, the three a dY row needs (y-1, y, y+1, reflect / zero
+// resolved at load time) are always resident -- and feed 36 MFMAs per wave (4 k-blocks x 9 taps): 4.7 MFLOP per 16.5 KB
+// = 288 FLOP / byte, 4.5x the GEMM view.  Both operands are pixel-major, so both fragments come from the transpose read
+// (ds_read_b64_tr_b16) exactly as above; a tap's horizontal shift is a row offset of the LDS address (the chunk swizzle is
+// a function of the row, so shifted reads stay conflict-free), its vertical shift picks the ring slot.
+//
+// The accumulators cover the whole K range of the workgroup, and the gradient leaves ONCE, straight into the PyTorch-layout
+// (or channels-last) .grad buffer: no slab, no reduce / fold pass.  Layers with few tiles split K over `splits` workgroups per
+// tile that add their parts IN SPLIT ORDER (split s waits for a per-tile ticket to reach s: workgroups are dispatched in
+// blockIdx order and the split index is the slow one, so the one waited for is always resident or ahead in the queue):
+// deterministic like the slab path, at the cost of a short serial tail.
+// ---------------------------------------------------------------------------------------------------------------
+struct Wgrad3Args {
+    const char* P; const char* Q; const char* zero_page;
+    float* grad; int* tickets;
+    int N, H, W;            // pixel grid of P and Q (same size: stride 1, pad 1)
+    int PCs, QCs, R, C;     // channel strides (elements), real rows / cols
+    int reflect;
+    int rows_per_split, splits, n_tiles, tiles;
+    int accumulate, grad_cl;
+};
+
+template <int DP>
+__global__ __launch_bounds__(256) void conv_wgrad3x3_bf16_kernel(const Wgrad3Args p) {
+    constexpr int XS = 64;                                   // pixels of a dY row segment
+    constexpr int QPX = 72;                                  // pixel slots of an X row (66 used: xs-1 .. xs+64), 9 LDS-DMA instructions
+    constexpr int NQ = DP + 3, NP = DP + 1;                  // ring depths (see the hazard argument at the issue site)
+    constexpr int QSLOT = QPX * 128, PSLOT = XS * 128;
+    constexpr int QBASE = NP * PSLOT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int split = blockIdx.x / p.tiles, tile = blockIdx.x - split * p.tiles;
+    const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
+    const char* const zp = p.zero_page;
+    const int H = p.H, W = p.W;
+
+    // ---- loaders: one LDS-DMA instruction = 8 pixel rows of 128 bytes; lane -> (row inside, chunk slot) ----
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    const int l_chunk = l_slot ^ ((((l_row >> 1) & 1)) << 2);          // slot holds channel chunk slot ^ swz(row); rows 8q + l_row: bit 1 is l_row's
+    const int p_ch = mt * 64 + l_chunk * 8, q_ch = nt * 64 + l_chunk * 8;
+    const bool p_chok = p_ch < p.PCs, q_chok = q_ch < p.QCs;
+
+    // ---- fragment addressing (bytes inside a slot), constant per lane ----
+    const int lr = lane & 31, hi = lane >> 5;
+    const int g16 = (lane >> 4) & 1, j16 = lane & 15;
+    const int frow = 8 * hi + (j16 >> 2);
+    const int ca = wm * 32 + 16 * g16 + 4 * (j16 & 3), cb = wn * 32 + 16 * g16 + 4 * (j16 & 3);
+    const int a_off = frow * 128 + ((((ca >> 3) ^ (((frow >> 1) & 1) << 2))) << 4) + ((ca & 7) << 1);
+    int b_off[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int r0 = frow + kx;
+        b_off[kx] = r0 * 128 + ((((cb >> 3) ^ (((r0 >> 1) & 1) << 2))) << 4) + ((cb & 7) << 1);
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int g_beg = split * p.rows_per_split;
+    const int g_end = min(g_beg + p.rows_per_split, p.N * H);
+    const int nseg = (W + XS - 1) / XS;
+
+    for (int n = g_beg / H; n * H < g_end; ++n) {
+        const int ya = max(g_beg - n * H, 0), yb = min(g_end - n * H, H);
+        const int T = yb - ya;
+        if (T <= 0) continue;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int xs = sg * XS;
+            const int nk16 = min(XS / 16, (W - xs + 15) >> 4);
+            // stage j (0 .. T+1) = X row ya-1+j (padding resolved here) into Q slot j % NQ, and for j >= 2 dY row ya+j-2 into P
+            // slot j % NP (j < 2: zero fill, which keeps every wave's instruction count per stage fixed for the counted waits)
+            int issued = 0;
+            auto issue = [&]() {
+                const int j = issued;
+                char* const pb = smem + (j % NP) * PSLOT;
+                char* const qb = smem + QBASE + (j % NQ) * QSLOT;
+                const int yp = ya + j - 2;
+                const bool prow_ok = j >= 2 && yp < yb;
+                const char* const prow = p.P + ((long long)(n * H + (prow_ok ? yp : 0)) * W) * p.PCs * 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int q = wid + 4 * i;
+                    const int x = xs + q * 8 + l_row;
+                    const bool ok = prow_ok && p_chok && x < W;
+                    wg_glds16(ok ? prow + ((long long)x * p.PCs + p_ch) * 2 : zp, pb + q * 1024);
+                }
+                int yq = ya - 1 + j;
+                bool qrow_ok = true;
+                if (p.reflect) { yq = yq < 0 ? -yq : yq; yq = yq >= H ? 2 * H - 2 - yq : yq; }
+                else qrow_ok = (unsigned)yq < (unsigned)H;
+                yq = min(max(yq, 0), H - 1);
+                const char* const qrow = p.Q + ((long long)(n * H + yq) * W) * p.QCs * 2;
+                auto qload = [&](int q) {
+                    const int px = q * 8 + l_row;                          // pixel slot: image x = xs - 1 + px
+                    int x = xs - 1 + px;
+                    bool ok = qrow_ok && q_chok && px < XS + 2;
+                    if (p.reflect) { x = x < 0 ? -x : x; x = x >= W ? 2 * W - 2 - x : x; }
+                    ok = ok && (unsigned)x < (unsigned)W;
+                    x = min(max(x, 0), W - 1);
+                    wg_glds16(ok ? qrow + ((long long)x * p.QCs + q_ch) * 2 : zp, qb + q * 1024);
+                };
+                qload(wid); qload(wid + 4);
+                if (wid == 0) qload(8);
+                ++issued;
+            };
+            const int nstages = T + 2;
+            for (int j = 0; j < 2 + DP && j < nstages; ++j) issue();
+            for (int t = 0; t < T; ++t) {
+                // stages <= t+2 must have landed; issued so far: min(t+2+DP, nstages) stages; a wave's loads complete in order
+                if (t + 2 + DP <= nstages) {
+                    if (wid == 0) wg_wait_vmcnt<5 * (DP - 1)>(); else wg_wait_vmcnt<4 * (DP - 1)>();
+                } else wg_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                // stage t+2+DP overwrites Q slot of stage t-1 (last read in step t-1) and the dY row of step t-1: every wave is past both
+                if (t + 2 + DP < nstages) issue();
+                const char* const pa = smem + ((t + 2) % NP) * PSLOT;
+                const unsigned q0 = QBASE + (t % NQ) * QSLOT, q1 = QBASE + ((t + 1) % NQ) * QSLOT, q2 = QBASE + ((t + 2) % NQ) * QSLOT;
+                for (int k16 = 0; k16 < nk16; ++k16) {
+                    union Frag { bf16x8 v; wg_v4s h[2]; };
+                    Frag a;
+                    a.h[0] = wg_tr_read(pa + a_off + k16 * 2048);
+                    a.h[1] = wg_tr_read(pa + a_off + k16 * 2048 + 512);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const char* const qs = smem + (ky == 0 ? q0 : ky == 1 ? q1 : q2) + k16 * 2048;
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            Frag b;
+                            b.h[0] = wg_tr_read(qs + b_off[kx]);
+                            b.h[1] = wg_tr_read(qs + b_off[kx] + 512);
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[ky * 3 + kx], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_barrier();                       // the next run's prologue refills slots the last step may still be reading
+        }
+    }
+
+    // ---- the gradient leaves once.  Split s > 0 waits for the ticket of its tile to reach s (in-order, deterministic) ----
+    const bool add = p.accumulate || split > 0;
+    if (p.splits > 1) {
+        if (tid == 0) {
+            while (__hip_atomic_load(p.tickets + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != split) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+        __threadfence();                                        // acquire: the previous split's stores (other XCD, other L2)
+    }
+    const int col = nt * 64 + wn * 32 + lr;
+    if (p.grad_cl) {                                            // [R][9][C]: 32 lanes of a half-wave = 128 contiguous bytes per (row, tap)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < p.R && col < p.C) {
+                    float* g = p.grad + ((long long)row * 9 + t) * p.C + col;
+                    *g = add ? *g + acc[t][r] : acc[t][r];
+                }
+            }
+    } else {
+        // [R][C][9]: a gradient row's 32 columns x 9 taps are 288 contiguous floats -- transposed through a wave-private LDS
+        // block ([32 cols][9 taps], stride 9 words: conflict-free) so that consecutive lanes touch consecutive addresses
+        const int c0 = nt * 64 + wn * 32;
+        const int ncol = min(32, p.C - c0);
+        const int row0 = mt * 64 + wm * 32;
+        if (ncol == 32 && (p.C & 3) == 0 && row0 + 32 <= p.R) {
+            // full wave tile, 16-byte aligned rows: four phases of 8 gradient rows (registers 4 ph .. 4 ph + 3 of both half-waves
+            // ARE rows 8 ph .. 8 ph + 7).  Per phase a lane parks its 36 values in the wave's [8 rows][288] block, then moves nine
+            // 16-byte vectors: all nine .grad loads of the read-modify-write are in flight together (the first version walked 144
+            // dependent 4-byte round trips per lane: 0.07 -> 0.2 ms per launch once a split or `accumulate` made it add)
+            float* const tb8 = reinterpret_cast<float*>(smem) + wid * (8 * 288);
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) tb8[(rr + 4 * hi) * 288 + lr * 9 + t] = acc[t][4 * ph + rr];
+                f32x4 old[9];
+                float* gp[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const int idx = lane + 64 * i;                       // 16-byte vector of the phase: row idx / 72, vector idx % 72 of the row
+                    const int rw = idx / 72, v4 = idx - rw * 72;
+                    gp[i] = p.grad + ((long long)(row0 + 8 * ph + rw) * p.C + c0) * 9 + v4 * 4;
+                    if (add) old[i] = *reinterpret_cast<const f32x4*>(gp[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(tb8 + (lane + 64 * i) * 4);
+                    if (add) v += old[i];
+                    *reinterpret_cast<f32x4*>(gp[i]) = v;
+                }
+            }
+        } else {
+        float* const tb = reinterpret_cast<float*>(smem) + wid * 576;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) tb[hi * 288 + lr * 9 + t] = acc[t][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int row = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                if (row >= p.R || ncol <= 0) continue;
+                float* const g = p.grad + ((long long)row * p.C + c0) * 9;
+                for (int f = lane; f < ncol * 9; f += 64) {
+                    const float v = tb[h2 * 288 + f];
+                    g[f] = add ? g[f] + v : v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        }
+    }
+    if (p.splits > 1) {
+        __threadfence();                                        // release this split's stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.tickets + tile, split + 1 == p.splits ? 0 : split + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 struct WgradReduceArgs {
     float* slab; float* grad;
     int splits, R, C, KHW, QCs, Rp, Cp, accumulate;
@@ -492,6 +732,60 @@ static int wgrad_cfg() {
     static const int v = [] { const char* e = getenv("V2V_WGRAD_CFG"); return e ? atoi(e) : 0; }();
     return v;
 }
+
+// self-re-arming ticket words of the nine-tap kernel's in-order K splits: one zeroed device pool per process, handed out
+// round-robin in runs of 64-word multiples (an op keeps its words for life; two ops share words only when thousands of ops apart)
+static int* wgrad3_tickets(int n) {
+    constexpr int POOL = 1 << 16;
+    static int* pool = nullptr;
+    static bool failed = false;
+    static unsigned next = 0;
+    const unsigned need = (unsigned)round_up(n, 64);
+    if (failed || need > POOL / 4) return nullptr;
+    if (pool == nullptr) {
+        if (hipMalloc(reinterpret_cast<void**>(&pool), POOL * sizeof(int)) != hipSuccess || hipMemset(pool, 0, POOL * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError(); pool = nullptr; failed = true; return nullptr;
+        }
+    }
+    unsigned at = __atomic_fetch_add(&next, need, __ATOMIC_RELAXED) % POOL;
+    if (at + need > POOL) at = __atomic_fetch_add(&next, need, __ATOMIC_RELAXED) % POOL;      // do not straddle the end
+    if (at + need > POOL) at = 0;
+    return pool + at;
+}
+
+// nine-tap kernel: which layers, and how many in-order K splits.  V2V_WGRAD3=0 switches it off (A/B), V2V_WGRAD3_SPLITS=n forces n.
+static int wgrad3_splits(const v2v_wgrad_desc* d) {
+    const char* const e_on = getenv("V2V_WGRAD3");            // (read per call: the tests and the A/B scripts flip them inside one process)
+    const char* const e_sp = getenv("V2V_WGRAD3_SPLITS");
+    const int on = (e_on && e_on[0] == '0') ? 0 : 1, forced = e_sp ? atoi(e_sp) : 0;
+    if (!on || d->dtype != V2V_BF16 || legacy_bf16()) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->OH != d->QH || d->OW != d->QW) return 0;
+    if (d->QH < 2 || d->QW < 2 || d->rows < 32 || d->cols < 32) return 0;
+    const long long tiles = ceil_div(d->rows, 64) * ceil_div(d->cols, 64);
+    const long long grows = (long long)d->N * d->OH;
+    long long s = forced > 0 ? forced : (tiles >= 192 ? 1 : ceil_div(256, tiles));
+    if (s > 8) s = 8;
+    if (s > grows / 2) s = grows / 2;
+    if (s < 1) s = 1;
+    if (forced <= 0 && tiles * s < 128) return 0;              // too few workgroups for the chip: the GEMM view splits K finer
+    return (int)s;
+}
+
+struct Wgrad3Op : Op {
+    Wgrad3Args a;
+    int launch(hipStream_t s) override {
+        auto kern = conv_wgrad3x3_bf16_kernel<2>;
+        const size_t lds = 3 * 8192 + 5 * 9216;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.splits)), dim3(256), lds, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "conv_wgrad3x3"; }
+};
 
 struct WgradOp : Op {
     WgradKArgs k; WgradReduceArgs r; int dtype, splits, bm; int grad_cl = 0;
@@ -608,6 +902,7 @@ using namespace v2v;
 
 extern "C" int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d) {
     if (wgrad_check(d) != 0) return V2V_EINVAL;
+    if (wgrad3_splits(d) == 1) return 256;                      // nine-tap kernel, unsplit: no slab (a split one may still fall back)
     int mt, nt, sp, kp;
     wgrad_plan(d, &mt, &nt, &sp, &kp);
     return (int64_t)sp * mt * wgrad_bm(d) * nt * WG_BN * (int64_t)sizeof(float);
@@ -617,6 +912,24 @@ extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
     int rc = wgrad_check(d);
     if (rc != 0) return rc;
     if (!d->workspace) { set_error("wgrad: workspace is NULL (size it with v2v_conv_wgrad_workspace)"); return V2V_EINVAL; }
+    if (const int s3 = wgrad3_splits(d)) {
+        const int n_tiles = (int)ceil_div(d->cols, 64), tiles = (int)ceil_div(d->rows, 64) * n_tiles;
+        int* tk = (s3 > 1 && !v2v_get_dry_run()) ? wgrad3_tickets(tiles) : nullptr;
+        if (s3 == 1 || tk != nullptr || v2v_get_dry_run()) {
+            auto op3 = std::make_unique<Wgrad3Op>();
+            Wgrad3Args& a = op3->a;
+            memset(&a, 0, sizeof(a));
+            a.P = (const char*)d->p; a.Q = (const char*)d->q; a.zero_page = (const char*)d->zero_page;
+            a.grad = d->grad; a.tickets = tk;
+            a.N = d->N; a.H = d->OH; a.W = d->OW; a.PCs = d->p_stride; a.QCs = d->q_stride; a.R = d->rows; a.C = d->cols;
+            a.reflect = d->pad_mode == V2V_PAD_REFLECT ? 1 : 0;
+            a.splits = s3; a.rows_per_split = (int)ceil_div((long long)d->N * d->OH, s3);
+            a.splits = (int)ceil_div((long long)d->N * d->OH, a.rows_per_split);
+            a.n_tiles = n_tiles; a.tiles = tiles;
+            a.accumulate = d->accumulate & 1; a.grad_cl = (d->accumulate >> 1) & 1;
+            return submit(std::move(op3), stream);
+        }
+    }
     auto op = std::make_unique<WgradOp>();
     int mt, nt, sp, kp;
     wgrad_plan(d, &mt, &nt, &sp, &kp);

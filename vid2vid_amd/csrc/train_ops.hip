@@ -138,6 +138,44 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
     }
 }
 
+// Graph-replayable form (optim.FusedAdam(capturable)): the 1-based step count and the learning rate live in DEVICE memory, so a
+// launch captured once into a hipGraph keeps advancing the bias corrections on every replay (a by-value `step` would be frozen
+// at its capture-time value).  state = {int step; float lr}: one thread bumps `step` in a launch of its own just before.
+struct AdamDevState { int step; float lr; };
+struct AdamDevArgs { float* p; const float* g; float* m; float* v; long long n; float b1, b2, eps, wd, gscale; AdamDevState* st; };
+
+__global__ void adam_tick_kernel(AdamDevState* st) { st->step += 1; }
+
+__global__ __launch_bounds__(256) void adam_step_dev_kernel(const AdamDevArgs a) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int step = a.st->step;
+    const double bc1 = 1.0 - pow((double)a.b1, (double)step);        // the host form's arithmetic (v2v_adam_step), once per thread
+    const double bc2 = 1.0 - pow((double)a.b2, (double)step);
+    const float step_size = a.st->lr / (float)bc1;
+    const float bc2_sqrt = (float)sqrt(bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        float g = a.g[i] * a.gscale;
+        const float p = a.p[i];
+        if (a.wd != 0.f) g += a.wd * p;
+        const float m = a.b1 * a.m[i] + (1.f - a.b1) * g;
+        const float v = a.b2 * a.v[i] + (1.f - a.b2) * g * g;
+        a.m[i] = m; a.v[i] = v;
+        const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+        a.p[i] = p - step_size * (m / denom);
+    }
+}
+
+struct AdamDevOp : Op {
+    AdamDevArgs a;
+    int launch(hipStream_t s) override {
+        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, a.st);
+        long long b = ceil_div(a.n, 256 * 4); if (b > 8192) b = 8192; if (b < 1) b = 1;
+        hipLaunchKernelGGL(adam_step_dev_kernel, dim3((unsigned)b), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    const char* name() const override { return "adam_step_dev"; }
+};
+
 struct AdamOp : Op {
     AdamArgs a;
     int launch(hipStream_t s) override {
@@ -219,6 +257,15 @@ extern "C" int v2v_adam_step(float* param, const float* grad, float* exp_avg, fl
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     op->a = AdamArgs{param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), weight_decay, grad_scale};
+    return submit(std::move(op), stream);
+}
+
+extern "C" int v2v_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                 void* state, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || !state) { set_error("adam (device state): bad argument"); return V2V_EINVAL; }
+    auto op = std::make_unique<AdamDevOp>();
+    op->a = AdamDevArgs{param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, grad_scale, reinterpret_cast<AdamDevState*>(state)};
     return submit(std::move(op), stream);
 }
 

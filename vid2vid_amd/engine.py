@@ -569,6 +569,15 @@ class Engine:
             self.pair_override = tuple(int(v) for v in os.environ["V2V_PAIR_TILE"].split(","))
         self.lanes_enabled = False   # set by the frame plan: emit independent towers / branches on parallel lanes
         self._thrash = None
+        # Round 6: weight-gradient launches of a backward pass go to a SIDE stream (autograd.ConvFn.backward).  dW is a leaf of
+        # the backward graph -- nothing downstream of a layer's backward needs it before the optimizer step -- while the chain
+        # norm-backward -> backward-data -> next layer is strictly serial and leaves the chip idle between its ~4000 dependent
+        # launches per chunk (the device is busy 70 % of a chunk, and replaying the chunk as ONE hipGraph does not change that:
+        # the gaps are the device's kernel-to-kernel turnaround, not host time; profiles/r06_v3_traingraph.txt).  V2V_WGRAD_STREAM=0
+        # keeps everything on one stream.
+        self.wgrad_stream_on = os.environ.get("V2V_WGRAD_STREAM", "1") != "0"
+        self._wgrad_stream = None
+        self._wgrad_join_queued = False
         self.plan = None        # Plan being recorded (for labels / keep-alive)
         self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
         self.tile_override = {}  # (cin,cout,KH,stride,transposed) -> tile id (tests / manual tuning)
@@ -685,6 +694,30 @@ class Engine:
         """The current lane continues after everything emitted so far on lane k."""
         if self.lanes_enabled and k != self._lane:
             check(lib.v2v_plan_lane_wait(self._lane, k), "plan_lane_wait")
+
+    def wgrad_side_stream(self):
+        """The stream weight-gradient kernels run on, or None (switch off / no device / record-only engine)."""
+        if not self.wgrad_stream_on or self.record_only or self.device.type != "cuda":
+            return None
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+            from . import parallel
+            parallel.register_grad_stream(self._wgrad_stream)      # bucket all-reduces sent from inside the pass must wait for it too
+        return self._wgrad_stream
+
+    def queue_wgrad_join(self):
+        """Called from inside a backward pass after the first side-stream launch: when the autograd engine has finished the pass,
+        the stream that called backward() waits for the side stream -- whatever reads .grad next (optimizer step, a test, a
+        gradient clip) is ordered behind every weight-gradient kernel without knowing about the side stream."""
+        if self._wgrad_join_queued:
+            return
+        self._wgrad_join_queued = True
+        side = self._wgrad_stream
+
+        def join():
+            self._wgrad_join_queued = False
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.autograd.Variable._execution_engine.queue_callback(join)
 
     def zero_page(self):
         """256 zero bytes: source of padded / ragged lanes of the LDS-DMA loaders."""
@@ -839,6 +872,11 @@ class Engine:
         tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
         if d.tile == 0 and tune_key in self._tuned:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
+        if d.tile in PERSISTENT_TILES and not (self.dtype == L.BF16 and d.out_mode == L.OUT_RAW_F32_NHWC):
+            # a cached / overridden selection made under another raw-output mode or dtype (the key holds the LOGICAL out_mode:
+            # V2V_RAW_BF16 flips the effective one; an fp32 engine may share the cache file): the persistent tiles write fp32 raw
+            # from bf16 only -- fall back to the library's default tile instead of failing at launch
+            d.tile, d.splitk, d.prefetch = 0, 1, 0
         if act_b is not None:
             d.tile, d.splitk, d.prefetch = 60, 1, 0          # per-channel epilogues exist in the 7x7 head kernels only
         if d.tile == 60 and self.rowsum_heads and (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed)) not in self.tile_override \
@@ -1312,8 +1350,12 @@ class Engine:
         return pc
 
     def _use_korder(self, d, mod, cin_stride, korder, role="fwd", reflect=False):
-        if d.tile in PERSISTENT_TILES and cin_stride == 32 and role == "fwd":
-            korder = 3            # 64-byte pixels on the persistent single-chunk tiles: paired-x packing (PairedXConv; pairx_eligible)
+        if d.tile in PERSISTENT_TILES and cin_stride == 32 and role == "fwd" and (self.pairx_eligible(d) or self.pairx_t_eligible(d)):
+            # 64-byte pixels on the persistent single-chunk tiles: paired-x packing (PairedXConv).  Gated on the view's own
+            # eligibility (round 6: an fp32 engine's 32-channel layers -- one 128-byte chunk, patch-eligible, so the
+            # persistent tiles are among the candidates -- took this branch and PairedXConv raised for FlowNet2's 64 -> 32
+            # layers at 512x256); everything else keeps the tile's own packing and the library refuses what it cannot run
+            korder = 3
         pc = self.packed(mod, cin_stride, role=role, reflect=reflect, korder=korder)
         d.w, d.w_korder = pc.buf.data_ptr(), korder
         return pc
@@ -1742,9 +1784,19 @@ class Engine:
         self.label("add_nhwc")
         return y
 
+    def _fg_labels(self, fg_labels):
+        """The foreground label ids on the device, built once per id list: torch.tensor(list, device=...) is a synchronous copy
+        from pageable memory -- not permitted inside a stream capture (graphed.ChunkGraphs), and a host round trip per frame."""
+        key = tuple(int(v) for v in fg_labels)
+        cache = self.__dict__.setdefault("_fg_label_cache", {})
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = torch.tensor(list(key), dtype=torch.int32, device=self.device)
+        return t
+
     def fg_mask(self, x, base_ch, fg_labels):
         mask = self.empty_f32(x.N, 1, x.H, x.W)
-        fg = torch.tensor(list(fg_labels), dtype=torch.int32, device=self.device)
+        fg = self._fg_labels(fg_labels)
         self._keep(fg)
         check(lib.v2v_fg_mask_nhwc(_ptr(x.t), _ptr(mask), x.N * x.H * x.W, x.Cs, base_ch, _ptr(fg), fg.numel(),
                                    self.dtype, _stream()), "fg_mask")
@@ -1771,7 +1823,7 @@ class Engine:
         mask = self.empty_f32(1, 1, H, W) if want_mask else None
         fg = None
         if want_mask:
-            fg = torch.tensor(list(fg_labels), dtype=torch.int32, device=self.device)
+            fg = self._fg_labels(fg_labels)
             self._keep(fg)
         u8 = labels.dtype == torch.uint8
         if u8 and inst is not None and inst.dtype != torch.int32:
@@ -1807,7 +1859,7 @@ class Engine:
         mask = self.empty_f32(1, 1, H, W) if want_mask else None
         fg = None
         if want_mask:
-            fg = torch.tensor(list(fg_labels), dtype=torch.int32, device=self.device)
+            fg = self._fg_labels(fg_labels)
             self._keep(fg)
         if labels.dtype == torch.uint8:              # uint8 label map + int32 instance map
             if inst is not None and inst.dtype != torch.int32:

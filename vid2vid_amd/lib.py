@@ -101,6 +101,7 @@ PROTOTYPES = {
     "v2v_loss_forward": (C.c_int, [_I, _P, _P, _P, _F, _F, _L, _I, _I, _L, _L, _L, _I, _P, _P, _I, _P]),
     "v2v_loss_backward": (C.c_int, [_I, _P, _P, _P, _F, _F, _L, _I, _I, _L, _L, _L, _I, _P, _P, _I, _P]),
     "v2v_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "v2v_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),
     "v2v_memset_zero": (C.c_int, [_P, _L, _P]),
     "v2v_bn_finalize": (C.c_int, [_P, _I, _I, _L, _P, _P, _F, _P, _P, _P, _F, _P, _P]),
     "v2v_bn_finalize_groups": (C.c_int, [_I]),

@@ -116,7 +116,10 @@ class FlowNet(BaseModel):
         fp.im1.copy_(im1.to(self.device, torch.float32))
         fp.im2.copy_(im2.to(self.device, torch.float32))
         if not self.engine.record_only:
-            fp.plan.launch()
+            if torch.cuda.is_current_stream_capturing():
+                fp.plan.run()                  # inside a stream capture (graphed.ChunkGraphs): the launches themselves join the capture
+            else:
+                fp.plan.launch()
             self.flops_launched += fp.conv_flops
             self.convs_launched += fp.n_convs
         return fp.flow.clone(), fp.conf.clone()

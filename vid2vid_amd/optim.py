@@ -85,6 +85,11 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.step_count = 0
         self.grad_sync = grad_sync          # parallel.GradSync or None (single process)
+        # capturable (graphed.ChunkGraphs): step count and learning rate live in device memory ({int32 step; float lr}) and the
+        # update runs as v2v_adam_step_dev, so a step() captured into a hipGraph advances its bias corrections on every replay
+        self.capturable = False
+        self._dev_state = None
+        self._dev_lr = None
 
     def rebuild(self, params, lr=None, betas=None):
         """Re-home a (larger) parameter list in fresh flat buffers IN PLACE: same optimizer object, same grad_sync,
@@ -107,14 +112,42 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.step_count = 0
+        if self.capturable:
+            self.make_capturable()
         self.state.clear()
+
+    def make_capturable(self):
+        """Move the step count / learning rate to device memory (idempotent).  From here on `step_count` of this object is the
+        count of step() CALLS the host has seen; the authoritative count is on the device (`device_step()`), because graph
+        replays run updates the host never sees."""
+        if self._dev_state is None:
+            self._dev_state = torch.zeros(2, dtype=torch.int32, device=self.flat.flat_param.device)
+        lr = float(self.param_groups[0]["lr"])
+        host = torch.zeros(2, dtype=torch.int32)
+        host[0] = int(self.step_count)               # word 0: updates done so far (int32)
+        host[1:2].view(torch.float32)[0] = lr        # word 1: learning rate (float bits)
+        self._dev_state.copy_(host)
+        self._dev_lr = lr
+        self.capturable = True
+
+    def sync_hyper(self):
+        """Capturable mode: push a learning rate changed on the host (update_learning_rate, models/base_model.py:154-160) to
+        the device word the captured update reads.  Cheap when nothing changed; call before replaying a captured step."""
+        if self.capturable:
+            lr = float(self.param_groups[0]["lr"])
+            if lr != self._dev_lr:
+                self._dev_state[1:2].view(torch.float32).fill_(lr)
+                self._dev_lr = lr
+
+    def device_step(self):
+        return int(self._dev_state[0].item()) if self.capturable else self.step_count
 
     # ---- checkpointing (an extension: the reference never saves optimizer state, SURVEY 8f rank 4) ----
     def state_dict(self):
         """Flat moments + step count + hyper-parameters.  The layout is the parameter order of this optimizer
         (FlatBuffers.offsets), so a checkpoint is valid for the same network definition."""
         grp = self.param_groups[0]
-        return {"step": self.step_count, "exp_avg": self.exp_avg.detach().cpu().clone(),
+        return {"step": self.device_step(), "exp_avg": self.exp_avg.detach().cpu().clone(),
                 "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(), "numel": self.flat.numel,
                 "hyper": {k: grp[k] for k in ("lr", "betas", "eps", "weight_decay")}}
 
@@ -128,6 +161,8 @@ class FusedAdam(torch.optim.Optimizer):
             self.exp_avg_sq.copy_(state["exp_avg_sq"])
         for k, v in state.get("hyper", {}).items():
             self.param_groups[0][k] = tuple(v) if k == "betas" else v
+        if self.capturable:
+            self.make_capturable()                   # re-seed the device words from the restored count / learning rate
 
     def zero_grad(self, set_to_none=False):
         from .lib import lib, check
@@ -160,6 +195,13 @@ class FusedAdam(torch.optim.Optimizer):
             sptr = None
             if f.flat_param.is_cuda:
                 sptr = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+            if self.capturable:
+                self.sync_hyper()
+                check(lib.v2v_adam_step_dev(C.c_void_p(f.flat_param.data_ptr()), C.c_void_p(f.flat_grad.data_ptr()),
+                                            C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+                                            f.numel, float(b1), float(b2), float(grp["eps"]), float(grp["weight_decay"]),
+                                            float(gscale), C.c_void_p(self._dev_state.data_ptr()), sptr), "adam_step_dev")
+                return
             check(lib.v2v_adam_step(C.c_void_p(f.flat_param.data_ptr()), C.c_void_p(f.flat_grad.data_ptr()),
                                     C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
                                     f.numel, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),

@@ -46,6 +46,16 @@ def host_staged(t, group=None):
     return bool(t.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo")
 
 
+_GRAD_STREAMS = []
+
+
+def register_grad_stream(stream):
+    """A stream other than the compute stream on which gradient-writing kernels run (engine.wgrad_side_stream): collectives
+    that are sent from inside a backward pass wait for it as well as for the compute stream."""
+    if stream not in _GRAD_STREAMS:
+        _GRAD_STREAMS.append(stream)
+
+
 class GradSync:
     """Bucketed in-place all-reduce (sum) of a flat gradient buffer, overlapped with the NEXT backward pass.
 
@@ -151,6 +161,9 @@ class GradSync:
         ev = torch.cuda.Event()
         ev.record(cur)
         side.wait_event(ev)
+        for gs_ in _GRAD_STREAMS:                    # weight-gradient kernels of the nodes that just reported (their own stream)
+            if gs_.device == b.device:
+                side.wait_stream(gs_)
         with torch.cuda.stream(side):
             self.reduce_bucket(b)
             done = torch.cuda.Event()
