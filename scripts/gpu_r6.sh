@@ -51,9 +51,21 @@ if has trainops; then
   grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_trainops.log | cut -c1-300 | tail -30
   lap trainops
 fi
+if has wgradpmc; then   # where do the nine-tap weight-gradient kernel's wave cycles go?  (one counter group per pass; 1024 -> 1024 at 64x32)
+  cd /tmp
+  for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+    tag=$(echo $pass | cut -d' ' -f1)
+    timeout 200 rocprofv3 --kernel-trace --pmc $pass -d /tmp/wg3pmc_$tag -o pmc -- python $R/scripts/wgrad3_run.py 1024 1024 32 64 12 1 > $R/gpurun_out/${TAG}_wgradpmc_$tag.log 2>&1; echo "wgradpmc $tag rc=$?"
+    python $R/scripts/pmc_summary.py $(find /tmp/wg3pmc_$tag -name "*.db" | head -1) "# rocprofv3 --kernel-trace --pmc $pass -- python scripts/wgrad3_run.py 1024 1024 32 64 12 1" 2>>$R/gpurun_out/${TAG}_wgradpmc_$tag.log | grep -E "^#|wgrad3x3" | cut -c1-30,96-200
+  done 2>&1 | tee $R/gpurun_out/${TAG}_wgradpmc.txt
+  grep "wgrad 3x3" $R/gpurun_out/${TAG}_wgradpmc_SQ_WAVE_CYCLES.log
+  cd $R
+  lap wgradpmc
+fi
 if has trainab; then     # one-stream vs side-stream weight gradients, GEMM-view vs nine-tap kernel, alternating on this box
   for rep in 1 2; do
-    for cfg in "V2V_WGRAD_STREAM=0 V2V_WGRAD3=0" "V2V_WGRAD_STREAM=0 V2V_WGRAD3=1" "V2V_WGRAD_STREAM=1 V2V_WGRAD3=0" "V2V_WGRAD_STREAM=1 V2V_WGRAD3=1"; do
+    for cfg in ${ABCFGS:-V2V_WGRAD_STREAM=0,V2V_WGRAD3=0,V2V_REPACK_ASYNC=0 V2V_WGRAD_STREAM=1,V2V_WGRAD3=1,V2V_REPACK_ASYNC=0 V2V_WGRAD_STREAM=1,V2V_WGRAD3=1,V2V_REPACK_ASYNC=1 V2V_WGRAD_STREAM=1,V2V_WGRAD3=1,V2V_REPACK_ASYNC=1,V2V_SKIP_WGRAD=1}; do
+      cfg=$(echo $cfg | tr ',' ' ')
       env $cfg timeout 600 python bench.py --mode train --steps 9 --warmup 3 --no-train-parity $GEO 2>gpurun_out/${TAG}_trainab.err | python -c "
 import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train [$cfg] run $rep:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', 'loss_G', j['config'].get('loss_G'), j['config'].get('loss_D'))"
     done

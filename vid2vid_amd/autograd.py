@@ -38,6 +38,9 @@ def _grad_ptr(p):
 
 
 _NORM_BIAS_GRAD = os.environ.get("V2V_NORM_BIAS_GRAD", "0") == "1"
+# measurement only (scripts/gpu_r6.sh trainab): leave the weight-gradient launches out, to see what the rest of the step costs
+# with nothing beside it on the chip.  The step it times is NOT a training step.
+_SKIP_WGRAD = os.environ.get("V2V_SKIP_WGRAD", "0") == "1"
 
 
 def is_channels_last(t):
@@ -161,7 +164,7 @@ class ConvFn(torch.autograd.Function):
                   "channel_sum " + cfg.label)
         # ---- weight ----
         transposed = isinstance(conv, nn.ConvTranspose2d)
-        if weight.requires_grad:
+        if weight.requires_grad and not _SKIP_WGRAD:
             d = WgradDesc()
             if transposed:
                 d.p, d.q = x_t.data_ptr(), g.data_ptr()

@@ -23,6 +23,7 @@
 #include "v2v_internal.h"
 #include <cstring>
 #include <cstdlib>
+#include <type_traits>
 
 namespace v2v {
 
@@ -426,20 +427,62 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_bf16_kernel(const WgradKAr
 // a function of the row, so shifted reads stay conflict-free), its vertical shift picks the ring slot.
 //
 // The accumulators cover the whole K range of the workgroup, and the gradient leaves ONCE, straight into the PyTorch-layout
-// (or channels-last) .grad buffer: no slab, no reduce / fold pass.  Layers with few tiles split K over `splits` workgroups per
-// tile that add their parts IN SPLIT ORDER (split s waits for a per-tile ticket to reach s: workgroups are dispatched in
-// blockIdx order and the split index is the slow one, so the one waited for is always resident or ahead in the queue):
-// deterministic like the slab path, at the cost of a short serial tail.
+// (or channels-last) .grad buffer: no reduce / fold pass.  Layers with few tiles split K over `splits` workgroups per tile; each
+// parks its accumulators in a slab and the last to arrive (one ticket per tile) adds the slabs in split order and writes the
+// gradient: deterministic like the reduce pass it replaces, inside the launch.
 // ---------------------------------------------------------------------------------------------------------------
 struct Wgrad3Args {
     const char* P; const char* Q; const char* zero_page;
-    float* grad; int* tickets;
+    float* grad; int* tickets; float* slab;
     int N, H, W;            // pixel grid of P and Q (same size: stride 1, pad 1)
     int PCs, QCs, R, C;     // channel strides (elements), real rows / cols
     int reflect;
     int rows_per_split, splits, n_tiles, tiles;
     int accumulate, grad_cl;
 };
+
+// One dY row segment against its three X rows: k-blocks of 16 pixels x 9 taps.  Two fragment sets: the 20 transpose reads of
+// k-block k+1 are issued in front of the 9 MFMAs of block k, which wait only for their own set (LDS returns in order:
+// lgkmcnt(20)), so that a step waits for LDS once -- for its first block -- and not in front of every MFMA (counters of the
+// first version: waves parked 66 % of their cycles, matrix pipe busy 20 %; profiles/r06_v5_wgradpmc.txt).  The reads are inline
+// asm with immediate offsets: with the builtin the compiler (a) cannot prove that they do not alias the LDS-DMA writes in flight
+// and drains vmcnt to 0 in front of the first read of every step -- which throws the two-stage prefetch away -- and (b) sinks
+// every read to just in front of its consumer.
+// pa: LDS byte address of the dY slot + the lane's A offset; qb[ky * 3 + kx]: X slot of row y-1+ky + the lane's B offset for kx.
+union Wg3Frag { bf16x8 v; wg_v4s h[2]; };
+
+template <int OFF> __device__ __forceinline__ void wg3_read(wg_v4s& r, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+}
+// the 20 reads of a k-block in two halves of 10 (the LDS counter holds 15): A + taps 0-3, then taps 4-8
+template <int K16> __device__ __forceinline__ void wg3_issue_a(Wg3Frag& a, Wg3Frag (&b)[9], unsigned pa, const unsigned (&qb)[9]) {
+    wg3_read<K16 * 2048>(a.h[0], pa);
+    wg3_read<K16 * 2048 + 512>(a.h[1], pa);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        wg3_read<K16 * 2048>(b[t].h[0], qb[t]);
+        wg3_read<K16 * 2048 + 512>(b[t].h[1], qb[t]);
+    }
+}
+template <int K16> __device__ __forceinline__ void wg3_issue_b(Wg3Frag (&b)[9], const unsigned (&qb)[9]) {
+#pragma unroll
+    for (int t = 4; t < 9; ++t) {
+        wg3_read<K16 * 2048>(b[t].h[0], qb[t]);
+        wg3_read<K16 * 2048 + 512>(b[t].h[1], qb[t]);
+    }
+}
+// wait until at most N LDS reads are outstanding; the fragment registers are tied to the wait so that no consumer moves above it
+template <int N> __device__ __forceinline__ void wg3_wait(Wg3Frag& a, Wg3Frag (&b)[9]) {
+    asm volatile("s_waitcnt lgkmcnt(%14)"
+                 : "+v"(a.h[0]), "+v"(a.h[1]), "+v"(b[0].h[0]), "+v"(b[0].h[1]), "+v"(b[1].h[0]), "+v"(b[1].h[1]), "+v"(b[2].h[0]),
+                   "+v"(b[2].h[1]), "+v"(b[3].h[0]), "+v"(b[3].h[1]), "+v"(b[4].h[0]), "+v"(b[4].h[1]), "+v"(b[5].h[0]), "+v"(b[5].h[1])
+                 : "n"(N));
+    asm volatile("" : "+v"(b[6].h[0]), "+v"(b[6].h[1]), "+v"(b[7].h[0]), "+v"(b[7].h[1]), "+v"(b[8].h[0]), "+v"(b[8].h[1]));
+}
+template <int T0, int T1> __device__ __forceinline__ void wg3_mma(f32x16 (&acc)[9], const Wg3Frag& a, const Wg3Frag (&b)[9]) {
+#pragma unroll
+    for (int t = T0; t < T1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b[t].v, acc[t], 0, 0, 0);
+}
 
 template <int DP>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_bf16_kernel(const Wgrad3Args p) {
@@ -531,6 +574,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_bf16_kernel(const Wgrad3Arg
             };
             const int nstages = T + 2;
             for (int j = 0; j < 2 + DP && j < nstages; ++j) issue();
+            auto run_steps = [&](auto NKc) {
+            constexpr int NK = decltype(NKc)::value;
             for (int t = 0; t < T; ++t) {
                 // stages <= t+2 must have landed; issued so far: min(t+2+DP, nstages) stages; a wave's loads complete in order
                 if (t + 2 + DP <= nstages) {
@@ -539,38 +584,81 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_bf16_kernel(const Wgrad3Arg
                 __builtin_amdgcn_s_barrier();
                 // stage t+2+DP overwrites Q slot of stage t-1 (last read in step t-1) and the dY row of step t-1: every wave is past both
                 if (t + 2 + DP < nstages) issue();
-                const char* const pa = smem + ((t + 2) % NP) * PSLOT;
                 const unsigned q0 = QBASE + (t % NQ) * QSLOT, q1 = QBASE + ((t + 1) % NQ) * QSLOT, q2 = QBASE + ((t + 2) % NQ) * QSLOT;
-                for (int k16 = 0; k16 < nk16; ++k16) {
-                    union Frag { bf16x8 v; wg_v4s h[2]; };
-                    Frag a;
-                    a.h[0] = wg_tr_read(pa + a_off + k16 * 2048);
-                    a.h[1] = wg_tr_read(pa + a_off + k16 * 2048 + 512);
+                const unsigned sb = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)smem;
+                const unsigned pa = sb + ((t + 2) % NP) * PSLOT + a_off;
+                unsigned qb[9];
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const char* const qs = smem + (ky == 0 ? q0 : ky == 1 ? q1 : q2) + k16 * 2048;
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            Frag b;
-                            b.h[0] = wg_tr_read(qs + b_off[kx]);
-                            b.h[1] = wg_tr_read(qs + b_off[kx] + 512);
-                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[ky * 3 + kx], 0, 0, 0);
-                        }
-                    }
+                for (int kx = 0; kx < 3; ++kx) { qb[kx] = sb + q0 + b_off[kx]; qb[3 + kx] = sb + q1 + b_off[kx]; qb[6 + kx] = sb + q2 + b_off[kx]; }
+                Wg3Frag fa[2], fb[2][9];
+                // block k: first half of the next set's reads, wait for THIS set (everything but those 10), five MFMAs, the other
+                // half, four MFMAs.  A set's registers are refilled only behind the issue of the last MFMA that reads them.
+                wg3_issue_a<0>(fa[0], fb[0], pa, qb); wg3_issue_b<0>(fb[0], qb);
+                wg3_issue_a<1>(fa[1], fb[1], pa, qb); wg3_wait<10>(fa[0], fb[0]); wg3_mma<0, 5>(acc, fa[0], fb[0]);
+                wg3_issue_b<1>(fb[1], qb);                                        wg3_mma<5, 9>(acc, fa[0], fb[0]);
+                if constexpr (NK == 4) {
+                    wg3_issue_a<2>(fa[0], fb[0], pa, qb); wg3_wait<10>(fa[1], fb[1]); wg3_mma<0, 5>(acc, fa[1], fb[1]);
+                    wg3_issue_b<2>(fb[0], qb);                                        wg3_mma<5, 9>(acc, fa[1], fb[1]);
+                    wg3_issue_a<3>(fa[1], fb[1], pa, qb); wg3_wait<10>(fa[0], fb[0]); wg3_mma<0, 5>(acc, fa[0], fb[0]);
+                    wg3_issue_b<3>(fb[1], qb);                                        wg3_mma<5, 9>(acc, fa[0], fb[0]);
                 }
+                wg3_wait<0>(fa[1], fb[1]); wg3_mma<0, 9>(acc, fa[1], fb[1]);
             }
+            };
+            // a segment runs two or four 16-pixel k-blocks per step, branch-free (pixels beyond the row's end are zero-filled dY:
+            // they add nothing), each as its own copy of the step loop
+            if (nk16 > 2) run_steps(std::integral_constant<int, 4>{}); else run_steps(std::integral_constant<int, 2>{});
             __builtin_amdgcn_s_barrier();                       // the next run's prologue refills slots the last step may still be reading
         }
     }
 
-    // ---- the gradient leaves once.  Split s > 0 waits for the ticket of its tile to reach s (in-order, deterministic) ----
-    const bool add = p.accumulate || split > 0;
+    // ---- the gradient leaves once.  K splits: every split parks its accumulators in a slab (fragment order: 16-byte stores, no
+    //      waiting), takes a ticket of its tile, and the LAST one to arrive adds all `splits` slabs IN SPLIT ORDER -- its own
+    //      included, so the result does not depend on which workgroup came last -- and writes the gradient.  (The first version
+    //      chained the splits through the ticket, each adding into .grad in turn: 16 us of fences and dependent round trips
+    //      per link, 0.083 ms for the 512 -> 512 layer on four splits against 0.052 for the kernels it replaces.) ----
+    const bool add = p.accumulate != 0;
     if (p.splits > 1) {
+        f32x4* const mine = reinterpret_cast<f32x4*>(p.slab) + (((long long)split * p.tiles + tile) * 4 + wid) * (36 * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                mine[(t * 4 + q) * 64] = v;
+            }
+        __syncthreads();                                        // (the compiler drains this wave's stores in front of the barrier)
+        int* const flag = reinterpret_cast<int*>(smem);
         if (tid == 0) {
-            while (__hip_atomic_load(p.tickets + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != split) __builtin_amdgcn_s_sleep(8);
+            __threadfence();                                    // release the slab: ONE wave writes back / invalidates for the workgroup
+            const int old = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == p.splits - 1;
+            if (last) {
+                __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm
+                __threadfence();                                // acquire the other splits' slabs (other XCDs, other L2s)
+            }
+            *flag = last;
         }
         __syncthreads();
-        __threadfence();                                        // acquire: the previous split's stores (other XCD, other L2)
+        if (*flag == 0) return;
+        __syncthreads();                                        // (everybody has read the flag: the block below reuses this LDS)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int sp = 0; sp < p.splits; ++sp) {
+            const f32x4* const src = reinterpret_cast<const f32x4*>(p.slab) + (((long long)sp * p.tiles + tile) * 4 + wid) * (36 * 64) + lane;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = src[(t * 4 + q) * 64];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[t][4 * q] += v[q][0]; acc[t][4 * q + 1] += v[q][1]; acc[t][4 * q + 2] += v[q][2]; acc[t][4 * q + 3] += v[q][3];
+                }
+            }
+        }
     }
     const int col = nt * 64 + wn * 32 + lr;
     if (p.grad_cl) {                                            // [R][9][C]: 32 lanes of a half-wave = 128 contiguous bytes per (row, tap)
@@ -619,7 +707,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_bf16_kernel(const Wgrad3Arg
                 }
             }
         } else {
-        float* const tb = reinterpret_cast<float*>(smem) + wid * 576;
+        float* const tb = reinterpret_cast<float*>(smem) + wid * (8 * 288);      // the wave's own block (waves of one workgroup may take different paths)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -638,11 +726,6 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_bf16_kernel(const Wgrad3Arg
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         }
-    }
-    if (p.splits > 1) {
-        __threadfence();                                        // release this split's stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(p.tickets + tile, split + 1 == p.splits ? 0 : split + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -763,11 +846,16 @@ static int wgrad3_splits(const v2v_wgrad_desc* d) {
     if (d->QH < 2 || d->QW < 2 || d->rows < 32 || d->cols < 32) return 0;
     const long long tiles = ceil_div(d->rows, 64) * ceil_div(d->cols, 64);
     const long long grows = (long long)d->N * d->OH;
-    long long s = forced > 0 ? forced : (tiles >= 192 ? 1 : ceil_div(256, tiles));
-    if (s > 8) s = 8;
+    // K splits (slab + last-arriver reduce inside the launch).  Measured with the pipelined step (profiles/r06_v6_wgrad_bench.txt):
+    // 512 -> 512 at 64x32 (64 tiles) 39 us on 2 splits / 44 on 4 against 52 for the GEMM view + reduce; 256 -> 256 at 128x64 (16
+    // tiles) 54 on 8 against 56; 128 -> 128 at 512x256 (4 tiles) 297 on 8 against 127 -- a workgroup's fixed costs (pipeline
+    // fill, slab round trip, the gradient's read-modify-write) do not shrink with its share of K, so: as few splits as give ~128
+    // workgroups, at most 8, and layers that cannot reach 128 workgroups that way stay on the GEMM view.
+    long long s = forced > 0 ? forced : (tiles >= 128 ? 1 : ceil_div(128, tiles));
+    if (forced <= 0 && s > 8) return 0;
     if (s > grows / 2) s = grows / 2;
     if (s < 1) s = 1;
-    if (forced <= 0 && tiles * s < 128) return 0;              // too few workgroups for the chip: the GEMM view splits K finer
+    if (forced <= 0 && tiles * s < 128) return 0;
     return (int)s;
 }
 
@@ -902,10 +990,14 @@ using namespace v2v;
 
 extern "C" int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d) {
     if (wgrad_check(d) != 0) return V2V_EINVAL;
-    if (wgrad3_splits(d) == 1) return 256;                      // nine-tap kernel, unsplit: no slab (a split one may still fall back)
+    const int s3 = wgrad3_splits(d);
+    if (s3 == 1) return 256;                                    // nine-tap kernel, unsplit: no slab
     int mt, nt, sp, kp;
     wgrad_plan(d, &mt, &nt, &sp, &kp);
-    return (int64_t)sp * mt * wgrad_bm(d) * nt * WG_BN * (int64_t)sizeof(float);
+    const int64_t gemm_view = (int64_t)sp * mt * wgrad_bm(d) * nt * WG_BN * (int64_t)sizeof(float);
+    // nine-tap kernel with K splits: [split][tile][4 waves][36 x 64 lanes x 16 bytes]  (it may still fall back to the GEMM view)
+    const int64_t nine_tap = s3 > 1 ? (int64_t)s3 * ceil_div(d->rows, 64) * ceil_div(d->cols, 64) * 4 * 36 * 64 * 16 : 0;
+    return gemm_view > nine_tap ? gemm_view : nine_tap;
 }
 
 extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
@@ -920,7 +1012,7 @@ extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
             Wgrad3Args& a = op3->a;
             memset(&a, 0, sizeof(a));
             a.P = (const char*)d->p; a.Q = (const char*)d->q; a.zero_page = (const char*)d->zero_page;
-            a.grad = d->grad; a.tickets = tk;
+            a.grad = d->grad; a.tickets = tk; a.slab = d->workspace;
             a.N = d->N; a.H = d->OH; a.W = d->OW; a.PCs = d->p_stride; a.QCs = d->q_stride; a.R = d->rows; a.C = d->cols;
             a.reflect = d->pad_mode == V2V_PAD_REFLECT ? 1 : 0;
             a.splits = s3; a.rows_per_split = (int)ceil_div((long long)d->N * d->OH, s3);

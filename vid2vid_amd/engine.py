@@ -98,6 +98,23 @@ def bump_param_epoch():
     _PARAM_EPOCH[0] += 1
 
 
+_ENGINES = []        # weak references to every live Engine (repack_after_step walks them)
+
+
+def repack_after_step(flat=None):
+    """optim.FusedAdam.step, after its update kernel: re-pack -- on each engine's side stream -- every packed weight copy that
+    was in use and is now stale.  Lazily, the training step re-packed each layer in front of its first use of the next chunk:
+    ~270 small launches per 512x256 chunk in the serial chain of the forward / backward passes (5 % of the step's kernel time
+    plus their launch turnarounds, profiles/r06_v1_train_kernel_stats.txt).  Issued here they run beside the next backward
+    pass; the compute stream waits for them once, at the engine's next convolution (Engine.wait_repack)."""
+    for ref in list(_ENGINES):
+        eng = ref()
+        if eng is None:
+            _ENGINES.remove(ref)
+        else:
+            eng.repack_async()
+
+
 class PackedConv:
     """Device-resident packed weights of one nn.Conv2d / nn.ConvTranspose2d.
 
@@ -144,6 +161,7 @@ class PackedConv:
         self.buf = torch.empty(n, dtype=_TORCH_DTYPE[eng.dtype], device=eng.device)
         self.bias = None
         self.version = None
+        self.used = True          # fetched since the last asynchronous re-pack (Engine.repack_async only refreshes what is in use)
         self.refresh()
 
     def refresh(self, force=False):
@@ -578,6 +596,10 @@ class Engine:
         self.wgrad_stream_on = os.environ.get("V2V_WGRAD_STREAM", "1") != "0"
         self._wgrad_stream = None
         self._wgrad_join_queued = False
+        self.repack_async_on = os.environ.get("V2V_REPACK_ASYNC", "1") != "0"
+        self._repack_event = None
+        import weakref
+        _ENGINES.append(weakref.ref(self))
         self.plan = None        # Plan being recorded (for labels / keep-alive)
         self.conv_log = []       # (label, desc summary) of every conv emitted; used by bench/roofline
         self.tile_override = {}  # (cin,cout,KH,stride,transposed) -> tile id (tests / manual tuning)
@@ -737,13 +759,40 @@ class Engine:
     # ---------------- weights ----------------
     def packed(self, mod, cin_stride, role="fwd", reflect=False, korder=0, refresh=True):
         key = (id(mod), cin_stride, role, reflect, korder)
+        if self._repack_event is not None:
+            self.wait_repack()    # packings refreshed on the side stream after the last optimizer step: this stream reads them from here on
         pc = self._packed.get(key)
         if pc is None:
             pc = PackedConv(self, mod, cin_stride, role, reflect, korder)
             self._packed[key] = pc
         elif self.plan is None and refresh:
             pc.refresh()          # eager (training) use: follow optimizer updates
+        pc.used = True
         return pc
+
+    def repack_async(self):
+        """Refresh the stale packings that were used since the last call, on the side stream (see repack_after_step)."""
+        side = self.wgrad_side_stream()
+        if side is None or self.plan is not None or not self.repack_async_on or torch.cuda.is_current_stream_capturing():
+            return
+        todo = [pc for pc in self._packed.values() if pc.used]
+        if not todo:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        side.wait_stream(cur)                       # behind the optimizer kernel (and every reader of the old packings)
+        with torch.cuda.stream(side):
+            for pc in todo:
+                pc.used = False
+                pc.refresh()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._repack_event = ev
+
+    def wait_repack(self):
+        ev = self._repack_event
+        if ev is not None:
+            self._repack_event = None
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     def refresh_weights(self, force=False):
         for pc in self._packed.values():

@@ -209,7 +209,9 @@ class FusedAdam(torch.optim.Optimizer):
 
         gs = self.grad_sync
         rest = f.ready.finish() if (f.ready is not None and f.ready.armed) else None      # buckets not sent from inside the pass
+        overlapped = False
         if gs is not None and f.flat_param.is_cuda and (gs.world > 1 or gs.force_collective):
+            overlapped = True                                # Adam runs on GradSync's side stream: packings follow lazily, behind wait_pending
             gs.run_overlapped(f.flat_grad, adam, owner=self, rest=rest)     # RCCL all-reduce + Adam on the side stream, behind this backward pass
         elif gs is not None and rest is not None:
             for b in rest:
@@ -219,4 +221,7 @@ class FusedAdam(torch.optim.Optimizer):
         else:
             adam(gs.all_reduce(f.flat_grad) if gs is not None else 1.0, None)
         f.epoch[0] += 1                                      # packed copies of THESE parameters are now stale
+        if f.flat_param.is_cuda and not overlapped:
+            from .engine import repack_after_step
+            repack_after_step(f)                             # ... and are re-packed beside the next backward pass (side stream)
         return None
