@@ -64,7 +64,7 @@ if has wgradpmc; then   # where do the nine-tap weight-gradient kernel's wave cy
 fi
 if has trainab; then     # one-stream vs side-stream weight gradients, GEMM-view vs nine-tap kernel, alternating on this box
   for rep in 1 2; do
-    for cfg in ${ABCFGS:-V2V_WGRAD_STREAM=0,V2V_WGRAD3=0,V2V_REPACK_ASYNC=0 V2V_WGRAD_STREAM=1,V2V_WGRAD3=1,V2V_REPACK_ASYNC=0 V2V_WGRAD_STREAM=1,V2V_WGRAD3=1,V2V_REPACK_ASYNC=1 V2V_WGRAD_STREAM=1,V2V_WGRAD3=1,V2V_REPACK_ASYNC=1,V2V_SKIP_WGRAD=1}; do
+    for cfg in ${ABCFGS:-V2V_WGRAD_STREAM=0,V2V_WGRAD3=0,V2V_REPACK_ASYNC=0,V2V_BN_BWD_ONE=0 V2V_BN_BWD_ONE=0 V2V_BN_BWD_ONE=1 V2V_BN_BWD_ONE=1,V2V_SKIP_WGRAD=1}; do
       cfg=$(echo $cfg | tr ',' ' ')
       env $cfg timeout 600 python bench.py --mode train --steps 9 --warmup 3 --no-train-parity $GEO 2>gpurun_out/${TAG}_trainab.err | python -c "
 import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train [$cfg] run $rep:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', 'loss_G', j['config'].get('loss_G'), j['config'].get('loss_D'))"

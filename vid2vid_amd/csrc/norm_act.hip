@@ -548,6 +548,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
     }
 }
 
+// (Round 6 tried the whole norm backward of a small layer in ONE launch -- operands kept in registers across the in-launch
+// finalize, the other workgroups of a 64-channel slab spinning on its flag: correct to a few ulp, but 27-52 us per launch for the
+// 2048-pixel x 1024-channel layers against 20 + 8.5 us for the reduce / apply pair below, because the ticket -> finalize -> flag
+// -> coefficient chain is five dependent agent-scope round trips and the spinning workgroups hold the CU slots the rest of the
+// grid waits for while weight-gradient kernels share the chip (profiles/r06_v9_train_kernel_stats_bn_fused.txt, r06_v8_trainab.txt:
+// 54.1 vs 54.3 ms per chunk).  Removed.)
 struct BnBwdOp : Op {
     BnBwdRedArgs r; BnBwdFinArgs f; BnBwdApplyArgs ap; int dtype, nblk; bool do_apply;
     int launch(hipStream_t s) override {

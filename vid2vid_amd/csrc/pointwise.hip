@@ -768,10 +768,62 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const FoldArgs a) {
     }
 }
 
+// The same fold, one 16-byte channel vector per thread (round 6): the scalar kernel above moves 2 bytes per lane behind three
+// 64-bit divisions per element -- 13-23 us per launch, 116 launches per 512x256 training chunk on the serial chain of the backward
+// pass (2.7 ms, profiles/r06_v7_train_kernel_stats.txt) for tensors that take 2 us at the HBM rate.  Same sources in the same
+// order, summed in fp32 and rounded once: bit-identical.
+template <typename T>
+__global__ __launch_bounds__(256) void reflect_fold_vec_kernel(const FoldArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const T* xp = reinterpret_cast<const T*>(a.xp);
+    T* x = reinterpret_cast<T*>(a.x);
+    const int HP = a.H + 2 * a.pad, WP = a.W + 2 * a.pad;
+    const int vpp = a.c_stride / VEC;                                  // vectors per pixel
+    const long long total = (long long)a.N * a.H * a.W * vpp;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long pix = e / vpp;
+        const int cv = (int)(e - pix * vpp) * VEC;
+        const int w = (int)(pix % a.W);
+        const long long t = pix / a.W;
+        const int h = (int)(t % a.H);
+        const long long n = t / a.H;
+        int hs[3], ws[3];
+        const int nh = fold_sources(h, a.H, a.pad, hs), nw = fold_sources(w, a.W, a.pad, ws);
+        float sum[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) sum[q] = 0.f;
+        for (int i = 0; i < nh; ++i)
+            for (int j = 0; j < nw; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4*>(xp + ((n * HP + hs[i]) * WP + ws[j]) * a.c_stride + cv);
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (sizeof(T) == 2) { sum[2 * q] += __uint_as_float(u[q] << 16); sum[2 * q + 1] += __uint_as_float(u[q] & 0xffff0000u); }
+                    else sum[q] += __uint_as_float(u[q]);
+                }
+            }
+        uint4 o;
+        if (sizeof(T) == 2) {
+            o.x = pack_bf16x2(sum[0], sum[1]); o.y = pack_bf16x2(sum[2], sum[3]);
+            o.z = pack_bf16x2(sum[4 % VEC], sum[5 % VEC]); o.w = pack_bf16x2(sum[6 % VEC], sum[7 % VEC]);
+        } else {
+            o.x = __float_as_uint(sum[0]); o.y = __float_as_uint(sum[1]); o.z = __float_as_uint(sum[2]); o.w = __float_as_uint(sum[3]);
+        }
+        *reinterpret_cast<uint4*>(x + pix * a.c_stride + cv) = o;
+    }
+}
+
 struct FoldOp : Op {
     FoldArgs a; int dtype;
     int launch(hipStream_t s) override {
         const long long n = (long long)a.N * a.H * a.W * a.c_stride;
+        const int vec = dtype == V2V_BF16 ? 8 : 4;
+        if (a.c_stride % vec == 0 && (((uintptr_t)a.xp | (uintptr_t)a.x) & 15) == 0) {
+            if (dtype == V2V_BF16) hipLaunchKernelGGL(reflect_fold_vec_kernel<bf16_t>, dim3(grid_for(n / vec)), dim3(256), 0, s, a);
+            else                   hipLaunchKernelGGL(reflect_fold_vec_kernel<float>, dim3(grid_for(n / vec)), dim3(256), 0, s, a);
+            return check_launch();
+        }
         if (dtype == V2V_BF16) hipLaunchKernelGGL(reflect_fold_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, a);
         else                   hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, a);
         return check_launch();
