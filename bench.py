@@ -153,9 +153,24 @@ def emit_record(full, stdout=None):
     # (the full record is NOT echoed to stderr: a driver that merges the two streams into one 10 KB tail must still end in the line)
     sys.stderr.write("bench: full record (%d bytes) in %s\n" % (len(text), FULL_RECORD))
     sys.stderr.flush()
-    line = json.dumps(compact_line(full), allow_nan=False)
-    assert len(line) <= LINE_BUDGET + 2000 and "\n" not in line, len(line)
-    stdout.write(line + "\n")
+    comp = compact_line(full)
+    line = json.dumps(comp, allow_nan=False)
+    # never abort without a line: if numeric / flattened keys still push it over the budget, drop the optional parts --
+    # leg timings, roofline extras, per-leg flats -- until it fits; the contract keys always go out
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "full_record")
+    if len(line) > LINE_BUDGET + 2000:
+        for victim in ("leg_seconds", "timing"):
+            comp.pop(victim, None)
+        if isinstance(comp.get("roofline"), dict):
+            comp["roofline"] = {k: v for k, v in comp["roofline"].items() if k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")}
+        line = json.dumps(comp, allow_nan=False)
+        for k in [k for k in list(comp) if k not in contract]:
+            if len(line) <= LINE_BUDGET + 2000:
+                break
+            comp.pop(k)
+            line = json.dumps(comp, allow_nan=False)
+    stdout.write(line.replace("\n", " ") + "\n")
     stdout.flush()
 
 
@@ -189,6 +204,13 @@ def parse():
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps frames each; `value` is the MEDIAN window")
     ap.add_argument("--min-warmup-s", type=float, default=0.5, help="warm up for at least this long (and at least --warmup frames) before the first window")
     ap.add_argument("--no-hires", action="store_true", help="infer: skip the 2048x1024 / 3-scale companion run reported under \"hires\"")
+    ap.add_argument("--dry-run", action="store_true", help="plumbing check of the launch commands the driver uses (`--gpus N [--mode train]` under "
+                    "torch.distributed.run): host CPU, gloo instead of RCCL, the library in dry-run mode (every launch argument-checked, nothing "
+                    "executed).  Prints one line with data = \"dry-run\"; its value is a host rate, not a measurement")
+    ap.add_argument("--ngf", type=int, default=128, help="generator width (128 = BASELINE's configuration; smaller only for --dry-run plumbing tests)")
+    ap.add_argument("--train-hires-parity-compat", dest="no_train_hires_parity", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-train-hires-parity", dest="no_train_hires_parity", action="store_true",
+                    help="(deprecated no-op: the 2048x1024 chunk's CPU-oracle parity is opt-in since round 5, --train-hires-parity)")
     ap.add_argument("--train-graph", action="store_true", help="train: replay each chunk kind as ONE captured hipGraph (vid2vid_amd/graphed.py) instead of "
                     "eager launches.  Measured equal (68.6 vs 69.0 ms per 512x256 chunk, profiles/r06_v3_traingraph.txt): the step is bound by the "
                     "device's kernel-to-kernel turnaround of ~4000 dependent launches, not by host time -- off by default")
@@ -306,8 +328,9 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
         raise SystemExit("bench.py: --group-size %d does not divide the world size %d" % (group, world))
     n_gen = args.n_gpus_gen if (group > 1 and args.n_gpus_gen > 0) else -1
     role_mode = group > 1 and 0 < n_gen < group
-    opt = make_opt(isTrain=True, label_nc=35, use_instance=True, fg=True, random_init_ok=True, loadSize=W,
-                   precision=args.precision, gpu_ids=list(range(group)) if role_mode else [local_rank],
+    dry = bool(getattr(args, "dry_run", False))
+    opt = make_opt(isTrain=True, label_nc=35, use_instance=True, fg=True, random_init_ok=True, loadSize=W, ngf=getattr(args, "ngf", 128),
+                   precision=args.precision, gpu_ids=list(range(group)) if role_mode else [0 if dry else local_rank],
                    n_gpus_gen=n_gen if role_mode else -1, n_scales_spatial=S, num_D=args.num_D,
                    n_frames_total=args.frames_total, max_frames_per_gpu=args.frames_per_gpu,
                    no_vgg=args.no_vgg, niter_fix_global=0)
@@ -325,8 +348,10 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
     with torch.no_grad():
         for si in range(S):
             getattr(modelG.module, "netG%d" % si).model_final_flow[1].weight.mul_(0.1)
+    gsync = None
     if world > 1 and not role_mode:
-        parallel.sync_optimizers([optimizer_G, optimizer_D] + list(optimizer_D_T))
+        gsync = parallel.sync_optimizers([optimizer_G, optimizer_D] + list(optimizer_D_T))
+        gsync.timing = True
     seq_index = (rank // group) if role_mode else rank          # every rank of a sequence group loads the SAME sequence
     n_seqs = (world // group) if role_mode else world
     eng = modelG.module.engine
@@ -482,6 +507,18 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
                         "convs_per_pair": (flowNet.module.convs_launched - c0) // (nrep * n_frames_load),
                         "note": "FlowNet2 (C + S + S + SD + fusion) on %dx%d pairs, hipGraph replay, correlation on the matrix pipe (v2v_correlation_nhwc)" % (W, H)}
 
+    # what travelled between the ranks, and how much of it the in-backward buckets hid (parallel.GradSync.overlap_report: HIP event
+    # timestamps of every bucket's all-reduce against the end of the backward pass that produced it)
+    sync_report = gsync.overlap_report() if gsync is not None else None
+    if role_mode:
+        collective_note = ("role mode: RCCL point-to-point of frames / gradients between generator and discriminator ranks, all-reduce of "
+                           "the flat G gradient over the generator ranks (vid2vid_amd/roles.py)")
+    elif world > 1:
+        collective_note = ("bucketed all-reduce (sum, 1/world inside the Adam kernel) of the flat fp32 gradient buffers of G, D and each D_T "
+                           "per chunk, G's buckets sent from inside its backward pass (vid2vid_amd/parallel.py); %d-byte buckets"
+                           % (gsync.bucket_elems * 4))
+    else:
+        collective_note = "none (one process)"
     sys.stdout = _stdout
     if rank == 0:
         log = list(eng.conv_log)
@@ -510,7 +547,7 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
             "metric": "frames trained/sec (train.py inner loop, %dx%d)" % (W, H),
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "dry-run (no device: host rate of the launch sequence)" if dry else "synthetic",
             "config": {"workload": "label2city %dx%d train, n_scales_spatial=%d num_D=%d n_scales_temporal=%d, --fg --use_instance%s, "
                                    "n_frames_total=%d, %d frames per chunk, niter_fix_global=0 (all scales train), G %.1fM + D %.1fM "
                                    "params random-init, FlowNet2 random-init, 1 sequence per GPU"
@@ -526,6 +563,12 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
                                        % (n_seqs, n_gen, group - n_gen)) if role_mode else
                                       "dp%d over sequences (RCCL all-reduce of flat gradients per optimizer)" % args.gpus,
                        "world_size": world, "sequences": n_seqs,
+                       "backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else "none"),
+                       "collective": collective_note, "grad_sync": sync_report, "dry_run": dry,
+                       "grad_sync_buckets_inside_backward": None if sync_report is None else sync_report["buckets_sent_inside_backward"],
+                       "grad_sync_buckets_at_step": None if sync_report is None else sync_report["buckets_sent_at_step"],
+                       "grad_sync_allreduce_ms": None if sync_report is None else sync_report["allreduce_ms"],
+                       "grad_sync_hidden_ms": None if sync_report is None else sync_report["hidden_ms"],
                        "loss_G": round(float(loss_G), 4), "loss_D": round(float(loss_D), 4), "output_finite": finite,
                        "peak_memory_gb": round(peak_alloc / 2 ** 30, 2),
                        "device_memory_in_use_gb": round((total_b - free_b) / 2 ** 30, 2),
@@ -562,11 +605,24 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but the launched world size is %d (WORLD_SIZE); refusing to report a rate for GPUs "
                          "that did not run\n" % (args.gpus, world))
         sys.exit(2)
+    dry = bool(args.dry_run)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world)
+    if dry:
+        # no device: the launch sequence, the process group, the sharding of sequences over ranks and the JSON line are what is checked
+        from vid2vid_amd import networks as N_
+        N_.set_record_only(True)
+        dev = torch.device("cpu")
+        for name, fn in (("synchronize", lambda *a, **k: None), ("empty_cache", lambda *a, **k: None),
+                         ("reset_peak_memory_stats", lambda *a, **k: None), ("max_memory_allocated", lambda *a, **k: 0),
+                         ("mem_get_info", lambda *a, **k: (0, 0))):
+            setattr(torch.cuda, name, fn)
+        for k_ in ("no_cpu_baseline", "no_train_line", "no_train_hires", "no_c1", "no_c4", "no_train_c3", "no_hires", "no_train_parity", "no_autotune"):
+            setattr(args, k_, True)
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
     from vid2vid_amd import synthetic
     from vid2vid_amd.options import make_opt
@@ -597,11 +653,11 @@ def main():
     def build_model(precision):
         if face:      # scripts/face/test_512.sh geometry: 15 raw input maps per frame, no instance map, no fg tower
             o = make_opt(label_nc=0, input_nc=15, use_instance=False, fg=False, use_real_img=True, random_init_ok=True,
-                         dataroot="datasets/face/", loadSize=W, precision=precision, gpu_ids=[local_rank],
-                         n_scales_spatial=args.scales)
+                         dataroot="datasets/face/", loadSize=W, precision=precision, gpu_ids=[] if dry else [local_rank],
+                         n_scales_spatial=args.scales, ngf=args.ngf)
         else:
             o = make_opt(label_nc=35, use_instance=True, fg=True, use_real_img=True, random_init_ok=True,
-                         loadSize=W, precision=precision, gpu_ids=[local_rank], n_scales_spatial=args.scales)
+                         loadSize=W, precision=precision, gpu_ids=[] if dry else [local_rank], n_scales_spatial=args.scales, ngf=args.ngf)
         o.use_graph = not args.no_graph
         return o, create_model(o)
 
@@ -663,6 +719,24 @@ def main():
     run_step(model, 0)                           # builds the frame plan (tile searches, graph): never inside the timed region
     torch.cuda.synchronize(dev)
     release_tuning()                             # N > 1, rank 0: the other ranks may now build with its selections
+    if dry:
+        el, els, nwarm = timed_fps(model, args.steps, args.warmup)
+        sys.stdout = _stdout
+        if rank == 0:
+            emit_record({
+                "metric": "synthesized frames/sec (Vid2VidModelG.inference, %dx%d)" % (W, H), "value": round(world * args.steps / el, 3),
+                "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "dry-run (no device: host rate of the launch sequence)",
+                "config": {"workload": "label2city %dx%d, n_scales_spatial=%d, ngf=%d, one sequence per rank" % (W, H, args.scales, args.ngf),
+                           "world_size": world, "sequences": world, "backend": dist.get_backend() if world > 1 else "none",
+                           "parallelism": "replicas only: one process per GPU, one sequence per rank, no data-path collective "
+                                          "(the timing all-reduce(MAX) and the barrier are the only collectives)",
+                           "collective": "none in the data path (inference replicas); barrier + all_reduce(MAX) of the window time",
+                           "dry_run": True, "launches_per_frame": model._active_plan.plan.num_ops},
+                "roofline": None, "cpu_baseline": None}, _stdout)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---------------- host-fed rate: uint8 labels + int32 instance ids from pinned host memory every frame ----
     # (a side figure, measured before the CPU oracle runs: after 128 oracle threads have been busy the launching thread of this

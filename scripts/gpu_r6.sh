@@ -74,7 +74,7 @@ import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); pri
   lap trainab
 fi
 if has train; then       # the three training geometries of the default line, timed only
-  for geo in "" "--width 1024 --height 512 --scales 2 --num-D 3" ; do
+  for geo in "" "--width 1024 --height 512 --scales 2 --num-D 3" "--width 2048 --height 1024 --scales 3 --num-D 4 --frames-per-gpu 1"; do
     timeout 600 python bench.py --mode train --steps 6 --warmup 2 --no-train-parity $geo 2>gpurun_out/${TAG}_train_t.err | python -c "
 import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train $geo:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', j['roofline'].get('frac'))"
   done 2>&1 | tee gpurun_out/${TAG}_train_values.txt

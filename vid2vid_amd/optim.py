@@ -208,6 +208,8 @@ class FusedAdam(torch.optim.Optimizer):
                                     float(grp["weight_decay"]), float(gscale), step_no, sptr), "adam_step")
 
         gs = self.grad_sync
+        if gs is not None and hasattr(gs, "mark_step"):
+            gs.mark_step(f.flat_param.device)
         rest = f.ready.finish() if (f.ready is not None and f.ready.armed) else None      # buckets not sent from inside the pass
         overlapped = False
         if gs is not None and f.flat_param.is_cuda and (gs.world > 1 or gs.force_collective):

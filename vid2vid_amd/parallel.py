@@ -96,6 +96,12 @@ class GradSync:
         self.force_collective = force_collective     # run the collective even for a world of 1 (single-GPU RCCL test)
         self._stream = None
         self._pending = {}                           # owner (an optimizer) -> event of its enqueued (all-reduce + Adam) pair
+        # timing = True (bench.py): HIP event pairs around every bucket's all-reduce on the side stream and an event on the compute
+        # stream at each optimizer step (= the end of the backward pass that fed it), so that the run can say how much collective
+        # time ran BESIDE backward work (overlap_report) instead of modelling it
+        self.timing = False
+        self._t_buckets = []                         # (start event, end event, early?, step index)
+        self._t_steps = []                           # event on the compute stream at step() entry, per step index
 
     @property
     def world(self):
@@ -131,8 +137,52 @@ class GradSync:
                 w.wait()
         return 1.0 / world if self.scale is None else self.scale
 
-    def reduce_bucket(self, b):
+    def _timed(self, fn, b, early):
+        if not (self.timing and b.is_cuda and len(self._t_buckets) < 4096):
+            return fn(b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(b.device))
+        fn(b)
+        e1.record(torch.cuda.current_stream(b.device))
+        self._t_buckets.append((e0, e1, early, len(self._t_steps)))
+
+    def mark_step(self, device):
+        """FusedAdam.step entry: the compute stream has enqueued the whole backward pass of this optimizer."""
+        if self.timing and device is not None and device.type == "cuda" and len(self._t_steps) < 4096:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(device))
+            self._t_steps.append(ev)
+
+    def overlap_report(self):
+        """After a synchronize: per-run totals of the collectives' device time and the part of it that had finished, or was
+        running, before the backward pass that produced the gradients ended on the compute stream (`hidden_ms`).  CPU / gloo runs
+        and runs without `timing` report counts only."""
+        rep = {"buckets_sent_inside_backward": self.early_buckets, "buckets_sent_at_step": self.late_buckets,
+               "bucket_bytes": self.bucket_elems * 4, "wire_dtype": str(self.wire_dtype or "fp32"),
+               "allreduce_ms": None, "hidden_ms": None, "note": "hidden = all-reduce time in front of the end of the backward pass that "
+               "produced the bucket (HIP events on the collective's side stream against an event of the compute stream at step())"}
+        if not self._t_buckets:
+            return rep
+        total = hidden = 0.0
+        for e0, e1, early, si in self._t_buckets:
+            try:
+                dur = e0.elapsed_time(e1)
+                total += dur
+                if early and si < len(self._t_steps):
+                    to_end = e0.elapsed_time(self._t_steps[si])        # > 0: the bucket started this long before the pass ended
+                    hidden += max(0.0, min(dur, to_end))
+            except RuntimeError:
+                continue
+        rep["allreduce_ms"], rep["hidden_ms"] = round(total, 3), round(hidden, 3)
+        return rep
+
+    def reduce_bucket(self, b, early=False):
         """Sum ONE bucket over the ranks in place on the current stream (the building block of the in-backward path)."""
+        if self.timing and b.is_cuda:
+            return self._timed(self._reduce_bucket, b, early)
+        return self._reduce_bucket(b)
+
+    def _reduce_bucket(self, b):
         if self.world == 1 and not (self.force_collective and dist.is_initialized()):
             return
         if host_staged(b, self.group):
@@ -165,7 +215,7 @@ class GradSync:
             if gs_.device == b.device:
                 side.wait_stream(gs_)
         with torch.cuda.stream(side):
-            self.reduce_bucket(b)
+            self.reduce_bucket(b, early=True)
             done = torch.cuda.Event()
             done.record(side)
         self._pending[owner_key] = done              # one side stream: the newest event covers every earlier send of this owner
