@@ -77,6 +77,11 @@ def compact_line(full):
             out.setdefault(leg + "_frac_of_mfma_peak", o["frac_of_mfma_peak"])
         if "peak_memory_gb" in o:
             out.setdefault(leg + "_peak_memory_gb", o["peak_memory_gb"])
+        dm = o.get("dominant")
+        if isinstance(dm, dict) and "frac" in dm:                 # the training leg's dominant kernel (roofline object of the train step)
+            out.setdefault(leg + "_dominant_frac", dm["frac"])
+            out.setdefault(leg + "_dominant_us", dm.get("avg_launch_us"))
+            out.setdefault(leg + "_dominant_traffic", dm.get("traffic"))
     par = full.get("parity")
     if isinstance(par, dict):
         for pk in ("fp32_ok", "fp32_max_rel", "bf16_max_rel", "bf16_mean_rel", "tolerance_fp32"):
@@ -96,6 +101,10 @@ def compact_line(full):
         for k in ("avg_launch_us", "launches_per_frame", "flop_per_launch", "flop_per_step", "conv_launches_per_step", "measured", "resblock_1024_tflops"):
             if k in r:
                 rr[k] = r[k]
+        if isinstance(r.get("dominant"), dict):                   # --mode train: the step's dominant kernel beside the whole-step figure
+            for k in ("kernel", "layer", "avg_launch_us", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch"):
+                if k in r["dominant"]:
+                    rr["dominant_" + k] = r["dominant"][k]
         td = r.get("traffic_detail")
         if isinstance(td, dict):
             rr["algorithmic_bytes_per_launch"] = td.get("algorithmic_bytes_per_launch")
@@ -249,6 +258,26 @@ def train_parity(args, dev, local_rank, opt, modelG, modelD, flowNet):
     with torch.no_grad():
         flow_ref, conf_ref = flowNet(B[:, tG - 1:], B[:, tG - 2:-1])
     flow_ref, conf_ref = flow_ref.detach().float(), conf_ref.detach().float()
+    # FlowNet2 itself at THIS size against the oracle's FlowNet2 (its output enters the chunk's losses); the
+    # network runs in the benchmarked precision here, so the 1e-3 gate applies to an fp32 run only (tests/test_gpu_golden.py
+    # ::test_flownet2_at_baseline_size_vs_oracle is the fp32 check at 512x256 and 1024x512)
+    fn2 = None
+    try:
+        from oracle import vid2vid_oracle as O
+        fmod = flowNet.module if hasattr(flowNet, "module") else flowNet
+        sdf = {k: v.detach().float().cpu() for k, v in fmod.flowNet.state_dict().items()}
+        im1, im2 = B[0, tG - 1:].float().cpu(), B[0, tG - 2:-1].float().cpu()
+        t0_ = time.perf_counter()
+        with torch.no_grad():
+            rf, rc = O.flow_and_conf(sdf, im1, im2)
+        e = (flow_ref[0].cpu() - rf).abs() / (rf.abs() + rf.pow(2).mean().sqrt().item() + 1e-12)
+        fn2 = {"flow_max_rel": float("%.3e" % e.max().item()), "flow_mean_rel": float("%.3e" % e.mean().item()),
+               "conf_mismatch_fraction": float("%.3e" % (conf_ref[0].cpu() != rc).float().mean().item()),
+               "precision": getattr(fmod, "precision", args.precision), "pairs": int(im1.shape[0]), "oracle_seconds": round(time.perf_counter() - t0_, 1),
+               "note": "FlowNet (FlowNet2 + confidence) of the benchmarked run on the chunk's real frame pairs against oracle.flow_and_conf "
+                       "holding the same weights; conf mismatches include pixels sitting on the 0.02 threshold"}
+    except Exception as ex:
+        fn2 = {"error": repr(ex)[:300]}
     srcG, srcD = modelG.module, modelD.module
     has_T = nfl >= opt.n_frames_D
 
@@ -298,9 +327,59 @@ def train_parity(args, dev, local_rank, opt, modelG, modelD, flowNet):
             "tolerance_fp32": {"forward_every_frame": 1e-3, "losses": 1e-3, "grad_norm": 1e-3,
                                "note": "teacher-forced: every frame t > 0 of the product's chunk starts from the oracle's previous frames "
                                        "(same inputs on both sides); free_running_fp32 = the same chunk with each side feeding its own frames"},
-            "fp32": c32, "fp32_ok": ok,
+            "fp32": c32, "fp32_ok": ok, "flownet2_vs_oracle": fn2,
             "free_running_fp32": None if free32 is None else {k: free32[k] for k in ("max_forward", "max_forward_frame0", "max_loss", "max_grad_norm", "max_grad_l2")},
             "bf16": c16, "oracle_seconds": round(ref["seconds"], 1)}
+
+
+def train_dominant_kernel(dev, ch, h, w, reps=24):
+    """conv_wgrad3x3_bf16_kernel (csrc/conv_wgrad.hip) on the ch -> ch 3x3 / reflect layer at h x w, accumulate = 1: average launch
+    duration by HIP events on the launch stream (cold operands: a 384 MB memset in front of every launch), algorithmic FLOP per
+    launch, fraction of the dense bf16 MFMA peak; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes of the
+    same launch (scripts/gpu_r6.sh wgradpmc -> profiles/*_wgrad_traffic.json) when the shape matches."""
+    import ctypes as C
+    import glob
+    import torch
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, WgradDesc, check
+    dy = torch.randn(1, h, w, ch, device=dev).bfloat16()
+    x = torch.randn(1, h, w, ch, device=dev).bfloat16()
+    zero = torch.zeros(256, dtype=torch.uint8, device=dev)
+    grad = torch.zeros(ch, ch, 3, 3, device=dev)
+    d = WgradDesc()
+    d.p, d.q = dy.data_ptr(), x.data_ptr()
+    d.N, d.OH, d.OW, d.QH, d.QW = 1, h, w, h, w
+    d.rows, d.cols, d.p_stride, d.q_stride = ch, ch, ch, ch
+    d.KH = d.KW = 3
+    d.stride, d.pad, d.pad_mode = 1, 1, L.PAD_REFLECT
+    d.dtype, d.accumulate = L.BF16, 1
+    d.grad, d.zero_page = grad.data_ptr(), zero.data_ptr()
+    nbytes = lib.v2v_conv_wgrad_workspace(C.byref(d))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    d.workspace = ws.data_ptr()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    thrash = torch.empty(96 << 20, dtype=torch.float32, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        thrash.zero_()
+        a.record(); check(lib.v2v_conv_wgrad(C.byref(d), st), "wgrad"); b.record()
+    torch.cuda.synchronize(dev)
+    us = sorted(a.elapsed_time(b) for a, b in ev)[reps // 2] * 1e3
+    flop = 2.0 * h * w * ch * ch * 9
+    ach = flop / us / 1e6
+    alg = (2 * h * w * ch * 2) + 2 * ch * ch * 9 * 4              # dY + X once (bf16), .grad read + written (fp32)
+    out = {"kernel": "conv_wgrad3x3_bf16_kernel (nine taps per workgroup, gradient accumulated straight into .grad)",
+           "layer": "%d -> %d 3x3 reflect at %dx%d" % (ch, ch, w, h), "bound": "mfma", "flop_per_launch": flop,
+           "avg_launch_us": round(us, 2), "achieved": round(ach, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+           "frac": round(ach / PEAK_TFLOPS["bf16"], 4), "algorithmic_bytes_per_launch": alg, "traffic": None,
+           "measured": "HIP events on the launch stream, alone on the chip, cold operands, median of %d" % reps}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wgrad_traffic.json")))
+    if files:
+        t = json.load(open(files[-1]))
+        if t.get("layer") == [ch, ch, h, w] and t.get("hbm_bytes_per_launch"):
+            out["traffic"] = t["hbm_bytes_per_launch"]
+            out["traffic_source"] = os.path.relpath(files[-1], ROOT) + ": rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes"
+    return out
 
 
 def run_train(args, dev, rank, world, local_rank, emit=True):
@@ -507,6 +586,15 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
                         "convs_per_pair": (flowNet.module.convs_launched - c0) // (nrep * n_frames_load),
                         "note": "FlowNet2 (C + S + S + SD + fusion) on %dx%d pairs, hipGraph replay, correlation on the matrix pipe (v2v_correlation_nhwc)" % (W, H)}
 
+    # ---- the training step's dominant kernel: the weight gradient of the 8*ngf -> 8*ngf 3x3 ResnetBlock layers
+    # (72 launches per 512x256 chunk, as many FLOP as the forward and backward-data launches of those layers), measured here with
+    # HIP events on the stream it is launched on, alone on the chip, accumulating into .grad as in the step ----
+    dominant = None
+    if rank == 0 and not dry and args.precision == "bf16" and not role_mode:
+        try:
+            dominant = train_dominant_kernel(dev, 8 * opt.ngf, H >> opt.n_downsample_G, W >> opt.n_downsample_G)
+        except Exception as ex:
+            dominant = {"error": repr(ex)[:300]}
     # what travelled between the ranks, and how much of it the in-backward buckets hid (parallel.GradSync.overlap_report: HIP event
     # timestamps of every bucket's all-reduce against the end of the backward pass that produced it)
     sync_report = gsync.overlap_report() if gsync is not None else None
@@ -535,7 +623,7 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
             "bound": "mfma", "kernel": "whole training step: every conv forward / backward-data / backward-weight launch "
                                        "(G, FlowNet2, D, D_T); see profiles/ for the rocprofv3 per-kernel split",
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-            "flop_per_step": flop_step, "conv_launches_per_step": n_launch // args.steps,
+            "flop_per_step": flop_step, "conv_launches_per_step": n_launch // args.steps, "dominant": dominant,
             "gflop_per_step_by_kind": {k: round(v / args.steps / 1e9, 1) for k, v in sorted(by_kind.items())},
             "note": ("algorithmic conv FLOP of one chunk / wall time of one chunk; the chunk's whole launch sequence is replayed as one "
                      "hipGraph per chunk kind (vid2vid_amd/graphed.py)" if graphs.enabled else
@@ -1230,6 +1318,31 @@ def main():
                                     "sample": "1 frame of the same %dx%d / 3-scale workload (no warm-up), fp32, oracle/vid2vid_oracle.py" % (Wh, Hh)}
             del m32
             torch.cuda.empty_cache()
+            # the parity-holding THROUGHPUT mode at this resolution: fp32 storage / statistics / norms, the 3x3
+            # convolutions as three bf16 MFMA products (engine.X3Conv) -- one oracle-checked frame, then frames/s
+            try:
+                _, mx = build_h("x3")
+                for s_ in range(Sh):
+                    getattr(mx, "netG%d" % s_).load_state_dict(sd_keep[s_])
+                mx.engine.refresh_weights()
+                ex = errs(mx)
+                for t_ in range(1, 3):
+                    step_h(mx, t_)
+                torch.cuda.synchronize(dev)
+                n_x = 8
+                t0 = time.perf_counter()
+                for t_ in range(3, 3 + n_x):
+                    step_h(mx, t_)
+                torch.cuda.synchronize(dev)
+                el_x = time.perf_counter() - t0
+                mxr = max(v["max_rel"] for v in ex.values())
+                line["x3"] = {"value": round(n_x / el_x, 3), "unit": "frames/s", "ms_per_step": round(el_x / n_x * 1e3, 3), "steps": n_x,
+                              "max_rel": mxr, "ok_1e-3": bool(mxr <= 1e-3 and all(v["finite"] for v in ex.values())), "errors": ex,
+                              "dtype": "x3 (fp32 storage / norms, 3x3 convolutions as three bf16 MFMA products)"}
+                del mx
+                torch.cuda.empty_cache()
+            except Exception as ex_:
+                line["x3"] = {"error": repr(ex_)[:300]}
         return line
 
     def c1_clip(c4=False):
@@ -1457,6 +1570,7 @@ def main():
                 out[key] = {"metric": tr["metric"], "value": tr["value"], "unit": tr["unit"], "ms_per_step": tr["ms_per_step"],
                             "steps": tr["steps"], "warmup": tr["warmup"], "dtype": tr["dtype"],
                             "frac_of_mfma_peak": tr["roofline"]["frac"], "tflops": tr["roofline"]["achieved"],
+                            "dominant": tr["roofline"].get("dominant"),
                             "peak_memory_gb": tr["config"].get("peak_memory_gb"),
                             "workload": tr["config"]["workload"], "output_finite": tr["config"]["output_finite"],
                             "parity": tr["parity"], "flownet2": tr["flownet2"],
@@ -1496,6 +1610,9 @@ def main():
                           ("c1", "c1_value"), ("c4", "c4_value")):
             if isinstance(out.get(key), dict) and "value" in out[key]:
                 flat[name] = out[key]["value"]
+        hx = out.get("hires", {}).get("x3") if isinstance(out.get("hires"), dict) else None
+        if isinstance(hx, dict) and "value" in hx:                 # 2048x1024 in the mode that carries north_star's 1e-3
+            flat.update(hires_x3_value=hx["value"], hires_x3_max_rel=hx["max_rel"], hires_x3_ok=hx["ok_1e-3"])
         if isinstance(out.get("train_hires"), dict) and isinstance(out["train_hires"].get("parity"), dict):
             flat["train_hires_fp32_ok"] = out["train_hires"]["parity"].get("fp32_ok")
         if isinstance(out.get("train"), dict) and isinstance(out["train"].get("parity"), dict):

@@ -62,9 +62,31 @@ if has wgradpmc; then   # where do the nine-tap weight-gradient kernel's wave cy
   cd $R
   lap wgradpmc
 fi
+if has wgradtraffic; then   # HBM bytes per launch of the nine-tap weight-gradient kernel (1024 -> 1024 at 64x32, accumulate): FETCH_SIZE / WRITE_SIZE in separate passes
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 200 rocprofv3 --kernel-trace --pmc $c -d /tmp/wg3tr_$c -o pmc -- python $R/scripts/wgrad3_run.py 1024 1024 32 64 12 1 > $R/gpurun_out/${TAG}_wgradtraffic_$c.log 2>&1; echo "wgradtraffic $c rc=$?"
+  done
+  python - <<PY
+import glob, json, sqlite3
+def avg(pat, counter):
+    db = glob.glob("/tmp/wg3tr_%s/**/*.db" % pat, recursive=True)[0]
+    c = sqlite3.connect(db)
+    r = c.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? and kernel_name like '%wgrad3x3%' group by kernel_name", (counter,)).fetchall()
+    return r[0]
+f, w = avg("FETCH_SIZE", "FETCH_SIZE"), avg("WRITE_SIZE", "WRITE_SIZE")
+res = {"kernel": f[0], "layer": [1024, 1024, 32, 64], "dispatches": f[1], "fetch_kib_per_launch_reported": f[2], "write_kib_per_launch_reported": w[2],
+       "hbm_bytes_per_launch": (2.0 * f[2] + w[2]) * 1024.0,
+       "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over scripts/wgrad3_run.py 1024 1024 32 64 12 1 (cold operands, accumulate = 1); FETCH_SIZE x2 (gfx950 correction of MI355X_MICROARCH.md), WRITE_SIZE as reported; units KiB"}
+json.dump(res, open("$R/gpurun_out/${TAG}_wgrad_traffic.json", "w"), indent=1)
+print(json.dumps(res))
+PY
+  cd $R
+  lap wgradtraffic
+fi
 if has trainab; then     # one-stream vs side-stream weight gradients, GEMM-view vs nine-tap kernel, alternating on this box
   for rep in 1 2; do
-    for cfg in ${ABCFGS:-V2V_WGRAD_STREAM=0,V2V_WGRAD3=0,V2V_REPACK_ASYNC=0,V2V_BN_BWD_ONE=0 V2V_BN_BWD_ONE=0 V2V_BN_BWD_ONE=1 V2V_BN_BWD_ONE=1,V2V_SKIP_WGRAD=1}; do
+    for cfg in ${ABCFGS:-V2V_FLOWNET_STREAM=0 V2V_FLOWNET_STREAM=1}; do
       cfg=$(echo $cfg | tr ',' ' ')
       env $cfg timeout 600 python bench.py --mode train --steps 9 --warmup 3 --no-train-parity $GEO 2>gpurun_out/${TAG}_trainab.err | python -c "
 import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train [$cfg] run $rep:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', 'loss_G', j['config'].get('loss_G'), j['config'].get('loss_D'))"

@@ -23,11 +23,14 @@ class _FlowPlan:
         self.im1 = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
         self.im2 = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
         self.flow = self.conf = None
+        # the engine is shared with the generator / discriminators of the same precision: FlowNet2's launches get their own scratch
+        # set (split-K slabs, ticket words, statistics) so that the plan may run on its own stream beside them (FlowNet.forward)
         if not eng.record_only:
             prev_autotune = eng.autotune
             eng.autotune = bool(getattr(model.opt, "autotune", True))
             try:
-                self._emit()                   # sizes the shared scratch, picks tile configurations
+                with eng.scratch_set("flownet2"):
+                    self._emit()               # sizes the scratch, picks tile configurations
             finally:
                 eng.autotune = prev_autotune
             torch.cuda.synchronize(dev)
@@ -35,7 +38,7 @@ class _FlowPlan:
         eng.plan = self.plan
         n0 = len(eng.conv_log)
         try:
-            with self.plan:
+            with self.plan, eng.scratch_set("flownet2"):
                 self._emit()
         finally:
             eng.plan = None
@@ -89,6 +92,8 @@ class FlowNet(BaseModel):
         for p in self.flowNet.parameters():
             p.requires_grad_(False)
         self._plans = {}
+        self._side = None
+        self.side_stream_on = os.environ.get("V2V_FLOWNET_STREAM", "0") == "1"      # measured: no gain once the weight gradients share the chip (profiles/r06_v11_trainab.txt): opt-in
         self.flops_launched, self.convs_launched = 0.0, 0
         self.bind_precision()
 
@@ -113,13 +118,48 @@ class FlowNet(BaseModel):
             self.engine.refresh_weights()
             fp = _FlowPlan(self, B, H, W, use_graph=getattr(self.opt, "use_graph", True))
             self._plans[key] = fp
-        fp.im1.copy_(im1.to(self.device, torch.float32))
-        fp.im2.copy_(im2.to(self.device, torch.float32))
-        if not self.engine.record_only:
-            if torch.cuda.is_current_stream_capturing():
-                fp.plan.run()                  # inside a stream capture (graphed.ChunkGraphs): the launches themselves join the capture
-            else:
-                fp.plan.launch()
-            self.flops_launched += fp.conv_flops
-            self.convs_launched += fp.n_convs
-        return fp.flow.clone(), fp.conf.clone()
+        if self.engine.record_only or self.device.type != "cuda" or not self.side_stream_on:
+            fp.im1.copy_(im1.to(self.device, torch.float32))
+            fp.im2.copy_(im2.to(self.device, torch.float32))
+            if not self.engine.record_only:
+                self._launch(fp)
+            return fp.flow.clone(), fp.conf.clone()
+        # Round 6: FlowNet2 on its OWN stream.  It is frozen and depends only on the real frames, but train.py calls it between
+        # modelG(...) and modelD(...): on one stream its 117 small convolutions per pair (3.7 % of the matrix peak) queue behind
+        # the whole generator forward pass.  Here the side stream waits only for the event that says the frames are on the device
+        # (networks.note_inputs_ready, recorded by Vid2VidModelG.forward) -- or, for inputs of unknown origin, for everything on
+        # the current stream -- and the current stream waits for FlowNet2's results: the generator's queued launches and FlowNet2
+        # share the chip.
+        from .. import networks
+        cur = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        im1d, im2d = im1.to(self.device, torch.float32), im2.to(self.device, torch.float32)
+        evs = [networks.inputs_ready_event(t) for t in (im1d, im2d)]
+        if all(e is not None for e in evs) and im1d is not None and (im1d.data_ptr() == im1.data_ptr()) and (im2d.data_ptr() == im2.data_ptr()):
+            for e in evs:
+                side.wait_event(e)
+        else:
+            side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            fp.im1.copy_(im1d)
+            fp.im2.copy_(im2d)
+            self._launch(fp)
+            flow, conf = fp.flow.clone(), fp.conf.clone()
+            done = torch.cuda.Event()
+            done.record(side)
+        cur.wait_event(done)
+        for t in (im1d, im2d):
+            t.record_stream(side)
+        for t in (flow, conf):
+            t.record_stream(cur)
+        return flow, conf
+
+    def _launch(self, fp):
+        if torch.cuda.is_current_stream_capturing():
+            fp.plan.run()                      # inside a stream capture (graphed.ChunkGraphs): the launches themselves join the capture
+        else:
+            fp.plan.launch()
+        self.flops_launched += fp.conv_flops
+        self.convs_launched += fp.n_convs

@@ -512,6 +512,7 @@ class Vid2VidModelG(BaseModel):
                                                      (input_A, input_B, inst_A, fake_B_prev)]
         # (packed weight copies follow the optimizer lazily: Engine.packed() refreshes the one a launch reads)
         real_A_all, real_B_all, _ = self.encode_input(input_A, input_B, inst_A)
+        networks.note_inputs_ready(real_B_all)       # FlowNet2 (called next by train.py, on these frames) need not wait for the generator
         self.bs = real_A_all.shape[0]
         is_first_frame = fake_B_prev is None
         if is_first_frame:

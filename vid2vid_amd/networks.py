@@ -60,6 +60,31 @@ def set_record_only(flag):
     L.lib.v2v_set_dry_run(1 if flag else 0)
 
 
+# ---- "these inputs are ready" events (round 6) ----------------------------------------------------------------------------
+# Vid2VidModelG.forward records an event right behind its input handling (the real frames are on the device from there on) and files
+# it under the frames' storage; FlowNet.forward, which train.py calls AFTER modelG(...) returns but whose inputs are exactly those
+# frames, then waits for that event instead of for everything the generator has enqueued since -- so FlowNet2 runs beside the
+# generator's forward pass on its own stream (models/flownet.py).  Unknown storages fall back to a full stream wait.
+_READY = {}
+
+
+def note_inputs_ready(t):
+    if t is None or not t.is_cuda:
+        return
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+    if len(_READY) >= 8:
+        _READY.pop(next(iter(_READY)))
+    # the tensor itself is kept (a few frames, at most 8 entries): while it is alive its storage cannot be handed to another tensor,
+    # so a later lookup by address can never find the event of a dead tensor's memory
+    _READY[(t.device.index, t.untyped_storage().data_ptr())] = (ev, t)
+
+
+def inputs_ready_event(t):
+    ent = _READY.get((t.device.index, t.untyped_storage().data_ptr())) if t.is_cuda else None
+    return None if ent is None else ent[0]
+
+
 def get_engine(device=None, precision=None):
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
