@@ -24,7 +24,7 @@ DEV = "cuda:0"
 eng = Engine(DEV, L.BF16)
 THRASH = torch.empty(96 << 20, dtype=torch.float32, device=DEV)
 ROUNDS = int(os.environ.get("DOM_ROUNDS", "9"))
-TILES = [int(t) for t in os.environ.get("DOM_TILES", "90,98,97,99,132,130,131,82").split(",")]
+TILES = [int(t) for t in os.environ.get("DOM_TILES", "90,82,91").split(",")]
 
 
 def timed(fn, cold):
@@ -113,7 +113,7 @@ def one(x, tile, S):
 
 
 for name, x, tile in (("N=1 t90 (128 wgs)", x1, 90), ("N=1 t82 (128 wgs)", x1, 82), ("N=2 t90 (256 wgs)", x2, 90), ("N=2 t81 256x128 (128 wgs)", x2, 81),
-                      ("N=2 t85 (4x64 px x 128)", x2, 85), ("N=2 t97 (256 wgs)", x2, 97)):
+                      ("N=2 t85 (4x64 px x 128)", x2, 85)):
     try:
         f = one(x, tile, 1); f(); torch.cuda.synchronize()
         single[name] = (f, x.N)

@@ -41,6 +41,24 @@ import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); pri
   timeout 300 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short -k "adam" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | cut -c1-300 | tail -12
   lap traingraph
 fi
+if has rawbf16; then     # persistent single-chunk tiles with bf16 raw output: kernel tests, then both resolutions with the switch off / on, same box
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -rf --tb=short -k "persistent or paired_x or conv2d_every_tile or fused_norm_pair or pair_equals or bn_apply" -p no:cacheprovider > gpurun_out/${TAG}_rawbf16_tests.log 2>&1; echo "rawbf16 tests rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_rawbf16_tests.log | cut -c1-300 | tail -20
+  for rep in 1 2; do
+    for v in 0 1; do
+      V2V_RAW_BF16_ONE=$v timeout 900 python bench.py $LEAN 2>gpurun_out/${TAG}_rawbf16_$v.err | python -c "
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('V2V_RAW_BF16_ONE=$v run $rep: 512x256', j['value'], 'frames/s | 2048x1024', j.get('hires_value'), 'frames/s')"
+      python - <<PY
+import json
+j = json.load(open("bench_full.json"))
+h = j.get("hires", {})
+pk = h.get("roofline", {}).get("per_kernel_ms", {})
+print("   hires per-kernel ms:", {k: v for k, v in list(pk.items())[:6]}, "| hires bf16 parity:", (h.get("parity") or {}).get("bf16"))
+PY
+    done
+  done 2>&1 | tee gpurun_out/${TAG}_rawbf16.txt
+  lap rawbf16
+fi
 if has wgradbench; then
   timeout 300 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -rf --tb=short -s -k "nine_tap" -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  |nine-tap" | cut -c1-300 | tail -20
   timeout 300 python scripts/wgrad_bench.py 2>&1 | tee gpurun_out/${TAG}_wgrad_bench.txt | cut -c1-250

@@ -30,7 +30,7 @@ def timed(run, reps=9):
 SHAPES = [("G2 res 64->64 @1024x512", 64, 64, 512, 1024), ("G1 fg res 64->64 @512x256", 64, 64, 256, 512),
           ("64->128 @512x256", 64, 128, 256, 512), ("64->64 @256x128", 64, 64, 128, 256),
           ("G2 fg res 32->32 @1024x512", 32, 32, 512, 1024)]       # 64-byte pixels: tiles 140 - 143 through the paired-x view (engine.PairedXConv)
-TILES = [(10, 1, 0), (13, 1, 0), (36, 1, 0), (54, 1, 0), (56, 1, 0), (57, 1, 0), (80, 1, 0), (83, 1, 0), (94, 1, 0), (95, 1, 0), (96, 1, 0), (140, 1, 0), (141, 1, 0), (142, 1, 0), (143, 1, 0)]   # (58 / 59: the experiment of profiles/r04_d4_*, not in the tree)
+TILES = [(10, 1, 0), (13, 1, 0), (36, 1, 0), (54, 1, 0), (56, 1, 0), (57, 1, 0), (80, 1, 0), (83, 1, 0), (94, 1, 0), (95, 1, 0), (96, 1, 0), (140, 1, 0), (141, 1, 0), (143, 1, 0)]   # (58 / 59: the experiment of profiles/r04_d4_*, not in the tree)
 if os.environ.get("ONE_TILES"):
     TILES = [(int(t), 1, 0) for t in os.environ["ONE_TILES"].split(",")]
 with torch.no_grad():

@@ -438,10 +438,10 @@ def test_conv7x7_window_tile_is_validated_by_the_library():
 
 
 def test_round5_experiment_tiles_are_reachable_through_the_engine():
-    """Tiles 97-99 / 130-132 (one barrier per two / three steps, deeper weight rings, static wave priority on tile 90's geometry):
-    the engine must hand them channel-chunk-major weights (tile_korder) and the library must accept them in dry-run mode for a
-    single launch, a paired launch and a paired launch with the norm fused -- the path scripts/dom_bench.py and the GPU parity tests
-    take.  (Round 5: 97-99 were first missing from engine.is_patch_tile and every launch failed on the GPU box.)"""
+    """The experiment tiles still in the library (round 6: 143; the round-5 tiles 97-99 / 130-132 / 142 were removed) and the persistent
+    tiles 140 / 141: the engine must hand them channel-chunk-major weights (tile_korder) and the library must accept them in dry-run
+    mode -- the path the GPU parity tests take.  (Round 5: 97-99 were first missing from engine.is_patch_tile and every launch failed
+    on the GPU box.)"""
     import torch.nn as nn
     from vid2vid_amd import networks as N
     from vid2vid_amd import lib as L
@@ -460,7 +460,7 @@ def test_round5_experiment_tiles_are_reachable_through_the_engine():
         x64 = eng.pack(torch.randn(1, 64, 32, 64))
         for t in EXP_TILES + (140, 141):
             assert t in PATCH_CFGS and is_patch_tile(t) and tile_korder(t) == 1, t
-            if t in (140, 141, 142, 143):                                  # persistent single-chunk tile: 64 input channels, <= 64 output channels, single launches
+            if t in (140, 141, 143):                                       # persistent single-chunk tile: 64 input channels, <= 64 output channels, single launches
                 eng.tile_override[(64, 64, 3, 1, 0)] = (t, 1, 0)
                 _, rows, _ = eng.conv(x64, conv64, L.PAD_REFLECT, 1, L.OUT_RAW_F32_NHWC, want_stats=True)
                 assert eng.conv_log[-1]["tile"] == t and rows == 8          # 8 tiles of 8 x 32 pixels, one statistics row per WORKGROUP

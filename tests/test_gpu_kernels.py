@@ -572,12 +572,9 @@ PATCH_CFGS = [(32, 1), (33, 1), (34, 1), (35, 1), (36, 1), (37, 1), (32, 2), (33
               (90, 1), (91, 1), (90, 2), (91, 3),
               # K quads
               (92, 1), (93, 1), (92, 2), (93, 2),
-              # round 5: one barrier per two steps (97: 6 weight stages; 99: 7 stages + static wave priority), 98: tile 90 with 6 stages
-              (97, 1), (98, 1), (99, 1), (97, 2), (99, 3), (98, 2),
-              # one barrier per three steps (7 / 8 weight stages), per two steps with 8 stages
-              (130, 1), (131, 1), (132, 1), (130, 2), (131, 3),
+              # (round 6: the round-5 experiment tiles 97-99 / 130-132 / 142 are gone from the library)
               # persistent, weights-resident single-chunk tile (csrc/conv3x3_one_kernel.h): bf16, 64 input channels, <= 64 output channels
-              (140, 1), (141, 1), (142, 1), (143, 1),
+              (140, 1), (141, 1), (143, 1),
               # single-chunk tiles (one patch buffer, three weight stages): bf16 layers with exactly 64 input channels
               (94, 1), (95, 1), (96, 1)]
 
@@ -612,7 +609,7 @@ def test_conv3x3_patch_kernel(case, prec):
             continue
         if tile in (94, 95, 96) and (ncc != 1 or prec != "bf16"):
             continue
-        if tile in (140, 141, 142, 143):                            # their own test below (one output mode, full tiles, no in-kernel finalize)
+        if tile in (140, 141, 143):                                 # their own test below (one output mode, full tiles, no in-kernel finalize)
             continue
         k = it % 2
         eng.tile_override[(cin, cout, 3, 1, 0)] = (tile, S, 12 if (tile <= 37 and it % 3 == 0) else 0)
@@ -667,7 +664,7 @@ def test_conv3x3_persistent_single_chunk_tile(case):
     pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     tiles = N * (H // 8) * (W // 32)
-    one_tiles = (140, 141) + ((142, 143) if cout == 64 else ())      # 141: two patch buffers; 142: + stores from the accumulators; 143: 141 with its stores left in flight
+    one_tiles = (140, 141) + ((143,) if cout == 64 else ())          # 141: two patch buffers; 143: 141 with its stores left in flight
     for x, ref in zip(xs, refs):
         xa = eng.pack(x.to(DEV))
         got = {}
@@ -689,6 +686,17 @@ def test_conv3x3_persistent_single_chunk_tile(case):
             assert float(((col - col94).abs() / scale).max()) < 1e-5, "statistics of tile %d vs tile 94" % t
             r = got[t][0].view(N, H, W, cs_raw)[..., :cout].permute(0, 3, 1, 2)
             assert_close(r.cpu(), ref, 1e-4, "tile %d vs torch" % t)
+            # round 6: the same launch with its raw output rounded to bf16 (V2V_OUT_RAW_ACT_NHWC, what Engine.conv asks of these tiles on
+            # the inference path): exactly the RNE rounding of the fp32 raw output, and the SAME statistics rows (they come from the
+            # fp32 accumulators, not from the rounded values)
+            if cout % 8 == 0:
+                eng.tile_override[(cin, cout, 3, 1, 0)] = (t, 1, 0)
+                with torch.no_grad():
+                    rawb, rows_b, _ = eng.conv(xa, conv, pm, po, L.OUT_RAW_F32_NHWC, want_stats=True, raw_act_ok=True)
+                assert rawb.dtype == torch.bfloat16 and rows_b == got[t][2] and eng.conv_log[-1]["tile"] == t
+                stb = eng.scratch("stats", rows_b * cout * 2)[:rows_b * cout * 2].view(rows_b, cout, 2)
+                assert torch.equal(rawb[:N * H * W * cout].view(N, H, W, cout), got[t][0].view(N, H, W, cs_raw)[..., :cout].bfloat16()), "bf16 raw of tile %d" % t
+                assert torch.equal(stb, got[t][1]), "statistics of the bf16-raw launch of tile %d" % t
             # in-kernel finalize (last workgroup) == v2v_bn_finalize over the rows the same launch left; at any layer size
             eng.tile_override[(cin, cout, 3, 1, 0)] = (t, 1, 0)
             for rep in range(2):
@@ -869,7 +877,7 @@ def test_conv2d_pair_equals_two_launches(case, prec):
     assert eng.pair_eligible(xa[0], convs[0], xa[1], convs[1])
     for tile, S in [(70, 1), (71, 1), (72, 1), (73, 1), (74, 1), (75, 1), (70, 2), (71, 2),
                     (80, 1), (81, 1), (82, 1), (83, 1), (84, 1), (85, 1), (80, 2), (81, 2), (86, 1), (87, 1), (86, 2),
-                    (90, 1), (91, 1), (90, 2), (92, 1), (93, 1), (92, 2), (97, 1), (98, 1), (99, 1), (97, 2), (130, 1), (131, 1), (132, 1)]:
+                    (90, 1), (91, 1), (90, 2), (92, 1), (93, 1), (92, 2)]:
         if 2 * S > ncc:
             continue
         eng.pair_override = (tile, S)
@@ -921,7 +929,7 @@ def test_fused_norm_pair_equals_conv_plus_bn_apply(case, prec):
     xa = [eng.pack((torch.randn(N, cin, H, W) * (1.0 + i)).to(DEV)) for i in range(2)]
     ra = [eng.pack(torch.randn(N, cout, H, W).to(DEV)) for _ in range(2)]
     pm, po = (L.PAD_REFLECT, 1) if mode == "reflect" else (L.PAD_ZERO, None)
-    for tile in (80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93, 97, 98, 99, 130, 131, 132):
+    for tile in (80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93):
         eng.pair_override = (tile, 1)
         if not eng.fused_norm_fits((tile, 1, 0), N, H, W, cout):
             continue

@@ -123,6 +123,18 @@ __device__ __forceinline__ void one_stats_finish(const ConvKArgs& p, float s1, f
     }
 }
 
+// Four consecutive channels of one output pixel, element index e of the raw tensor: fp32 (16 bytes) or -- round 6,
+// V2V_OUT_RAW_ACT_NHWC -- rounded to bf16 (8 bytes).  The raw tensor of these HBM-bound layers is written once and read once by
+// bn_apply: as bf16 the pair moves 4 instead of 8 bytes per element (the statistics are taken from the fp32 accumulators either way).
+__device__ __forceinline__ void one_store4(float* out, unsigned e, const f32x4 v4, bool raw_bf16) {
+    if (raw_bf16) {
+        uint2 pk;
+        pk.x = pack_bf16x2(v4[0], v4[1]);
+        pk.y = pack_bf16x2(v4[2], v4[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + e) = pk;
+    } else *reinterpret_cast<f32x4*>(out + e) = v4;
+}
+
 template <typename T, int TH, int TW, int BN>
 __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
@@ -252,6 +264,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
     // predicate.  The arithmetic and its order are conv_epilogue's fast path: bit-identical to tiles 80 / 94.
     float* const out = reinterpret_cast<float*>(p.out);
     const unsigned cs_out = (unsigned)p.cout_stride;
+    const bool raw_bf16 = p.out_mode == V2V_OUT_RAW_ACT_NHWC;   // (wave-uniform) raw output rounded to bf16: half the bytes
     const int ccol = wn * WN + lr;                            // this lane's output channel in the accumulator layout
     const float bv = (p.bias != nullptr && ccol < p.cout) ? p.bias[pairx ? (ccol & 31) : ccol] : 0.f;
     const int vcol = wn * WN + 4 * (lane & 7);                // first channel of the 16-byte vectors this lane stores
@@ -318,11 +331,11 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // rows wm * WM + i * 32 .. + 31 of the tile = tile row wm * (WM / TW) + i (TW == 32), columns 0 .. 31
-            float* const orow = out + ((unsigned)((c_img * H + oh0 + wm * (WM / TW) + i) * W + ow0)) * cs_out + (unsigned)vcol;
+            const unsigned e0 = ((unsigned)((c_img * H + oh0 + wm * (WM / TW) + i) * W + ow0)) * cs_out + (unsigned)vcol;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + ((lane >> 3) + 8 * k) * 32 + 4 * (lane & 7));
-                if (vfull) *reinterpret_cast<f32x4*>(orow + (unsigned)((lane >> 3) + 8 * k) * cs_out) = v4;
+                if (vfull) one_store4(out, e0 + (unsigned)((lane >> 3) + 8 * k) * cs_out, v4, raw_bf16);
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the block is in registers before the next one overwrites it
@@ -350,13 +363,8 @@ __global__ __launch_bounds__(512) void conv3x3_one_kernel(const ConvKArgs p) {
 // OLDER than the 8 stores of tile i's epilogue and the patch of tile i+2 behind them, so both may stay in flight -- a wave no longer
 // waits for its own stores right after issuing them (tile 141's `vmcnt(n)` did: 39 % of its wave cycles were parked,
 // profiles/r05_v7_onepmc.txt).  The stores are unconditional (the immediate counts them): exactly 64 output channels (host check).
-// ASYNC 1 (tile 142): the tile's output leaves the accumulators with plain 4-byte stores (a lane's 32 channels x 4 B = one 128-byte line per
-// row and half-wave) instead of passing the wave's LDS transposition block -- the patch buffer is then free the moment the steps end,
-// the patch of tile i+2 is issued BEFORE the epilogue's stores, and the counted wait at the top of tile i+1 leaves those stores in flight
-// together with that patch: `vmcnt(n + 32)` (32 stores per wave and tile, unconditional: the host admits exactly 64 output channels).  A
-// wave then never waits for its own stores; with tile 141 it did (they are older than the prefetch it must not wait for), which is why
-// the second patch buffer alone bought nothing: load, steps and store phases stayed in series inside every workgroup, and because all
-// workgroups run in lockstep the HBM and the matrix pipes were never busy at the same time.
+// (ASYNC 1, tile 142 -- stores straight from the accumulators, issued behind the patch of tile i+2 -- measured slower, 75.8 us on the
+// 2048-tile layer: 4-byte stores lose to the LDS-transposed 16-byte ones; removed in round 6)
 template <typename T, int TH, int TW, int BN, int ASYNC = 0>
 __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) {
     constexpr int VEC = ElemTraits<T>::VEC;
@@ -490,6 +498,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
 
     float* const out = reinterpret_cast<float*>(p.out);
     const unsigned cs_out = (unsigned)p.cout_stride;
+    const bool raw_bf16 = p.out_mode == V2V_OUT_RAW_ACT_NHWC;   // (wave-uniform) raw output rounded to bf16: half the bytes
     const int ccol = wn * WN + lr;
     const float bv = (p.bias != nullptr && ccol < p.cout) ? p.bias[pairx ? (ccol & 31) : ccol] : 0.f;
     const int vcol = wn * WN + 4 * (lane & 7);
@@ -517,9 +526,9 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
 
         // only the patch issued LAST (tile i+1, or its dummy) may still be in flight: this tile's patch, the weights and the stores of
         // the previous epilogue are older
-        constexpr int NST = ASYNC == 1 ? 32 : 8;             // stores per wave and tile: 4-byte (ASYNC 1) or 16-byte through the LDS block
-        if (ASYNC != 0 && !first) {                          // ... and, ASYNC, the stores of the previous tile's epilogue (ASYNC 1: issued behind
-            // that patch; ASYNC 2 (tile 143): in front of it -- either way they are YOUNGER than this tile's patch, so they may stay in flight)
+        constexpr int NST = 8;                               // stores per wave and tile: 16-byte (or 8-byte bf16) through the LDS block
+        if (ASYNC != 0 && !first) {                          // ... and, ASYNC 2 (tile 143), the stores of the previous tile's epilogue, issued
+            // in front of that patch -- YOUNGER than this tile's patch, so they may stay in flight)
             if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP + NST) : "memory");
             else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GP - 1 + NST) : "memory");
         } else {
@@ -546,20 +555,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // every wave has finished reading this patch: the buffer becomes epilogue scratch
 
-        if constexpr (ASYNC == 1) {
-            issue_patch_vb(vb + 2 * G, patch);               // the buffer is free: nothing of the epilogue touches it
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                float* const orow = out + ((unsigned)((n_img * H + oh0 + wm * (WM / TW) + i) * W + ow0)) * cs_out + (unsigned)ccol;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[i][r] + bv;
-                    s1 += v;
-                    s2 = __builtin_fmaf(v, v, s2);
-                    orow[(unsigned)((r & 3) + 8 * (r >> 2) + 4 * hi) * cs_out] = v;      // 32 lanes = 32 consecutive channels = one 128-byte line
-                }
-            }
-        } else {
+        {
         float* const tw = reinterpret_cast<float*>(patch) + wid * 1024;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -572,11 +568,11 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            float* const orow = out + ((unsigned)((n_img * H + oh0 + wm * (WM / TW) + i) * W + ow0)) * cs_out + (unsigned)vcol;
+            const unsigned e0 = ((unsigned)((n_img * H + oh0 + wm * (WM / TW) + i) * W + ow0)) * cs_out + (unsigned)vcol;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + ((lane >> 3) + 8 * k) * 32 + 4 * (lane & 7));
-                if (ASYNC == 2 || vfull) *reinterpret_cast<f32x4*>(orow + (unsigned)((lane >> 3) + 8 * k) * cs_out) = v4;   // ASYNC 2: exactly 64 channels (host check): unconditional, the vmcnt immediate counts them
+                if (ASYNC == 2 || vfull) one_store4(out, e0 + (unsigned)((lane >> 3) + 8 * k) * cs_out, v4, raw_bf16);   // ASYNC 2: exactly 64 channels (host check): unconditional, the vmcnt immediate counts them
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -585,7 +581,7 @@ __global__ __launch_bounds__(512) void conv3x3_one_db_kernel(const ConvKArgs p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave's transposition block is retired
         __builtin_amdgcn_s_barrier();                        // (NOT __syncthreads(): its fence is a vmcnt(0) -- prefetch and stores must stay in flight)
         // the patch of tile i+2 into the buffer this tile is done with
-        if constexpr (ASYNC != 1) issue_patch_vb(vb + 2 * G, patch);
+        issue_patch_vb(vb + 2 * G, patch);
         vb += G;
         cur ^= 1;
     }
@@ -703,6 +699,7 @@ __global__ __launch_bounds__(512) void conv3x3_t2_one_kernel(const ConvKArgs p) 
 
     float* const out = reinterpret_cast<float*>(p.out);
     const unsigned cs_out = (unsigned)p.cout_stride;
+    const bool raw_bf16 = p.out_mode == V2V_OUT_RAW_ACT_NHWC;   // (wave-uniform) raw output rounded to bf16: half the bytes
     const int OH = p.OH, OW = p.OW;
     const float bv = (p.bias != nullptr && lr < p.cout) ? p.bias[p.pair_x ? (lr & 15) : lr] : 0.f;      // (paired-x view: 32 columns = 2 pixels x 16 channels)
     const int vcol = 4 * (lane & 7);
@@ -762,11 +759,11 @@ __global__ __launch_bounds__(512) void conv3x3_t2_one_kernel(const ConvKArgs p) 
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // block row m = input position (a0 + wid, b0 + m) -> output pixel (2 (a0 + wid) + py, 2 (b0 + m) + px)
-            float* const orow = out + ((unsigned)((n_img * OH + 2 * (a0 + wid) + (CL >> 1)) * OW + 2 * b0 + (CL & 1))) * cs_out + (unsigned)vcol;
+            const unsigned e0 = ((unsigned)((n_img * OH + 2 * (a0 + wid) + (CL >> 1)) * OW + 2 * b0 + (CL & 1))) * cs_out + (unsigned)vcol;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x4 v4 = *reinterpret_cast<const f32x4*>(tw + ((lane >> 3) + 8 * k) * 32 + 4 * (lane & 7));
-                if (vfull) *reinterpret_cast<f32x4*>(orow + (unsigned)(2 * ((lane >> 3) + 8 * k)) * cs_out) = v4;
+                if (vfull) one_store4(out, e0 + (unsigned)(2 * ((lane >> 3) + 8 * k)) * cs_out, v4, raw_bf16);
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -816,12 +813,11 @@ static inline int launch_one_typed(int cfg, const ConvKArgs& k_in, int cus, hipS
         }
     }
     if constexpr (std::is_same<T, bf16_t>::value) {
-        if (cfg >= 141 && cfg <= 143) {
+        if (cfg == 141 || cfg == 143) {
             constexpr int TH = 8, TW = 32, BN = 64, NW = 8;
             constexpr int NG = ((TH + 2) * (TW + 2) + 7) / 8;
             const size_t lds = (size_t)9 * BN * 128 + (size_t)2 * NG * 1024 + (size_t)(4 * BN * 2 * 4);
-            void (*kern)(const ConvKArgs) = cfg == 142 ? conv3x3_one_db_kernel<T, TH, TW, BN, 1> : cfg == 143 ? conv3x3_one_db_kernel<T, TH, TW, BN, 2>
-                                                                                                   : conv3x3_one_db_kernel<T, TH, TW, BN, 0>;
+            void (*kern)(const ConvKArgs) = cfg == 143 ? conv3x3_one_db_kernel<T, TH, TW, BN, 2> : conv3x3_one_db_kernel<T, TH, TW, BN, 0>;
             static bool attr_done[3] = {false, false, false};
             if (!attr_done[cfg - 141]) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -502,10 +502,10 @@ static const PatchCfg kPp3Cfgs[] = {
     {90, 8, 32, 64}, {91, 4, 64, 64},      // K pairs: 4 x 1 wave tiles of 64 x 64, two K halves (see the kernel comment)
     {92, 8, 32, 64}, {93, 4, 64, 64},      // K quads: 2 x 1 wave tiles of 128 x 64, four K quarters: 6 reads per 8 MFMAs
     {94, 8, 32, 64}, {95, 4, 64, 64},      // single-chunk layers: one patch buffer, 72 / 80 KiB
-    {97, 8, 32, 64}, {98, 8, 32, 64}, {99, 8, 32, 64},     // round-5 experiments on tile 90's geometry (K pairs): 97 one barrier per two steps
-                                           // (6 stages), 98 = 90 with 6 stages (the ring one deeper), 99 = 97 with 7 stages and static priority
-    {130, 8, 32, 64}, {131, 8, 32, 64}, {132, 8, 32, 64},  // 130 / 131: one barrier per THREE steps, 7 / 8 stages; 132: per two steps, 8 stages
-    {140, 8, 32, 64}, {141, 8, 32, 64}, {142, 8, 32, 64}, {143, 8, 32, 64},    // conv3x3_one_kernel.h: persistent, weights-resident single-chunk tile (geometry only; launched by launch_one_typed)
+    // (round 6: the round-5 experiment tiles 97-99 / 130-132 -- one barrier per two / three steps, deeper weight rings, static wave
+    //  priority on tile 90's geometry, all bit-identical to tile 90 and none faster, DESIGN 3.1 -- are no longer instantiated; the
+    //  FLAGS parameter of the body that built them stays)
+    {140, 8, 32, 64}, {141, 8, 32, 64}, {143, 8, 32, 64},    // conv3x3_one_kernel.h: persistent, weights-resident single-chunk tile (geometry only; launched by launch_one_typed)
     {96, 4, 32, 64},                       // single-chunk layers, FOUR waves (2 x 2, 64 x 32 wave tiles), 28 + 24 = 52 KiB, 167 + 32 registers: the
                                            // tile that really puts two workgroups on a CU (staged for round 5; 94 / 95 never did: DESIGN 3.6 item 15)
     {120, 4, 32, 64}, {121, 4, 32, 128},   // 7x7 window (staged for round 5): 10 x 38 pixel patch, 49 tap steps per channel chunk
@@ -529,12 +529,6 @@ static inline int launch_pp3_typed(int cfg, const ConvKArgs& k, int groups, hipS
         case 87: return launch_pp3_cfg<T, 2, 64, 128, 4, 0, 2, 2>(k, groups, s);   // same for 64-wide tile rows
         case 90: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 4, 1, 2>(k, groups, s);   // as 82 (256 px x 64, 5 slices), K pairs: 8 reads per 8 MFMAs
         case 91: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 4, 1, 2>(k, groups, s);   // as 83 for 64-wide tile rows
-        case 97: return launch_pp3_cfg<T, 8, 32, 64, 6, 0, 4, 1, 2, false, 3, 1>(k, groups, s);   // as 90, ONE BARRIER PER TWO STEPS, 6 stages (144 KiB)
-        case 98: return launch_pp3_cfg<T, 8, 32, 64, 6, 0, 4, 1, 2>(k, groups, s);                // as 90 with the weight ring one stage deeper (144 KiB)
-        case 99: return launch_pp3_cfg<T, 8, 32, 64, 7, 0, 4, 1, 2, false, 3, 5>(k, groups, s);   // as 97 with 7 stages (152 KiB) and static priority for waves 4-7
-        case 130: return launch_pp3_cfg<T, 8, 32, 64, 7, 0, 4, 1, 2, false, 3, 2>(k, groups, s);  // as 90, ONE BARRIER PER THREE STEPS, 7 stages (152 KiB)
-        case 131: return launch_pp3_cfg<T, 8, 32, 64, 8, 0, 4, 1, 2, false, 3, 2>(k, groups, s);  // the same with 8 stages (160 KiB: all of the LDS)
-        case 132: return launch_pp3_cfg<T, 8, 32, 64, 8, 0, 4, 1, 2, false, 3, 1>(k, groups, s);  // one barrier per two steps, 8 stages
         case 92: return launch_pp3_cfg<T, 8, 32, 64, 5, 0, 2, 1, 4>(k, groups, s);   // as 82, K quads
         case 93: return launch_pp3_cfg<T, 4, 64, 64, 4, 0, 2, 1, 4>(k, groups, s);   // as 83, K quads
         case 120: case 121:                // 7x7 window: bf16 only for now (the fp32 instantiations double an 8-minute translation unit)

@@ -432,7 +432,6 @@ struct ConvOp : Op {
     int groups = 1;      // 2: grouped launch (v2v_conv2d_pair), second member's tensors in k.g1
     int launch(hipStream_t s) override {
         if (cfg >= 140 || cfg == 114) return launch_one_bf16(cfg, k, device_cus(), s);     // persistent, weights-resident single-chunk tiles (bf16: host check); 114: the transposed stride-2 one
-        if (cfg >= 130) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, groups, s) : launch_pp3_f32(cfg, k, groups, s);    // round-5 experiment tiles of the 3x3 single-phase kernel
         if (cfg >= 120) return dtype == V2V_BF16 ? launch_pp3_bf16(cfg, k, 1, s) : launch_pp3_f32(cfg, k, 1, s);    // 7x7 window on the single-phase kernel
         if (cfg >= 110) return dtype == V2V_BF16 ? launch_t2_bf16(cfg, k, s) : launch_t2_f32(cfg, k, s);
         if (cfg >= 100) return dtype == V2V_BF16 ? launch_s2_bf16(cfg, k, s) : launch_s2_f32(cfg, k, s);
@@ -476,9 +475,9 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
     bool pair_x = false;
     if (d->tile >= 140 && d->tile <= 143 && d->cin_stride == 32) {
         if (d->dtype != V2V_BF16 || d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->cin > 32 || d->cout != 32 ||
-            d->cout_stride != 32 || d->out_mode != V2V_OUT_RAW_F32_NHWC || d->w_korder != 3 || (d->W & 1) || d->OW != d->W || d->OH != d->H) {
+            d->cout_stride != 32 || (d->out_mode != V2V_OUT_RAW_F32_NHWC && d->out_mode != V2V_OUT_RAW_ACT_NHWC) || d->w_korder != 3 || (d->W & 1) || d->OW != d->W || d->OH != d->H) {
             set_error("conv: tile configs 140 - 143 on 64-byte pixels (paired-x view) need a bf16 3x3/s1/p1 Conv2d, <= 32 -> exactly 32 channels, "
-                      "dense raw fp32 NHWC output, an even width and paired-x weights (w_korder 3)");
+                      "dense raw NHWC output (fp32 or bf16), an even width and paired-x weights (w_korder 3)");
             return V2V_EINVAL;
         }
         dd = *d;
@@ -489,9 +488,9 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
     } else if (d->tile == 114 && d->cin_stride == 32) {
         // ... and the transposed counterpart: ConvTranspose2d <= 32 -> 16 over [H][W][32] as 64 -> 32 over [H][W/2][64], output [2H][2W][16] = [2H][W][32]
         if (d->dtype != V2V_BF16 || !d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->cin > 32 || d->cout != 16 ||
-            d->cout_stride != 16 || d->out_mode != V2V_OUT_RAW_F32_NHWC || d->w_korder != 3 || (d->W & 1) || d->OW != 2 * d->W || d->OH != 2 * d->H) {
+            d->cout_stride != 16 || (d->out_mode != V2V_OUT_RAW_F32_NHWC && d->out_mode != V2V_OUT_RAW_ACT_NHWC) || d->w_korder != 3 || (d->W & 1) || d->OW != 2 * d->W || d->OH != 2 * d->H) {
             set_error("conv: tile config 114 on 64-byte pixels (paired-x view) needs a bf16 ConvTranspose2d(3x3, s2, p1, op1), <= 32 -> exactly 16 channels, "
-                      "dense raw fp32 NHWC output, an even width and paired-x weights (w_korder 3)");
+                      "dense raw NHWC output (fp32 or bf16), an even width and paired-x weights (w_korder 3)");
             return V2V_EINVAL;
         }
         dd = *d;
@@ -569,8 +568,8 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
     }
     if (d->out_mode == V2V_OUT_NORM_ACT_NHWC) {
         if ((launching && (!d->fin_counter || !d->stats || !d->fin_scale_shift || d->fin_count <= 0)) || d->splitk > 1 || d->transposed ||
-            d->cout != d->cout_stride || !((d->tile >= 80 && d->tile < 88) || (d->tile >= 90 && d->tile <= 93) || (d->tile >= 97 && d->tile <= 99) || (d->tile >= 130 && d->tile <= 139)) || d->cout > 128 * 64) {
-            set_error("conv: fused norm needs tile 80..87 / 90..93 / 97..99, splitk <= 1, cout == cout_stride, stats, fin_counter (256 ints), fin_scale_shift, fin_count");
+            d->cout != d->cout_stride || !((d->tile >= 80 && d->tile < 88) || (d->tile >= 90 && d->tile <= 93)) || d->cout > 128 * 64) {
+            set_error("conv: fused norm needs tile 80..87 / 90..93, splitk <= 1, cout == cout_stride, stats, fin_counter (256 ints), fin_scale_shift, fin_count");
             return V2V_EINVAL;
         }
         k.res0 = (const char*)d->res0; k.res1 = (const char*)d->res1;
@@ -674,7 +673,7 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
         k.m_tiles = d->N * k.tiles_h * k.tiles_w;
         k.n_tiles = (int)ceil_div(d->cout, pc->BN);
         if (op->cfg == 114 && (d->dtype != V2V_BF16 || d->cin_stride != 64 || d->cout > pc->BN || (d->cout & 3) || (d->cout_stride & 3) || ((unsigned long long)d->out & 15ull) ||
-                               d->out_mode != V2V_OUT_RAW_F32_NHWC || d->fin_workspace != nullptr || d->H % pc->TH != 0 || d->W % pc->TW != 0 ||
+                               (d->out_mode != V2V_OUT_RAW_F32_NHWC && d->out_mode != V2V_OUT_RAW_ACT_NHWC) || d->fin_workspace != nullptr || d->H % pc->TH != 0 || d->W % pc->TW != 0 ||
                                d->OH != 2 * d->H || d->OW != 2 * d->W)) {
             // conv3x3_one_kernel.h, conv3x3_t2_one_kernel: ONE output mode (raw fp32 NHWC + one statistics row per workgroup), full tiles only
             set_error("conv: tile config 114 (persistent transposed stride-2 tile) needs bf16, cin_stride 64, cout <= %d and %% 4 == 0, raw fp32 NHWC output (16-byte aligned "
@@ -711,7 +710,7 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
                       op->cfg, bke_of(d->dtype)); return V2V_EINVAL;
         }
         if ((op->cfg >= 140 && op->cfg <= 143) && ((op->cfg >= 142 && d->cout != pc->BN) || d->cout > pc->BN || (d->cout & 3) || (d->cout_stride & 3) || ((unsigned long long)d->out & 15ull) ||
-                               d->out_mode != V2V_OUT_RAW_F32_NHWC || d->fin_workspace != nullptr || d->OH % pc->TH != 0 || d->OW % pc->TW != 0)) {
+                               (d->out_mode != V2V_OUT_RAW_F32_NHWC && d->out_mode != V2V_OUT_RAW_ACT_NHWC) || d->fin_workspace != nullptr || d->OH % pc->TH != 0 || d->OW % pc->TW != 0)) {
             // conv3x3_one_kernel.h: ONE output mode (raw fp32 NHWC + one statistics row per workgroup, single-level in-kernel finalize), full tiles only
             set_error("conv: tile configs 140 - 143 (persistent, weights resident) need cout <= %d (142 / 143: exactly) and %% 4 == 0, raw fp32 NHWC output (16-byte aligned rows), "
                       "no two-level finalize workspace, OH %% %d == 0 and OW %% %d == 0", pc->BN, pc->TH, pc->TW);
@@ -895,8 +894,8 @@ extern "C" int v2v_conv2d_pair(const v2v_conv_desc* a, const v2v_conv_desc* b, v
     int rc = build_conv(a, op.get());
     if (rc == 0) rc = build_conv(b, &ob);
     if (rc != 0) return rc;
-    if (op->cfg < 70 || (op->cfg >= 94 && !(op->cfg >= 97 && op->cfg <= 99) && !(op->cfg >= 130 && op->cfg <= 139)) || ob.cfg != op->cfg) {
-        set_error("conv pair: both members need the same grouped-launch tile config (70..93, 97..99), got %d / %d", op->cfg, ob.cfg);
+    if (op->cfg < 70 || op->cfg >= 94 || ob.cfg != op->cfg) {
+        set_error("conv pair: both members need the same grouped-launch tile config (70..93), got %d / %d", op->cfg, ob.cfg);
         return V2V_EINVAL;
     }
     const bool same =

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a_in) {
         // rate (profiles/r04_f3_per_layer_roofline_hires.txt) -- an issue-bound streaming kernel.  Same fp32 expression per element
         // (fma(raw, scale, shift) -> activation -> + add0 -> + add1 -> RNE to bf16): bit-identical results.
         const bool simple = a.act == V2V_ACT_NONE || a.act == V2V_ACT_RELU || a.act == V2V_ACT_LEAKY;
-        if (!a.raw_bf16 && a.x3 == nullptr && (a.C & 7) == 0 && a.c_stride == a.C && a.c_stride_raw == a.C && simple &&
+        if (a.x3 == nullptr && (a.C & 7) == 0 && a.c_stride == a.C && a.c_stride_raw == a.C && simple &&
             nvec < (1ll << 28) && (stride % vpr) == 0) {
             const unsigned nv = (unsigned)nvec, st = (unsigned)stride;
             unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,12 +207,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a_in) {
             const float slope = a.act_param;
             const uint4* const r0 = reinterpret_cast<const uint4*>(add0);
             const uint4* const r1 = reinterpret_cast<const uint4*>(add1);
+            const bool rawb = a.raw_bf16 != 0;               // round 6: raw stored as bf16 (persistent single-chunk tiles): one 16-byte load
             for (; v < nv; v += st) {
-                const float4 ra = *reinterpret_cast<const float4*>(a.raw + (size_t)v * 8), rb = *reinterpret_cast<const float4*>(a.raw + (size_t)v * 8 + 4);
+                float r[8];
+                if (rawb) {
+                    const uint4 rq = reinterpret_cast<const uint4*>(a.raw)[v];
+                    r[0] = __uint_as_float(rq.x << 16); r[1] = __uint_as_float(rq.x & 0xffff0000u); r[2] = __uint_as_float(rq.y << 16); r[3] = __uint_as_float(rq.y & 0xffff0000u);
+                    r[4] = __uint_as_float(rq.z << 16); r[5] = __uint_as_float(rq.z & 0xffff0000u); r[6] = __uint_as_float(rq.w << 16); r[7] = __uint_as_float(rq.w & 0xffff0000u);
+                } else {
+                    const float4 ra = *reinterpret_cast<const float4*>(a.raw + (size_t)v * 8), rb = *reinterpret_cast<const float4*>(a.raw + (size_t)v * 8 + 4);
+                    r[0] = ra.x; r[1] = ra.y; r[2] = ra.z; r[3] = ra.w; r[4] = rb.x; r[5] = rb.y; r[6] = rb.z; r[7] = rb.w;
+                }
                 uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0;
                 if (r0) q0 = r0[v];
                 if (r1) q1 = r1[v];
-                const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
                 float o[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {

@@ -467,16 +467,15 @@ PATCH_CFGS = {32: (2, 64, 64), 33: (4, 64, 64), 34: (2, 64, 128), 35: (4, 32, 64
               90: (8, 32, 64), 91: (4, 64, 64),        # 90 / 91: 82 / 83 with K pairs (8 fragment reads per 8 MFMAs)
               92: (8, 32, 64), 93: (4, 64, 64),        # 92 / 93: K quads (6 reads per 8 MFMAs)
               94: (8, 32, 64), 95: (4, 64, 64), 96: (4, 32, 64),
-              # round-5 experiments on tile 90's geometry (K pairs): 97 one barrier per two steps (6 weight stages), 98 the ring one
-              # stage deeper, 99 = 97 with 7 stages + static wave priority.  Offered to the tile searches only with V2V_EXP_TILES=1.
-              97: (8, 32, 64), 98: (8, 32, 64), 99: (8, 32, 64),
-              130: (8, 32, 64), 131: (8, 32, 64), 132: (8, 32, 64),
+              # (the round-5 experiment tiles 97-99 / 130-132 on tile 90's geometry and 142 -- all bit-identical to the tiles they varied, none
+              #  faster, DESIGN 3.1 -- were removed in round 6)
               # csrc/conv3x3_one_kernel.h (round 5): PERSISTENT, weights-resident tile for single-chunk layers with <= 64 output channels
               # (one workgroup per CU walks its tiles; no barrier / DMA / wait inside a tile's 9 steps).  140: bit-identical to tile 94 and
               # 18-20 % faster (profiles/r05_v2_one_bench.txt, r05_v3_one_bench.txt); 141 (two patch buffers): another 5 % on the 2048-tile
               # layer, 5-7 % slower on the small ones (profiles/r05_v6_stagger.txt) -- both are offered, the search decides per shape;
-              # 142 (stores from the accumulators, left in flight) is slower: experiment.
-              140: (8, 32, 64), 141: (8, 32, 64), 142: (8, 32, 64), 143: (8, 32, 64)}     # (141: two patch buffers; 142: + stores straight from the accumulators, left in flight) 130 / 131: one barrier per three steps (7 / 8 stages), 132: per two steps, 8 stages.   94 / 95: single-chunk layers (64 bf16 input channels): one patch buffer, 3 weight stages (72 / 80 KiB)
+              # 143: 141 with its stores left in flight (experiment, V2V_EXP_TILES=1).   94 / 95: single-chunk layers (64 bf16 input
+              # channels): one patch buffer, 3 weight stages (72 / 80 KiB)
+              140: (8, 32, 64), 141: (8, 32, 64), 143: (8, 32, 64)}
 # stride-2 3x3 convolutions on the plane-resident patch kernel (csrc/conv3x3_s2_kernel.h): id -> (TH, TW, BN) of the OUTPUT tile
 S2_CFGS = {100: (4, 32, 64), 101: (4, 32, 128), 102: (4, 32, 64), 103: (4, 32, 128)}
 # ConvTranspose2d(3x3, stride 2) with all four output-parity classes per workgroup (csrc/conv3x3_t2_kernel.h): id -> (TH, TW, BN), tile of INPUT positions
@@ -487,10 +486,10 @@ T2_CFGS = {110: (4, 32, 64), 111: (4, 32, 128), 112: (8, 32, 64), 113: (4, 32, 6
 S7_CFGS = {120: (4, 32, 64), 121: (4, 32, 128)}
 ABLATION_TILES = {78: (8, 32, 128), 79: (8, 32, 64), 88: (8, 32, 128), 89: (8, 32, 64)}     # instrumented copies of 71 / 70 (scripts/pp2_ablate.py); never auto-selected
 PAIR_TILES = (70, 71, 72, 73, 74, 75, 80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93)
-ONE_TILES = (140, 141, 142, 143)                                # persistent, weights-resident single-chunk tiles (csrc/conv3x3_one_kernel.h)
+ONE_TILES = (140, 141, 143)                                     # persistent, weights-resident single-chunk tiles (csrc/conv3x3_one_kernel.h)
 PERSISTENT_TILES = ONE_TILES + (114,)                           # ... and the transposed stride-2 one: ONE statistics row per workgroup, finalize in the launch at any size
 ONE_FIN = os.environ.get("V2V_ONE_FIN", "1") != "0"             # ... finalize their <= 256 statistics rows in the launch (0: separate bn_finalize launch, for A/B)
-EXP_TILES = (97, 98, 99, 130, 131, 132, 142, 143)               # (140 / 141: validated and faster -- regular tiles since visits r05_v3 / r05_v6)
+EXP_TILES = (143,)                                              # (140 / 141: validated and faster -- regular tiles since visits r05_v3 / r05_v6)
 if os.environ.get("V2V_EXP_TILES", "0") == "1":
     PAIR_TILES = PAIR_TILES + EXP_TILES
 
@@ -567,6 +566,7 @@ class Engine:
         # but the convolutions' epilogues pay more for the bf16 packing than the stores save (+3 % / +7 % conv time) -- the frame is
         # 1.7 % SLOWER at both resolutions and the bf16 error grows (fake_B mean 1.44e-2 -> 1.64e-2).  OFF by default.
         self.raw_bf16 = bool(int(os.environ.get("V2V_RAW_BF16", "0")))
+        self.raw_bf16_one = os.environ.get("V2V_RAW_BF16_ONE", "1") != "0"      # bf16 raw output of the persistent single-chunk tiles (Engine.conv)
         # V2V_HEAD_ROWSUM=0: the bf16 generator heads (7x7, <= 4 output channels, planar fp32) stay on conv7x7_head_kernel (tile 60)
         # instead of conv7x7_rowsum_kernel (tile 62: row GEMM over (kernel column, channel) + shifted sum) -- A/B switch
         self.rowsum_heads = bool(int(os.environ.get("V2V_HEAD_ROWSUM", "1")))
@@ -910,8 +910,9 @@ class Engine:
         d.OH, d.OW = OH, OW
         # raw_act_ok (conv_group -> norm_apply only): the raw tensor may be stored in the activation dtype.  Never on the autograd
         # path (the backward kernels read fp32 raw), never for the 7x7 layers (tiles 60 / 61 and the gather-sum stems write fp32)
-        raw_t = bool(raw_act_ok and out_mode == L.OUT_RAW_F32_NHWC and self.raw_bf16 and self.dtype == L.BF16 and out is None
-                     and pc.KH != 7 and not torch.is_grad_enabled())
+        raw_ok_t = bool(raw_act_ok and out_mode == L.OUT_RAW_F32_NHWC and self.dtype == L.BF16 and out is None
+                        and pc.KH != 7 and not torch.is_grad_enabled())
+        raw_t = raw_ok_t and self.raw_bf16
         d.dtype, d.out_mode, d.act = self.dtype, (L.OUT_RAW_ACT_NHWC if raw_t else out_mode), act
         d.act_param, d.out_scale = act_param, out_scale
         if act_b is not None:          # (first channel, activation, parameter, scale) of the second head of a merged pair
@@ -921,7 +922,13 @@ class Engine:
         tune_key = (pc.cin, pc.cout, pc.KH, pc.stride, int(pc.transposed), N, H, W, out_mode, x.Cs)
         if d.tile == 0 and tune_key in self._tuned:
             d.tile, d.splitk, d.prefetch = _cfg3(self._tuned[tune_key])
-        if d.tile in PERSISTENT_TILES and not (self.dtype == L.BF16 and d.out_mode == L.OUT_RAW_F32_NHWC):
+        if raw_ok_t and not raw_t and self.raw_bf16_one and d.tile in PERSISTENT_TILES:
+            # round 6: the persistent single-chunk tiles write their raw output rounded to bf16 (the statistics come from the fp32
+            # accumulators): these layers are HBM-bound and the raw tensor is written once and read once by bn_apply -- 4 instead of
+            # 8 bytes per element for the pair.  V2V_RAW_BF16_ONE=0 keeps fp32 raw.
+            raw_t = True
+            d.out_mode = L.OUT_RAW_ACT_NHWC
+        if d.tile in PERSISTENT_TILES and not (self.dtype == L.BF16 and d.out_mode in (L.OUT_RAW_F32_NHWC, L.OUT_RAW_ACT_NHWC)):
             # a cached / overridden selection made under another raw-output mode or dtype (the key holds the LOGICAL out_mode:
             # V2V_RAW_BF16 flips the effective one; an fp32 engine may share the cache file): the persistent tiles write fp32 raw
             # from bf16 only -- fall back to the library's default tile instead of failing at launch
@@ -1423,13 +1430,13 @@ class Engine:
         """Persistent single-chunk tiles 140 / 141 (/ 143) on a layer with 64-byte pixels (<= 32 -> 32 channels, bf16, raw fp32 output): the
         paired-x view (PairedXConv) -- pairs of pixels as one 128-byte pixel of a 64 -> 64 layer."""
         return (self.dtype == L.BF16 and not d.transposed and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad == 1
-                and d.cin_stride == 32 and d.cout == 32 and d.out_mode == L.OUT_RAW_F32_NHWC and d.W % 2 == 0 and (d.W // 2) % 32 == 0
+                and d.cin_stride == 32 and d.cout == 32 and d.out_mode in (L.OUT_RAW_F32_NHWC, L.OUT_RAW_ACT_NHWC) and d.W % 2 == 0 and (d.W // 2) % 32 == 0
                 and d.H % 8 == 0 and os.environ.get("V2V_PAIRX", "1") != "0")
 
     def pairx_t_eligible(self, d):
         """Persistent transposed tile 114 on a layer with 64-byte pixels (<= 32 -> 16 channels): the paired-x view (PairedXConvT)."""
         return (self.dtype == L.BF16 and bool(d.transposed) and d.KH == 3 and d.KW == 3 and d.stride == 2 and d.pad == 1
-                and d.cin_stride == 32 and d.cout == 16 and d.out_mode == L.OUT_RAW_F32_NHWC and d.W % 2 == 0 and (d.W // 2) % 32 == 0
+                and d.cin_stride == 32 and d.cout == 16 and d.out_mode in (L.OUT_RAW_F32_NHWC, L.OUT_RAW_ACT_NHWC) and d.W % 2 == 0 and (d.W // 2) % 32 == 0
                 and d.H % 8 == 0 and d.OH == 2 * d.H and d.OW == 2 * d.W and os.environ.get("V2V_PAIRX", "1") != "0")
 
     def s7_eligible(self, d):
