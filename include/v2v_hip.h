@@ -61,7 +61,9 @@ extern "C" {
 #define V2V_OUT_RAW_ACT_NHWC 4  /* pre-norm like mode 0, but STORED in the activation dtype (bf16 storage: half the bytes of the
                                  * raw tensor the following v2v_bn_apply_raw reads back); the per-tile statistics and the in-kernel
                                  * finalize still come from the fp32 accumulators, bit for bit those of mode 0.  Generic, patch
-                                 * and single-phase tiles (not tiles 60 / 61).  With V2V_F32 storage identical to mode 0.           */
+                                 * and single-phase tiles, and (round 6) the persistent single-chunk tiles 140 / 141 / 143 / 114,
+                                 * for which it is the inference path's default; not tiles 60 / 61.  With V2V_F32 storage identical
+                                 * to mode 0.                                                                                      */
 
 /* Descriptor of one convolution / transposed convolution launch.  POD, passed by pointer,
  * copied by the callee before it returns. */
@@ -102,7 +104,7 @@ typedef struct v2v_conv_desc {
     int32_t prefetch;       /* 0 = off; P > 0: weight-prefetch helper wave, P K-chunks ahead (see below) */
     void*   slabs;          /* splitk > 1: v2v_conv_splitk_workspace() bytes of scratch              */
     int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
-    int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major, 2 full-tap chunk-major (transposed), 3 paired-x (below) */
+    int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major, 2 full-tap chunk-major (transposed), 3 paired-x (below); a korder-4 packing is read as 1 */
     int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA), 512 = return at once (launch floor), 1024 = no main loop (prologue + epilogue), 2048 = one workgroup per channel tile stays away from the fused-norm barrier (exercises its give-up path: NaN outputs + v2v_device_status bit 0) */
     const void* res0;       /* V2V_OUT_NORM_ACT_NHWC: NULL or a residual [N][OH][OW][cout_stride] (activation dtype) added after the activation */
     const void* res1;       /* second residual, NULL or as res0                                                   */
@@ -175,7 +177,13 @@ int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t ci
  * Transposed counterpart (tile id 114 when cin_stride == 32): ConvTranspose2d(3x3, s2, p1, op1) with <= 32 input and exactly 16 output
  * channels (models/networks.py:254-260 at ngf_s = 16) as the 64 -> 32 transposed layer over [H][W/2][64] -> [2H][W][32] whose weight
  * W3[b*32+ci][e*16+co][ky][kx'] = W[ci][co][ky][kx] (kx = e+1-2b, 3+e-2b, e-1-2b for kx' = 1, 2, 0; zero outside 0..2) the caller packed
- * with korder 2; descriptor: the layer's own geometry (cin_stride 32, cout = cout_stride = 16, OW = 2 W), 16 bias values, 16 statistics columns. */
+ * with korder 2; descriptor: the layer's own geometry (cin_stride 32, cout = cout_stride = 16, OW = 2 W), 16 bias values, 16 statistics columns.
+ * korder 4 (round 6): the BACKWARD-DATA operator of a 3x3 / stride 1 Conv2d as a convolution -- `w` is the layer's own [cout][cin][3][3]
+ * parameter, passed with transposed = 1 (role-swapped read: `cin` = the layer's cout = channels of dY, `cout` = the layer's cin = channels
+ * of dX), packed channel-chunk-major like korder 1 with the taps FLIPPED (matrix tap t = kernel tap 8 - t).  Run it with
+ * v2v_conv_desc { transposed 0, KH = KW = 3, stride 1, pad = 2 - p, V2V_PAD_ZERO, w_korder 1 } on tile ids 80..93: p = 1 gives dX on the layer's
+ * grid, p = 0 (the layer sat behind a ReflectionPad2d(1)) the gradient of the PADDED input, (H+2) x (W+2), which v2v_reflect_pad_fold folds
+ * (the autograd of models/networks.py:571-587).  Tile ids 80..93 accept pad 1 or 2; every other 3x3 patch tile pad 1 only. */
 
 /* Number of statistics rows the launch described by `d` writes: n_classes * m_tiles -- except for the persistent tile ids 140..143 and
  * 114, which keep their sums in registers across the tiles (114: and the four parity classes) a workgroup walks and leave ONE row per

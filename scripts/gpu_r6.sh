@@ -104,7 +104,7 @@ PY
 fi
 if has trainab; then     # one-stream vs side-stream weight gradients, GEMM-view vs nine-tap kernel, alternating on this box
   for rep in 1 2; do
-    for cfg in ${ABCFGS:-V2V_FLOWNET_STREAM=0 V2V_FLOWNET_STREAM=1}; do
+    for cfg in ${ABCFGS:-V2V_BWD_PATCH=0 V2V_BWD_PATCH=1}; do
       cfg=$(echo $cfg | tr ',' ' ')
       env $cfg timeout 600 python bench.py --mode train --steps 9 --warmup 3 --no-train-parity $GEO 2>gpurun_out/${TAG}_trainab.err | python -c "
 import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train [$cfg] run $rep:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', 'loss_G', j['config'].get('loss_G'), j['config'].get('loss_D'))"

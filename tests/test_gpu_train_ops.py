@@ -273,6 +273,50 @@ def test_backward_data_on_the_patch_kernels(case, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(128, 64, 16, 32, "reflect", 82, 1), (64, 128, 17, 29, "reflect", 90, 1), (128, 128, 32, 64, "reflect", 90, 2),
+                                  (64, 192, 9, 40, "zero", 80, 1), (192, 64, 32, 32, "zero", 83, 1), (128, 128, 8, 64, "reflect", 86, 1)])
+def test_backward_data_of_stride1_3x3_on_the_single_phase_tiles(case, prec):
+    """Round 6: backward-data of a 3x3 / stride 1 Conv2d as a CONVOLUTION on the single-phase 3x3 tiles -- the role-swapped parameter
+    with flipped taps (PackedConv korder 4, v2v_conv_pack_weights korder 4) and pad 2 - p: behind a ReflectionPad2d a "full"
+    convolution onto the (H+2) x (W+2) padded grid (the kernels' patch origin follows v2v_conv_desc.pad), folded by reflect_pad_fold;
+    with zero padding the same-size convolution.  Forced through bwd_tile_override; dX / dW against CPU autograd, odd sizes, split-K,
+    ragged tiles (the padded grid is never a multiple of the tile)."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd import autograd as AG
+    cin, cout, H, W, mode, tile, S = case
+    bke = 64 if prec == "bf16" else 32
+    if cout % bke != 0:
+        pytest.skip("dY channel stride must be whole 128-byte chunks")
+    torch.manual_seed(cin + cout + tile + H)
+    eng = _engine(prec)
+    conv = nn.Conv2d(cin, cout, 3, stride=1, padding=0 if mode == "reflect" else 1)
+    cref = nn.Conv2d(cin, cout, 3, stride=1, padding=0 if mode == "reflect" else 1)
+    eng.bwd_tile_override[(cout, cin, 3, 1, 1)] = (tile, S, 0)                # dY (cout channels) -> dX (cin channels); role-swapped = "transposed" stride 1
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.2); conv.bias.normal_(0, 0.5)
+    rnd = (lambda t: t.bfloat16().float()) if prec == "bf16" else (lambda t: t.clone())
+    x = torch.randn(2, cin, H, W)
+    xr = rnd(x).requires_grad_(True)
+    with torch.no_grad():
+        cref.weight.copy_(rnd(conv.weight)); cref.bias.copy_(conv.bias)
+    yr = _ref_conv(xr, cref, 3, 1, 1, mode)
+    r = rnd(torch.randn_like(yr))
+    (yr * r).sum().backward()
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    ya = AG.conv_group(eng, eng.pack(xg), conv, _pad_mode(mode), 1, None, L.ACT_NONE, 0.0, None, None, False, 1.0, "t")
+    y = eng.unpack(ya)
+    assert_close(y.detach().cpu(), yr.detach(), 1e-4 if prec == "fp32" else 1e-2, "forward " + str(case))
+    n0 = len(eng.conv_log)
+    (y * r.to(DEV)).sum().backward()
+    assert any(c.get("kind") == "bwd_data" for c in eng.conv_log[n0:])
+    assert any(pc.korder == 4 for pc in eng._packed.values()), "the backward-data operator did not take the convolution form"
+    tol = 2e-4 if prec == "fp32" else 3e-2
+    assert_close(xg.grad.cpu(), xr.grad, tol, "dX " + str(case))
+    assert_close(conv.weight.grad.cpu(), cref.weight.grad, tol, "dW " + str(case))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("norm_kind", ["batch", "instance"])
 @pytest.mark.parametrize("act", ["relu", "leaky", "none"])
 def test_conv_norm_act_residual_backward(norm_kind, act, prec):

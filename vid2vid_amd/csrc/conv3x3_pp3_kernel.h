@@ -182,7 +182,9 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         const int q = (k * NW + wid) * 8 + (lane >> 3);
         const int ls = (lane & 7) ^ ((q >> 1) & 7);
         const int pr = q / PW, pc = q - pr * PW;
-        int ih = oh0 + pr - PADK, iw = ow0 + pc - PADK;
+        // first tap's input offset = -pad: PADK for the layer's own operator; 3x3 backward-data of a reflect-padded layer is the same
+        // kernel with pad 2 over an output grid two pixels larger (round 6: v2v_conv_desc.pad 1 or 2 for the single-phase tiles)
+        int ih = oh0 + pr + p.dh0[0], iw = ow0 + pc + p.dw0[0];
         bool ok = q < PR;
         int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
         int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
@@ -394,11 +396,13 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     __syncthreads();
     V2V_STAMP(p, 3);
 
-    const bool tile_full = oh0 + TH <= H && ow0 + TW <= W;    // every row of the tile is a pixel of the layer (uniform: conv_epilogue's fast paths)
+    // OUTPUT grid (= the input grid for the layers' own pad-1 operators; two pixels larger for the pad-2 backward-data form, round 6)
+    const int OHo = p.OH, OWo = p.OW;
+    const bool tile_full = oh0 + TH <= OHo && ow0 + TW <= OWo;    // every row of the tile is a pixel of the layer (uniform: conv_epilogue's fast paths)
     auto pix_of = [&](int row) __attribute__((always_inline)) -> int {        // TW is a power of two; N*OH*OW < 2^31 (host check)
         const int oh = oh0 + row / TW, ow = ow0 + (row & (TW - 1));
-        if (oh >= H || ow >= W) return -1;
-        return (n_img * H + oh) * W + ow;
+        if (oh >= OHo || ow >= OWo) return -1;
+        return (n_img * OHo + oh) * OWo + ow;
     };
     if constexpr (KS == 1) {
         conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full);

@@ -703,7 +703,8 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
         // weights packed channel-chunk outer (korder 1)
         const PatchCfg* pc = op->cfg >= 80 ? find_pp3_cfg(op->cfg) : op->cfg >= 70 ? find_pp2_cfg(op->cfg) : op->cfg >= 50 ? find_pp_cfg(op->cfg) : find_patch_cfg(op->cfg);
         if (!pc) { set_error("conv: unknown tile config %d", op->cfg); return V2V_EINVAL; }
-        if (d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 ||
+        const bool pad2_ok = d->pad == 2 && op->cfg >= 80 && op->cfg <= 93 && d->pad_mode == V2V_PAD_ZERO && d->out_mode != V2V_OUT_NORM_ACT_NHWC;   // single-phase tiles: "full" 3x3 convolution (backward-data behind a ReflectionPad2d)
+        if (d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || (d->pad != 1 && !pad2_ok) ||
             d->cin_stride % bke_of(d->dtype) != 0 || d->w_korder != 1 ||
             (long long)d->N * d->H * d->W * d->cin_stride * (d->dtype == V2V_BF16 ? 2 : 4) >= (1ll << 32)) {
             set_error("conv: patch tile config %d needs a 3x3/s1/p1 Conv2d, cin_stride %% %d == 0 and korder-1 weights",
@@ -805,11 +806,20 @@ extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int
         if (!transposed || stride != 2 || KH != 3 || KW != 3 || cin_stride % bke_of(dtype) != 0) {
             set_error("pack: korder 2 needs a ConvTranspose2d(3x3, stride 2) whose channel stride is a multiple of the 128-byte chunk"); return V2V_EINVAL;
         }
+    } else if (korder == 4) {
+        // backward-data operator of a 3x3 / stride 1 Conv2d AS A CONVOLUTION (round 6): the parameter read with its roles swapped
+        // (transposed layout: dim 0 = this operator's input channels) and its taps FLIPPED, packed channel-chunk-major like a
+        // Conv2d's korder 1 -- what the 3x3 patch kernels read; the caller runs them with pad = 2 - (the layer's pad)
+        if (!transposed || stride != 1 || KH != 3 || KW != 3 || cin_stride % bke_of(dtype) != 0 || src_cl) {
+            set_error("pack: korder 4 needs the role-swapped (transposed = 1) read of a 3x3 / stride 1 Conv2d weight, channel stride a multiple of the 128-byte chunk"); return V2V_EINVAL;
+        }
     } else if (korder != 0 && (korder != 1 || transposed || cin_stride % bke_of(dtype) != 0)) {
         set_error("pack: korder 1 needs a Conv2d whose channel stride is a multiple of the 128-byte chunk"); return V2V_EINVAL;
     }
     ConvGeom g;
-    conv_geom(cin_stride, cout, KH, KW, transposed, stride, pad, dtype, &g);
+    conv_geom(cin_stride, cout, KH, KW, korder == 4 ? 0 : transposed, stride, pad, dtype, &g);
+    int kh0_flip = -1;
+    if (korder == 4) { kh0_flip = KH - 1; korder = 1; }
     if (korder == 2) {
         g.ncls = 1; g.nkh[0] = 3; g.nkw[0] = 3; g.kh0[0] = 0; g.kw0[0] = 0;
         g.ktot[0] = g.kpad[0] = g.wrow[0] = 9 * cin_stride; g.woff[0] = 0;
@@ -826,6 +836,7 @@ extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int
         a.nkh[c] = g.nkh[c]; a.nkw[c] = g.nkw[c]; a.kh0[c] = g.kh0[c]; a.kw0[c] = g.kw0[c];
         a.kpad[c] = g.kpad[c]; a.wrow[c] = g.wrow[c]; a.woff[c] = g.woff[c];
     }
+    if (kh0_flip >= 0) { a.kh0[0] = kh0_flip; a.kw0[0] = KW - 1; a.kstep = -1; }      // tap t of the matrix = kernel tap (2 - t): flipped
     return submit(std::move(op), stream);
 }
 

@@ -154,8 +154,11 @@ class PackedConv:
         self.out_pad = mod.output_padding[0] if mod_t else 0
         self.cin_stride = cin_stride
         self.dtype = eng.dtype
+        if korder == 4 and (role != "bwd" or mod_t or (self.KH, self.KW) != (3, 3) or self.stride != 1):
+            raise ValueError("korder 4: the backward-data operator of a 3x3 / stride 1 Conv2d, packed as a convolution with flipped taps")
         n = ((lib.v2v_conv_packed_elems(64, 64, 32, 3, 3, 1, 2, 1, eng.dtype) if mod_t else lib.v2v_conv_packed_elems(64, 64, 64, 3, 3, 0, 1, self.pad, eng.dtype))
              if korder == 3 else
+             lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, 3, 3, 0, 1, 1, eng.dtype) if korder == 4 else
              lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, self.KH, self.KW,
                                        int(self.transposed), self.stride, self.pad, eng.dtype))
         self.buf = torch.empty(n, dtype=_TORCH_DTYPE[eng.dtype], device=eng.device)
@@ -193,6 +196,8 @@ class PackedConv:
         w32 = w.detach()
         src_cl = (w32.dtype == torch.float32 and w32.dim() == 4 and not w32.is_contiguous()
                   and w32.permute(0, 2, 3, 1).is_contiguous())          # optim.FlatBuffers: channels-last master weights
+        if self.korder == 4:
+            src_cl = False                                               # (the flipped packing reads the standard layout only)
         if not src_cl and (w32.dtype != torch.float32 or not w32.is_contiguous()):
             w32 = w32.float().contiguous()
         check(lib.v2v_conv_pack_weights(_ptr(w32), _ptr(self.buf), self.cin, self.cin_stride, self.cout,
@@ -1405,7 +1410,21 @@ class Engine:
         d.w, d.w_korder = pc.buf.data_ptr(), 1
         return pc
 
+    def bwd_patch_eligible(self, d, mod):
+        """Backward-data of a 3x3 / stride 1 Conv2d on the single-phase 3x3 tiles (round 6): the operator IS a 3x3 convolution of the
+        output gradient with the role-swapped, tap-flipped weights (PackedConv korder 4) and pad 2 - p -- behind a ReflectionPad2d
+        (p = 0) a "full" convolution onto the padded grid, which reflect_pad_fold then folds.  The generic tiles ran these at
+        62 us for the 1024 -> 1024 layers (the forward, same FLOP, takes 44 on tile 90: profiles/r06_v17_train_by_grid.txt)."""
+        bke = 64 if self.dtype == L.BF16 else 32
+        return (isinstance(mod, nn.Conv2d) and tuple(mod.kernel_size) == (3, 3) and tuple(mod.stride) == (1, 1) and mod.groups == 1
+                and d.cin_stride % bke == 0 and d.out_mode == L.OUT_ACT_NHWC and os.environ.get("V2V_BWD_PATCH", "1") != "0")
+
     def _use_korder(self, d, mod, cin_stride, korder, role="fwd", reflect=False):
+        if role == "bwd" and korder == 1 and 80 <= d.tile <= 93 and self.bwd_patch_eligible(d, mod):
+            pc = self.packed(mod, cin_stride, role="bwd", reflect=reflect, korder=4)
+            d.transposed, d.pad = 0, pc.KH - 1 - pc.pad
+            d.w, d.w_korder = pc.buf.data_ptr(), 1
+            return pc
         if d.tile in PERSISTENT_TILES and cin_stride == 32 and role == "fwd" and (self.pairx_eligible(d) or self.pairx_t_eligible(d)):
             # 64-byte pixels on the persistent single-chunk tiles: paired-x packing (PairedXConv).  Gated on the view's own
             # eligibility (ADVICE r5; round 6: an fp32 engine's 32-channel layers -- one 128-byte chunk, patch-eligible, so the
@@ -1414,6 +1433,8 @@ class Engine:
             korder = 3
         pc = self.packed(mod, cin_stride, role=role, reflect=reflect, korder=korder)
         d.w, d.w_korder = pc.buf.data_ptr(), korder
+        if role == "bwd":
+            d.transposed, d.pad = int(pc.transposed), pc.pad      # (a previous candidate may have been the convolution form above)
         return pc
 
     def _use_korder0(self, d, mod, cin_stride):
@@ -1523,6 +1544,15 @@ class Engine:
                     if S > 1 and (tiles * S > 1024 or ncc < S):
                         continue
                     if S == 1 and tiles < 64:
+                        continue
+                    cands.append((t, S, 0))
+        if mod is not None and role == "bwd" and self.bwd_patch_eligible(d, mod):
+            for t in (80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93):
+                th, tw, bn = PATCH_CFGS[t]
+                tiles = d.N * -(-d.OH // th) * -(-d.OW // tw) * -(-cout // bn)
+                ncc = d.cin_stride // (64 if self.dtype == L.BF16 else 32)
+                for S in (1, 2):
+                    if (S > 1 and (tiles * S > 1024 or ncc < S)) or (S == 1 and tiles < 64):
                         continue
                     cands.append((t, S, 0))
         if mod is not None and role == "fwd" and self.pairx_eligible(d) and d.N * (d.H // 8) * (d.W // 64) >= 64:
