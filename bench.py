@@ -523,6 +523,14 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
             traceback.print_exc()
             parity = {"error": repr(ex)[:400]}
 
+    # Inside the default command this leg runs behind a dozen other models (inference, 2048x1024, the configs[0] / [3] clips, their
+    # fp32 / x3 twins and the CPU oracle's tensors): millions of live Python objects.  A training chunk allocates ~10^5 objects (autograd
+    # nodes, views, descriptors), so the cyclic collector's full passes -- whose cost grows with everything alive -- land inside the
+    # timed chunks and the host falls behind the device (27.4 frames trained/s in the default line against 39-40 for the same leg
+    # alone, profiles/r06_v22_bench_default_line.json vs r06_v23).  What is alive now is not garbage of this leg: park it.
+    import gc
+    gc.collect()
+    gc.freeze()
     # tile search on the first sequence (every conv shape of the step: forward, backward-data), then plain warm-up
     eng.autotune = not args.no_autotune
     t_tune = time.perf_counter()
@@ -607,6 +615,7 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
                            % (gsync.bucket_elems * 4))
     else:
         collective_note = "none (one process)"
+    gc.unfreeze()
     sys.stdout = _stdout
     if rank == 0:
         log = list(eng.conv_log)

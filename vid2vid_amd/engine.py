@@ -112,7 +112,7 @@ def repack_after_step(flat=None):
         if eng is None:
             _ENGINES.remove(ref)
         else:
-            eng.repack_async()
+            eng.repack_async(flat)
 
 
 class PackedConv:
@@ -165,6 +165,11 @@ class PackedConv:
         self.bias = None
         self.version = None
         self.used = True          # fetched since the last asynchronous re-pack (Engine.repack_async only refreshes what is in use)
+        # the flat optimizer buffer that owns this layer's parameter (None: not managed by a FusedAdam, or a composed view such as
+        # MergedConv whose `weight` is assembled on read): repack_after_step walks only the packings of the buffer that was stepped --
+        # an engine shared by several models (bench.py builds a dozen) holds thousands of packings
+        w_own = mod.__dict__.get("_parameters", {}).get("weight") if isinstance(mod, nn.Module) else None
+        self.flat_id = id(getattr(w_own, "_v2v_flat", None)) if w_own is not None and getattr(w_own, "_v2v_flat", None) is not None else None
         self.refresh()
 
     def refresh(self, force=False):
@@ -775,12 +780,15 @@ class Engine:
         pc.used = True
         return pc
 
-    def repack_async(self):
-        """Refresh the stale packings that were used since the last call, on the side stream (see repack_after_step)."""
+    def repack_async(self, flat=None):
+        """Refresh the stale packings of `flat`'s parameters that were used since the last call, on the side stream (see
+        repack_after_step).  Packings whose owner is unknown (parameters re-homed after the packing was made, composed views) are
+        left to the lazy refresh in front of their next use."""
         side = self.wgrad_side_stream()
         if side is None or self.plan is not None or not self.repack_async_on or torch.cuda.is_current_stream_capturing():
             return
-        todo = [pc for pc in self._packed.values() if pc.used]
+        fid = id(flat) if flat is not None else None
+        todo = [pc for pc in self._packed.values() if pc.used and (fid is None or pc.flat_id == fid)]
         if not todo:
             return
         cur = torch.cuda.current_stream(self.device)
