@@ -23,6 +23,8 @@ if has trainprof; then   # steady-state rocprofv3 table of the training step (a 
   DB=$(find /tmp/prof_tr_$TAG -name "*.db" | head -1)
   python $R/scripts/rocprof_summary.py $DB "# round 6, visit $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --mode train --steps 6 --warmup 2 --no-train-parity $GEO (bf16, VGG on; tile selections replayed from a cache filled by a previous run)" > $R/gpurun_out/${TAG}_train_kernel_stats.txt 2>> $R/gpurun_out/${TAG}_train.err
   python $R/scripts/rocprof_by_grid.py $DB > $R/gpurun_out/${TAG}_train_by_grid.txt 2>> $R/gpurun_out/${TAG}_train.err
+  python $R/scripts/rocprof_gaps.py $DB > $R/gpurun_out/${TAG}_train_gaps.txt 2>> $R/gpurun_out/${TAG}_train.err
+  head -50 $R/gpurun_out/${TAG}_train_gaps.txt | cut -c1-160
   head -45 $R/gpurun_out/${TAG}_train_kernel_stats.txt | cut -c1-200
   head -60 $R/gpurun_out/${TAG}_train_by_grid.txt | cut -c1-200
   python -c "

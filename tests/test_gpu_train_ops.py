@@ -317,6 +317,47 @@ def test_backward_data_of_stride1_3x3_on_the_single_phase_tiles(case, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(128, 3, 16, 32, "reflect"), (64, 2, 19, 45, "reflect"), (32, 3, 40, 72, "reflect"), (32, 1, 8, 33, "zero"),
+                                  (16, 3, 24, 64, "reflect")])
+def test_backward_data_of_the_7x7_heads_on_the_16_byte_pixel_kernel(case, prec):
+    """Round 6: backward-data of the generator heads (ngf -> 3 / 2 / 1 channels, 7x7 behind ReflectionPad2d(3)) on conv7x7_c8_kernel
+    (tile 61): the output gradient is one 16-byte vector per pixel, the operator a 7x7 convolution with the role-swapped, tap-flipped
+    weights (v2v_conv_pack_weights korder 5) and zero padding 6 - p onto the (H+6) x (W+6) padded grid (activation-typed NHWC output),
+    folded by reflect_pad_fold; zero padding 3: the same-size convolution.  Forced through bwd_tile_override; dX / dW against CPU
+    autograd; ragged tiles, every N-tile count of the kernel (16 ... 128 dX channels)."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd import autograd as AG
+    cin, cout, H, W, mode = case
+    torch.manual_seed(cin + cout + H)
+    eng = _engine(prec)
+    pad = 0 if mode == "reflect" else 3
+    conv = nn.Conv2d(cin, cout, 7, stride=1, padding=pad)
+    cref = nn.Conv2d(cin, cout, 7, stride=1, padding=pad)
+    eng.bwd_tile_override[(cout, cin, 7, 1, 1)] = (61, 1, 0)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.1); conv.bias.normal_(0, 0.5)
+    rnd = (lambda t: t.bfloat16().float()) if prec == "bf16" else (lambda t: t.clone())
+    x = torch.randn(2, cin, H, W)
+    xr = rnd(x).requires_grad_(True)
+    with torch.no_grad():
+        cref.weight.copy_(rnd(conv.weight)); cref.bias.copy_(conv.bias)
+    yr = torch.tanh(_ref_conv(xr, cref, 7, 1, 3, mode))
+    r = rnd(torch.randn_like(yr))
+    (yr * r).sum().backward()
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = AG.conv_group(eng, eng.pack(xg), conv, _pad_mode(mode), 3, None, L.ACT_TANH, 0.0, None, None, True, 1.0, "head")
+    assert_close(y.detach().cpu(), yr.detach(), 1e-4 if prec == "fp32" else 2e-2, "forward " + str(case))
+    n0 = len(eng.conv_log)
+    (y * r.to(DEV)).sum().backward()
+    assert any(c.get("kind") == "bwd_data" for c in eng.conv_log[n0:])
+    assert any(pc.korder == 5 for pc in eng._packed.values()), "the backward-data operator did not take the 16-byte-pixel kernel"
+    tol = 2e-4 if prec == "fp32" else 3e-2
+    assert_close(xg.grad.cpu(), xr.grad, tol, "dX " + str(case))
+    assert_close(conv.weight.grad.cpu(), cref.weight.grad, tol, "dW " + str(case))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("norm_kind", ["batch", "instance"])
 @pytest.mark.parametrize("act", ["relu", "leaky", "none"])
 def test_conv_norm_act_residual_backward(norm_kind, act, prec):

@@ -213,22 +213,24 @@ class ConvFn(torch.autograd.Function):
 def _conv_backward_data(eng, cfg, conv, transposed, g, cout, x, N, OH, OW):
     """dX through the forward kernel with role-swapped weights (include/v2v_hip.h, v2v_conv2d)."""
     reflect = cfg.pad_mode == L.PAD_REFLECT
-    pc = eng.packed(conv, g.stride(2), role="bwd", reflect=reflect)
+    # the generic operator's geometry (engine.PackedConv role 'bwd'); tune_backward_data fetches the packing the selected tile reads --
+    # only that one is kept fresh after optimizer steps (Engine.repack_async walks the packings in use)
+    bwd_pad = 0 if reflect else conv.padding[0]
     H, W = x.H, x.W
     p = cfg.pad
     HO, WO = (H + 2 * p, W + 2 * p) if reflect else (H, W)
     needs_zero = x.Cs != cfg.cin
     out = (torch.zeros if needs_zero else torch.empty)((N, HO, WO, x.Cs), dtype=eng.tdtype, device=eng.device)
     d = ConvDesc()
-    d.in_, d.w, d.bias, d.out, d.stats = g.data_ptr(), pc.buf.data_ptr(), None, out.data_ptr(), None
+    d.in_, d.w, d.bias, d.out, d.stats = g.data_ptr(), None, None, out.data_ptr(), None
     d.zero_page = eng.zero_page().data_ptr()
     d.N, d.H, d.W = N, OH, OW
     d.cin, d.cin_stride, d.cout, d.cout_stride = cout, g.stride(2), cfg.cin, x.Cs
     d.KH, d.KW = conv.kernel_size
     d.stride = conv.stride[0]
-    d.pad = pc.pad
+    d.pad = bwd_pad
     d.pad_mode = L.PAD_ZERO
-    d.transposed = int(pc.transposed)
+    d.transposed = int(not transposed)
     d.OH, d.OW = HO, WO
     d.dtype, d.out_mode, d.act, d.act_param, d.out_scale, d.tile = eng.dtype, L.OUT_ACT_NHWC, L.ACT_NONE, 0.0, 1.0, 0
     eng.tune_backward_data(d, cfg.cin, conv=conv, reflect=reflect)     # (also points d.w at the packing the selected tile reads)

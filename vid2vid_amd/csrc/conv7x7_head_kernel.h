@@ -47,9 +47,58 @@ template <> struct Mma16<float> {
 template <typename T, int NT>
 __device__ __forceinline__ void head_epilogue(const ConvKArgs& p, f32x4 (&acc)[4][NT], char* smem, const int tid, const int wid, const int lp,
                                               const int kg, const int mt, const int n_img, const int oh0, const int ow0) {
-    const int H = p.H, W = p.W;
-    const bool raw_mode = p.out_mode == V2V_OUT_RAW_F32_NHWC;
+    const int H = p.OH, W = p.OW;                                     // the OUTPUT grid (= the input's but for conv7x7_c8_kernel with zero padding > 3)
+    // activation-typed NHWC without activation (tile 61 as a backward-data operator, round 6): fp32 engines write exactly the raw layout
+    const bool act_nhwc = p.out_mode == V2V_OUT_ACT_NHWC;
+    const bool raw_mode = p.out_mode == V2V_OUT_RAW_F32_NHWC || (act_nhwc && sizeof(T) == 4);
+    const bool act_bf16 = act_nhwc && sizeof(T) == 2;
     const long long hw = (long long)H * W;
+    if (act_bf16) {
+        // bf16 NHWC rows through the same wave-private [32][36] fp32 block: a lane packs 8 channels into one 16-byte store
+        // (host: cout and cout_stride are whole 8-channel vectors, no bias / activation / statistics)
+        const int lane = tid & 63;
+        __syncthreads();
+        float* const tw = reinterpret_cast<float*>(smem) + wid * (32 * 36);
+        unsigned short* const outp = reinterpret_cast<unsigned short*>(p.out);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int oh = oh0 + 2 * wid + h;
+#pragma unroll
+            for (int n2 = 0; n2 < (NT + 1) / 2; ++n2) {
+                const int nn_cnt = NT - 2 * n2 >= 2 ? 2 : 1;
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) {
+                        if (nn < nn_cnt) {
+                            const int n = 2 * n2 + nn;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) tw[(gi * 16 + kg * 4 + r) * 36 + nn * 16 + lp] = acc[2 * h + gi][n < NT ? n : 0][r];
+                        }
+                    }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int lpp = nn_cnt * 2;                           // lanes per pixel (8 channels = 16 bytes each)
+                const int ppp = 64 / lpp;
+                const int pl0 = lane / lpp, c8 = (lane % lpp) * 8;
+                for (int pl = pl0; pl < 32; pl += ppp) {
+                    const int ow = ow0 + pl;
+                    const int co = n2 * 32 + c8;
+                    if (oh < H && ow < W && co < p.cout) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(tw + pl * 36 + c8);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(tw + pl * 36 + c8 + 4);
+                        uint4 pk;
+                        pk.x = pack_bf16x2(a4[0], a4[1]); pk.y = pack_bf16x2(a4[2], a4[3]);
+                        pk.z = pack_bf16x2(b4[0], b4[1]); pk.w = pack_bf16x2(b4[2], b4[3]);
+                        *reinterpret_cast<uint4*>(outp + (((long long)n_img * H + oh) * W + ow) * p.cout_stride + co) = pk;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        return;
+    }
     // Round 5: raw fp32 NHWC output leaves with 16-BYTE stores through a wave-private LDS block (one tile row of 32 pixels x up to 32
     // channels at a time: [32][36] fp32 = 4.5 KiB per wave), as in every other convolution kernel of the library.  The element-wise path
     // below writes 4 bytes per lane, 64-byte runs at a 128-byte pitch: 268 MB of the 6 -> 32 stem at 2048x1024 as 67 M four-byte stores
@@ -301,7 +350,7 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const ConvKArgs p, cons
         if (g < NG) {
             const int q = g * 64 + lane;
             const int pr = q / PW, pc = q - pr * PW;
-            int ih = oh0 + pr - HALO, iw = ow0 + pc - HALO;
+            int ih = oh0 + pr + p.dh0[0], iw = ow0 + pc + p.dw0[0];  // first tap's offset = -pad (3; zero padding: up to 6, the "full" convolution)
             int rh = ih < 0 ? -ih : ih;  rh = rh >= H ? 2 * H - 2 - rh : rh;
             int rw = iw < 0 ? -iw : iw;  rw = rw >= W ? 2 * W - 2 - rw : rw;
             ih = reflect ? rh : ih;

@@ -600,13 +600,20 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
     int tile_bm, tile_bn;
     if (op->cfg == 61) {
         // conv7x7_c8_kernel: 7x7 / stride 1 / pad 3 Conv2d over pixels of exactly 16 bytes (8 bf16 / 4 fp32 channels), <= 128 output channels
-        if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->cout > 128 ||
+        // Round 6: zero padding of 3 ... 6 (the output grid is then (H + 2 pad - 6) x (W + 2 pad - 6): pad 6 is the "full" convolution the
+        // backward-data of a head behind ReflectionPad2d(3) is), and activation-typed NHWC output without activation for that use
+        const int vec = d->dtype == V2V_BF16 ? 8 : 4;
+        const bool act_out = d->out_mode == V2V_OUT_ACT_NHWC;
+        if (d->transposed || d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad < 3 || d->pad > 6 || (d->pad != 3 && d->pad_mode != V2V_PAD_ZERO) ||
+            d->OH != d->H + 2 * d->pad - 6 || d->OW != d->W + 2 * d->pad - 6 || d->cout > 128 ||
             d->cin_stride * (d->dtype == V2V_BF16 ? 2 : 4) != 16 || d->w_korder != 0 || d->splitk > 1 || d->fin_counter || d->act_split != 0 ||
-            !(d->out_mode == V2V_OUT_F32_NCHW || d->out_mode == V2V_OUT_RAW_F32_NHWC) ||
+            !(d->out_mode == V2V_OUT_F32_NCHW || d->out_mode == V2V_OUT_RAW_F32_NHWC || act_out) ||
+            (act_out && (d->act != V2V_ACT_NONE || d->out_scale != 1.f || d->cout % vec != 0 || d->cout_stride % vec != 0 || ((unsigned long long)d->out & 15ull))) ||
             (d->stats && d->out_mode != V2V_OUT_RAW_F32_NHWC) ||
             (long long)d->N * d->H * d->W * 16 >= (1ll << 32)) {
-            set_error("conv: tile config 61 (7x7 over 16-byte pixels) needs a 7x7/s1/p3 Conv2d, a channel stride of 16 bytes, cout <= 128, planar fp32 "
-                      "or raw NHWC output without in-kernel norm finalize"); return V2V_EINVAL;
+            set_error("conv: tile config 61 (7x7 over 16-byte pixels) needs a 7x7/s1 Conv2d with pad 3 (or zero padding of 3 ... 6), a channel stride of "
+                      "16 bytes, cout <= 128, planar fp32 / raw NHWC output without in-kernel norm finalize, or plain activation-typed NHWC output "
+                      "(no activation, whole 16-byte vectors)"); return V2V_EINVAL;
         }
         k.tiles_h = (int)ceil_div(d->OH, 8);
         k.tiles_w = (int)ceil_div(d->OW, 32);
@@ -813,13 +820,20 @@ extern "C" int v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int
         if (!transposed || stride != 1 || KH != 3 || KW != 3 || cin_stride % bke_of(dtype) != 0 || src_cl) {
             set_error("pack: korder 4 needs the role-swapped (transposed = 1) read of a 3x3 / stride 1 Conv2d weight, channel stride a multiple of the 128-byte chunk"); return V2V_EINVAL;
         }
+    } else if (korder == 5) {
+        // the same operator for a square stride-1 Conv2d of any size, packed TAP-major like a Conv2d's korder 0: what conv7x7_c8_kernel
+        // (tile 61) reads for the backward-data of the 7x7 heads (3 gradient channels = one 16-byte pixel); run with pad = 6 - (the layer's pad)
+        if (!transposed || stride != 1 || KH != KW || !(KH & 1) || src_cl) {
+            set_error("pack: korder 5 needs the role-swapped (transposed = 1) read of a square, odd, stride-1 Conv2d weight"); return V2V_EINVAL;
+        }
     } else if (korder != 0 && (korder != 1 || transposed || cin_stride % bke_of(dtype) != 0)) {
         set_error("pack: korder 1 needs a Conv2d whose channel stride is a multiple of the 128-byte chunk"); return V2V_EINVAL;
     }
     ConvGeom g;
-    conv_geom(cin_stride, cout, KH, KW, korder == 4 ? 0 : transposed, stride, pad, dtype, &g);
+    conv_geom(cin_stride, cout, KH, KW, (korder == 4 || korder == 5) ? 0 : transposed, stride, pad, dtype, &g);
     int kh0_flip = -1;
     if (korder == 4) { kh0_flip = KH - 1; korder = 1; }
+    if (korder == 5) { kh0_flip = KH - 1; korder = 0; }
     if (korder == 2) {
         g.ncls = 1; g.nkh[0] = 3; g.nkw[0] = 3; g.kh0[0] = 0; g.kw0[0] = 0;
         g.ktot[0] = g.kpad[0] = g.wrow[0] = 9 * cin_stride; g.woff[0] = 0;

@@ -156,9 +156,12 @@ class PackedConv:
         self.dtype = eng.dtype
         if korder == 4 and (role != "bwd" or mod_t or (self.KH, self.KW) != (3, 3) or self.stride != 1):
             raise ValueError("korder 4: the backward-data operator of a 3x3 / stride 1 Conv2d, packed as a convolution with flipped taps")
+        if korder == 5 and (role != "bwd" or mod_t or self.KH != self.KW or self.KH % 2 == 0 or self.stride != 1):
+            raise ValueError("korder 5: the backward-data operator of a square stride-1 Conv2d, packed tap-major as a convolution with flipped taps")
         n = ((lib.v2v_conv_packed_elems(64, 64, 32, 3, 3, 1, 2, 1, eng.dtype) if mod_t else lib.v2v_conv_packed_elems(64, 64, 64, 3, 3, 0, 1, self.pad, eng.dtype))
              if korder == 3 else
              lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, 3, 3, 0, 1, 1, eng.dtype) if korder == 4 else
+             lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, self.KH, self.KW, 0, 1, self.KH // 2, eng.dtype) if korder == 5 else
              lib.v2v_conv_packed_elems(self.cin, cin_stride, self.cout, self.KH, self.KW,
                                        int(self.transposed), self.stride, self.pad, eng.dtype))
         self.buf = torch.empty(n, dtype=_TORCH_DTYPE[eng.dtype], device=eng.device)
@@ -201,7 +204,7 @@ class PackedConv:
         w32 = w.detach()
         src_cl = (w32.dtype == torch.float32 and w32.dim() == 4 and not w32.is_contiguous()
                   and w32.permute(0, 2, 3, 1).is_contiguous())          # optim.FlatBuffers: channels-last master weights
-        if self.korder == 4:
+        if self.korder in (4, 5):
             src_cl = False                                               # (the flipped packing reads the standard layout only)
         if not src_cl and (w32.dtype != torch.float32 or not w32.is_contiguous()):
             w32 = w32.float().contiguous()
@@ -1376,6 +1379,8 @@ class Engine:
         if key not in self._tuned:
             if not (self.autotune and self.plan is None and not self.record_only):
                 d.tile, d.splitk, d.prefetch = 0, 0, 0
+                if conv is not None:
+                    self._use_korder(d, conv, d.cin_stride, 0, role="bwd", reflect=reflect)
                 self._splitk_workspace(d)
                 return
             # conv given: the patch kernels are candidates too -- backward-data of a stride-2 Conv2d is a transposed stride-2 convolution
@@ -1427,7 +1432,24 @@ class Engine:
         return (isinstance(mod, nn.Conv2d) and tuple(mod.kernel_size) == (3, 3) and tuple(mod.stride) == (1, 1) and mod.groups == 1
                 and d.cin_stride % bke == 0 and d.out_mode == L.OUT_ACT_NHWC and os.environ.get("V2V_BWD_PATCH", "1") != "0")
 
+    def bwd_c8_eligible(self, d, mod):
+        """Backward-data of the 7x7 heads (ngf -> 3 behind ReflectionPad2d(3): models/networks.py:178-183) on conv7x7_c8_kernel
+        (tile 61): the output gradient is ONE 16-byte vector per pixel, the operator a 7x7 convolution of it with the role-swapped,
+        tap-flipped weights (PackedConv korder 5) and zero padding 6 - p.  The generic tiles walk it in 128-byte K chunks that are
+        7/8 padding: 816 us per head at 2048x1024 (profiles/r06_v14_train_hires_by_grid.txt)."""
+        vec = 8 if self.dtype == L.BF16 else 4
+        return (isinstance(mod, nn.Conv2d) and tuple(mod.kernel_size) == (7, 7) and tuple(mod.stride) == (1, 1) and mod.groups == 1
+                and d.cin_stride == vec and mod.in_channels <= 128 and mod.in_channels % vec == 0 and d.cout_stride % vec == 0
+                and d.out_mode == L.OUT_ACT_NHWC and os.environ.get("V2V_BWD_C8", "1") != "0")
+
     def _use_korder(self, d, mod, cin_stride, korder, role="fwd", reflect=False):
+        if role == "bwd" and d.tile == 61:
+            if not self.bwd_c8_eligible(d, mod):
+                raise ValueError("tile 61 as a backward-data operator: a 7x7 / stride 1 Conv2d whose output gradient is one 16-byte vector per pixel")
+            pc = self.packed(mod, cin_stride, role="bwd", reflect=reflect, korder=5)
+            d.transposed, d.pad = 0, pc.KH - 1 - pc.pad
+            d.w, d.w_korder = pc.buf.data_ptr(), 0
+            return pc
         if role == "bwd" and korder == 1 and 80 <= d.tile <= 93 and self.bwd_patch_eligible(d, mod):
             pc = self.packed(mod, cin_stride, role="bwd", reflect=reflect, korder=4)
             d.transposed, d.pad = 0, pc.KH - 1 - pc.pad
@@ -1554,6 +1576,8 @@ class Engine:
                     if S == 1 and tiles < 64:
                         continue
                     cands.append((t, S, 0))
+        if mod is not None and role == "bwd" and self.bwd_c8_eligible(d, mod):
+            cands.append((61, 1, 0))          # conv7x7_c8_kernel on the tap-flipped role-swapped weights (full convolution of the head's output gradient)
         if mod is not None and role == "bwd" and self.bwd_patch_eligible(d, mod):
             for t in (80, 81, 82, 83, 84, 85, 86, 87, 90, 91, 92, 93):
                 th, tw, bn = PATCH_CFGS[t]
