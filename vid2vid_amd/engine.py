@@ -20,6 +20,7 @@ import ctypes as C
 import json
 import math
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -1522,7 +1523,7 @@ class Engine:
             return False
         skc = self._sk_counters.get((self._lane, self._sset))
         if skc is None or skc.numel() < tickets.value:
-            if self.plan is not None and not self.record_only:
+            if self.plan is not None and not self.record_only and skc is not None:      # (a first buffer of this lane is safe: nothing recorded points at one yet)
                 raise RuntimeError("split-K ticket buffer must not grow while a plan is recording")
             skc = self._sk_counters[(self._lane, self._sset)] = torch.zeros(max(4096, tickets.value), dtype=torch.int32, device=self.device)
         d.slabs = self.scratch("slabs", (nbytes + 3) // 4).data_ptr()
@@ -1639,6 +1640,9 @@ class Engine:
             ms = time_cfg(t, S, pf, 3)
             if ms is not None:
                 timed.append((ms, (t, S, pf)))
+        if os.environ.get("V2V_TUNE_DEBUG"):
+            print("autotune %s: %d candidates, %d ran; fastest %s; last error: %s" % ((d.cin, d.cout, d.KH, d.stride, d.transposed, d.cout_stride), len(cands), len(timed),
+                  sorted(timed)[:3], lib.v2v_last_error().decode()[:200]), file=sys.stderr)
         if not timed:
             return (0, 1, 0)
         # second pass over the front-runners with more repetitions: single medians of 3 are noisy enough to flip

@@ -143,6 +143,13 @@ class FlowNet2(nn.Module):
         B, _, H, W = im1.shape
         dv = self.div_flow
         x1, x2 = R.normalize(im1, im2, self.rgb_max)
+        # ---- FlowNetSD on x (models.py:143-150): depends on the images only -- recorded on its own plan lane (round 6), it runs beside
+        #      the FlowNetC -> FlowNetS -> FlowNetS chain, whose ~150 small dependent launches leave most of the chip idle ----
+        xsd = R.pack_cat(B, H, W, [(x1, 1.0), (x2, 1.0)])
+        with eng.on_lane(R.LANE_SD):
+            flownetsd_flow = R.up4(R.unpack(self._flownetsd(R, xsd)), False, 1.0 / dv)
+            norm_sd = R.channelnorm(flownetsd_flow)
+            _, diff_sd = R.warp_diff(x1, x2, flownetsd_flow, want_warped=False)
         # ---- FlowNetC on the two streams (models.py:105-106) ----
         flow = R.up4(R.unpack(self._flownetc(R, x1, x2)), True, dv)
         # ---- FlowNetS 1 and 2 on [x, warped img1, flow/div, |diff|] (models.py:108-131) ----
@@ -153,12 +160,8 @@ class FlowNet2(nn.Module):
         flownets2_flow = flow
         norm_s2 = R.channelnorm(flownets2_flow)
         _, diff_s2 = R.warp_diff(x1, x2, flownets2_flow, want_warped=False)
-        # ---- FlowNetSD on x (models.py:143-150) ----
-        xsd = R.pack_cat(B, H, W, [(x1, 1.0), (x2, 1.0)])
-        flownetsd_flow = R.up4(R.unpack(self._flownetsd(R, xsd)), False, 1.0 / dv)
-        norm_sd = R.channelnorm(flownetsd_flow)
-        _, diff_sd = R.warp_diff(x1, x2, flownetsd_flow, want_warped=False)
         # ---- fusion (models.py:155-156) ----
+        eng.join(R.LANE_SD)
         cat3 = R.pack_cat(B, H, W, [(x1, 1.0), (flownetsd_flow, 1.0), (flownets2_flow, 1.0), (norm_sd, 1.0),
                                     (norm_s2, 1.0), (diff_sd, 1.0), (diff_s2, 1.0)])
         return R.unpack(self._fusion(R, cat3))
@@ -169,9 +172,7 @@ class FlowNet2(nn.Module):
         feat = c6
         flow = R.cv(getattr(m, "predict_flow6"), c6)
         for lvl, skip in zip((5, 4, 3, 2), skips):
-            flow_up = R.cv(getattr(m, "upsampled_flow%d_to_%d" % (lvl + 1, lvl)), flow)
-            dec = R.cv(getattr(m, "deconv%d" % lvl), feat)
-            feat = R.cat([skip, dec, flow_up])
+            feat = R.cat_level(skip, getattr(m, "deconv%d" % lvl), feat, getattr(m, "upsampled_flow%d_to_%d" % (lvl + 1, lvl)), flow)
             head_in = R.cv(getattr(m, "inter_conv%d" % lvl), feat) if with_inter else feat
             flow = R.cv(getattr(m, "predict_flow%d" % lvl), head_in)
         return flow
@@ -223,9 +224,9 @@ class FlowNet2(nn.Module):
         c1 = R.cv(m.conv1_1, R.cv(m.conv1, c0))
         c2 = R.cv(m.conv2_1, R.cv(m.conv2, c1))
         flow2 = R.cv(m.predict_flow2, c2)
-        cat1 = R.cat([c1, R.cv(m.deconv1, c2), R.cv(m.upsampled_flow2_to_1, flow2)])
+        cat1 = R.cat_level(c1, m.deconv1, c2, m.upsampled_flow2_to_1, flow2)
         flow1 = R.cv(m.predict_flow1, R.cv(m.inter_conv1, cat1))
-        cat0 = R.cat([c0, R.cv(m.deconv0, cat1), R.cv(m.upsampled_flow1_to_0, flow1)])
+        cat0 = R.cat_level(c0, m.deconv0, cat1, m.upsampled_flow1_to_0, flow1)
         return R.cv(m.predict_flow0, R.cv(m.inter_conv0, cat0))
 
 
@@ -233,19 +234,54 @@ class _Runner:
     """Launch emitters for the FlowNet2 glue (all recordable into a Plan)."""
 
     def __init__(self, eng):
+        import os
         self.eng = eng
+        self.direct_cat = os.environ.get("V2V_FLOWNET_DIRECT_CAT", "1") != "0"
+        self.fork_decoder = os.environ.get("V2V_FLOWNET_FORK", "0") == "1"
 
     def _f32(self, *shape):
         return self.eng.empty_f32(*shape)
 
-    def cv(self, mod, x):
-        """conv / deconv (+ LeakyReLU(0.1) when the container has one), activation fused in the epilogue."""
+    LANE_SD = 1          # FlowNetSD; the refinement ladders fork their deconv branch onto lane (current + 2)
+
+    def cv(self, mod, x, out=None):
+        """conv / deconv (+ LeakyReLU(0.1) when the container has one), activation fused in the epilogue.  out: an Act view
+        (channel range of a concat buffer) the launch writes instead of a tensor of its own."""
         if isinstance(mod, nn.Sequential):
             cmod = mod[0]
             act = (L.ACT_LEAKY, 0.1) if len(mod) > 1 else (L.ACT_NONE, 0.0)
         else:
             cmod, act = mod, (L.ACT_NONE, 0.0)
-        return self.eng.conv_group(x, cmod, L.PAD_ZERO, None, None, act[0], act[1], label="flownet")
+        if out is None:
+            return self.eng.conv_group(x, cmod, L.PAD_ZERO, None, None, act[0], act[1], label="flownet")
+        res, _, _ = self.eng.conv(x, cmod, L.PAD_ZERO, None, L.OUT_ACT_NHWC, act[0], act[1], 1.0, out=out, label="flownet")
+        return res
+
+    def cat_level(self, skip, deconv_mod, feat, up_mod, flow):
+        """One level of a refinement ladder: cat(skip, deconv(feat), upsampled_flow(flow)) (FlowNetS.py:71-90 and the same lines
+        of FlowNetC / FlowNetSD / FlowNetFusion).  Round 6: the deconvolution and the flow up-sampling WRITE their channel ranges
+        of the concat buffer (whole 16-byte vectors: every offset is a multiple of 8 channels) instead of tensors of their own that
+        two copy launches then moved; only the skip tensor -- which the encoder's next layer also reads, at its own stride -- is
+        copied (3 pairs at 512x256: 208 -> 172 launches, 3.40 -> 3.27 ms per pass).  The deconvolution (and that copy) do not depend
+        on the flow head; recorded on a forked plan lane (V2V_FLOWNET_FORK=1) the 18 fork / join edge pairs cost more than the
+        overlap returns (2.93 -> 3.21 ms with FlowNetSD on its lane, profiles/r06_v36_flownet2_ab.txt): off."""
+        eng = self.eng
+        c_dec, c_up = deconv_mod[0].out_channels, up_mod.out_channels
+        N, H, W = skip.N, skip.H, skip.W
+        total = skip.C + c_dec + c_up
+        vec = 8 if eng.dtype == L.BF16 else 4
+        if skip.C % vec != 0 or (skip.C + c_dec) % vec != 0 or not self.direct_cat:
+            return self.cat([skip, self.cv(deconv_mod, feat), self.cv(up_mod, flow)])
+        out = self._zeros_act(N, H, W, total)
+        side = eng._lane + 2 if self.fork_decoder else eng._lane
+        with eng.on_lane(side):
+            check(lib.v2v_concat_channels_nhwc(_ptr(skip.t), skip.Cs, 0, _ptr(out.t), out.Cs, 0, skip.C, N * H * W,
+                                               eng.dtype, _stream()), "concat_channels")
+            eng.label("concat_channels_nhwc")
+            self.cv(deconv_mod, feat, out=Act(out.t[..., skip.C:skip.C + c_dec], c_dec))
+        self.cv(up_mod, flow, out=Act(out.t[..., skip.C + c_dec:], c_up))
+        eng.join(side)
+        return out
 
     def normalize(self, im1, im2, rgb_max):
         B, _, H, W = im1.shape

@@ -25,23 +25,30 @@ class _FlowPlan:
         self.flow = self.conf = None
         # the engine is shared with the generator / discriminators of the same precision: FlowNet2's launches get their own scratch
         # set (split-K slabs, ticket words, statistics) so that the plan may run on its own stream beside them (FlowNet.forward)
-        if not eng.record_only:
-            prev_autotune = eng.autotune
-            eng.autotune = bool(getattr(model.opt, "autotune", True))
-            try:
-                with eng.scratch_set("flownet2"):
-                    self._emit()               # sizes the scratch, picks tile configurations
-            finally:
-                eng.autotune = prev_autotune
-            torch.cuda.synchronize(dev)
-        self.plan = Plan()
-        eng.plan = self.plan
-        n0 = len(eng.conv_log)
+        # Round 6: FlowNetSD beside the FlowNetC -> FlowNetS -> FlowNetS chain, and the deconvolution of every refinement level beside
+        # its flow head, as parallel plan lanes (hipGraph branches; flownet2.FlowNet2.emit).  V2V_FLOWNET_LANES=0: one lane (A/B).
+        prev_lanes = eng.lanes_enabled
+        eng.lanes_enabled = os.environ.get("V2V_FLOWNET_LANES", "1") != "0" and not eng.record_only
         try:
-            with self.plan, eng.scratch_set("flownet2"):
-                self._emit()
+            if not eng.record_only:
+                prev_autotune = eng.autotune
+                eng.autotune = bool(getattr(model.opt, "autotune", True))
+                try:
+                    with eng.scratch_set("flownet2"):
+                        self._emit()               # sizes the scratch (of every lane), picks tile configurations
+                finally:
+                    eng.autotune = prev_autotune
+                torch.cuda.synchronize(dev)
+            self.plan = Plan()
+            eng.plan = self.plan
+            n0 = len(eng.conv_log)
+            try:
+                with self.plan, eng.scratch_set("flownet2"):
+                    self._emit()
+            finally:
+                eng.plan = None
         finally:
-            eng.plan = None
+            eng.lanes_enabled = prev_lanes
         self.conv_flops = sum(c["flops"] for c in eng.conv_log[n0:])     # algorithmic FLOP of one replay (bench roofline)
         self.n_convs = len(eng.conv_log) - n0
         if use_graph and not eng.record_only:
