@@ -561,6 +561,7 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_host = time.perf_counter() - t0                           # the host has issued every launch of the timed chunks (no wait in between)
     barrier()
     elapsed = time.perf_counter() - t0
     peak_alloc = torch.cuda.max_memory_allocated(dev)
@@ -652,7 +653,7 @@ def run_train(args, dev, rank, world, local_rank, emit=True):
                                       n_frames_load, sum(q.numel() for q in modelG.module.parameters()) / 1e6,
                                       sum(q.numel() for q in modelD.module.parameters()) / 1e6),
                        "frames_per_step": n_frames_load, "active_temporal_scales_last_step": int(t_act),
-                       "autotune_s": round(t_tune, 1),
+                       "autotune_s": round(t_tune, 1), "host_issue_ms_per_step": round(t_host / args.steps * 1e3, 2),
                        "train_graph": {"enabled": bool(graphs.enabled), "chunk_kinds": len(graphs.graphs), "capture_s": round(t_capture, 1),
                                        "replays": graphs.replays},
                        "parallelism": ("%d sequence group(s) x (%d generator + %d discriminator ranks): frames of a chunk split over the generator "

@@ -104,7 +104,7 @@ typedef struct v2v_conv_desc {
     int32_t prefetch;       /* 0 = off; P > 0: weight-prefetch helper wave, P K-chunks ahead (see below) */
     void*   slabs;          /* splitk > 1: v2v_conv_splitk_workspace() bytes of scratch              */
     int32_t* sk_counter;    /* splitk > 1: `tickets` ints, zero before the first launch (re-armed in-kernel) */
-    int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major, 2 full-tap chunk-major (transposed), 3 paired-x (below); a korder-4 packing is read as 1 */
+    int32_t w_korder;       /* K order `w` was packed in (v2v_conv_pack_weights): 0 tap-major, 1 channel-chunk-major, 2 full-tap chunk-major (transposed), 3 paired-x (below); a korder-4 packing is read as 1, a korder-5 packing as 0 */
     int32_t ablate;         /* profiling only, results are WRONG when non-zero: 1 = activation tiles from the zero page, 2 = weight tiles from one hot line, 4 = no output stores, 16 = loaders only (no LDS reads / MFMA), 512 = return at once (launch floor), 1024 = no main loop (prologue + epilogue), 2048 = one workgroup per channel tile stays away from the fused-norm barrier (exercises its give-up path: NaN outputs + v2v_device_status bit 0) */
     const void* res0;       /* V2V_OUT_NORM_ACT_NHWC: NULL or a residual [N][OH][OW][cout_stride] (activation dtype) added after the activation */
     const void* res1;       /* second residual, NULL or as res0                                                   */
@@ -183,7 +183,12 @@ int     v2v_conv_pack_weights(const float* w, void* dst, int32_t cin, int32_t ci
  * of dX), packed channel-chunk-major like korder 1 with the taps FLIPPED (matrix tap t = kernel tap 8 - t).  Run it with
  * v2v_conv_desc { transposed 0, KH = KW = 3, stride 1, pad = 2 - p, V2V_PAD_ZERO, w_korder 1 } on tile ids 80..93: p = 1 gives dX on the layer's
  * grid, p = 0 (the layer sat behind a ReflectionPad2d(1)) the gradient of the PADDED input, (H+2) x (W+2), which v2v_reflect_pad_fold folds
- * (the autograd of models/networks.py:571-587).  Tile ids 80..93 accept pad 1 or 2; every other 3x3 patch tile pad 1 only. */
+ * (the autograd of models/networks.py:571-587).  Tile ids 80..93 accept pad 1 or 2; every other 3x3 patch tile pad 1 only.
+ * korder 5 (round 6): the same operator for a square, odd, stride-1 Conv2d of any size, packed TAP-major like korder 0 with the taps flipped
+ * -- what tile id 61 (7x7 over 16-byte pixels) reads for the backward-data of the 7x7 heads (models/networks.py:178-183: dY has 3 | 2 | 1
+ * channels = one 16-byte vector per pixel).  Run it with v2v_conv_desc { transposed 0, KH = KW = 7, stride 1, pad = 6 - p, V2V_PAD_ZERO,
+ * w_korder 0, tile 61, out_mode V2V_OUT_ACT_NHWC }: tile 61 accepts zero padding of 3 ... 6 (OH = H + 2 pad - 6) and, besides planar fp32
+ * and raw fp32 NHWC, plain activation-typed NHWC output (no activation, cout and cout_stride whole 16-byte vectors, no statistics). */
 
 /* Number of statistics rows the launch described by `d` writes: n_classes * m_tiles -- except for the persistent tile ids 140..143 and
  * 114, which keep their sums in registers across the tiles (114: and the four parity classes) a workgroup walks and leave ONE row per

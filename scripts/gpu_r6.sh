@@ -109,7 +109,7 @@ if has trainab; then     # one-stream vs side-stream weight gradients, GEMM-view
     for cfg in ${ABCFGS:-V2V_BWD_PATCH=0 V2V_BWD_PATCH=1}; do
       cfg=$(echo $cfg | tr ',' ' ')
       env $cfg timeout 600 python bench.py --mode train --steps 9 --warmup 3 --no-train-parity $GEO 2>gpurun_out/${TAG}_trainab.err | python -c "
-import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train [$cfg] run $rep:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', 'loss_G', j['config'].get('loss_G'), j['config'].get('loss_D'))"
+import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train [$cfg] run $rep:', j['value'], 'frames/s', j['ms_per_step'], 'ms/chunk', 'host issue', j['config'].get('host_issue_ms_per_step'), 'loss_G', j['config'].get('loss_G'), j['config'].get('loss_D'))"
     done
   done 2>&1 | tee gpurun_out/${TAG}_trainab.txt
   tail -3 gpurun_out/${TAG}_trainab.err | cut -c1-300

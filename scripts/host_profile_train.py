@@ -79,6 +79,12 @@ def step():
 
 for _ in range(3):
     step()                     # one sequence: all temporal scales active by the last chunk
+import gc
+gc.collect(); gc.freeze()
+t0 = time.perf_counter()
+for _ in range(steps):
+    step()
+print("# dry-run host time per chunk (no profiler): %.1f ms, %dx%d, ngf %d" % ((time.perf_counter() - t0) / steps * 1e3, W, H, ngf))
 t0 = time.perf_counter()
 pr = cProfile.Profile()
 pr.enable()
