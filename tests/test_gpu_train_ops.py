@@ -758,6 +758,49 @@ def test_two_optimizers_wait_only_for_their_own_overlapped_step():
         dist.destroy_process_group()
 
 
+def test_discard_stale_grads_follows_train_py_protocol():
+    """optim.FusedAdam(discard_stale_grads): a "generator" conv and a "discriminator" conv stepped the way train.py:130-138 does it
+    (zero_grad G / loss_G.backward through BOTH / step G, then zero_grad D / loss_D.backward on the detached fake / step D).  With the
+    flag the discriminator's weight gradient of loss_G.backward() is not computed (no wgrad launch logged for it after D's first
+    step) -- and the weights of both layers after three iterations are bit-identical to the run without the flag, where that
+    gradient is computed and wiped by D's zero_grad()."""
+    from vid2vid_amd import lib as L
+    from vid2vid_amd import autograd as AG
+    from vid2vid_amd.optim import FusedAdam
+
+    def run(flag):
+        torch.manual_seed(21)
+        eng = _engine("fp32")
+        g = nn.Conv2d(8, 8, 3, padding=1).to(DEV)
+        d = nn.Conv2d(8, 4, 3, padding=1).to(DEV)
+        og, od = FusedAdam(list(g.parameters()), lr=1e-2), FusedAdam(list(d.parameters()), lr=1e-2)
+        og.discard_stale_grads = od.discard_stale_grads = flag
+        x = torch.randn(1, 8, 12, 16, device=DEV)
+        real = torch.randn(1, 8, 12, 16, device=DEV)
+        d_wgrads_in_g_pass = []
+        for it in range(3):
+            fake = AG.conv_group(eng, eng.pack(x), g, L.PAD_ZERO, 1, None, L.ACT_RELU, 0.0, None, None, False, 1.0, "g")
+            pred_fake = AG.conv_group(eng, fake, d, L.PAD_ZERO, 1, None, L.ACT_NONE, 0.0, None, None, False, 1.0, "d")
+            loss_G = (eng.unpack(pred_fake) ** 2).mean()
+            pf = AG.conv_group(eng, fake.detach(), d, L.PAD_ZERO, 1, None, L.ACT_NONE, 0.0, None, None, False, 1.0, "d")
+            pr = AG.conv_group(eng, eng.pack(real), d, L.PAD_ZERO, 1, None, L.ACT_NONE, 0.0, None, None, False, 1.0, "d")
+            loss_D = (eng.unpack(pf) ** 2).mean() + ((eng.unpack(pr) - 1) ** 2).mean()
+            og.zero_grad()
+            n0 = len(eng.conv_log)
+            loss_G.backward()
+            d_wgrads_in_g_pass.append(sum(1 for c in eng.conv_log[n0:] if c.get("kind") == "wgrad" and c["label"].endswith(":d")))
+            og.step()
+            od.zero_grad(); loss_D.backward(); od.step()
+        torch.cuda.synchronize()
+        return g.weight.detach().clone(), d.weight.detach().clone(), d.bias.detach().clone(), d_wgrads_in_g_pass
+
+    gw0, dw0, db0, n_off = run(False)
+    gw1, dw1, db1, n_on = run(True)
+    assert n_off == [1, 1, 1], n_off
+    assert n_on == [1, 0, 0], n_on                            # before D's first step its .grad is still what torch would hold
+    assert torch.equal(gw0, gw1) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", [(1, 5, 16, 24), (2, 16, 17, 23), (1, 64, 8, 6), (1, 3, 2, 2)])
 def test_maxpool2_forward_backward(shape, prec):

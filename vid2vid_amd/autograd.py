@@ -25,6 +25,13 @@ from .engine import Act, pad_channels, _ptr, _stream, _TORCH_DTYPE
 from .parallel import note_use, note_done
 
 
+def _live(p):
+    """False when a gradient written to this parameter now would be wiped unread: its FusedAdam (discard_stale_grads) has stepped
+    and not been re-armed by zero_grad() -- the discriminators' parameters during loss_G.backward() (train.py:130-138)."""
+    flat = getattr(p, "_v2v_flat", None)
+    return True if flat is None else flat.live
+
+
 def _grad_ptr(p):
     """Pointer of the parameter's gradient buffer (allocated zeroed on first use)."""
     if p is None or not p.requires_grad:
@@ -136,7 +143,7 @@ class ConvFn(torch.autograd.Function):
             g = torch.empty((N, OH, OW, cs_g), dtype=eng.tdtype, device=eng.device)
             rows = lib.v2v_bn_backward_rows(P)
             ws = eng.scratch("bn_bwd_ws", rows * 2 * cout + 2 * cout)
-            affine = getattr(norm, "affine", False)
+            affine = getattr(norm, "affine", False) and _live(norm.weight)
             check(lib.v2v_bn_backward(_ptr(dy), _ptr(raw), (cout + 3) // 4 * 4, _ptr(ss), _ptr(g), cs_g,
                                       _grad_ptr(norm.weight) if affine else None,
                                       _grad_ptr(norm.bias) if affine else None, 1, _ptr(ws),
@@ -156,15 +163,16 @@ class ConvFn(torch.autograd.Function):
         # arithmetic (dRaw is mean-free by construction) and rounding noise of ~1e-7 x |dRaw| in the reference's autograd.  The
         # exact value is accumulated here (nothing is launched); V2V_NORM_BIAS_GRAD=1 restores the summed noise (one more
         # reduction launch per layer: 197 of the 434 channel-sum / norm-backward reductions of a 512x256 training chunk).
+        live = _live(weight)                                  # (a layer's bias lives in the same flat buffer as its weight)
         if bias is not None and bias.requires_grad and norm is not None and not _NORM_BIAS_GRAD:
             _grad_ptr(bias)                                   # += 0: only makes sure the (zeroed) buffer exists
-        elif bias is not None and bias.requires_grad:
+        elif bias is not None and bias.requires_grad and live:
             ws = eng.scratch("chsum_ws", lib.v2v_bn_backward_rows(P) * 2 * cout)
             check(lib.v2v_channel_sum(_ptr(g), _grad_ptr(bias), 1, _ptr(ws), P, cout, cs_gs, dt, st),
                   "channel_sum " + cfg.label)
         # ---- weight ----
         transposed = isinstance(conv, nn.ConvTranspose2d)
-        if weight.requires_grad and not _SKIP_WGRAD:
+        if weight.requires_grad and not _SKIP_WGRAD and live:
             d = WgradDesc()
             if transposed:
                 d.p, d.q = x_t.data_ptr(), g.data_ptr()

@@ -7,6 +7,7 @@ re-broadcasts all parameters per call; here there is one process per GPU with pe
 replicas, wrapped in `RankModel`, which only exposes `.module` (the attribute train.py and
 create_optimizer reach through) and all-reduces gradients over RCCL in `parallel.py`.
 """
+import os
 import torch
 import torch.nn as nn
 
@@ -87,4 +88,12 @@ def create_optimizer(opt, models):
     optimizer_G = modelG.module.optimizer_G
     optimizer_D = modelD.module.optimizer_D
     optimizer_D_T = [getattr(modelD.module, "optimizer_D_T" + str(s)) for s in range(opt.n_scales_temporal)]
+    # the caller is train.py's loop: zero_grad() -> backward() -> step() per optimizer.  The discriminators' weight gradients of
+    # loss_G.backward() are wiped by optimizer_D.zero_grad() before anything reads them; V2V_DISCARD_STALE_GRADS=1 does not compute
+    # them (optim.FusedAdam.discard_stale_grads; bit-identical weights, tests/test_gpu_train_ops.py).  Measured: 37.7 / 38.4 vs
+    # 38.4 / 37.9 frames trained/s (profiles/r06_v40_trainab.txt) -- nothing, so torch's exact semantics stay the default.
+    if os.environ.get("V2V_DISCARD_STALE_GRADS", "0") == "1":
+        for o in [optimizer_G, optimizer_D] + optimizer_D_T:
+            if hasattr(o, "discard_stale_grads"):
+                o.discard_stale_grads = True
     return modelG, modelD, flowNet, optimizer_G, optimizer_D, optimizer_D_T

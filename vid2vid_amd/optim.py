@@ -41,6 +41,9 @@ class FlatBuffers:
         # update counter of THIS buffer: the fused optimizer writes flat_param from a HIP kernel (invisible to torch's
         # tensor version counters), so packed weight copies (engine.PackedConv) watch this box through the parameter
         self.epoch = [0]
+        # gradients written NOW will be used by a step: False only between step() and the next zero_grad() of a FusedAdam with
+        # `discard_stale_grads` (the backward kernels then leave this buffer's gradients out: autograd.ConvFn.backward)
+        self.live = True
         self.ready = None                            # parallel.BucketReady once a GradSync is attached (sync_optimizers)
         # V2V_WEIGHTS_CL=1: 4-D (convolution) weights live CHANNELS-LAST in the flat buffers: physically [d0][KH][KW][d1],
         # logically still [d0][d1][KH][KW] (a permuted view, as torch.channels_last tensors are).  That is the column order the
@@ -90,6 +93,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.capturable = False
         self._dev_state = None
         self._dev_lr = None
+        # train.py's protocol is zero_grad() -> backward() -> step() per optimizer (train.py:130-138), and loss_G.backward() also
+        # runs through the discriminators: their weight gradients of THAT pass are wiped by optimizer_D.zero_grad() before anything
+        # reads them (in the reference too -- torch computes and discards them).  With this flag (models.create_optimizer sets it
+        # on the three training optimizers) gradients of this optimizer's parameters are produced only between its zero_grad() and
+        # its step() -- and before its first step, when .grad is still what torch would hold.  Off: torch's semantics exactly
+        # (gradients accumulate whenever a backward pass reaches the parameter).
+        self.discard_stale_grads = False
 
     def rebuild(self, params, lr=None, betas=None):
         """Re-home a (larger) parameter list in fresh flat buffers IN PLACE: same optimizer object, same grad_sync,
@@ -174,6 +184,7 @@ class FusedAdam(torch.optim.Optimizer):
         if not g.is_cuda and not lib.v2v_get_dry_run():
             raise RuntimeError("FusedAdam runs on the MI355X only")
         check(lib.v2v_memset_zero(C.c_void_p(g.data_ptr()), g.numel() * 4, stream), "memset_zero")
+        self.flat.live = True
         if self.flat.ready is not None:
             self.flat.ready.arm()                    # the backward pass that follows writes the gradients of THIS step
 
@@ -223,6 +234,8 @@ class FusedAdam(torch.optim.Optimizer):
         else:
             adam(gs.all_reduce(f.flat_grad) if gs is not None else 1.0, None)
         f.epoch[0] += 1                                      # packed copies of THESE parameters are now stale
+        if self.discard_stale_grads:
+            f.live = False                                   # until the next zero_grad(): gradients written in between would be wiped unread
         if f.flat_param.is_cuda and not overlapped:
             from .engine import repack_after_step
             repack_after_step(f)                             # ... and are re-packed beside the next backward pass (side stream)
