@@ -94,3 +94,26 @@ for (R, Cc, N, OH, OW, splits) in NINE:
         line += " | nine-tap x%d splits %.3f ms (%.0f TFLOP/s, diff %.1e)" % (sp, ms, flops / ms / 1e9, err)
     os.environ.pop("V2V_WGRAD3_SPLITS")
     print(line)
+
+# ---- round 6: the kernel-row 7x7 kernel (conv_wgrad_krow_bf16_kernel + its reduce) beside the GEMM view, same operands ----
+KROW = [(128, 108, 1, 256, 512, (0, 4, 8, 16)), (64, 108, 1, 256, 512, (0, 8, 16)), (128, 6, 1, 256, 512, (0, 8)), (3, 128, 1, 256, 512, (0, 8)),
+        (64, 108, 1, 512, 1024, (0, 16)), (32, 108, 1, 1024, 2048, (0, 16, 32)), (3, 32, 1, 1024, 2048, (0, 16)), (32, 6, 1, 1024, 2048, (0, 16))]
+if os.environ.get("WGRAD_BENCH_KROW", "1") != "0":
+    for (R, Cc, N, OH, OW, splits) in KROW:
+        Rs, Cs = (R + 7) // 8 * 8, (Cc + 7) // 8 * 8
+        dy = torch.zeros(N, OH, OW, Rs, device=dev); dy[..., :R] = torch.randn(N, OH, OW, R, device=dev)
+        x = torch.zeros(N, OH, OW, Cs, device=dev); x[..., :Cc] = torch.randn(N, OH, OW, Cc, device=dev)
+        dy, x = dy.bfloat16(), x.bfloat16()
+        flops = 2.0 * N * OH * OW * R * Cc * 49
+        os.environ["V2V_WGRAD_KROW"] = "0"
+        ref, ms0 = run(dy, x, 7, 1, 3, L.PAD_REFLECT, L.BF16, reps=7)
+        os.environ["V2V_WGRAD_KROW"] = "1"
+        line = "wgrad 7x7 R=%4d C=%4d %dx%dx%d: GEMM view + reduce %.3f ms (%.0f TFLOP/s)" % (R, Cc, N, OH, OW, ms0, flops / ms0 / 1e9)
+        for sp in splits:
+            if sp:
+                os.environ["V2V_WGRAD_KROW_SPLITS"] = str(sp)
+            got, ms = run(dy, x, 7, 1, 3, L.PAD_REFLECT, L.BF16, reps=7)
+            err = (got - ref).abs().max().item() / (ref.pow(2).mean().sqrt().item() + 1e-12)
+            line += " | kernel row %s %.3f ms (%.0f TFLOP/s, diff %.1e)" % ("x%d" % sp if sp else "auto", ms, flops / ms / 1e9, err)
+            os.environ.pop("V2V_WGRAD_KROW_SPLITS", None)
+        print(line)

@@ -179,6 +179,80 @@ def test_wgrad_nine_tap_kernel(case, monkeypatch):
     assert torch.equal(g_again, g_new)                                     # deterministic (in-order splits), tickets re-armed
 
 
+WGRAD_KROW_CASES = [
+    # rows (cout), cols (cin), H, W, N, mode, forced splits (0 = the library's choice), channels-last gradient
+    (128, 108, 64, 128, 1, "reflect", 0, False),      # the label stems (108 one-hot channels -> ngf), library's split count
+    (32, 108, 20, 70, 2, "reflect", 3, False),        # half-empty row tile (the 2048x1024 scale's stems), ragged width, splits crossing the image boundary
+    (3, 32, 24, 64, 1, "reflect", 2, False),          # a head: 3 gradient rows
+    (64, 6, 9, 33, 1, "zero", 1, False),              # previous-frame stem (6 channels), zero padding, one partial segment, unsplit
+    (96, 72, 8, 130, 1, "zero", 2, True),             # channels-last gradient, three segments, 4-row splits
+    (16, 40, 7, 16, 3, "reflect", 5, False),          # images of 7 rows (reflect reaches 3 rows back), batch 3
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_KROW_CASES)
+def test_wgrad_kernel_row_7x7(case, monkeypatch):
+    """conv_wgrad_krow_bf16_kernel (round 6; 7x7 / stride 1 / pad 3: the seven taps of one kernel row per workgroup, K splits parked
+    in slabs, wgrad_krow_reduce_kernel sums them in split order and scatters into .grad) against torch's weight gradient of the
+    same bf16-rounded operands (fp64) and against the GEMM-view kernel it replaces (V2V_WGRAD_KROW=0): overwrite and accumulate,
+    both gradient layouts, reflect and zero padding, ragged tiles / widths, batches, splits crossing image boundaries, repeat
+    launches bit-identical."""
+    import ctypes as C
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, WgradDesc, check
+    R, Cc, H, W, N, mode, splits, cl = case
+    torch.manual_seed(R + Cc + W)
+    Rs, Cs = (R + 7) // 8 * 8, (Cc + 7) // 8 * 8
+    dy = torch.zeros(N, H, W, Rs, device=DEV); dy[..., :R] = torch.randn(N, H, W, R, device=DEV)
+    x = torch.zeros(N, H, W, Cs, device=DEV); x[..., :Cc] = torch.randn(N, H, W, Cc, device=DEV)
+    dyb, xb = dy.bfloat16(), x.bfloat16()
+    zero = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(grad, accumulate):
+        d = WgradDesc()
+        d.p, d.q = dyb.data_ptr(), xb.data_ptr()
+        d.N, d.OH, d.OW, d.QH, d.QW = N, H, W, H, W
+        d.rows, d.cols, d.p_stride, d.q_stride = R, Cc, Rs, Cs
+        d.KH = d.KW = 7
+        d.stride, d.pad, d.pad_mode = 1, 3, L.PAD_REFLECT if mode == "reflect" else L.PAD_ZERO
+        d.dtype, d.accumulate = L.BF16, (1 if accumulate else 0) + (2 if cl else 0)
+        d.grad, d.zero_page = grad.data_ptr(), zero.data_ptr()
+        nbytes = lib.v2v_conv_wgrad_workspace(C.byref(d))
+        assert nbytes > 0
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=DEV)
+        d.workspace = ws.data_ptr()
+        check(lib.v2v_conv_wgrad(C.byref(d), st), "wgrad")
+        torch.cuda.synchronize()
+
+    shape = (R, 7, 7, Cc) if cl else (R, Cc, 7, 7)
+    logical = (lambda g: g.permute(0, 3, 1, 2)) if cl else (lambda g: g)
+    xr = xb[..., :Cc].float().permute(0, 3, 1, 2).contiguous()
+    dyr = dyb[..., :R].float().permute(0, 3, 1, 2).contiguous()
+    xp = F.pad(xr, (3, 3, 3, 3), mode="reflect") if mode == "reflect" else F.pad(xr, (3, 3, 3, 3))
+    ref = torch.nn.grad.conv2d_weight(xp.double(), (R, Cc, 7, 7), dyr.double()).float().cpu()
+    if splits:
+        monkeypatch.setenv("V2V_WGRAD_KROW_SPLITS", str(splits))
+    g_new = torch.full(shape, 7.0, device=DEV)                             # overwrite mode must not read the buffer
+    run(g_new, False)
+    monkeypatch.setenv("V2V_WGRAD_KROW", "0")
+    g_old = torch.zeros(shape, device=DEV)
+    run(g_old, False)
+    monkeypatch.setenv("V2V_WGRAD_KROW", "1")
+    rms = ref.pow(2).mean().sqrt().item()
+    e_ref = (logical(g_new).cpu() - ref).abs().max().item() / rms
+    e_old = (g_new - g_old).abs().max().item() / rms
+    print("kernel-row 7x7 wgrad %s: vs torch %.2e, vs the GEMM-view kernel %.2e (of the gradient's rms)" % (str(case), e_ref, e_old))
+    assert e_ref < 2e-5 and e_old < 2e-5
+    base = torch.randn(shape, device=DEV)
+    g_acc = base.clone()
+    run(g_acc, True)
+    assert (g_acc - base - g_new).abs().max().item() / rms < 1e-6
+    g_again = torch.empty(shape, device=DEV)
+    run(g_again, False)
+    assert torch.equal(g_again, g_new)
+
+
 CONVT_CASES = [
     # cin, cout, k, pad, out_pad, H, W, N
     (32, 16, 3, 1, 1, 12, 20, 2),      # generator up path (networks.py:176)

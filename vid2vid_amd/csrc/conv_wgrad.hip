@@ -729,6 +729,232 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_bf16_kernel(const Wgrad3Arg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: weight gradient of the 7x7 / stride 1 stems and heads with ONE KERNEL ROW of taps per workgroup (bf16).
+//
+// The GEMM view runs these layers at 15 % of the matrix peak (512x256: 458 us for the 108 -> 128 label stem) down to 217 TFLOP/s
+// at 2048x1024 (6.6 ms per launch: 12 % of that training chunk's kernel time, profiles/r06_v14_train_hires_by_grid.txt): every
+// 128-column block (2.6 taps) is a workgroup of its own, so X goes through L2 43 times.  The nine-tap kernel's scheme with the
+// 49 taps split by kernel row: a workgroup owns 64 gradient rows x 64 columns x the SEVEN taps of kernel row ky (4 waves x 7
+// MFMA tiles = 112 accumulator registers) and walks its K range image row by image row in 64-pixel segments -- per step one dY
+// row segment [64 px][64 ch] and the ONE X row it meets at this ky, [70 px][64 ch] (y + ky - 3, reflect / zero resolved at
+// load time), enter LDS by LDS-DMA and feed 28 MFMAs per wave; the seven horizontal shifts are row offsets of the LDS address.
+// 224 FLOP per byte of L2 -> LDS traffic against the GEMM view's 64; X passes L2 seven times (once per ky).
+//
+// Every workgroup parks its accumulators in a slab [split][ky][tile][wave][fragment order] (16-byte stores) and
+// wgrad_krow_reduce_kernel sums the K splits in split order and scatters into .grad: deterministic, one owner per element.
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradKrowArgs {
+    const char* P; const char* Q; const char* zero_page;
+    float* slab;
+    int N, H, W;            // pixel grid of P and Q (same size: stride 1, pad = 3)
+    int PCs, QCs;           // channel strides (elements)
+    int reflect, pad;
+    int rows_per_split, splits, n_tiles, tiles;
+};
+
+template <int K16, int NT, int TH> __device__ __forceinline__ void wgk_issue_a(Wg3Frag& a, Wg3Frag (&b)[NT], unsigned pa, const unsigned (&qb)[NT]) {
+    wg3_read<K16 * 2048>(a.h[0], pa);
+    wg3_read<K16 * 2048 + 512>(a.h[1], pa);
+#pragma unroll
+    for (int t = 0; t < TH; ++t) {
+        wg3_read<K16 * 2048>(b[t].h[0], qb[t]);
+        wg3_read<K16 * 2048 + 512>(b[t].h[1], qb[t]);
+    }
+}
+template <int K16, int NT, int TH> __device__ __forceinline__ void wgk_issue_b(Wg3Frag (&b)[NT], const unsigned (&qb)[NT]) {
+#pragma unroll
+    for (int t = TH; t < NT; ++t) {
+        wg3_read<K16 * 2048>(b[t].h[0], qb[t]);
+        wg3_read<K16 * 2048 + 512>(b[t].h[1], qb[t]);
+    }
+}
+// at most N LDS reads outstanding; every fragment register is tied behind the wait (volatile asm statements keep their order)
+template <int N, int NT> __device__ __forceinline__ void wgk_wait(Wg3Frag& a, Wg3Frag (&b)[NT]) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.h[0]), "+v"(a.h[1]) : "n"(N));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(b[t].h[0]), "+v"(b[t].h[1]));
+}
+template <int T0, int T1, int NT> __device__ __forceinline__ void wgk_mma(f32x16 (&acc)[NT], const Wg3Frag& a, const Wg3Frag (&b)[NT]) {
+#pragma unroll
+    for (int t = T0; t < T1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b[t].v, acc[t], 0, 0, 0);
+}
+
+template <int DP, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_krow_bf16_kernel(const WgradKrowArgs p) {
+    constexpr int XS = 64;                                   // pixels of a dY row segment
+    constexpr int QPX = 72;                                  // pixel slots of an X row (XS + NT - 1 used), 9 LDS-DMA instructions
+    constexpr int NS = DP + 1;                               // ring depth of both operands
+    constexpr int QSLOT = QPX * 128, PSLOT = XS * 128;
+    constexpr int QBASE = NS * PSLOT;
+    constexpr int TH = 3;                                    // taps read with the A fragment (2 + 2 TH reads), the rest behind them
+    static_assert(XS + NT - 1 <= QPX && 2 * (NT - TH) <= 15 && 2 + 2 * TH <= 15, "fragment reads of a half fit the LDS counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int split = blockIdx.x / p.tiles, tile = blockIdx.x - split * p.tiles;
+    const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
+    const int ky = blockIdx.y;
+    const char* const zp = p.zero_page;
+    const int H = p.H, W = p.W;
+
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    const int l_chunk = l_slot ^ ((((l_row >> 1) & 1)) << 2);
+    const int p_ch = mt * 64 + l_chunk * 8, q_ch = nt * 64 + l_chunk * 8;
+    const bool p_chok = p_ch < p.PCs, q_chok = q_ch < p.QCs;
+
+    const int hi = lane >> 5;
+    const int g16 = (lane >> 4) & 1, j16 = lane & 15;
+    const int frow = 8 * hi + (j16 >> 2);
+    const int ca = wm * 32 + 16 * g16 + 4 * (j16 & 3), cb = wn * 32 + 16 * g16 + 4 * (j16 & 3);
+    const int a_off = frow * 128 + ((((ca >> 3) ^ (((frow >> 1) & 1) << 2))) << 4) + ((ca & 7) << 1);
+    int b_off[NT];
+#pragma unroll
+    for (int kx = 0; kx < NT; ++kx) {
+        const int r0 = frow + kx;
+        b_off[kx] = r0 * 128 + ((((cb >> 3) ^ (((r0 >> 1) & 1) << 2))) << 4) + ((cb & 7) << 1);
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int g_beg = split * p.rows_per_split;
+    const int g_end = min(g_beg + p.rows_per_split, p.N * H);
+    const int nseg = (W + XS - 1) / XS;
+
+    for (int n = g_beg / H; n * H < g_end; ++n) {
+        const int ya = max(g_beg - n * H, 0), yb = min(g_end - n * H, H);
+        const int T = yb - ya;
+        if (T <= 0) continue;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int xs = sg * XS;
+            const int nk16 = min(XS / 16, (W - xs + 15) >> 4);
+            // stage j (0 .. T-1) = dY row ya+j into P slot j % NS and X row ya+j+ky-pad (padding resolved here) into Q slot j % NS
+            int issued = 0;
+            auto issue = [&]() {
+                const int j = issued;
+                char* const pb = smem + (j % NS) * PSLOT;
+                char* const qb = smem + QBASE + (j % NS) * QSLOT;
+                const int yp = ya + j;
+                const char* const prow = p.P + ((long long)(n * H + yp) * W) * p.PCs * 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int q = wid + 4 * i;
+                    const int x = xs + q * 8 + l_row;
+                    const bool ok = p_chok && x < W;
+                    wg_glds16(ok ? prow + ((long long)x * p.PCs + p_ch) * 2 : zp, pb + q * 1024);
+                }
+                int yq = yp + ky - p.pad;
+                bool qrow_ok = true;
+                if (p.reflect) { yq = yq < 0 ? -yq : yq; yq = yq >= H ? 2 * H - 2 - yq : yq; }
+                else qrow_ok = (unsigned)yq < (unsigned)H;
+                yq = min(max(yq, 0), H - 1);
+                const char* const qrow = p.Q + ((long long)(n * H + yq) * W) * p.QCs * 2;
+                auto qload = [&](int q) {
+                    const int px = q * 8 + l_row;                          // pixel slot: image x = xs - pad + px
+                    int x = xs - p.pad + px;
+                    bool ok = qrow_ok && q_chok && px < XS + NT - 1;
+                    if (p.reflect) { x = x < 0 ? -x : x; x = x >= W ? 2 * W - 2 - x : x; }
+                    ok = ok && (unsigned)x < (unsigned)W;
+                    x = min(max(x, 0), W - 1);
+                    wg_glds16(ok ? qrow + ((long long)x * p.QCs + q_ch) * 2 : zp, qb + q * 1024);
+                };
+                qload(wid); qload(wid + 4);
+                if (wid == 0) qload(8);
+                ++issued;
+            };
+            const int nstages = T;
+            for (int j = 0; j < DP && j < nstages; ++j) issue();
+            auto run_steps = [&](auto NKc) {
+            constexpr int NK = decltype(NKc)::value;
+            for (int t = 0; t < T; ++t) {
+                // stage t must have landed; issued so far: min(t+DP, nstages) stages; a wave's loads complete in order
+                if (t + DP <= nstages) {
+                    if (wid == 0) wg_wait_vmcnt<5 * (DP - 1)>(); else wg_wait_vmcnt<4 * (DP - 1)>();
+                } else wg_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                // stage t+DP overwrites the slots of stage t-1 (last read in step t-1): every wave is past them
+                if (t + DP < nstages) issue();
+                const unsigned sb = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)smem;
+                const unsigned pa = sb + (t % NS) * PSLOT + a_off;
+                const unsigned q0 = sb + QBASE + (t % NS) * QSLOT;
+                unsigned qb[NT];
+#pragma unroll
+                for (int kx = 0; kx < NT; ++kx) qb[kx] = q0 + b_off[kx];
+                Wg3Frag fa[2], fb[2][NT];
+                constexpr int NA = 2 + 2 * TH;
+                wgk_issue_a<0, NT, TH>(fa[0], fb[0], pa, qb); wgk_issue_b<0, NT, TH>(fb[0], qb);
+                wgk_issue_a<1, NT, TH>(fa[1], fb[1], pa, qb); wgk_wait<NA, NT>(fa[0], fb[0]); wgk_mma<0, TH, NT>(acc, fa[0], fb[0]);
+                wgk_issue_b<1, NT, TH>(fb[1], qb);                                            wgk_mma<TH, NT, NT>(acc, fa[0], fb[0]);
+                if constexpr (NK == 4) {
+                    wgk_issue_a<2, NT, TH>(fa[0], fb[0], pa, qb); wgk_wait<NA, NT>(fa[1], fb[1]); wgk_mma<0, TH, NT>(acc, fa[1], fb[1]);
+                    wgk_issue_b<2, NT, TH>(fb[0], qb);                                            wgk_mma<TH, NT, NT>(acc, fa[1], fb[1]);
+                    wgk_issue_a<3, NT, TH>(fa[1], fb[1], pa, qb); wgk_wait<NA, NT>(fa[0], fb[0]); wgk_mma<0, TH, NT>(acc, fa[0], fb[0]);
+                    wgk_issue_b<3, NT, TH>(fb[1], qb);                                            wgk_mma<TH, NT, NT>(acc, fa[0], fb[0]);
+                }
+                wgk_wait<0, NT>(fa[1], fb[1]); wgk_mma<0, NT, NT>(acc, fa[1], fb[1]);
+            }
+            };
+            if (nk16 > 2) run_steps(std::integral_constant<int, 4>{}); else run_steps(std::integral_constant<int, 2>{});
+            __builtin_amdgcn_s_barrier();                       // the next run's prologue refills slots the last step may still be reading
+        }
+    }
+    // ---- park the accumulators: slab[((split * NT + ky) * tiles + tile) * 4 + wave][(t * 4 + q) * 64 + lane] (f32x4) ----
+    f32x4* const mine = reinterpret_cast<f32x4*>(p.slab) + ((((long long)split * NT + ky) * p.tiles + tile) * 4 + wid) * (NT * 4 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+            mine[(t * 4 + q) * 64] = v;
+        }
+}
+
+struct WgradKrowReduceArgs {
+    const float* slab; float* grad;
+    int splits, R, C, NT, tiles, n_tiles, accumulate, grad_cl;
+};
+
+// one thread per (row, col, ky): sums the K splits in split order for its NT taps and writes NT consecutive gradient values
+// ([R][C][ky][kx]; channels-last [R][ky][kx][C]: stride C).  Fragment order of the slab: row-in-32 = (r & 3) + 8 (r >> 2) + 4 hi,
+// r = 4 q + e (register r of tap t = component e of vector (t * 4 + q)), lane = col-in-32 + 32 hi.
+__global__ __launch_bounds__(256) void wgrad_krow_reduce_kernel(const WgradKrowReduceArgs a) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.R * a.C * a.NT;
+    if (e >= total) return;
+    const int ky = (int)(e % a.NT);
+    const long long rc = e / a.NT;
+    const int col = (int)(rc % a.C), row = (int)(rc / a.C);
+    const int mt = row >> 6, wm = (row >> 5) & 1, rr = row & 31;
+    const int nt = col >> 6, wn = (col >> 5) & 1, lr = col & 31;
+    const int hi = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
+    const int q = r >> 2, comp = r & 3, lane = lr + 32 * hi, wave = wm * 2 + wn, tile = mt * a.n_tiles + nt;
+    float s[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) s[t] = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) {
+        const float* src = a.slab + ((((((long long)sp * a.NT + ky) * a.tiles + tile) * 4 + wave) * (a.NT * 4 * 64)) + q * 64 + lane) * 4 + comp;
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+            if (t < a.NT) s[t] += src[(long long)t * 4 * 64 * 4];
+    }
+    if (a.grad_cl) {
+        float* g = a.grad + ((long long)row * a.NT * a.NT + (long long)ky * a.NT) * a.C + col;
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+            if (t < a.NT) g[(long long)t * a.C] = a.accumulate ? g[(long long)t * a.C] + s[t] : s[t];
+    } else {
+        float* g = a.grad + ((long long)row * a.C + col) * a.NT * a.NT + ky * a.NT;
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+            if (t < a.NT) g[t] = a.accumulate ? g[t] + s[t] : s[t];
+    }
+}
+
 struct WgradReduceArgs {
     float* slab; float* grad;
     int splits, R, C, KHW, QCs, Rp, Cp, accumulate;
@@ -858,6 +1084,44 @@ static int wgrad3_splits(const v2v_wgrad_desc* d) {
     if (forced <= 0 && tiles * s < 128) return 0;
     return (int)s;
 }
+
+// kernel-row kernel (7x7 / stride 1 / same size): K splits so that tiles x 7 x splits covers the chip about twice; 0 = not this layer.
+// V2V_WGRAD_KROW=0 switches it off (A/B), V2V_WGRAD_KROW_SPLITS=n forces n.
+static int wgrad_krow_splits(const v2v_wgrad_desc* d) {
+    const char* const e_on = getenv("V2V_WGRAD_KROW");
+    const char* const e_sp = getenv("V2V_WGRAD_KROW_SPLITS");
+    const int on = (e_on && e_on[0] == '0') ? 0 : 1, forced = e_sp ? atoi(e_sp) : 0;
+    if (!on || d->dtype != V2V_BF16 || legacy_bf16()) return 0;
+    if (d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->OH != d->QH || d->OW != d->QW) return 0;
+    if (d->QH < 4 || d->QW < 4) return 0;
+    // the 6-channel previous-frame stems leave 58 of a tile's 64 columns empty: 0.24 ms against 0.084 for the GEMM view at 512x256
+    // (profiles/r06_v41_wgrad_krow_bench.txt); from 32 columns up (the heads: 3 gradient rows x 32 ... 128 columns) the kernel row wins
+    if (d->cols < 32 && forced <= 0) return 0;
+    const long long tiles = ceil_div(d->rows, 64) * ceil_div(d->cols, 64);
+    const long long grows = (long long)d->N * d->OH;
+    // one workgroup per compute unit (the kernel holds a whole CU's registers): 128 x 108 at 512x256 0.45 / 0.27 / 0.29 / 0.31 ms on
+    // 4 / 8 / 16 / 19 splits = 112 / 224 / 448 / 532 workgroups
+    long long s = forced > 0 ? forced : 256 / (tiles * 7);
+    if (s > grows / 4) s = grows / 4;                            // >= 4 image rows per split
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+struct WgradKrowOp : Op {
+    WgradKrowArgs a; WgradKrowReduceArgs r;
+    int launch(hipStream_t s) override {
+        auto kern = conv_wgrad_krow_bf16_kernel<2, 7>;
+        const size_t lds = 3 * 8192 + 3 * 9216;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.splits), 7), dim3(256), lds, s, a);
+        int rc = check_launch();
+        if (rc != 0) return rc;
+        const long long total = (long long)r.R * r.C * r.NT;
+        hipLaunchKernelGGL(wgrad_krow_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, r);
+        return check_launch();
+    }
+    const char* name() const override { return "conv_wgrad_krow"; }
+};
 
 struct Wgrad3Op : Op {
     Wgrad3Args a;
@@ -997,7 +1261,11 @@ extern "C" int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d) {
     const int64_t gemm_view = (int64_t)sp * mt * wgrad_bm(d) * nt * WG_BN * (int64_t)sizeof(float);
     // nine-tap kernel with K splits: [split][tile][4 waves][36 x 64 lanes x 16 bytes]  (it may still fall back to the GEMM view)
     const int64_t nine_tap = s3 > 1 ? (int64_t)s3 * ceil_div(d->rows, 64) * ceil_div(d->cols, 64) * 4 * 36 * 64 * 16 : 0;
-    return gemm_view > nine_tap ? gemm_view : nine_tap;
+    // kernel-row kernel (7x7): [split][ky][tile][4 waves][28 x 64 lanes x 16 bytes]
+    const int sk = wgrad_krow_splits(d);
+    const int64_t krow = sk > 0 ? (int64_t)sk * 7 * ceil_div(d->rows, 64) * ceil_div(d->cols, 64) * 4 * 28 * 64 * 16 : 0;
+    const int64_t m = gemm_view > nine_tap ? gemm_view : nine_tap;
+    return m > krow ? m : krow;
 }
 
 extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
@@ -1021,6 +1289,22 @@ extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
             a.accumulate = d->accumulate & 1; a.grad_cl = (d->accumulate >> 1) & 1;
             return submit(std::move(op3), stream);
         }
+    }
+    if (const int sk = wgrad_krow_splits(d)) {
+        auto opk = std::make_unique<WgradKrowOp>();
+        WgradKrowArgs& a = opk->a;
+        memset(&a, 0, sizeof(a));
+        a.P = (const char*)d->p; a.Q = (const char*)d->q; a.zero_page = (const char*)d->zero_page;
+        a.slab = d->workspace;
+        a.N = d->N; a.H = d->OH; a.W = d->OW; a.PCs = d->p_stride; a.QCs = d->q_stride;
+        a.reflect = d->pad_mode == V2V_PAD_REFLECT ? 1 : 0; a.pad = d->pad;
+        a.rows_per_split = (int)ceil_div((long long)d->N * d->OH, sk);
+        a.splits = (int)ceil_div((long long)d->N * d->OH, a.rows_per_split);
+        a.n_tiles = (int)ceil_div(d->cols, 64); a.tiles = (int)ceil_div(d->rows, 64) * a.n_tiles;
+        WgradKrowReduceArgs& r = opk->r;
+        r.slab = d->workspace; r.grad = d->grad; r.splits = a.splits; r.R = d->rows; r.C = d->cols; r.NT = 7;
+        r.tiles = a.tiles; r.n_tiles = a.n_tiles; r.accumulate = d->accumulate & 1; r.grad_cl = (d->accumulate >> 1) & 1;
+        return submit(std::move(opk), stream);
     }
     auto op = std::make_unique<WgradOp>();
     int mt, nt, sp, kp;
