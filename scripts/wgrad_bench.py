@@ -117,3 +117,23 @@ if os.environ.get("WGRAD_BENCH_KROW", "1") != "0":
             line += " | kernel row %s %.3f ms (%.0f TFLOP/s, diff %.1e)" % ("x%d" % sp if sp else "auto", ms, flops / ms / 1e9, err)
             os.environ.pop("V2V_WGRAD_KROW_SPLITS", None)
         print(line)
+
+# ---- the same kernel with three taps per workgroup on the 3x3 layers the nine-tap kernel leaves to the GEMM view ----
+KROW3 = [(128, 128, 1, 256, 512), (64, 64, 1, 256, 512), (64, 64, 1, 512, 1024), (32, 32, 1, 1024, 2048), (64, 32, 1, 1024, 2048), (256, 256, 1, 64, 128)]
+if os.environ.get("WGRAD_BENCH_KROW", "1") != "0":
+    for (R, Cc, N, OH, OW) in KROW3:
+        dy = torch.randn(N, OH, OW, R, device=dev).bfloat16()
+        x = torch.randn(N, OH, OW, Cc, device=dev).bfloat16()
+        flops = 2.0 * N * OH * OW * R * Cc * 9
+        os.environ["V2V_WGRAD_KROW3"] = "0"
+        ref, ms0 = run(dy, x, 3, 1, 1, L.PAD_REFLECT, L.BF16, reps=7)
+        os.environ["V2V_WGRAD_KROW3"] = "1"
+        line = "wgrad 3x3 R=%4d C=%4d %dx%dx%d: as before %.3f ms (%.0f TFLOP/s)" % (R, Cc, N, OH, OW, ms0, flops / ms0 / 1e9)
+        for sp in (0, 16, 32, 64):
+            if sp:
+                os.environ["V2V_WGRAD_KROW_SPLITS"] = str(sp)
+            got, ms = run(dy, x, 3, 1, 1, L.PAD_REFLECT, L.BF16, reps=7)
+            err = (got - ref).abs().max().item() / (ref.pow(2).mean().sqrt().item() + 1e-12)
+            line += " | kernel row %s %.3f ms (%.0f TFLOP/s, diff %.1e)" % ("x%d" % sp if sp else "auto", ms, flops / ms / 1e9, err)
+            os.environ.pop("V2V_WGRAD_KROW_SPLITS", None)
+        print(line)

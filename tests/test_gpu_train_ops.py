@@ -187,6 +187,10 @@ WGRAD_KROW_CASES = [
     (64, 6, 9, 33, 1, "zero", 1, False),              # previous-frame stem (6 channels), zero padding, one partial segment, unsplit
     (96, 72, 8, 130, 1, "zero", 2, True),             # channels-last gradient, three segments, 4-row splits
     (16, 40, 7, 16, 3, "reflect", 5, False),          # images of 7 rows (reflect reaches 3 rows back), batch 3
+    # the same kernel with THREE taps per workgroup: 3x3 layers the nine-tap kernel leaves to the GEMM view (forced splits select it at test sizes)
+    (96, 72, 19, 70, 2, "zero", 3, False, 3),
+    (64, 64, 12, 130, 1, "reflect", 2, True, 3),
+    (40, 33, 6, 64, 2, "reflect", 4, False, 3),
 ]
 
 
@@ -200,7 +204,9 @@ def test_wgrad_kernel_row_7x7(case, monkeypatch):
     import ctypes as C
     from vid2vid_amd import lib as L
     from vid2vid_amd.lib import lib, WgradDesc, check
-    R, Cc, H, W, N, mode, splits, cl = case
+    R, Cc, H, W, N, mode, splits, cl = case[:8]
+    K = case[8] if len(case) > 8 else 7
+    pd = K // 2
     torch.manual_seed(R + Cc + W)
     Rs, Cs = (R + 7) // 8 * 8, (Cc + 7) // 8 * 8
     dy = torch.zeros(N, H, W, Rs, device=DEV); dy[..., :R] = torch.randn(N, H, W, R, device=DEV)
@@ -214,8 +220,8 @@ def test_wgrad_kernel_row_7x7(case, monkeypatch):
         d.p, d.q = dyb.data_ptr(), xb.data_ptr()
         d.N, d.OH, d.OW, d.QH, d.QW = N, H, W, H, W
         d.rows, d.cols, d.p_stride, d.q_stride = R, Cc, Rs, Cs
-        d.KH = d.KW = 7
-        d.stride, d.pad, d.pad_mode = 1, 3, L.PAD_REFLECT if mode == "reflect" else L.PAD_ZERO
+        d.KH = d.KW = K
+        d.stride, d.pad, d.pad_mode = 1, pd, L.PAD_REFLECT if mode == "reflect" else L.PAD_ZERO
         d.dtype, d.accumulate = L.BF16, (1 if accumulate else 0) + (2 if cl else 0)
         d.grad, d.zero_page = grad.data_ptr(), zero.data_ptr()
         nbytes = lib.v2v_conv_wgrad_workspace(C.byref(d))
@@ -225,12 +231,12 @@ def test_wgrad_kernel_row_7x7(case, monkeypatch):
         check(lib.v2v_conv_wgrad(C.byref(d), st), "wgrad")
         torch.cuda.synchronize()
 
-    shape = (R, 7, 7, Cc) if cl else (R, Cc, 7, 7)
+    shape = (R, K, K, Cc) if cl else (R, Cc, K, K)
     logical = (lambda g: g.permute(0, 3, 1, 2)) if cl else (lambda g: g)
     xr = xb[..., :Cc].float().permute(0, 3, 1, 2).contiguous()
     dyr = dyb[..., :R].float().permute(0, 3, 1, 2).contiguous()
-    xp = F.pad(xr, (3, 3, 3, 3), mode="reflect") if mode == "reflect" else F.pad(xr, (3, 3, 3, 3))
-    ref = torch.nn.grad.conv2d_weight(xp.double(), (R, Cc, 7, 7), dyr.double()).float().cpu()
+    xp = F.pad(xr, (pd,) * 4, mode="reflect") if mode == "reflect" else F.pad(xr, (pd,) * 4)
+    ref = torch.nn.grad.conv2d_weight(xp.double(), (R, Cc, K, K), dyr.double()).float().cpu()
     if splits:
         monkeypatch.setenv("V2V_WGRAD_KROW_SPLITS", str(splits))
     g_new = torch.full(shape, 7.0, device=DEV)                             # overwrite mode must not read the buffer
@@ -242,7 +248,7 @@ def test_wgrad_kernel_row_7x7(case, monkeypatch):
     rms = ref.pow(2).mean().sqrt().item()
     e_ref = (logical(g_new).cpu() - ref).abs().max().item() / rms
     e_old = (g_new - g_old).abs().max().item() / rms
-    print("kernel-row 7x7 wgrad %s: vs torch %.2e, vs the GEMM-view kernel %.2e (of the gradient's rms)" % (str(case), e_ref, e_old))
+    print("kernel-row wgrad %s: vs torch %.2e, vs the GEMM-view kernel %.2e (of the gradient's rms)" % (str(case), e_ref, e_old))
     assert e_ref < 2e-5 and e_old < 2e-5
     base = torch.randn(shape, device=DEV)
     g_acc = base.clone()

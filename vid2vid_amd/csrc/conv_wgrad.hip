@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_krow_bf16_kernel(const WgradKr
     constexpr int NS = DP + 1;                               // ring depth of both operands
     constexpr int QSLOT = QPX * 128, PSLOT = XS * 128;
     constexpr int QBASE = NS * PSLOT;
-    constexpr int TH = 3;                                    // taps read with the A fragment (2 + 2 TH reads), the rest behind them
+    constexpr int TH = NT < 3 ? NT : 3;                      // taps read with the A fragment (2 + 2 TH reads), the rest behind them
     static_assert(XS + NT - 1 <= QPX && 2 * (NT - TH) <= 15 && 2 + 2 * TH <= 15, "fragment reads of a half fit the LDS counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -919,39 +919,35 @@ struct WgradKrowReduceArgs {
     int splits, R, C, NT, tiles, n_tiles, accumulate, grad_cl;
 };
 
-// one thread per (row, col, ky): sums the K splits in split order for its NT taps and writes NT consecutive gradient values
-// ([R][C][ky][kx]; channels-last [R][ky][kx][C]: stride C).  Fragment order of the slab: row-in-32 = (r & 3) + 8 (r >> 2) + 4 hi,
-// r = 4 q + e (register r of tap t = component e of vector (t * 4 + q)), lane = col-in-32 + 32 hi.
+// one thread per 16-byte slab vector (ky, tile, wave, tap, q, lane): the K splits are summed in split order with coalesced 16-byte
+// reads (consecutive lanes = consecutive vectors), the four components -- gradient rows 8 q + 4 hi + e of column lane & 31 -- leave as
+// four 4-byte read-modify-writes ([R][C][ky][kx]; channels-last [R][ky][kx][C]).  (The first version gave a thread one (row, col, ky)
+// and walked the slabs with 4-byte reads 4 KB apart: 64 us per launch for 26 MB, profiles/r06_v45_train_kernel_stats.txt.)
 __global__ __launch_bounds__(256) void wgrad_krow_reduce_kernel(const WgradKrowReduceArgs a) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)a.R * a.C * a.NT;
-    if (e >= total) return;
-    const int ky = (int)(e % a.NT);
-    const long long rc = e / a.NT;
-    const int col = (int)(rc % a.C), row = (int)(rc / a.C);
-    const int mt = row >> 6, wm = (row >> 5) & 1, rr = row & 31;
-    const int nt = col >> 6, wn = (col >> 5) & 1, lr = col & 31;
-    const int hi = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
-    const int q = r >> 2, comp = r & 3, lane = lr + 32 * hi, wave = wm * 2 + wn, tile = mt * a.n_tiles + nt;
-    float s[7];
+    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per_split = (long long)a.NT * a.tiles * 4 * a.NT * 4 * 64;       // vectors of one split
+    if (v >= per_split) return;
+    const int lane = (int)(v & 63);
+    long long u = v >> 6;
+    const int q = (int)(u & 3); u >>= 2;
+    const int t = (int)(u % a.NT); u /= a.NT;
+    const int wave = (int)(u & 3); u >>= 2;
+    const int tile = (int)(u % a.tiles);
+    const int ky = (int)(u / a.tiles);
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.slab) + v;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < a.splits; ++sp) s += src[(long long)sp * per_split];
+    const int mt = tile / a.n_tiles, nt = tile - mt * a.n_tiles;
+    const int col = nt * 64 + (wave & 1) * 32 + (lane & 31);
+    if (col >= a.C) return;
+    const int row0 = mt * 64 + (wave >> 1) * 32 + 8 * q + 4 * (lane >> 5);
+    const int khw = a.NT * a.NT, tap = ky * a.NT + t;
 #pragma unroll
-    for (int t = 0; t < 7; ++t) s[t] = 0.f;
-    for (int sp = 0; sp < a.splits; ++sp) {
-        const float* src = a.slab + ((((((long long)sp * a.NT + ky) * a.tiles + tile) * 4 + wave) * (a.NT * 4 * 64)) + q * 64 + lane) * 4 + comp;
-#pragma unroll
-        for (int t = 0; t < 7; ++t)
-            if (t < a.NT) s[t] += src[(long long)t * 4 * 64 * 4];
-    }
-    if (a.grad_cl) {
-        float* g = a.grad + ((long long)row * a.NT * a.NT + (long long)ky * a.NT) * a.C + col;
-#pragma unroll
-        for (int t = 0; t < 7; ++t)
-            if (t < a.NT) g[(long long)t * a.C] = a.accumulate ? g[(long long)t * a.C] + s[t] : s[t];
-    } else {
-        float* g = a.grad + ((long long)row * a.C + col) * a.NT * a.NT + ky * a.NT;
-#pragma unroll
-        for (int t = 0; t < 7; ++t)
-            if (t < a.NT) g[t] = a.accumulate ? g[t] + s[t] : s[t];
+    for (int e = 0; e < 4; ++e) {
+        const int row = row0 + e;
+        if (row >= a.R) break;
+        float* g = a.grad_cl ? a.grad + ((long long)row * khw + tap) * a.C + col : a.grad + ((long long)row * a.C + col) * khw + tap;
+        *g = a.accumulate ? *g + s[e] : s[e];
     }
 }
 
@@ -1085,6 +1081,8 @@ static int wgrad3_splits(const v2v_wgrad_desc* d) {
     return (int)s;
 }
 
+static bool wgrad_krow3_on() { const char* e = getenv("V2V_WGRAD_KROW3"); return !(e && e[0] == '0'); }
+
 // kernel-row kernel (7x7 / stride 1 / same size): K splits so that tiles x 7 x splits covers the chip about twice; 0 = not this layer.
 // V2V_WGRAD_KROW=0 switches it off (A/B), V2V_WGRAD_KROW_SPLITS=n forces n.
 static int wgrad_krow_splits(const v2v_wgrad_desc* d) {
@@ -1092,7 +1090,15 @@ static int wgrad_krow_splits(const v2v_wgrad_desc* d) {
     const char* const e_sp = getenv("V2V_WGRAD_KROW_SPLITS");
     const int on = (e_on && e_on[0] == '0') ? 0 : 1, forced = e_sp ? atoi(e_sp) : 0;
     if (!on || d->dtype != V2V_BF16 || legacy_bf16()) return 0;
-    if (d->KH != 7 || d->KW != 7 || d->stride != 1 || d->pad != 3 || d->OH != d->QH || d->OW != d->QW) return 0;
+    const bool k7 = d->KH == 7 && d->KW == 7 && d->pad == 3;
+    // 3x3 layers the nine-tap kernel leaves to the GEMM view (too few tiles to fill the chip with <= 8 in-launch splits: the 64- and
+    // 32-channel layers of the fine scales): three taps per workgroup, three times the workgroups, splits summed by the reduce kernel
+    const char* const e3 = getenv("V2V_WGRAD3");              // (V2V_WGRAD3=0 asks for the GEMM view on the 3x3 layers: the tests' reference)
+    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1 && !(e3 && e3[0] == '0') && wgrad3_splits(d) == 0 && wgrad_krow3_on();
+    if (!(k7 || k3) || d->stride != 1 || d->OH != d->QH || d->OW != d->QW) return 0;
+    // (three taps per workgroup pay from ~25 GFLOP up: 128 -> 128 at 512x256 0.129 -> 0.091 ms, 64 -> 64 at 1024x512 0.187 -> 0.143; 64 -> 64 at
+    //  512x256, 9.7 GFLOP, 0.065 -> 0.087: profiles/r06_v43_wgrad_krow3_bench.txt)
+    if (k3 && forced <= 0 && 2.0 * d->N * d->OH * d->OW * d->rows * d->cols * 9.0 < 25e9) return 0;
     if (d->QH < 4 || d->QW < 4) return 0;
     // the 6-channel previous-frame stems leave 58 of a tile's 64 columns empty: 0.24 ms against 0.084 for the GEMM view at 512x256
     // (profiles/r06_v41_wgrad_krow_bench.txt); from 32 columns up (the heads: 3 gradient rows x 32 ... 128 columns) the kernel row wins
@@ -1101,22 +1107,22 @@ static int wgrad_krow_splits(const v2v_wgrad_desc* d) {
     const long long grows = (long long)d->N * d->OH;
     // one workgroup per compute unit (the kernel holds a whole CU's registers): 128 x 108 at 512x256 0.45 / 0.27 / 0.29 / 0.31 ms on
     // 4 / 8 / 16 / 19 splits = 112 / 224 / 448 / 532 workgroups
-    long long s = forced > 0 ? forced : 256 / (tiles * 7);
+    long long s = forced > 0 ? forced : 256 / (tiles * d->KH);
     if (s > grows / 4) s = grows / 4;                            // >= 4 image rows per split
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > 96) s = 96;
     return (int)s;
 }
 
 struct WgradKrowOp : Op {
     WgradKrowArgs a; WgradKrowReduceArgs r;
     int launch(hipStream_t s) override {
-        auto kern = conv_wgrad_krow_bf16_kernel<2, 7>;
         const size_t lds = 3 * 8192 + 3 * 9216;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.splits), 7), dim3(256), lds, s, a);
+        if (r.NT == 7) hipLaunchKernelGGL((conv_wgrad_krow_bf16_kernel<2, 7>), dim3((unsigned)(a.tiles * a.splits), 7), dim3(256), lds, s, a);
+        else           hipLaunchKernelGGL((conv_wgrad_krow_bf16_kernel<2, 3>), dim3((unsigned)(a.tiles * a.splits), 3), dim3(256), lds, s, a);
         int rc = check_launch();
         if (rc != 0) return rc;
-        const long long total = (long long)r.R * r.C * r.NT;
+        const long long total = (long long)r.NT * r.tiles * 4 * r.NT * 4 * 64;       // 16-byte vectors of one split's slabs
         hipLaunchKernelGGL(wgrad_krow_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, r);
         return check_launch();
     }
@@ -1263,7 +1269,7 @@ extern "C" int64_t v2v_conv_wgrad_workspace(const v2v_wgrad_desc* d) {
     const int64_t nine_tap = s3 > 1 ? (int64_t)s3 * ceil_div(d->rows, 64) * ceil_div(d->cols, 64) * 4 * 36 * 64 * 16 : 0;
     // kernel-row kernel (7x7): [split][ky][tile][4 waves][28 x 64 lanes x 16 bytes]
     const int sk = wgrad_krow_splits(d);
-    const int64_t krow = sk > 0 ? (int64_t)sk * 7 * ceil_div(d->rows, 64) * ceil_div(d->cols, 64) * 4 * 28 * 64 * 16 : 0;
+    const int64_t krow = sk > 0 ? (int64_t)sk * d->KH * ceil_div(d->rows, 64) * ceil_div(d->cols, 64) * 4 * (4 * d->KW) * 64 * 16 : 0;
     const int64_t m = gemm_view > nine_tap ? gemm_view : nine_tap;
     return m > krow ? m : krow;
 }
@@ -1302,7 +1308,7 @@ extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
         a.splits = (int)ceil_div((long long)d->N * d->OH, a.rows_per_split);
         a.n_tiles = (int)ceil_div(d->cols, 64); a.tiles = (int)ceil_div(d->rows, 64) * a.n_tiles;
         WgradKrowReduceArgs& r = opk->r;
-        r.slab = d->workspace; r.grad = d->grad; r.splits = a.splits; r.R = d->rows; r.C = d->cols; r.NT = 7;
+        r.slab = d->workspace; r.grad = d->grad; r.splits = a.splits; r.R = d->rows; r.C = d->cols; r.NT = d->KH;
         r.tiles = a.tiles; r.n_tiles = a.n_tiles; r.accumulate = d->accumulate & 1; r.grad_cl = (d->accumulate >> 1) & 1;
         return submit(std::move(opk), stream);
     }
