@@ -95,7 +95,7 @@ class ConvFn(torch.autograd.Function):
             note_use(ctx.grad_params)
         if norm is not None:
             N, H, W = x.N, x.H, x.W
-            pc = eng.packed(conv, x.Cs)
+            pc = eng.packed(conv, x.Cs, refresh=False, touch=False)      # geometry only (a fetch with refresh re-packed the tap-major copy of every patch-tile layer once per step, on this stream)
             if pc.transposed:
                 OH = (H - 1) * pc.stride - 2 * cfg.pad + pc.KH + pc.out_pad
                 OW = (W - 1) * pc.stride - 2 * cfg.pad + pc.KW + pc.out_pad

@@ -771,7 +771,10 @@ class Engine:
         return self._grids[key]
 
     # ---------------- weights ----------------
-    def packed(self, mod, cin_stride, role="fwd", reflect=False, korder=0, refresh=True):
+    def packed(self, mod, cin_stride, role="fwd", reflect=False, korder=0, refresh=True, touch=True):
+        """touch=False: the caller only wants the layer's geometry -- the packing is not marked as in use (repack_async re-packs
+        after every optimizer step what was used since the last one: a patch-tile layer's tap-major packing, fetched by Engine.conv
+        for its geometry and never read by a launch, was a third of those re-packs)."""
         key = (id(mod), cin_stride, role, reflect, korder)
         if self._repack_event is not None:
             self.wait_repack()    # packings refreshed on the side stream after the last optimizer step: this stream reads them from here on
@@ -779,9 +782,11 @@ class Engine:
         if pc is None:
             pc = PackedConv(self, mod, cin_stride, role, reflect, korder)
             self._packed[key] = pc
+            pc.used = touch
         elif self.plan is None and refresh:
             pc.refresh()          # eager (training) use: follow optimizer updates
-        pc.used = True
+        if touch:
+            pc.used = True
         return pc
 
     def repack_async(self, flat=None):
@@ -906,7 +911,7 @@ class Engine:
         """Emit one convolution.  Returns (out, stats_rows, (N,OH,OW)).
         fin = (norm module, ss tensor [4*cout]): finalize the training-mode norm statistics inside the conv
         kernel (last-arriving workgroup), so no separate bn_finalize launch is needed."""
-        pc = self.packed(mod, x.Cs, refresh=False)     # geometry now; the packing that the chosen tile reads is refreshed below
+        pc = self.packed(mod, x.Cs, refresh=False, touch=False)     # geometry now; the packing that the chosen tile reads is fetched (and refreshed) below
         pad = pc.pad if pad_override is None else pad_override
         N, H, W = x.N, x.H, x.W
         if pc.transposed:
@@ -958,8 +963,10 @@ class Engine:
             d.tile = 62                                       # conv7x7_rowsum_kernel: the heads as row GEMM + shifted sum (bf16)
         if tile_korder(d.tile):
             pc = self._use_korder(d, mod, x.Cs, tile_korder(d.tile))
-        elif self.plan is None:
-            pc.refresh()               # eager use: follow optimizer updates (only the packing this launch reads)
+        else:
+            pc.used = True             # this launch reads the tap-major packing
+            if self.plan is None:
+                pc.refresh()           # eager use: follow optimizer updates (only the packing this launch reads)
         d.bias = None if pc.bias is None else pc.bias.data_ptr()      # of the packing in use (aliases the parameter)
         if pc.cin != x.C:
             raise RuntimeError("conv %s: input has %d channels, layer expects %d" % (label, x.C, pc.cin))
