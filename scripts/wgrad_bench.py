@@ -137,3 +137,27 @@ if os.environ.get("WGRAD_BENCH_KROW", "1") != "0":
             line += " | kernel row %s %.3f ms (%.0f TFLOP/s, diff %.1e)" % ("x%d" % sp if sp else "auto", ms, flops / ms / 1e9, err)
             os.environ.pop("V2V_WGRAD_KROW_SPLITS", None)
         print(line)
+
+# ---- the strided instantiations (4x4 / stride 2 and 1 of the discriminators, 3x3 / stride 2 down layers) beside the GEMM view ----
+KROWS = [(64, 39, 4, 2, 2, 2, 129, 257), (128, 64, 4, 2, 2, 2, 65, 129), (256, 128, 4, 2, 2, 2, 33, 65), (512, 256, 4, 1, 2, 2, 34, 66), (1, 512, 4, 1, 2, 2, 35, 67),
+         (256, 128, 3, 2, 1, 1, 128, 256), (512, 256, 3, 2, 1, 1, 64, 128), (1024, 512, 3, 2, 1, 1, 32, 64), (64, 39, 4, 2, 2, 2, 513, 1025), (128, 64, 4, 2, 2, 2, 257, 513)]
+if os.environ.get("WGRAD_BENCH_KROW", "1") != "0":
+    for (R, Cc, K, s, p, N, OH, OW) in KROWS:
+        H, W = (OH - 1) * s + K - 2 * p, (OW - 1) * s + K - 2 * p
+        Rs, Cs = (R + 7) // 8 * 8, (Cc + 7) // 8 * 8
+        dy = torch.zeros(N, OH, OW, Rs, device=dev); dy[..., :R] = torch.randn(N, OH, OW, R, device=dev)
+        x = torch.zeros(N, H, W, Cs, device=dev); x[..., :Cc] = torch.randn(N, H, W, Cc, device=dev)
+        dy, x = dy.bfloat16(), x.bfloat16()
+        flops = 2.0 * N * OH * OW * R * Cc * K * K
+        os.environ["V2V_WGRAD_KROW_S"] = "0"
+        ref, ms0 = run(dy, x, K, s, p, L.PAD_ZERO, L.BF16, reps=7)
+        os.environ["V2V_WGRAD_KROW_S"] = "1"
+        line = "wgrad %dx%d/s%d R=%4d C=%4d %dx%dx%d: GEMM view + reduce %.3f ms (%.0f TFLOP/s)" % (K, K, s, R, Cc, N, OH, OW, ms0, flops / ms0 / 1e9)
+        for sp in (0, 4, 16, 48):
+            if sp:
+                os.environ["V2V_WGRAD_KROW_SPLITS"] = str(sp)
+            got, ms = run(dy, x, K, s, p, L.PAD_ZERO, L.BF16, reps=7)
+            err = (got - ref).abs().max().item() / (ref.pow(2).mean().sqrt().item() + 1e-12)
+            line += " | kernel row %s %.3f ms (%.0f TFLOP/s, diff %.1e)" % ("x%d" % sp if sp else "auto", ms, flops / ms / 1e9, err)
+            os.environ.pop("V2V_WGRAD_KROW_SPLITS", None)
+        print(line)

@@ -259,6 +259,83 @@ def test_wgrad_kernel_row_7x7(case, monkeypatch):
     assert torch.equal(g_again, g_new)
 
 
+WGRAD_KROW_STRIDED_CASES = [
+    # rows, cols, OH, OW (dY grid), QH, QW (X grid), N, K, stride, pad, forced splits, channels-last gradient
+    (64, 39, 17, 33, 32, 64, 2, 4, 2, 2, 3, False),      # discriminator layer 1: 4x4 / stride 2 / pad 2 (OH = H/2 + 1), ragged columns
+    (128, 64, 9, 70, 16, 138, 1, 4, 2, 2, 2, False),     # 4x4 / stride 2, two dY segments (the second: 6 pixels)
+    (96, 128, 10, 35, 9, 34, 1, 4, 1, 2, 2, True),       # the discriminators' stride-1 4x4 layers (OH = H + 1), channels-last gradient
+    (1, 72, 6, 20, 5, 19, 3, 4, 1, 2, 4, False),         # the last layer: ONE gradient row
+    (80, 64, 8, 40, 16, 80, 2, 3, 2, 1, 3, False),       # generator down layer: 3x3 / stride 2 / pad 1
+    (64, 40, 12, 64, 24, 128, 1, 3, 2, 1, 2, False),     # ConvTranspose2d(3x3, stride 2, pad 1, output_padding 1): P = the layer's input, Q = dY (twice the size)
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_KROW_STRIDED_CASES)
+def test_wgrad_kernel_row_strided(case, monkeypatch):
+    """conv_wgrad_krow_bf16_kernel<2, 4 | 3, 1 | 2>: the strided layers (X row segments staged de-interleaved for stride 2) against
+    torch's fp64 weight gradient of the same bf16 operands and against the GEMM-view kernel (V2V_WGRAD_KROW=0); overwrite, accumulate,
+    both gradient layouts, one gradient row, splits crossing image boundaries, bit-identical repeats."""
+    import ctypes as C
+    from vid2vid_amd import lib as L
+    from vid2vid_amd.lib import lib, WgradDesc, check
+    R, Cc, OH, OW, QH, QW, N, K, stride, pad, splits, cl = case
+    torch.manual_seed(R + Cc + OW)
+    Rs, Cs = (R + 7) // 8 * 8, (Cc + 7) // 8 * 8
+    dy = torch.zeros(N, OH, OW, Rs, device=DEV); dy[..., :R] = torch.randn(N, OH, OW, R, device=DEV)
+    x = torch.zeros(N, QH, QW, Cs, device=DEV); x[..., :Cc] = torch.randn(N, QH, QW, Cc, device=DEV)
+    dyb, xb = dy.bfloat16(), x.bfloat16()
+    zero = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(grad, accumulate):
+        d = WgradDesc()
+        d.p, d.q = dyb.data_ptr(), xb.data_ptr()
+        d.N, d.OH, d.OW, d.QH, d.QW = N, OH, OW, QH, QW
+        d.rows, d.cols, d.p_stride, d.q_stride = R, Cc, Rs, Cs
+        d.KH = d.KW = K
+        d.stride, d.pad, d.pad_mode = stride, pad, L.PAD_ZERO
+        d.dtype, d.accumulate = L.BF16, (1 if accumulate else 0) + (2 if cl else 0)
+        d.grad, d.zero_page = grad.data_ptr(), zero.data_ptr()
+        nbytes = lib.v2v_conv_wgrad_workspace(C.byref(d))
+        assert nbytes > 0
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=DEV)
+        d.workspace = ws.data_ptr()
+        check(lib.v2v_conv_wgrad(C.byref(d), st), "wgrad")
+        torch.cuda.synchronize()
+
+    shape = (R, K, K, Cc) if cl else (R, Cc, K, K)
+    logical = (lambda g: g.permute(0, 3, 1, 2)) if cl else (lambda g: g)
+    xr = xb[..., :Cc].double().permute(0, 3, 1, 2).contiguous().cpu()
+    dyr = dyb[..., :R].double().permute(0, 3, 1, 2).contiguous().cpu()
+    # dW[r][c][ky][kx] = sum_p dY[p][r] X[p * stride + k - pad][c] (zero outside): the weight gradient of a strided correlation
+    xp = F.pad(xr, (pad, pad + stride + K, pad, pad + stride + K))
+    ref = torch.zeros(R, Cc, K, K, dtype=torch.float64)
+    for ky in range(K):
+        for kx in range(K):
+            win = xp[:, :, ky:ky + stride * OH:stride, kx:kx + stride * OW:stride][:, :, :OH, :OW]
+            ref[:, :, ky, kx] = torch.einsum("nrhw,nchw->rc", dyr, win)
+    ref = ref.float()
+    monkeypatch.setenv("V2V_WGRAD_KROW_SPLITS", str(splits))
+    g_new = torch.full(shape, 7.0, device=DEV)
+    run(g_new, False)
+    monkeypatch.setenv("V2V_WGRAD_KROW", "0")
+    g_old = torch.zeros(shape, device=DEV)
+    run(g_old, False)
+    monkeypatch.setenv("V2V_WGRAD_KROW", "1")
+    rms = ref.pow(2).mean().sqrt().item()
+    e_ref = (logical(g_new).cpu() - ref).abs().max().item() / rms
+    e_old = (g_new - g_old).abs().max().item() / rms
+    print("strided kernel-row wgrad %s: vs torch %.2e, vs the GEMM-view kernel %.2e (of the gradient's rms)" % (str(case), e_ref, e_old))
+    assert e_ref < 2e-5 and e_old < 2e-5
+    base = torch.randn(shape, device=DEV)
+    g_acc = base.clone()
+    run(g_acc, True)
+    assert (g_acc - base - g_new).abs().max().item() / rms < 1e-6
+    g_again = torch.empty(shape, device=DEV)
+    run(g_again, False)
+    assert torch.equal(g_again, g_new)
+
+
 CONVT_CASES = [
     # cin, cout, k, pad, out_pad, H, W, N
     (32, 16, 3, 1, 1, 12, 20, 2),      # generator up path (networks.py:176)

@@ -747,7 +747,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_bf16_kernel(const Wgrad3Arg
 struct WgradKrowArgs {
     const char* P; const char* Q; const char* zero_page;
     float* slab;
-    int N, H, W;            // pixel grid of P and Q (same size: stride 1, pad = 3)
+    int N, H, W;            // pixel grid of P (dY: OH x OW)
+    int QH, QW;             // pixel grid of Q (X): Q pixel of dY pixel (y, x) and tap (ky, kx) = (y * S + ky - pad, x * S + kx - pad)
     int PCs, QCs;           // channel strides (elements)
     int reflect, pad;
     int rows_per_split, splits, n_tiles, tiles;
@@ -780,15 +781,24 @@ template <int T0, int T1, int NT> __device__ __forceinline__ void wgk_mma(f32x16
     for (int t = T0; t < T1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b[t].v, acc[t], 0, 0, 0);
 }
 
-template <int DP, int NT>
+// S = 2 (round 6: the discriminators' 4x4 / stride 2 layers, the generator's 3x3 / stride 2 down layers and -- operands swapped --
+// its ConvTranspose2d up layers): the X pixels a dY segment meets are 2 j + kx - pad; an X row segment is staged DE-INTERLEAVED,
+// even offsets in one 72-pixel sub-array and odd ones in a second, so that tap kx again reads 64 consecutive LDS rows:
+// sub-array kx & 1 at row offset kx >> 1.
+template <int DP, int NT, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_krow_bf16_kernel(const WgradKrowArgs p) {
     constexpr int XS = 64;                                   // pixels of a dY row segment
-    constexpr int QPX = 72;                                  // pixel slots of an X row (XS + NT - 1 used), 9 LDS-DMA instructions
+    constexpr int SUBPX = 72;                                // pixel slots of one X sub-array (S = 1: the only one)
+    constexpr int QPX = SUBPX * S;                           // pixel slots of an X row stage: 9 S LDS-DMA instructions
     constexpr int NS = DP + 1;                               // ring depth of both operands
     constexpr int QSLOT = QPX * 128, PSLOT = XS * 128;
     constexpr int QBASE = NS * PSLOT;
     constexpr int TH = NT < 3 ? NT : 3;                      // taps read with the A fragment (2 + 2 TH reads), the rest behind them
-    static_assert(XS + NT - 1 <= QPX && 2 * (NT - TH) <= 15 && 2 + 2 * TH <= 15, "fragment reads of a half fit the LDS counter");
+    constexpr int NQI = QPX / 8;                             // LDS-DMA instructions of an X row stage, dealt to the four waves in turn
+    constexpr int NHI = NQI % 4;                             // waves 0 .. NHI-1 issue one more than the others
+    constexpr int CLO = 2 + NQI / 4, CHI = CLO + 1;          // loads per stage and wave (2 of them dY)
+    static_assert(S == 1 || S == 2, "stride");
+    static_assert(XS + (NT - 1) / S <= SUBPX && 2 * (NT - TH) <= 15 && 2 + 2 * TH <= 15, "fragment reads of a half fit the LDS counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_krow_bf16_kernel(const WgradKr
     const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
     const int ky = blockIdx.y;
     const char* const zp = p.zero_page;
-    const int H = p.H, W = p.W;
+    const int H = p.H, W = p.W, QH = p.QH, QW = p.QW;
 
     const int l_row = lane >> 3, l_slot = lane & 7;
     const int l_chunk = l_slot ^ ((((l_row >> 1) & 1)) << 2);
@@ -812,8 +822,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_krow_bf16_kernel(const WgradKr
     int b_off[NT];
 #pragma unroll
     for (int kx = 0; kx < NT; ++kx) {
-        const int r0 = frow + kx;
-        b_off[kx] = r0 * 128 + ((((cb >> 3) ^ (((r0 >> 1) & 1) << 2))) << 4) + ((cb & 7) << 1);
+        const int sub = S == 2 ? (kx & 1) : 0;
+        const int r0 = frow + (S == 2 ? (kx >> 1) : kx);
+        b_off[kx] = sub * (SUBPX * 128) + r0 * 128 + ((((cb >> 3) ^ (((r0 >> 1) & 1) << 2))) << 4) + ((cb & 7) << 1);
     }
 
     f32x16 acc[NT];
@@ -833,7 +844,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_krow_bf16_kernel(const WgradKr
         for (int sg = 0; sg < nseg; ++sg) {
             const int xs = sg * XS;
             const int nk16 = min(XS / 16, (W - xs + 15) >> 4);
-            // stage j (0 .. T-1) = dY row ya+j into P slot j % NS and X row ya+j+ky-pad (padding resolved here) into Q slot j % NS
+            // stage j (0 .. T-1) = dY row ya+j into P slot j % NS and X row (ya+j) S + ky - pad (padding resolved here) into Q slot j % NS
             int issued = 0;
             auto issue = [&]() {
                 const int j = issued;
@@ -848,23 +859,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_krow_bf16_kernel(const WgradKr
                     const bool ok = p_chok && x < W;
                     wg_glds16(ok ? prow + ((long long)x * p.PCs + p_ch) * 2 : zp, pb + q * 1024);
                 }
-                int yq = yp + ky - p.pad;
+                int yq = yp * S + ky - p.pad;
                 bool qrow_ok = true;
-                if (p.reflect) { yq = yq < 0 ? -yq : yq; yq = yq >= H ? 2 * H - 2 - yq : yq; }
-                else qrow_ok = (unsigned)yq < (unsigned)H;
-                yq = min(max(yq, 0), H - 1);
-                const char* const qrow = p.Q + ((long long)(n * H + yq) * W) * p.QCs * 2;
+                if (p.reflect) { yq = yq < 0 ? -yq : yq; yq = yq >= QH ? 2 * QH - 2 - yq : yq; }
+                else qrow_ok = (unsigned)yq < (unsigned)QH;
+                yq = min(max(yq, 0), QH - 1);
+                const char* const qrow = p.Q + ((long long)(n * QH + yq) * QW) * p.QCs * 2;
                 auto qload = [&](int q) {
-                    const int px = q * 8 + l_row;                          // pixel slot: image x = xs - pad + px
-                    int x = xs - p.pad + px;
-                    bool ok = qrow_ok && q_chok && px < XS + NT - 1;
-                    if (p.reflect) { x = x < 0 ? -x : x; x = x >= W ? 2 * W - 2 - x : x; }
-                    ok = ok && (unsigned)x < (unsigned)W;
-                    x = min(max(x, 0), W - 1);
+                    const int slot = q * 8 + l_row;                        // LDS pixel slot of this lane
+                    const int sub = S == 2 ? slot / SUBPX : 0, i = slot - sub * SUBPX;
+                    const int o = S == 2 ? 2 * i + sub : i;                // offset from the segment's first X pixel
+                    int x = xs * S - p.pad + o;
+                    bool ok = qrow_ok && q_chok && o <= (XS - 1) * S + NT - 1;
+                    if (p.reflect) { x = x < 0 ? -x : x; x = x >= QW ? 2 * QW - 2 - x : x; }
+                    ok = ok && (unsigned)x < (unsigned)QW;
+                    x = min(max(x, 0), QW - 1);
                     wg_glds16(ok ? qrow + ((long long)x * p.QCs + q_ch) * 2 : zp, qb + q * 1024);
                 };
-                qload(wid); qload(wid + 4);
-                if (wid == 0) qload(8);
+#pragma unroll
+                for (int q4 = 0; q4 < NQI / 4; ++q4) qload(wid + 4 * q4);
+                if (wid < NHI) qload(wid + 4 * (NQI / 4));
                 ++issued;
             };
             const int nstages = T;
@@ -874,7 +888,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_krow_bf16_kernel(const WgradKr
             for (int t = 0; t < T; ++t) {
                 // stage t must have landed; issued so far: min(t+DP, nstages) stages; a wave's loads complete in order
                 if (t + DP <= nstages) {
-                    if (wid == 0) wg_wait_vmcnt<5 * (DP - 1)>(); else wg_wait_vmcnt<4 * (DP - 1)>();
+                    if (wid < NHI) wg_wait_vmcnt<CHI * (DP - 1)>(); else wg_wait_vmcnt<CLO * (DP - 1)>();
                 } else wg_wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 // stage t+DP overwrites the slots of stage t-1 (last read in step t-1): every wave is past them
@@ -1081,6 +1095,7 @@ static int wgrad3_splits(const v2v_wgrad_desc* d) {
     return (int)s;
 }
 
+static double wgrad_krow_s_min_flop() { static const double v = [] { const char* e = getenv("V2V_WGRAD_KROW_S_MINFLOP"); return e ? atof(e) : 4e9; }(); return v; }
 static bool wgrad_krow3_on() { const char* e = getenv("V2V_WGRAD_KROW3"); return !(e && e[0] == '0'); }
 
 // kernel-row kernel (7x7 / stride 1 / same size): K splits so that tiles x 7 x splits covers the chip about twice; 0 = not this layer.
@@ -1095,7 +1110,14 @@ static int wgrad_krow_splits(const v2v_wgrad_desc* d) {
     // 32-channel layers of the fine scales): three taps per workgroup, three times the workgroups, splits summed by the reduce kernel
     const char* const e3 = getenv("V2V_WGRAD3");              // (V2V_WGRAD3=0 asks for the GEMM view on the 3x3 layers: the tests' reference)
     const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1 && !(e3 && e3[0] == '0') && wgrad3_splits(d) == 0 && wgrad_krow3_on();
-    if (!(k7 || k3) || d->stride != 1 || d->OH != d->QH || d->OW != d->QW) return 0;
+    // round 6, last: the strided layers (4x4 / stride 2 and stride 1 of the discriminators, 3x3 / stride 2 down layers, and -- the caller swaps
+    // the operands -- the ConvTranspose2d(3x3, stride 2) up layers), zero padding.  V2V_WGRAD_KROW_S=0 leaves them on the GEMM view.
+    static const auto ks_on = [] { const char* e = getenv("V2V_WGRAD_KROW_S"); return !(e && e[0] == '0'); };
+    const bool k4 = d->KH == 4 && d->KW == 4 && (d->stride == 1 || d->stride == 2) && d->pad_mode == V2V_PAD_ZERO && ks_on();
+    const bool k3s2 = d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad_mode == V2V_PAD_ZERO && ks_on();
+    if (!(k7 || k3 || k4 || k3s2)) return 0;
+    if ((k7 || k3) && (d->stride != 1 || d->OH != d->QH || d->OW != d->QW)) return 0;
+    if ((k4 || k3s2) && forced <= 0 && 2.0 * d->N * d->OH * d->OW * d->rows * d->cols * d->KH * d->KW < wgrad_krow_s_min_flop()) return 0;
     // (three taps per workgroup pay from ~25 GFLOP up: 128 -> 128 at 512x256 0.129 -> 0.091 ms, 64 -> 64 at 1024x512 0.187 -> 0.143; 64 -> 64 at
     //  512x256, 9.7 GFLOP, 0.065 -> 0.087: profiles/r06_v43_wgrad_krow3_bench.txt)
     if (k3 && forced <= 0 && 2.0 * d->N * d->OH * d->OW * d->rows * d->cols * 9.0 < 25e9) return 0;
@@ -1107,7 +1129,8 @@ static int wgrad_krow_splits(const v2v_wgrad_desc* d) {
     const long long grows = (long long)d->N * d->OH;
     // one workgroup per compute unit (the kernel holds a whole CU's registers): 128 x 108 at 512x256 0.45 / 0.27 / 0.29 / 0.31 ms on
     // 4 / 8 / 16 / 19 splits = 112 / 224 / 448 / 532 workgroups
-    long long s = forced > 0 ? forced : 256 / (tiles * d->KH);
+    // (the 3- and 4-tap instantiations fit two or three workgroups per compute unit: twice the workgroups)
+    long long s = forced > 0 ? forced : (d->KH == 7 ? 256 : 512) / (tiles * d->KH);
     if (s > grows / 4) s = grows / 4;                            // >= 4 image rows per split
     if (s < 1) s = 1;
     if (s > 96) s = 96;
@@ -1116,10 +1139,22 @@ static int wgrad_krow_splits(const v2v_wgrad_desc* d) {
 
 struct WgradKrowOp : Op {
     WgradKrowArgs a; WgradKrowReduceArgs r;
+    int stride = 1;
+    template <int NT, int S> void run(hipStream_t s) {
+        auto kern = conv_wgrad_krow_bf16_kernel<2, NT, S>;
+        const size_t lds = 3 * (8192 + 9216 * S);
+        if (lds > 64 * 1024) {
+            static bool attr_done = false;
+            if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.splits), NT), dim3(256), lds, s, a);
+    }
     int launch(hipStream_t s) override {
-        const size_t lds = 3 * 8192 + 3 * 9216;
-        if (r.NT == 7) hipLaunchKernelGGL((conv_wgrad_krow_bf16_kernel<2, 7>), dim3((unsigned)(a.tiles * a.splits), 7), dim3(256), lds, s, a);
-        else           hipLaunchKernelGGL((conv_wgrad_krow_bf16_kernel<2, 3>), dim3((unsigned)(a.tiles * a.splits), 3), dim3(256), lds, s, a);
+        if (r.NT == 7)                     run<7, 1>(s);
+        else if (r.NT == 4 && stride == 2) run<4, 2>(s);
+        else if (r.NT == 4)                run<4, 1>(s);
+        else if (stride == 2)              run<3, 2>(s);
+        else                               run<3, 1>(s);
         int rc = check_launch();
         if (rc != 0) return rc;
         const long long total = (long long)r.NT * r.tiles * 4 * r.NT * 4 * 64;       // 16-byte vectors of one split's slabs
@@ -1302,8 +1337,9 @@ extern "C" int v2v_conv_wgrad(const v2v_wgrad_desc* d, void* stream) {
         memset(&a, 0, sizeof(a));
         a.P = (const char*)d->p; a.Q = (const char*)d->q; a.zero_page = (const char*)d->zero_page;
         a.slab = d->workspace;
-        a.N = d->N; a.H = d->OH; a.W = d->OW; a.PCs = d->p_stride; a.QCs = d->q_stride;
+        a.N = d->N; a.H = d->OH; a.W = d->OW; a.QH = d->QH; a.QW = d->QW; a.PCs = d->p_stride; a.QCs = d->q_stride;
         a.reflect = d->pad_mode == V2V_PAD_REFLECT ? 1 : 0; a.pad = d->pad;
+        opk->stride = d->stride;
         a.rows_per_split = (int)ceil_div((long long)d->N * d->OH, sk);
         a.splits = (int)ceil_div((long long)d->N * d->OH, a.rows_per_split);
         a.n_tiles = (int)ceil_div(d->cols, 64); a.tiles = (int)ceil_div(d->rows, 64) * a.n_tiles;
