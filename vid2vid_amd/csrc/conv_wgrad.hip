@@ -1109,7 +1109,7 @@ static int wgrad_krow_splits(const v2v_wgrad_desc* d) {
     // 3x3 layers the nine-tap kernel leaves to the GEMM view (too few tiles to fill the chip with <= 8 in-launch splits: the 64- and
     // 32-channel layers of the fine scales): three taps per workgroup, three times the workgroups, splits summed by the reduce kernel
     const char* const e3 = getenv("V2V_WGRAD3");              // (V2V_WGRAD3=0 asks for the GEMM view on the 3x3 layers: the tests' reference)
-    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1 && !(e3 && e3[0] == '0') && wgrad3_splits(d) == 0 && wgrad_krow3_on();
+    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1 && d->stride == 1 && !(e3 && e3[0] == '0') && wgrad3_splits(d) == 0 && wgrad_krow3_on();
     // round 6, last: the strided layers (4x4 / stride 2 and stride 1 of the discriminators, 3x3 / stride 2 down layers, and -- the caller swaps
     // the operands -- the ConvTranspose2d(3x3, stride 2) up layers), zero padding.  V2V_WGRAD_KROW_S=0 leaves them on the GEMM view.
     static const auto ks_on = [] { const char* e = getenv("V2V_WGRAD_KROW_S"); return !(e && e[0] == '0'); };
