@@ -240,13 +240,36 @@ def _role_worker(rank, world, port, n_gen, group, k, n_chunks, q):
         if L.owns_DT:
             out["param_DT"] = D.optimizer_D_T0.flat.flat_param.clone()
         dist.barrier()
-        q.put((rank, out))
+        q.put((rank, _plain(out)))
     except Exception:
         import traceback
         q.put((rank, {"error": traceback.format_exc()}))
     finally:
         parallel._ACTIVE_SYNCS.clear()
         dist.destroy_process_group()
+
+
+def _plain(o):
+    """Tensors -> numpy before a result crosses the process boundary: a tensor in a multiprocessing queue travels as a file
+    descriptor served by the SENDER, and a worker that exits right after q.put() takes that server with it (FileNotFoundError
+    in the parent's q.get(), seen once the workers got fast enough)."""
+    if isinstance(o, torch.Tensor):
+        return ("__t__", o.detach().cpu().numpy())
+    if isinstance(o, dict):
+        return {k: _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_plain(v) for v in o)
+    return o
+
+
+def _tensors(o):
+    if isinstance(o, tuple) and len(o) == 2 and isinstance(o[0], str) and o[0] == "__t__":
+        return torch.from_numpy(o[1])
+    if isinstance(o, dict):
+        return {k: _tensors(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_tensors(v) for v in o)
+    return o
 
 
 def _run_roles(world, n_gen, group, k, n_chunks):
@@ -259,7 +282,7 @@ def _run_roles(world, n_gen, group, k, n_chunks):
     res = {}
     for _ in range(world):
         r, out = q.get(timeout=300)
-        res[r] = out
+        res[r] = _tensors(out)
     for p in procs:
         p.join(timeout=60)
     for r, out in res.items():
