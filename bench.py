@@ -205,6 +205,10 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true", help="train: skip the per-shape tile search of the first chunks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--oracle-threads", type=int, default=16,
+                    help="host threads of the CPU legs (cpu_baseline, the oracle sides of the parity legs); 0 = torch's default pool.  On the GPU box's "
+                         "128-thread default the oracle is 7x SLOWER than on 16 (0.104 / 0.343 / 0.642 / 0.712 frames/s on 128 / 64 / 32 / 16 threads, "
+                         "profiles/r06_v57_cpu_baseline_threads.txt): the baseline is quoted on the pool it runs fastest on")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--retune", action="store_true", help="ignore profiles/tune_cache.json and measure the tile selections in this run")
     ap.add_argument("--profile-frames", type=int, default=3)
@@ -686,6 +690,10 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
+    if int(os.environ.get("V2V_ORACLE_THREADS", "0")) > 0:
+        args.oracle_threads = int(os.environ["V2V_ORACLE_THREADS"])
+    if args.oracle_threads > 0 and torch.get_num_threads() > args.oracle_threads:
+        torch.set_num_threads(args.oracle_threads)      # (nothing of the product runs on torch's CPU pool)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -929,8 +937,9 @@ def main():
         except OSError:
             pass
         cpu = {"value": round(args.cpu_frames / cpu_s, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
-               "sample": "%d frames (after 1 warm-up) of the same %dx%d workload, fp32, oracle/vid2vid_oracle.py on %s"
-                         % (args.cpu_frames, W, H, model_name or "host CPU")}
+               "sample": "%d frames (after 1 warm-up) of the same %dx%d workload, fp32, oracle/vid2vid_oracle.py on %d threads of %s (--oracle-threads: "
+                         "the pool size it runs fastest on; the default 128-thread pool is 7x slower)"
+                         % (args.cpu_frames, W, H, ncores, model_name or "host CPU")}
 
         def errors_of(m):
             """Every frame starts from the REFERENCE's previous frames (same inputs on both sides, as north_star words

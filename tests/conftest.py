@@ -22,6 +22,12 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=lambda it: 1 if "ref_checker" in it.keywords else 0)
     import torch
     if torch.cuda.is_available():
+        # The CPU oracle (torch on the host cores) is the slow side of the full-size comparisons, and it gets SLOWER with the GPU
+        # box's 128 default threads: the 1024x512 training-chunk oracle takes 172 s on 128 threads, 93 on 64, 59 on 32, 46 on 16
+        # (its CPU autograd is a chain of small ops; profiles/r06_v56_oracle_threads.txt).  V2V_TEST_THREADS overrides.
+        n = int(os.environ.get("V2V_TEST_THREADS", "16"))
+        if n > 0 and torch.get_num_threads() > n:
+            torch.set_num_threads(n)
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:
