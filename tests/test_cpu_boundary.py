@@ -2,6 +2,8 @@
 lowering (plan recording, no execution) and the 'oracle is test infrastructure' rule."""
 import os
 import re
+import subprocess
+import sys
 import types
 
 import numpy as np
@@ -608,3 +610,52 @@ def test_round5_label_paths_dry_run():
         assert rc != 0                                  # 200 labels do not fit the 7-bit code
     finally:
         N.set_record_only(False)
+
+
+def _load_hazard_check():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mfma_hazard_check", os.path.join(ROOT, "scripts", "mfma_hazard_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_mfma_hazard_check_flags_the_round5_miscompute_pattern(tmp_path, capsys):
+    """The checker on a hand-written disassembly of the pattern the V2V_STAMP_MASK build of conv_igemm_kernel<float,64,64,2,2,2,false>
+    contained (round 5's "stamp build miscompute", root-caused in round 6): the loop's last 16-pass fp32 MFMA, the exit branch, and a
+    `v_accvgpr_read_b32` of the last accumulator register a few wait states later -- once too early, once behind enough s_nop."""
+    mod = _load_hazard_check()
+
+    def dis(nops):
+        lines = ["0000000000001000 <k>:",
+                 "\tv_mfma_f32_32x32x2_f32 a[0:15], v35, v39, a[0:15]           // 000000001000: D3C40000 04024F23",
+                 "\ts_cmp_eq_u32 s85, s5                                       // 000000001008: BF060555",
+                 "\ts_cbranch_scc1 2                                           // 00000000100C: BF850002",
+                 "\ts_mov_b32 s84, s85                                         // 000000001010: BED40055",
+                 "\ts_branch 65531                                             // 000000001014: BF82FFFB",
+                 "\ts_load_dwordx2 s[6:7], s[0:1], 0x2b0                       // 000000001018: C0060180 000002B0"]
+        a = 0x1020
+        for n in nops:
+            lines.append("\ts_nop %d                                                    // %012X: BF80%04X" % (n, a, n))
+            a += 4
+        lines.append("\tv_accvgpr_read_b32 v17, a15                                // %012X: D3D84011 1800010F" % a)
+        lines.append("\ts_endpgm                                                   // %012X: BF810000" % (a + 8))
+        p = tmp_path / ("k_%d.dis" % len(nops))
+        p.write_text("\n".join(lines) + "\n")
+        return str(p)
+
+    assert mod.check(dis([3])) == 1                      # 7 of 18 wait states: what the stamp build did
+    assert "VIOLATION 7 of 18" in capsys.readouterr().out
+    assert mod.check(dis([7, 6])) == 0                   # 18 wait states: fine
+    assert mod.passes_of("v_mfma_f32_32x32x16_bf16") == (8, 11) and mod.passes_of("v_mfma_f32_16x16x32_bf16") == (4, 7)
+
+
+def test_shipped_library_passes_the_mfma_hazard_check():
+    """Every MFMA of the in-tree libv2v_hip.so keeps the result latency towards every non-MFMA access of its accumulators on every
+    control-flow path (the compiler's own hazard search can miss the loop-exit edge; `__graft_entry__.build()` runs the same check)."""
+    so = os.path.join(ROOT, "vid2vid_amd", "libv2v_hip.so")
+    if not os.path.exists(so) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no built library / no llvm-objdump here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "mfma_hazard_check.py"), "--lib", so], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "MFMAs" in r.stdout

@@ -74,17 +74,14 @@ struct ConvKArgs {
 // phase stamp k of this workgroup (thread 0): 0 entry, 1 prologue set up (first loads issued), 2 first tile landed, 3 main loop done,
 // 4 outputs stored, 5 statistics row published, 6 exit.  COMPILED OUT of the product build (V2V_STAMP_MASK = 0).  The instrumented
 // library is a PROFILING build only:  touch conv_igemm_kernel.h && make -C vid2vid_amd/csrc EXTRA=-DV2V_STAMP_MASK=0x7f, run
-// scripts/kernel_phases.py, rebuild without EXTRA.  Its timings are what it is for; its RESULTS ARE NOT TO BE TRUSTED:
-//   round 4 saw its fp32 golden tests fail "intermittently" (profiles/r04_a4_stamps_flaky.txt) and suspected a latent race that the
-//   product build only hides.  Round 5 took it apart (profiles/r05_v2_stampdiag.txt, r05_v3_stamp_bisect.txt):
-//   (1) every deterministic kernel test passes on the stamp build; (2) a failing run's tile selections (V2V_TUNE_CACHE) replayed
-//   on the stamp build fail EVERY time (8 of 8), the selections of a passing run pass every time -- the run-to-run variation is the
-//   timing-based tile search, not a race; (3) the same selections pass on the product build 8 of 8; (4) delta debugging the 49
-//   entries in which a failing and a passing selection differ leaves ONE: the 32 -> 32 3x3 layer at 8x16 pixels, fp32, on tile 10
-//   (64 x 64, no prefetch wave) with split-K 2 instead of tile 9 -- one instantiation x one split of the stamp build computes that layer
-//   wrong, deterministically (no register or scalar spills in it: llvm-readelf --notes; the product build's copy of the same
-//   configuration is pinned by tests/test_gpu_kernels.py::test_conv2d_splitk_on_a_tiny_layer_every_small_tile).  Why the stamp
-//   build's copy differs was not pursued further: it is code that never ships.
+// scripts/kernel_phases.py, rebuild without EXTRA.
+//   History: rounds 4-5 saw this build fail fp32 golden tests -- deterministically for one tile selection (the 32 -> 32 3x3 layer at
+//   8x16 pixels on tile 10 x split-K 2: profiles/r05_v3_stamp_bisect.txt), never on the product build.  Round 6 root-caused it
+//   (profiles/r06_v58_stamp_rootcause.txt): not a race and not undefined behaviour of this source -- stamp 3 alone moves the epilogue's
+//   `v_accvgpr_read_b32 v17, a15` to the top of the block the loop's exit branch reaches, 2-7 wait states behind the last 16-pass
+//   v_mfma_f32_32x32x2_f32 where the hardware needs 18 and has no interlock; the compiler's hazard search prices only the long way
+//   round the loop (see mfma_results_ready() below, which now separates the K loop from the epilogue, and
+//   scripts/mfma_hazard_check.py, which every build of the library has to pass).
 #ifndef V2V_STAMP_MASK
 #define V2V_STAMP_MASK 0
 #endif
@@ -146,6 +143,20 @@ __device__ __forceinline__ void glds16(const char* g, char* lds) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// gfx950 has no interlock between an MFMA and a later NON-MFMA access of its result registers: software keeps passes + 2 (fp32
+// input) / passes + 3 wait states between them, and the compiler's hazard recogniser can miss the edge "last MFMA of the K loop ->
+// first accumulator read of the epilogue" (its backwards search marks the loop's MFMA block as visited when it first reaches it the
+// long way round, through the loop header: GCNHazardRecognizer::getWaitStatesSince).  Round 6 found exactly that in the
+// V2V_STAMP_MASK build of conv_igemm_kernel<float,64,64,2,2,2,false>: `v_accvgpr_read_b32 v17, a15` two wait states behind a 16-pass
+// v_mfma_f32_32x32x2_f32 that needs 18 -- the "stamp build miscompute" of round 5 (scripts/stamp_probe.py,
+// scripts/mfma_hazard_check.py = the static check every build of the library has to pass, tests/test_cpu_boundary.py).
+// Called between a K loop and the first use of its accumulators: 19 wait states (~40 ns once per workgroup), and nothing is
+// scheduled across it.
+__device__ __forceinline__ void mfma_results_ready() {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <typename T> struct Mma;
@@ -1139,6 +1150,7 @@ __global__ __launch_bounds__((WGM * WGN + (HELPER ? 1 : 0)) * 64) void conv_igem
             }
         }
     }
+    mfma_results_ready();
     __syncthreads();                      // LDS ring is free: reused for the statistics reduction
     V2V_STAMP(p, 3);
 
