@@ -86,6 +86,9 @@ for t in TILES:
     except Exception as ex:                                   # a tile the library refuses is reported, not fatal
         print("tile %d: %s" % (t, str(ex)[:200]))
 ref = outs[TILES[0]]
+import hashlib
+print("checksum of tile %d's two outputs (%s): %s" % (TILES[0], os.path.basename(L.LIB_PATH), hashlib.sha1(b"".join(
+    o.t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes() for o in ref)).hexdigest()[:16]))
 for t in TILES[1:]:
     if "pair t%d fused" % t in variants:
         d = max((outs[t][i].t.float() - ref[i].t.float()).abs().max().item() for i in range(2))

@@ -353,7 +353,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            // 2. while the other workgroups of this channel tile arrive: park the pre-norm values (fp32) in LDS in pixel-major
+            // 2. the arrival ticket is taken as soon as this workgroup's row is in memory (round 6: it used to wait behind step 3's
+            //    staging and behind the residual loads' latency -- every workgroup, the last to arrive included, announced itself
+            //    1-2 us later than it could); its return travels while step 3 runs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int total = p.fin_rows > 0 ? p.fin_rows : (int)gridDim.y * p.m_tiles;
+            int* const arrive = p.fin_counter + nt;
+            int ticket = 0;
+            if (tid == 0) {
+                // ablate 2048 (test of the give-up path): the first workgroup of the channel tile never arrives
+                const int inc = ((p.ablate & 2048) && stat_row == 0) ? 0 : 1;
+                ticket = __hip_atomic_fetch_add(arrive, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            V2V_STAMP(p, 4);              // fused norm: 4 row published + ticket issued, 5 every workgroup of the channel tile has arrived,
+                                          // 6 scale / shift in LDS, 7 normalised tile stored (scripts/fused_tail_phases.py)
+            // 3. while the other workgroups of this channel tile arrive: park the pre-norm values (fp32) in LDS in pixel-major
             //    order and fetch this thread's share of the residuals, so that the work behind the barrier is one short,
             //    vectorised pass (the first version normalised in the MFMA layout with 2-byte stores: +8 us per launch)
             constexpr int NTH = NW * 64, PH = NTH / BN;
@@ -392,16 +407,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                     if (res1) rv1[q] = *reinterpret_cast<const u32x4*>(res1 + e);
                 }
             }
-            // 3. spin barrier of the workgroups that share this output-channel tile (all resident: host check)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int total = p.fin_rows > 0 ? p.fin_rows : (int)gridDim.y * p.m_tiles;
+            // 4. spin barrier of the workgroups that share this output-channel tile (all resident: host check)
             int* const flag = reinterpret_cast<int*>(smem + 16384);
             if (tid == 0) {
-                int* const arrive = p.fin_counter + nt;
-                // ablate 2048 (test of the give-up path): the first workgroup of the channel tile never arrives
-                const int inc = ((p.ablate & 2048) && stat_row == 0) ? 0 : 1;
-                int ok = __hip_atomic_fetch_add(arrive, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1 ? 1 : 0;
+                int ok = ticket == total - 1 ? 1 : 0;
                 for (int it = 0; !ok && it < (1 << 20); ++it) {    // bounded (~1 s): a barrier that cannot complete gives up
                     __builtin_amdgcn_s_sleep(1);
                     ok = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total ? 1 : 0;
@@ -410,8 +419,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                 *flag = ok;
             }
             __syncthreads();
+            V2V_STAMP(p, 5);
             const bool barrier_ok = *flag != 0;
-            // 4. scale / shift from all rows, fixed order: the arithmetic of the in-kernel finalize below, in every workgroup
+            // 5. scale / shift from all rows, fixed order: the arithmetic of the in-kernel finalize below, in every workgroup
             double* acc2 = reinterpret_cast<double*>(smem);          // [PH][BN][2], <= 8 KiB
             float* ssl = reinterpret_cast<float*>(smem + 12288);     // [2][BN] scale, shift
             {
@@ -457,16 +467,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                 }
             }
             __syncthreads();
-            // everyone has read the rows: the last to leave re-arms both tickets for the next launch / graph replay
-            if (tid == 0) {
-                int* const depart = p.fin_counter + 128 + nt;
-                const int tk = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tk == total - 1) {
-                    __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            // 5. normalise, activate, add the residuals, 16-byte stores (bn_apply_kernel's arithmetic, element for element)
+            V2V_STAMP(p, 6);
+            // 6. normalise, activate, add the residuals, 16-byte stores (bn_apply_kernel's arithmetic, element for element)
             T* const out = reinterpret_cast<T*>(p.out);
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
@@ -497,6 +499,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                     *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + eo) = pk;
                 }
             }
+            // everyone has read the rows (the barrier behind step 5): the last to leave re-arms both tickets for the next launch / graph
+            // replay.  Behind the stores (round 6): the returning atomic is a ~2 us round trip that thread 0's wave used to sit out IN FRONT
+            // of its share of step 6 (profiles/r06_v66_fused_tail_phases.txt); here it travels beside the stores' own completion
+            if (tid == 0) {
+                int* const depart = p.fin_counter + 128 + nt;
+                const int tk = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == total - 1) {
+                    __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if ((V2V_STAMP_MASK >> 7) & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // profiling build only: the stamp behind the stores' completion
+            V2V_STAMP(p, 7);
             return;
         }
     }
