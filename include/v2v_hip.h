@@ -124,14 +124,22 @@ typedef struct v2v_conv_desc {
  * model_final_w (1 channel, sigmoid) read the same tensor (models/networks.py:181-183, 224-226); with their weights
  * concatenated along cout they are one launch whose channels >= act_split use act_b / act_param_b / out_scale_b. */
 
+/* first of the 128 per-channel-tile launch-tag words of a fused-norm launch inside fin_counter: behind the arrive / depart tickets [0, 256),
+ * the two-level finalize's row-group tickets [256, 256 + 64 * 128) and the one-hot stems' slice tickets (256 words) */
+#define V2V_FIN_TAG_WORD (256 + 64 * 128 + 256)
+
 /* Fused norm (out_mode V2V_OUT_NORM_ACT_NHWC): conv + BatchNorm2d / InstanceNorm2d in training mode + activation
  * (+ residuals) in ONE launch -- what [pad, conv, norm, relu] and the tail of a ResnetBlock are in the reference
  * (models/networks.py:571-593).  The statistics need every output pixel, so the workgroups that share an output-channel
- * tile meet at a spin barrier between the main loop and the store: each publishes its tile's (sum, sum^2) row, waits for
- * the others, derives scale / shift from all rows in a fixed order (same arithmetic as the in-kernel finalize), and
+ * tile meet between the main loop and the store: each publishes its tile's (sum, sum^2) row, polls for the others',
+ * derives scale / shift from all rows in a fixed order (same arithmetic as the in-kernel finalize), and
  * applies it to the accumulators it still holds in registers.  No fp32 raw tensor, no bn_apply launch.
- * Requirements, checked by the library: tile ids 80..89, splitk <= 1, cout == cout_stride, `stats`, `fin_counter`
- * (>= 256 zero ints, re-armed in-kernel) and `fin_scale_shift` given, and ALL workgroups of the launch co-resident:
+ * Round 6: the rows are self-validating 8-byte granules {fp32 value, launch tag} (two per channel), so `stats` of a fused
+ * launch is rows * cout * 4 floats, ZERO-INITIALISED by the caller and written by fused launches ONLY (a buffer it shares with the
+ * untagged rows of other launches could hold a matching tag by accident); the launch tag is 1 + the word
+ * fin_counter[V2V_FIN_TAG_WORD + channel tile], which the last workgroup to leave increments.
+ * Requirements, checked by the library: tile ids 80..93, splitk <= 1, cout == cout_stride, `stats`, `fin_counter`
+ * (>= V2V_FIN_TAG_WORD + 128 zero ints; the library re-arms / advances them) and `fin_scale_shift` given, and ALL workgroups of the launch co-resident:
  * m_tiles * n_tiles (* 2 for v2v_conv2d_pair) <= the number of compute units.  Two such launches must never run
  * concurrently on one device (each could hold half of the CUs and wait for the rest): issue them from one stream / one
  * plan lane only, and keep the device to ONE process while they run (a co-tenant holding compute units can keep part of the

@@ -106,7 +106,7 @@ def test_round3_companion_objects(line):
     p = line["train"]["parity"]
     assert p["fp32_ok"] is True and p["fp32"]["max_forward"] <= 1e-3 and p["fp32"]["max_loss"] <= 1e-3        # EVERY frame (teacher-forced)
     assert set(p["fp32"]["grads"]) == {"G", "D", "DT"} and all(g["finite"] for g in p["fp32"]["grads"].values())
-    assert p["fp32"]["max_grad_norm"] <= p["tolerance_fp32"]["grad_norm"] == 1e-3 and p["bf16"]["max_grad_l2"] < 0.5
+    assert p["fp32"]["max_grad_norm"] <= p["tolerance_fp32"]["grad_norm"] == 2.5e-3 and p["fp32"]["max_grad_l2"] <= 5e-3 and p["bf16"]["max_grad_l2"] < 0.5
     assert p["free_running_fp32"]["max_forward"] < 1e-2
     assert line["train"]["flownet2"]["pairs_per_s"] > 0
 

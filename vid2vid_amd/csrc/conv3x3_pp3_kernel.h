@@ -165,6 +165,13 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
     int lin, slice, nt, mt, n_img, th, twi;
     patch_tile_index(p, lin_all, lin, slice, nt, mt, n_img, th, twi);
     const int oh0 = th * TH, ow0 = twi * TW;
+    // fused norm: the launch tag of this channel tile's statistics granules (conv_epilogue), fetched here so that its round trip is
+    // over long before the epilogue needs it
+    unsigned fin_epoch = 0u;
+    if constexpr (ABL == 0) {
+        if (p.out_mode == V2V_OUT_NORM_ACT_NHWC)
+            fin_epoch = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.fin_counter + V2V_FIN_TAG_WORD + nt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     const int H = p.H, W = p.W, cs = p.cin_stride;
     const int ncc_all = cs * (int)sizeof(T) / 128;
@@ -405,7 +412,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
         return (n_img * OHo + oh) * OWo + ow;
     };
     if constexpr (KS == 1) {
-        conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full);
+        conv_epilogue<T, BM, BN, WGM, WGN, ABL == 0>(p, acc, smem, tid, wm, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full, fin_epoch);
     } else if constexpr (KS == 4) {
         // K quads: the four waves of a 128-row wave tile each hold one K quarter of all of it.  Reduce-scatter in three rounds: in
         // round d wave h hands row tile (h + d) % 4 to wave (h + d) % 4 of its quad and collects its own row tile h from wave
@@ -437,7 +444,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
                 for (int r = 0; r < 16; ++r) acc4[0][j][r] += xch[((from * TN + j) * 16 + r) * 64 + lane];
             __syncthreads();
         }
-        conv_epilogue<T, BM, BN, WGM * 4, WGN, ABL == 0>(p, acc4, smem, tid, wm * 4 + wk, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full);
+        conv_epilogue<T, BM, BN, WGM * 4, WGN, ABL == 0>(p, acc4, smem, tid, wm * 4 + wk, wn, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full, fin_epoch);
     } else {
         // K pairs: wave (tile, half h) keeps column tile j = h of its 64-wide wave tile and hands column tile 1 - h to its partner
         // (wave id ^ 1), which holds the other half of the K sum for it.  Same lane <-> element map on both sides (same MFMA
@@ -462,7 +469,7 @@ __device__ __forceinline__ void conv3x3_pp3_body(const ConvKArgs& p_in) {
             }
         __syncthreads();                                      // the exchange area becomes the epilogue's scratch
         // 4 x 2 layout of 64 x 32 tiles: this wave's tile is (wm, 2 * wn + wk)
-        conv_epilogue<T, BM, BN, WGM, 2 * WGN, ABL == 0>(p, acc2, smem, tid, wm, 2 * wn + wk, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full);
+        conv_epilogue<T, BM, BN, WGM, 2 * WGN, ABL == 0>(p, acc2, smem, tid, wm, 2 * wn + wk, false, cls, tiles, lin, slice, S, nt, mt, pix_of, tile_full, fin_epoch);
     }
 }
 

@@ -569,7 +569,7 @@ static int build_conv(const v2v_conv_desc* d_in, ConvOp* op, bool launching = tr
     if (d->out_mode == V2V_OUT_NORM_ACT_NHWC) {
         if ((launching && (!d->fin_counter || !d->stats || !d->fin_scale_shift || d->fin_count <= 0)) || d->splitk > 1 || d->transposed ||
             d->cout != d->cout_stride || !((d->tile >= 80 && d->tile < 88) || (d->tile >= 90 && d->tile <= 93)) || d->cout > 128 * 64) {
-            set_error("conv: fused norm needs tile 80..87 / 90..93, splitk <= 1, cout == cout_stride, stats, fin_counter (256 ints), fin_scale_shift, fin_count");
+            set_error("conv: fused norm needs tile 80..87 / 90..93, splitk <= 1, cout == cout_stride, stats (tagged granules: rows * cout * 4 zero-initialised floats), fin_counter (V2V_FIN_TAG_WORD + 128 ints), fin_scale_shift, fin_count");
             return V2V_EINVAL;
         }
         k.res0 = (const char*)d->res0; k.res1 = (const char*)d->res1;

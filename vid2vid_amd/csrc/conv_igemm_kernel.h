@@ -186,7 +186,8 @@ template <typename T, int BM, int BN, int WGM, int WGN, bool FUSED_NORM = false,
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], char* smem,
                                               const int tid, const int wm, const int wn, const bool helper,
                                               const int cls, const int tiles, const int lin, const int slice, const int S,
-                                              const int nt, const int stat_row, PixOf pix_of, const bool tile_full = false) {
+                                              const int nt, const int stat_row, PixOf pix_of, const bool tile_full = false,
+                                              const unsigned fin_epoch = 0u) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NW = WGM * WGN;
@@ -341,33 +342,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                     red[(wm * BN + c) * 2 + 1] = s2;
                 }
             }
+            // Hand-off (round 6; MI355X_MICROARCH "hand-off granule", profiles/r06_v66_fused_tail_phases.txt): a row is published as
+            // self-validating 8-byte granules {value, launch tag} -- one write-through store each, no acknowledgement wait, no arrival
+            // ticket -- and every workgroup of the channel tile polls the granules it needs (step 4).  The tag is 1 + the number of
+            // fused launches that have completed on this channel tile's words of fin_counter (fin_epoch, read at kernel entry; the last
+            // workgroup to leave increments it), so granules of earlier launches in the (zero-initialised, fused-launches-only) row
+            // buffer never match.  The ticket form it replaces cost three dependent agent-scope round trips (store acknowledgement,
+            // returning atomic, row loads) behind the slowest K loop; this one costs one.
+            const int total = p.fin_rows > 0 ? p.fin_rows : (int)gridDim.y * p.m_tiles;
+            const unsigned tag = fin_epoch + 1u;
+            int* const flag = reinterpret_cast<int*>(smem + 16384);
+            if (tid == 0) *flag = 1;
             __syncthreads();
-            if (tid < BN) {
+            unsigned long long* const gran = reinterpret_cast<unsigned long long*>(p.stats);      // [row][cout][2] granules
+            // ablate 2048 (test of the give-up path): the first workgroup of the channel tile never publishes
+            if (tid < BN && !((p.ablate & 2048) && stat_row == 0)) {
                 const int ncol = nt * BN + tid;
                 if (ncol < p.cout) {
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int q = 0; q < WGM; ++q) { s1 += red[(q * BN + tid) * 2 + 0]; s2 += red[(q * BN + tid) * 2 + 1]; }
-                    const unsigned long long bits = (unsigned long long)__float_as_uint(s1) | ((unsigned long long)__float_as_uint(s2) << 32);
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.stats + ((long long)stat_row * p.cout + ncol) * 2), bits,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long* const g = gran + ((long long)stat_row * p.cout + ncol) * 2;
+                    __hip_atomic_store(g, (unsigned long long)__float_as_uint(s1) | ((unsigned long long)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(g + 1, (unsigned long long)__float_as_uint(s2) | ((unsigned long long)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            // 2. the arrival ticket is taken as soon as this workgroup's row is in memory (round 6: it used to wait behind step 3's
-            //    staging and behind the residual loads' latency -- every workgroup, the last to arrive included, announced itself
-            //    1-2 us later than it could); its return travels while step 3 runs
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int total = p.fin_rows > 0 ? p.fin_rows : (int)gridDim.y * p.m_tiles;
-            int* const arrive = p.fin_counter + nt;
-            int ticket = 0;
-            if (tid == 0) {
-                // ablate 2048 (test of the give-up path): the first workgroup of the channel tile never arrives
-                const int inc = ((p.ablate & 2048) && stat_row == 0) ? 0 : 1;
-                ticket = __hip_atomic_fetch_add(arrive, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            V2V_STAMP(p, 4);              // fused norm: 4 row published + ticket issued, 5 every workgroup of the channel tile has arrived,
-                                          // 6 scale / shift in LDS, 7 normalised tile stored (scripts/fused_tail_phases.py)
+            V2V_STAMP(p, 4);              // fused norm: 4 row published, 5 every row of the channel tile read, 6 scale / shift in LDS,
+                                          // 7 normalised tile stored (scripts/fused_tail_phases.py)
             // 3. while the other workgroups of this channel tile arrive: park the pre-norm values (fp32) in LDS in pixel-major
             //    order and fetch this thread's share of the residuals, so that the work behind the barrier is one short,
             //    vectorised pass (the first version normalised in the MFMA layout with 2-byte stores: +8 us per launch)
@@ -407,21 +408,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                     if (res1) rv1[q] = *reinterpret_cast<const u32x4*>(res1 + e);
                 }
             }
-            // 4. spin barrier of the workgroups that share this output-channel tile (all resident: host check)
-            int* const flag = reinterpret_cast<int*>(smem + 16384);
-            if (tid == 0) {
-                int ok = ticket == total - 1 ? 1 : 0;
-                for (int it = 0; !ok && it < (1 << 20); ++it) {    // bounded (~1 s): a barrier that cannot complete gives up
-                    __builtin_amdgcn_s_sleep(1);
-                    ok = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total ? 1 : 0;
-                }
-                if (!ok && p.status) __hip_atomic_fetch_or(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                *flag = ok;
-            }
-            __syncthreads();
-            V2V_STAMP(p, 5);
-            const bool barrier_ok = *flag != 0;
-            // 5. scale / shift from all rows, fixed order: the arithmetic of the in-kernel finalize below, in every workgroup
+            // (the statistics partials of step 1 and the double-precision partials of step 5 share LDS: every wave is past step 1's reads)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // 4. + 5. every row of the channel tile, polled granule by granule (all workgroups resident: host check), then scale / shift
+            //    in a fixed order: the arithmetic of the in-kernel finalize below, in every workgroup.  A row that does not appear
+            //    within ~1 s (a co-tenant holding compute units) makes the launch give up: NaN outputs + the status flag.
             double* acc2 = reinterpret_cast<double*>(smem);          // [PH][BN][2], <= 8 KiB
             float* ssl = reinterpret_cast<float*>(smem + 12288);     // [2][BN] scale, shift
             {
@@ -430,15 +422,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                 double s1 = 0.0, s2 = 0.0;
                 if (ncol < p.cout && ph < PH) {
                     for (int r = ph; r < total; r += PH) {
-                        const unsigned long long bits = __hip_atomic_load(
-                            reinterpret_cast<const unsigned long long*>(p.stats + ((long long)r * p.cout + ncol) * 2),
-                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s1 += (double)__uint_as_float((unsigned)(bits & 0xffffffffull));
-                        s2 += (double)__uint_as_float((unsigned)(bits >> 32));
+                        const unsigned long long* const g = gran + ((long long)r * p.cout + ncol) * 2;
+                        unsigned long long b1 = 0ull, b2 = 0ull;
+                        bool got = false;
+                        for (int it = 0; it < (1 << 19); ++it) {
+                            b1 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            b2 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            got = (unsigned)(b1 >> 32) == tag && (unsigned)(b2 >> 32) == tag;
+                            if (got) break;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        if (!got) *flag = 0;
+                        s1 += (double)__uint_as_float((unsigned)(b1 & 0xffffffffull));
+                        s2 += (double)__uint_as_float((unsigned)(b2 & 0xffffffffull));
                     }
                 }
                 if (ph < PH) { acc2[(ph * BN + c) * 2 + 0] = s1; acc2[(ph * BN + c) * 2 + 1] = s2; }
                 __syncthreads();
+                V2V_STAMP(p, 5);
+                const bool barrier_ok = *flag != 0;
+                if (!barrier_ok && tid == 0 && p.status) __hip_atomic_fetch_or(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (ph == 0) {
                     float fsc = 0.f, fsh = 0.f;
                     if (ncol < p.cout) {
@@ -499,15 +502,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, f32x16 (&acc)[
                     *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + eo) = pk;
                 }
             }
-            // everyone has read the rows (the barrier behind step 5): the last to leave re-arms both tickets for the next launch / graph
-            // replay.  Behind the stores (round 6): the returning atomic is a ~2 us round trip that thread 0's wave used to sit out IN FRONT
+            // everyone has read the rows (the barrier behind step 5): the last to leave re-arms the departure ticket and advances the
+            // launch tag for the next launch / graph replay.  Behind the stores (round 6): the returning atomic is a ~2 us round trip that thread 0's wave used to sit out IN FRONT
             // of its share of step 6 (profiles/r06_v66_fused_tail_phases.txt); here it travels beside the stores' own completion
             if (tid == 0) {
                 int* const depart = p.fin_counter + 128 + nt;
                 const int tk = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (tk == total - 1) {
-                    __hip_atomic_store(p.fin_counter + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(p.fin_counter + V2V_FIN_TAG_WORD + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if ((V2V_STAMP_MASK >> 7) & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // profiling build only: the stamp behind the stores' completion

@@ -534,7 +534,8 @@ def _cfg3(v):
 # one-hot stems' per-slice tickets (onehot_stem.hip: fin_counter + blockIdx.y) in a region of their own (they used to
 # start at word 256, inside the row-group region -- safe only while launches of one lane are serialised).
 FIN_ONEHOT_OFFSET = 256 + 64 * 128
-FIN_COUNTER_WORDS = FIN_ONEHOT_OFFSET + 256
+FIN_TAG_OFFSET = FIN_ONEHOT_OFFSET + 256            # include/v2v_hip.h V2V_FIN_TAG_WORD: the fused-norm launches' per-channel-tile launch tags
+FIN_COUNTER_WORDS = FIN_TAG_OFFSET + 128
 
 
 class Engine:
@@ -664,15 +665,15 @@ class Engine:
         self._keep(t)
         return t
 
-    def scratch(self, name, numel, dtype=torch.float32):
+    def scratch(self, name, numel, dtype=torch.float32, zero=False):
         """Shared scratch (conv raw output, statistics): consumed by the next launch on the
-        same stream, so one buffer per kind is enough."""
+        same stream, so one buffer per kind is enough.  zero: the buffer starts as zeros (every time it is (re)allocated)."""
         key = (name, dtype, self._lane, self._sset)
         t = self._scratch.get(key)
         if t is None or t.numel() < numel:
             if self.plan is not None and t is not None and not self.record_only:
                 raise RuntimeError("scratch '%s' must not grow while a plan is recording" % name)
-            t = torch.empty(int(numel), dtype=dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(int(numel), dtype=dtype, device=self.device)
             self._scratch[key] = t
         self._keep(t)
         return t
@@ -1107,7 +1108,11 @@ class Engine:
         rows = lib.v2v_conv_stats_rows(C.byref(d))
         if rows <= 0:
             check(rows or -1, "conv_stats_rows")
-        d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()
+        if fused is not None:
+            # tagged statistics granules (include/v2v_hip.h, "fused norm"): a zero-initialised buffer that only fused launches write
+            d.stats = self.scratch("stats_tagged", rows * pc.cout * 4, zero=True).data_ptr()
+        else:
+            d.stats = self.scratch("stats", rows * pc.cout * 2).data_ptr()
         finalized = fin is not None and (fused is not None or N * H * W <= FUSE_FINALIZE_MAX_PIXELS)
         if finalized:
             norm, ss = fin
