@@ -24,7 +24,7 @@ print({k: v for k, v in j.items() if not isinstance(v, (dict, list))})
 print("windows", j["timing"]["windows_ms_per_step"])
 r = j["roofline"]
 print("roofline", r["kernel"], r["frac"], r["avg_launch_us"], "eager", r.get("eager"), "rocprof", r.get("in_graph_rocprof"))
-print("per_kernel_ms", r["per_kernel_ms"])
+print("per_kernel_ms", r.get("per_kernel_ms"))
 for k in ("c1", "hires", "train", "train_hires"):
     print(k, json.dumps(j.get(k))[:2500])
 PY
@@ -324,7 +324,7 @@ j = json.load(open("gpurun_out/${TAG}_bench_default.json"))
 print({k: v for k, v in j.items() if not isinstance(v, (dict, list))})
 r = j["roofline"]
 print("roofline", r["kernel"], r["frac"], r["avg_launch_us"], "traffic", r["traffic"], "eager", r.get("eager"), "rocprof", r.get("in_graph_rocprof"))
-print("per_kernel_ms", r["per_kernel_ms"])
+print("per_kernel_ms", r.get("per_kernel_ms"))
 for k in ("x3", "fp32", "c1", "hires", "train", "train_hires", "c4", "train_c3", "cpu_baseline"):
     print(k, json.dumps(j.get(k))[:1200])
 PY
