@@ -659,3 +659,23 @@ def test_shipped_library_passes_the_mfma_hazard_check():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "mfma_hazard_check.py"), "--lib", so], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "MFMAs" in r.stdout
+
+
+def test_fused_norm_tag_words_match_the_header():
+    """include/v2v_hip.h V2V_FIN_TAG_WORD (the fused-norm launches' per-channel-tile launch tags inside fin_counter) is what the engine
+    allocates for, and a fused launch's statistics buffer is the zero-initialised, tagged one (never the shared untagged `stats`)."""
+    hdr = open(os.path.join(ROOT, "include", "v2v_hip.h")).read()
+    m = re.search(r"#define\s+V2V_FIN_TAG_WORD\s+\(([^)]+)\)", hdr)
+    assert m, "V2V_FIN_TAG_WORD missing from the header"
+    from vid2vid_amd import engine as E
+    assert eval(m.group(1), {"__builtins__": {}}) == E.FIN_TAG_OFFSET == E.FIN_ONEHOT_OFFSET + 256
+    assert E.FIN_COUNTER_WORDS == E.FIN_TAG_OFFSET + 128
+    eng = E.Engine("cpu", record_only=True)
+    a = eng.scratch("stats_tagged", 64, zero=True)
+    assert int(a.abs().sum()) == 0
+    a.fill_(7.0)
+    assert eng.scratch("stats_tagged", 32, zero=True) is a                 # no re-allocation, no re-zeroing while it fits
+    b = eng.scratch("stats_tagged", 128, zero=True)
+    assert b is not a and int(b.abs().sum()) == 0                          # a grown buffer starts as zeros: stale tags cannot survive
+    src = open(os.path.join(ROOT, "vid2vid_amd", "engine.py")).read()
+    assert 'self.scratch("stats_tagged", rows * pc.cout * 4, zero=True)' in src
